@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/s, forward+backward of PQ_Transformer on synthetic 40k-point clouds.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W    (N>1, one rank per GPU, RCCL)
+
+Metric (BASELINE.json): scenes/sec fwd+bwd, 40k-pt ScanNet-like clouds, batch 8/GPU.  A step is one
+forward + backward of the whole model in train mode (BN batch statistics, dropout active) on a batch
+of 8 scenes per GPU that is already resident in HBM; loss = sum of the means of every float
+end_point that requires grad.  Under N>1 each rank draws different scenes, the model
+is wrapped in DDP (gradient all-reduce over RCCL/xGMI, SyncBatchNorm as in the reference) and
+value = N * 8 * K / max-over-ranks(time): weak scaling.
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline     : the native kernel that took the most device time inside the timed region,
+                 timed with events on the launch stream, against its algorithmic bytes
+                 (SURVEY.md 8d formulas) and the 8 TB/s HBM peak;
+  cpu_baseline : the same model on the CPU oracle ("port"), timed on a bounded sample on rank 0
+                 at N=1 only -- a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "omni-pq_amd")
+for _p in (REPO, PKG, os.path.join(PKG, "pointnet2"), os.path.join(PKG, "models")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
+    ap.add_argument("--points", type=int, default=40000)
+    ap.add_argument("--extra-channels", type=int, default=0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-scenes", type=int, default=2)
+    ap.add_argument("--no-op-timing", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-operator table to stderr")
+    return ap.parse_args()
+
+
+def mean_size_arr():
+    return 0.3 + np.arange(54, dtype=np.float64).reshape(18, 3) * 0.05
+
+
+def build_model(extra_channels):
+    from pq_transformer import PQ_Transformer
+    return PQ_Transformer(input_feature_dim=extra_channels, num_class=18, num_proposal=256,
+                          num_quad_proposal=256, num_heading_bin=1, num_size_cluster=18,
+                          mean_size_arr=mean_size_arr())
+
+
+def loss_of(end_points):
+    total = 0.0
+    for k in sorted(end_points.keys()):
+        v = end_points[k]
+        if v.is_floating_point() and v.requires_grad:
+            total = total + v.float().mean()
+    return total
+
+
+def algorithmic_bytes(name, a):
+    """SURVEY.md 8(d) per-call bytes (f32 features, e = 4) from the C-ABI integer arguments."""
+    if name == "omnipq_furthest_point_sampling":
+        b, n, m = a[:3]
+        return b * (12 * n + 4 * m)
+    if name == "omnipq_ball_query":
+        b, n, m, s = a[:4]
+        return b * (12 * n + 12 * m + 4 * m * s)
+    if name in ("omnipq_group_points", "omnipq_group_points_grad"):
+        b, c, n, m, s = a[:5]
+        return b * (4 * m * s + 4 * c * min(n, m * s) + 4 * c * m * s)
+    if name in ("omnipq_gather_points", "omnipq_gather_points_grad"):
+        b, c, n, m = a[:4]
+        return b * (4 * m + 8 * c * m)
+    if name == "omnipq_three_nn":
+        b, n, m = a[:3]
+        return b * (12 * n + 12 * m + 24 * n)
+    if name == "omnipq_three_interpolate":
+        b, c, m, n = a[:4]
+        return b * (4 * c * m + 24 * n + 4 * c * n)
+    if name == "omnipq_three_interpolate_grad":
+        b, c, n, m = a[:4]
+        return b * (4 * c * m + 24 * n + 4 * c * n)
+    return 0
+
+
+def summarize_ops(sink, steps):
+    """-> {(name, args): [total_ms, calls, bytes_per_call]}"""
+    table = {}
+    for name, a, e0, e1 in sink:
+        ms = e0.elapsed_time(e1)
+        row = table.setdefault((name, a), [0.0, 0, algorithmic_bytes(name, a)])
+        row[0] += ms
+        row[1] += 1
+    return table
+
+
+def cpu_baseline(args):
+    """The oracle-backed model (C restatement of the native ops + PyTorch CPU for the rest) on a
+    bounded sample of the same workload.  Runs in THIS process before any GPU work is timed."""
+    import pointnet2_utils
+    import synth
+    from oracle import oracle_ext
+    saved = pointnet2_utils._ext
+    pointnet2_utils._ext = oracle_ext
+    try:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        b = args.cpu_sample_scenes
+        net = build_model(args.extra_channels)
+        net.train()
+        pc = synth.make_clouds(2, b, args.points, extra_channels=args.extra_channels, kind="room")
+        t0 = time.perf_counter()
+        ep = net({"point_clouds": pc})
+        loss_of(ep).backward()
+        dt = time.perf_counter() - t0
+        cpu_name = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if line.startswith("model name"):
+                        cpu_name = line.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
+        return {"value": b / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+                "sample": f"1 fwd+bwd step, {b} scenes x {args.points} pts, fp32, oracle C ops + PyTorch CPU, "
+                          f"{dt:.1f} s on {cpu_name}"}
+    finally:
+        pointnet2_utils._ext = saved
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: for --gpus N>1 launch with torch.distributed.run (see the docstring)")
+        args.gpus = world
+
+    cpu_rec = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_rec = cpu_baseline(args)
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import pointnet2_utils
+    import synth
+    ext = pointnet2_utils._ext
+    assert ext.__name__ == "pointnet2._ext", "the product binding must be the one that runs"
+
+    torch.manual_seed(1234)
+    net = build_model(args.extra_channels).to(dev)
+    net.train()
+    model = net
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank],
+                                                          broadcast_buffers=False)   # train.py:382
+    amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
+
+    # a small pool of distinct batches, resident in HBM before anything is timed
+    pool = [synth.make_clouds(100 + i, args.batch, args.points, extra_channels=args.extra_channels,
+                              kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
+
+    def step(i):
+        for p in net.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            ep = model({"point_clouds": pool[i % len(pool)]})
+            loss = loss_of(ep)
+        loss.backward()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    sink = None
+    if not args.no_op_timing:
+        sink = []
+        ext.set_timing_sink(sink)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ext.set_timing_sink(None)
+    ext.fps_check()
+    assert torch.isfinite(loss.detach()).item(), "non-finite loss"
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        scenes = world * args.batch * args.steps
+        rec = {
+            "metric": "scenes/sec fwd+bwd, 40k-pt ScanNet clouds, batch 8/GPU",
+            "value": scenes / dt_max, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
+                                   f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
+                       "global_batch": world * args.batch, "points": args.points,
+                       "parallelism": f"dp{world}"},
+        }
+        if sink:
+            table = summarize_ops(sink, args.steps)
+            (name, a), (ms, calls, nbytes) = max(table.items(), key=lambda kv: kv[1][0])
+            avg_ms = ms / calls
+            gbs = nbytes / (avg_ms * 1e-3) / 1e9
+            rec["roofline"] = {"bound": "hbm", "kernel": name, "shape": list(a), "achieved": gbs,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": None, "avg_ms": avg_ms, "launches_per_step": calls / args.steps,
+                               "algorithmic_bytes_per_launch": nbytes}
+            native_ms = sum(v[0] for v in table.values()) / args.steps
+            rec["native_ops_ms_per_step"] = native_ms
+            if args.breakdown:
+                for (nm, aa), (ms_, calls_, nb) in sorted(table.items(), key=lambda kv: -kv[1][0]):
+                    print(f"{nm:38s} {str(aa):34s} {ms_ / args.steps:9.3f} ms/step  x{calls_ / args.steps:4.1f}"
+                          f"  {nb / (ms_ / calls_ * 1e-3) / 1e9 if ms_ > 0 else 0:9.1f} GB/s", file=sys.stderr)
+        if cpu_rec is not None:
+            rec["cpu_baseline"] = cpu_rec
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+/*
+ * omnipq_pointops.h -- C ABI of the MI355X (gfx950) point-set operator library
+ * `libomnipq_pointops.so`.
+ *
+ * This is the drop-in boundary for the native half of the reference's hot path:
+ * the nine kernel wrappers that AIR-DISCOVER/Omni-PQ's pybind module
+ * `pointnet2._ext` (pointnet2/_ext_src/src/bindings.cpp:11-24) reaches through
+ * the forward declarations in
+ *      sampling.cpp:11-20, ball_query.cpp:12-14, group_points.cpp:11-17,
+ *      interpolate.cpp:12-20.
+ * Each entry point below names the wrapper it replaces.  Argument order and
+ * meaning are the reference's; two things are added because the reference's
+ * wrappers take them from global state:
+ *   - `stream` : the hipStream_t to launch on (the reference uses ATen's current
+ *                stream, e.g. ball_query_gpu.cu:54).  NULL = the default stream.
+ *   - a return code instead of `exit(-1)` (cuda_utils.h:35-44): 0 on success,
+ *     otherwise a hipError_t value or one of the OMNIPQ_E* codes below.
+ *
+ * Conventions (all entry points): raw DEVICE pointers, caller owns every buffer,
+ * tensors are dense row-major with the shapes given per function, float = f32,
+ * int = i32.  Launches are asynchronous on `stream`; nothing synchronises.
+ * The functions are re-entrant (forward runs on the Python thread, the *_grad
+ * ones on the autograd engine's worker thread).
+ *
+ * Numerics contract: squared distances are evaluated as
+ *      fma(dz, dz, fma(dx, dx, dy*dy))          (f32, one rounding per op)
+ * which is what nvcc's default -fmad=true contraction makes of the reference's
+ * `dx*dx + dy*dy + dz*dz`; index outputs (FPS, ball query, 3-NN) are therefore
+ * defined bit-exactly by this header + the reference's comparison rules.
+ */
+#ifndef OMNIPQ_POINTOPS_H
+#define OMNIPQ_POINTOPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMNIPQ_ABI_VERSION 1
+
+#define OMNIPQ_OK 0
+#define OMNIPQ_EINVAL 10001     /* bad shape / null pointer */
+#define OMNIPQ_ETOOLARGE 10002  /* problem exceeds what one launch supports */
+#define OMNIPQ_ETIMEOUT 10003   /* an in-kernel hand-off gave up (device flag) */
+
+int omnipq_abi_version(void);
+const char *omnipq_error_string(int code);
+
+/* cuda_utils.h:20-24 opt_n_threads(): the reference's block size for `work_size`
+ * items, 2^floor(log2) clamped to [1, 512].  Exposed because the FPS tie rule is
+ * defined by it (max d2, then lowest k mod opt_n_threads(n), then lowest k). */
+int omnipq_opt_n_threads(int work_size);
+
+/* replaces furthest_point_sampling_kernel_wrapper (sampling.cpp:18-20,
+ * sampling_gpu.cu:180-234).
+ *   dataset (b,n,3) f32; temp (b,n) f32 scratch that the caller pre-fills with 1e10
+ *   (sampling.cpp:80-82) and that holds the final running min-distances on return,
+ *   as in the reference; idxs (b,m) i32 out.  idxs[:,0] = 0; points with
+ *   x^2+y^2+z^2 <= 1e-3 are never selected after that (sampling_gpu.cu:105-106). */
+int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                   float *temp, int *idxs, void *stream);
+
+/* replaces gather_points_kernel_wrapper (sampling.cpp:11-13).
+ *   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
+int omnipq_gather_points(int b, int c, int n, int npoints, const float *points,
+                         const int *idx, float *out, void *stream);
+
+/* replaces gather_points_grad_kernel_wrapper (sampling.cpp:14-16).
+ *   grad_out (b,c,npoints), idx (b,npoints) -> grad_points (b,c,n), which the caller
+ *   zero-fills (sampling.cpp:57-59); contributions are accumulated with f32 atomics. */
+int omnipq_gather_points_grad(int b, int c, int n, int npoints,
+                              const float *grad_out, const int *idx,
+                              float *grad_points, void *stream);
+
+/* replaces query_ball_point_kernel_wrapper (ball_query.cpp:12-14).
+ *   new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): the first `nsample` point
+ *   indices k, in increasing k, with d2(k) < radius*radius (strict, f32); unused
+ *   slots repeat the first hit; a ball with no hit gets zeros.  Every slot is
+ *   written (the reference relies on a zero-filled buffer, ball_query.cpp:27-29). */
+int omnipq_ball_query(int b, int n, int m, float radius, int nsample,
+                      const float *new_xyz, const float *xyz, int *idx,
+                      void *stream);
+
+/* replaces group_points_kernel_wrapper (group_points.cpp:11-13).
+ *   points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
+int omnipq_group_points(int b, int c, int n, int npoints, int nsample,
+                        const float *points, const int *idx, float *out,
+                        void *stream);
+
+/* replaces group_points_grad_kernel_wrapper (group_points.cpp:15-17).
+ *   grad_out (b,c,npoints,nsample) -> grad_points (b,c,n), zero-filled by the caller. */
+int omnipq_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                             const float *grad_out, const int *idx,
+                             float *grad_points, void *stream);
+
+/* replaces three_nn_kernel_wrapper (interpolate.cpp:12-13).
+ *   unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances ascending,
+ *   idx (b,n,3); strict '<' insertion, ties keep the lower index; with m < 3 the
+ *   missing entries are (+inf, 0). */
+int omnipq_three_nn(int b, int n, int m, const float *unknown,
+                    const float *known, float *dist2, int *idx, void *stream);
+
+/* replaces three_interpolate_kernel_wrapper (interpolate.cpp:14-16).
+ *   points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n) */
+int omnipq_three_interpolate(int b, int c, int m, int n, const float *points,
+                             const int *idx, const float *weight, float *out,
+                             void *stream);
+
+/* replaces three_interpolate_grad_kernel_wrapper (interpolate.cpp:17-20).
+ *   grad_out (b,c,n) -> grad_points (b,c,m), zero-filled by the caller. */
+int omnipq_three_interpolate_grad(int b, int c, int n, int m,
+                                  const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points,
+                                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNIPQ_POINTOPS_H */

@@ -1,0 +1,70 @@
+// Shared device/host helpers for the gfx950 point-set kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "omnipq_pointops.h"
+
+#define OMNIPQ_LAUNCH_CHECK()                    \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+#define OMNIPQ_HIP(call)                         \
+  do {                                           \
+    hipError_t e__ = (call);                     \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+namespace omnipq {
+
+// a*a + b*b + c*c exactly as the numerics contract in omnipq_pointops.h states it:
+// the right-hand product of the first sum is rounded on its own, the other two fuse.
+// (Compile the index kernels with -ffp-contract=off so nothing else fuses.)
+__device__ __forceinline__ float sumsq3(float a, float b, float c) {
+  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+}
+
+// a*x + b*y + c*z with the same contraction pattern (three_interpolate).
+__device__ __forceinline__ float dot3(float a, float x, float b, float y, float c, float z) {
+  return __builtin_fmaf(c, z, __builtin_fmaf(a, x, b * y));
+}
+
+// ---- wave64 reductions on the DPP network (no LDS traffic) ---------------------------
+// Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then row_bcast15 / row_bcast31
+// carry the row totals forward; lane 63 ends up with the reduction over all 64 lanes.
+// `old` = the lane's own value, so lanes without a DPP source combine with themselves
+// (fine for idempotent max/min).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define STEP(CTRL, RM) v = fmaxf(v, __builtin_bit_cast(float, dpp_i32<CTRL, RM>(__builtin_bit_cast(int, v))))
+  STEP(0x111, 0xF);  // row_shr:1
+  STEP(0x112, 0xF);  // row_shr:2
+  STEP(0x114, 0xF);  // row_shr:4
+  STEP(0x118, 0xF);  // row_shr:8
+  STEP(0x142, 0xA);  // row_bcast:15 -> rows 1,3
+  STEP(0x143, 0xC);  // row_bcast:31 -> rows 2,3
+#undef STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define STEP(CTRL, RM) { unsigned o = (unsigned)dpp_i32<CTRL, RM>((int)v); v = o < v ? o : v; }
+  STEP(0x111, 0xF);
+  STEP(0x112, 0xF);
+  STEP(0x114, 0xF);
+  STEP(0x118, 0xF);
+  STEP(0x142, 0xA);
+  STEP(0x143, 0xC);
+#undef STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+}  // namespace omnipq

@@ -1,0 +1,71 @@
+"""PointNet++ backbone: 4 set-abstraction + 2 feature-propagation layers
+(reference models/backbone_module.py:21-139; layer hyper-parameters :38-75 are hard-coded there
+and here).  Fills the `sa*_`, `fp2_` and `seed_` keys of `end_points`.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
+    if _p not in sys.path:
+        sys.path.append(_p)
+
+from pointnet2_modules import PointnetSAModuleVotes, PointnetFPModule  # noqa: E402
+
+# (name, npoint, radius, nsample)
+_SA_GEOMETRY = (("sa1", 2048, 0.2, 64), ("sa2", 1024, 0.4, 32), ("sa3", 512, 0.8, 16),
+                ("sa4", 256, 1.2, 16))
+
+
+class Pointnet2Backbone(nn.Module):
+    """input (B, N, 3 + input_feature_dim) -> 1024 seeds with 288-channel features."""
+
+    def __init__(self, input_feature_dim=0, width=2, depth=2):
+        super().__init__()
+        self.depth = depth
+        self.width = width
+        hidden = [128 * width] * depth
+        in_ch = [input_feature_dim, 128 * width, 256 * width, 256 * width]
+        mid = [[64 * width] * depth, hidden, hidden, hidden]
+        out_ch = [128 * width, 256 * width, 256 * width, 256 * width]
+        for (name, npoint, radius, nsample), ci, cm, co in zip(_SA_GEOMETRY, in_ch, mid, out_ch):
+            setattr(self, name, PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=nsample,
+                                                      mlp=[ci] + cm + [co], use_xyz=True,
+                                                      normalize_xyz=True))
+        self.fp1 = PointnetFPModule(mlp=[256 * width + 256 * width, 256 * width, 256 * width])
+        self.fp2 = PointnetFPModule(mlp=[256 * width + 256 * width, 256 * width, 288])
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud, end_points=None):
+        if not end_points:
+            end_points = {}
+        xyz, features = self._break_up_pc(pointcloud)
+
+        for name in ("sa1", "sa2", "sa3", "sa4"):
+            xyz, features, inds = getattr(self, name)(xyz, features)
+            if name in ("sa1", "sa2"):          # the reference records inds for these two only
+                end_points[name + "_inds"] = inds
+            end_points[name + "_xyz"] = xyz
+            end_points[name + "_features"] = features
+
+        features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
+                            end_points["sa3_features"], end_points["sa4_features"])
+        features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
+                            end_points["sa2_features"], features)
+        end_points["fp2_features"] = features
+        end_points["fp2_xyz"] = end_points["sa2_xyz"]
+        num_seed = end_points["fp2_xyz"].shape[1]
+        # seeds are the first num_seed FPS picks of sa1, i.e. indices into the input cloud
+        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        end_points["seed_inds"] = end_points["fp2_inds"]
+        end_points["seed_xyz"] = end_points["fp2_xyz"]
+        end_points["seed_features"] = end_points["fp2_features"]
+        return end_points

@@ -1,0 +1,252 @@
+"""PQ_Transformer: joint 3-D object (box) and layout (quad) prediction on a point cloud.
+
+Same constructor, `forward(inputs: dict) -> end_points: dict` contract, `end_points` keys and
+`state_dict` names as the reference's models/pq_transformer.py:123-278.  Data flow (:196-267):
+
+    backbone (4 SA + 2 FP)            -> 1024 seeds x 288 ch
+    FPSModule(256) on the seeds       -> quad queries
+    VotingModule + L2-normalise + SA  -> 256 object queries
+    proposal heads on both query sets -> initial centres (used as query positions)
+    6 x TransformerDecoderLayer over the 512 joint queries, keys = projected seed features,
+        each followed by an object head and a quad head ("0head_".."4head_", "last_")
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+for _p in (_HERE, _ROOT, os.path.join(_ROOT, "pointnet2")):
+    if _p not in sys.path:
+        sys.path.append(_p)
+
+from backbone_module import Pointnet2Backbone  # noqa: E402
+from transformer import TransformerDecoderLayer  # noqa: E402
+from utils.pointnet_util import FPSModule  # noqa: E402
+from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
+from voting_module import VotingModule  # noqa: E402
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """xyz (B,P,C_in) -> learned embedding (B,288,P): Conv1d, BN, ReLU, Conv1d (reference :17-33)."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_residuals_normalized,
+                  size_scores, size_residuals_normalized, sem_cls_scores, end_points, num_class,
+                  num_heading_bin, num_size_cluster, mean_size_arr, prefix):
+    """Store the raw head outputs under `prefix` and decode the predicted box size
+    (reference :35-59; the mean-size table follows the scores' device instead of `.cuda()`)."""
+    B, K = objectness_scores.shape[0], objectness_scores.shape[1]
+    size_residuals_normalized = size_residuals_normalized.view([B, K, num_size_cluster, 3])
+    if not torch.is_tensor(mean_size_arr):
+        mean_size_arr = torch.from_numpy(np.asarray(mean_size_arr).astype(np.float32))
+    means = mean_size_arr.to(size_scores.device).unsqueeze(0).unsqueeze(0)
+    size_residuals = size_residuals_normalized * means
+    size_recover = size_residuals + means
+    pick = torch.argmax(size_scores, -1).unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, 3)
+    pred_size = torch.gather(size_recover, 2, pick).squeeze(2)
+    end_points[f'{prefix}objectness_scores'] = objectness_scores
+    end_points[f'{prefix}center'] = center
+    end_points[f'{prefix}heading_scores'] = heading_scores
+    end_points[f'{prefix}heading_residuals_normalized'] = heading_residuals_normalized
+    end_points[f'{prefix}heading_residuals'] = heading_residuals_normalized * (np.pi / num_heading_bin)
+    end_points[f'{prefix}size_scores'] = size_scores
+    end_points[f'{prefix}size_residuals_normalized'] = size_residuals_normalized
+    end_points[f'{prefix}size_residuals'] = size_residuals
+    end_points[f'{prefix}pred_size'] = pred_size
+    end_points[f'{prefix}sem_cls_scores'] = sem_cls_scores
+    return end_points, pred_size
+
+
+def _trunk(self, net):
+    net = F.relu(self.bn1(self.conv1(net)))
+    return F.relu(self.bn2(self.conv2(net)))
+
+
+class PredictHead(nn.Module):
+    """Object head: 2 x (Conv1d+BN+ReLU) trunk, then seven 1x1 heads (reference :62-91)."""
+
+    def __init__(self, hidden_dim, num_heading_bin, num_size_cluster, num_class, mean_size_arr):
+        super().__init__()
+        self.num_class = num_class
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_heading_bin = num_heading_bin
+        self.objectness_scores_head = nn.Conv1d(hidden_dim, 2, 1)
+        self.center_head = nn.Conv1d(hidden_dim, 3, 1)
+        self.heading_class_head = nn.Conv1d(hidden_dim, num_heading_bin, 1)
+        self.heading_residual_head = nn.Conv1d(hidden_dim, num_heading_bin, 1)
+        self.size_class_head = nn.Conv1d(hidden_dim, num_size_cluster, 1)
+        self.size_residual_head = nn.Conv1d(hidden_dim, num_size_cluster * 3, 1)
+        self.sem_cls_scores_head = nn.Conv1d(hidden_dim, num_class, 1)
+        self.conv1 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+        self.conv2 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+        self.bn1 = nn.BatchNorm1d(hidden_dim)
+        self.bn2 = nn.BatchNorm1d(hidden_dim)
+        self._means = None
+
+    def _mean_sizes(self, device):
+        if self._means is None or self._means.device != device:
+            self._means = torch.from_numpy(np.asarray(self.mean_size_arr).astype(np.float32)).to(device)
+        return self._means
+
+    def forward(self, net, base_xyz, end_points, prefix):
+        net = _trunk(self, net)
+        t = lambda head: head(net).transpose(2, 1)   # noqa: E731  (B,K,*)
+        center = t(self.center_head) + base_xyz
+        end_points, pred_size = decode_scores(
+            base_xyz, t(self.objectness_scores_head), center, t(self.heading_class_head),
+            t(self.heading_residual_head), t(self.size_class_head), t(self.size_residual_head),
+            t(self.sem_cls_scores_head), end_points, self.num_class, self.num_heading_bin,
+            self.num_size_cluster, self._mean_sizes(net.device), prefix)
+        return center, pred_size, end_points
+
+
+class QuadPredictHead(nn.Module):
+    """Layout-quad head: scores, centre, normal, size (reference :94-121).  The normal is divided
+    by the 2-norm of the WHOLE (B,K,3) tensor (:112-113) -- batch-coupled, reproduced as is."""
+
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.quad_scores_head = nn.Conv1d(hidden_dim, 2, 1)
+        self.center_head = nn.Conv1d(hidden_dim, 3, 1)
+        self.normal_vector_head = nn.Conv1d(hidden_dim, 3, 1)
+        self.size_head = nn.Conv1d(hidden_dim, 2, 1)
+        self.conv1 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+        self.conv2 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+        self.bn1 = nn.BatchNorm1d(hidden_dim)
+        self.bn2 = nn.BatchNorm1d(hidden_dim)
+
+    def forward(self, net, base_xyz, end_points, prefix):
+        net = _trunk(self, net)
+        center = self.center_head(net).transpose(2, 1) + base_xyz
+        normal = self.normal_vector_head(net).transpose(2, 1)
+        normal = normal.div(torch.norm(normal, p=2))
+        size = self.size_head(net).transpose(2, 1)
+        end_points[f'{prefix}quad_scores'] = self.quad_scores_head(net).transpose(2, 1)
+        end_points[f'{prefix}quad_center'] = center
+        end_points[f'{prefix}normal_vector'] = normal
+        end_points[f'{prefix}quad_size'] = size
+        return center, size, end_points
+
+
+class PQ_Transformer(nn.Module):
+    def __init__(self, input_feature_dim, num_class, num_proposal, num_quad_proposal, num_heading_bin,
+                 num_size_cluster, mean_size_arr, sampling='vote', num_layer=6, aux_loss=False,
+                 decoder_num=1, args=None):
+        super().__init__()
+        self.i = 0
+        self.input_feature_dim = input_feature_dim
+        self.num_proposal = num_proposal
+        self.num_class = num_class
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_heading_bin = num_heading_bin
+        self.aux_loss = aux_loss
+        self.sampling = sampling
+        self.num_quad_proposal = num_quad_proposal
+        self.num_layer = num_layer
+        self.decoder_num = decoder_num
+
+        self.backbone = Pointnet2Backbone(input_feature_dim=input_feature_dim)
+        hidden_dim = 288
+        self.decoder_key_proj = nn.Conv1d(288, hidden_dim, kernel_size=1)
+        self.decoder_query_proj = nn.Conv1d(288, hidden_dim, kernel_size=1)
+        self.quad_decoder_query_proj = nn.Conv1d(288, hidden_dim, kernel_size=1)
+        self.fps_module = FPSModule(self.num_quad_proposal)
+        if self.sampling != 'vote':
+            raise NotImplementedError
+        self.vote = VotingModule(1, 288)
+        self.vote_aggregation = PointnetSAModuleVotes(npoint=self.num_proposal, radius=0.3, nsample=16,
+                                                      mlp=[288, 288, 288, 288], use_xyz=True,
+                                                      normalize_xyz=True)
+        self.quad_proposal = QuadPredictHead(hidden_dim)
+        self.proposal = PredictHead(hidden_dim, num_heading_bin, num_size_cluster, num_class, mean_size_arr)
+
+        self.prediction_heads = nn.ModuleList()
+        self.prediction_quad_heads = nn.ModuleList()
+        self.decoder = nn.ModuleList()
+        self.decoder_self_posembeds = nn.ModuleList()
+        self.decoder_cross_posembeds = nn.ModuleList()
+        for i in range(6):      # six layers are always built; num_layer of them run (:180-190)
+            self.prediction_heads.append(
+                PredictHead(hidden_dim, num_heading_bin, num_size_cluster, num_class, mean_size_arr))
+            self.prediction_quad_heads.append(QuadPredictHead(hidden_dim))
+            self.decoder_cross_posembeds.append(PositionEmbeddingLearned(3, 288))
+            self.decoder_self_posembeds.append(PositionEmbeddingLearned(3, 288))
+            self.decoder.append(TransformerDecoderLayer(
+                self_posembed=self.decoder_self_posembeds[i],
+                cross_posembed=self.decoder_cross_posembeds[i]))
+
+        self.init_weights()
+        self.init_bn_momentum()
+        nn.SyncBatchNorm.convert_sync_batchnorm(self)      # in place for every child BN (:194)
+
+    def forward(self, inputs):
+        end_points = self.backbone(inputs['point_clouds'], {})
+        seed_xyz = end_points['fp2_xyz']
+        seed_features = end_points['fp2_features']
+
+        # layout branch: FPS over the seeds
+        quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features)
+        end_points['aggregated_sample_xyz'] = quad_xyz
+
+        # object branch: vote, normalise, aggregate
+        vote_xyz, vote_features = self.vote(seed_xyz, seed_features)
+        vote_features = vote_features.div(torch.norm(vote_features, p=2, dim=1).unsqueeze(1))
+        end_points['vote_xyz'] = vote_xyz
+        end_points['vote_features'] = vote_features
+        cluster_xyz, cluster_feature, _ = self.vote_aggregation(vote_xyz, vote_features)
+        end_points['aggregated_vote_xyz'] = cluster_xyz
+        end_points['cluster_feature'] = cluster_feature
+
+        center, _, end_points = self.proposal(cluster_feature, base_xyz=cluster_xyz,
+                                              end_points=end_points, prefix='proposal_')
+        center_q, _, end_points = self.quad_proposal(quad_feature, base_xyz=quad_xyz,
+                                                     end_points=end_points, prefix='proposal_')
+        base_xyz = center.detach().clone()
+        base_xyz_q = center_q.detach().clone()
+
+        query_joint = torch.cat([self.decoder_query_proj(cluster_feature),
+                                 self.quad_decoder_query_proj(quad_feature)], -1)
+        key = self.decoder_key_proj(seed_features)
+        key_pos = seed_xyz
+
+        for i in range(self.num_layer):
+            prefix = 'last_' if (i == self.num_layer - 1) else f'{i}head_'
+            query_pos_joint = torch.cat([base_xyz, base_xyz_q], 1)
+            query_joint = self.decoder[i](query_joint, key, query_pos_joint, key_pos)
+            query = query_joint[:, :, 0:self.num_proposal]
+            query_q = query_joint[:, :, self.num_proposal:]
+            base_xyz, _, end_points = self.prediction_heads[i](
+                query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix)
+            base_xyz_q, _, end_points = self.prediction_quad_heads[i](
+                query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix)
+            base_xyz = base_xyz.detach().clone()
+            base_xyz_q = base_xyz_q.detach().clone()
+        return end_points
+
+    def init_weights(self):
+        for p in self.decoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def init_bn_momentum(self):
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = 0.1

@@ -1,0 +1,35 @@
+"""Vote generation from seed points (reference models/voting_module.py:16-65).
+
+Three 1x1 convolutions over the seed features (288 -> 288 -> 288 -> (3 + 288) * vote_factor); the
+first three output channels of every vote are an xyz offset added to the seed position, the rest a
+residual added to the seed feature.  Parameter names (`conv1..3`, `bn1..2`) are the reference's.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class VotingModule(nn.Module):
+    def __init__(self, vote_factor, seed_feature_dim):
+        super().__init__()
+        self.vote_factor = vote_factor
+        self.in_dim = seed_feature_dim
+        self.out_dim = self.in_dim          # residual features: in_dim == out_dim
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv3 = nn.Conv1d(self.in_dim, (3 + self.out_dim) * self.vote_factor, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.bn2 = nn.BatchNorm1d(self.in_dim)
+
+    def forward(self, seed_xyz, seed_features):
+        """seed_xyz (B,K,3), seed_features (B,C,K) -> vote_xyz (B,K*vf,3), vote_features (B,C,K*vf)"""
+        B, K = seed_xyz.shape[0], seed_xyz.shape[1]
+        vf, C = self.vote_factor, self.out_dim
+        net = F.relu(self.bn1(self.conv1(seed_features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        net = self.conv3(net)                                   # (B, (3+C)*vf, K)
+        net = net.transpose(2, 1).reshape(B, K, vf, 3 + C)
+        vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(B, K * vf, 3)
+        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
+        vote_features = vote_features.reshape(B, K * vf, C).transpose(2, 1).contiguous()
+        return vote_xyz, vote_features

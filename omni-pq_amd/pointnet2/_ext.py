@@ -1,0 +1,206 @@
+"""`pointnet2._ext` for MI355X: the nine native point-set operators, on gfx950 HIP kernels.
+
+Drop-in for the reference's pybind/CUDA module of the same name (pointnet2/_ext_src/src/
+bindings.cpp:11-24): same function names, argument order, return values, dtype/contiguity
+checks and the same refusal of CPU tensors ("CPU not supported", e.g. ball_query.cpp:35-37).
+The work is done by `libomnipq_pointops.so` (hand-written HIP, see ../csrc and
+include/omnipq_pointops.h), reached through its C ABI with raw device pointers and the
+calling thread's current HIP stream -- this file is the thin binding a maintainer of the
+reference would write against that ABI.
+
+There is no fallback: if the shared library is missing or a tensor is not on a GPU the call
+raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get(
+    "OMNIPQ_POINTOPS_LIB",
+    os.path.join(os.path.dirname(_HERE), "lib", "libomnipq_pointops.so"))
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"pointnet2._ext: {_LIB_PATH} not found -- build it with `python omni-pq_amd/build.py` "
+        "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for these operators.")
+
+_lib = ctypes.CDLL(_LIB_PATH)
+_lib.omnipq_error_string.restype = ctypes.c_char_p
+_lib.omnipq_abi_version.restype = ctypes.c_int
+if _lib.omnipq_abi_version() != 1:
+    raise ImportError("pointnet2._ext: libomnipq_pointops.so has an unexpected ABI version")
+
+LIB_PATH = _LIB_PATH
+
+
+def _check(x, name, dtype=None, cuda_like=None):
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if dtype is torch.float32 and x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+    if dtype is torch.int32 and x.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+    if cuda_like is not None and cuda_like.is_cuda and not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def _need_gpu(x):
+    if not x.is_cuda:
+        raise RuntimeError("CPU not supported")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-call device timing (bench.py's roofline leg): when a list is installed here every
+# C-ABI call is bracketed by two events recorded on the stream the kernel is launched on.
+_timing_sink = None
+
+
+def set_timing_sink(sink):
+    """sink: None, or a list that receives (entry_point_name, int_args, start_event, end_event)."""
+    global _timing_sink
+    _timing_sink = sink
+
+
+def _run(fn, anchor, *args):
+    """Call a C-ABI entry point on `anchor`'s device and current stream; raise on error."""
+    if anchor.device.index != torch.cuda.current_device():
+        with torch.cuda.device(anchor.device):
+            return _run(fn, anchor, *args)
+    sink = _timing_sink
+    if sink is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args, _stream())
+        e1.record()
+        sink.append((fn.__name__, tuple(a for a in args if isinstance(a, int)), e0, e1))
+    else:
+        rc = fn(*args, _stream())
+    if rc != 0:
+        raise RuntimeError(f"{fn.__name__} failed: {_lib.omnipq_error_string(rc).decode()} ({rc})")
+
+
+def gather_points(points, idx):
+    """(B,C,N) f32, (B,M) i32 -> (B,C,M)   [sampling.cpp:22-46]"""
+    _check(points, "points", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=points)
+    _need_gpu(points)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), device=points.device, dtype=torch.float32)
+    _run(_lib.omnipq_gather_points, points, b, c, n, m, _ptr(points), _ptr(idx), _ptr(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """(B,C,M), (B,M) -> (B,C,n) scatter-add   [sampling.cpp:48-71]"""
+    _check(grad_out, "grad_out", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=grad_out)
+    _need_gpu(grad_out)
+    b, c, m = grad_out.shape
+    out = torch.zeros((b, c, int(n)), device=grad_out.device, dtype=torch.float32)
+    _run(_lib.omnipq_gather_points_grad, grad_out, b, c, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out))
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:72-93]"""
+    _check(points, "points", torch.float32)
+    _need_gpu(points)
+    b, n = points.shape[0], points.shape[1]
+    out = torch.zeros((b, int(nsamples)), device=points.device, dtype=torch.int32)
+    tmp = torch.full((b, n), 1e10, device=points.device, dtype=torch.float32)
+    _run(_lib.omnipq_furthest_point_sampling, points, b, n, int(nsamples), _ptr(points), _ptr(tmp), _ptr(out))
+    return out
+
+
+def three_nn(unknowns, knows):
+    """(B,n,3), (B,m,3) -> [dist2 (B,n,3) squared, idx (B,n,3) i32]   [interpolate.cpp:22-48]"""
+    _check(unknowns, "unknowns", torch.float32)
+    _check(knows, "knows", torch.float32, cuda_like=unknowns)
+    _need_gpu(unknowns)
+    b, n = unknowns.shape[0], unknowns.shape[1]
+    m = knows.shape[1]
+    idx = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.int32)
+    dist2 = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
+    _run(_lib.omnipq_three_nn, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx))
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """(B,C,m), (B,n,3) i32, (B,n,3) f32 -> (B,C,n)   [interpolate.cpp:50-78]"""
+    _check(points, "points", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=points)
+    _check(weight, "weight", torch.float32, cuda_like=points)
+    _need_gpu(points)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), device=points.device, dtype=torch.float32)
+    _run(_lib.omnipq_three_interpolate, points, b, c, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """(B,C,n) -> (B,C,m) scatter-add   [interpolate.cpp:80-107]"""
+    _check(grad_out, "grad_out", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=grad_out)
+    _check(weight, "weight", torch.float32, cuda_like=grad_out)
+    _need_gpu(grad_out)
+    b, c, n = grad_out.shape
+    out = torch.zeros((b, c, int(m)), device=grad_out.device, dtype=torch.float32)
+    _run(_lib.omnipq_three_interpolate_grad, grad_out, b, c, n, int(m), _ptr(grad_out), _ptr(idx),
+         _ptr(weight), _ptr(out))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(B,M,3), (B,N,3) -> (B,M,nsample) i32   [ball_query.cpp:16-40]"""
+    _check(new_xyz, "new_xyz", torch.float32)
+    _check(xyz, "xyz", torch.float32, cuda_like=new_xyz)
+    _need_gpu(new_xyz)
+    b, n = xyz.shape[0], xyz.shape[1]
+    m = new_xyz.shape[1]
+    idx = torch.empty((b, m, int(nsample)), device=new_xyz.device, dtype=torch.int32)
+    _run(_lib.omnipq_ball_query, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
+         _ptr(xyz), _ptr(idx))
+    return idx
+
+
+def group_points(points, idx):
+    """(B,C,N), (B,M,S) i32 -> (B,C,M,S)   [group_points.cpp:19-42]"""
+    _check(points, "points", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=points)
+    _need_gpu(points)
+    b, c, n = points.shape
+    npoints, nsample = idx.shape[1], idx.shape[2]
+    out = torch.empty((b, c, npoints, nsample), device=points.device, dtype=torch.float32)
+    _run(_lib.omnipq_group_points, points, b, c, n, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """(B,C,M,S), (B,M,S) -> (B,C,n) scatter-add   [group_points.cpp:44-67]"""
+    _check(grad_out, "grad_out", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=grad_out)
+    _need_gpu(grad_out)
+    b, c, npoints, nsample = grad_out.shape
+    out = torch.zeros((b, c, int(n)), device=grad_out.device, dtype=torch.float32)
+    _run(_lib.omnipq_group_points_grad, grad_out, b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx),
+         _ptr(out))
+    return out
+
+
+def fps_check():
+    """Raise if a multi-workgroup FPS launch on this device reported a hand-off timeout."""
+    rc = _lib.omnipq_fps_check(_stream())
+    if rc != 0:
+        raise RuntimeError(f"omnipq_fps_check: {_lib.omnipq_error_string(rc).decode()} ({rc})")

@@ -1,0 +1,225 @@
+"""PointNet++ set-abstraction (SA) and feature-propagation (FP) layers.
+
+API- and state_dict-compatible with the reference's `pointnet2/pointnet2_modules.py`:
+`PointnetSAModuleVotes` (:164-272) and `PointnetFPModule` (:356-416) are the two the model
+uses; `PointnetSAModuleMSG` / `PointnetSAModule` / `PointnetSAModuleMSGVotes` /
+`PointnetLFPModuleMSG` (:78-158, :274-353, :418-496) are kept for API completeness.
+
+Pipeline of an SA layer (reference :233-267):
+    centres  = xyz[FPS(xyz, npoint)]                      furthest_point_sample + gather
+    groups   = ball_query(radius, nsample) around centres, relative xyz (/radius) ++ features
+    features = max over the ball of SharedMLP(groups)
+"""
+import os
+import sys
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.append(_HERE)
+
+import pointnet2_utils  # noqa: E402
+import pytorch_utils as pt_utils  # noqa: E402
+
+
+def _centres(xyz, npoint, inds=None):
+    """FPS (unless `inds` is given) + gather -> (new_xyz (B,npoint,3) | None, inds)."""
+    if npoint is None:
+        return None, inds
+    if inds is None:
+        inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    flipped = xyz.transpose(1, 2).contiguous()
+    new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
+    return new_xyz, inds
+
+
+def _max_over_ball(x):
+    """(B, C, M, S) -> (B, C, M)"""
+    return F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
+
+
+def _with_xyz_channels(mlp_spec, use_xyz):
+    # The reference bumps the caller's list in place (:204-206, :120-121); keep that visible side
+    # effect -- `mlp=[0, ...]` becomes `[3, ...]` for the caller too.
+    if use_xyz and len(mlp_spec) > 0:
+        mlp_spec[0] += 3
+    return mlp_spec
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None):
+        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B, sum C_k, npoint)"""
+        new_xyz, _ = _centres(xyz, self.npoint)
+        pooled = [_max_over_ball(mlp(grouper(xyz, new_xyz, features)))
+                  for grouper, mlp in zip(self.groupers, self.mlps)]
+        return new_xyz, torch.cat(pooled, dim=1)
+
+
+def _build_scales(module, npoint, radii, nsamples, mlps, bn, use_xyz, sample_uniformly):
+    assert len(radii) == len(nsamples) == len(mlps)
+    module.npoint = npoint
+    module.groupers = nn.ModuleList()
+    module.mlps = nn.ModuleList()
+    for radius, nsample, spec in zip(radii, nsamples, mlps):
+        if npoint is not None:
+            grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz,
+                                                   sample_uniformly=sample_uniformly)
+        else:
+            grouper = pointnet2_utils.GroupAll(use_xyz)
+        module.groupers.append(grouper)
+        if use_xyz:
+            spec[0] += 3
+        module.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Set abstraction with multi-scale grouping (one grouper + MLP per radius)."""
+
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int],
+                 mlps: List[List[int]], bn: bool = True, use_xyz: bool = True,
+                 sample_uniformly: bool = False):
+        super().__init__()
+        _build_scales(self, npoint, radii, nsamples, mlps, bn, use_xyz, sample_uniformly)
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale set abstraction."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
+                 nsample: int = None, bn: bool = True, use_xyz: bool = True):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn,
+                         use_xyz=use_xyz)
+
+
+class PointnetSAModuleVotes(nn.Module):
+    """Single-scale SA layer that also returns the sampled point indices (VoteNet lineage).
+
+    forward(xyz (B,N,3), features (B,C,N) | None, inds (B,npoint) int32 | None)
+        -> new_xyz (B,npoint,3), new_features (B, mlp[-1], npoint), inds (B,npoint) int32
+        [, unique_cnt (B,npoint)]
+    """
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
+                 nsample: int = None, bn: bool = True, use_xyz: bool = True, pooling: str = 'max',
+                 sigma: float = None, normalize_xyz: bool = False, sample_uniformly: bool = False,
+                 ret_unique_cnt: bool = False):
+        super().__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.nsample = nsample
+        self.pooling = pooling
+        self.use_xyz = use_xyz
+        self.sigma = sigma if sigma is not None else \
+            (self.radius / 2 if self.radius is not None else None)
+        self.normalize_xyz = normalize_xyz
+        self.ret_unique_cnt = ret_unique_cnt
+        if npoint is not None:
+            self.grouper = pointnet2_utils.QueryAndGroup(
+                radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True, normalize_xyz=normalize_xyz,
+                sample_uniformly=sample_uniformly, ret_unique_cnt=ret_unique_cnt)
+        else:
+            self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
+        self.mlp_module = pt_utils.SharedMLP(_with_xyz_channels(mlp, use_xyz), bn=bn)
+
+    def _pool(self, x, grouped_xyz):
+        if self.pooling == 'max':
+            return _max_over_ball(x)
+        if self.pooling == 'avg':
+            return F.avg_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
+        if self.pooling == 'rbf':
+            # radial-basis weighting of the ball members (reference :262-266)
+            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1, keepdim=False) / (self.sigma ** 2) / 2)
+            return torch.sum(x * rbf.unsqueeze(1), -1) / float(self.nsample)
+        raise ValueError(f"unknown pooling {self.pooling!r}")
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
+        if inds is not None:
+            assert inds.shape[1] == self.npoint
+        new_xyz, inds = _centres(xyz, self.npoint, inds)
+        grouped = self.grouper(xyz, new_xyz, features)
+        unique_cnt = grouped[2] if self.ret_unique_cnt else None
+        grouped_features, grouped_xyz = grouped[0], grouped[1]
+        new_features = self._pool(self.mlp_module(grouped_features), grouped_xyz)
+        if self.ret_unique_cnt:
+            return new_xyz, new_features, inds, unique_cnt
+        return new_xyz, new_features, inds
+
+
+class PointnetSAModuleMSGVotes(nn.Module):
+    """Multi-scale SA layer returning the sampled indices."""
+
+    def __init__(self, *, mlps: List[List[int]], npoint: int, radii: List[float],
+                 nsamples: List[int], bn: bool = True, use_xyz: bool = True,
+                 sample_uniformly: bool = False):
+        super().__init__()
+        _build_scales(self, npoint, radii, nsamples, mlps, bn, use_xyz, sample_uniformly)
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
+        new_xyz, inds = _centres(xyz, self.npoint, inds)
+        pooled = [_max_over_ball(mlp(grouper(xyz, new_xyz, features)))
+                  for grouper, mlp in zip(self.groupers, self.mlps)]
+        return new_xyz, torch.cat(pooled, dim=1), inds
+
+
+def inverse_distance_weights(dist):
+    """(B,n,3) distances -> normalised 1/(d+1e-8) weights (reference :395-397)."""
+    recip = 1.0 / (dist + 1e-8)
+    return recip / torch.sum(recip, dim=2, keepdim=True)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: 3-NN inverse-distance interpolation of `known_feats` onto the
+    `unknown` points, concatenated with their skip features, then a SharedMLP.
+
+    forward(unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) | None, known_feats (B,C2,m))
+        -> (B, mlp[-1], n)
+    """
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
+                known_feats: torch.Tensor) -> torch.Tensor:
+        if known is None:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        else:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx,
+                                                             inverse_distance_weights(dist))
+        stacked = interpolated if unknow_feats is None else \
+            torch.cat([interpolated, unknow_feats], dim=1)
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
+
+
+class PointnetLFPModuleMSG(nn.Module):
+    """Learnable feature propagation: group features of set 1 around the points of set 2,
+    MLP + max-pool per scale, concatenate set-2 features, post-MLP."""
+
+    def __init__(self, *, mlps: List[List[int]], radii: List[float], nsamples: List[int],
+                 post_mlp: List[int], bn: bool = True, use_xyz: bool = True,
+                 sample_uniformly: bool = False):
+        super().__init__()
+        self.post_mlp = pt_utils.SharedMLP(post_mlp, bn=bn)
+        _build_scales(self, 0, radii, nsamples, mlps, bn, use_xyz, sample_uniformly)
+        del self.npoint
+
+    def forward(self, xyz2: torch.Tensor, xyz1: torch.Tensor, features2: torch.Tensor,
+                features1: torch.Tensor) -> torch.Tensor:
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            y = _max_over_ball(mlp(grouper(xyz1, xyz2, features1)))
+            if features2 is not None:
+                y = torch.cat([y, features2], dim=1)
+            outs.append(self.post_mlp(y.unsqueeze(-1)))
+        return torch.cat(outs, dim=1).squeeze(-1)

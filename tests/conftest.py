@@ -1,0 +1,72 @@
+"""Shared test plumbing.
+
+CPU suite (`-m "not gpu"`): the oracle against the committed golden fixtures, host logic, the
+C-ABI's exported symbols, world_size-2 gloo data parallel.  GPU suite (`-m gpu`): the HIP path
+against the oracle and the fixtures, through the C ABI.  Only here (and in bench.py's
+cpu_baseline leg / __graft_entry__.smoke) is the oracle ever imported.
+"""
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+PKG = os.path.join(REPO, "omni-pq_amd")
+for p in (REPO, HERE, PKG, os.path.join(PKG, "pointnet2"), os.path.join(PKG, "models")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libomnipq_pointops.so, (re)built with hipcc if stale (cross-compiles without a GPU)."""
+    sys.path.insert(0, PKG)
+    import build as omnipq_build
+    return omnipq_build.build()
+
+
+@pytest.fixture()
+def oracle_backend(built_lib):
+    """Plug the CPU oracle in place of `pointnet2._ext` for host-logic tests, then restore."""
+    import pointnet2_utils
+    from oracle import oracle_ext
+    saved = pointnet2_utils._ext
+    pointnet2_utils._ext = oracle_ext
+    try:
+        yield oracle_ext
+    finally:
+        pointnet2_utils._ext = saved
+
+
+def load_golden(name):
+    import torch
+    return torch.load(os.path.join(GOLDEN, name + ".pt"))
+
+
+def check_summary(got, ref, name, tol=1e-4):
+    """Compare a tensor with a tests/procedural.py:summarize record.
+    ints: exact.  floats: max|a-b| <= tol * max|b| on the stored elements (+ norms when sampled)."""
+    import torch
+    assert list(got.shape) == ref["shape"], f"{name}: shape {list(got.shape)} != {ref['shape']}"
+    flat = got.detach().cpu().reshape(-1)
+    if "full" in ref:
+        want, have = ref["full"], flat
+    else:
+        want, have = ref["sample"], flat[::ref["stride"]]
+    if not got.is_floating_point():
+        assert torch.equal(have, want), f"{name}: integer mismatch at {int((have != want).sum())} places"
+        return 0.0
+    scale = float(want.abs().max()) + 1e-30
+    err = float((have.float() - want).abs().max()) / scale
+    assert err <= tol, f"{name}: rel err {err:.3e} > {tol}"
+    if "l2" in ref:
+        l2 = float(flat.double().norm())
+        assert abs(l2 - ref["l2"]) <= 10 * tol * (abs(ref["l2"]) + 1e-30), f"{name}: l2 {l2} vs {ref['l2']}"
+    return err

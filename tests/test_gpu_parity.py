@@ -1,0 +1,232 @@
+"""GPU: the HIP path against the CPU oracle and the committed reference fixtures.
+
+Index outputs (FPS, ball query, 3-NN) must be bit-exact; float outputs within 1e-4 of max-abs
+(BASELINE.json north_star).  Kernel-level tests call the C ABI directly with raw device pointers
+(tests/capi.py); layer/model tests go through `pointnet2._ext` as a user of the drop-in would.
+"""
+import ctypes
+
+import pytest
+import torch
+
+import capi
+import synth
+from conftest import load_golden
+from oracle import oracle_ext
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    return float((a.cpu().float() - b.float()).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+# --------------------------------------------------------------------------- FPS
+FPS_CASES = [
+    # (kind, B, N, M)   -- covers every launch shape of csrc/fps.hip
+    ("uniform", 2, 1, 1), ("uniform", 2, 7, 7), ("uniform", 3, 64, 16), ("uniform", 2, 100, 37),
+    ("adv", 2, 256, 64), ("adv", 2, 300, 300), ("room", 2, 512, 128), ("adv", 2, 777, 200),
+    ("room", 2, 1024, 256), ("room", 2, 2048, 1024), ("adv", 2, 2049, 300), ("room", 2, 4096, 512),
+    ("room", 1, 8192, 512), ("adv", 2, 8193, 400),        # first multi-workgroup size
+    ("room", 2, 20000, 600), ("room", 2, 40000, 2048),    # sa1 of BASELINE configs 2/3
+    ("room", 1, 50000, 700), ("uniform", 2, 80000, 300),  # configs 4 and 5
+    ("adv", 1, 140000, 64),                               # 8 points per thread, many workgroups
+]
+
+
+def cloud(kind, seed, b, n):
+    if kind == "adv":
+        return synth.adversarial_cloud(seed, b, max(n, 32))[:, :n].contiguous()
+    return synth.make_clouds(seed, b, n, kind=kind) if n >= 64 else \
+        torch.rand((b, n, 3), generator=torch.Generator().manual_seed(seed)) * 2 + 0.1
+
+
+@pytest.mark.parametrize("kind,b,n,m", FPS_CASES)
+def test_fps_index_exact(kind, b, n, m):
+    xyz = cloud(kind, 5, b, n)
+    want = oracle_ext.furthest_point_sampling(xyz, m)
+    got, tmp = capi.fps(xyz.to(dev()), m)
+    assert torch.equal(got.cpu(), want), f"first mismatch at {(got.cpu() != want).nonzero()[:3].tolist()}"
+    # the scratch buffer holds the final running min-distances, as the reference leaves it
+    want_tmp = torch.full((b, n), 1e10)
+    oracle_ext.lib().oracle_furthest_point_sampling(b, n, m, ctypes.c_void_p(xyz.data_ptr()),
+                                                    ctypes.c_void_p(want_tmp.data_ptr()),
+                                                    ctypes.c_void_p(torch.zeros((b, m), dtype=torch.int32).data_ptr()))
+    assert torch.equal(tmp.cpu(), want_tmp)
+
+
+def test_fps_all_points_inside_skip_ball_yields_zeros():
+    xyz = torch.rand(2, 500, 3) * 0.01            # |p|^2 <= 1e-3 everywhere
+    got, _ = capi.fps(xyz.to(dev()), 40)
+    assert torch.equal(got.cpu(), oracle_ext.furthest_point_sampling(xyz, 40))
+    assert int(got.abs().sum()) == 0
+
+
+def test_fps_all_duplicates_tie_rule():
+    xyz = torch.ones(2, 1500, 3)
+    got, _ = capi.fps(xyz.to(dev()), 20)
+    assert torch.equal(got.cpu(), oracle_ext.furthest_point_sampling(xyz, 20))
+
+
+def test_fps_lattice_ties_follow_launch_geometry():
+    """Many exactly equal distances: the winner is decided by (k mod opt_n_threads(n), k)."""
+    g = torch.arange(12, dtype=torch.float32)
+    lat = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3) + 1.0
+    for n in (1728, 1000, 600):
+        xyz = lat[:, :n].contiguous()
+        got, _ = capi.fps(xyz.to(dev()), 200)
+        assert torch.equal(got.cpu(), oracle_ext.furthest_point_sampling(xyz, 200)), n
+
+
+def test_fps_empty_and_degenerate_arguments():
+    d = dev()
+    xyz = torch.rand(2, 10, 3, device=d)
+    out = torch.full((2, 0), -7, device=d, dtype=torch.int32)
+    tmp = torch.full((2, 10), 1e10, device=d)
+    assert capi.call("omnipq_furthest_point_sampling", 2, 10, 0, capi.P(xyz), capi.P(tmp), capi.P(out)) == 0
+    assert capi.call("omnipq_furthest_point_sampling", 0, 10, 4, capi.P(xyz), capi.P(tmp), capi.P(out)) == 0
+    assert capi.call("omnipq_furthest_point_sampling", 2, 10, 4, capi.P(None), capi.P(tmp), capi.P(out)) == 10001
+    assert capi.call("omnipq_furthest_point_sampling", 1, (1 << 20) + 1, 4, capi.P(xyz), capi.P(tmp),
+                     capi.P(out)) == 10002
+
+
+# --------------------------------------------------------------------------- ball query
+BQ_CASES = [
+    ("room", 2, 512, 128, 0.4, 16), ("room", 2, 4096, 1024, 0.2, 32), ("adv", 2, 600, 150, 0.3, 8),
+    ("adv", 2, 2048, 512, 0.25, 64), ("uniform", 1, 100, 3, 0.5, 5), ("uniform", 2, 65, 17, 5.0, 100),
+    ("room", 2, 40000, 2048, 0.2, 64), ("room", 1, 2048, 1024, 0.4, 32), ("room", 1, 1024, 512, 0.8, 16),
+    ("room", 1, 512, 256, 1.2, 16), ("uniform", 1, 300, 300, 1e-4, 8),
+]
+
+
+@pytest.mark.parametrize("kind,b,n,m,radius,nsample", BQ_CASES)
+def test_ball_query_index_exact(kind, b, n, m, radius, nsample):
+    xyz = cloud(kind, 9, b, n)
+    centres = xyz[:, torch.randperm(n, generator=torch.Generator().manual_seed(1))[:m]].contiguous()
+    if kind == "adv":
+        centres[:, 0] = 50.0          # the outlier's own ball
+        centres[:, 1] = -40.0         # an empty ball
+    want = oracle_ext.ball_query(centres, xyz, radius, nsample)
+    got = capi.ball_query(centres.to(dev()), xyz.to(dev()), radius, nsample)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_ball_query_radius_boundary_is_strict():
+    """d2 == radius^2 exactly must be OUT (ball_query_gpu.cu:35 `d2 < radius2`)."""
+    xyz = torch.zeros(1, 8, 3)
+    xyz[0, :, 0] = torch.tensor([0.0, 0.5, 0.25, 0.5, 1.0, 0.499999, 0.5, 0.125])
+    centres = torch.zeros(1, 1, 3)
+    want = oracle_ext.ball_query(centres, xyz, 0.5, 8)
+    got = capi.ball_query(centres.to(dev()), xyz.to(dev()), 0.5, 8)
+    assert torch.equal(got.cpu(), want)
+    assert want[0, 0].tolist() == [0, 2, 5, 7, 0, 0, 0, 0]
+
+
+# --------------------------------------------------------------------------- gather / group / 3-NN
+@pytest.mark.parametrize("b,c,n,m,s", [(2, 5, 512, 128, 16), (2, 259, 2048, 1024, 32), (1, 1, 64, 1, 1),
+                                       (3, 13, 1000, 77, 9), (8, 3, 40000, 2048, 64)])
+def test_group_and_gather_exact_and_grads(b, c, n, m, s):
+    gen = torch.Generator().manual_seed(3)
+    pts = torch.randn((b, c, n), generator=gen)
+    idx = torch.randint(0, n, (b, m, s), generator=gen, dtype=torch.int32)
+    idx[:, :, 0] = idx[:, :, -1]                      # repeated targets in the scatter
+    d = dev()
+    got = capi.group_points(pts.to(d), idx.to(d))
+    assert torch.equal(got.cpu(), oracle_ext.group_points(pts, idx))
+    go = torch.randn((b, c, m, s), generator=gen)
+    gg = capi.group_points_grad(go.to(d), idx.to(d), n)
+    assert rel_err(gg, oracle_ext.group_points_grad(go, idx, n)) <= TOL
+    idx1 = idx[:, :, 0].contiguous()
+    got1 = capi.gather_points(pts.to(d), idx1.to(d))
+    assert torch.equal(got1.cpu(), oracle_ext.gather_points(pts, idx1))
+    go1 = torch.randn((b, c, m), generator=gen)
+    gg1 = capi.gather_points_grad(go1.to(d), idx1.to(d), n)
+    assert rel_err(gg1, oracle_ext.gather_points_grad(go1, idx1, n)) <= TOL
+
+
+@pytest.mark.parametrize("kind,b,n,m", [("room", 2, 512, 256), ("room", 8, 1024, 512), ("adv", 2, 600, 150),
+                                        ("uniform", 1, 70, 2), ("uniform", 1, 5, 1), ("room", 1, 3000, 2500)])
+def test_three_nn_exact_and_interpolate(kind, b, n, m):
+    xyz = cloud(kind, 13, b, max(n, m))
+    unknown = xyz[:, :n].contiguous()
+    known = xyz[:, torch.randperm(xyz.shape[1], generator=torch.Generator().manual_seed(2))[:m]].contiguous()
+    d = dev()
+    d2, idx = capi.three_nn(unknown.to(d), known.to(d))
+    w_d2, w_idx = oracle_ext.three_nn(unknown, known)
+    assert torch.equal(idx.cpu(), w_idx)
+    assert torch.equal(d2.cpu(), w_d2)                 # same fma form -> bit-equal squared distances
+    if m < 3:
+        return
+    gen = torch.Generator().manual_seed(4)
+    c = 11
+    feats = torch.randn((b, c, m), generator=gen)
+    dist = torch.sqrt(w_d2)
+    recip = 1.0 / (dist + 1e-8)
+    weight = (recip / recip.sum(2, keepdim=True)).contiguous()
+    got = capi.three_interpolate(feats.to(d), w_idx.to(d), weight.to(d))
+    assert torch.equal(got.cpu(), oracle_ext.three_interpolate(feats, w_idx, weight))
+    go = torch.randn((b, c, n), generator=gen)
+    gg = capi.three_interpolate_grad(go.to(d), w_idx.to(d), weight.to(d), m)
+    assert rel_err(gg, oracle_ext.three_interpolate_grad(go, w_idx, weight, m)) <= TOL
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_config2():
+    """BASELINE config 2 sizes (B=8, N=40000): properties that need no oracle run."""
+    xyz = synth.make_clouds(2, 8, 40000, kind="room").to(dev())
+    inds, tmp = capi.fps(xyz, 2048)
+    assert int(inds[:, 0].abs().sum()) == 0 and int(inds.min()) >= 0 and int(inds.max()) < 40000
+    centres = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    # FPS never re-picks a point while un-picked points remain at positive distance
+    assert all(len(set(row.tolist())) == 2048 for row in inds.cpu())
+    # every cloud point is within the final coverage radius of some centre: temp == min_j |p - c_j|^2
+    d = torch.cdist(xyz[0:1, :4000], centres[0:1]) ** 2
+    assert torch.allclose(d.min(-1).values, tmp[0:1, :4000], rtol=1e-4, atol=1e-6)
+    idx = capi.ball_query(centres, xyz, 0.2, 64)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 40000
+    # first slot of every ball is the smallest member index and members are inside the ball
+    members = torch.gather(xyz, 1, idx.long().reshape(8, -1, 1).expand(-1, -1, 3)).reshape(8, 2048, 64, 3)
+    d2 = ((members - centres.unsqueeze(2)) ** 2).sum(-1)
+    assert float(d2.max()) < 0.2 * 0.2 * (1 + 1e-5)
+    assert bool((idx[:, :, :1] <= idx).all())           # padding repeats the first (smallest) hit
+    # idempotence: a centre is always inside its own ball
+    assert bool((idx == inds.unsqueeze(-1)).any(-1).float().mean() > 0.99)
+
+
+# --------------------------------------------------------------------------- layers and model vs fixtures
+@pytest.mark.parametrize("name", ["ops_room512", "ops_room4096", "ops_adv600", "ops_adv2048"])
+def test_ops_through_python_layers_match_reference_fixture(name):
+    import pointnet2_utils
+    from test_oracle_golden import run_op_case
+    assert pointnet2_utils._ext.__name__ == "pointnet2._ext"
+    run_op_case(name, load_golden(name), pointnet2_utils, device="cuda", tol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048"])
+def test_sa_module_on_gpu_matches_reference_fixture(name):
+    import pointnet2_modules
+    from test_oracle_golden import run_sa_case
+    run_sa_case(name, load_golden(name), pointnet2_modules, device="cuda", tol=TOL)
+
+
+def test_fp_module_on_gpu_matches_reference_fixture():
+    import pointnet2_modules
+    from test_oracle_golden import run_fp_case
+    run_fp_case("fp2_like", load_golden("fp2_like"), pointnet2_modules, device="cuda", tol=TOL)
+
+
+def test_model_eval_on_gpu_matches_reference_fixture():
+    from test_oracle_golden import run_model_case
+    ep = run_model_case(load_golden("model_eval_8192"), device="cuda", tol=TOL)
+    assert ep["sa1_inds"].dtype == torch.int32 and ep["sa1_inds"].is_cuda
+
+
+def test_model_train_on_gpu_matches_reference_fixture():
+    from test_oracle_golden import run_model_case
+    run_model_case(load_golden("model_train_8192"), device="cuda", tol=TOL, grad_tol=5e-3)

@@ -1,0 +1,100 @@
+"""CPU: host-side behaviour of the drop-in layers (no GPU work)."""
+import pytest
+import torch
+
+
+def test_product_ext_refuses_cpu_tensors(built_lib):
+    """The reference's native module raises "CPU not supported" (ball_query.cpp:35-37); so does the
+    product binding -- there is no CPU fallback to route through."""
+    import pointnet2_utils
+    ext = pointnet2_utils._ext
+    assert ext.__name__ == "pointnet2._ext" and ext.LIB_PATH.endswith("libomnipq_pointops.so")
+    xyz = torch.rand(1, 16, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.furthest_point_sampling(xyz, 4)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.ball_query(xyz[:, :4].contiguous(), xyz, 0.5, 4)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ext.furthest_point_sampling(torch.rand(1, 3, 16).transpose(1, 2), 4)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        ext.gather_points(torch.rand(1, 2, 16), torch.zeros(1, 4, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="float tensor"):
+        ext.three_nn(torch.rand(1, 4, 3).double(), torch.rand(1, 4, 3))
+
+
+def test_mlp_spec_is_bumped_in_place(oracle_backend):
+    """reference pointnet2_modules.py:204-206 mutates the caller's list."""
+    import pointnet2_modules
+    spec = [0, 8, 16]
+    pointnet2_modules.PointnetSAModuleVotes(mlp=spec, npoint=4, radius=0.5, nsample=4)
+    assert spec == [3, 8, 16]
+
+
+def test_state_dict_names_are_the_checkpoint_contract(oracle_backend):
+    import pointnet2_modules
+    sa = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 8, 16], npoint=4, radius=0.5, nsample=4)
+    keys = list(sa.state_dict().keys())
+    assert keys[:6] == ["mlp_module.layer0.conv.weight", "mlp_module.layer0.bn.bn.weight",
+                        "mlp_module.layer0.bn.bn.bias", "mlp_module.layer0.bn.bn.running_mean",
+                        "mlp_module.layer0.bn.bn.running_var", "mlp_module.layer0.bn.bn.num_batches_tracked"]
+    assert sa.state_dict()["mlp_module.layer0.conv.weight"].shape == (8, 3, 1, 1)
+    fp = pointnet2_modules.PointnetFPModule(mlp=[12, 8])
+    assert "mlp.layer0.conv.weight" in fp.state_dict()
+
+
+def test_outputs_are_fresh_tensors_and_indices_nondifferentiable(oracle_backend):
+    import pointnet2_utils as U
+    xyz = torch.rand(2, 64, 3)
+    feats = torch.rand(2, 5, 64, requires_grad=True)
+    inds = U.furthest_point_sample(xyz, 8)
+    assert inds.dtype == torch.int32 and not inds.requires_grad
+    new_xyz = U.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    idx = U.ball_query(0.5, 4, xyz, new_xyz)
+    g = U.grouping_operation(feats, idx)
+    assert g.is_contiguous() and g._base is None
+    g2 = g - 1.0
+    g2.sum().backward()
+    assert feats.grad is not None and feats.grad.shape == feats.shape
+    dist, idx3 = U.three_nn(xyz, new_xyz)
+    assert idx3.dtype == torch.int32 and (dist >= 0).all()
+
+
+def test_sa_accepts_precomputed_inds_and_all_pooling_modes(oracle_backend):
+    import pointnet2_modules
+    xyz = torch.rand(2, 128, 3)
+    inds = torch.arange(16, dtype=torch.int32).repeat(2, 1)
+    for pooling in ("max", "avg", "rbf"):
+        sa = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 8], npoint=16, radius=0.4, nsample=8,
+                                                     pooling=pooling, normalize_xyz=True)
+        new_xyz, f, out_inds = sa(xyz, None, inds)
+        assert torch.equal(out_inds, inds) and f.shape == (2, 8, 16)
+        assert torch.equal(new_xyz, xyz[:, :16])
+    with pytest.raises(AssertionError):
+        sa(xyz, None, inds[:, :8].contiguous())
+
+
+def test_msg_and_lfp_variants_run(oracle_backend):
+    import pointnet2_modules as M
+    xyz = torch.rand(2, 96, 3)
+    feats = torch.rand(2, 6, 96)
+    msg = M.PointnetSAModuleMSG(npoint=8, radii=[0.3, 0.6], nsamples=[4, 8], mlps=[[6, 8], [6, 12]])
+    new_xyz, f = msg(xyz, feats)
+    assert f.shape == (2, 20, 8)
+    msgv = M.PointnetSAModuleMSGVotes(npoint=8, radii=[0.3], nsamples=[4], mlps=[[6, 8]])
+    _, f2, inds = msgv(xyz, feats)
+    assert f2.shape == (2, 8, 8) and inds.shape == (2, 8)
+    sa_all = M.PointnetSAModule(mlp=[6, 10])
+    _, f3 = sa_all(xyz, feats)
+    assert f3.shape == (2, 10, 1)
+    lfp = M.PointnetLFPModuleMSG(mlps=[[6, 8]], radii=[0.5], nsamples=[4], post_mlp=[8 + 3, 5])
+    y = lfp(new_xyz, xyz, torch.rand(2, 3, 8), feats)
+    assert y.shape == (2, 5, 8)
+
+
+def test_synth_generators_are_deterministic_and_sharded():
+    import synth
+    a = synth.make_clouds(3, 2, 256, extra_channels=6)
+    b = synth.make_clouds(3, 1, 256, extra_channels=6, first_scene=1)
+    assert a.shape == (2, 256, 9) and torch.equal(a[1], b[0])
+    adv = synth.adversarial_cloud(0, 1, 640)
+    assert (adv[0, 0] == 0).all() and float(adv[0, -1, 0]) == 50.0
