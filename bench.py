@@ -50,6 +50,7 @@ def parse():
                     help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-operator table to stderr")
     return ap.parse_args()
@@ -121,8 +122,11 @@ def cpu_baseline(args):
     saved = pointnet2_utils._ext
     pointnet2_utils._ext = oracle_ext
     try:
-        cores = os.cpu_count() or 1
+        # a 2-scene step has far less parallel slack than a 256-thread host offers; beyond ~32
+        # threads PyTorch's CPU convs and the OpenMP loops only fight over the memory system
+        cores = min(os.cpu_count() or 1, args.cpu_threads)
         torch.set_num_threads(cores)
+        oracle_ext.set_num_threads(cores)
         b = args.cpu_sample_scenes
         net = build_model(args.extra_channels)
         net.train()

@@ -47,7 +47,8 @@ const char *omnipq_error_string(int code);
 
 /* cuda_utils.h:20-24 opt_n_threads(): the reference's block size for `work_size`
  * items, 2^floor(log2) clamped to [1, 512].  Exposed because the FPS tie rule is
- * defined by it (max d2, then lowest k mod opt_n_threads(n), then lowest k). */
+ * defined by it: max d2, then the lowest BIT-REVERSED (k mod opt_n_threads(n)) -- the order
+ * the reference's shared-memory reduction tree induces -- then lowest k. */
 int omnipq_opt_n_threads(int work_size);
 
 /* replaces furthest_point_sampling_kernel_wrapper (sampling.cpp:18-20,

@@ -3,8 +3,9 @@
 // Replaces furthest_point_sampling_kernel (reference pointnet2/_ext_src/src/
 // sampling_gpu.cu:74-178), whose result this kernel reproduces index for index:
 //   idx[0] = 0; round j picks argmax_k temp[k] after temp[k] = min(temp[k], |p_k - p_old|^2)
-//   over the points with |p_k|^2 > 1e-3, ties -> lowest (k mod bs), then lowest k,
-//   where bs = opt_n_threads(n) is the reference's block size (cuda_utils.h:20-24).
+//   over the points with |p_k|^2 > 1e-3, ties -> lowest bit-reversed (k mod bs), then lowest k,
+//   where bs = opt_n_threads(n) is the reference's block size (cuda_utils.h:20-24) -- the order
+//   its shared-memory reduction tree induces (see tie_key below).
 //   If no point qualifies the round yields 0.
 //
 // MI355X design (not the reference's one-block-per-scene, re-read-everything loop):
@@ -31,8 +32,18 @@ constexpr unsigned kNoKey = 0xFFFFFFFFu;
 constexpr int kKBits = 20;  // k < 2^20 points per scene
 constexpr unsigned kKMask = (1u << kKBits) - 1;
 
+// Tie order among equal d2.  The reference reduces its block with a shared-memory tree that
+// folds slot t+h into slot t for h = bs/2 .. 1 and keeps slot t on a tie (sampling_gpu.cu:64-70,
+// 124-177).  Two tied threads first meet at h = lowest set bit of (tid_a xor tid_b) and the one
+// whose bit h is 0 survives, so bit 0 of tid is the MOST significant tie criterion: the block
+// winner is the tied thread with the smallest BIT-REVERSED tid (tid = k mod bs); inside one
+// thread the strided scan with strict '>' keeps the lowest k.  Key = (bitrev(tid), k), min wins.
 __device__ __forceinline__ unsigned tie_key(int k, int bs_mask) {
-  return ((unsigned)(k & bs_mask) << kKBits) | (unsigned)k;
+  // bs_mask = 2^p - 1; __brev leaves the p reversed bits at the top of the word
+  const unsigned rev = __brev((unsigned)(k & bs_mask));
+  const int p = __builtin_popcount((unsigned)bs_mask);
+  const unsigned r = p ? (rev >> (32 - p)) : 0u;
+  return (r << kKBits) | (unsigned)k;
 }
 
 // (d2, c) is better than (bd2, bc)?

@@ -54,6 +54,11 @@ def set_dist_form(form):
     lib().oracle_set_dist_form(ctypes.c_int(int(form)))
 
 
+def set_num_threads(n):
+    """Cap the OpenMP team of the oracle (batch / query loops)."""
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
 def opt_n_threads(work_size):
     return int(lib().oracle_opt_n_threads(ctypes.c_int(int(work_size))))
 

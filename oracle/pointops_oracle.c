@@ -42,6 +42,13 @@
 static int g_dist_form = 1;
 
 void oracle_set_dist_form(int form) { g_dist_form = form; }
+
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+#else
+void oracle_set_num_threads(int n) { (void)n; }
+#endif
 int oracle_get_dist_form(void) { return g_dist_form; }
 
 /* a*a + b*b + c*c as the reference's device code evaluates it (see header). */
@@ -112,10 +119,12 @@ void oracle_gather_points_grad(int b, int c, int n, int m,
 }
 
 /* sampling_gpu.cu:64-178  furthest_point_sampling_kernel<block_size>.
- * The block's threads are simulated one by one so that the tie rule (max d2,
- * then lowest tid = k mod block_size, then lowest k) falls out of the same
- * code path as on the device: per-thread strided scan with strict '>'
- * (:117-118), then the shared-memory tree with __update (:64-70).
+ * The block's threads and its shared-memory tree are simulated literally so
+ * that the tie rule falls out of the same code path as on the device:
+ * per-thread strided scan with strict '>' (:117-118, lowest k of a thread
+ * wins), then the tree with __update (:64-70), which folds slot t+h into t
+ * for h = bs/2..1 keeping t on a tie -- i.e. among tied threads the one with
+ * the smallest BIT-REVERSED tid wins (not simply the lowest tid).
  * temp must be pre-filled with 1e10 by the caller (sampling.cpp:80-82). */
 void oracle_furthest_point_sampling(int b, int n, int m, const float *dataset,
                                     float *temp, int *idxs) {

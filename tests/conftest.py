@@ -22,6 +22,12 @@ GOLDEN = os.path.join(HERE, "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the oracle's OpenMP loops are small; a 256-thread host only adds fork/join overhead
+    try:
+        from oracle import oracle_ext
+        oracle_ext.set_num_threads(min(os.cpu_count() or 1, 16))
+    except Exception:  # pragma: no cover - the oracle is built lazily by the fixtures
+        pass
 
 
 @pytest.fixture(scope="session")
@@ -50,9 +56,12 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name + ".pt"))
 
 
-def check_summary(got, ref, name, tol=1e-4):
+def check_summary(got, ref, name, tol=1e-4, metric="max"):
     """Compare a tensor with a tests/procedural.py:summarize record.
-    ints: exact.  floats: max|a-b| <= tol * max|b| on the stored elements (+ norms when sampled)."""
+    ints: exact.  floats: max|a-b| <= tol * max|b| on the stored elements (+ norms when sampled);
+    metric="l2": ||a-b||_2 <= tol * ||b||_2 instead -- used for parameter gradients, which are sums
+    of ~1e5-1e6 signed terms: f32 summation order alone moves single elements by >1e-3 of max-abs
+    while the vector as a whole stays put."""
     import torch
     assert list(got.shape) == ref["shape"], f"{name}: shape {list(got.shape)} != {ref['shape']}"
     flat = got.detach().cpu().reshape(-1)
@@ -63,8 +72,12 @@ def check_summary(got, ref, name, tol=1e-4):
     if not got.is_floating_point():
         assert torch.equal(have, want), f"{name}: integer mismatch at {int((have != want).sum())} places"
         return 0.0
+    if metric == "l2":
+        err = float((have.double() - want.double()).norm()) / (float(want.double().norm()) + 1e-30)
+        assert err <= tol, f"{name}: rel L2 err {err:.3e} > {tol}"
+        return err
     scale = float(want.abs().max()) + 1e-30
-    err = float((have.float() - want).abs().max()) / scale
+    err = float((have.double() - want.double()).abs().max()) / scale
     assert err <= tol, f"{name}: rel err {err:.3e} > {tol}"
     if "l2" in ref:
         l2 = float(flat.double().norm())

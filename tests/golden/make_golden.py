@@ -143,6 +143,61 @@ def fp_case(name, B, n, m, c_unknown, c_known, mlp):
                 "mlp": list(mlp)}, out)
 
 
+class Oracle64:
+    """float64 stand-in for `_ext`: index decisions come from the f32 oracle (all coordinates fed
+    to it are f32-representable), copies / weighted sums / scatter-adds are done in f64 by torch.
+    Used only to measure how far f32 arithmetic itself is from the exact result."""
+
+    @staticmethod
+    def furthest_point_sampling(points, nsamples):
+        return oracle_ext.furthest_point_sampling(points.float().contiguous(), nsamples)
+
+    @staticmethod
+    def ball_query(new_xyz, xyz, radius, nsample):
+        return oracle_ext.ball_query(new_xyz.float().contiguous(), xyz.float().contiguous(), radius, nsample)
+
+    @staticmethod
+    def three_nn(unknowns, knows):
+        _, idx = oracle_ext.three_nn(unknowns.float().contiguous(), knows.float().contiguous())
+        picked = torch.gather(knows.unsqueeze(1).expand(-1, unknowns.shape[1], -1, -1), 2,
+                              idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+        return [((picked - unknowns.unsqueeze(2)) ** 2).sum(-1), idx]
+
+    @staticmethod
+    def gather_points(points, idx):
+        return torch.gather(points, 2, idx.long().unsqueeze(1).expand(-1, points.shape[1], -1))
+
+    @staticmethod
+    def gather_points_grad(grad_out, idx, n):
+        out = torch.zeros(grad_out.shape[0], grad_out.shape[1], n, dtype=grad_out.dtype)
+        return out.scatter_add_(2, idx.long().unsqueeze(1).expand(-1, grad_out.shape[1], -1), grad_out)
+
+    @staticmethod
+    def group_points(points, idx):
+        B, C, _ = points.shape
+        flat = idx.long().reshape(B, 1, -1).expand(-1, C, -1)
+        return torch.gather(points, 2, flat).reshape(B, C, idx.shape[1], idx.shape[2])
+
+    @staticmethod
+    def group_points_grad(grad_out, idx, n):
+        B, C = grad_out.shape[:2]
+        out = torch.zeros(B, C, n, dtype=grad_out.dtype)
+        return out.scatter_add_(2, idx.long().reshape(B, 1, -1).expand(-1, C, -1), grad_out.reshape(B, C, -1))
+
+    @staticmethod
+    def three_interpolate(points, idx, weight):
+        B, C, _ = points.shape
+        g = torch.gather(points, 2, idx.long().reshape(B, 1, -1).expand(-1, C, -1)).reshape(B, C, -1, 3)
+        return (g * weight.unsqueeze(1)).sum(-1)
+
+    @staticmethod
+    def three_interpolate_grad(grad_out, idx, weight, m):
+        B, C, _ = grad_out.shape
+        out = torch.zeros(B, C, m, dtype=grad_out.dtype)
+        contrib = (grad_out.unsqueeze(-1) * weight.unsqueeze(1)).reshape(B, C, -1)
+        return out.scatter_add_(2, idx.long().reshape(B, 1, -1).expand(-1, C, -1), contrib)
+
+
 def mean_size_arr():
     return (0.3 + np.arange(54, dtype=np.float64).reshape(18, 3) * 0.05)
 
@@ -181,6 +236,34 @@ def model_case(name, xyz, train):
             out["gradnorm." + k] = float(p.grad.double().norm()) if p.grad is not None else None
     out["state_dict_keys"] = list(net.state_dict().keys())
     out["state_dict_shapes"] = [list(v.shape) for v in net.state_dict().values()]
+
+    # The same forward in float64 with the votes pinned to the f32 run's values: the distance of
+    # the f32 fixture from these numbers is the rounding noise of f32 arithmetic itself.
+    vote_ref = end_points["vote_xyz"].detach().double()
+    net64 = net.double()
+    for m in net64.modules():
+        if hasattr(m, "_means"):
+            m._means = None
+    ref_utils._ext = Oracle64
+    handle = net64.vote.register_forward_hook(lambda mod, inp, o: (vote_ref, o[1]))
+    try:
+        with torch.no_grad():
+            ep64 = net64({"point_clouds": xyz.double()})
+    finally:
+        handle.remove()
+        ref_utils._ext = oracle_ext
+    worst = 0.0
+    for k, v in ep64.items():
+        if v.is_floating_point():
+            out["ep64." + k] = summarize(v.float() if v.numel() <= 8192 else v)
+            a, b = end_points[k].detach().double(), v
+            err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+            out["f32_vs_f64." + k] = err
+            worst = max(worst, err)
+        else:
+            assert torch.equal(v, end_points[k]), k
+    out["f32_vs_f64.worst"] = worst
+    print(f"{name}: reference f32 vs f64 worst rel err {worst:.3e}")
     save(name, {"point_clouds": xyz, "train": train}, out)
 
 

@@ -16,6 +16,11 @@ from oracle import oracle_ext
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# End-to-end tensors (6 decoder layers deep) are compared against the FLOAT64 evaluation of the
+# reference stored in the fixtures, with 1e-4 or 4x the reference's own f32-vs-f64 distance on
+# that tensor, whichever is larger (tests/test_oracle_golden.py:run_model_case): in train mode the
+# reference's f32 arithmetic is itself up to 2.9e-4 away from f64 (fixture key f32_vs_f64.*).
+MODEL_TOL = 1e-4
 
 
 def dev():
@@ -55,9 +60,11 @@ def test_fps_index_exact(kind, b, n, m):
     assert torch.equal(got.cpu(), want), f"first mismatch at {(got.cpu() != want).nonzero()[:3].tolist()}"
     # the scratch buffer holds the final running min-distances, as the reference leaves it
     want_tmp = torch.full((b, n), 1e10)
+    scratch_idx = torch.zeros((b, m), dtype=torch.int32)        # must outlive the call
     oracle_ext.lib().oracle_furthest_point_sampling(b, n, m, ctypes.c_void_p(xyz.data_ptr()),
                                                     ctypes.c_void_p(want_tmp.data_ptr()),
-                                                    ctypes.c_void_p(torch.zeros((b, m), dtype=torch.int32).data_ptr()))
+                                                    ctypes.c_void_p(scratch_idx.data_ptr()))
+    assert torch.equal(scratch_idx, want)
     assert torch.equal(tmp.cpu(), want_tmp)
 
 
@@ -92,8 +99,9 @@ def test_fps_empty_and_degenerate_arguments():
     assert capi.call("omnipq_furthest_point_sampling", 2, 10, 0, capi.P(xyz), capi.P(tmp), capi.P(out)) == 0
     assert capi.call("omnipq_furthest_point_sampling", 0, 10, 4, capi.P(xyz), capi.P(tmp), capi.P(out)) == 0
     assert capi.call("omnipq_furthest_point_sampling", 2, 10, 4, capi.P(None), capi.P(tmp), capi.P(out)) == 10001
+    out4 = torch.zeros((2, 4), device=d, dtype=torch.int32)
     assert capi.call("omnipq_furthest_point_sampling", 1, (1 << 20) + 1, 4, capi.P(xyz), capi.P(tmp),
-                     capi.P(out)) == 10002
+                     capi.P(out4)) == 10002
 
 
 # --------------------------------------------------------------------------- ball query
@@ -185,9 +193,12 @@ def test_full_size_properties_config2():
     centres = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
     # FPS never re-picks a point while un-picked points remain at positive distance
     assert all(len(set(row.tolist())) == 2048 for row in inds.cpu())
-    # every cloud point is within the final coverage radius of some centre: temp == min_j |p - c_j|^2
-    d = torch.cdist(xyz[0:1, :4000], centres[0:1]) ** 2
-    assert torch.allclose(d.min(-1).values, tmp[0:1, :4000], rtol=1e-4, atol=1e-6)
+    # the scratch buffer is the coverage distance: temp[k] == min_j |p_k - c_j|^2 over the picks
+    # (the last pick is never folded into temp: the loop ends before using it, sampling_gpu.cu:94-178)
+    d = ((xyz[0, :4000, None, :] - centres[0, None, :-1, :]) ** 2).sum(-1)
+    seen = (xyz[0, :4000] ** 2).sum(-1) > 1.1e-3          # points inside the 1e-3 ball keep 1e10
+    assert torch.allclose(d.min(-1).values[seen], tmp[0, :4000][seen], rtol=1e-5, atol=1e-7)
+    assert bool((tmp[0, :4000][(xyz[0, :4000] ** 2).sum(-1) < 0.9e-3] == 1e10).all())
     idx = capi.ball_query(centres, xyz, 0.2, 64)
     assert int(idx.min()) >= 0 and int(idx.max()) < 40000
     # first slot of every ball is the smallest member index and members are inside the ball
@@ -195,8 +206,11 @@ def test_full_size_properties_config2():
     d2 = ((members - centres.unsqueeze(2)) ** 2).sum(-1)
     assert float(d2.max()) < 0.2 * 0.2 * (1 + 1e-5)
     assert bool((idx[:, :, :1] <= idx).all())           # padding repeats the first (smallest) hit
-    # idempotence: a centre is always inside its own ball
-    assert bool((idx == inds.unsqueeze(-1)).any(-1).float().mean() > 0.99)
+    # a ball that is not full (its tail repeats the first hit) lists every member, so it must
+    # contain its own centre (distance 0 < r^2)
+    not_full = idx[:, :, -1] == idx[:, :, 0]
+    has_self = (idx == inds.unsqueeze(-1)).any(-1)
+    assert bool(has_self[not_full].all()) and int(not_full.sum()) > 1000
 
 
 # --------------------------------------------------------------------------- layers and model vs fixtures
@@ -212,21 +226,42 @@ def test_ops_through_python_layers_match_reference_fixture(name):
 def test_sa_module_on_gpu_matches_reference_fixture(name):
     import pointnet2_modules
     from test_oracle_golden import run_sa_case
-    run_sa_case(name, load_golden(name), pointnet2_modules, device="cuda", tol=TOL)
+    run_sa_case(name, load_golden(name), pointnet2_modules, device="cuda", tol=TOL, grad_tol=1e-2,
+                grad_metric="l2")
 
 
 def test_fp_module_on_gpu_matches_reference_fixture():
     import pointnet2_modules
     from test_oracle_golden import run_fp_case
-    run_fp_case("fp2_like", load_golden("fp2_like"), pointnet2_modules, device="cuda", tol=TOL)
+    run_fp_case("fp2_like", load_golden("fp2_like"), pointnet2_modules, device="cuda", tol=TOL, grad_tol=1e-2,
+                grad_metric="l2")
 
 
 def test_model_eval_on_gpu_matches_reference_fixture():
     from test_oracle_golden import run_model_case
-    ep = run_model_case(load_golden("model_eval_8192"), device="cuda", tol=TOL)
+    ep = run_model_case(load_golden("model_eval_8192"), device="cuda", tol=MODEL_TOL, forced=True)
     assert ep["sa1_inds"].dtype == torch.int32 and ep["sa1_inds"].is_cuda
 
 
 def test_model_train_on_gpu_matches_reference_fixture():
     from test_oracle_golden import run_model_case
-    run_model_case(load_golden("model_train_8192"), device="cuda", tol=TOL, grad_tol=5e-3)
+    run_model_case(load_golden("model_train_8192"), device="cuda", tol=MODEL_TOL, grad_tol=5e-3, forced=True)
+
+
+def test_in_model_sampling_on_learned_votes_is_index_exact():
+    """FPS / ball query on the model's OWN vote coordinates (learned, so not covered by fixtures)
+    agree with the oracle run on exactly those coordinates."""
+    from test_oracle_golden import build_model
+    from procedural import load_procedural
+    fx = load_golden("model_eval_8192")
+    net = load_procedural(build_model(0)).to(dev()).eval()
+    with torch.no_grad():
+        ep = net({"point_clouds": fx["inputs"]["point_clouds"].to(dev())})
+    votes = ep["vote_xyz"].cpu().contiguous()
+    inds = oracle_ext.furthest_point_sampling(votes, 256)
+    want = torch.gather(votes, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(ep["aggregated_vote_xyz"].cpu(), want)
+    seeds = ep["seed_xyz"].cpu().contiguous()
+    inds_q = oracle_ext.furthest_point_sampling(seeds, 256)
+    want_q = torch.gather(seeds, 1, inds_q.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(ep["aggregated_sample_xyz"].cpu(), want_q)

@@ -58,7 +58,8 @@ def test_ops_match_reference_layers(name, oracle_backend):
     run_op_case(name, load_golden(name), pointnet2_utils)
 
 
-def run_sa_case(name, fx, modules, device="cpu", tol=1e-5):
+def run_sa_case(name, fx, modules, device="cpu", tol=1e-5, grad_tol=None, grad_metric="max"):
+    grad_tol = 20 * tol if grad_tol is None else grad_tol
     inp, out = fx["inputs"], fx["outputs"]
     spec = dict(inp["spec"])
     mod = modules.PointnetSAModuleVotes(mlp=list(spec.pop("mlp")), **spec)
@@ -74,9 +75,9 @@ def run_sa_case(name, fx, modules, device="cpu", tol=1e-5):
     params = list(mod.parameters())
     grads = torch.autograd.grad(new_feats, params + ([f] if f is not None else []), g_up)
     for (k, _), g in zip(mod.named_parameters(), grads):
-        check_summary(g, out["grad." + k], "grad." + k, 20 * tol)
+        check_summary(g, out["grad." + k], "grad." + k, grad_tol, grad_metric)
     if f is not None:
-        check_summary(grads[-1], out["grad.features"], "grad.features", 20 * tol)
+        check_summary(grads[-1], out["grad.features"], "grad.features", grad_tol, grad_metric)
     for k, v in mod.state_dict().items():
         if "running" in k:
             check_summary(v, out["buf." + k], "buf." + k, tol)
@@ -88,7 +89,8 @@ def test_sa_module_matches_reference(name, oracle_backend):
     run_sa_case(name, load_golden(name), pointnet2_modules)
 
 
-def run_fp_case(name, fx, modules, device="cpu", tol=1e-5):
+def run_fp_case(name, fx, modules, device="cpu", tol=1e-5, grad_tol=None, grad_metric="max"):
+    grad_tol = 20 * tol if grad_tol is None else grad_tol
     inp, out = fx["inputs"], fx["outputs"]
     mod = modules.PointnetFPModule(mlp=list(inp["mlp"]))
     load_procedural(mod)
@@ -102,9 +104,9 @@ def run_fp_case(name, fx, modules, device="cpu", tol=1e-5):
     g_up = procedural_tensor(name + ".g_out", tuple(y.shape), torch.float32).to(device)
     grads = torch.autograd.grad(y, list(mod.parameters()) + [uf, kf], g_up)
     for (k, _), g in zip(mod.named_parameters(), grads):
-        check_summary(g, out["grad." + k], "grad." + k, 20 * tol)
-    check_summary(grads[-2], out["grad.unknown_feats"], "grad.unknown_feats", 20 * tol)
-    check_summary(grads[-1], out["grad.known_feats"], "grad.known_feats", 20 * tol)
+        check_summary(g, out["grad." + k], "grad." + k, grad_tol, grad_metric)
+    check_summary(grads[-2], out["grad.unknown_feats"], "grad.unknown_feats", grad_tol, grad_metric)
+    check_summary(grads[-1], out["grad.known_feats"], "grad.known_feats", grad_tol, grad_metric)
 
 
 def test_fp_module_matches_reference(oracle_backend):
@@ -131,7 +133,22 @@ def zero_dropout(net):
             m.dropout = 0.0
 
 
-def run_model_case(fx, device="cpu", tol=1e-5, grad_tol=1e-3):
+def force_votes(net, vote_xyz_ref):
+    """Teacher-force the vote coordinates to the fixture's values (keeping the autograd graph).
+
+    Everything after the votes is sampled from LEARNED coordinates: FPS and ball query on vote_xyz
+    are discontinuous, so f32 rounding differences between two correct implementations (CPU vs
+    GPU BLAS) flip picks and make every later tensor incomparable.  With the votes pinned, later
+    tensors are comparable again; the un-forced run still checks everything up to the votes, and
+    the GPU suite separately checks that the in-model FPS / ball query agree with the oracle on
+    the model's own votes."""
+    def hook(_mod, _inp, output):
+        xyz, feats = output
+        return xyz + (vote_xyz_ref.to(xyz.device) - xyz).detach(), feats
+    return net.vote.register_forward_hook(hook)
+
+
+def run_model_case(fx, device="cpu", tol=1e-5, grad_tol=1e-3, forced=False):
     inp, out = fx["inputs"], fx["outputs"]
     net = build_model(inp["point_clouds"].shape[-1] - 3)
     sd = net.state_dict()
@@ -145,12 +162,37 @@ def run_model_case(fx, device="cpu", tol=1e-5, grad_tol=1e-3):
         zero_dropout(net)
     else:
         net.eval()
+    if forced:
+        vote_ref = out["ep.vote_xyz"]["full"].reshape(out["ep.vote_xyz"]["shape"])
+        with torch.no_grad():            # un-forced pass: everything up to and including the votes
+            ep0 = net({"point_clouds": inp["point_clouds"].to(device)})
+        for k in list(ep0.keys()):
+            if k == "aggregated_vote_xyz":
+                break
+            check_summary(ep0[k], out["ep." + k], k, tol)
+        handle = force_votes(net, vote_ref)
     with torch.set_grad_enabled(train):
         ep = net({"point_clouds": inp["point_clouds"].to(device)})
+    if forced:
+        handle.remove()
     assert sorted(ep.keys()) == out["keys"]
     for k, v in ep.items():
         assert str(v.dtype) == out["dtype." + k], (k, v.dtype)
-        check_summary(v, out["ep." + k], k, tol)
+        if forced and k.endswith("pred_size"):
+            # argmax over near-tied size scores: discontinuous (the reference's own f32 run flips a
+            # pick w.r.t. f64 on this fixture) -> check the decode against this run's own tensors
+            p = k[: -len("pred_size")]
+            pick = torch.argmax(ep[p + "size_scores"], -1)
+            means = torch.from_numpy(mean_size_arr().astype("float32")).to(v.device)
+            want = torch.gather(ep[p + "size_residuals"] + means, 2,
+                                pick[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+            assert torch.equal(v, want), k
+        elif forced and ("ep64." + k) in out:
+            # measured against the float64 evaluation of the reference; the allowance is what the
+            # reference's own f32 arithmetic needs on this tensor (never less than `tol`)
+            check_summary(v, out["ep64." + k], k, max(tol, 4.0 * out["f32_vs_f64." + k]))
+        else:
+            check_summary(v, out["ep." + k], k, tol)
     if train:
         loss = 0.0
         for k in sorted(ep.keys()):
@@ -190,3 +232,9 @@ def test_crosscheck_record():
     assert rec["ball_rows_equal"] == 1.0 and rec["three_nn_rows_equal"] == 1.0
     # golden inputs are insensitive to the FMA-contraction form of the distance
     assert all(v == 0 for k, v in rec.items() if "_diff_" in k)
+
+
+def test_model_train_with_forced_votes_is_equivalent(oracle_backend):
+    """The teacher-forcing used by the GPU suite must not change anything when the votes already
+    agree (CPU + oracle reproduces the fixture bit for bit)."""
+    run_model_case(load_golden("model_train_8192"), forced=True)
