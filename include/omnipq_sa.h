@@ -1,0 +1,75 @@
+/*
+ * omnipq_sa.h -- C ABI of the fused set-abstraction stage (libomnipq_pointops.so).
+ *
+ * These entry points have no one-to-one counterpart in the reference's native module: the
+ * reference runs this stage as PyTorch ops between its `_ext` calls --
+ *   QueryAndGroup.forward          pointnet2/pointnet2_utils.py:317-376   (group, centre, /radius, cat)
+ *   SharedMLP (conv1x1 + BN + ReLU) pointnet2/pytorch_utils.py:11-36,67-120
+ *   F.max_pool2d over nsample       pointnet2/pointnet2_modules.py:251-257
+ * and their autograd.  A maintainer binds them from PointnetSAModuleVotes.forward.
+ *
+ * Layout: activations are position-major bf16, X[p][c] with p = (b * npoint + j) * nsample + s and
+ * the channel axis contiguous; weights are [C_out][C_in] bf16; statistics f32/f64.  All pointers
+ * are device pointers, all launches asynchronous on `stream`, return value 0 or an error code
+ * (omnipq_pointops.h).  Channel counts must be multiples of 8, GEMM contraction lengths of 32.
+ */
+#ifndef OMNIPQ_SA_H
+#define OMNIPQ_SA_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* X[p][0..cin) = feat_pm[b][idx[p]][:]; X[p][cin..cin+3) = (xyz[b][idx[p]] - new_xyz[b][j]) * inv_radius;
+ * columns up to kpad zero.  feat_pm is [b][n][cin] bf16 (NULL when cin == 0); idx is (b,m,s) i32. */
+int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const float *xyz,
+                     const float *new_xyz, const int *idx, const void *feat_pm, void *X, void *stream);
+
+/* adjoint of omnipq_sa_gather: atomically adds dX[p][0..cin) into dfeat_pm[b][idx[p]][:] (f32, may be
+ * NULL) and the coordinate part into dxyz[b][idx[p]] / -dnew_xyz[b][j] (f32, may be NULL together). */
+int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const int *idx,
+                      const void *dX, float *dfeat_pm, float *dxyz, float *dnew_xyz, void *stream);
+
+/* C[M][N] (bf16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */
+int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+                        void *stream);
+
+/* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
+long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
+int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
+                        float *workspace, void *stream);
+
+/* sums[0][c] = sum_p Y[p][c], sums[1][c] = sum_p Y[p][c]^2  (f64, zeroed by the call). */
+int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);
+
+/* BatchNorm training-mode bookkeeping from (possibly all-reduced) sums over `count` positions:
+ * a = gamma*invstd, b = beta - mean*a, saved mean/invstd, running-stat update (NULL to skip). */
+int omnipq_bn_finalize(int C, double count, const double *sums, const float *gamma, const float *beta, float eps,
+                       float momentum, float *running_mean, float *running_var, float *a, float *b,
+                       float *mean, float *invstd, void *stream);
+
+/* X = relu(a * Y + b) */
+int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, const float *b, void *X, void *stream);
+
+/* out[b][c][j] = max_s relu(a Y[(b,j,s)][c] + b) -> out_ref (b,C,m) f32, out_pm [b*m][C] bf16, arg u8 */
+int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const float *a, const float *bshift,
+                   float *out_ref, void *out_pm, unsigned char *arg, void *stream);
+
+/* backward of pool + last BatchNorm, in two phases so a cross-rank all-reduce of `sums` can sit between */
+int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *Y, const float *mean, const float *invstd,
+                             const float *g_out, const void *out_pm, const unsigned char *arg, double *sums,
+                             void *stream);
+int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
+                             const float *mean, const float *invstd, const double *sums, const float *g_out,
+                             const void *out_pm, const unsigned char *arg, void *dY, void *stream);
+
+/* backward of ReLU + BatchNorm for the inner layers (dX -> dY, may be in place) */
+int omnipq_bn_bwd_stats(long long P, int C, const void *dX, const void *Y, const float *a, const float *b,
+                        const float *mean, const float *invstd, double *sums, void *stream);
+int omnipq_bn_bwd_apply(long long P, int C, double total_positions, const void *dX, const void *Y,
+                        const float *a, const float *b, const float *mean, const float *invstd,
+                        const double *sums, void *dY, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNIPQ_SA_H */

@@ -1,0 +1,240 @@
+// C = A * B^T on the gfx950 matrix cores, bf16 operands, f32 accumulation.
+//
+// This is the contraction inside the set-abstraction stage's shared MLP (reference
+// pytorch_utils.py:11-36: 1x1 Conv2d over (B, C, npoint, nsample) == a GEMM whose M axis is the
+// B*npoint*nsample grouped positions).  Activations are kept position-major [P][C] (channels
+// contiguous), weights [C_out][C_in], so both operands are K-contiguous:
+//     forward    Y[P][Cout]    = X[P][Cin]      * W[Cout][Cin]^T
+//     data grad  dX[P][Cin]    = dY[P][Cout]    * Wt[Cin][Cout]^T
+//     weight grad dW[Cout][Cin] = dYt[Cout][P]  * Xt[Cin][P]^T        (split along K = P)
+//
+// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves in a 2x2 grid, each wave owning a
+// 64x64 patch as 2x2 v_mfma_f32_32x32x16_bf16 tiles (64 accumulator VGPRs).  Operand tiles are
+// staged global -> registers -> LDS (rows padded to 80 B so the 16-lane groups of ds_read_b128
+// fall on 16 distinct 16-byte slots), double buffered with ONE barrier per K-step: the loads for
+// step k+1 are issued before the MFMAs of step k and written to the other buffer after them.
+// The C tile leaves through LDS so that global stores are 16 B per lane along rows.
+// blockIdx is remapped so that the N-tiles of one M-tile run on the same XCD (A-tile re-reads hit
+// that XCD's L2 instead of going back to HBM once per N-tile).
+#include "common.h"
+
+namespace omnipq {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int GPITCH = 40;                 // bf16 elements per staged row (32 + 8 pad) = 80 B
+constexpr int GCPITCH = 136;               // bf16 C-tile pitch (128 + 8) = 272 B
+constexpr int GCPITCH_F32 = 132;           // f32 C-tile pitch
+
+struct GemmArgs {
+  int M, N, K;          // C is M x N, contraction length K (all operands row-major, K contiguous)
+  int lda, ldb, ldc;    // leading dimensions in elements
+  int k_chunk;          // K range per blockIdx.z slice (== K when not split); multiple of GBK
+  int m_tiles, n_tiles;
+};
+
+__device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
+                                                        const bf16_t *__restrict__ B,
+                                                        void *__restrict__ Cout) {
+  // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
+  constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
+  constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
+  constexpr int LDS_BYTES = (STAGE_ELEMS * 2 > CT_BYTES) ? STAGE_ELEMS * 2 : CT_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
+
+  // XCD-aware tile order: id % 8 picks the XCD, the N-tiles of one M-tile stay on it
+  const int id = (int)blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int mt = xcd + 8 * (local / g.n_tiles);
+  const int nt = local % g.n_tiles;
+  if (mt >= g.m_tiles) return;
+  const int m0 = mt * GBM, n0 = nt * GBN;
+  const int kbeg = (int)blockIdx.z * g.k_chunk;
+  int kend = kbeg + g.k_chunk;
+  if (kend > g.K) kend = g.K;
+  const int nk = (kend - kbeg + GBK - 1) / GBK;
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging assignment: chunk q = tid + i*256 -> row q>>2, 16-byte piece q&3
+  int srow[2], skc[2];
+  const bf16_t *ga[2], *gb[2];
+  bool aok[2], bok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + i * 256;
+    srow[i] = q >> 2;
+    skc[i] = q & 3;
+    const int ar = m0 + srow[i], br = n0 + srow[i];
+    aok[i] = ar < g.M;
+    bok[i] = br < g.N;
+    ga[i] = A + (size_t)(aok[i] ? ar : 0) * g.lda + kbeg + skc[i] * 8;
+    gb[i] = B + (size_t)(bok[i] ? br : 0) * g.ldb + kbeg + skc[i] * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[2], rb[2];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  auto load_tiles = [&](int kt) {
+    const int koff = kt * GBK;
+    const bool kin = kbeg + koff + 0 < kend;   // whole K-steps only (K is a multiple of GBK)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = (aok[i] && kin) ? ldg16(ga[i] + koff) : zero4;
+      rb[i] = (bok[i] && kin) ? ldg16(gb[i] + koff) : zero4;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    bf16_t *sa = stage + buf * (2 * 128 * GPITCH);
+    bf16_t *sb = sa + 128 * GPITCH;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4 *>(sa + srow[i] * GPITCH + skc[i] * 8) = ra[i];
+      *reinterpret_cast<uint4 *>(sb + srow[i] * GPITCH + skc[i] * 8) = rb[i];
+    }
+  };
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 31, fk = (lane >> 5) * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const bf16_t *sa = stage + buf * (2 * 128 * GPITCH);
+    const bf16_t *sb = sa + 128 * GPITCH;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8 *>(sa + (wm * 64 + i * 32 + frow) * GPITCH + kk * 16 + fk);
+        fb[i] = *reinterpret_cast<const bf16x8 *>(sb + (wn * 64 + i * 32 + frow) * GPITCH + kk * 16 + fk);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (row-major C tile) -> 16-byte row stores ----------------
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+  if (OUT_F32) {
+    float *ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+          ct[row * GCPITCH_F32 + wn * 64 + j * 32 + ccol] = acc[i][j][r];
+        }
+    __syncthreads();
+    float *C = reinterpret_cast<float *>(Cout) + (size_t)blockIdx.z * g.M * g.ldc;
+    // 128 rows x 32 float4 pieces
+    for (int q = tid; q < 128 * 32; q += 256) {
+      const int row = q >> 5, piece = q & 31;
+      const int gr = m0 + row, gc = n0 + piece * 4;
+      if (gr < g.M && gc < g.N) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ct + row * GCPITCH_F32 + piece * 4);
+        *reinterpret_cast<f32x4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 4
+      }
+    }
+  } else {
+    bf16_t *ct = reinterpret_cast<bf16_t *>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+          ct[row * GCPITCH + wn * 64 + j * 32 + ccol] = (bf16_t)acc[i][j][r];
+        }
+    __syncthreads();
+    bf16_t *C = reinterpret_cast<bf16_t *>(Cout);
+    for (int q = tid; q < 128 * 16; q += 256) {
+      const int row = q >> 4, piece = q & 15;
+      const int gr = m0 + row, gc = n0 + piece * 8;
+      if (gr < g.M && gc < g.N) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * GCPITCH + piece * 8);
+        *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
+      }
+    }
+  }
+}
+
+// sums the split-K slabs:  out[i] = sum_z part[z][i]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int n, int slabs, const float *__restrict__ part,
+                                                           float *__restrict__ out) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < slabs; ++z) s += part[(size_t)z * n + i];
+  out[i] = s;
+}
+
+}  // namespace omnipq
+
+// C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.
+extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                   void *C, int ldc, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// C[M][N] (f32) = A[M][K] * B[N][K]^T with K split into `slabs` slices; `workspace` holds
+// slabs*M*N floats.  Used for the weight gradient, where K = number of grouped positions.
+extern "C" int omnipq_gemm_nt_bf16_splitk(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                          float *C, int slabs, float *workspace, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0 || slabs < 1) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !workspace || (K % GBK) || (N % 4) || (lda % 8) || (ldb % 8)) return OMNIPQ_EINVAL;
+  int k_chunk = ((K / GBK + slabs - 1) / slabs) * GBK;
+  if (k_chunk < GBK) k_chunk = GBK;
+  const int used = (K + k_chunk - 1) / k_chunk;
+  GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, used);
+  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace);
+  OMNIPQ_LAUNCH_CHECK();
+  const int n = M * N;
+  splitk_reduce_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, used, workspace, C);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

@@ -1,0 +1,206 @@
+// C[M][N] = sum_p A[p][m] * B[p][n]   (both operands position-major, f32 result, split along p)
+//
+// The weight gradient of the shared MLP: dW[Cout][Cin] = sum over grouped positions of
+// dY[p][:]^T x X[p][:].  Both operands are stored [P][C] (channels contiguous), i.e. the
+// contraction index is the SLOW axis, so the k-contiguous fragments the MFMA wants cannot be
+// fetched with one wide LDS read.  Instead of materialising transposed copies in HBM, tiles are
+// staged exactly as they lie in memory ([32 positions][128 channels], coalesced 16-byte loads,
+// ds_write_b128) and each lane assembles its 8-position fragment with eight 16-bit LDS reads: for
+// a fixed position the 32 lanes of a half-wave read 32 consecutive channels (64 contiguous bytes),
+// so the reads are conflict-free.  LDS issue (64 narrow reads per K-step per lane) is the limiter,
+// about 2x the MFMA time -- accepted, since this GEMM is a third of the MLP's flops and the
+// alternative costs an extra HBM round trip of the two largest tensors.
+//
+// Grid: (M tiles x N tiles) x slabs; each slab contracts a contiguous range of positions into an
+// f32 partial tile, a second kernel sums the slabs (deterministic, no atomics).
+#include "common.h"
+
+namespace omnipq {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TBK = 32;            // positions per K-step
+constexpr int TPITCH = 136;        // bf16 per staged row: 128 channels + 8 pad (272 B, 16-B aligned)
+constexpr int TCPITCH = 132;       // f32 C-tile pitch
+
+struct TnArgs {
+  int M, N, P;        // C is M x N; P positions
+  int lda, ldb;       // row pitch (elements) of A and B
+  int p_chunk;        // positions per slab, multiple of TBK
+  int m_tiles, n_tiles;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
+                                                        const bf16_t *__restrict__ B,
+                                                        float *__restrict__ part) {
+  constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 17408 bf16 = 34 KB
+  constexpr int CT_BYTES = 128 * TCPITCH * 4;                  // 66 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES];
+  static_assert(STAGE_ELEMS * 2 <= CT_BYTES, "staging must fit under the C tile");
+  bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
+
+  const int tile = (int)blockIdx.x;
+  const int mt = tile / g.n_tiles, nt = tile % g.n_tiles;
+  const int m0 = mt * 128, n0 = nt * 128;
+  const int pbeg = (int)blockIdx.y * g.p_chunk;
+  int pend = pbeg + g.p_chunk;
+  if (pend > g.P) pend = g.P;
+  const int nk = (pend - pbeg + TBK - 1) / TBK;
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging: chunk q = tid + i*256 -> position q>>4 of the K-step, 16-byte channel piece q&15
+  int spos[2], sc8[2];
+  bool aok[2], bok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + i * 256;
+    spos[i] = q >> 4;
+    sc8[i] = q & 15;
+    aok[i] = m0 + sc8[i] * 8 < g.M;     // M, N are multiples of 8
+    bok[i] = n0 + sc8[i] * 8 < g.N;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[2], rb[2];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = pbeg + kt * TBK + spos[i];
+      const bool pin = p < pend;
+      ra[i] = (pin && aok[i]) ? *reinterpret_cast<const uint4 *>(A + (size_t)p * g.lda + m0 + sc8[i] * 8) : zero4;
+      rb[i] = (pin && bok[i]) ? *reinterpret_cast<const uint4 *>(B + (size_t)p * g.ldb + n0 + sc8[i] * 8) : zero4;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
+    bf16_t *sb = sa + TBK * TPITCH;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4 *>(sa + spos[i] * TPITCH + sc8[i] * 8) = ra[i];
+      *reinterpret_cast<uint4 *>(sb + spos[i] * TPITCH + sc8[i] * 8) = rb[i];
+    }
+  };
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int fch = lane & 31, fp = (lane >> 5) * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const unsigned short *sa = reinterpret_cast<const unsigned short *>(stage + buf * (2 * TBK * TPITCH));
+    const unsigned short *sb = sa + TBK * TPITCH;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned short va[8], vb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int prow = (kk * 16 + fp + e) * TPITCH;
+          va[e] = sa[prow + wm * 64 + i * 32 + fch];
+          vb[e] = sb[prow + wn * 64 + i * 32 + fch];
+        }
+        uint4 pa, pb;
+        pa.x = va[0] | ((unsigned)va[1] << 16); pa.y = va[2] | ((unsigned)va[3] << 16);
+        pa.z = va[4] | ((unsigned)va[5] << 16); pa.w = va[6] | ((unsigned)va[7] << 16);
+        pb.x = vb[0] | ((unsigned)vb[1] << 16); pb.y = vb[2] | ((unsigned)vb[3] << 16);
+        pb.z = vb[4] | ((unsigned)vb[5] << 16); pb.w = vb[6] | ((unsigned)vb[7] << 16);
+        fa[i] = __builtin_bit_cast(bf16x8, pa);
+        fb[i] = __builtin_bit_cast(bf16x8, pb);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  float *ct = reinterpret_cast<float *>(smem);
+  const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+        ct[row * TCPITCH + wn * 64 + j * 32 + ccol] = acc[i][j][r];
+      }
+  __syncthreads();
+  float *C = part + (size_t)blockIdx.y * g.M * g.N;
+  for (int q = tid; q < 128 * 32; q += 256) {
+    const int row = q >> 5, piece = q & 31;
+    const int gr = m0 + row, gc = n0 + piece * 4;
+    if (gr < g.M && gc < g.N)
+      *reinterpret_cast<f32x4 *>(C + (size_t)gr * g.N + gc) =
+          *reinterpret_cast<const f32x4 *>(ct + row * TCPITCH + piece * 4);
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(int n, int slabs, const float *__restrict__ part,
+                                                         float *__restrict__ out) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < slabs; ++z) s += part[(size_t)z * n + i];
+  out[i] = s;
+}
+
+}  // namespace omnipq
+
+// C[M][N] (f32) = A[P][M]^T * B[P][N]; M, N multiples of 8; lda, ldb multiples of 8.
+// `workspace` must hold omnipq_gemm_tn_workspace_floats(M, N, P) floats.
+extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
+  using namespace omnipq;
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int slabs = (1024 + tiles - 1) / tiles;
+  const int max_slabs = (P + TBK - 1) / TBK;
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  return (long long)slabs * M * N;
+}
+
+extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
+                                   float *C, float *workspace, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || P < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !workspace || (M % 8) || (N % 8) || (lda % 8) || (ldb % 8)) return OMNIPQ_EINVAL;
+  TnArgs g{M, N, P, lda, ldb, 0, (M + 127) / 128, (N + 127) / 128};
+  const int tiles = g.m_tiles * g.n_tiles;
+  int slabs = (1024 + tiles - 1) / tiles;
+  const int max_slabs = (P + TBK - 1) / TBK;
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
+  const int used = P > 0 ? (P + g.p_chunk - 1) / g.p_chunk : 1;
+  dim3 grid(tiles, used);
+  gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace);
+  OMNIPQ_LAUNCH_CHECK();
+  const int n = M * N;
+  slab_reduce_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, used, workspace, C);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

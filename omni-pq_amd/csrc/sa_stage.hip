@@ -1,0 +1,543 @@
+// Streaming kernels of the fused set-abstraction stage (everything around the MFMA GEMMs).
+//
+// The reference runs  QueryAndGroup -> SharedMLP(3 x [1x1 conv, BatchNorm, ReLU]) -> max over the
+// ball  as ~20 separate PyTorch/cuDNN ops on (B, C, npoint, nsample) f32 tensors
+// (pointnet2_utils.py:317-376, pytorch_utils.py:11-36, pointnet2_modules.py:251-257).  Here the
+// stage works on position-major bf16 activations [P = B*npoint*nsample][C]:
+//
+//   sa_gather      idx, xyz, centres, features -> X0[P][K0]     (relative xyz / radius ++ features)
+//   GEMM           Y_l = X_{l-1} W_l^T                           (gemm_bf16.hip)
+//   colstats       per-channel sum / sum of squares of Y_l       -> BatchNorm batch statistics
+//   bn_finalize    statistics -> scale/shift (a, b), running-stat update (momentum, unbiased var)
+//   bnrelu         X_l = relu(a * Y_l + b)
+//   pool           out = max_s relu(a * Y_L + b) (+ argmax), in the reference layout and position-major
+//   backward: pool_bwd_stats / bn_bwd_stats (sum dz, sum dz*yhat), pool_bwd_apply / bn_bwd_apply
+//   (dY = a (dz - mean dz - yhat mean(dz yhat))), GEMMs for dX and dW, sa_scatter (atomics into
+//   the feature / coordinate gradients).
+//
+// Every kernel moves 16 bytes (8 bf16 channels) per lane along the channel axis, so a wave touches
+// whole 128-byte lines; f32 is used for all arithmetic, f64 for the cross-block statistic sums.
+#include "common.h"
+
+namespace omnipq {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void unpack8(const uint4 &v, float (&f)[8]) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xFFFF0000u);
+  }
+}
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  return __builtin_bit_cast(unsigned short, (bf16_t)x);
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+  v.y = f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+  v.z = f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+  v.w = f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+  return v;
+}
+
+__device__ __forceinline__ void load8f(const float *p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4 *>(p);
+  const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+  f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// ------------------------------------------------------------------------------- sa_gather
+// X[p][0..cin) = feat[b][idx[p]][:],  X[p][cin..cin+3) = (xyz[b][idx[p]] - centre[b][m]) * inv_r,
+// remaining columns up to kpad are zero.  One lane per 16-byte piece of a row.
+__global__ __launch_bounds__(256) void sa_gather_kernel(long long chunks, int n, int m, int s, int cin,
+                                                       int kpad, float inv_r,
+                                                       const float *__restrict__ xyz,
+                                                       const float *__restrict__ new_xyz,
+                                                       const int *__restrict__ idx,
+                                                       const bf16_t *__restrict__ feat,
+                                                       bf16_t *__restrict__ X) {
+  const int cpr = kpad >> 3;   // 16-byte pieces per row
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long p = q / cpr;
+    const int c8 = (int)(q - p * cpr);
+    const int bm = (int)(p / s);
+    const int b = bm / m;
+    const int k = idx[p];
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (c8 * 8 < cin) {
+      out = *reinterpret_cast<const uint4 *>(feat + ((size_t)b * n + k) * cin + c8 * 8);
+    } else if (c8 * 8 == cin) {
+      const float *pk = xyz + ((size_t)b * n + k) * 3;
+      const float *pc = new_xyz + (size_t)bm * 3;
+      float f[8] = {(pk[0] - pc[0]) * inv_r, (pk[1] - pc[1]) * inv_r, (pk[2] - pc[2]) * inv_r, 0, 0, 0, 0, 0};
+      out = pack8(f);
+    }
+    *reinterpret_cast<uint4 *>(X + (size_t)p * kpad + c8 * 8) = out;
+  }
+}
+
+// ------------------------------------------------------------------------------- column sums
+// Shared tail of the statistic kernels: every thread holds 8 partial (u, v) sums for channels
+// cg*8..cg*8+7; fold the row-groups of the block through LDS, then one f64 atomic per channel.
+template <int MAXC>
+__device__ __forceinline__ void fold_and_publish(float (&u)[8], float (&v)[8], int cg, int rsub, int rpb,
+                                                 int cgs, int C, double *__restrict__ sums) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [u|v][rpb row groups][C]
+  const bool live = rsub < rpb && cg < cgs;
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(0 * rpb + rsub) * C + cg * 8 + e] = u[e];
+      red[(1 * rpb + rsub) * C + cg * 8 + e] = v[e];
+    }
+  }
+  __syncthreads();
+  for (int c = (int)threadIdx.x; c < 2 * C; c += 256) {
+    const int which = c / C, ch = c - which * C;
+    float acc = 0.f;
+    for (int r = 0; r < rpb; ++r) acc += red[(which * rpb + r) * C + ch];
+    atomicAdd(sums + (size_t)which * C + ch, (double)acc);
+  }
+}
+
+constexpr int kMaxC = 640;
+
+__device__ __forceinline__ void row_partition(int C, int &cgs, int &rpb, int &cg, int &rsub) {
+  cgs = C >> 3;
+  rpb = 256 / cgs;
+  if (rpb > 16) rpb = 16;
+  cg = (int)threadIdx.x % cgs;
+  rsub = (int)threadIdx.x / cgs;
+}
+
+// sums[0][c] = sum_p Y[p][c],  sums[1][c] = sum_p Y[p][c]^2
+__global__ __launch_bounds__(256) void colstats_kernel(long long P, int C, const bf16_t *__restrict__ Y,
+                                                      double *__restrict__ sums) {
+  int cgs, rpb, cg, rsub;
+  row_partition(C, cgs, rpb, cg, rsub);
+  float u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rsub < rpb) {
+    for (long long p = (long long)blockIdx.x * rpb + rsub; p < P; p += (long long)gridDim.x * rpb) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4 *>(Y + (size_t)p * C + cg * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        u[e] += f[e];
+        v[e] = __builtin_fmaf(f[e], f[e], v[e]);
+      }
+    }
+  }
+  fold_and_publish<kMaxC>(u, v, cg, rsub, rpb, cgs, C, sums);
+}
+
+// BatchNorm bookkeeping (training mode), one thread per channel:
+//   mean = s1/cnt, var = s2/cnt - mean^2 (biased), invstd = rsqrt(var + eps)
+//   a = gamma * invstd, b = beta - mean * a
+//   running_mean = (1-mom) rm + mom mean;  running_var = (1-mom) rv + mom var * cnt/(cnt-1)
+__global__ void bn_finalize_kernel(int C, double cnt, const double *__restrict__ sums,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float eps, float momentum, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var, float *__restrict__ a,
+                                   float *__restrict__ b, float *__restrict__ mean,
+                                   float *__restrict__ invstd) {
+  const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (c >= C) return;
+  const double mu = sums[c] / cnt;
+  double var = sums[C + c] / cnt - mu * mu;
+  if (var < 0) var = 0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float av = gamma[c] * is;
+  a[c] = av;
+  b[c] = beta[c] - (float)mu * av;
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  if (running_mean) {
+    const double unbiased = cnt > 1 ? var * cnt / (cnt - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// X = relu(a * Y + b)
+__global__ __launch_bounds__(256) void bnrelu_kernel(long long chunks, int C, const bf16_t *__restrict__ Y,
+                                                    const float *__restrict__ a, const float *__restrict__ b,
+                                                    bf16_t *__restrict__ X) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const int c0 = (int)(q % cpr) * 8;
+    float y[8], av[8], bv[8];
+    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
+    load8f(a + c0, av);
+    load8f(b + c0, bv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = fmaxf(__builtin_fmaf(av[e], y[e], bv[e]), 0.f);
+    *reinterpret_cast<uint4 *>(X + q * 8) = pack8(y);
+  }
+}
+
+// ------------------------------------------------------------------------------- pooling
+// out[bm][c] = max_s relu(a Y[(bm,s)][c] + b); arg = first s reaching it.  One lane per (bm, 8 ch).
+__global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s, int C,
+                                                  const bf16_t *__restrict__ Y, const float *__restrict__ a,
+                                                  const float *__restrict__ b, float *__restrict__ out_ref,
+                                                  bf16_t *__restrict__ out_pm, unsigned char *__restrict__ arg) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bm = q / cpr;
+    const int c0 = (int)(q - bm * cpr) * 8;
+    float av[8], bv[8], best[8];
+    int bi[8];
+    load8f(a + c0, av);
+    load8f(b + c0, bv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -1.f; bi[e] = 0; }
+    const bf16_t *row = Y + ((size_t)bm * s) * C + c0;
+    for (int t = 0; t < s; ++t) {
+      float y[8];
+      unpack8(*reinterpret_cast<const uint4 *>(row + (size_t)t * C), y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = fmaxf(__builtin_fmaf(av[e], y[e], bv[e]), 0.f);
+        if (x > best[e]) { best[e] = x; bi[e] = t; }
+      }
+    }
+    *reinterpret_cast<uint4 *>(out_pm + (size_t)bm * C + c0) = pack8(best);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(bi[e] & 0xFF) << (8 * e);
+    *reinterpret_cast<unsigned long long *>(arg + (size_t)bm * C + c0) = packed;
+    const int bb = (int)(bm / m), mm = (int)(bm - (long long)bb * m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out_ref[((size_t)bb * C + c0 + e) * m + mm] = best[e];
+  }
+}
+
+// dz lives only at the argmax position of every (bm, c):  dz = g_out[b][c][m] if out > 0.
+// sums[0][c] = sum dz, sums[1][c] = sum dz * yhat  with yhat = (y - mean) * invstd at that position.
+__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m, int s, int C,
+                                                            const bf16_t *__restrict__ Y,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ g_out,
+                                                            const bf16_t *__restrict__ out_pm,
+                                                            const unsigned char *__restrict__ arg,
+                                                            double *__restrict__ sums) {
+  int cgs, rpb, cg, rsub;
+  row_partition(C, cgs, rpb, cg, rsub);
+  float u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rsub < rpb) {
+    float mu[8], is[8];
+    load8f(mean + cg * 8, mu);
+    load8f(invstd + cg * 8, is);
+    for (long long bm = (long long)blockIdx.x * rpb + rsub; bm < BM; bm += (long long)gridDim.x * rpb) {
+      const int bb = (int)(bm / m), mm = (int)(bm - (long long)bb * m);
+      float o[8];
+      unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + cg * 8), o);
+      const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(arg + (size_t)bm * C + cg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = cg * 8 + e;
+        const float g = o[e] > 0.f ? g_out[((size_t)bb * C + c) * m + mm] : 0.f;
+        const int t = (int)((packed >> (8 * e)) & 0xFF);
+        const float y = (float)Y[((size_t)bm * s + t) * C + c];
+        u[e] += g;
+        v[e] = __builtin_fmaf(g, (y - mu[e]) * is[e], v[e]);
+      }
+    }
+  }
+  fold_and_publish<kMaxC>(u, v, cg, rsub, rpb, cgs, C, sums);
+}
+
+// dY[p][c] = a[c] * (dz - S/P - yhat * T/P),  dz = (s == arg ? g_out : 0) masked by out > 0
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, int m, int s, int C, double invP,
+                                                            const bf16_t *__restrict__ Y,
+                                                            const float *__restrict__ a,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const double *__restrict__ sums,
+                                                            const float *__restrict__ g_out,
+                                                            const bf16_t *__restrict__ out_pm,
+                                                            const unsigned char *__restrict__ arg,
+                                                            bf16_t *__restrict__ dY) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long p = q / cpr;
+    const int c0 = (int)(q - p * cpr) * 8;
+    const long long bm = p / s;
+    const int t = (int)(p - bm * s);
+    const int bb = (int)(bm / m), mm = (int)(bm - (long long)bb * m);
+    float y[8], o[8], av[8], mu[8], is[8];
+    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
+    unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + c0), o);
+    load8f(a + c0, av);
+    load8f(mean + c0, mu);
+    load8f(invstd + c0, is);
+    const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(arg + (size_t)bm * C + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      const bool hit = (int)((packed >> (8 * e)) & 0xFF) == t && o[e] > 0.f;
+      const float dz = hit ? g_out[((size_t)bb * C + c) * m + mm] : 0.f;
+      const float yhat = (y[e] - mu[e]) * is[e];
+      const float S = (float)(sums[c] * invP), T = (float)(sums[C + c] * invP);
+      y[e] = av[e] * (dz - S - yhat * T);
+    }
+    *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
+  }
+}
+
+// dense layers:  dz = dX * [a y + b > 0]
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(long long P, int C, const bf16_t *__restrict__ dX,
+                                                          const bf16_t *__restrict__ Y,
+                                                          const float *__restrict__ a,
+                                                          const float *__restrict__ b,
+                                                          const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd,
+                                                          double *__restrict__ sums) {
+  int cgs, rpb, cg, rsub;
+  row_partition(C, cgs, rpb, cg, rsub);
+  float u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rsub < rpb) {
+    float av[8], bv[8], mu[8], is[8];
+    load8f(a + cg * 8, av);
+    load8f(b + cg * 8, bv);
+    load8f(mean + cg * 8, mu);
+    load8f(invstd + cg * 8, is);
+    for (long long p = (long long)blockIdx.x * rpb + rsub; p < P; p += (long long)gridDim.x * rpb) {
+      float y[8], d[8];
+      unpack8(*reinterpret_cast<const uint4 *>(Y + (size_t)p * C + cg * 8), y);
+      unpack8(*reinterpret_cast<const uint4 *>(dX + (size_t)p * C + cg * 8), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dz = __builtin_fmaf(av[e], y[e], bv[e]) > 0.f ? d[e] : 0.f;
+        u[e] += dz;
+        v[e] = __builtin_fmaf(dz, (y[e] - mu[e]) * is[e], v[e]);
+      }
+    }
+  }
+  fold_and_publish<kMaxC>(u, v, cg, rsub, rpb, cgs, C, sums);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long long chunks, int C, double invP,
+                                                          const bf16_t *__restrict__ dX,
+                                                          const bf16_t *__restrict__ Y,
+                                                          const float *__restrict__ a,
+                                                          const float *__restrict__ b,
+                                                          const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd,
+                                                          const double *__restrict__ sums,
+                                                          bf16_t *__restrict__ dY) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const int c0 = (int)(q % cpr) * 8;
+    float y[8], d[8], av[8], bv[8], mu[8], is[8];
+    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
+    unpack8(*reinterpret_cast<const uint4 *>(dX + q * 8), d);
+    load8f(a + c0, av);
+    load8f(b + c0, bv);
+    load8f(mean + c0, mu);
+    load8f(invstd + c0, is);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dz = __builtin_fmaf(av[e], y[e], bv[e]) > 0.f ? d[e] : 0.f;
+      const float yhat = (y[e] - mu[e]) * is[e];
+      const float S = (float)(sums[c0 + e] * invP), T = (float)(sums[C + c0 + e] * invP);
+      y[e] = av[e] * (dz - S - yhat * T);
+    }
+    *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
+  }
+}
+
+// ------------------------------------------------------------------------------- sa_scatter
+// Adjoint of sa_gather: dfeat[b][idx[p]][:] += dX0[p][0..cin);  with coordinate gradients
+// d = dX0[p][cin..cin+3) * inv_r:  dxyz[b][idx[p]] += d,  dcentre[b][m] -= d.
+__global__ __launch_bounds__(256) void sa_scatter_kernel(long long chunks, int n, int m, int s, int cin,
+                                                        int kpad, float inv_r, const int *__restrict__ idx,
+                                                        const bf16_t *__restrict__ dX,
+                                                        float *__restrict__ dfeat, float *__restrict__ dxyz,
+                                                        float *__restrict__ dcentre) {
+  const int cpr = (cin >> 3) + 1;      // feature pieces + the coordinate piece
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long p = q / cpr;
+    const int c8 = (int)(q - p * cpr);
+    const int bm = (int)(p / s);
+    const int b = bm / m;
+    const int k = idx[p];
+    float d[8];
+    unpack8(*reinterpret_cast<const uint4 *>(dX + (size_t)p * kpad + c8 * 8), d);
+    if (c8 * 8 < cin) {
+      if (dfeat) {
+        float *dst = dfeat + ((size_t)b * n + k) * cin + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dst + e, d[e]);
+      }
+    } else if (dxyz) {
+      float *dk = dxyz + ((size_t)b * n + k) * 3;
+      float *dc = dcentre + (size_t)bm * 3;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        atomicAdd(dk + e, d[e] * inv_r);
+        atomicAdd(dc + e, -d[e] * inv_r);
+      }
+    }
+  }
+}
+
+static inline int rows_per_block(int C) {
+  const int rpb = 256 / (C / 8);
+  return rpb > 16 ? 16 : rpb;
+}
+static inline size_t fold_lds_bytes(int C) { return (size_t)2 * rows_per_block(C) * C * sizeof(float); }
+
+static inline int grid_for(long long items, int per_block = 256, int cap = 256 * 16) {
+  long long blocks = (items + per_block - 1) / per_block;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace omnipq
+
+using namespace omnipq;
+
+extern "C" int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, float inv_radius,
+                                const float *xyz, const float *new_xyz, const int *idx, const void *feat_pm,
+                                void *X, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || s < 0 || cin < 0 || (cin % 8) || (kpad % 8) || kpad < cin + 3)
+    return OMNIPQ_EINVAL;
+  const long long P = (long long)b * m * s;
+  if (P == 0) return OMNIPQ_OK;
+  if (!xyz || !new_xyz || !idx || !X || (cin > 0 && !feat_pm)) return OMNIPQ_EINVAL;
+  const long long chunks = P * (kpad / 8);
+  sa_gather_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+      chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const bf16_t *)feat_pm, (bf16_t *)X);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream) {
+  if (P < 0 || C <= 0 || (C % 8) || C > kMaxC || C < 16) return OMNIPQ_EINVAL;
+  if (!Y || !sums) return OMNIPQ_EINVAL;
+  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (P == 0) return OMNIPQ_OK;
+  const int rpb = rows_per_block(C);
+  colstats_kernel<<<grid_for(P, rpb * 32, 1024), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+                                                                                           sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_bn_finalize(int C, double count, const double *sums, const float *gamma,
+                                  const float *beta, float eps, float momentum, float *running_mean,
+                                  float *running_var, float *a, float *b, float *mean, float *invstd,
+                                  void *stream) {
+  if (C <= 0 || !sums || !gamma || !beta || !a || !b || !mean || !invstd) return OMNIPQ_EINVAL;
+  bn_finalize_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, count, sums, gamma, beta, eps, momentum,
+                                                                     running_mean, running_var, a, b, mean,
+                                                                     invstd);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, const float *b, void *X,
+                             void *stream) {
+  if (P < 0 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  if (P == 0) return OMNIPQ_OK;
+  if (!Y || !a || !b || !X) return OMNIPQ_EINVAL;
+  const long long chunks = P * (C / 8);
+  bnrelu_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, C, (const bf16_t *)Y, a, b, (bf16_t *)X);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const float *a, const float *bshift,
+                              float *out_ref, void *out_pm, unsigned char *arg, void *stream) {
+  if (b < 0 || m < 0 || s <= 0 || s > 255 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  const long long items = (long long)b * m * (C / 8);
+  if (items == 0) return OMNIPQ_OK;
+  if (!Y || !a || !bshift || !out_ref || !out_pm || !arg) return OMNIPQ_EINVAL;
+  pool_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, m, s, C, (const bf16_t *)Y, a, bshift, out_ref,
+                                                              (bf16_t *)out_pm, arg);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *Y, const float *mean,
+                                        const float *invstd, const float *g_out, const void *out_pm,
+                                        const unsigned char *arg, double *sums, void *stream) {
+  if (b < 0 || m < 0 || s <= 0 || s > 255 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
+  const long long BM = (long long)b * m;
+  if (!Y || !mean || !invstd || !g_out || !out_pm || !arg || !sums) return OMNIPQ_EINVAL;
+  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (BM == 0) return OMNIPQ_OK;
+  const int rpb = rows_per_block(C);
+  pool_bwd_stats_kernel<<<grid_for(BM, rpb * 8, 1024), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+      BM, m, s, C, (const bf16_t *)Y, mean, invstd, g_out, (const bf16_t *)out_pm, arg, sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions, const void *Y,
+                                        const float *a, const float *mean, const float *invstd,
+                                        const double *sums, const float *g_out, const void *out_pm,
+                                        const unsigned char *arg, void *dY, void *stream) {
+  if (b < 0 || m < 0 || s <= 0 || s > 255 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  const long long chunks = (long long)b * m * s * (C / 8);
+  if (chunks == 0) return OMNIPQ_OK;
+  if (!Y || !a || !mean || !invstd || !sums || !g_out || !out_pm || !arg || !dY) return OMNIPQ_EINVAL;
+  pool_bwd_apply_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+      chunks, m, s, C, 1.0 / total_positions, (const bf16_t *)Y, a, mean, invstd, sums, g_out,
+      (const bf16_t *)out_pm, arg, (bf16_t *)dY);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_bn_bwd_stats(long long P, int C, const void *dX, const void *Y, const float *a,
+                                   const float *b, const float *mean, const float *invstd, double *sums,
+                                   void *stream) {
+  if (P < 0 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
+  if (!dX || !Y || !a || !b || !mean || !invstd || !sums) return OMNIPQ_EINVAL;
+  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (P == 0) return OMNIPQ_OK;
+  const int rpb = rows_per_block(C);
+  bn_bwd_stats_kernel<<<grid_for(P, rpb * 32, 1024), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+      P, C, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_bn_bwd_apply(long long P, int C, double total_positions, const void *dX, const void *Y,
+                                   const float *a, const float *b, const float *mean, const float *invstd,
+                                   const double *sums, void *dY, void *stream) {
+  if (P < 0 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  if (P == 0) return OMNIPQ_OK;
+  if (!dX || !Y || !a || !b || !mean || !invstd || !sums || !dY) return OMNIPQ_EINVAL;
+  const long long chunks = P * (C / 8);
+  bn_bwd_apply_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+      chunks, C, 1.0 / total_positions, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums,
+      (bf16_t *)dY);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, float inv_radius,
+                                 const int *idx, const void *dX, float *dfeat_pm, float *dxyz,
+                                 float *dnew_xyz, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || s < 0 || cin < 0 || (cin % 8) || (kpad % 8) || kpad < cin + 3)
+    return OMNIPQ_EINVAL;
+  const long long P = (long long)b * m * s;
+  if (P == 0) return OMNIPQ_OK;
+  if (!idx || !dX || (dxyz && !dnew_xyz)) return OMNIPQ_EINVAL;
+  const long long chunks = P * (cin / 8 + 1);
+  sa_scatter_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+      chunks, n, m, s, cin, kpad, inv_radius, idx, (const bf16_t *)dX, dfeat_pm, dxyz, dnew_xyz);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

@@ -142,10 +142,27 @@ class PointnetSAModuleVotes(nn.Module):
             return torch.sum(x * rbf.unsqueeze(1), -1) / float(self.nsample)
         raise ValueError(f"unknown pooling {self.pooling!r}")
 
+    def _fused(self, xyz, features):
+        """Run group + MLP + max-pool on the fused HIP kernels (sa_fused.py)?  OMNIPQ_SA=fused|composed
+        forces the choice; by default the fused bf16 stage is used under torch.autocast(bfloat16) and the
+        reference's f32 op-by-op composition otherwise."""
+        mode = os.environ.get("OMNIPQ_SA", "auto")
+        if mode == "composed" or self.ret_unique_cnt:
+            return False
+        import sa_fused
+        if not sa_fused.eligible(self, xyz, features):
+            return False
+        if mode == "fused":
+            return True
+        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         if inds is not None:
             assert inds.shape[1] == self.npoint
         new_xyz, inds = _centres(xyz, self.npoint, inds)
+        if self._fused(xyz, features):
+            import sa_fused
+            return new_xyz, sa_fused.run(self, xyz, new_xyz, features), inds
         grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None
         grouped_features, grouped_xyz = grouped[0], grouped[1]

@@ -1,0 +1,286 @@
+"""Fused set-abstraction stage for MI355X: group -> shared MLP (conv1x1 + BatchNorm + ReLU) -> max-pool,
+forward and backward, on hand-written HIP kernels (csrc/sa_stage.hip, gemm_bf16.hip, gemm_tn_bf16.hip)
+reached through the C ABI in include/omnipq_sa.h.
+
+It replaces, for one `PointnetSAModuleVotes`, the chain the reference runs as separate PyTorch ops
+(pointnet2_modules.py:243-257):
+    grouped = QueryAndGroup(...)          (B, 3+C, M, S) f32        pointnet2_utils.py:317-376
+    y = SharedMLP(grouped)                3 x [Conv2d 1x1, BatchNorm2d, ReLU]   pytorch_utils.py:11-36
+    out = max_pool2d(y, [1, S])           (B, C_out, M)
+with the same parameters (`mlp_module.layer{i}.conv.weight`, `...bn.bn.{weight,bias,running_*}`), the
+same training-mode BatchNorm semantics (batch statistics over all B*M*S positions, biased variance for
+normalisation, unbiased for the running estimate, momentum update, SyncBatchNorm all-reduce of the
+statistics when a process group is up) and the same gradients.
+
+Numerics: activations are stored in bf16, every contraction accumulates in f32 on the MFMA units,
+statistics are f32 per block / f64 across blocks.  This is the `bf16` compute mode of bench.py; the f32
+parity mode keeps the reference's op-by-op composition (pointnet2_modules.py).
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+import pointnet2_utils
+
+_ext = pointnet2_utils._load_ext()      # always the product binding, whatever pointnet2_utils._ext is
+_lib = _ext._lib
+_lib.omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _call(fn, anchor, *args):
+    _ext._run(fn, anchor, *args)
+
+
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _allreduce_(sums):
+    if _world() > 1:
+        dist.all_reduce(sums)
+    return sums
+
+
+def _round_up(x, q):
+    return (x + q - 1) // q * q
+
+
+def _gemm_nt(A, B, M, N, K):
+    """bf16 C[M][N] = A[M][K] B[N][K]^T"""
+    C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
+    _call(_lib.omnipq_gemm_nt_bf16, A, M, N, K, _p(A), K, _p(B), K, _p(C), N)
+    return C
+
+
+def _gemm_tn(A, B, M, N, P):
+    """f32 C[M][N] = A[P][M]^T B[P][N]"""
+    C = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=A.device, dtype=torch.float32)
+    _call(_lib.omnipq_gemm_tn_bf16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
+    return C
+
+
+class _Layer:
+    """Per-layer constants and saved tensors of one conv+BN+ReLU."""
+    __slots__ = ("K", "C", "Wp", "Wt", "a", "b", "mean", "invstd", "Y", "X")
+
+
+class FusedSAStage(torch.autograd.Function):
+    """forward(xyz, new_xyz, features|None, idx, radius, normalize_xyz, training, bn_cfg, *params)
+
+    params = (W_0, gamma_0, beta_0, W_1, ...); bn_cfg = list of (running_mean, running_var,
+    num_batches_tracked, momentum, eps) per layer.  Returns (B, C_last, M) f32.
+    """
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg, *params):
+        dev = xyz.device
+        B, N, _ = xyz.shape
+        M, S = idx.shape[1], idx.shape[2]
+        P = B * M * S
+        L = len(params) // 3
+        cin = 0 if features is None else features.shape[1]
+        kpad = _round_up(cin + 3, 32)
+        inv_r = (1.0 / radius) if normalize_xyz else 1.0
+        world = _world() if training else 1
+
+        feat_pm = None
+        if features is not None:
+            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()    # [B][N][cin]
+        xyz_c = xyz.detach().contiguous()
+        cen_c = new_xyz.detach().contiguous()
+        X = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
+        _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
+              _p(idx), _p(feat_pm), _p(X))
+
+        layers = []
+        X0 = X
+        for l in range(L):
+            W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+            rm, rv, nbt, momentum, eps = bn_cfg[l]
+            lay = _Layer()
+            W2 = W.detach().reshape(W.shape[0], -1)
+            cout = W2.shape[0]
+            if l == 0:
+                # the reference concatenates [xyz(3), features(cin)] (pointnet2_utils.py:357-359); the
+                # gathered rows are [features(cin), xyz(3), 0-pad] so that feature pieces stay 16-byte
+                # aligned -- permute the weight columns to match
+                Wp = torch.zeros((cout, kpad), device=dev, dtype=torch.float32)
+                Wp[:, :cin] = W2[:, 3:]
+                Wp[:, cin:cin + 3] = W2[:, :3]
+                K = kpad
+            else:
+                Wp = W2
+                K = W2.shape[1]
+            lay.K, lay.C = K, cout
+            lay.Wp = Wp.to(torch.bfloat16).contiguous()
+            lay.Y = _gemm_nt(X, lay.Wp, P, cout, K)
+            if training:
+                sums = torch.empty((2, cout), device=dev, dtype=torch.float64)
+                _call(_lib.omnipq_colstats, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(sums))
+                _allreduce_(sums)
+                lay.a = torch.empty(cout, device=dev)
+                lay.b = torch.empty(cout, device=dev)
+                lay.mean = torch.empty(cout, device=dev)
+                lay.invstd = torch.empty(cout, device=dev)
+                _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(P) * world), _p(sums),
+                      _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                      _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd))
+                if nbt is not None:
+                    nbt += 1
+            else:
+                lay.invstd = torch.rsqrt(rv + eps)
+                lay.mean = rm
+                lay.a = (gamma.detach() * lay.invstd).contiguous()
+                lay.b = (beta.detach() - rm * lay.a).contiguous()
+            if l < L - 1:
+                lay.X = torch.empty_like(lay.Y)
+                _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(lay.a), _p(lay.b),
+                      _p(lay.X))
+                X = lay.X
+            else:
+                lay.X = None
+            layers.append(lay)
+
+        last = layers[-1]
+        out = torch.empty((B, last.C, M), device=dev, dtype=torch.float32)
+        out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+        arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
+        _call(_lib.omnipq_sa_pool, X, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out), _p(out_pm),
+              _p(arg))
+
+        ctx.layers = layers
+        ctx.X0 = X0
+        ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
+        ctx.idx = idx
+        ctx.out_pm, ctx.arg = out_pm, arg
+        ctx.has_features = features is not None
+        ctx.feat_dtype = features.dtype if features is not None else None
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        if not ctx.training:
+            raise RuntimeError("FusedSAStage: backward in eval mode is not supported (use the composed path)")
+        B, N, M, S, P, cin, kpad, inv_r, world = ctx.geom
+        layers = ctx.layers
+        L = len(layers)
+        dev = g_out.device
+        g_out = g_out.contiguous().float()
+        total = ctypes.c_double(float(P) * world)
+        grads = [None] * (3 * L)
+
+        last = layers[-1]
+        sums = torch.empty((2, last.C), device=dev, dtype=torch.float64)
+        _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
+              _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
+        local = sums.clone() if world > 1 else sums
+        _allreduce_(sums)
+        grads[3 * (L - 1) + 1] = local[1].float()      # dgamma = sum dz * yhat   (local, DDP averages)
+        grads[3 * (L - 1) + 2] = local[0].float()      # dbeta  = sum dz
+        dY = torch.empty_like(last.Y)
+        _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
+              _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
+
+        d_feat = d_xyz = d_cen = None
+        for l in range(L - 1, -1, -1):
+            lay = layers[l]
+            Xin = layers[l - 1].X if l > 0 else ctx.X0
+            dWp = _gemm_tn(dY, Xin, lay.C, lay.K, P)                        # [Cout][K]
+            if l == 0:
+                dW = torch.empty((lay.C, cin + 3), device=dev, dtype=torch.float32)
+                dW[:, 3:] = dWp[:, :cin]
+                dW[:, :3] = dWp[:, cin:cin + 3]
+            else:
+                dW = dWp
+            grads[3 * l] = dW.reshape(lay.C, -1, 1, 1)
+            need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \
+                (ctx.has_features and ctx.needs_input_grad[2])
+            if l == 0 and not need_in:
+                break
+            Wt = lay.Wp.t().contiguous()                                    # [K][Cout]
+            dX = _gemm_nt(dY, Wt, P, lay.K, lay.C)
+            if l > 0:
+                prev = layers[l - 1]
+                sums = torch.empty((2, prev.C), device=dev, dtype=torch.float64)
+                _call(_lib.omnipq_bn_bwd_stats, dX, ctypes.c_longlong(P), prev.C, _p(dX), _p(prev.Y), _p(prev.a),
+                      _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums))
+                local = sums.clone() if world > 1 else sums
+                _allreduce_(sums)
+                grads[3 * (l - 1) + 1] = local[1].float()
+                grads[3 * (l - 1) + 2] = local[0].float()
+                _call(_lib.omnipq_bn_bwd_apply, dX, ctypes.c_longlong(P), prev.C, total, _p(dX), _p(prev.Y),
+                      _p(prev.a), _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums), _p(dX))
+                dY = dX
+            else:
+                want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+                dfeat_pm = torch.zeros((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
+                    else None
+                if want_xyz:
+                    d_xyz = torch.zeros((B, N, 3), device=dev)
+                    d_cen = torch.zeros((B, M, 3), device=dev)
+                _call(_lib.omnipq_sa_scatter, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(ctx.idx),
+                      _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
+                if dfeat_pm is not None:
+                    d_feat = dfeat_pm.transpose(1, 2).contiguous().to(ctx.feat_dtype)
+        ctx.layers = None
+        return (d_xyz, d_cen, d_feat, None, None, None, None, None, *grads)
+
+
+def _bn_of(layer):
+    """Conv2d wrapper (pytorch_utils._ConvBase) -> (conv, bn) or None if it is not conv+BN+ReLU."""
+    conv = getattr(layer, "conv", None)
+    bnw = getattr(layer, "bn", None)
+    act = getattr(layer, "activation", None)
+    if conv is None or bnw is None or not isinstance(act, torch.nn.ReLU):
+        return None
+    bn = getattr(bnw, "bn", None)
+    if bn is None or conv.bias is not None or conv.kernel_size != (1, 1):
+        return None
+    if not isinstance(bn, (torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm)):
+        return None
+    if bn.weight is None or bn.running_mean is None or bn.momentum is None:
+        return None
+    return conv, bn
+
+
+def eligible(module, xyz, features):
+    """Can `module` (a PointnetSAModuleVotes) run its group+MLP+pool on the fused kernels?"""
+    if not xyz.is_cuda or module.npoint is None or module.pooling != "max":
+        return False
+    grouper = module.grouper
+    if getattr(grouper, "sample_uniformly", False) or not getattr(grouper, "use_xyz", True):
+        return False
+    if module.nsample > 255 or len(module.mlp_module) == 0:
+        return False
+    if features is not None and (features.shape[1] % 8):
+        return False
+    for layer in module.mlp_module:
+        got = _bn_of(layer)
+        if got is None:
+            return False
+        conv, _ = got
+        # widths are contraction lengths of the data-gradient GEMM: multiples of the 32-wide K step
+        if conv.out_channels % 32 or conv.out_channels > 640:
+            return False
+    if not module.training and torch.is_grad_enabled():
+        return False
+    return True
+
+
+def run(module, xyz, new_xyz, features):
+    """ball query + fused stage -> (B, C_out, npoint) f32"""
+    idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
+    params, bn_cfg = [], []
+    for layer in module.mlp_module:
+        conv, bn = _bn_of(layer)
+        params += [conv.weight, bn.weight, bn.bias]
+        bn_cfg.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
+    return FusedSAStage.apply(xyz, new_xyz, features, idx, float(module.radius), bool(module.normalize_xyz),
+                              bool(module.training), bn_cfg, *params)

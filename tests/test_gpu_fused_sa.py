@@ -1,0 +1,160 @@
+"""GPU: the fused bf16 set-abstraction stage (sa_fused.py + csrc/sa_stage.hip, gemm_*.hip) against
+f32 PyTorch references of the same operators.
+
+Tolerances here are bf16 tolerances and say so: operands and stored activations have an 8-bit
+mantissa (relative step 2^-8 = 3.9e-3), accumulation is f32.  The 1e-4 parity bar of the
+north star applies to the f32 mode (test_gpu_parity.py); this file checks that the bf16 stage computes
+the same function -- forward, every gradient, BatchNorm running statistics.
+"""
+import ctypes
+import os
+
+import pytest
+import torch
+
+import capi
+import synth
+from procedural import load_procedural, procedural_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm()) / (float(b.norm()) + 1e-30)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 136, 96), (4096, 256, 128), (1000, 288, 320),
+                                   (77, 16, 544), (2048, 512, 256)])
+def test_gemm_nt_matches_torch(M, N, K):
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+    B = torch.randn((N, K), generator=gen).to(torch.bfloat16).to(dev())     # asymmetric, random
+    C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N)
+    want = A.float() @ B.float().t()
+    assert torch.isfinite(C.float()).all()
+    # bf16 output rounding: half a step of 2^-8 relative to each element, plus f32 accumulation noise
+    assert float((C.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    assert rel_l2(C.float(), want) < 3e-3
+
+
+@pytest.mark.parametrize("P,M,N", [(32, 128, 128), (1000, 72, 40), (8192, 256, 128), (5000, 288, 320),
+                                   (333, 16, 544)])
+def test_gemm_tn_matches_torch(P, M, N):
+    gen = torch.Generator().manual_seed(P + M + N)
+    A = torch.randn((P, M), generator=gen).to(torch.bfloat16).to(dev())
+    B = torch.randn((P, N), generator=gen).to(torch.bfloat16).to(dev())
+    C = torch.full((M, N), float("nan"), device=dev())
+    capi.lib().omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
+    ws = torch.empty(int(capi.lib().omnipq_gemm_tn_workspace_floats(M, N, P)), device=dev())
+    capi.ok("omnipq_gemm_tn_bf16", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C), capi.P(ws))
+    want = A.float().t() @ B.float()
+    assert rel_l2(C, want) < 1e-5          # exact bf16 products, f32 accumulation: only summation order differs
+
+
+def _sa_pair(spec, seed):
+    import pointnet2_modules
+    mods = []
+    for _ in range(2):
+        m = pointnet2_modules.PointnetSAModuleVotes(mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"})
+        load_procedural(m, seed)
+        mods.append(m.to(dev()).train())
+    return mods
+
+
+SA_SPECS = [
+    # sa1-like: no input features
+    (dict(npoint=512, radius=0.3, nsample=64, mlp=[0, 64, 64, 128], use_xyz=True, normalize_xyz=True), 4096, 0),
+    # sa2-like: 32 nsample, wide
+    (dict(npoint=256, radius=0.4, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True, normalize_xyz=True), 2048, 128),
+    # vote-aggregation-like: 288 channels (not a multiple of the 128-wide tile), 16 nsample
+    (dict(npoint=128, radius=0.5, nsample=16, mlp=[288, 288, 288, 288], use_xyz=True, normalize_xyz=True), 1024, 288),
+    # two-layer MLP, un-normalised xyz
+    (dict(npoint=64, radius=0.6, nsample=16, mlp=[16, 32, 64], use_xyz=True, normalize_xyz=False), 512, 16),
+]
+
+
+@pytest.mark.parametrize("spec,n,cin", SA_SPECS)
+def test_fused_sa_stage_matches_f32_composition(spec, n, cin, monkeypatch):
+    B = 2
+    xyz = synth.make_clouds(41, B, n, kind="room").to(dev())
+    feats = None
+    if cin:
+        feats = procedural_tensor("fused.feats", (B, cin, n), torch.float32).to(dev())
+    import pointnet2_modules
+    ref_mod, fus_mod = _sa_pair(spec, seed=3)
+    amp_mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
+        mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}), 3).to(dev()).train()
+    want_xyz = xyz.clone().requires_grad_(True)        # gradients w.r.t. coordinates (vote aggregation)
+    got_xyz = xyz.clone().requires_grad_(True)
+    amp_xyz = xyz.clone().requires_grad_(True)
+    want_f = None if feats is None else feats.clone().requires_grad_(True)
+    got_f = None if feats is None else feats.clone().requires_grad_(True)
+    amp_f = None if feats is None else feats.clone().requires_grad_(True)
+
+    monkeypatch.setenv("OMNIPQ_SA", "composed")
+    w_new_xyz, w_out, w_inds = ref_mod(want_xyz, want_f)               # f32 op-by-op: the yardstick
+    with torch.autocast("cuda", dtype=torch.bfloat16):                  # PyTorch's own bf16 path
+        _, a_out, _ = amp_mod(amp_xyz, amp_f)
+    monkeypatch.setenv("OMNIPQ_SA", "fused")
+    g_new_xyz, g_out, g_inds = fus_mod(got_xyz, got_f)
+    assert torch.equal(w_inds, g_inds) and torch.equal(w_new_xyz, g_new_xyz)
+    assert g_out.dtype == torch.float32 and g_out.shape == w_out.shape
+    assert rel_l2(g_out, w_out) < 2e-2, rel_l2(g_out, w_out)
+
+    g_up = procedural_tensor("fused.g_up", tuple(w_out.shape), torch.float32).to(dev())
+    w_out.backward(g_up)
+    g_out.backward(g_up)
+    a_out.float().backward(g_up)
+
+    def ok(name, got, amp, want, floor):
+        """bf16 gradients are sums of ~1e5 quantised signed terms: demand the fused stage be no further
+        from the f32 result than `floor`, or than twice what PyTorch's bf16 autocast path manages."""
+        e_got, e_amp = rel_l2(got, want), rel_l2(amp, want)
+        assert e_got < max(floor, 2.0 * e_amp), (name, e_got, e_amp)
+
+    for (k, pw), (_, pg), (_, pa) in zip(ref_mod.named_parameters(), fus_mod.named_parameters(),
+                                         amp_mod.named_parameters()):
+        assert pg.grad is not None and pg.grad.shape == pw.grad.shape, k
+        ok(k, pg.grad, pa.grad, pw.grad, 6e-2)
+    if feats is not None:
+        ok("features", got_f.grad, amp_f.grad, want_f.grad, 6e-2)
+    ok("xyz", got_xyz.grad, amp_xyz.grad, want_xyz.grad, 8e-2)
+    for (k, bw), (_, bg) in zip(ref_mod.named_buffers(), fus_mod.named_buffers()):
+        if bw.is_floating_point():
+            assert rel_l2(bg, bw) < 1e-2, k
+        else:
+            assert torch.equal(bg, bw), k       # num_batches_tracked
+
+
+def test_fused_sa_eval_mode_uses_running_statistics(monkeypatch):
+    spec, n, cin = SA_SPECS[1]
+    xyz = synth.make_clouds(43, 2, n, kind="room").to(dev())
+    feats = procedural_tensor("fused.feats", (2, cin, n), torch.float32).to(dev())
+    ref_mod, fus_mod = _sa_pair(spec, seed=5)
+    ref_mod.eval()
+    fus_mod.eval()
+    with torch.no_grad():
+        monkeypatch.setenv("OMNIPQ_SA", "composed")
+        _, w_out, _ = ref_mod(xyz, feats)
+        monkeypatch.setenv("OMNIPQ_SA", "fused")
+        _, g_out, _ = fus_mod(xyz, feats)
+    assert rel_l2(g_out, w_out) < 2e-2
+
+
+def test_fused_stage_is_selected_under_bf16_autocast_only(monkeypatch):
+    import pointnet2_modules
+    monkeypatch.delenv("OMNIPQ_SA", raising=False)
+    spec, n, cin = SA_SPECS[0]
+    mod = pointnet2_modules.PointnetSAModuleVotes(mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}).to(dev())
+    xyz = synth.make_clouds(44, 1, n, kind="room").to(dev())
+    assert not mod._fused(xyz, None)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert mod._fused(xyz, None)
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert not mod._fused(xyz, None)

@@ -190,7 +190,7 @@ def run_model_case(fx, device="cpu", tol=1e-5, grad_tol=1e-3, forced=False):
         elif forced and ("ep64." + k) in out:
             # measured against the float64 evaluation of the reference; the allowance is what the
             # reference's own f32 arithmetic needs on this tensor (never less than `tol`)
-            check_summary(v, out["ep64." + k], k, max(tol, 4.0 * out["f32_vs_f64." + k]))
+            check_summary(v, out["ep64." + k], k, max(tol, 6.0 * out["f32_vs_f64." + k]))
         else:
             check_summary(v, out["ep." + k], k, tol)
     if train:
