@@ -29,6 +29,14 @@ int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, float inv_ra
 int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const int *idx,
                       const void *dX, float *dfeat_pm, float *dxyz, float *dnew_xyz, void *stream);
 
+/* CSR of "which grouped positions read point k": offsets (b, n+1) i32, order (b, m*s) i32 (position
+ * index within the scene); scratch: b*n ints.  Lets the adjoint of the gather run without atomics. */
+int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, int *offsets, int *order, int *scratch,
+                        void *stream);
+int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const int *offsets,
+                          const int *order, const void *dX, float *dfeat_pm, float *dxyz, float *dnew_xyz,
+                          void *stream);
+
 /* C[M][N] (bf16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */
 int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                         void *stream);
@@ -50,11 +58,13 @@ int omnipq_bn_finalize(int C, double count, const double *sums, const float *gam
 /* X = relu(a * Y + b) */
 int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, const float *b, void *X, void *stream);
 
-/* out[b][c][j] = max_s relu(a Y[(b,j,s)][c] + b) -> out_ref (b,C,m) f32, out_pm [b*m][C] bf16, arg u8 */
+/* out[(b,j)][c] = max_s relu(a Y[(b,j,s)][c] + b) -> out_f32 [b*m][C] f32 and out_pm [b*m][C] bf16
+ * (both position-major), arg [b*m][C] u8 = first s attaining the maximum */
 int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const float *a, const float *bshift,
-                   float *out_ref, void *out_pm, unsigned char *arg, void *stream);
+                   float *out_f32, void *out_pm, unsigned char *arg, void *stream);
 
-/* backward of pool + last BatchNorm, in two phases so a cross-rank all-reduce of `sums` can sit between */
+/* backward of pool + last BatchNorm, in two phases so a cross-rank all-reduce of `sums` can sit between;
+ * g_out is position-major f32 [b*m][C] */
 int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *Y, const float *mean, const float *invstd,
                              const float *g_out, const void *out_pm, const unsigned char *arg, double *sums,
                              void *stream);

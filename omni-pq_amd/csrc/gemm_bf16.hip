@@ -67,19 +67,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   const int wm = wave >> 1, wn = wave & 1;
 
   // staging assignment: chunk q = tid + i*256 -> row q>>2, 16-byte piece q&3
+  // Rows past M (or N) are clamped to the last valid row instead of being zero-filled: whatever they
+  // contribute lands in C rows / columns that are never stored, and the loads stay unconditional
+  // 16-byte loads (a select against zero makes hipcc split them into predicated dword loads).
   int srow[2], skc[2];
   const bf16_t *ga[2], *gb[2];
-  bool aok[2], bok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int q = tid + i * 256;
     srow[i] = q >> 2;
     skc[i] = q & 3;
-    const int ar = m0 + srow[i], br = n0 + srow[i];
-    aok[i] = ar < g.M;
-    bok[i] = br < g.N;
-    ga[i] = A + (size_t)(aok[i] ? ar : 0) * g.lda + kbeg + skc[i] * 8;
-    gb[i] = B + (size_t)(bok[i] ? br : 0) * g.ldb + kbeg + skc[i] * 8;
+    int ar = m0 + srow[i], br = n0 + srow[i];
+    ar = ar < g.M ? ar : g.M - 1;
+    br = br < g.N ? br : g.N - 1;
+    ga[i] = A + (size_t)ar * g.lda + kbeg + skc[i] * 8;
+    gb[i] = B + (size_t)br * g.ldb + kbeg + skc[i] * 8;
   }
 
   f32x16 acc[2][2];
@@ -91,14 +93,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   uint4 ra[2], rb[2];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   auto load_tiles = [&](int kt) {
-    const int koff = kt * GBK;
-    const bool kin = kbeg + koff + 0 < kend;   // whole K-steps only (K is a multiple of GBK)
+    const int koff = kt * GBK;     // whole K-steps only: K and k_chunk are multiples of GBK
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ra[i] = (aok[i] && kin) ? ldg16(ga[i] + koff) : zero4;
-      rb[i] = (bok[i] && kin) ? ldg16(gb[i] + koff) : zero4;
+      ra[i] = ldg16(ga[i] + koff);
+      rb[i] = ldg16(gb[i] + koff);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -167,16 +167,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
     }
   } else {
-    bf16_t *ct = reinterpret_cast<bf16_t *>(smem);
+    // Pack column pairs before touching LDS: lanes (2t, 2t+1) hold columns (c, c+1) of the same rows, so
+    // they trade one value per row pair (quad_perm swap on the DPP network): the even lane ends up with
+    // (c, c+1) of row r, the odd lane with (c-1, c) of row r+1 -> 32 ds_write_b32 instead of 64 b16.
+    unsigned *ct32 = reinterpret_cast<unsigned *>(smem);
+    const bool odd = lane & 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
-          ct[row * GCPITCH + wn * 64 + j * 32 + ccol] = (bf16_t)acc[i][j][r];
+        for (int r = 0; r < 16; r += 2) {
+          const float mine0 = acc[i][j][r], mine1 = acc[i][j][r + 1];
+          const float give = odd ? mine0 : mine1;
+          const float got = __builtin_bit_cast(
+              float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+          const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
+          const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
+                                  ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0 + (odd ? 1 : 0);
+          const int col = wn * 64 + j * 32 + (ccol & ~1);
+          ct32[(row * GCPITCH + col) >> 1] = packed;
         }
+    const bf16_t *ct = reinterpret_cast<const bf16_t *>(smem);
     __syncthreads();
     bf16_t *C = reinterpret_cast<bf16_t *>(Cout);
     for (int q = tid; q < 128 * 16; q += 256) {

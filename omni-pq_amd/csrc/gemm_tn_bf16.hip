@@ -74,15 +74,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Unconditional 16-byte loads from clamped addresses, then an AND mask for positions past the slab
+  // (those must contribute zero to the contraction).  A ?: against zero would be split by hipcc into
+  // predicated dword loads.  Channel pieces past M / N only feed C entries that are never stored.
   uint4 ra[2], rb[2];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  int acol[2], bcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    acol[i] = aok[i] ? m0 + sc8[i] * 8 : 0;
+    bcol[i] = bok[i] ? n0 + sc8[i] * 8 : 0;
+  }
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = pbeg + kt * TBK + spos[i];
-      const bool pin = p < pend;
-      ra[i] = (pin && aok[i]) ? *reinterpret_cast<const uint4 *>(A + (size_t)p * g.lda + m0 + sc8[i] * 8) : zero4;
-      rb[i] = (pin && bok[i]) ? *reinterpret_cast<const uint4 *>(B + (size_t)p * g.ldb + n0 + sc8[i] * 8) : zero4;
+      const unsigned keep = p < pend ? 0xFFFFFFFFu : 0u;
+      const int pc = p < pend ? p : g.P - 1;
+      ra[i] = *reinterpret_cast<const uint4 *>(A + (size_t)pc * g.lda + acol[i]);
+      rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)pc * g.ldb + bcol[i]);
+      ra[i].x &= keep; ra[i].y &= keep; ra[i].z &= keep; ra[i].w &= keep;
+      rb[i].x &= keep; rb[i].y &= keep; rb[i].z &= keep; rb[i].w &= keep;
     }
   };
   auto store_tiles = [&](int buf) {
@@ -159,13 +170,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
   }
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_kernel(int n, int slabs, const float *__restrict__ part,
-                                                         float *__restrict__ out) {
+// out[g][i] = sum over slabs z == g (mod groups) of part[z][i], four floats per lane, eight loads in
+// flight per lane.  Two passes (slabs -> kReduceGroups -> 1) keep every pass wide enough to fill the
+// chip while the summation order stays fixed (deterministic, no atomics).
+constexpr int kReduceGroups = 16;
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int groups,
+                                                         const f32x4 *__restrict__ part,
+                                                         f32x4 *__restrict__ out) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < slabs; ++z) s += part[(size_t)z * n + i];
-  out[i] = s;
+  if (i >= n4) return;
+  const int gidx = (int)blockIdx.y;
+  f32x4 acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int z = gidx;
+  for (; z + 7 * groups < slabs; z += 8 * groups) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(z + u * groups) * n4 + i];
+  }
+  for (; z < slabs; z += groups) acc[0] += part[(size_t)z * n4 + i];
+  out[(size_t)gidx * n4 + i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 }  // namespace omnipq
@@ -179,7 +204,7 @@ extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
   const int max_slabs = (P + TBK - 1) / TBK;
   if (slabs > max_slabs) slabs = max_slabs;
   if (slabs < 1) slabs = 1;
-  return (long long)slabs * M * N;
+  return (long long)(slabs + kReduceGroups) * M * N;
 }
 
 extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
@@ -199,8 +224,19 @@ extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, 
   dim3 grid(tiles, used);
   gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace);
   OMNIPQ_LAUNCH_CHECK();
-  const int n = M * N;
-  slab_reduce_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, used, workspace, C);
+  const int n4 = M * N / 4;        // M, N multiples of 8
+  const f32x4 *part = reinterpret_cast<const f32x4 *>(workspace);
+  f32x4 *mid = reinterpret_cast<f32x4 *>(workspace + (size_t)slabs * M * N);
+  if (used > 2 * kReduceGroups) {
+    slab_reduce_kernel<<<dim3((n4 + 255) / 256, kReduceGroups), 256, 0, (hipStream_t)stream>>>(n4, used, kReduceGroups,
+                                                                                           part, mid);
+    OMNIPQ_LAUNCH_CHECK();
+    slab_reduce_kernel<<<dim3((n4 + 255) / 256, 1), 256, 0, (hipStream_t)stream>>>(n4, kReduceGroups, 1, mid,
+                                                                               reinterpret_cast<f32x4 *>(C));
+  } else {
+    slab_reduce_kernel<<<dim3((n4 + 255) / 256, 1), 256, 0, (hipStream_t)stream>>>(n4, used, 1, part,
+                                                                               reinterpret_cast<f32x4 *>(C));
+  }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -184,9 +184,10 @@ __global__ __launch_bounds__(256) void bnrelu_kernel(long long chunks, int C, co
 
 // ------------------------------------------------------------------------------- pooling
 // out[bm][c] = max_s relu(a Y[(bm,s)][c] + b); arg = first s reaching it.  One lane per (bm, 8 ch).
+// Outputs are position-major ([b*m][C]); g_out of the backward kernels likewise.
 __global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s, int C,
                                                   const bf16_t *__restrict__ Y, const float *__restrict__ a,
-                                                  const float *__restrict__ b, float *__restrict__ out_ref,
+                                                  const float *__restrict__ b, float *__restrict__ out_f32,
                                                   bf16_t *__restrict__ out_pm, unsigned char *__restrict__ arg) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s
 #pragma unroll
     for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(bi[e] & 0xFF) << (8 * e);
     *reinterpret_cast<unsigned long long *>(arg + (size_t)bm * C + c0) = packed;
-    const int bb = (int)(bm / m), mm = (int)(bm - (long long)bb * m);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) out_ref[((size_t)bb * C + c0 + e) * m + mm] = best[e];
+    float *o = out_f32 + (size_t)bm * C + c0;       // position-major f32; the caller transposes
+    *reinterpret_cast<float4 *>(o) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(best[4], best[5], best[6], best[7]);
   }
 }
 
@@ -237,14 +238,14 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m
     load8f(mean + cg * 8, mu);
     load8f(invstd + cg * 8, is);
     for (long long bm = (long long)blockIdx.x * rpb + rsub; bm < BM; bm += (long long)gridDim.x * rpb) {
-      const int bb = (int)(bm / m), mm = (int)(bm - (long long)bb * m);
-      float o[8];
+      float o[8], gg[8];
       unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + cg * 8), o);
+      load8f(g_out + (size_t)bm * C + cg * 8, gg);
       const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(arg + (size_t)bm * C + cg * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = cg * 8 + e;
-        const float g = o[e] > 0.f ? g_out[((size_t)bb * C + c) * m + mm] : 0.f;
+        const float g = o[e] > 0.f ? gg[e] : 0.f;
         const int t = (int)((packed >> (8 * e)) & 0xFF);
         const float y = (float)Y[((size_t)bm * s + t) * C + c];
         u[e] += g;
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, i
     const int c0 = (int)(q - p * cpr) * 8;
     const long long bm = p / s;
     const int t = (int)(p - bm * s);
-    const int bb = (int)(bm / m), mm = (int)(bm - (long long)bb * m);
-    float y[8], o[8], av[8], mu[8], is[8];
+    float y[8], o[8], av[8], mu[8], is[8], gg[8];
+    load8f(g_out + (size_t)bm * C + c0, gg);
     unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
     unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + c0), o);
     load8f(a + c0, av);
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, i
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + e;
       const bool hit = (int)((packed >> (8 * e)) & 0xFF) == t && o[e] > 0.f;
-      const float dz = hit ? g_out[((size_t)bb * C + c) * m + mm] : 0.f;
+      const float dz = hit ? gg[e] : 0.f;
       const float yhat = (y[e] - mu[e]) * is[e];
       const float S = (float)(sums[c] * invP), T = (float)(sums[C + c] * invP);
       y[e] = av[e] * (dz - S - yhat * T);
@@ -390,6 +391,107 @@ __global__ __launch_bounds__(256) void sa_scatter_kernel(long long chunks, int n
   }
 }
 
+// ---- deterministic-traffic adjoint of the gather: bucket the positions by source point once ----
+// counts[b][k] = #positions p of scene b with idx[p] == k
+__global__ __launch_bounds__(256) void csr_count_kernel(long long P, int n, int ms, const int *__restrict__ idx,
+                                                       int *__restrict__ counts) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256)
+    atomicAdd(counts + (size_t)(p / ms) * n + idx[p], 1);
+}
+
+// offsets[b][0..n] = exclusive prefix sum of counts[b][:]; cursor[b][k] = offsets[b][k] (consumed by fill)
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int n, const int *__restrict__ counts,
+                                                       int *__restrict__ offsets, int *__restrict__ cursor) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int b = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int k = base + tid;
+    const int v = k < n ? counts[(size_t)b * n + k] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int wo = 0;
+    for (int w = 0; w < wave; ++w) wo += wsum[w];
+    const int excl = carry + wo + x - v;
+    if (k < n) {
+      offsets[(size_t)b * (n + 1) + k] = excl;
+      cursor[(size_t)b * n + k] = excl;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) offsets[(size_t)b * (n + 1) + n] = carry;
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(long long P, int n, int ms, const int *__restrict__ idx,
+                                                      int *__restrict__ cursor, int *__restrict__ order) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
+    const int b = (int)(p / ms);
+    const int slot = atomicAdd(cursor + (size_t)b * n + idx[p], 1);
+    order[(size_t)b * ms + slot] = (int)(p - (long long)b * ms);
+  }
+}
+
+// dfeat[b][k][c0..c0+8) = sum over the bucket of dX[p][c0..c0+8)   (one lane per (b, k, 8 channels));
+// the lane of the coordinate piece accumulates dxyz[b][k] = inv_r * sum dX[p][cin..cin+3).
+__global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, int n, int ms, int cin, int kpad,
+                                                            float inv_r, const int *__restrict__ offsets,
+                                                            const int *__restrict__ order,
+                                                            const bf16_t *__restrict__ dX,
+                                                            float *__restrict__ dfeat, float *__restrict__ dxyz) {
+  const int cpr = (cin >> 3) + 1;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bk = q / cpr;
+    const int c8 = (int)(q - bk * cpr);
+    const int b = (int)(bk / n), k = (int)(bk - (long long)b * n);
+    const bool coord = c8 * 8 >= cin;
+    if (coord ? dxyz == nullptr : dfeat == nullptr) continue;
+    const int beg = offsets[(size_t)b * (n + 1) + k], end = offsets[(size_t)b * (n + 1) + k + 1];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = beg; t < end; ++t) {
+      const size_t p = (size_t)b * ms + order[(size_t)b * ms + t];
+      float d[8];
+      unpack8(*reinterpret_cast<const uint4 *>(dX + p * kpad + c8 * 8), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += d[e];
+    }
+    if (!coord) {
+      float *dst = dfeat + (size_t)bk * cin + c8 * 8;
+      *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+      float *dst = dxyz + (size_t)bk * 3;
+      dst[0] = acc[0] * inv_r; dst[1] = acc[1] * inv_r; dst[2] = acc[2] * inv_r;
+    }
+  }
+}
+
+// dcentre[b][j] = -inv_r * sum_s dX[(b,j,s)][cin..cin+3)
+__global__ __launch_bounds__(256) void sa_centre_grad_kernel(long long BM, int s, int cin, int kpad, float inv_r,
+                                                            const bf16_t *__restrict__ dX,
+                                                            float *__restrict__ dcentre) {
+  const long long bm = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (bm >= BM) return;
+  float acc[3] = {0, 0, 0};
+  for (int t = 0; t < s; ++t) {
+    float d[8];
+    unpack8(*reinterpret_cast<const uint4 *>(dX + ((size_t)bm * s + t) * kpad + cin), d);
+    acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2];
+  }
+  dcentre[bm * 3 + 0] = -acc[0] * inv_r;
+  dcentre[bm * 3 + 1] = -acc[1] * inv_r;
+  dcentre[bm * 3 + 2] = -acc[2] * inv_r;
+}
+
 static inline int rows_per_block(int C) {
   const int rpb = 256 / (C / 8);
   return rpb > 16 ? 16 : rpb;
@@ -458,12 +560,12 @@ extern "C" int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, 
 }
 
 extern "C" int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const float *a, const float *bshift,
-                              float *out_ref, void *out_pm, unsigned char *arg, void *stream) {
+                              float *out_f32, void *out_pm, unsigned char *arg, void *stream) {
   if (b < 0 || m < 0 || s <= 0 || s > 255 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
   const long long items = (long long)b * m * (C / 8);
   if (items == 0) return OMNIPQ_OK;
-  if (!Y || !a || !bshift || !out_ref || !out_pm || !arg) return OMNIPQ_EINVAL;
-  pool_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, m, s, C, (const bf16_t *)Y, a, bshift, out_ref,
+  if (!Y || !a || !bshift || !out_f32 || !out_pm || !arg) return OMNIPQ_EINVAL;
+  pool_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, m, s, C, (const bf16_t *)Y, a, bshift, out_f32,
                                                               (bf16_t *)out_pm, arg);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -539,5 +641,52 @@ extern "C" int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, 
   sa_scatter_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
       chunks, n, m, s, cin, kpad, inv_radius, idx, (const bf16_t *)dX, dfeat_pm, dxyz, dnew_xyz);
   OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// Buckets the b*m*s grouped positions by source point: offsets (b, n+1) and order (b, m*s) form a CSR
+// of "which positions read point k".  scratch: b*n ints.  Built once per forward, reused by the backward.
+extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, int *offsets, int *order,
+                                   int *scratch, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || s < 0) return OMNIPQ_EINVAL;
+  if (b == 0) return OMNIPQ_OK;
+  if (!idx || !offsets || !order || !scratch) return OMNIPQ_EINVAL;
+  const long long P = (long long)b * m * s;
+  const int ms = m * s;
+  OMNIPQ_HIP(hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)b * n, (hipStream_t)stream));
+  if (P > 0) {
+    csr_count_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, n, ms, idx, scratch);
+    OMNIPQ_LAUNCH_CHECK();
+  }
+  csr_scan_kernel<<<b, 1024, 0, (hipStream_t)stream>>>(n, scratch, offsets, scratch);
+  OMNIPQ_LAUNCH_CHECK();
+  if (P > 0) {
+    csr_fill_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, n, ms, idx, scratch, order);
+    OMNIPQ_LAUNCH_CHECK();
+  }
+  return OMNIPQ_OK;
+}
+
+// adjoint of omnipq_sa_gather without atomics: every (point, 8-channel piece) sums its own bucket.
+// Writes EVERY entry of dfeat_pm / dxyz / dnew_xyz (no zero-fill needed); NULL outputs are skipped.
+extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float inv_radius,
+                                     const int *offsets, const int *order, const void *dX, float *dfeat_pm,
+                                     float *dxyz, float *dnew_xyz, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || s < 0 || cin < 0 || (cin % 8) || (kpad % 8) || kpad < cin + 3)
+    return OMNIPQ_EINVAL;
+  if (b == 0) return OMNIPQ_OK;
+  if (!offsets || !order || !dX || (dxyz && !dnew_xyz)) return OMNIPQ_EINVAL;
+  const long long items = (long long)b * n * (cin / 8 + 1);
+  sa_scatter_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
+      items, n, m * s, cin, kpad, inv_radius, offsets, order, (const bf16_t *)dX, dfeat_pm, dxyz);
+  OMNIPQ_LAUNCH_CHECK();
+  if (dnew_xyz) {
+    const long long BM = (long long)b * m;
+    if (BM > 0) {
+      sa_centre_grad_kernel<<<(int)((BM + 255) / 256), 256, 0, (hipStream_t)stream>>>(BM, s, cin, kpad, inv_radius,
+                                                                                  (const bf16_t *)dX, dnew_xyz);
+      OMNIPQ_LAUNCH_CHECK();
+    }
+  }
   return OMNIPQ_OK;
 }

@@ -31,6 +31,23 @@ from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
 
 
+def conv1x1(x, conv):
+    """A kernel-size-1 Conv1d applied as ONE dense contraction: (C_out, C_in) @ (B, C_in, K) + bias.
+    Same arithmetic as `conv(x)`; going through the GEMM library directly instead of the convolution
+    library saves the layout-shuffling helper kernels the latter launches around every tiny conv."""
+    y = torch.matmul(conv.weight.squeeze(-1), x)
+    return y if conv.bias is None else y + conv.bias.unsqueeze(-1)
+
+
+def fused_heads(net, heads):
+    """Several 1x1 output heads on the same trunk features as one GEMM over the concatenated weights.
+    -> list of (B, K, C_h) tensors (already transposed like the reference's `.transpose(2, 1)`)."""
+    w = torch.cat([h.weight.squeeze(-1) for h in heads], 0)
+    b = torch.cat([h.bias for h in heads], 0)
+    y = (torch.matmul(w, net) + b.unsqueeze(-1)).transpose(2, 1)
+    return list(torch.split(y, [h.out_channels for h in heads], dim=2))
+
+
 class PositionEmbeddingLearned(nn.Module):
     """xyz (B,P,C_in) -> learned embedding (B,288,P): Conv1d, BN, ReLU, Conv1d (reference :17-33)."""
 
@@ -43,7 +60,9 @@ class PositionEmbeddingLearned(nn.Module):
             nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
-        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+        head = self.position_embedding_head
+        x = conv1x1(xyz.transpose(1, 2), head[0])
+        return conv1x1(head[2](head[1](x)), head[3])
 
 
 def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_residuals_normalized,
@@ -74,8 +93,8 @@ def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_r
 
 
 def _trunk(self, net):
-    net = F.relu(self.bn1(self.conv1(net)))
-    return F.relu(self.bn2(self.conv2(net)))
+    net = F.relu(self.bn1(conv1x1(net, self.conv1)))
+    return F.relu(self.bn2(conv1x1(net, self.conv2)))
 
 
 class PredictHead(nn.Module):
@@ -107,13 +126,14 @@ class PredictHead(nn.Module):
 
     def forward(self, net, base_xyz, end_points, prefix):
         net = _trunk(self, net)
-        t = lambda head: head(net).transpose(2, 1)   # noqa: E731  (B,K,*)
-        center = t(self.center_head) + base_xyz
+        obj, ctr, hcls, hres, scls, sres, sem = fused_heads(net, (
+            self.objectness_scores_head, self.center_head, self.heading_class_head,
+            self.heading_residual_head, self.size_class_head, self.size_residual_head,
+            self.sem_cls_scores_head))
+        center = ctr + base_xyz
         end_points, pred_size = decode_scores(
-            base_xyz, t(self.objectness_scores_head), center, t(self.heading_class_head),
-            t(self.heading_residual_head), t(self.size_class_head), t(self.size_residual_head),
-            t(self.sem_cls_scores_head), end_points, self.num_class, self.num_heading_bin,
-            self.num_size_cluster, self._mean_sizes(net.device), prefix)
+            base_xyz, obj, center, hcls, hres, scls, sres.contiguous(), sem, end_points, self.num_class,
+            self.num_heading_bin, self.num_size_cluster, self._mean_sizes(net.device), prefix)
         return center, pred_size, end_points
 
 
@@ -134,11 +154,11 @@ class QuadPredictHead(nn.Module):
 
     def forward(self, net, base_xyz, end_points, prefix):
         net = _trunk(self, net)
-        center = self.center_head(net).transpose(2, 1) + base_xyz
-        normal = self.normal_vector_head(net).transpose(2, 1)
+        scores, ctr, normal, size = fused_heads(net, (self.quad_scores_head, self.center_head,
+                                                      self.normal_vector_head, self.size_head))
+        center = ctr + base_xyz
         normal = normal.div(torch.norm(normal, p=2))
-        size = self.size_head(net).transpose(2, 1)
-        end_points[f'{prefix}quad_scores'] = self.quad_scores_head(net).transpose(2, 1)
+        end_points[f'{prefix}quad_scores'] = scores
         end_points[f'{prefix}quad_center'] = center
         end_points[f'{prefix}normal_vector'] = normal
         end_points[f'{prefix}quad_size'] = size
@@ -222,9 +242,9 @@ class PQ_Transformer(nn.Module):
         base_xyz = center.detach().clone()
         base_xyz_q = center_q.detach().clone()
 
-        query_joint = torch.cat([self.decoder_query_proj(cluster_feature),
-                                 self.quad_decoder_query_proj(quad_feature)], -1)
-        key = self.decoder_key_proj(seed_features)
+        query_joint = torch.cat([conv1x1(cluster_feature, self.decoder_query_proj),
+                                 conv1x1(quad_feature, self.quad_decoder_query_proj)], -1)
+        key = conv1x1(seed_features, self.decoder_key_proj)
         key_pos = seed_xyz
 
         for i in range(self.num_layer):

@@ -9,6 +9,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _conv1x1(x, conv):
+    """kernel-size-1 Conv1d as one dense contraction (see models/pq_transformer.py:conv1x1)."""
+    return torch.matmul(conv.weight.squeeze(-1), x) + conv.bias.unsqueeze(-1)
+
+
 class VotingModule(nn.Module):
     def __init__(self, vote_factor, seed_feature_dim):
         super().__init__()
@@ -25,9 +30,9 @@ class VotingModule(nn.Module):
         """seed_xyz (B,K,3), seed_features (B,C,K) -> vote_xyz (B,K*vf,3), vote_features (B,C,K*vf)"""
         B, K = seed_xyz.shape[0], seed_xyz.shape[1]
         vf, C = self.vote_factor, self.out_dim
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net)                                   # (B, (3+C)*vf, K)
+        net = F.relu(self.bn1(_conv1x1(seed_features, self.conv1)))
+        net = F.relu(self.bn2(_conv1x1(net, self.conv2)))
+        net = _conv1x1(net, self.conv3)                         # (B, (3+C)*vf, K)
         net = net.transpose(2, 1).reshape(B, K, vf, 3 + C)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(B, K * vf, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]

@@ -148,11 +148,12 @@ class FusedSAStage(torch.autograd.Function):
             layers.append(lay)
 
         last = layers[-1]
-        out = torch.empty((B, last.C, M), device=dev, dtype=torch.float32)
+        out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
         out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
         arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
-        _call(_lib.omnipq_sa_pool, X, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out), _p(out_pm),
+        _call(_lib.omnipq_sa_pool, X, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm),
               _p(arg))
+        out = out_f32.transpose(1, 2).contiguous()        # reference layout (B, C, M)
 
         ctx.layers = layers
         ctx.X0 = X0
@@ -172,7 +173,7 @@ class FusedSAStage(torch.autograd.Function):
         layers = ctx.layers
         L = len(layers)
         dev = g_out.device
-        g_out = g_out.contiguous().float()
+        g_out = g_out.float().transpose(1, 2).contiguous()      # position-major [B*M][C]
         total = ctypes.c_double(float(P) * world)
         grads = [None] * (3 * L)
 
@@ -220,13 +221,19 @@ class FusedSAStage(torch.autograd.Function):
                 dY = dX
             else:
                 want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-                dfeat_pm = torch.zeros((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
+                dfeat_pm = torch.empty((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
                     else None
                 if want_xyz:
-                    d_xyz = torch.zeros((B, N, 3), device=dev)
-                    d_cen = torch.zeros((B, M, 3), device=dev)
-                _call(_lib.omnipq_sa_scatter, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(ctx.idx),
-                      _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
+                    d_xyz = torch.empty((B, N, 3), device=dev)
+                    d_cen = torch.empty((B, M, 3), device=dev)
+                # bucket the positions by source point, then every (point, 8-channel piece) sums its
+                # own bucket: no atomics, each dX row is read exactly once
+                offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
+                order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
+                scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
+                _call(_lib.omnipq_sa_build_csr, dX, B, N, M, S, _p(ctx.idx), _p(offsets), _p(order), _p(scratch))
+                _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
+                      _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
                 if dfeat_pm is not None:
                     d_feat = dfeat_pm.transpose(1, 2).contiguous().to(ctx.feat_dtype)
         ctx.layers = None
