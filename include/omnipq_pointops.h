@@ -60,6 +60,12 @@ int omnipq_opt_n_threads(int work_size);
 int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset,
                                    float *temp, int *idxs, void *stream);
 
+/* Synchronises `stream`, then reports (and clears) the device-side give-up flag of the multi-workgroup
+ * FPS launches on the current device: OMNIPQ_ETIMEOUT if an in-kernel hand-off ever timed out (the
+ * indices of that launch are then garbage), else 0.  The reference has no counterpart (its FPS never
+ * leaves one block); callers that cannot tolerate silent corruption call this once per step. */
+int omnipq_fps_check(void *stream);
+
 /* replaces gather_points_kernel_wrapper (sampling.cpp:11-13).
  *   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 int omnipq_gather_points(int b, int c, int n, int npoints, const float *points,

@@ -7,14 +7,19 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(REPO, "omni-pq_amd", "lib", "libomnipq_pointops.so")
-HEADER = os.path.join(REPO, "include", "omnipq_pointops.h")
+INCLUDE = os.path.join(REPO, "include")
 
 
 def declared_symbols():
-    """Every function the public header declares."""
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(omnipq_\w+)\s*\(", text)))
+    """Every function the public headers (include/*.h) declare."""
+    names = set()
+    for fn in sorted(os.listdir(INCLUDE)):
+        if not fn.endswith(".h"):
+            continue
+        text = open(os.path.join(INCLUDE, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(omnipq_\w+)\s*\(", text))
+    return sorted(names)
 
 
 _lib = None

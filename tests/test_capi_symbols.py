@@ -6,7 +6,7 @@ import capi
 
 def test_library_exports_every_declared_symbol(built_lib):
     syms = capi.declared_symbols()
-    assert len(syms) >= 12 and "omnipq_furthest_point_sampling" in syms
+    assert len(syms) >= 25 and "omnipq_furthest_point_sampling" in syms and "omnipq_sa_gather" in syms
     lib = ctypes.CDLL(built_lib)
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing

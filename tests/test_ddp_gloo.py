@@ -1,0 +1,87 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing of the path.
+
+No GPU kernels run here (the product has no CPU path): the oracle is plugged in as the native backend
+and BatchNorm is left out of the toy modules, because torch's SyncBatchNorm refuses CPU tensors once a
+process group exists.  Covered: disjoint scene sharding, DDP gradient averaging through the custom
+autograd Functions (gather / group / three_interpolate backward run on the autograd worker thread), and
+the all-reduce the fused SA stage uses for its BatchNorm statistics.
+"""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401  (sys.path set-up)
+    import pointnet2_utils
+    from oracle import oracle_ext
+    pointnet2_utils._ext = oracle_ext
+    oracle_ext.set_num_threads(2)
+    torch.set_num_threads(2)
+    import pointnet2_modules
+    import sa_fused
+    import synth
+    from procedural import load_procedural
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 1) every rank draws its own scenes
+        per_rank = 2
+        mine = synth.make_clouds(9, per_rank, 256, kind="room", first_scene=rank * per_rank)
+        everyone = synth.make_clouds(9, per_rank * world, 256, kind="room")
+        assert torch.equal(mine, everyone[rank * per_rank:(rank + 1) * per_rank])
+
+        # 2) DDP over SA + FP (no BN): averaged gradients == mean of the per-rank gradients
+        class Tiny(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.sa = pointnet2_modules.PointnetSAModuleVotes(mlp=[4, 8, 16], npoint=32, radius=0.8,
+                                                                  nsample=8, bn=False, normalize_xyz=True)
+                self.fp = pointnet2_modules.PointnetFPModule(mlp=[16 + 4, 12], bn=False)
+
+            def forward(self, xyz, feats):
+                new_xyz, f, _ = self.sa(xyz, feats)
+                return self.fp(xyz, new_xyz, feats, f)
+
+        net = load_procedural(Tiny(), 1)
+        feats = torch.randn(per_rank, 4, 256, generator=torch.Generator().manual_seed(100 + rank))
+        ddp = torch.nn.parallel.DistributedDataParallel(net, broadcast_buffers=False)
+        ddp(mine, feats).square().mean().backward()
+        got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+
+        solo = load_procedural(Tiny(), 1)
+        solo(mine, feats).square().mean().backward()
+        local = torch.cat([p.grad.reshape(-1) for p in solo.parameters()])
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = torch.stack(gathered).mean(0)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), float((got - want).abs().max())
+
+        # 3) the statistics all-reduce of the fused SA stage (SyncBatchNorm semantics)
+        sums = torch.full((2, 5), float(rank + 1), dtype=torch.float64)
+        sa_fused._allreduce_(sums)
+        assert torch.equal(sums, torch.full((2, 5), float(sum(range(1, world + 1))), dtype=torch.float64))
+        assert sa_fused._world() == world
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel(tmp_path, built_lib):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
