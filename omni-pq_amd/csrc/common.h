@@ -41,16 +41,50 @@ __device__ __forceinline__ int dpp_i32(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
 }
 
+// f32 max over the wave as ONE dependent chain of six v_max_f32 with the DPP fetch folded into the
+// instruction (hipcc emits v_mov_dpp + two v_max per step for the builtin form, and this chain is
+// the critical path of every FPS round).  `s_nop 1` = the two wait states a DPP read needs after a
+// VALU write of its source.  Lanes without a DPP source are disabled by bound_ctrl:0 and keep v.
+// Inputs must not be NaN (v_max_f32 would pick the other operand either way).
 __device__ __forceinline__ float wave_max_f32(float v) {
-#define STEP(CTRL, RM) v = fmaxf(v, __builtin_bit_cast(float, dpp_i32<CTRL, RM>(__builtin_bit_cast(int, v))))
-  STEP(0x111, 0xF);  // row_shr:1
-  STEP(0x112, 0xF);  // row_shr:2
-  STEP(0x114, 0xF);  // row_shr:4
-  STEP(0x118, 0xF);  // row_shr:8
-  STEP(0x142, 0xA);  // row_bcast:15 -> rows 1,3
-  STEP(0x143, 0xC);  // row_bcast:31 -> rows 2,3
-#undef STEP
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  float r;
+  asm volatile(
+      "v_mov_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "=&v"(r)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
+}
+
+// Same over the first 16 lanes only (one DPP row): result = max over lanes 0..15, taken from lane 15.
+__device__ __forceinline__ float row0_max_f32(float v) {
+  float r;
+  asm volatile(
+      "v_mov_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "=&v"(r)
+      : "v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 15));
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {

@@ -16,11 +16,13 @@
 //   * per round: thread-local argmax -> wave argmax on the DPP network (f32 max, then
 //     u32 min over the tie key among the lanes that hold the max) -> one LDS slot per
 //     wave -> one barrier -> 16-lane DPP reduce;
-//   * with G > 1 the G workgroup winners are exchanged through 8-byte
-//     {d2, tag, k} granules written write-through and polled by ONE wave with relaxed
-//     agent-scope loads (data-is-the-flag hand-off, no fence; cdna guide G16 R2),
-//     double-buffered by round parity.  Every spin is bounded; a give-up sets an error
-//     word the host wrapper reports as OMNIPQ_ETIMEOUT.
+//   * the winner's COORDINATES travel with the reduction (readlane out of the owning lane), so the
+//     next round never fetches the chosen point from memory;
+//   * with G > 1 the G workgroup winners are exchanged through 8-byte {value, tag = round}
+//     granules (d2, tie key and -- for G <= 12 -- x, y, z) written write-through and polled by
+//     ONE wave with relaxed agent-scope loads (data-is-the-flag hand-off, no fence; cdna guide
+//     G16 R2), double-buffered by round parity.  Every spin is bounded; a give-up sets an
+//     error word that omnipq_fps_check() reports as OMNIPQ_ETIMEOUT.
 #include "common.h"
 
 #include <math.h>
@@ -52,25 +54,71 @@ __device__ __forceinline__ bool better(float d2, unsigned c, float bd2, unsigned
 }
 
 // Two-phase wave argmax: max d2, then min tie key among the lanes holding it.
+// ROW0: only lanes 0..15 carry candidates (the per-wave winners of a workgroup).
+template <bool ROW0 = false>
 __device__ __forceinline__ void wave_argmax(float &d2, unsigned &c) {
-  const float wmax = wave_max_f32(d2);
-  const unsigned cand = (d2 == wmax) ? c : kNoKey;
-  c = wave_min_u32(cand);
+  const float wmax = ROW0 ? row0_max_f32(d2) : wave_max_f32(d2);
+  const bool top = d2 == wmax;
+  const unsigned long long tied = __ballot(top);
+  if (__builtin_popcountll(tied) == 1) {
+    // the usual case: one lane holds the maximum -- fetch its key directly, no second reduction
+    c = (unsigned)__builtin_amdgcn_readlane((int)c, (int)__builtin_ctzll(tied));
+  } else {
+    c = wave_min_u32(top ? c : kNoKey);
+  }
   d2 = wmax;
 }
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
-template <int THREADS, int PPT, bool MULTI>
+#ifdef OMNIPQ_FPS_TRACE
+// Debug build only (tools/probe): cycle stamps of the phases of rounds 1..16, thread 0 of block 0.
+__device__ long long g_fps_trace[16 * 8];
+#define FPS_STAMP(slot)                                                            \
+  if (blockIdx.x == 0 && threadIdx.x == 0 && j <= 16) g_fps_trace[(j - 1) * 8 + (slot)] = \
+      (long long)__builtin_readcyclecounter()
+#else
+#define FPS_STAMP(slot)
+#endif
+
+// Five values travel with every winner: (d2, tie key, x, y, z).  The coordinates ride along so that the
+// next round never has to fetch the chosen point from memory (a dependent global/scalar load per round
+// costs more than the whole on-chip reduction).
+struct Winner {
+  float d2;
+  unsigned c;
+  float x, y, z;
+};
+
+// Wave argmax on (d2, c), then pull the winner's coordinates out of the lane that owns it.
+// `x, y, z` must be valid in any lane whose (d2, c) can win.
+template <bool ROW0 = false>
+__device__ __forceinline__ Winner wave_winner(float d2, unsigned c, float x, float y, float z) {
+  const float md2 = d2;
+  const unsigned mc = c;
+  wave_argmax<ROW0>(d2, c);
+  const unsigned long long owners = __ballot(md2 == d2 && mc == c);
+  const int src = owners ? (int)__builtin_ctzll(owners) : 0;
+  Winner w;
+  w.d2 = d2;
+  w.c = c;
+  w.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+  w.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), src));
+  w.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), src));
+  return w;
+}
+
+// MULTI: G workgroups per scene.  XG (MULTI only): the exchange granules also carry the winner's
+// coordinates (needs 5*G <= 64 polling lanes); otherwise the chosen point is re-read from memory.
+template <int THREADS, int PPT, bool MULTI, bool XG>
 __global__ __launch_bounds__(THREADS) void fps_kernel(
     int n, int m, int bs_mask, int G, const float *__restrict__ dataset,
     float *__restrict__ temp, int *__restrict__ idxs,
-    unsigned long long *__restrict__ slots,  // [2][scenes][G]   (MULTI only)
+    unsigned long long *__restrict__ slots,  // [2][scenes][5][G] {value, tag} granules (MULTI only)
     int *__restrict__ err_word, int scene0, int spin_limit) {
   constexpr int NW = THREADS / 64;
-  __shared__ float s_d2[2][NW];
-  __shared__ unsigned s_c[2][NW];
-  __shared__ int s_k[2];
+  __shared__ float s_f[2][5][NW];   // per-wave winners: d2, c (bits), x, y, z
+  __shared__ float s_w[2][5];       // scene winner broadcast (MULTI)
 
   const int scene_local = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x;
   const int g = MULTI ? (int)blockIdx.x % G : 0;
@@ -105,16 +153,13 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     }
   }
 
-  int old = 0;
+  // round 0: the seed is point 0 (sampling_gpu.cu:87-88)
+  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
   if (g == 0 && tid == 0) idxs[0] = 0;
 
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
-    const int olds = __builtin_amdgcn_readfirstlane(old);
-    const float x1 = dataset[olds * 3 + 0];
-    const float y1 = dataset[olds * 3 + 1];
-    const float z1 = dataset[olds * 3 + 2];
-
+    FPS_STAMP(0);
     float bd2 = -1.f;  // "no candidate", as the reference's best = -1 (:96)
     unsigned bc = kNoKey;
 #pragma unroll
@@ -130,67 +175,155 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
         bc = cc;
       }
     }
-    wave_argmax(bd2, bc);
+    // coordinates of this lane's candidate (only the winning lane's are ever read)
+    float cx = px[0], cy = py[0], cz = pz[0];
+#pragma unroll
+    for (int i = 1; i < PPT; ++i)
+      if (pc[i] == bc) {
+        cx = px[i];
+        cy = py[i];
+        cz = pz[i];
+      }
+    FPS_STAMP(1);
+    const Winner ww = wave_winner(bd2, bc, cx, cy, cz);
+    FPS_STAMP(2);
     if (lane == 0) {
-      s_d2[par][wave] = bd2;
-      s_c[par][wave] = bc;
+      s_f[par][0][wave] = ww.d2;
+      s_f[par][1][wave] = __builtin_bit_cast(float, ww.c);
+      s_f[par][2][wave] = ww.x;
+      s_f[par][3][wave] = ww.y;
+      s_f[par][4][wave] = ww.z;
     }
     __syncthreads();
+    FPS_STAMP(3);
 
     if (!MULTI) {
       // every wave folds the NW wave winners itself: no second barrier
-      float d2 = lane < NW ? s_d2[par][lane] : -1.f;
-      unsigned c = lane < NW ? s_c[par][lane] : kNoKey;
-      wave_argmax(d2, c);
-      old = d2 < 0.f ? 0 : (int)(c & kKMask);
-      if (tid == 0) idxs[j] = old;
+      const bool in = lane < NW;
+      const float d2 = in ? s_f[par][0][lane] : -1.f;
+      const unsigned c = in ? __builtin_bit_cast(unsigned, s_f[par][1][lane]) : kNoKey;
+      const float wx = in ? s_f[par][2][lane] : 0.f;
+      const float wy = in ? s_f[par][3][lane] : 0.f;
+      const float wz = in ? s_f[par][4][lane] : 0.f;
+      const Winner sw = wave_winner<true>(d2, c, wx, wy, wz);
+      const bool none = sw.d2 < 0.f;   // nothing selectable: the reference falls back to index 0
+      if (none) {
+        x1 = dataset[0]; y1 = dataset[1]; z1 = dataset[2];
+      } else {
+        x1 = sw.x; y1 = sw.y; z1 = sw.z;
+      }
+      if (tid == 0) idxs[j] = none ? 0 : (int)(sw.c & kKMask);
+      FPS_STAMP(4);
     } else {
       if (wave == 0) {
-        float d2 = lane < NW ? s_d2[par][lane] : -1.f;
-        unsigned c = lane < NW ? s_c[par][lane] : kNoKey;
-        wave_argmax(d2, c);
-        const unsigned tag = (unsigned)(j % 4095) + 1u;  // never 0 (slots start zeroed)
-        gu64 *row = (gu64 *)(slots + ((size_t)par * nscenes + scene_local) * G);
-        if (lane == 0) {
-          const unsigned kk = d2 < 0.f ? 0u : (c & kKMask);
-          const unsigned long long gran =
-              ((unsigned long long)__builtin_bit_cast(unsigned, d2) << 32) |
-              ((unsigned long long)tag << kKBits) | kk;
-          __hip_atomic_store(row + g, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool in = lane < NW;
+        const float d2 = in ? s_f[par][0][lane] : -1.f;
+        const unsigned c = in ? __builtin_bit_cast(unsigned, s_f[par][1][lane]) : kNoKey;
+        const float wx = in ? s_f[par][2][lane] : 0.f;
+        const float wy = in ? s_f[par][3][lane] : 0.f;
+        const float wz = in ? s_f[par][4][lane] : 0.f;
+        const Winner gw = wave_winner<true>(d2, c, wx, wy, wz);
+        FPS_STAMP(4);
+        const unsigned tag = (unsigned)j;      // rounds start at 1, slots start zeroed
+        gu64 *row = (gu64 *)(slots + ((size_t)par * nscenes + scene_local) * 5 * G);
+        const int nvals = XG ? 5 : 2;
+        if (lane < nvals) {
+          unsigned val = __builtin_bit_cast(unsigned, gw.d2);
+          if (lane == 1) val = gw.c;
+          if (lane == 2) val = __builtin_bit_cast(unsigned, gw.x);
+          if (lane == 3) val = __builtin_bit_cast(unsigned, gw.y);
+          if (lane == 4) val = __builtin_bit_cast(unsigned, gw.z);
+          __hip_atomic_store(row + lane * G + g, ((unsigned long long)tag << 32) | val, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
         }
-        unsigned long long v = 0;
-        int spins = 0;
+        // poll: lane L watches granule L (value v = L / G of workgroup L % G)
+        float fd2 = -1.f;
+        unsigned fc = kNoKey, myval = 0;
         bool failed = false;
-        for (;;) {
-          bool ok = true;
-          if (lane < G) {
-            v = __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = (((unsigned)v >> kKBits) & 0xFFFu) == tag;
+        const int npoll = nvals * G;     // XG: <= 64 by construction; else 2G <= 64 per pass below
+        if (XG || 2 * G <= 64) {
+          int spins = 0;
+          for (;;) {
+            bool ok = true;
+            if (lane < npoll) {
+              const unsigned long long v =
+                  __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = (unsigned)(v >> 32) == tag;
+              myval = (unsigned)v;
+            }
+            if (__all(ok)) break;
+            if (++spins > spin_limit) {
+              failed = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
           }
-          if (__all(ok)) break;
-          if (++spins > spin_limit) {
-            failed = true;
-            break;
+          const unsigned cval = (unsigned)__shfl((int)myval, lane + G);   // tie key of workgroup `lane`
+          if (lane < G && !failed) {
+            fd2 = __builtin_bit_cast(float, myval);
+            fc = cval;
           }
-          __builtin_amdgcn_s_sleep(1);
+        } else {
+          // more than 32 workgroups per scene: d2 and tie keys in two polling passes
+          unsigned vals[2] = {0, 0};
+          for (int v = 0; v < 2 && !failed; ++v) {
+            int spins = 0;
+            for (;;) {
+              bool ok = true;
+              if (lane < G) {
+                const unsigned long long q =
+                    __hip_atomic_load(row + v * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(q >> 32) == tag;
+                vals[v] = (unsigned)q;
+              }
+              if (__all(ok)) break;
+              if (++spins > spin_limit) {
+                failed = true;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          if (lane < G && !failed) {
+            fd2 = __builtin_bit_cast(float, vals[0]);
+            fc = vals[1];
+          }
         }
-        float gd2 = -1.f;
-        unsigned gc = kNoKey;
-        if (lane < G && !failed) {
-          gd2 = __builtin_bit_cast(float, (unsigned)(v >> 32));
-          const int kk = (int)((unsigned)v & kKMask);
-          gc = gd2 < 0.f ? kNoKey : tie_key(kk, bs_mask);
+        FPS_STAMP(5);
+        // winner over the G workgroups; with XG its coordinates sit in lanes 2G.., 3G.., 4G..
+        const float md2 = fd2;
+        const unsigned mc = fc;
+        wave_argmax(fd2, fc);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        if (XG) {
+          const unsigned long long owners = __ballot(md2 == fd2 && mc == fc && lane < G);
+          const int gs = owners ? (int)__builtin_ctzll(owners) : 0;
+          fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)myval, 2 * G + gs));
+          fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)myval, 3 * G + gs));
+          fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)myval, 4 * G + gs));
         }
-        wave_argmax(gd2, gc);
         if (lane == 0) {
-          s_k[par] = failed ? -1 : (gd2 < 0.f ? 0 : (int)(gc & kKMask));
+          s_w[par][0] = failed ? -2.f : fd2;
+          s_w[par][1] = __builtin_bit_cast(float, fc);
+          s_w[par][2] = fx;
+          s_w[par][3] = fy;
+          s_w[par][4] = fz;
           if (failed) atomicExch(err_word, 1);
         }
       }
       __syncthreads();
-      old = s_k[par];
-      if (old < 0) break;  // hand-off gave up: leave, the host reports OMNIPQ_ETIMEOUT
-      if (g == 0 && tid == 0) idxs[j] = old;
+      FPS_STAMP(6);
+      const float sd2 = s_w[par][0];
+      if (sd2 == -2.f) break;  // hand-off gave up: leave, the host reports OMNIPQ_ETIMEOUT
+      const bool none = sd2 < 0.f;
+      const int kk = none ? 0 : (int)(__builtin_bit_cast(unsigned, s_w[par][1]) & kKMask);
+      if (XG && !none) {
+        x1 = s_w[par][2]; y1 = s_w[par][3]; z1 = s_w[par][4];
+      } else {
+        const int ks = __builtin_amdgcn_readfirstlane(kk);
+        x1 = dataset[ks * 3 + 0]; y1 = dataset[ks * 3 + 1]; z1 = dataset[ks * 3 + 2];
+      }
+      if (g == 0 && tid == 0) idxs[j] = kk;
     }
   }
 
@@ -233,8 +366,8 @@ static int get_workspace(size_t slot_bytes, FpsWorkspace **out) {
 template <int THREADS, int PPT>
 static int launch_single(int b, int n, int m, int bs_mask, const float *dataset, float *temp,
                          int *idxs, hipStream_t stream) {
-  fps_kernel<THREADS, PPT, false><<<b, THREADS, 0, stream>>>(n, m, bs_mask, 1, dataset, temp, idxs,
-                                                             nullptr, nullptr, 0, 0);
+  fps_kernel<THREADS, PPT, false, false><<<b, THREADS, 0, stream>>>(n, m, bs_mask, 1, dataset, temp, idxs,
+                                                                    nullptr, nullptr, 0, 0);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -247,21 +380,31 @@ static int launch_multi(int b, int n, int m, int bs_mask, int G, const float *da
   int chunk = 224 / G;
   if (chunk < 1) chunk = 1;
   if (chunk > b) chunk = b;
-  const size_t slot_bytes = (size_t)2 * chunk * G * sizeof(unsigned long long);
+  const size_t slot_bytes = (size_t)2 * chunk * 5 * G * sizeof(unsigned long long);
   FpsWorkspace *ws = nullptr;
   int rc = get_workspace(slot_bytes, &ws);
   if (rc) return rc;
   for (int s0 = 0; s0 < b; s0 += chunk) {
     const int ns = (b - s0 < chunk) ? (b - s0) : chunk;
-    OMNIPQ_HIP(hipMemsetAsync(ws->slots, 0, (size_t)2 * ns * G * sizeof(unsigned long long), stream));
-    fps_kernel<THREADS, PPT, true><<<ns * G, THREADS, 0, stream>>>(
-        n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22);
+    OMNIPQ_HIP(hipMemsetAsync(ws->slots, 0, (size_t)2 * ns * 5 * G * sizeof(unsigned long long), stream));
+    if (5 * G <= 64)
+      fps_kernel<THREADS, PPT, true, true><<<ns * G, THREADS, 0, stream>>>(
+          n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22);
+    else
+      fps_kernel<THREADS, PPT, true, false><<<ns * G, THREADS, 0, stream>>>(
+          n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22);
     OMNIPQ_LAUNCH_CHECK();
   }
   return OMNIPQ_OK;
 }
 
 }  // namespace omnipq
+
+#ifdef OMNIPQ_FPS_TRACE
+extern "C" int omnipq_debug_read_fps_trace(long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(omnipq::g_fps_trace), sizeof(long long) * 16 * 8);
+}
+#endif
 
 extern "C" int omnipq_opt_n_threads(int work_size) {
   // cuda_utils.h:20-24, evaluated with the same double arithmetic
@@ -309,10 +452,12 @@ extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *
   if (n <= 4096) return launch_single<1024, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_single<1024, 8>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   // several workgroups per scene
+  // up to 12 workgroups the exchange also carries the winner's coordinates (5*G polling lanes)
   const int per4 = 1024 * 4, per8 = 1024 * 8;
-  int G = (n + per4 - 1) / per4;
-  if (G <= 32) return launch_multi<4>(b, n, m, bs_mask, G, dataset, temp, idxs, stream);
-  G = (n + per8 - 1) / per8;
-  if (G <= 64) return launch_multi<8>(b, n, m, bs_mask, G, dataset, temp, idxs, stream);
+  const int G4 = (n + per4 - 1) / per4, G8 = (n + per8 - 1) / per8;
+  if (G4 <= 12) return launch_multi<4>(b, n, m, bs_mask, G4, dataset, temp, idxs, stream);
+  if (G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);
+  if (G4 <= 32) return launch_multi<4>(b, n, m, bs_mask, G4, dataset, temp, idxs, stream);
+  if (G8 <= 64) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);
   return OMNIPQ_ETOOLARGE;
 }
