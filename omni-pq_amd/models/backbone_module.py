@@ -7,6 +7,7 @@ import sys
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
@@ -15,6 +16,7 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
         sys.path.append(_p)
 
 from pointnet2_modules import PointnetSAModuleVotes, PointnetFPModule  # noqa: E402
+import pointnet2_utils  # noqa: E402
 
 # (name, npoint, radius, nsample)
 _SA_GEOMETRY = (("sa1", 2048, 0.2, 64), ("sa2", 1024, 0.4, 32), ("sa3", 512, 0.8, 16),
@@ -39,6 +41,61 @@ class Pointnet2Backbone(nn.Module):
         self.fp1 = PointnetFPModule(mlp=[256 * width + 256 * width, 256 * width, 256 * width])
         self.fp2 = PointnetFPModule(mlp=[256 * width + 256 * width, 256 * width, 288])
 
+    # ---- sampling plan -----------------------------------------------------------------------
+    # The four FPS passes of the backbone (and the one of FPSModule on the seeds) depend on the input
+    # coordinates only, never on features: 40000 -> 2048 -> 1024 -> 512 -> 256 is a chain of
+    # latency-bound kernels (thousands of dependent argmax rounds on a handful of CUs).  On a GPU
+    # they run on a side stream: the sa1 pass can be started one batch ahead (`prefetch`), the
+    # later ones overlap with the MLP of the previous layer.  Results are identical to calling
+    # furthest_point_sample inside each SA layer (reference pointnet2_modules.py:233-236).
+    _plan = None
+    _side = None
+
+    def _side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    @staticmethod
+    def _key(xyz_src):
+        return (xyz_src.data_ptr(), xyz_src._version, tuple(xyz_src.shape))
+
+    def _launch_plan(self, pointcloud):
+        """FPS chain for `pointcloud` on the side stream -> {"key", "inds": [4 x (B,npoint) int32],
+        "events": [4 x Event]}; the caller's stream has to wait on events[i] before using inds[i]."""
+        main = torch.cuda.current_stream(pointcloud.device)
+        side = self._side_stream(pointcloud.device)
+        side.wait_stream(main)
+        plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud}
+        with torch.cuda.stream(side), torch.no_grad():
+            xyz = pointcloud[..., 0:3].contiguous()
+            for name in ("sa1", "sa2", "sa3", "sa4"):
+                npoint = getattr(self, name).npoint
+                inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                plan["inds"].append(inds)
+                plan["events"].append(ev)
+                if name != "sa4":
+                    xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
+                        .transpose(1, 2).contiguous()
+        return plan
+
+    def prefetch(self, pointcloud):
+        """Start the sampling plan of a FUTURE batch now (e.g. while the current batch is in backward).
+        A later forward() on the very same tensor picks the result up; any other input recomputes."""
+        if pointcloud.is_cuda:
+            self._plan = self._launch_plan(pointcloud)
+
+    def _take_plan(self, pointcloud):
+        if not pointcloud.is_cuda or os.environ.get("OMNIPQ_SAMPLING_PLAN", "1") == "0":
+            return None
+        plan = self._plan
+        self._plan = None
+        if plan is None or plan["key"] != self._key(pointcloud):
+            plan = self._launch_plan(pointcloud)
+        return plan
+
     def _break_up_pc(self, pc):
         xyz = pc[..., 0:3].contiguous()
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
@@ -48,9 +105,15 @@ class Pointnet2Backbone(nn.Module):
         if not end_points:
             end_points = {}
         xyz, features = self._break_up_pc(pointcloud)
+        plan = self._take_plan(pointcloud)
 
-        for name in ("sa1", "sa2", "sa3", "sa4"):
-            xyz, features, inds = getattr(self, name)(xyz, features)
+        for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
+            inds = None
+            if plan is not None:
+                torch.cuda.current_stream(pointcloud.device).wait_event(plan["events"][li])
+                inds = plan["inds"][li]
+                inds.record_stream(torch.cuda.current_stream(pointcloud.device))
+            xyz, features, inds = getattr(self, name)(xyz, features, inds)
             if name in ("sa1", "sa2"):          # the reference records inds for these two only
                 end_points[name + "_inds"] = inds
             end_points[name + "_xyz"] = xyz

@@ -69,6 +69,17 @@ class MultiheadAttention(Module):
         assert E == self.embed_dim and key.shape == value.shape
         H, D = self.num_heads, self.head_dim
         q, k, v = self._project(query, key, value)
+        if not need_weights and attn_mask is None and key_padding_mask is None and query.is_cuda:
+            # One fused attention kernel (scores, softmax, dropout, PV never leave the chip) instead of
+            # scale / bmm / softmax / dropout / bmm: same math, softmax(q k^T / sqrt(D)) v with dropout
+            # on the probabilities (reference :375-391).
+            S = k.shape[0]
+            qh = q.reshape(L, N, H, D).permute(1, 2, 0, 3)
+            kh = k.reshape(S, N, H, D).permute(1, 2, 0, 3)
+            vh = v.reshape(S, N, H, D).permute(1, 2, 0, 3)
+            out = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=self.dropout if self.training else 0.0)
+            out = out.permute(2, 0, 1, 3).reshape(L, N, E)
+            return F.linear(out, self.out_proj.weight, self.out_proj.bias), None
         q = q * (float(D) ** -0.5)
         q = q.contiguous().view(L, N * H, D).transpose(0, 1)
         k = k.contiguous().view(-1, N * H, D).transpose(0, 1)

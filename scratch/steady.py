@@ -2,7 +2,7 @@ import sqlite3, sys
 from collections import defaultdict
 c=sqlite3.connect(sys.argv[1])
 rows=c.execute("select name,start,end from kernels order by start").fetchall()
-fps=[r for r in rows if 'fps_kernel<1024, 4, true>' in r[0] or 'fps_multi' in r[0]]
+fps=[r for r in rows if 'fps_kernel<1024, 4, true' in r[0]]
 nsteps=int(sys.argv[2]) if len(sys.argv)>2 else 2
 t0=fps[-1-nsteps][1]; t1=fps[-1][1]
 sel=[r for r in rows if t0<=r[1]<t1]
