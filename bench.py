@@ -53,8 +53,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
-    ap.add_argument("--graph", default="off", choices=["off", "on"],
-                    help="replay the whole fwd+bwd step from a captured hipGraph (single-process runs only)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "off", "on"],
+                    help="replay the whole fwd+bwd step from a captured hipGraph; auto = on for a single "
+                         "process, off under torch.distributed (collectives inside the step stay eager)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-operator table to stderr")
     return ap.parse_args()
 
@@ -196,6 +197,68 @@ def cpu_baseline(args):
         pointnet2_utils._ext = saved
 
 
+def make_step(net, model, pool, args, amp_dtype, world):
+    """-> (step(i) -> loss tensor, launch mode string).  Eager: forward, loss, prefetch of the next
+    batch's sampling, backward.  Graph (single process): the same sequence captured once and replayed."""
+    def step(i):
+        for p in net.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            ep = model({"point_clouds": pool[i % len(pool)]})
+            loss = loss_of(ep)
+        if not args.no_prefetch:
+            # software pipelining across steps: the NEXT batch's furthest-point sampling (coordinates
+            # only) runs on a side stream underneath this batch's backward.  Every step still does
+            # one batch worth of sampling inside the timed region.
+            net.prefetch({"point_clouds": pool[(i + 1) % len(pool)]})
+        loss.backward()
+        return loss
+
+    use_graph = args.graph in ("on", "auto") and world == 1
+    if use_graph:
+        # The whole step (forward, loss, next batch's sampling, backward; ~3000 launches) is captured ONCE
+        # into a hipGraph and replayed: same kernels, same order, no per-launch host work.  Two static
+        # input buffers: `cur` feeds forward/backward, `nxt` feeds the sampling plan of the following
+        # step (side stream, underneath backward), whose indices land in the backbone's persistent plan
+        # buffers and are consumed by the next replay.  Per step two 3.84 MB device-to-device copies refill
+        # the buffers inside the timed region.
+        cur = pool[0].clone()
+        nxt = pool[0].clone()
+
+        def graph_body():
+            for p in net.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+                ep = model({"point_clouds": cur})
+                loss = loss_of(ep)
+            if not args.no_prefetch:
+                net.prefetch({"point_clouds": nxt}, trusted=True)
+            loss.backward()
+            net.join_prefetch()
+            return loss
+
+        def feed(i):
+            cur.copy_(nxt)
+            nxt.copy_(pool[(i + 1) % len(pool)])
+
+        nxt.copy_(pool[0])
+        if not args.no_prefetch:
+            net.prefetch({"point_clouds": nxt}, trusted=True)      # plan of the first batch
+        for i in range(max(args.warmup, 3)):          # eager warm-up: allocator, workspaces, autotuning
+            feed(i)
+            graph_body()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = graph_body()
+
+        def step(i):                                   # noqa: F811
+            feed(i)
+            graph.replay()
+            return static_loss
+    return step, ("hipGraph replay" if use_graph else "eager")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,55 +298,14 @@ def main():
     pool = [synth.make_clouds(100 + i, args.batch, args.points, extra_channels=args.extra_channels,
                               kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
 
-    def step(i):
-        for p in net.parameters():
-            p.grad = None
-        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-            ep = model({"point_clouds": pool[i % len(pool)]})
-            loss = loss_of(ep)
-        if not args.no_prefetch:
-            # software pipelining across steps: the NEXT batch's furthest-point sampling (coordinates
-            # only) runs on a side stream underneath this batch's backward.  Every step still does
-            # one batch worth of sampling inside the timed region.
-            net.prefetch({"point_clouds": pool[(i + 1) % len(pool)]})
-        loss.backward()
-        return loss
+    step, launch_mode = make_step(net, model, pool, args, amp_dtype, world)
+    use_graph = launch_mode != "eager"
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph == "on" and world == 1
-    if use_graph:
-        # The whole step (forward, loss, backward; ~3000 launches) is captured ONCE into a hipGraph and
-        # replayed: same kernels, same order, no per-launch host work.  The batch is copied into a static
-        # input buffer before each replay (3.84 MB device-to-device, inside the timed region).
-        static_pc = pool[0].clone()
-        args.no_prefetch = True           # the captured step samples its own batch on the side stream
-        eager_step = step
-
-        def graph_body():
-            for p in net.parameters():
-                p.grad = None
-            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                ep = model({"point_clouds": static_pc})
-                loss = loss_of(ep)
-            loss.backward()
-            return loss
-
-        for i in range(max(args.warmup, 3)):          # eager warm-up: allocator, workspaces, autotuning
-            static_pc.copy_(pool[i % len(pool)])
-            graph_body()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = graph_body()
-
-        def step(i):                                   # noqa: F811
-            static_pc.copy_(pool[i % len(pool)])
-            graph.replay()
-            return static_loss
     for i in range(args.warmup):
         step(i)
     fence()
@@ -298,6 +320,25 @@ def main():
     dt = time.perf_counter() - t0
     ext.set_timing_sink(None)
     ext.fps_check()
+    timing_note = "events around every C-ABI launch inside the timed region"
+    timing_steps = args.steps
+    if use_graph and not args.no_op_timing:
+        # A graph replay cannot host events, so the per-kernel durations for the roofline are taken
+        # right after the timed region from eager steps over the same batches (same kernels, same
+        # shapes; rocprofv3 of this command sees both and its averages agree).
+        eager_args = argparse.Namespace(**{**vars(args), "graph": "off"})
+        eager_step, _ = make_step(net, model, pool, eager_args, amp_dtype, world)
+        eager_step(0)
+        fence()
+        sink = []
+        ext.set_timing_sink(sink)
+        timing_steps = min(args.steps, 5)
+        for i in range(timing_steps):
+            eager_step(1 + i)
+        fence()
+        ext.set_timing_sink(None)
+        timing_note = (f"events around every C-ABI launch in {timing_steps} eager steps run right after the timed "
+                       "hipGraph replays (a replay cannot host events)")
     assert torch.isfinite(loss.detach()).item(), "non-finite loss"
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -319,18 +360,19 @@ def main():
                        "parallelism": f"dp{world}"},
         }
         if sink:
-            table = summarize_ops(sink, args.steps)
+            table = summarize_ops(sink, timing_steps)
             (name, a), (ms, calls, nbytes) = max(table.items(), key=lambda kv: kv[1][0])
             avg_ms = ms / calls
             gbs = nbytes / (avg_ms * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": name, "shape": list(a), "achieved": gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": None, "avg_ms": avg_ms, "launches_per_step": calls / args.steps,
+                               "traffic": None, "avg_ms": avg_ms, "launches_per_step": calls / timing_steps,
+                               "timing": timing_note,
                                "algorithmic_bytes_per_launch": nbytes}
-            native_ms = sum(v[0] for v in table.values()) / args.steps
+            native_ms = sum(v[0] for v in table.values()) / timing_steps
             rec["native_ops_ms_per_step"] = native_ms
             # the stage BASELINE.json's target is quoted on: every kernel of the five SA layers, fwd+bwd
-            sa_ms = sum(v[0] for (nm, _), v in table.items() if nm in SA_STAGE_CALLS) / args.steps
+            sa_ms = sum(v[0] for (nm, _), v in table.items() if nm in SA_STAGE_CALLS) / timing_steps
             e = 4 if args.dtype == "fp32" else 2
             sa_bytes = sa_stage_algorithmic_bytes(args.batch, args.points, args.extra_channels, e)
             rec["sa_stage"] = {"ms_per_step": sa_ms, "algorithmic_bytes": sa_bytes, "feature_bytes": e,
@@ -339,7 +381,7 @@ def main():
                                "frac": sa_bytes / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sa_ms > 0 else None}
             if args.breakdown:
                 for (nm, aa), (ms_, calls_, nb) in sorted(table.items(), key=lambda kv: -kv[1][0]):
-                    print(f"{nm:38s} {str(aa):34s} {ms_ / args.steps:9.3f} ms/step  x{calls_ / args.steps:4.1f}"
+                    print(f"{nm:38s} {str(aa):34s} {ms_ / timing_steps:9.3f} ms/step  x{calls_ / timing_steps:4.1f}"
                           f"  {nb / (ms_ / calls_ * 1e-3) / 1e9 if ms_ > 0 else 0:9.1f} GB/s", file=sys.stderr)
         if cpu_rec is not None:
             rec["cpu_baseline"] = cpu_rec

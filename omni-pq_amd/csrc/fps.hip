@@ -117,8 +117,16 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     unsigned long long *__restrict__ slots,  // [2][scenes][5][G] {value, tag} granules (MULTI only)
     int *__restrict__ err_word, int scene0, int spin_limit) {
   constexpr int NW = THREADS / 64;
-  __shared__ float s_f[2][5][NW];   // per-wave winners: d2, c (bits), x, y, z
-  __shared__ float s_w[2][5];       // scene winner broadcast (MULTI)
+  // per-wave winners {d2, c (bits), x, y, z, pad}: one 16-byte + one 4-byte LDS access each way, read
+  // UNCONDITIONALLY by every lane (slot = lane mod NW; duplicates are harmless in a max) -- predicated
+  // reads cost a branch and a full LDS round trip each.
+  __shared__ __attribute__((aligned(16))) float s_f[2][NW][8];
+  __shared__ __attribute__((aligned(16))) float s_w[2][8];       // scene winner broadcast (MULTI)
+  // Picks are parked in LDS and flushed 1024 at a time: a global store per round would be waited for
+  // by the next round's barrier (its release semantics drain vmcnt), i.e. one memory round trip per
+  // round on the critical path.
+  constexpr int IDXBUF = 1024;
+  __shared__ int s_idx[IDXBUF];
 
   const int scene_local = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x;
   const int g = MULTI ? (int)blockIdx.x % G : 0;
@@ -153,12 +161,21 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     }
   }
 
-  // round 0: the seed is point 0 (sampling_gpu.cu:87-88)
-  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
-  if (g == 0 && tid == 0) idxs[0] = 0;
+  // round 0: the seed is point 0 (sampling_gpu.cu:87-88).  Its coordinates stay in registers: a round
+  // with nothing selectable falls back to index 0, and a per-round `none ? dataset[0] : winner` would
+  // put a global-load wait on the critical path of EVERY round.
+  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+  float x1 = x0, y1 = y0, z1 = z0;
+  if (tid == 0) s_idx[0] = 0;
 
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
+    if ((j & (IDXBUF - 1)) == 0) {      // flush picks j-1024 .. j-1
+      __syncthreads();
+      if (g == 0)
+        for (int t = tid; t < IDXBUF; t += THREADS) idxs[j - IDXBUF + t] = s_idx[t];
+      __syncthreads();
+    }
     FPS_STAMP(0);
     float bd2 = -1.f;  // "no candidate", as the reference's best = -1 (:96)
     unsigned bc = kNoKey;
@@ -188,41 +205,27 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     const Winner ww = wave_winner(bd2, bc, cx, cy, cz);
     FPS_STAMP(2);
     if (lane == 0) {
-      s_f[par][0][wave] = ww.d2;
-      s_f[par][1][wave] = __builtin_bit_cast(float, ww.c);
-      s_f[par][2][wave] = ww.x;
-      s_f[par][3][wave] = ww.y;
-      s_f[par][4][wave] = ww.z;
+      *reinterpret_cast<float4 *>(&s_f[par][wave][0]) =
+          make_float4(ww.d2, __builtin_bit_cast(float, ww.c), ww.x, ww.y);
+      s_f[par][wave][4] = ww.z;
     }
     __syncthreads();
+    const float4 slot4 = *reinterpret_cast<const float4 *>(&s_f[par][lane & (NW - 1)][0]);
+    const float slotz = s_f[par][lane & (NW - 1)][4];
     FPS_STAMP(3);
 
     if (!MULTI) {
       // every wave folds the NW wave winners itself: no second barrier
-      const bool in = lane < NW;
-      const float d2 = in ? s_f[par][0][lane] : -1.f;
-      const unsigned c = in ? __builtin_bit_cast(unsigned, s_f[par][1][lane]) : kNoKey;
-      const float wx = in ? s_f[par][2][lane] : 0.f;
-      const float wy = in ? s_f[par][3][lane] : 0.f;
-      const float wz = in ? s_f[par][4][lane] : 0.f;
-      const Winner sw = wave_winner<true>(d2, c, wx, wy, wz);
+      const Winner sw = wave_winner<true>(slot4.x, __builtin_bit_cast(unsigned, slot4.y), slot4.z, slot4.w, slotz);
       const bool none = sw.d2 < 0.f;   // nothing selectable: the reference falls back to index 0
-      if (none) {
-        x1 = dataset[0]; y1 = dataset[1]; z1 = dataset[2];
-      } else {
-        x1 = sw.x; y1 = sw.y; z1 = sw.z;
-      }
-      if (tid == 0) idxs[j] = none ? 0 : (int)(sw.c & kKMask);
+      x1 = none ? x0 : sw.x;
+      y1 = none ? y0 : sw.y;
+      z1 = none ? z0 : sw.z;
+      if (tid == 0) s_idx[j & (IDXBUF - 1)] = none ? 0 : (int)(sw.c & kKMask);
       FPS_STAMP(4);
     } else {
       if (wave == 0) {
-        const bool in = lane < NW;
-        const float d2 = in ? s_f[par][0][lane] : -1.f;
-        const unsigned c = in ? __builtin_bit_cast(unsigned, s_f[par][1][lane]) : kNoKey;
-        const float wx = in ? s_f[par][2][lane] : 0.f;
-        const float wy = in ? s_f[par][3][lane] : 0.f;
-        const float wz = in ? s_f[par][4][lane] : 0.f;
-        const Winner gw = wave_winner<true>(d2, c, wx, wy, wz);
+        const Winner gw = wave_winner<true>(slot4.x, __builtin_bit_cast(unsigned, slot4.y), slot4.z, slot4.w, slotz);
         FPS_STAMP(4);
         const unsigned tag = (unsigned)j;      // rounds start at 1, slots start zeroed
         gu64 *row = (gu64 *)(slots + ((size_t)par * nscenes + scene_local) * 5 * G);
@@ -317,14 +320,21 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
       if (sd2 == -2.f) break;  // hand-off gave up: leave, the host reports OMNIPQ_ETIMEOUT
       const bool none = sd2 < 0.f;
       const int kk = none ? 0 : (int)(__builtin_bit_cast(unsigned, s_w[par][1]) & kKMask);
-      if (XG && !none) {
-        x1 = s_w[par][2]; y1 = s_w[par][3]; z1 = s_w[par][4];
+      if (XG) {
+        x1 = none ? x0 : s_w[par][2];
+        y1 = none ? y0 : s_w[par][3];
+        z1 = none ? z0 : s_w[par][4];
       } else {
         const int ks = __builtin_amdgcn_readfirstlane(kk);
         x1 = dataset[ks * 3 + 0]; y1 = dataset[ks * 3 + 1]; z1 = dataset[ks * 3 + 2];
       }
-      if (g == 0 && tid == 0) idxs[j] = kk;
+      if (tid == 0) s_idx[j & (IDXBUF - 1)] = kk;
     }
+  }
+  __syncthreads();
+  if (g == 0) {
+    const int done = ((m - 1) / IDXBUF) * IDXBUF;       // first pick not flushed yet
+    for (int t = done + tid; t < m; t += THREADS) idxs[t] = s_idx[t - done];
   }
 
 #pragma unroll

@@ -60,18 +60,33 @@ class Pointnet2Backbone(nn.Module):
     def _key(xyz_src):
         return (xyz_src.data_ptr(), xyz_src._version, tuple(xyz_src.shape))
 
-    def _launch_plan(self, pointcloud):
+    def _plan_buffers(self, pointcloud):
+        """Persistent index buffers of the plan (one set per batch shape), so that a plan started inside a
+        captured hipGraph lands at the same addresses on every replay."""
+        key = (pointcloud.shape[0], str(pointcloud.device))
+        bufs = self.__dict__.setdefault("_plan_bufs", {})
+        if key not in bufs:
+            bufs[key] = [torch.zeros((pointcloud.shape[0], getattr(self, n).npoint), device=pointcloud.device,
+                                     dtype=torch.int32) for n in ("sa1", "sa2", "sa3", "sa4")]
+        return bufs[key]
+
+    def _launch_plan(self, pointcloud, trusted=False):
         """FPS chain for `pointcloud` on the side stream -> {"key", "inds": [4 x (B,npoint) int32],
         "events": [4 x Event]}; the caller's stream has to wait on events[i] before using inds[i]."""
         main = torch.cuda.current_stream(pointcloud.device)
         side = self._side_stream(pointcloud.device)
         side.wait_stream(main)
-        plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud}
+        bufs = self._plan_buffers(pointcloud)
+        plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud, "trusted": trusted}
+        ext = pointnet2_utils._ext
         with torch.cuda.stream(side), torch.no_grad():
             xyz = pointcloud[..., 0:3].contiguous()
-            for name in ("sa1", "sa2", "sa3", "sa4"):
+            for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
                 npoint = getattr(self, name).npoint
-                inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+                if hasattr(ext, "set_timing_sink"):          # the product binding: write in place
+                    inds = ext.furthest_point_sampling(xyz, npoint, out=bufs[li])
+                else:
+                    inds = ext.furthest_point_sampling(xyz, npoint)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 plan["inds"].append(inds)
@@ -81,18 +96,25 @@ class Pointnet2Backbone(nn.Module):
                         .transpose(1, 2).contiguous()
         return plan
 
-    def prefetch(self, pointcloud):
+    def prefetch(self, pointcloud, trusted=False):
         """Start the sampling plan of a FUTURE batch now (e.g. while the current batch is in backward).
-        A later forward() on the very same tensor picks the result up; any other input recomputes."""
+        A later forward() on the very same tensor picks the result up; any other input recomputes.
+        trusted=True: the next forward() takes the plan whatever tensor it is given (the caller vouches
+        that the contents match -- used when a captured graph feeds forward() from a static buffer)."""
         if pointcloud.is_cuda:
-            self._plan = self._launch_plan(pointcloud)
+            self._plan = self._launch_plan(pointcloud, trusted)
+
+    def join(self, device=None):
+        """Make the current stream wait for everything queued on the sampling stream."""
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     def _take_plan(self, pointcloud):
         if not pointcloud.is_cuda or os.environ.get("OMNIPQ_SAMPLING_PLAN", "1") == "0":
             return None
         plan = self._plan
         self._plan = None
-        if plan is None or plan["key"] != self._key(pointcloud):
+        if plan is None or not (plan["trusted"] or plan["key"] == self._key(pointcloud)):
             plan = self._launch_plan(pointcloud)
         return plan
 
@@ -111,8 +133,7 @@ class Pointnet2Backbone(nn.Module):
             inds = None
             if plan is not None:
                 torch.cuda.current_stream(pointcloud.device).wait_event(plan["events"][li])
-                inds = plan["inds"][li]
-                inds.record_stream(torch.cuda.current_stream(pointcloud.device))
+                inds = plan["inds"][li].clone()        # the plan's buffers are reused by the next plan
             xyz, features, inds = getattr(self, name)(xyz, features, inds)
             if name in ("sa1", "sa2"):          # the reference records inds for these two only
                 end_points[name + "_inds"] = inds

@@ -261,11 +261,15 @@ class PQ_Transformer(nn.Module):
             base_xyz_q = base_xyz_q.detach().clone()
         return end_points
 
-    def prefetch(self, inputs):
+    def prefetch(self, inputs, trusted=False):
         """Optional: start the coordinate-only sampling (FPS chain of the backbone) of a FUTURE batch on
         a side stream; `forward` on the same `inputs['point_clouds']` tensor then skips it.  Results do
         not change (sa1's FPS depends only on the input cloud)."""
-        self.backbone.prefetch(inputs['point_clouds'])
+        self.backbone.prefetch(inputs['point_clouds'], trusted)
+
+    def join_prefetch(self):
+        """Order the current stream after the sampling stream (needed before a graph capture ends)."""
+        self.backbone.join()
 
     def init_weights(self):
         for p in self.decoder.parameters():

@@ -112,12 +112,17 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
-def furthest_point_sampling(points, nsamples):
-    """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:72-93]"""
+def furthest_point_sampling(points, nsamples, out=None):
+    """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:72-93].  `out` (extension): write into an existing
+    int32 tensor instead of allocating one."""
     _check(points, "points", torch.float32)
     _need_gpu(points)
     b, n = points.shape[0], points.shape[1]
-    out = torch.zeros((b, int(nsamples)), device=points.device, dtype=torch.int32)
+    if out is None:
+        out = torch.zeros((b, int(nsamples)), device=points.device, dtype=torch.int32)
+    else:
+        _check(out, "out", torch.int32, cuda_like=points)
+        assert tuple(out.shape) == (b, int(nsamples))
     tmp = torch.full((b, n), 1e10, device=points.device, dtype=torch.float32)
     _run(_lib.omnipq_furthest_point_sampling, points, b, n, int(nsamples), _ptr(points), _ptr(tmp), _ptr(out))
     return out

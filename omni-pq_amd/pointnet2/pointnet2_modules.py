@@ -154,7 +154,7 @@ class PointnetSAModuleVotes(nn.Module):
             return False
         if mode == "fused":
             return True
-        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         if inds is not None:
