@@ -85,7 +85,7 @@ class GatherOperation(Function):
     def forward(ctx, features, idx):
         ctx.n_points = features.size(2)
         ctx.save_for_backward(idx)
-        return _ext.gather_points(features, idx)
+        return _ext.gather_points(features.contiguous(), idx)       # strided (B,C,N) views are accepted
 
     @staticmethod
     @_bwd
@@ -119,7 +119,7 @@ class ThreeInterpolate(Function):
     def forward(ctx, features, idx, weight):
         ctx.n_known = features.size(2)
         ctx.save_for_backward(idx, weight)
-        return _ext.three_interpolate(features, idx, weight)
+        return _ext.three_interpolate(features.contiguous(), idx, weight.contiguous())
 
     @staticmethod
     @_bwd
@@ -138,7 +138,7 @@ class GroupingOperation(Function):
     def forward(ctx, features, idx):
         ctx.n_points = features.size(2)
         ctx.save_for_backward(idx)
-        return _ext.group_points(features, idx)
+        return _ext.group_points(features.contiguous(), idx)
 
     @staticmethod
     @_bwd

@@ -65,6 +65,11 @@ def _gemm_tn(A, B, M, N, P):
     return C
 
 
+# position-major bf16 copy of the last fused stage's output, keyed by (data_ptr, shape) of the tensor it
+# returned; consumed (and dropped) by the next fused stage if that very tensor comes in as `features`
+_PM_CACHE = {}
+
+
 class _Layer:
     """Per-layer constants and saved tensors of one conv+BN+ReLU."""
     __slots__ = ("K", "C", "Wp", "Wt", "a", "b", "mean", "invstd", "Y", "X")
@@ -91,7 +96,10 @@ class FusedSAStage(torch.autograd.Function):
 
         feat_pm = None
         if features is not None:
-            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()    # [B][N][cin]
+            # position-major bf16 copy [B][N][cin]; the previous fused stage left exactly that behind
+            feat_pm = _PM_CACHE.pop((features.data_ptr(), tuple(features.shape)), None)
+            if feat_pm is None:
+                feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()
         xyz_c = xyz.detach().contiguous()
         cen_c = new_xyz.detach().contiguous()
         X = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
@@ -153,7 +161,12 @@ class FusedSAStage(torch.autograd.Function):
         arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
         _call(_lib.omnipq_sa_pool, X, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm),
               _p(arg))
-        out = out_f32.transpose(1, 2).contiguous()        # reference layout (B, C, M)
+        # reference layout (B, C, M) as a VIEW of the position-major result: values, shape and dtype are
+        # the reference's, only the strides differ (no transpose pass; every consumer on this path
+        # either accepts strides or wants the position-major form back)
+        out = out_f32.transpose(1, 2)
+        _PM_CACHE.clear()
+        _PM_CACHE[(out.data_ptr(), tuple(out.shape))] = out_pm
 
         ctx.layers = layers
         ctx.X0 = X0
@@ -173,7 +186,7 @@ class FusedSAStage(torch.autograd.Function):
         layers = ctx.layers
         L = len(layers)
         dev = g_out.device
-        g_out = g_out.float().transpose(1, 2).contiguous()      # position-major [B*M][C]
+        g_out = g_out.float().transpose(1, 2).contiguous()      # position-major [B*M][C] (no-op for a view)
         total = ctypes.c_double(float(P) * world)
         grads = [None] * (3 * L)
 
@@ -235,7 +248,7 @@ class FusedSAStage(torch.autograd.Function):
                 _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
                       _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
                 if dfeat_pm is not None:
-                    d_feat = dfeat_pm.transpose(1, 2).contiguous().to(ctx.feat_dtype)
+                    d_feat = dfeat_pm.transpose(1, 2).to(ctx.feat_dtype)      # (B, cin, N) view, see forward
         ctx.layers = None
         return (d_xyz, d_cen, d_feat, None, None, None, None, None, *grads)
 
