@@ -31,20 +31,33 @@ from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
 
 
+# The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
+# here on row-major activations (points x channels) through F.linear -- one GEMM with the bias in its
+# epilogue -- instead of Conv1d on (B, C, K): same arithmetic, no layout-shuffling copies around every call,
+# and the heads' outputs come out directly in the (B, K, C) form the reference produces with .transpose(2, 1).
+def rows(x):
+    """(B, C, K) -> (B*K, C) rows (a free reshape when x is a transposed view of (B, K, C) data)."""
+    B, C, K = x.shape
+    return x.transpose(1, 2).reshape(B * K, C)
+
+
+def lin(x2d, conv):
+    """kernel-size-1 Conv1d applied to rows: (N, C_in) -> (N, C_out)"""
+    return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
+
+
 def conv1x1(x, conv):
-    """A kernel-size-1 Conv1d applied as ONE dense contraction: (C_out, C_in) @ (B, C_in, K) + bias.
-    Same arithmetic as `conv(x)`; going through the GEMM library directly instead of the convolution
-    library saves the layout-shuffling helper kernels the latter launches around every tiny conv."""
-    y = torch.matmul(conv.weight.squeeze(-1), x)
-    return y if conv.bias is None else y + conv.bias.unsqueeze(-1)
+    """(B, C_in, K) -> (B, C_out, K), as a transposed view of the row-major result."""
+    B, _, K = x.shape
+    return lin(rows(x), conv).view(B, K, -1).transpose(1, 2)
 
 
-def fused_heads(net, heads):
-    """Several 1x1 output heads on the same trunk features as one GEMM over the concatenated weights.
-    -> list of (B, K, C_h) tensors (already transposed like the reference's `.transpose(2, 1)`)."""
+def fused_heads(x2d, heads, B, K):
+    """Several 1x1 output heads on the same trunk rows as ONE GEMM over the concatenated weights
+    -> list of (B, K, C_h) tensors."""
     w = torch.cat([h.weight.squeeze(-1) for h in heads], 0)
     b = torch.cat([h.bias for h in heads], 0)
-    y = (torch.matmul(w, net) + b.unsqueeze(-1)).transpose(2, 1)
+    y = F.linear(x2d, w, b).view(B, K, -1)
     return list(torch.split(y, [h.out_channels for h in heads], dim=2))
 
 
@@ -61,8 +74,10 @@ class PositionEmbeddingLearned(nn.Module):
 
     def forward(self, xyz):
         head = self.position_embedding_head
-        x = conv1x1(xyz.transpose(1, 2), head[0])
-        return conv1x1(head[2](head[1](x)), head[3])
+        B, P, _ = xyz.shape
+        x = lin(xyz.reshape(B * P, -1), head[0])
+        x = lin(head[2](head[1](x)), head[3])
+        return x.view(B, P, -1).transpose(1, 2)
 
 
 def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_residuals_normalized,
@@ -93,8 +108,9 @@ def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_r
 
 
 def _trunk(self, net):
-    net = F.relu(self.bn1(conv1x1(net, self.conv1)))
-    return F.relu(self.bn2(conv1x1(net, self.conv2)))
+    """(B, C, K) -> trunk features as rows (B*K, C)"""
+    x = F.relu(self.bn1(lin(rows(net), self.conv1)))
+    return F.relu(self.bn2(lin(x, self.conv2)))
 
 
 class PredictHead(nn.Module):
@@ -125,15 +141,16 @@ class PredictHead(nn.Module):
         return self._means
 
     def forward(self, net, base_xyz, end_points, prefix):
-        net = _trunk(self, net)
-        obj, ctr, hcls, hres, scls, sres, sem = fused_heads(net, (
+        B, K = net.shape[0], net.shape[2]
+        x = _trunk(self, net)
+        obj, ctr, hcls, hres, scls, sres, sem = fused_heads(x, (
             self.objectness_scores_head, self.center_head, self.heading_class_head,
             self.heading_residual_head, self.size_class_head, self.size_residual_head,
-            self.sem_cls_scores_head))
+            self.sem_cls_scores_head), B, K)
         center = ctr + base_xyz
         end_points, pred_size = decode_scores(
-            base_xyz, obj, center, hcls, hres, scls, sres.contiguous(), sem, end_points, self.num_class,
-            self.num_heading_bin, self.num_size_cluster, self._mean_sizes(net.device), prefix)
+            base_xyz, obj, center, hcls, hres, scls, sres, sem, end_points, self.num_class,
+            self.num_heading_bin, self.num_size_cluster, self._mean_sizes(x.device), prefix)
         return center, pred_size, end_points
 
 
@@ -153,9 +170,9 @@ class QuadPredictHead(nn.Module):
         self.bn2 = nn.BatchNorm1d(hidden_dim)
 
     def forward(self, net, base_xyz, end_points, prefix):
-        net = _trunk(self, net)
-        scores, ctr, normal, size = fused_heads(net, (self.quad_scores_head, self.center_head,
-                                                      self.normal_vector_head, self.size_head))
+        B, K = net.shape[0], net.shape[2]
+        scores, ctr, normal, size = fused_heads(_trunk(self, net), (
+            self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head), B, K)
         center = ctr + base_xyz
         normal = normal.div(torch.norm(normal, p=2))
         end_points[f'{prefix}quad_scores'] = scores

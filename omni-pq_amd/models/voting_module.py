@@ -9,9 +9,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def _conv1x1(x, conv):
-    """kernel-size-1 Conv1d as one dense contraction (see models/pq_transformer.py:conv1x1)."""
-    return torch.matmul(conv.weight.squeeze(-1), x) + conv.bias.unsqueeze(-1)
+def _lin(x2d, conv):
+    """kernel-size-1 Conv1d applied to rows (points x channels): one GEMM with the bias in its epilogue
+    (see models/pq_transformer.py:lin)."""
+    return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
 
 
 class VotingModule(nn.Module):
@@ -30,11 +31,11 @@ class VotingModule(nn.Module):
         """seed_xyz (B,K,3), seed_features (B,C,K) -> vote_xyz (B,K*vf,3), vote_features (B,C,K*vf)"""
         B, K = seed_xyz.shape[0], seed_xyz.shape[1]
         vf, C = self.vote_factor, self.out_dim
-        net = F.relu(self.bn1(_conv1x1(seed_features, self.conv1)))
-        net = F.relu(self.bn2(_conv1x1(net, self.conv2)))
-        net = _conv1x1(net, self.conv3)                         # (B, (3+C)*vf, K)
-        net = net.transpose(2, 1).reshape(B, K, vf, 3 + C)
+        seed_rows = seed_features.transpose(2, 1)               # (B, K, C): rows = seed points
+        net = F.relu(self.bn1(_lin(seed_rows.reshape(B * K, C), self.conv1)))
+        net = F.relu(self.bn2(_lin(net, self.conv2)))
+        net = _lin(net, self.conv3).view(B, K, vf, 3 + C)       # the reference's transpose(2,1).view
         vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(B, K * vf, 3)
-        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
+        vote_features = seed_rows.unsqueeze(2) + net[..., 3:]
         vote_features = vote_features.reshape(B, K * vf, C).transpose(2, 1).contiguous()
         return vote_xyz, vote_features

@@ -188,6 +188,30 @@ class PointnetSAModuleMSGVotes(nn.Module):
         return new_xyz, torch.cat(pooled, dim=1), inds
 
 
+def _rows_mlp(shared_mlp, x_rows):
+    """Run a SharedMLP whose layers are plain [1x1 Conv2d (no bias), BatchNorm2d, ReLU] on row-major
+    activations (points x channels): per layer one F.linear + BatchNorm over the rows + ReLU.  Same
+    arithmetic as the (B, C, n, 1) convolution stack (pytorch_utils.py:11-36), without the convolution
+    library's layout shuffles.  Returns None when a layer has another shape (caller composes as usual)."""
+    plan = []
+    for layer in shared_mlp:
+        conv = getattr(layer, "conv", None)
+        bnw = getattr(layer, "bn", None)
+        act = getattr(layer, "activation", None)
+        if conv is None or bnw is None or conv.bias is not None or not isinstance(act, nn.ReLU) \
+                or tuple(conv.kernel_size) != (1, 1) or list(layer._modules.keys())[0] != "conv":
+            return None
+        plan.append((conv, bnw.bn))
+    for conv, bn in plan:
+        y = F.linear(x_rows, conv.weight.view(conv.out_channels, -1))
+        if isinstance(bn, nn.BatchNorm2d):           # wants 4-D: (N, C) -> (N, C, 1, 1) is a free view
+            y = bn(y.view(y.shape[0], y.shape[1], 1, 1)).view(y.shape[0], y.shape[1])
+        else:                                        # SyncBatchNorm (after conversion) takes rows as is
+            y = bn(y)
+        x_rows = F.relu(y)
+    return x_rows
+
+
 def inverse_distance_weights(dist):
     """(B,n,3) distances -> normalised 1/(d+1e-8) weights (reference :395-397)."""
     recip = 1.0 / (dist + 1e-8)
@@ -214,6 +238,12 @@ class PointnetFPModule(nn.Module):
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx,
                                                              inverse_distance_weights(dist))
+        B, n = interpolated.shape[0], interpolated.shape[2]
+        parts = [interpolated.transpose(1, 2)] + ([] if unknow_feats is None else [unknow_feats.transpose(1, 2)])
+        rows_in = torch.cat(parts, dim=2).reshape(B * n, -1)            # (B*n, C2 + C1), points as rows
+        y = _rows_mlp(self.mlp, rows_in)
+        if y is not None:
+            return y.view(B, n, -1).transpose(1, 2)                     # (B, C_out, n) view
         stacked = interpolated if unknow_feats is None else \
             torch.cat([interpolated, unknow_feats], dim=1)
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
