@@ -100,6 +100,7 @@ def _loss_weights(sizes, device):
 
 def algorithmic_bytes(name, a):
     """SURVEY.md 8(d) per-call bytes (f32 features, e = 4) from the C-ABI integer arguments."""
+    name = name.split("@")[0]
     if name == "omnipq_furthest_point_sampling":
         b, n, m = a[:3]
         return b * (12 * n + 4 * m)
@@ -372,7 +373,8 @@ def main():
             native_ms = sum(v[0] for v in table.values()) / timing_steps
             rec["native_ops_ms_per_step"] = native_ms
             # the stage BASELINE.json's target is quoted on: every kernel of the five SA layers, fwd+bwd
-            sa_ms = sum(v[0] for (nm, _), v in table.items() if nm in SA_STAGE_CALLS) / timing_steps
+            sa_ms = sum(v[0] for (nm, _), v in table.items()
+                        if nm.endswith("@sa") or nm in ("omnipq_group_points", "omnipq_group_points_grad")) / timing_steps
             e = 4 if args.dtype == "fp32" else 2
             sa_bytes = sa_stage_algorithmic_bytes(args.batch, args.points, args.extra_channels, e)
             rec["sa_stage"] = {"ms_per_step": sa_ms, "algorithmic_bytes": sa_bytes, "feature_bytes": e,

@@ -41,6 +41,10 @@ int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float i
 int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                         void *stream);
 
+/* C = A B^T + bias[n] (f32 bias added before the bf16 rounding) */
+int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+                             int ldc, const float *bias, void *stream);
+
 /* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
 long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
@@ -53,7 +57,8 @@ int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *strea
  * a = gamma*invstd, b = beta - mean*a, saved mean/invstd, running-stat update (NULL to skip). */
 int omnipq_bn_finalize(int C, double count, const double *sums, const float *gamma, const float *beta, float eps,
                        float momentum, float *running_mean, float *running_var, float *a, float *b,
-                       float *mean, float *invstd, void *stream);
+                       float *mean, float *invstd, const float *conv_bias /* NULL, or the bias a preceding
+                       linear layer would add: only the running mean sees it */, void *stream);
 
 /* X = relu(a * Y + b) */
 int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, const float *b, void *X, void *stream);
@@ -64,7 +69,8 @@ int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const float *a, co
                    float *out_f32, void *out_pm, unsigned char *arg, void *stream);
 
 /* backward of pool + last BatchNorm, in two phases so a cross-rank all-reduce of `sums` can sit between;
- * g_out is position-major f32 [b*m][C] */
+ * g_out is position-major f32 [b*m][C].  In every *_bwd_* entry point `sums` holds THREE rows of C doubles:
+ * [sum dz | sum dz*yhat | scratch for the apply phase]; only the first two rows are data. */
 int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *Y, const float *mean, const float *invstd,
                              const float *g_out, const void *out_pm, const unsigned char *arg, double *sums,
                              void *stream);

@@ -42,7 +42,8 @@ __device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_ca
 template <bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
-                                                        void *__restrict__ Cout) {
+                                                        void *__restrict__ Cout,
+                                                        const float *__restrict__ bias) {
   // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
   constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
   constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
@@ -172,13 +173,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     // (c, c+1) of row r, the odd lane with (c-1, c) of row r+1 -> 32 ds_write_b32 instead of 64 b16.
     unsigned *ct32 = reinterpret_cast<unsigned *>(smem);
     const bool odd = lane & 1;
+    float bcol[2] = {0.f, 0.f};            // per-column bias (f32, added before the single bf16 rounding)
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + ccol;
+        bcol[j] = c < g.N ? bias[c] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float mine0 = acc[i][j][r], mine1 = acc[i][j][r + 1];
+          const float mine0 = acc[i][j][r] + bcol[j], mine1 = acc[i][j][r + 1] + bcol[j];
           const float give = odd ? mine0 : mine1;
           const float got = __builtin_bit_cast(
               float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
@@ -225,7 +234,22 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C);
+  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// Same with a per-column f32 bias added to the accumulators before rounding:  C = A B^T + bias[n].
+extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                        void *C, int ldc, const float *bias, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -244,7 +268,8 @@ extern "C" int omnipq_gemm_nt_bf16_splitk(int M, int N, int K, const void *A, in
   GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, used);
-  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace);
+  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
+                                                           nullptr);
   OMNIPQ_LAUNCH_CHECK();
   const int n = M * N;
   splitk_reduce_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, used, workspace, C);

@@ -141,12 +141,15 @@ __global__ __launch_bounds__(256) void colstats_kernel(long long P, int C, const
 //   mean = s1/cnt, var = s2/cnt - mean^2 (biased), invstd = rsqrt(var + eps)
 //   a = gamma * invstd, b = beta - mean * a
 //   running_mean = (1-mom) rm + mom mean;  running_var = (1-mom) rv + mom var * cnt/(cnt-1)
+// conv_bias (may be NULL): a bias the producing linear layer would have added before the BatchNorm.  It
+// cancels in the normalised output (training mode subtracts the batch mean), so the GEMM never adds it;
+// only the running mean has to see it.
 __global__ void bn_finalize_kernel(int C, double cnt, const double *__restrict__ sums,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float eps, float momentum, float *__restrict__ running_mean,
                                    float *__restrict__ running_var, float *__restrict__ a,
                                    float *__restrict__ b, float *__restrict__ mean,
-                                   float *__restrict__ invstd) {
+                                   float *__restrict__ invstd, const float *__restrict__ conv_bias) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (c >= C) return;
   const double mu = sums[c] / cnt;
@@ -160,7 +163,8 @@ __global__ void bn_finalize_kernel(int C, double cnt, const double *__restrict__
   invstd[c] = is;
   if (running_mean) {
     const double unbiased = cnt > 1 ? var * cnt / (cnt - 1) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    const float shift = conv_bias ? conv_bias[c] : 0.f;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mu + shift);
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
@@ -257,12 +261,18 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m
 }
 
 // dY[p][c] = a[c] * (dz - S/P - yhat * T/P),  dz = (s == arg ? g_out : 0) masked by out > 0
-__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, int m, int s, int C, double invP,
+// sums (f64 totals) -> per-channel means as f32:  st[c] = sum dz / P,  st[C + c] = sum dz*yhat / P
+__global__ void bwd_means_kernel(int n2, double invP, const double *__restrict__ sums, float *__restrict__ st) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n2) st[i] = (float)(sums[i] * invP);
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, int m, int s, int C,
                                                             const bf16_t *__restrict__ Y,
                                                             const float *__restrict__ a,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
-                                                            const double *__restrict__ sums,
+                                                            const float *__restrict__ st,
                                                             const float *__restrict__ g_out,
                                                             const bf16_t *__restrict__ out_pm,
                                                             const unsigned char *__restrict__ arg,
@@ -273,7 +283,9 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, i
     const int c0 = (int)(q - p * cpr) * 8;
     const long long bm = p / s;
     const int t = (int)(p - bm * s);
-    float y[8], o[8], av[8], mu[8], is[8], gg[8];
+    float y[8], o[8], av[8], mu[8], is[8], gg[8], Sv[8], Tv[8];
+    load8f(st + c0, Sv);
+    load8f(st + C + c0, Tv);
     load8f(g_out + (size_t)bm * C + c0, gg);
     unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
     unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + c0), o);
@@ -283,12 +295,10 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, i
     const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(arg + (size_t)bm * C + c0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c0 + e;
       const bool hit = (int)((packed >> (8 * e)) & 0xFF) == t && o[e] > 0.f;
       const float dz = hit ? gg[e] : 0.f;
       const float yhat = (y[e] - mu[e]) * is[e];
-      const float S = (float)(sums[c] * invP), T = (float)(sums[C + c] * invP);
-      y[e] = av[e] * (dz - S - yhat * T);
+      y[e] = av[e] * (dz - Sv[e] - yhat * Tv[e]);
     }
     *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
   }
@@ -326,31 +336,32 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(long long P, int C, c
   fold_and_publish<kMaxC>(u, v, cg, rsub, rpb, cgs, C, sums);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long long chunks, int C, double invP,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long long chunks, int C,
                                                           const bf16_t *__restrict__ dX,
                                                           const bf16_t *__restrict__ Y,
                                                           const float *__restrict__ a,
                                                           const float *__restrict__ b,
                                                           const float *__restrict__ mean,
                                                           const float *__restrict__ invstd,
-                                                          const double *__restrict__ sums,
+                                                          const float *__restrict__ st,
                                                           bf16_t *__restrict__ dY) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
     const int c0 = (int)(q % cpr) * 8;
-    float y[8], d[8], av[8], bv[8], mu[8], is[8];
+    float y[8], d[8], av[8], bv[8], mu[8], is[8], Sv[8], Tv[8];
     unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
     unpack8(*reinterpret_cast<const uint4 *>(dX + q * 8), d);
     load8f(a + c0, av);
     load8f(b + c0, bv);
     load8f(mean + c0, mu);
     load8f(invstd + c0, is);
+    load8f(st + c0, Sv);
+    load8f(st + C + c0, Tv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float dz = __builtin_fmaf(av[e], y[e], bv[e]) > 0.f ? d[e] : 0.f;
       const float yhat = (y[e] - mu[e]) * is[e];
-      const float S = (float)(sums[c0 + e] * invP), T = (float)(sums[C + c0 + e] * invP);
-      y[e] = av[e] * (dz - S - yhat * T);
+      y[e] = av[e] * (dz - Sv[e] - yhat * Tv[e]);
     }
     *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
   }
@@ -492,11 +503,32 @@ __global__ __launch_bounds__(256) void sa_centre_grad_kernel(long long BM, int s
   dcentre[bm * 3 + 2] = -acc[2] * inv_r;
 }
 
+// f32 per-channel means for the *_bwd_apply kernels live right behind the f64 sums: the `sums` buffer of
+// the backward entry points has THREE rows of C doubles, [sum dz | sum dz*yhat | scratch] (omnipq_sa.h).
+static inline float *means_scratch(const double *sums, int C) {
+  return reinterpret_cast<float *>(const_cast<double *>(sums) + 2 * (size_t)C);
+}
+
 static inline int rows_per_block(int C) {
   const int rpb = 256 / (C / 8);
   return rpb > 16 ? 16 : rpb;
 }
 static inline size_t fold_lds_bytes(int C) { return (size_t)2 * rows_per_block(C) * C * sizeof(float); }
+
+// Blocks for the column-statistic kernels: each block owns rows_per_block(C) row lanes; aim for >= 512 blocks
+// (small problems: one row per lane) and cap the per-lane loop at 32 rows (large problems: 1024 blocks).
+static inline int stats_grid(long long rows, int C) {
+  const int rpb = rows_per_block(C);
+  long long blocks = (rows + rpb - 1) / rpb;          // one row per lane
+  if (blocks > 512) {
+    long long per_lane = (blocks + 511) / 512;
+    if (per_lane > 32) per_lane = 32;
+    blocks = (rows + rpb * per_lane - 1) / (rpb * per_lane);
+  }
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
 
 static inline int grid_for(long long items, int per_block = 256, int cap = 256 * 16) {
   long long blocks = (items + per_block - 1) / per_block;
@@ -530,7 +562,8 @@ extern "C" int omnipq_colstats(long long P, int C, const void *Y, double *sums, 
   OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (P == 0) return OMNIPQ_OK;
   const int rpb = rows_per_block(C);
-  colstats_kernel<<<grid_for(P, rpb * 32, 1024), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+  (void)rpb;
+  colstats_kernel<<<stats_grid(P, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
                                                                                            sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -539,11 +572,11 @@ extern "C" int omnipq_colstats(long long P, int C, const void *Y, double *sums, 
 extern "C" int omnipq_bn_finalize(int C, double count, const double *sums, const float *gamma,
                                   const float *beta, float eps, float momentum, float *running_mean,
                                   float *running_var, float *a, float *b, float *mean, float *invstd,
-                                  void *stream) {
+                                  const float *conv_bias, void *stream) {
   if (C <= 0 || !sums || !gamma || !beta || !a || !b || !mean || !invstd) return OMNIPQ_EINVAL;
   bn_finalize_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, count, sums, gamma, beta, eps, momentum,
                                                                      running_mean, running_var, a, b, mean,
-                                                                     invstd);
+                                                                     invstd, conv_bias);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -580,7 +613,8 @@ extern "C" int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *
   OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (BM == 0) return OMNIPQ_OK;
   const int rpb = rows_per_block(C);
-  pool_bwd_stats_kernel<<<grid_for(BM, rpb * 8, 1024), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+  (void)rpb;
+  pool_bwd_stats_kernel<<<stats_grid(BM, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
       BM, m, s, C, (const bf16_t *)Y, mean, invstd, g_out, (const bf16_t *)out_pm, arg, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -594,9 +628,10 @@ extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total
   const long long chunks = (long long)b * m * s * (C / 8);
   if (chunks == 0) return OMNIPQ_OK;
   if (!Y || !a || !mean || !invstd || !sums || !g_out || !out_pm || !arg || !dY) return OMNIPQ_EINVAL;
+  float *st = means_scratch(sums, C);
+  bwd_means_kernel<<<(2 * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(2 * C, 1.0 / total_positions, sums, st);
   pool_bwd_apply_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, m, s, C, 1.0 / total_positions, (const bf16_t *)Y, a, mean, invstd, sums, g_out,
-      (const bf16_t *)out_pm, arg, (bf16_t *)dY);
+      chunks, m, s, C, (const bf16_t *)Y, a, mean, invstd, st, g_out, (const bf16_t *)out_pm, arg, (bf16_t *)dY);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -609,7 +644,8 @@ extern "C" int omnipq_bn_bwd_stats(long long P, int C, const void *dX, const voi
   OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (P == 0) return OMNIPQ_OK;
   const int rpb = rows_per_block(C);
-  bn_bwd_stats_kernel<<<grid_for(P, rpb * 32, 1024), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+  (void)rpb;
+  bn_bwd_stats_kernel<<<stats_grid(P, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
       P, C, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -622,9 +658,10 @@ extern "C" int omnipq_bn_bwd_apply(long long P, int C, double total_positions, c
   if (P == 0) return OMNIPQ_OK;
   if (!dX || !Y || !a || !b || !mean || !invstd || !sums || !dY) return OMNIPQ_EINVAL;
   const long long chunks = P * (C / 8);
+  float *st = means_scratch(sums, C);
+  bwd_means_kernel<<<(2 * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(2 * C, 1.0 / total_positions, sums, st);
   bn_bwd_apply_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, C, 1.0 / total_positions, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums,
-      (bf16_t *)dY);
+      chunks, C, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, st, (bf16_t *)dY);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

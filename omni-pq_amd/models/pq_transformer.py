@@ -29,6 +29,7 @@ from transformer import TransformerDecoderLayer  # noqa: E402
 from utils.pointnet_util import FPSModule  # noqa: E402
 from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
+import rows_mlp  # noqa: E402
 
 
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
@@ -52,13 +53,23 @@ def conv1x1(x, conv):
     return lin(rows(x), conv).view(B, K, -1).transpose(1, 2)
 
 
-def fused_heads(x2d, heads, B, K):
-    """Several 1x1 output heads on the same trunk rows as ONE GEMM over the concatenated weights
-    -> list of (B, K, C_h) tensors."""
+def head_stack(self, net, heads):
+    """Trunk (2 x Conv1d+BN+ReLU) and every 1x1 output head of a prediction head on (B, C, K) features.
+    The output heads share one GEMM over their concatenated weights.  -> list of (B, K, C_h) tensors, i.e.
+    already in the layout the reference reaches with `.transpose(2, 1)`."""
+    B, K = net.shape[0], net.shape[2]
+    x = rows(net)
     w = torch.cat([h.weight.squeeze(-1) for h in heads], 0)
     b = torch.cat([h.bias for h in heads], 0)
-    y = F.linear(x2d, w, b).view(B, K, -1)
-    return list(torch.split(y, [h.out_channels for h in heads], dim=2))
+    stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
+             rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2), rows_mlp.Layer(w, b)]
+    if rows_mlp.usable(x, stack, self.training):
+        y = rows_mlp.run(x, stack, self.training)                  # hand-written MFMA / BN kernels
+    else:
+        x = F.relu(self.bn1(lin(x, self.conv1)))
+        x = F.relu(self.bn2(lin(x, self.conv2)))
+        y = F.linear(x, w, b)
+    return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -75,8 +86,12 @@ class PositionEmbeddingLearned(nn.Module):
     def forward(self, xyz):
         head = self.position_embedding_head
         B, P, _ = xyz.shape
-        x = lin(xyz.reshape(B * P, -1), head[0])
-        x = lin(head[2](head[1](x)), head[3])
+        x = xyz.reshape(B * P, -1)
+        stack = [rows_mlp.Layer(head[0].weight, head[0].bias, head[1]), rows_mlp.Layer(head[3].weight, head[3].bias)]
+        if rows_mlp.usable(x, stack, self.training):
+            x = rows_mlp.run(x, stack, self.training)
+        else:
+            x = lin(head[2](head[1](lin(x, head[0]))), head[3])
         return x.view(B, P, -1).transpose(1, 2)
 
 
@@ -107,12 +122,6 @@ def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_r
     return end_points, pred_size
 
 
-def _trunk(self, net):
-    """(B, C, K) -> trunk features as rows (B*K, C)"""
-    x = F.relu(self.bn1(lin(rows(net), self.conv1)))
-    return F.relu(self.bn2(lin(x, self.conv2)))
-
-
 class PredictHead(nn.Module):
     """Object head: 2 x (Conv1d+BN+ReLU) trunk, then seven 1x1 heads (reference :62-91)."""
 
@@ -141,16 +150,14 @@ class PredictHead(nn.Module):
         return self._means
 
     def forward(self, net, base_xyz, end_points, prefix):
-        B, K = net.shape[0], net.shape[2]
-        x = _trunk(self, net)
-        obj, ctr, hcls, hres, scls, sres, sem = fused_heads(x, (
+        obj, ctr, hcls, hres, scls, sres, sem = head_stack(self, net, (
             self.objectness_scores_head, self.center_head, self.heading_class_head,
             self.heading_residual_head, self.size_class_head, self.size_residual_head,
-            self.sem_cls_scores_head), B, K)
+            self.sem_cls_scores_head))
         center = ctr + base_xyz
         end_points, pred_size = decode_scores(
             base_xyz, obj, center, hcls, hres, scls, sres, sem, end_points, self.num_class,
-            self.num_heading_bin, self.num_size_cluster, self._mean_sizes(x.device), prefix)
+            self.num_heading_bin, self.num_size_cluster, self._mean_sizes(net.device), prefix)
         return center, pred_size, end_points
 
 
@@ -170,9 +177,8 @@ class QuadPredictHead(nn.Module):
         self.bn2 = nn.BatchNorm1d(hidden_dim)
 
     def forward(self, net, base_xyz, end_points, prefix):
-        B, K = net.shape[0], net.shape[2]
-        scores, ctr, normal, size = fused_heads(_trunk(self, net), (
-            self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head), B, K)
+        scores, ctr, normal, size = head_stack(self, net, (
+            self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head))
         center = ctr + base_xyz
         normal = normal.div(torch.norm(normal, p=2))
         end_points[f'{prefix}quad_scores'] = scores

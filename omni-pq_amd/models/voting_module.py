@@ -4,9 +4,19 @@ Three 1x1 convolutions over the seed features (288 -> 288 -> 288 -> (3 + 288) * 
 first three output channels of every vote are an xyz offset added to the seed position, the rest a
 residual added to the seed feature.  Parameter names (`conv1..3`, `bn1..2`) are the reference's.
 """
+import os
+import sys
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
+    if _p not in sys.path:
+        sys.path.append(_p)
+
+import rows_mlp  # noqa: E402
 
 
 def _lin(x2d, conv):
@@ -32,9 +42,17 @@ class VotingModule(nn.Module):
         B, K = seed_xyz.shape[0], seed_xyz.shape[1]
         vf, C = self.vote_factor, self.out_dim
         seed_rows = seed_features.transpose(2, 1)               # (B, K, C): rows = seed points
-        net = F.relu(self.bn1(_lin(seed_rows.reshape(B * K, C), self.conv1)))
-        net = F.relu(self.bn2(_lin(net, self.conv2)))
-        net = _lin(net, self.conv3).view(B, K, vf, 3 + C)       # the reference's transpose(2,1).view
+        x = seed_rows.reshape(B * K, C)
+        stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
+                 rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2),
+                 rows_mlp.Layer(self.conv3.weight, self.conv3.bias)]
+        if rows_mlp.usable(x, stack, self.training):
+            net = rows_mlp.run(x, stack, self.training)
+        else:
+            net = F.relu(self.bn1(_lin(x, self.conv1)))
+            net = F.relu(self.bn2(_lin(net, self.conv2)))
+            net = _lin(net, self.conv3)
+        net = net.view(B, K, vf, 3 + C)                         # the reference's transpose(2,1).view
         vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(B, K * vf, 3)
         vote_features = seed_rows.unsqueeze(2) + net[..., 3:]
         vote_features = vote_features.reshape(B, K * vf, C).transpose(2, 1).contiguous()

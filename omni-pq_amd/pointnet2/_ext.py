@@ -55,13 +55,22 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _stream():
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(device_index=None):
+    """The calling thread's current HIP stream as a raw handle (fast path: no Stream object)."""
+    if _raw_stream is not None:
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(device_index))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 # Optional per-call device timing (bench.py's roofline leg): when a list is installed here every
 # C-ABI call is bracketed by two events recorded on the stream the kernel is launched on.
 _timing_sink = None
+timing_tag = ""          # set by callers (e.g. "sa" inside the fused SA stage) to label sink entries
 
 
 def set_timing_sink(sink):
@@ -72,7 +81,8 @@ def set_timing_sink(sink):
 
 def _run(fn, anchor, *args):
     """Call a C-ABI entry point on `anchor`'s device and current stream; raise on error."""
-    if anchor.device.index != torch.cuda.current_device():
+    dev = anchor.device.index
+    if dev != torch.cuda.current_device():
         with torch.cuda.device(anchor.device):
             return _run(fn, anchor, *args)
     sink = _timing_sink
@@ -80,11 +90,11 @@ def _run(fn, anchor, *args):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = fn(*args, _stream())
+        rc = fn(*args, _stream(dev))
         e1.record()
-        sink.append((fn.__name__, tuple(a for a in args if isinstance(a, int)), e0, e1))
+        sink.append((fn.__name__ + timing_tag, tuple(a for a in args if isinstance(a, int)), e0, e1))
     else:
-        rc = fn(*args, _stream())
+        rc = fn(*args, _stream(dev))
     if rc != 0:
         raise RuntimeError(f"{fn.__name__} failed: {_lib.omnipq_error_string(rc).decode()} ({rc})")
 

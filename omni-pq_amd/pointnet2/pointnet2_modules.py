@@ -202,6 +202,10 @@ def _rows_mlp(shared_mlp, x_rows):
                 or tuple(conv.kernel_size) != (1, 1) or list(layer._modules.keys())[0] != "conv":
             return None
         plan.append((conv, bnw.bn))
+    import rows_mlp
+    stack = [rows_mlp.Layer(conv.weight, None, bn) for conv, bn in plan]
+    if rows_mlp.usable(x_rows, stack, shared_mlp.training):
+        return rows_mlp.run(x_rows, stack, shared_mlp.training)        # hand-written MFMA / BN kernels
     for conv, bn in plan:
         y = F.linear(x_rows, conv.weight.view(conv.out_channels, -1))
         if isinstance(bn, nn.BatchNorm2d):           # wants 4-D: (N, C) -> (N, C, 1, 1) is a free view

@@ -1,0 +1,194 @@
+"""Per-point MLPs on row-major activations, on the same hand-written HIP kernels as the fused SA stage.
+
+The reference applies its small per-point networks as stacks of kernel-size-1 convolutions with
+BatchNorm and ReLU on (B, C, K) tensors:
+    heads        Conv1d+BN+ReLU x2, then 4-7 output Conv1d        models/pq_transformer.py:62-121
+    pos. embed   Conv1d(3->288)+BN+ReLU, Conv1d(288->288)          models/pq_transformer.py:17-33
+    voting       Conv1d+BN+ReLU x2, Conv1d(288->291)               models/voting_module.py:32-53
+    FP layers    SharedMLP: Conv2d(1x1, no bias)+BN+ReLU x2        pointnet2/pointnet2_modules.py:356-416
+Here each stack is ONE autograd node over rows (points x channels, bf16): per layer a MFMA GEMM
+(`omnipq_gemm_nt_bf16[_bias]`), for BatchNorm layers the statistic / finalize / normalise+ReLU kernels of
+csrc/sa_stage.hip, and in backward the matching `bn_bwd_*` kernels, the data-gradient GEMM and the
+split-K weight-gradient GEMM.  Training-mode BatchNorm semantics are the reference's (batch statistics,
+momentum update of the running estimates, SyncBatchNorm all-reduce of the sums under a process group).  A
+linear bias that feeds a BatchNorm is never added: the batch mean removes it again; only the running
+mean accounts for it (and its gradient is exactly zero).
+
+Used under `torch.autocast("cuda", dtype=torch.bfloat16)`; otherwise callers keep PyTorch's f32 layers.
+"""
+import ctypes
+
+import torch
+
+import sa_fused
+from sa_fused import _allreduce_, _call, _gemm_tn, _lib, _p, _round_up, _world
+
+
+class Layer:
+    """One linear layer of the stack: weight (C_out, C_in[,1[,1]]), optional bias, optional BatchNorm
+    module (BatchNorm1d/2d/SyncBatchNorm; with it a ReLU follows, as everywhere in the reference)."""
+
+    def __init__(self, weight, bias=None, bn=None):
+        self.weight, self.bias, self.bn = weight, bias, bn
+
+
+def usable(x, layers, training):
+    """bf16 autocast on a GPU, training-mode BN (or no grad in eval), widths the kernels accept."""
+    if not x.is_cuda or not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.bfloat16:
+        return False
+    for lay in layers:
+        if lay.bn is not None:
+            bn = lay.bn
+            if bn.weight is None or bn.running_mean is None or bn.momentum is None:
+                return False
+            if lay.weight.shape[0] % 32 or lay.weight.shape[0] > 640:      # kernel limits (multiples of the K step)
+                return False
+            if not training and torch.is_grad_enabled():
+                return False
+    return True
+
+
+def run(x_rows, layers, training):
+    """x_rows (N, C_in) -> (N, C_out of the last layer), bf16."""
+    spec, params = [], []
+    for lay in layers:
+        bn = lay.bn
+        spec.append(None if bn is None else
+                    (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
+        params += [lay.weight, lay.bias, None if bn is None else bn.weight, None if bn is None else bn.bias]
+    return RowsMLP.apply(x_rows, spec, bool(training), *params)
+
+
+class _L:
+    __slots__ = ("K", "C", "Cp", "Wp", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias")
+
+
+class RowsMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec, training, *params):
+        dev = x.device
+        N, cin = x.shape
+        L = len(spec)
+        world = _world() if training else 1
+        K = _round_up(cin, 32)
+        if K == cin:
+            X = x.detach().to(torch.bfloat16).contiguous()
+        else:
+            X = torch.zeros((N, K), device=dev, dtype=torch.bfloat16)
+            X[:, :cin] = x.detach()
+        X0 = X
+        layers = []
+        for l in range(L):
+            W, bias, gamma, beta = params[4 * l:4 * l + 4]
+            lay = _L()
+            W2 = W.detach().reshape(W.shape[0], -1)
+            cout, wk = W2.shape
+            lay.C, lay.K, lay.Cp = cout, K, _round_up(cout, 32)
+            lay.has_bn, lay.has_bias = spec[l] is not None, bias is not None
+            if lay.Cp == cout and wk == K:
+                lay.Wp = W2.to(torch.bfloat16).contiguous()
+            else:
+                lay.Wp = torch.zeros((lay.Cp, K), device=dev, dtype=torch.bfloat16)
+                lay.Wp[:cout, :wk] = W2
+            Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
+            if lay.has_bias and not lay.has_bn:
+                bp = bias.detach().float()
+                if lay.Cp != cout:
+                    bp = torch.nn.functional.pad(bp, (0, lay.Cp - cout))
+                _call(_lib.omnipq_gemm_nt_bf16_bias, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp, _p(bp))
+            else:
+                _call(_lib.omnipq_gemm_nt_bf16, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp)
+            lay.Y = Y
+            if lay.has_bn:
+                rm, rv, nbt, momentum, eps = spec[l]
+                if lay.Cp != cout:
+                    raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
+                if training:
+                    sums = torch.empty((2, cout), device=dev, dtype=torch.float64)
+                    _call(_lib.omnipq_colstats, X, ctypes.c_longlong(N), cout, _p(Y), _p(sums))
+                    _allreduce_(sums)
+                    lay.a, lay.b = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+                    lay.mean, lay.invstd = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+                    cb = bias.detach().float().contiguous() if lay.has_bias else None
+                    _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(N) * world), _p(sums),
+                          _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                          _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(cb))
+                    if nbt is not None:
+                        nbt += 1
+                else:
+                    lay.invstd = torch.rsqrt(rv + eps)
+                    shift = rm - bias.detach().float() if lay.has_bias else rm
+                    lay.mean = shift
+                    lay.a = (gamma.detach() * lay.invstd).contiguous()
+                    lay.b = (beta.detach() - shift * lay.a).contiguous()
+                lay.X = torch.empty_like(Y)
+                _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
+                X = lay.X
+            else:
+                lay.X = Y
+                X = Y
+            K = lay.Cp
+            layers.append(lay)
+        ctx.layers, ctx.X0, ctx.geom = layers, X0, (N, cin, world)
+        ctx.wshapes = [tuple(params[4 * l].shape) for l in range(L)]
+        ctx.training = training
+        ctx.in_dtype = x.dtype
+        last = layers[-1]
+        return X if last.Cp == last.C else X[:, :last.C]
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.training and any(l.has_bn for l in ctx.layers):
+            raise RuntimeError("RowsMLP: backward through eval-mode BatchNorm is not supported")
+        N, cin, world = ctx.geom
+        layers = ctx.layers
+        L = len(layers)
+        dev = g.device
+        total = ctypes.c_double(float(N) * world)
+        grads = [None] * (4 * L)
+        last = layers[-1]
+        if last.Cp == last.C:
+            dcur = g.to(torch.bfloat16).contiguous()
+            if dcur.data_ptr() == g.data_ptr():
+                dcur = dcur.clone()            # the BatchNorm backward below works in place
+        else:
+            dcur = torch.zeros((N, last.Cp), device=dev, dtype=torch.bfloat16)
+            dcur[:, :last.C] = g
+        dx = None
+        for l in range(L - 1, -1, -1):
+            lay = layers[l]
+            Xin = layers[l - 1].X if l > 0 else ctx.X0
+            if lay.has_bn:
+                sums = torch.empty((3, lay.C), device=dev, dtype=torch.float64)
+                _call(_lib.omnipq_bn_bwd_stats, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y), _p(lay.a),
+                      _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
+                local = sums[:2].clone() if world > 1 else sums
+                _allreduce_(sums[:2])
+                grads[4 * l + 2] = local[1].float()
+                grads[4 * l + 3] = local[0].float()
+                if lay.has_bias:
+                    grads[4 * l + 1] = torch.zeros(lay.C, device=dev)       # removed by the batch mean
+                _call(_lib.omnipq_bn_bwd_apply, dcur, ctypes.c_longlong(N), lay.C, total, _p(dcur), _p(lay.Y),
+                      _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums), _p(dcur))
+            elif lay.has_bias:
+                sums = torch.empty((2, lay.Cp), device=dev, dtype=torch.float64)
+                _call(_lib.omnipq_colstats, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(sums))
+                grads[4 * l + 1] = sums[0, :lay.C].float()
+            dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N)
+            grads[4 * l] = dWp[:lay.C, :layers[l - 1].C if l > 0 else cin].reshape(ctx.wshapes[l])
+            if l > 0 or ctx.needs_input_grad[0]:
+                Wt = lay.Wp.t().contiguous()
+                dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
+                _call(_lib.omnipq_gemm_nt_bf16, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(Wt), lay.Cp, _p(dprev),
+                      lay.K)
+                if l > 0:
+                    dcur = dprev
+                else:
+                    dx = dprev[:, :cin].to(ctx.in_dtype)
+        # weight gradients in the parameters' own shapes
+        out = [dx, None, None]
+        for l in range(L):
+            for j in range(4):
+                out.append(grads[4 * l + j])
+        ctx.layers = None
+        return tuple(out)

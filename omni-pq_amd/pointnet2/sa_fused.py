@@ -36,6 +36,20 @@ def _call(fn, anchor, *args):
     _ext._run(fn, anchor, *args)
 
 
+class _tagged:
+    """Label the timing-sink entries of everything launched inside (bench.py's per-stage accounting)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        self.prev = _ext.timing_tag
+        _ext.timing_tag = self.tag
+
+    def __exit__(self, *exc):
+        _ext.timing_tag = self.prev
+
+
 def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -84,6 +98,12 @@ class FusedSAStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg, *params):
+        with _tagged("@sa"):
+            return FusedSAStage._forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg,
+                                         *params)
+
+    @staticmethod
+    def _forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg, *params):
         dev = xyz.device
         B, N, _ = xyz.shape
         M, S = idx.shape[1], idx.shape[2]
@@ -138,7 +158,7 @@ class FusedSAStage(torch.autograd.Function):
                 lay.invstd = torch.empty(cout, device=dev)
                 _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(P) * world), _p(sums),
                       _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
-                      _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd))
+                      _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(None))
                 if nbt is not None:
                     nbt += 1
             else:
@@ -180,6 +200,11 @@ class FusedSAStage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
+        with _tagged("@sa"):
+            return FusedSAStage._backward(ctx, g_out)
+
+    @staticmethod
+    def _backward(ctx, g_out):
         if not ctx.training:
             raise RuntimeError("FusedSAStage: backward in eval mode is not supported (use the composed path)")
         B, N, M, S, P, cin, kpad, inv_r, world = ctx.geom
@@ -191,11 +216,11 @@ class FusedSAStage(torch.autograd.Function):
         grads = [None] * (3 * L)
 
         last = layers[-1]
-        sums = torch.empty((2, last.C), device=dev, dtype=torch.float64)
+        sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
         _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
               _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
-        local = sums.clone() if world > 1 else sums
-        _allreduce_(sums)
+        local = sums[:2].clone() if world > 1 else sums
+        _allreduce_(sums[:2])
         grads[3 * (L - 1) + 1] = local[1].float()      # dgamma = sum dz * yhat   (local, DDP averages)
         grads[3 * (L - 1) + 2] = local[0].float()      # dbeta  = sum dz
         dY = torch.empty_like(last.Y)
@@ -222,11 +247,11 @@ class FusedSAStage(torch.autograd.Function):
             dX = _gemm_nt(dY, Wt, P, lay.K, lay.C)
             if l > 0:
                 prev = layers[l - 1]
-                sums = torch.empty((2, prev.C), device=dev, dtype=torch.float64)
+                sums = torch.empty((3, prev.C), device=dev, dtype=torch.float64)
                 _call(_lib.omnipq_bn_bwd_stats, dX, ctypes.c_longlong(P), prev.C, _p(dX), _p(prev.Y), _p(prev.a),
                       _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums))
-                local = sums.clone() if world > 1 else sums
-                _allreduce_(sums)
+                local = sums[:2].clone() if world > 1 else sums
+                _allreduce_(sums[:2])
                 grads[3 * (l - 1) + 1] = local[1].float()
                 grads[3 * (l - 1) + 2] = local[0].float()
                 _call(_lib.omnipq_bn_bwd_apply, dX, ctypes.c_longlong(P), prev.C, total, _p(dX), _p(prev.Y),
@@ -296,7 +321,8 @@ def eligible(module, xyz, features):
 
 def run(module, xyz, new_xyz, features):
     """ball query + fused stage -> (B, C_out, npoint) f32"""
-    idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
+    with _tagged("@sa"):
+        idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
     params, bn_cfg = [], []
     for layer in module.mlp_module:
         conv, bn = _bn_of(layer)

@@ -190,3 +190,62 @@ def test_graph_replay_reproduces_the_eager_step():
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-2 * abs(a), (l0, l1)
     assert rel_l2(g1, g0) < 5e-2
+
+
+@pytest.mark.parametrize("cin,widths,n", [(288, (288, 288, 97), 2048), (3, (288, 288), 8192), (288, (288, 288, 291), 8192),
+                                          (1024, (512, 288), 4096)])
+def test_rows_mlp_matches_f32_layers(cin, widths, n):
+    """rows_mlp.RowsMLP (linear [+BN+ReLU] stacks on the hand-written kernels) against the same stack in f32
+    PyTorch: outputs, every parameter gradient, the input gradient, BatchNorm running statistics.
+    Layer layout as in the reference's heads: all but the last layer are Linear(bias)+BN+ReLU."""
+    import rows_mlp
+    torch.manual_seed(cin + n)
+    d = dev()
+
+    def build():
+        torch.manual_seed(11)
+        lins, bns = [], []
+        c = cin
+        for i, w in enumerate(widths):
+            lins.append(torch.nn.Conv1d(c, w, 1).to(d))
+            bns.append(torch.nn.BatchNorm1d(w).to(d) if i < len(widths) - 1 else None)
+            if bns[-1] is not None:
+                with torch.no_grad():
+                    bns[-1].weight.uniform_(0.5, 1.5)
+                    bns[-1].bias.uniform_(-0.3, 0.3)
+            c = w
+        return lins, bns
+
+    x0 = torch.randn(n, cin, device=d)
+    g_up = torch.randn(n, widths[-1], device=d)
+
+    lins, bns = build()
+    x_ref = x0.clone().requires_grad_(True)
+    h = x_ref
+    for lin_, bn in zip(lins, bns):
+        h = torch.nn.functional.linear(h, lin_.weight.squeeze(-1), lin_.bias)
+        if bn is not None:
+            h = torch.relu(bn(h))
+    h.backward(g_up)
+    ref_out = h.detach()
+
+    lins2, bns2 = build()
+    x_got = x0.clone().requires_grad_(True)
+    stack = [rows_mlp.Layer(l.weight, l.bias, b) for l, b in zip(lins2, bns2)]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert rows_mlp.usable(x_got, stack, True)
+        y = rows_mlp.run(x_got, stack, True)
+    assert y.shape == ref_out.shape
+    y.float().backward(g_up)
+    assert rel_l2(y, ref_out) < 2e-2
+    assert rel_l2(x_got.grad, x_ref.grad) < 1e-1          # three bf16 layers deep
+    for a, b in zip(lins2, lins):
+        assert rel_l2(a.weight.grad, b.weight.grad) < 1e-1
+    # bias of the last (plain) layer has a real gradient; biases feeding a BatchNorm have exactly zero
+    assert rel_l2(lins2[-1].bias.grad, lins[-1].bias.grad) < 3e-2
+    for a, bn in zip(lins2[:-1], bns2[:-1]):
+        assert float(a.bias.grad.abs().max()) == 0.0
+    for a, b in zip(bns2[:-1], bns[:-1]):
+        assert rel_l2(a.weight.grad, b.weight.grad) < 1e-1 and rel_l2(a.bias.grad, b.bias.grad) < 1e-1
+        assert rel_l2(a.running_mean, b.running_mean) < 1e-2 and rel_l2(a.running_var, b.running_var) < 1e-2
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
