@@ -55,7 +55,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
     ap.add_argument("--graph", default="auto", choices=["auto", "off", "on"],
                     help="replay the whole fwd+bwd step from a captured hipGraph; auto = on for a single "
-                         "process, off under torch.distributed (collectives inside the step stay eager)")
+                         "process and, under torch.distributed, on iff tools/rccl_graph_probe.py shows that RCCL "
+                         "collectives replay correctly from a graph on this node (else eager DDP)")
+    ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--breakdown", action="store_true", help="print a per-operator table to stderr")
     return ap.parse_args()
 
@@ -198,9 +200,58 @@ def cpu_baseline(args):
         pointnet2_utils._ext = saved
 
 
-def make_step(net, model, pool, args, amp_dtype, world):
+def probe_rccl_graph(timeout):
+    """Run tools/rccl_graph_probe.py in a child of THIS rank (same rank / world, rendezvous on the next
+    port), before this process touches the GPU.  True iff it exits 0 in time; a stuck child is killed
+    by pid."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+        env.pop(k, None)
+    child = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "rccl_graph_probe.py")], env=env,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        return child.wait(timeout=timeout) == 0
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.wait()
+        return False
+
+
+class GraphUnavailable(RuntimeError):
+    """Raised on EVERY rank when any rank could not capture the step."""
+
+
+class FlatGradients:
+    """Data parallelism for the captured step: after backward every rank's gradients are packed into one
+    flat f32 buffer, summed with ONE all-reduce over RCCL and averaged -- what DistributedDataParallel's
+    buckets compute (train.py:382), as a single large collective that a graph can hold.  The averaged
+    gradients are handed back as views of the flat buffer."""
+
+    def __init__(self, net, world):
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.world = world
+        self.flat = None
+
+    def reduce(self):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        self.flat = torch.cat([g.reshape(-1).float() for g in grads])
+        dist.all_reduce(self.flat)
+        self.flat.mul_(1.0 / self.world)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+
+def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_graph=False):
     """-> (step(i) -> loss tensor, launch mode string).  Eager: forward, loss, prefetch of the next
-    batch's sampling, backward.  Graph (single process): the same sequence captured once and replayed."""
+    batch's sampling, backward.  Graph: the same sequence captured once and replayed -- always for a
+    single process; under torch.distributed only when `dist_graph` (the probe passed), with the
+    SyncBatchNorm all-reduces and the flat gradient all-reduce inside the graph."""
     def step(i):
         for p in net.parameters():
             p.grad = None
@@ -215,8 +266,9 @@ def make_step(net, model, pool, args, amp_dtype, world):
         loss.backward()
         return loss
 
-    use_graph = args.graph in ("on", "auto") and world == 1
+    use_graph = args.graph in ("on", "auto") and (not distributed or dist_graph)
     if use_graph:
+        flat = FlatGradients(net, world) if distributed else None
         # The whole step (forward, loss, next batch's sampling, backward; ~3000 launches) is captured ONCE
         # into a hipGraph and replayed: same kernels, same order, no per-launch host work.  Two static
         # input buffers: `cur` feeds forward/backward, `nxt` feeds the sampling plan of the following
@@ -236,6 +288,8 @@ def make_step(net, model, pool, args, amp_dtype, world):
                 net.prefetch({"point_clouds": nxt}, trusted=True)
             loss.backward()
             net.join_prefetch()
+            if flat is not None:
+                flat.reduce()
             return loss
 
         def feed(i):
@@ -249,9 +303,25 @@ def make_step(net, model, pool, args, amp_dtype, world):
             feed(i)
             graph_body()
         torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = graph_body()
+        captured = True
+        try:
+            with torch.cuda.graph(graph):
+                static_loss = graph_body()
+        except Exception as exc:       # noqa: BLE001 -- whatever refused the capture, the eager path still works
+            if not distributed:
+                raise
+            captured = False
+            print(f"bench.py: graph capture failed on this rank ({exc!r}); falling back to eager", file=sys.stderr)
+        if distributed:
+            flag = torch.tensor([1 if captured else 0], device=cur.device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not bool(flag.item()):
+                raise GraphUnavailable()
 
         def step(i):                                   # noqa: F811
             feed(i)
@@ -274,15 +344,30 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_rec = cpu_baseline(args)
 
+    force_dist = os.environ.get("OMNIPQ_BENCH_FORCE_DIST") == "1"      # single-rank exercise of the N>1 path
+    probe_ok = False
+    if (world > 1 or force_dist) and args.graph != "off":
+        probe_ok = probe_rccl_graph(args.probe_timeout)
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        # every rank must take the same path: graph only if ALL probes passed
+        flag = torch.tensor([1 if probe_ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        probe_ok = bool(flag.item())
 
     import pointnet2_utils
     import synth
+    if force_dist:
+        import sa_fused
+        sa_fused._FORCE_COLLECTIVES = True
     ext = pointnet2_utils._ext
     assert ext.__name__ == "pointnet2._ext", "the product binding must be the one that runs"
 
@@ -290,7 +375,12 @@ def main():
     net = build_model(args.extra_channels).to(dev)
     net.train()
     model = net
-    if world > 1:
+    distributed = world > 1 or force_dist
+    dist_graph = distributed and probe_ok and args.graph != "off"
+    if distributed and dist_graph:
+        for p in net.parameters():             # what DDP's constructor does: rank 0's initial weights everywhere
+            dist.broadcast(p.data, 0)
+    elif distributed:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank],
                                                           broadcast_buffers=False)   # train.py:382
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
@@ -299,11 +389,19 @@ def main():
     pool = [synth.make_clouds(100 + i, args.batch, args.points, extra_channels=args.extra_channels,
                               kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
 
-    step, launch_mode = make_step(net, model, pool, args, amp_dtype, world)
+    try:
+        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, dist_graph)
+    except GraphUnavailable:
+        dist_graph = False
+        for p in net.parameters():
+            p.grad = None
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
+        args.graph = "off"
+        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, False)
     use_graph = launch_mode != "eager"
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -355,6 +453,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "launch": "hipGraph replay" if use_graph else "eager",
+            "data_parallel": (None if not distributed else
+                              "SyncBN + one flat gradient all-reduce, all inside the graph (RCCL graph probe passed)"
+                              if use_graph else
+                              "DistributedDataParallel, eager" + (" (RCCL graph probe passed)" if probe_ok else
+                                                                  " (RCCL graph probe failed or skipped)")),
             "config": {"workload": f"BASELINE configs[1]: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
                                    f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,
@@ -387,9 +490,12 @@ def main():
                           f"  {nb / (ms_ / calls_ * 1e-3) / 1e9 if ms_ > 0 else 0:9.1f} GB/s", file=sys.stderr)
         if cpu_rec is not None:
             rec["cpu_baseline"] = cpu_rec
-        print(json.dumps(rec), flush=True)
-    if world > 1:
+    if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stderr.flush()
+        print(json.dumps(rec), flush=True)      # the last line of stdout
 
 
 if __name__ == "__main__":

@@ -50,8 +50,20 @@ long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                         float *workspace, void *stream);
 
-/* sums[0][c] = sum_p Y[p][c], sums[1][c] = sum_p Y[p][c]^2  (f64, zeroed by the call). */
+/* sums[0][c] = sum_p Y[p][c], sums[1][c] = sum_p Y[p][c]^2  (f64, zeroed by the call; the _z variant
+ * trusts the caller that sums[0..2C) is already zero and saves the memset launch). */
 int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);
+int omnipq_colstats_z(long long P, int C, const void *Y, double *sums, void *stream);
+
+/* Weight preparation in one pass: W f32 [cout][cin] (row pitch ldw) -> Wp bf16 [cp][k] zero-padded with its
+ * columns rotated left by `rot` (SA layer 0: [xyz, feat] -> [feat, xyz]) and, if Wt != NULL, Wt bf16 [k][cp]
+ * = Wp^T.  omnipq_unprep_wgrad undoes padding and rotation for the f32 weight gradient. */
+int omnipq_prep_weight(int cout, int cin, int ldw, int cp, int k, int rot, const float *W, void *Wp, void *Wt,
+                       void *stream);
+int omnipq_unprep_wgrad(int cout, int cin, int k, int rot, const float *dWp, float *dW, void *stream);
+
+/* dbeta[c] = (float) sums[c], dgamma[c] = (float) sums[C + c] */
+int omnipq_sums_to_f32(int C, const double *sums, float *dbeta, float *dgamma, void *stream);
 
 /* BatchNorm training-mode bookkeeping from (possibly all-reduced) sums over `count` positions:
  * a = gamma*invstd, b = beta - mean*a, saved mean/invstd, running-stat update (NULL to skip). */
@@ -81,6 +93,8 @@ int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions,
 /* backward of ReLU + BatchNorm for the inner layers (dX -> dY, may be in place) */
 int omnipq_bn_bwd_stats(long long P, int C, const void *dX, const void *Y, const float *a, const float *b,
                         const float *mean, const float *invstd, double *sums, void *stream);
+int omnipq_bn_bwd_stats_z(long long P, int C, const void *dX, const void *Y, const float *a, const float *b,
+                          const float *mean, const float *invstd, double *sums, void *stream);
 int omnipq_bn_bwd_apply(long long P, int C, double total_positions, const void *dX, const void *Y,
                         const float *a, const float *b, const float *mean, const float *invstd,
                         const double *sums, void *dY, void *stream);

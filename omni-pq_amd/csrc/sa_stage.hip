@@ -267,6 +267,45 @@ __global__ void bwd_means_kernel(int n2, double invP, const double *__restrict__
   if (i < n2) st[i] = (float)(sums[i] * invP);
 }
 
+// weight preparation for the GEMMs, one pass: W f32 [cout][cin] (row pitch ldw) ->
+//   Wp bf16 [cp][k]   zero-padded, columns rotated left by `rot` (SA layer 0: [xyz(3), feat] -> [feat, xyz])
+//   Wt bf16 [k][cp]   its transpose (operand of the data-gradient GEMM)
+__global__ __launch_bounds__(256) void prep_weight_kernel(int cout, int cin, int ldw, int cp, int k, int rot,
+                                                         const float *__restrict__ W, bf16_t *__restrict__ Wp,
+                                                         bf16_t *__restrict__ Wt) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= cp * k) return;
+  const int r = i / k, c = i - r * k;
+  float v = 0.f;
+  if (r < cout && c < cin) {
+    const int src = c < cin - rot ? c + rot : c - (cin - rot);
+    v = W[(size_t)r * ldw + src];
+  }
+  const bf16_t h = (bf16_t)v;
+  Wp[i] = h;
+  if (Wt) Wt[(size_t)c * cp + r] = h;
+}
+
+// inverse of the padding / rotation for the weight gradient: dWp f32 [cp][k] -> dW f32 [cout][cin]
+__global__ __launch_bounds__(256) void unprep_wgrad_kernel(int cout, int cin, int k, int rot,
+                                                          const float *__restrict__ dWp, float *__restrict__ dW) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= cout * cin) return;
+  const int r = i / cin, src = i - r * cin;                      // src = column in the parameter
+  const int c = src >= rot ? src - rot : src + (cin - rot);      // column in the rotated, padded matrix
+  dW[i] = dWp[(size_t)r * k + c];
+}
+
+// f64 totals -> f32 vectors (BatchNorm affine gradients: dbeta = sum dz, dgamma = sum dz*yhat)
+__global__ void sums_to_f32_kernel(int C, const double *__restrict__ sums, float *__restrict__ dbeta,
+                                   float *__restrict__ dgamma) {
+  const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (c < C) {
+    dbeta[c] = (float)sums[c];
+    dgamma[c] = (float)sums[C + c];
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, int m, int s, int C,
                                                             const bf16_t *__restrict__ Y,
                                                             const float *__restrict__ a,
@@ -556,10 +595,21 @@ extern "C" int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, f
   return OMNIPQ_OK;
 }
 
+// `zeroed` != 0: the caller guarantees sums[0 .. 2C) is already zero (e.g. a slice of an arena cleared once
+// per step), so the call does not spend a memset launch on it.
+static int colstats_impl(long long P, int C, const void *Y, double *sums, int zeroed, void *stream);
+
 extern "C" int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream) {
+  return colstats_impl(P, C, Y, sums, 0, stream);
+}
+extern "C" int omnipq_colstats_z(long long P, int C, const void *Y, double *sums, void *stream) {
+  return colstats_impl(P, C, Y, sums, 1, stream);
+}
+
+static int colstats_impl(long long P, int C, const void *Y, double *sums, int zeroed, void *stream) {
   if (P < 0 || C <= 0 || (C % 8) || C > kMaxC || C < 16) return OMNIPQ_EINVAL;
   if (!Y || !sums) return OMNIPQ_EINVAL;
-  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (!zeroed) OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (P == 0) return OMNIPQ_OK;
   const int rpb = rows_per_block(C);
   (void)rpb;
@@ -636,12 +686,25 @@ extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total
   return OMNIPQ_OK;
 }
 
+static int bn_bwd_stats_impl(long long P, int C, const void *dX, const void *Y, const float *a, const float *b,
+                             const float *mean, const float *invstd, double *sums, int zeroed, void *stream);
+
 extern "C" int omnipq_bn_bwd_stats(long long P, int C, const void *dX, const void *Y, const float *a,
                                    const float *b, const float *mean, const float *invstd, double *sums,
                                    void *stream) {
+  return bn_bwd_stats_impl(P, C, dX, Y, a, b, mean, invstd, sums, 0, stream);
+}
+extern "C" int omnipq_bn_bwd_stats_z(long long P, int C, const void *dX, const void *Y, const float *a,
+                                     const float *b, const float *mean, const float *invstd, double *sums,
+                                     void *stream) {
+  return bn_bwd_stats_impl(P, C, dX, Y, a, b, mean, invstd, sums, 1, stream);
+}
+
+static int bn_bwd_stats_impl(long long P, int C, const void *dX, const void *Y, const float *a, const float *b,
+                             const float *mean, const float *invstd, double *sums, int zeroed, void *stream) {
   if (P < 0 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
   if (!dX || !Y || !a || !b || !mean || !invstd || !sums) return OMNIPQ_EINVAL;
-  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (!zeroed) OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (P == 0) return OMNIPQ_OK;
   const int rpb = rows_per_block(C);
   (void)rpb;
@@ -725,5 +788,30 @@ extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kp
       OMNIPQ_LAUNCH_CHECK();
     }
   }
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_prep_weight(int cout, int cin, int ldw, int cp, int k, int rot, const float *W, void *Wp,
+                                  void *Wt, void *stream) {
+  if (cout <= 0 || cin <= 0 || cp < cout || k < cin || rot < 0 || rot > cin || !W || !Wp) return OMNIPQ_EINVAL;
+  const int n = cp * k;
+  prep_weight_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, ldw, cp, k, rot, W, (bf16_t *)Wp,
+                                                                   (bf16_t *)Wt);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_unprep_wgrad(int cout, int cin, int k, int rot, const float *dWp, float *dW, void *stream) {
+  if (cout <= 0 || cin <= 0 || k < cin || rot < 0 || rot > cin || !dWp || !dW) return OMNIPQ_EINVAL;
+  const int n = cout * cin;
+  unprep_wgrad_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, k, rot, dWp, dW);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sums_to_f32(int C, const double *sums, float *dbeta, float *dgamma, void *stream) {
+  if (C <= 0 || !sums || !dbeta || !dgamma) return OMNIPQ_EINVAL;
+  sums_to_f32_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, sums, dbeta, dgamma);
+  OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -21,7 +21,8 @@ import ctypes
 import torch
 
 import sa_fused
-from sa_fused import _allreduce_, _call, _gemm_tn, _lib, _p, _round_up, _world
+from sa_fused import (_allreduce_, _call, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
+                      unprep_wgrad, zeros_f32, zeros_f64)
 
 
 class Layer:
@@ -60,7 +61,7 @@ def run(x_rows, layers, training):
 
 
 class _L:
-    __slots__ = ("K", "C", "Cp", "Wp", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias")
+    __slots__ = ("K", "C", "Cp", "Wp", "Wt", "wk", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias")
 
 
 class RowsMLP(torch.autograd.Function):
@@ -84,12 +85,8 @@ class RowsMLP(torch.autograd.Function):
             W2 = W.detach().reshape(W.shape[0], -1)
             cout, wk = W2.shape
             lay.C, lay.K, lay.Cp = cout, K, _round_up(cout, 32)
-            lay.has_bn, lay.has_bias = spec[l] is not None, bias is not None
-            if lay.Cp == cout and wk == K:
-                lay.Wp = W2.to(torch.bfloat16).contiguous()
-            else:
-                lay.Wp = torch.zeros((lay.Cp, K), device=dev, dtype=torch.bfloat16)
-                lay.Wp[:cout, :wk] = W2
+            lay.has_bn, lay.has_bias, lay.wk = spec[l] is not None, bias is not None, wk
+            lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training)
             Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
             if lay.has_bias and not lay.has_bn:
                 bp = bias.detach().float()
@@ -104,8 +101,8 @@ class RowsMLP(torch.autograd.Function):
                 if lay.Cp != cout:
                     raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
                 if training:
-                    sums = torch.empty((2, cout), device=dev, dtype=torch.float64)
-                    _call(_lib.omnipq_colstats, X, ctypes.c_longlong(N), cout, _p(Y), _p(sums))
+                    sums = zeros_f64(2, cout, dev)
+                    _call(_lib.omnipq_colstats_z, X, ctypes.c_longlong(N), cout, _p(Y), _p(sums))
                     _allreduce_(sums)
                     lay.a, lay.b = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
                     lay.mean, lay.invstd = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
@@ -159,28 +156,25 @@ class RowsMLP(torch.autograd.Function):
             lay = layers[l]
             Xin = layers[l - 1].X if l > 0 else ctx.X0
             if lay.has_bn:
-                sums = torch.empty((3, lay.C), device=dev, dtype=torch.float64)
-                _call(_lib.omnipq_bn_bwd_stats, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y), _p(lay.a),
+                sums = zeros_f64(3, lay.C, dev)
+                _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y), _p(lay.a),
                       _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
-                local = sums[:2].clone() if world > 1 else sums
+                grads[4 * l + 2], grads[4 * l + 3] = affine_grads(sums, lay.C)       # local totals
                 _allreduce_(sums[:2])
-                grads[4 * l + 2] = local[1].float()
-                grads[4 * l + 3] = local[0].float()
                 if lay.has_bias:
-                    grads[4 * l + 1] = torch.zeros(lay.C, device=dev)       # removed by the batch mean
+                    grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
                 _call(_lib.omnipq_bn_bwd_apply, dcur, ctypes.c_longlong(N), lay.C, total, _p(dcur), _p(lay.Y),
                       _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums), _p(dcur))
             elif lay.has_bias:
-                sums = torch.empty((2, lay.Cp), device=dev, dtype=torch.float64)
-                _call(_lib.omnipq_colstats, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(sums))
+                sums = zeros_f64(2, lay.Cp, dev)
+                _call(_lib.omnipq_colstats_z, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(sums))
                 grads[4 * l + 1] = sums[0, :lay.C].float()
             dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N)
-            grads[4 * l] = dWp[:lay.C, :layers[l - 1].C if l > 0 else cin].reshape(ctx.wshapes[l])
+            grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             if l > 0 or ctx.needs_input_grad[0]:
-                Wt = lay.Wp.t().contiguous()
                 dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
-                _call(_lib.omnipq_gemm_nt_bf16, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(Wt), lay.Cp, _p(dprev),
-                      lay.K)
+                _call(_lib.omnipq_gemm_nt_bf16, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
+                      _p(dprev), lay.K)
                 if l > 0:
                     dcur = dprev
                 else:

@@ -54,8 +54,11 @@ def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+_FORCE_COLLECTIVES = False       # test hook: issue the SyncBatchNorm all-reduces even over a 1-rank group
+
+
 def _allreduce_(sums):
-    if _world() > 1:
+    if _world() > 1 or (_FORCE_COLLECTIVES and dist.is_initialized()):
         dist.all_reduce(sums)
     return sums
 
@@ -77,6 +80,68 @@ def _gemm_tn(A, B, M, N, P):
     ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=A.device, dtype=torch.float32)
     _call(_lib.omnipq_gemm_tn_bf16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
     return C
+
+
+class _ZeroPool:
+    """Zero-initialised scratch handed out in slices that are used once and never recycled: a chunk is
+    cleared by ONE memset when it is allocated, instead of one memset per statistics buffer (a training
+    step asks for ~200 of them).  A slice keeps its chunk alive; chunks are a few hundred KB."""
+
+    def __init__(self, dtype, chunk):
+        self.dtype, self.chunk = dtype, chunk
+        self.buf, self.used, self.key = None, 0, None
+
+    def take(self, n, device):
+        key = (device, torch.cuda.current_stream(device).cuda_stream, torch.cuda.is_current_stream_capturing())
+        n8 = _round_up(n, 16)
+        if self.buf is None or self.key != key or self.used + n8 > self.buf.numel():
+            self.buf = torch.zeros(max(self.chunk, n8), device=device, dtype=self.dtype)
+            self.used, self.key = 0, key
+        out = self.buf[self.used:self.used + n]
+        self.used += n8
+        return out
+
+
+_ZEROS_F64 = _ZeroPool(torch.float64, 1 << 16)
+_ZEROS_F32 = _ZeroPool(torch.float32, 1 << 15)
+
+
+def zeros_f64(rows, cols, device):
+    return _ZEROS_F64.take(rows * cols, device).view(rows, cols)
+
+
+def zeros_f32(n, device):
+    return _ZEROS_F32.take(n, device)
+
+
+def prep_weight(W2, cp, k, rot=0, transpose=True):
+    """f32 (cout, cin) parameter -> bf16 [cp][k] (zero-padded, columns rotated left by rot) and its
+    transpose [k][cp], in one launch."""
+    W2 = W2.detach()
+    if W2.dtype != torch.float32 or W2.stride(1) != 1:
+        W2 = W2.float().contiguous()
+    cout, cin = W2.shape
+    Wp = torch.empty((cp, k), device=W2.device, dtype=torch.bfloat16)
+    Wt = torch.empty((k, cp), device=W2.device, dtype=torch.bfloat16) if transpose else None
+    _call(_lib.omnipq_prep_weight, W2, cout, cin, W2.stride(0), cp, k, rot, _p(W2), _p(Wp), _p(Wt))
+    return Wp, Wt
+
+
+def unprep_wgrad(dWp, cout, cin, rot, shape):
+    """f32 [cp][k] gradient of the prepared weight -> gradient in the parameter's own shape."""
+    cp, k = dWp.shape
+    if cp == cout and k == cin and rot == 0:
+        return dWp.view(shape)
+    dW = torch.empty(shape, device=dWp.device, dtype=torch.float32)
+    _call(_lib.omnipq_unprep_wgrad, dWp, cout, cin, k, rot, _p(dWp), _p(dW))
+    return dW
+
+
+def affine_grads(sums, C):
+    """(dgamma, dbeta) f32 from the local f64 totals [sum dz | sum dz*yhat]."""
+    both = torch.empty((2, C), device=sums.device, dtype=torch.float32)
+    _call(_lib.omnipq_sums_to_f32, sums, C, _p(sums), _p(both[0]), _p(both[1]))
+    return both[1], both[0]
 
 
 # position-major bf16 copy of the last fused stage's output, keyed by (data_ptr, shape) of the tensor it
@@ -134,23 +199,16 @@ class FusedSAStage(torch.autograd.Function):
             lay = _Layer()
             W2 = W.detach().reshape(W.shape[0], -1)
             cout = W2.shape[0]
-            if l == 0:
-                # the reference concatenates [xyz(3), features(cin)] (pointnet2_utils.py:357-359); the
-                # gathered rows are [features(cin), xyz(3), 0-pad] so that feature pieces stay 16-byte
-                # aligned -- permute the weight columns to match
-                Wp = torch.zeros((cout, kpad), device=dev, dtype=torch.float32)
-                Wp[:, :cin] = W2[:, 3:]
-                Wp[:, cin:cin + 3] = W2[:, :3]
-                K = kpad
-            else:
-                Wp = W2
-                K = W2.shape[1]
+            # the reference concatenates [xyz(3), features(cin)] (pointnet2_utils.py:357-359); the
+            # gathered rows are [features(cin), xyz(3), 0-pad] so that feature pieces stay 16-byte
+            # aligned -- layer 0 rotates the weight columns to match
+            K = kpad if l == 0 else W2.shape[1]
             lay.K, lay.C = K, cout
-            lay.Wp = Wp.to(torch.bfloat16).contiguous()
+            lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=training)
             lay.Y = _gemm_nt(X, lay.Wp, P, cout, K)
             if training:
-                sums = torch.empty((2, cout), device=dev, dtype=torch.float64)
-                _call(_lib.omnipq_colstats, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(sums))
+                sums = zeros_f64(2, cout, dev)
+                _call(_lib.omnipq_colstats_z, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(sums))
                 _allreduce_(sums)
                 lay.a = torch.empty(cout, device=dev)
                 lay.b = torch.empty(cout, device=dev)
@@ -219,10 +277,9 @@ class FusedSAStage(torch.autograd.Function):
         sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
         _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
               _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
-        local = sums[:2].clone() if world > 1 else sums
+        # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
+        grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
         _allreduce_(sums[:2])
-        grads[3 * (L - 1) + 1] = local[1].float()      # dgamma = sum dz * yhat   (local, DDP averages)
-        grads[3 * (L - 1) + 2] = local[0].float()      # dbeta  = sum dz
         dY = torch.empty_like(last.Y)
         _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
               _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
@@ -232,28 +289,20 @@ class FusedSAStage(torch.autograd.Function):
             lay = layers[l]
             Xin = layers[l - 1].X if l > 0 else ctx.X0
             dWp = _gemm_tn(dY, Xin, lay.C, lay.K, P)                        # [Cout][K]
-            if l == 0:
-                dW = torch.empty((lay.C, cin + 3), device=dev, dtype=torch.float32)
-                dW[:, 3:] = dWp[:, :cin]
-                dW[:, :3] = dWp[:, cin:cin + 3]
-            else:
-                dW = dWp
-            grads[3 * l] = dW.reshape(lay.C, -1, 1, 1)
+            wk = cin + 3 if l == 0 else lay.K
+            grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
             need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \
                 (ctx.has_features and ctx.needs_input_grad[2])
             if l == 0 and not need_in:
                 break
-            Wt = lay.Wp.t().contiguous()                                    # [K][Cout]
-            dX = _gemm_nt(dY, Wt, P, lay.K, lay.C)
+            dX = _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)                      # Wt = [K][Cout]
             if l > 0:
                 prev = layers[l - 1]
-                sums = torch.empty((3, prev.C), device=dev, dtype=torch.float64)
-                _call(_lib.omnipq_bn_bwd_stats, dX, ctypes.c_longlong(P), prev.C, _p(dX), _p(prev.Y), _p(prev.a),
+                sums = zeros_f64(3, prev.C, dev)
+                _call(_lib.omnipq_bn_bwd_stats_z, dX, ctypes.c_longlong(P), prev.C, _p(dX), _p(prev.Y), _p(prev.a),
                       _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums))
-                local = sums[:2].clone() if world > 1 else sums
+                grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = affine_grads(sums, prev.C)
                 _allreduce_(sums[:2])
-                grads[3 * (l - 1) + 1] = local[1].float()
-                grads[3 * (l - 1) + 2] = local[0].float()
                 _call(_lib.omnipq_bn_bwd_apply, dX, ctypes.c_longlong(P), prev.C, total, _p(dX), _p(prev.Y),
                       _p(prev.a), _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums), _p(dX))
                 dY = dX

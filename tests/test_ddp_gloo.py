@@ -71,6 +71,15 @@ def _worker(rank, world, port, out_dir):
         want = torch.stack(gathered).mean(0)
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), float((got - want).abs().max())
 
+        # 2b) bench.py's data parallelism for the captured step (one flat all-reduce) == DDP's averaging
+        sys.path.insert(0, os.path.dirname(HERE))
+        import bench
+        flat = bench.FlatGradients(solo, world)
+        flat.reduce()
+        got_flat = torch.cat([p.grad.reshape(-1) for p in solo.parameters()])
+        assert torch.allclose(got_flat, want, rtol=1e-6, atol=1e-8), float((got_flat - want).abs().max())
+        assert all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in solo.parameters())
+
         # 3) the statistics all-reduce of the fused SA stage (SyncBatchNorm semantics)
         sums = torch.full((2, 5), float(rank + 1), dtype=torch.float64)
         sa_fused._allreduce_(sums)
