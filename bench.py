@@ -494,6 +494,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # RCCL's version banner sits in C stdio's buffer: out with it first
         sys.stderr.flush()
         print(json.dumps(rec), flush=True)      # the last line of stdout
 

@@ -50,6 +50,13 @@ long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                         float *workspace, void *stream);
 
+/* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares
+ * of the bf16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of
+ * omnipq_gemm_nt_stats_workspace_floats(M, N) elements (0 for few rows: then it may be NULL). */
+long long omnipq_gemm_nt_stats_workspace_floats(int M, int N);
+int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+                              int ldc, const float *bias, double *sums, float *workspace, void *stream);
+
 /* sums[0][c] = sum_p Y[p][c], sums[1][c] = sum_p Y[p][c]^2  (f64, zeroed by the call; the _z variant
  * trusts the caller that sums[0..2C) is already zero and saves the memset launch). */
 int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);

@@ -39,11 +39,16 @@ struct GemmArgs {
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
-template <bool OUT_F32>
+// STATS (bf16 output only): per-column sum and sum of squares of the ROUNDED tile values, folded into the
+// store loop -- the BatchNorm statistics of the layer without a second pass over the tensor.
+//   1: atomically added to stats_out = double[2][N]          (few M-tiles: little contention)
+//   2: written to stats_out = float[m_tiles][2][N] partials  (many M-tiles: partial_reduce_kernel sums them)
+template <bool OUT_F32, int STATS = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
-                                                        const float *__restrict__ bias) {
+                                                        const float *__restrict__ bias,
+                                                        void *__restrict__ stats_out = nullptr) {
   // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
   constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
   constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
@@ -201,15 +206,69 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     const bf16_t *ct = reinterpret_cast<const bf16_t *>(smem);
     __syncthreads();
     bf16_t *C = reinterpret_cast<bf16_t *>(Cout);
+    float cs[8], cs2[8];                   // this thread's 8 columns (piece = tid & 15), rows tid>>4 + 16*it
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cs2[e] = 0.f;
     for (int q = tid; q < 128 * 16; q += 256) {
       const int row = q >> 4, piece = q & 15;
       const int gr = m0 + row, gc = n0 + piece * 8;
       if (gr < g.M && gc < g.N) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * GCPITCH + piece * 8);
         *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
+        if (STATS) {
+          const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __builtin_bit_cast(float, w[e] << 16), hi = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            cs[2 * e] += lo;
+            cs2[2 * e] += lo * lo;
+            cs[2 * e + 1] += hi;
+            cs2[2 * e + 1] += hi * hi;
+          }
+        }
+      }
+    }
+    if (STATS) {
+      __syncthreads();                     // the C tile is dead: reuse it as [16 row groups][2][128] floats
+      float *red = reinterpret_cast<float *>(smem);
+      const int rg = tid >> 4, piece = tid & 15;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(rg * 2 + 0) * 128 + piece * 8 + e] = cs[e];
+        red[(rg * 2 + 1) * 128 + piece * 8 + e] = cs2[e];
+      }
+      __syncthreads();
+      const int which = tid >> 7, col = tid & 127;
+      float tot = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot += red[(r * 2 + which) * 128 + col];
+      if (n0 + col < g.N) {
+        if (STATS == 1)
+          atomicAdd(reinterpret_cast<double *>(stats_out) + (size_t)which * g.N + n0 + col, (double)tot);
+        else
+          reinterpret_cast<float *>(stats_out)[((size_t)mt * 2 + which) * g.N + n0 + col] = tot;
       }
     }
   }
+}
+
+// sums[j] += sum over the M-tiles of part[t][j],  j in [0, 2N): grid (ceil(2N/256), slabs)
+__global__ __launch_bounds__(256) void partial_reduce_kernel(int m_tiles, int n2, const float *__restrict__ part,
+                                                            double *__restrict__ sums) {
+  const int j = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (j >= n2) return;
+  const int per = (m_tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = (int)blockIdx.y * per;
+  int t1 = t0 + per;
+  if (t1 > m_tiles) t1 = m_tiles;
+  float acc0 = 0.f, acc1 = 0.f;
+  int t = t0;
+  for (; t + 1 < t1; t += 2) {
+    acc0 += part[(size_t)t * n2 + j];
+    acc1 += part[(size_t)(t + 1) * n2 + j];
+  }
+  if (t < t1) acc0 += part[(size_t)t * n2 + j];
+  if (t0 < t1) atomicAdd(sums + j, (double)acc0 + (double)acc1);
 }
 
 // sums the split-K slabs:  out[i] = sum_z part[z][i]
@@ -235,6 +294,46 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// M-tile count up to which the statistics go straight to f64 atomics (<= 64 adds per address)
+static constexpr int kStatsDirectTiles = 64;
+
+extern "C" long long omnipq_gemm_nt_stats_workspace_floats(int M, int N) {
+  const long long m_tiles = (M + omnipq::GBM - 1) / omnipq::GBM;
+  return m_tiles <= kStatsDirectTiles ? 0 : m_tiles * 2 * (long long)N;
+}
+
+// C = A B^T (+ bias) as above, and sums[0][n] += sum_m C[m][n], sums[1][n] += sum_m C[m][n]^2 over the bf16
+// values actually stored.  `sums` (double[2][N]) must be zero on entry; `workspace` holds
+// omnipq_gemm_nt_stats_workspace_floats(M, N) floats (may be NULL when that is 0).
+extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                         void *C, int ldc, const float *bias, double *sums, float *workspace,
+                                         void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !sums || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  if (g.m_tiles <= kStatsDirectTiles) {
+    gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+                                                                sums);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (!workspace) return OMNIPQ_EINVAL;
+  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+                                                              workspace);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  if (slabs < 1) slabs = 1;
+  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
+                                                                                    sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

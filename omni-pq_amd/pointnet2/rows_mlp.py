@@ -21,7 +21,7 @@ import ctypes
 import torch
 
 import sa_fused
-from sa_fused import (_allreduce_, _call, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
+from sa_fused import (_allreduce_, _call, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
                       unprep_wgrad, zeros_f32, zeros_f64)
 
 
@@ -87,8 +87,17 @@ class RowsMLP(torch.autograd.Function):
             lay.C, lay.K, lay.Cp = cout, K, _round_up(cout, 32)
             lay.has_bn, lay.has_bias, lay.wk = spec[l] is not None, bias is not None, wk
             lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training)
-            Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
-            if lay.has_bias and not lay.has_bn:
+            if lay.has_bn and lay.Cp != cout:
+                raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
+            sums = None
+            if lay.has_bn and training:
+                sums = zeros_f64(2, cout, dev)
+                Y = _gemm_nt_stats(X, lay.Wp, N, lay.Cp, K, sums)
+            else:
+                Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
+            if sums is not None:
+                pass
+            elif lay.has_bias and not lay.has_bn:
                 bp = bias.detach().float()
                 if lay.Cp != cout:
                     bp = torch.nn.functional.pad(bp, (0, lay.Cp - cout))
@@ -98,11 +107,7 @@ class RowsMLP(torch.autograd.Function):
             lay.Y = Y
             if lay.has_bn:
                 rm, rv, nbt, momentum, eps = spec[l]
-                if lay.Cp != cout:
-                    raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
                 if training:
-                    sums = zeros_f64(2, cout, dev)
-                    _call(_lib.omnipq_colstats_z, X, ctypes.c_longlong(N), cout, _p(Y), _p(sums))
                     _allreduce_(sums)
                     lay.a, lay.b = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
                     lay.mean, lay.invstd = torch.empty(cout, device=dev), torch.empty(cout, device=dev)

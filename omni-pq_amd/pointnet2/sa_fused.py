@@ -26,6 +26,7 @@ import pointnet2_utils
 _ext = pointnet2_utils._load_ext()      # always the product binding, whatever pointnet2_utils._ext is
 _lib = _ext._lib
 _lib.omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
+_lib.omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
 
 
 def _p(t):
@@ -71,6 +72,15 @@ def _gemm_nt(A, B, M, N, K):
     """bf16 C[M][N] = A[M][K] B[N][K]^T"""
     C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
     _call(_lib.omnipq_gemm_nt_bf16, A, M, N, K, _p(A), K, _p(B), K, _p(C), N)
+    return C
+
+
+def _gemm_nt_stats(A, B, M, N, K, sums, bias=None):
+    """bf16 C = A B^T and, in the same pass, sums (f64 [2][N], zero on entry) += column sum / sum of squares."""
+    C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
+    n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
+    ws = torch.empty((n_ws,), device=A.device, dtype=torch.float32) if n_ws else None
+    _call(_lib.omnipq_gemm_nt_bf16_stats, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws))
     return C
 
 
@@ -205,10 +215,9 @@ class FusedSAStage(torch.autograd.Function):
             K = kpad if l == 0 else W2.shape[1]
             lay.K, lay.C = K, cout
             lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=training)
-            lay.Y = _gemm_nt(X, lay.Wp, P, cout, K)
             if training:
                 sums = zeros_f64(2, cout, dev)
-                _call(_lib.omnipq_colstats_z, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(sums))
+                lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums)         # GEMM + batch statistics
                 _allreduce_(sums)
                 lay.a = torch.empty(cout, device=dev)
                 lay.b = torch.empty(cout, device=dev)
@@ -220,6 +229,7 @@ class FusedSAStage(torch.autograd.Function):
                 if nbt is not None:
                     nbt += 1
             else:
+                lay.Y = _gemm_nt(X, lay.Wp, P, cout, K)
                 lay.invstd = torch.rsqrt(rv + eps)
                 lay.mean = rm
                 lay.a = (gamma.detach() * lay.invstd).contiguous()

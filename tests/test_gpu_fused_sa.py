@@ -43,6 +43,35 @@ def test_gemm_nt_matches_torch(M, N, K):
     assert rel_l2(C.float(), want) < 3e-3
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(100, 128, 32, False), (2048, 288, 288, False), (8192, 64, 64, True),
+                                        (8193, 128, 128, False), (40000, 256, 32, False), (300, 544, 96, True)])
+def test_gemm_nt_stats_epilogue(M, N, K, bias):
+    """GEMM + BatchNorm statistics in one pass == the plain GEMM and the column sums of what it stored
+    (both the direct-atomics and the per-tile-partials variants; sums are ADDED to the buffer)."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+    B = torch.randn((N, K), generator=gen).to(torch.bfloat16).to(dev())
+    bvec = torch.randn(N, generator=gen).to(dev()) if bias else None
+    C0 = torch.empty((M, N), device=dev(), dtype=torch.bfloat16)
+    if bias:
+        capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C0), N, capi.P(bvec))
+    else:
+        capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C0), N)
+    C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    sums = torch.ones((2, N), device=dev(), dtype=torch.float64)
+    capi.lib().omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
+    n_ws = int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N))
+    assert (n_ws == 0) == (M <= 64 * 128)
+    ws = torch.empty(max(n_ws, 1), device=dev())
+    capi.ok("omnipq_gemm_nt_bf16_stats", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N,
+            capi.P(bvec) if bias else ctypes.c_void_p(0), capi.P(sums), capi.P(ws))
+    assert torch.equal(C, C0)
+    y = C.double()
+    want = torch.stack([y.sum(0), (y * y).sum(0)]) + 1.0
+    # f32 partial sums over 128-row tiles, f64 across tiles
+    assert float(((sums - want).abs() / (want.abs() + 1.0)).max()) < 1e-5
+
+
 @pytest.mark.parametrize("P,M,N", [(32, 128, 128), (1000, 72, 40), (8192, 256, 128), (5000, 288, 320),
                                    (333, 16, 544)])
 def test_gemm_tn_matches_torch(P, M, N):
