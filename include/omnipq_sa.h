@@ -57,6 +57,14 @@ long long omnipq_gemm_nt_stats_workspace_floats(int M, int N);
 int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                               int ldc, const float *bias, double *sums, float *workspace, void *stream);
 
+/* Data-gradient GEMM + BatchNorm-backward sums of the layer below in one pass:
+ *   dX = dY Wt^T (bf16, [M][N]),  dz = dX * [a y + b > 0],
+ *   sums[0][n] += sum_m dz,  sums[1][n] += sum_m dz * (y - mean) * invstd
+ * Y: that layer's pre-BN activations, [M][N] with pitch ldc.  sums / workspace as above. */
+int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+                              int ldc, const void *Y, const float *a, const float *b, const float *mean,
+                              const float *invstd, double *sums, float *workspace, void *stream);
+
 /* sums[0][c] = sum_p Y[p][c], sums[1][c] = sum_p Y[p][c]^2  (f64, zeroed by the call; the _z variant
  * trusts the caller that sums[0..2C) is already zero and saves the memset launch). */
 int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);

@@ -43,12 +43,21 @@ __device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_ca
 // store loop -- the BatchNorm statistics of the layer without a second pass over the tensor.
 //   1: atomically added to stats_out = double[2][N]          (few M-tiles: little contention)
 //   2: written to stats_out = float[m_tiles][2][N] partials  (many M-tiles: partial_reduce_kernel sums them)
+// 3 / 4: the same two destinations for the BatchNorm-backward sums of a data-gradient GEMM: with C = dX the
+//   gradient w.r.t. the ReLU output, Y the pre-BN activations of that layer (same shape and pitch as C),
+//   dz = dX * [a y + b > 0],   column sums of dz and of dz * (y - mean) * invstd.
+struct BnBwdEpilogue {
+  const bf16_t *Y;
+  const float *a, *b, *mean, *invstd;
+};
+
 template <bool OUT_F32, int STATS = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
-                                                        void *__restrict__ stats_out = nullptr) {
+                                                        void *__restrict__ stats_out = nullptr,
+                                                        BnBwdEpilogue bn = BnBwdEpilogue()) {
   // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
   constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
   constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
@@ -209,13 +218,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     float cs[8], cs2[8];                   // this thread's 8 columns (piece = tid & 15), rows tid>>4 + 16*it
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cs2[e] = 0.f;
+    float av[8], bv[8], mu[8], is[8];
+    if (STATS >= 3) {
+      int c0 = n0 + (tid & 15) * 8;
+      c0 = c0 < g.N ? c0 : 0;              // columns past N are never accumulated
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        av[e] = bn.a[c0 + e];
+        bv[e] = bn.b[c0 + e];
+        mu[e] = bn.mean[c0 + e];
+        is[e] = bn.invstd[c0 + e];
+      }
+    }
     for (int q = tid; q < 128 * 16; q += 256) {
       const int row = q >> 4, piece = q & 15;
       const int gr = m0 + row, gc = n0 + piece * 8;
       if (gr < g.M && gc < g.N) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * GCPITCH + piece * 8);
         *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
-        if (STATS) {
+        if (STATS >= 3) {
+          const uint4 yv = *reinterpret_cast<const uint4 *>(bn.Y + (size_t)gr * g.ldc + gc);
+          const unsigned w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned sh = (e & 1) ? 0u : 16u;
+            const float d = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << sh));
+            const float y = __builtin_bit_cast(float, (e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << sh));
+            const float dz = __builtin_fmaf(av[e], y, bv[e]) > 0.f ? d : 0.f;
+            cs[e] += dz;
+            cs2[e] = __builtin_fmaf(dz, (y - mu[e]) * is[e], cs2[e]);
+          }
+        } else if (STATS) {
           const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -243,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot += red[(r * 2 + which) * 128 + col];
       if (n0 + col < g.N) {
-        if (STATS == 1)
+        if (STATS == 1 || STATS == 3)
           atomicAdd(reinterpret_cast<double *>(stats_out) + (size_t)which * g.N + n0 + col, (double)tot);
         else
           reinterpret_cast<float *>(stats_out)[((size_t)mt * 2 + which) * g.N + n0 + col] = tot;
@@ -328,6 +361,43 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
   if (!workspace) return OMNIPQ_EINVAL;
   gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
                                                               workspace);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  if (slabs < 1) slabs = 1;
+  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
+                                                                                    sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// Data-gradient GEMM of a conv+BN+ReLU stack with the BatchNorm-backward sums of the layer BELOW folded in:
+//   dX[M][N] = dY[M][K] Wt[N][K]^T  (stored bf16),   dz = dX * [a y + b > 0],
+//   sums[0][n] += sum_m dz,   sums[1][n] += sum_m dz * (y - mean) * invstd
+// Y = that layer's pre-BN activations [M][N] (pitch ldc, like dX); sums double[2][N] zero on entry;
+// workspace as for omnipq_gemm_nt_bf16_stats.
+extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                         void *C, int ldc, const void *Y, const float *a, const float *b,
+                                         const float *mean, const float *invstd, double *sums, float *workspace,
+                                         void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !sums || !Y || !a || !b || !mean || !invstd) return OMNIPQ_EINVAL;
+  if ((K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  BnBwdEpilogue bn{(const bf16_t *)Y, a, b, mean, invstd};
+  if (g.m_tiles <= kStatsDirectTiles) {
+    gemm_nt_kernel<false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                nullptr, sums, bn);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (!workspace) return OMNIPQ_EINVAL;
+  gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr,
+                                                              workspace, bn);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;

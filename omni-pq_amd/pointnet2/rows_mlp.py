@@ -21,7 +21,7 @@ import ctypes
 import torch
 
 import sa_fused
-from sa_fused import (_allreduce_, _call, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
+from sa_fused import (_allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
                       unprep_wgrad, zeros_f32, zeros_f64)
 
 
@@ -157,13 +157,15 @@ class RowsMLP(torch.autograd.Function):
             dcur = torch.zeros((N, last.Cp), device=dev, dtype=torch.bfloat16)
             dcur[:, :last.C] = g
         dx = None
+        sums = None               # BN-backward sums of the current layer if the GEMM above already produced them
         for l in range(L - 1, -1, -1):
             lay = layers[l]
             Xin = layers[l - 1].X if l > 0 else ctx.X0
             if lay.has_bn:
-                sums = zeros_f64(3, lay.C, dev)
-                _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y), _p(lay.a),
-                      _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
+                if sums is None:
+                    sums = zeros_f64(3, lay.C, dev)
+                    _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
+                          _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
                 grads[4 * l + 2], grads[4 * l + 3] = affine_grads(sums, lay.C)       # local totals
                 _allreduce_(sums[:2])
                 if lay.has_bias:
@@ -176,7 +178,12 @@ class RowsMLP(torch.autograd.Function):
                 grads[4 * l + 1] = sums[0, :lay.C].float()
             dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N)
             grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
-            if l > 0 or ctx.needs_input_grad[0]:
+            sums = None
+            if l > 0 and layers[l - 1].has_bn:
+                sums = zeros_f64(3, lay.K, dev)
+                dprev = _gemm_nt_bnbwd(dcur, lay.Wt, N, lay.K, lay.Cp, layers[l - 1], sums)
+                dcur = dprev
+            elif l > 0 or ctx.needs_input_grad[0]:
                 dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
                 _call(_lib.omnipq_gemm_nt_bf16, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
                       _p(dprev), lay.K)

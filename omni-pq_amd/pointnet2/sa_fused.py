@@ -84,6 +84,17 @@ def _gemm_nt_stats(A, B, M, N, K, sums, bias=None):
     return C
 
 
+def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
+    """dX = dY Wt^T (bf16 [M][N]) and, in the same pass, the BatchNorm-backward sums of the layer `below`
+    (its pre-BN output Y and constants a, b, mean, invstd) into sums (f64 [>=2][N], zero on entry)."""
+    C = torch.empty((M, N), device=dY.device, dtype=torch.bfloat16)
+    n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
+    ws = torch.empty((n_ws,), device=dY.device, dtype=torch.float32) if n_ws else None
+    _call(_lib.omnipq_gemm_nt_bf16_bnbwd, dY, M, N, K, _p(dY), K, _p(Wt), K, _p(C), N, _p(below.Y), _p(below.a),
+          _p(below.b), _p(below.mean), _p(below.invstd), _p(sums), _p(ws))
+    return C
+
+
 def _gemm_tn(A, B, M, N, P):
     """f32 C[M][N] = A[P][M]^T B[P][N]"""
     C = torch.empty((M, N), device=A.device, dtype=torch.float32)
@@ -305,18 +316,18 @@ class FusedSAStage(torch.autograd.Function):
                 (ctx.has_features and ctx.needs_input_grad[2])
             if l == 0 and not need_in:
                 break
-            dX = _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)                      # Wt = [K][Cout]
             if l > 0:
                 prev = layers[l - 1]
                 sums = zeros_f64(3, prev.C, dev)
-                _call(_lib.omnipq_bn_bwd_stats_z, dX, ctypes.c_longlong(P), prev.C, _p(dX), _p(prev.Y), _p(prev.a),
-                      _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums))
+                # Wt = [K][Cout]; the BN-backward sums of the layer below come out of the same pass
+                dX = _gemm_nt_bnbwd(dY, lay.Wt, P, lay.K, lay.C, prev, sums)
                 grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = affine_grads(sums, prev.C)
                 _allreduce_(sums[:2])
                 _call(_lib.omnipq_bn_bwd_apply, dX, ctypes.c_longlong(P), prev.C, total, _p(dX), _p(prev.Y),
                       _p(prev.a), _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums), _p(dX))
                 dY = dX
             else:
+                dX = _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)
                 want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
                 dfeat_pm = torch.empty((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
                     else None

@@ -72,6 +72,33 @@ def test_gemm_nt_stats_epilogue(M, N, K, bias):
     assert float(((sums - want).abs() / (want.abs() + 1.0)).max()) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 128, 32), (2048, 288, 288), (8320, 128, 256), (40000, 64, 128)])
+def test_gemm_nt_bn_backward_epilogue(M, N, K):
+    """Data-gradient GEMM with the BatchNorm-backward sums folded in == GEMM followed by omnipq_bn_bwd_stats."""
+    gen = torch.Generator().manual_seed(M + N + K + 1)
+    dY = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+    Wt = (torch.randn((N, K), generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev())
+    Y = torch.randn((M, N), generator=gen).to(torch.bfloat16).to(dev())
+    a = (torch.randn(N, generator=gen)).to(dev())
+    b = (0.3 * torch.randn(N, generator=gen)).to(dev())
+    mean = (0.1 * torch.randn(N, generator=gen)).to(dev())
+    invstd = (0.5 + torch.rand(N, generator=gen)).to(dev())
+    dX0 = torch.empty((M, N), device=dev(), dtype=torch.bfloat16)
+    capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(dY), K, capi.P(Wt), K, capi.P(dX0), N)
+    want = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+    capi.ok("omnipq_bn_bwd_stats", ctypes.c_longlong(M), N, capi.P(dX0), capi.P(Y), capi.P(a), capi.P(b),
+            capi.P(mean), capi.P(invstd), capi.P(want))
+    dX = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+    capi.lib().omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
+    ws = torch.empty(max(int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N)), 1), device=dev())
+    capi.ok("omnipq_gemm_nt_bf16_bnbwd", M, N, K, capi.P(dY), K, capi.P(Wt), K, capi.P(dX), N, capi.P(Y), capi.P(a),
+            capi.P(b), capi.P(mean), capi.P(invstd), capi.P(sums), capi.P(ws))
+    assert torch.equal(dX, dX0)
+    scale = want.abs().max(dim=1, keepdim=True).values + 1e-3          # f32 partial sums, different order
+    assert float(((sums - want).abs() / scale).max()) < 1e-5
+
+
 @pytest.mark.parametrize("P,M,N", [(32, 128, 128), (1000, 72, 40), (8192, 256, 128), (5000, 288, 320),
                                    (333, 16, 544)])
 def test_gemm_tn_matches_torch(P, M, N):
