@@ -1,0 +1,511 @@
+// Multi-head attention of the transformer decoder on the gfx950 matrix cores, forward and backward.
+//
+// Reference: models/utils/multi_head_attention.py:375-391 -- q scaled by head_dim^-0.5, bmm(q, k^T),
+// softmax over the keys, dropout on the probabilities, bmm(p, v); called 12 times per forward by
+// models/transformer.py (self attention over the 256 proposals, cross attention 256 x 1024 seeds),
+// 8 heads of 36 channels.  The problem is tiny (a few GFLOP) and latency bound, so the design goal is
+// many short waves rather than peak MFMA rate:
+//   * tensors stay in the reference's (tokens, batch, embed) layout -- the kernels index heads with
+//     strides, there are no permute copies before or after;
+//   * one workgroup = 32 queries (forward, dQ) or 32 keys (dK/dV) of one (batch, head); its 4 waves split
+//     the other axis in interleaved blocks of 32 and merge at the end (online-softmax merge in forward,
+//     plain sums in backward), so a 1024-key cross attention is 8 iterations deep, not 32;
+//   * scores are computed TRANSPOSED (keys x queries) in forward/dQ: the 32x32 MFMA result then has the
+//     query on the lane axis, so softmax statistics are per lane, and the probabilities are already in the
+//     register layout of the next MFMA's B operand (contraction over keys = over accumulator registers) --
+//     P never touches LDS.  The operand on the other side of that contraction (V^T, K^T; dO, Q in dK/dV)
+//     needs lane = channel, which is the tensors' contiguous axis: it is staged [token][channel] in LDS
+//     and gathered with 2-byte reads in the accumulator's row order;
+//   * head_dim 36 is padded to 48 for the q.k contraction (3 K-steps of 16) by zero-filling fragments;
+//   * dropout is a counter-based hash of (seed, batch*head, query, key), recomputed in backward; the seed
+//     lives in device memory so that a captured hipGraph draws new masks on every replay.
+// Numerics: bf16 operands, f32 accumulation and softmax, probabilities rounded to bf16 for the second
+// contraction (as torch's fused attention does under bf16 autocast).
+#include "common.h"
+#include "omnipq_attn.h"
+
+namespace omnipq {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ATT_DMAX = 48;        // padded head dim of the q.k contraction
+constexpr int ATT_PITCH = 52;       // LDS row pitch (bf16) of a staged [32 tokens][<=48 channels] block
+
+struct AttnArgs {
+  int N, H, L, S, D;
+  long long q_sl, q_sn, k_sl, k_sn, v_sl, v_sn, o_sl, o_sn;      // element strides: token, batch
+  float scale, scale_log2;          // head_dim^-0.5 and the same times log2(e)
+  float keep_inv;                   // 1 / (1 - p)
+  unsigned drop_thresh;             // keep iff hash >= thresh; 0 = no dropout
+  unsigned salt;
+  const unsigned long long *seed_ptr;
+};
+
+__device__ __forceinline__ unsigned drop_seed(const AttnArgs &g) {
+  if (!g.drop_thresh) return 0u;
+  const unsigned long long s = *g.seed_ptr * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (g.salt + 1u);
+  return (unsigned)(s >> 32) ^ (unsigned)s;
+}
+
+__device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) {
+  unsigned x = idx ^ seed;
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+
+// row of accumulator register r for a lane in half h of the 32x32 MFMA result
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Fragment with lane = token, k = channels [16 j + 8 h, +8): two 8-byte loads, zero where channel >= D
+// (D % 4 == 0) or the token is out of range.
+__device__ __forceinline__ bf16x8 frag_tok(const bf16_t *row, int j, int h, int D, bool valid) {
+  const int d0 = 16 * j + 8 * h;
+  uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+  if (valid && d0 < D) lo = *reinterpret_cast<const uint2 *>(row + d0);
+  if (valid && d0 + 4 < D) hi = *reinterpret_cast<const uint2 *>(row + d0 + 4);
+  uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+__device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
+  const uint4 x = __builtin_bit_cast(uint4, a), y = __builtin_bit_cast(uint4, b);
+  float s = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x);
+  s += bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y);
+  s += bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z);
+  s += bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
+  return s;
+}
+
+// 8 accumulator registers [8 j2, +8) -> bf16x8 operand (contraction index = accumulator row order)
+__device__ __forceinline__ bf16x8 pack_regs(const float *p, int j2) {
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (bf16_t)p[8 * j2 + e];
+  return f;
+}
+
+// Stage one wave's [32 tokens][D channels] block into its private LDS area (8-byte pieces).
+__device__ __forceinline__ void stage_block(bf16_t *lds, const bf16_t *base, long long s_tok, int t0, int T, int D,
+                                            int lane) {
+  const int ppr = D >> 2;                                     // 8-byte pieces per row
+  for (int id = lane; id < 32 * ppr; id += 64) {
+    const int tok = id / ppr, part = id - tok * ppr;
+    uint2 v = make_uint2(0u, 0u);
+    if (t0 + tok < T) v = *reinterpret_cast<const uint2 *>(base + (long long)(t0 + tok) * s_tok + part * 4);
+    *reinterpret_cast<uint2 *>(lds + tok * ATT_PITCH + part * 4) = v;
+  }
+}
+
+// Operand with lane = channel (tile t: channel 32 t + lane&31, clamped into the staged row), contraction
+// index = accumulator row order of k-step j2: tokens acc_row(8 j2 + e, h), e = 0..7.
+__device__ __forceinline__ bf16x8 frag_chan(const bf16_t *lds, int t, int j2, int h, int lane) {
+  int d = 32 * t + (lane & 31);
+  d = d < ATT_DMAX ? d : ATT_DMAX - 1;
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = lds[acc_row(8 * j2 + e, h) * ATT_PITCH + d];
+  return f;
+}
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// ---- forward ------------------------------------------------------------------------------------------
+// grid (ceil(L/32), N*H), 256 threads.  out: O (bf16, strides o_*), lse2[N*H][L] = log2 sum exp2(s) (f32).
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
+                                                      const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
+                                                      bf16_t *__restrict__ O, float *__restrict__ lse2) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4 + 4 * 32 * 4 * 2];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ql = lane & 31;
+  const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
+  const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
+  const bool qv = q < g.L;
+  const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
+  bf16_t *vs = reinterpret_cast<bf16_t *>(smem) + wave * 32 * ATT_PITCH;
+
+  bf16x8 qf[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) qf[j] = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
+
+  const unsigned seed = drop_seed(g);
+  float m = -1e30f, lsum = 0.f;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
+  for (int it = 0; it < iters; ++it) {
+    const int k0 = (it * 4 + wave) * 32;
+    const int key = k0 + ql;
+    const bool kv = key < g.S;
+    __syncthreads();                                        // previous block's LDS reads are done
+    stage_block(vs, Vb, g.v_sl, k0, g.S, g.D, lane);
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bf16x8 kf = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+      st = MFMA(kf, qf[j], st);                             // S^T: rows = keys, cols = queries
+    }
+    float p[16], bm = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = k0 + acc_row(r, h) < g.S;
+      p[r] = ok ? st[r] * g.scale_log2 : -1e30f;
+      bm = fmaxf(bm, p[r]);
+    }
+    bm = fmaxf(bm, xor32(bm));
+    const float m_new = fmaxf(m, bm);
+    const float alpha = exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = k0 + acc_row(r, h) < g.S;
+      p[r] = ok ? exp2f(p[r] - m_new) : 0.f;
+      rs += p[r];
+    }
+    rs += xor32(rs);
+    lsum = lsum * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+    if (g.drop_thresh) {
+      const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        p[r] = drop_hash(base + (unsigned)acc_row(r, h), seed) >= g.drop_thresh ? p[r] * g.keep_inv : 0.f;
+    }
+    __syncthreads();                                        // V block staged
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const bf16x8 pf = pack_regs(p, j2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = MFMA(frag_chan(vs, t, j2, h, lane), pf, acc[t]);   // O^T: rows = channels
+    }
+  }
+
+  // ---- merge the 4 waves: m* = max m_w, weights 2^(m_w - m*) ----
+  __syncthreads();
+  float *ms = reinterpret_cast<float *>(smem + 4 * 64 * 33 * 4);      // [4][32] m, then [4][32] l
+  float *comb = reinterpret_cast<float *>(smem);                      // [4][64 channels][33]
+  if (h == 0) ms[wave * 32 + ql] = m;
+  __syncthreads();
+  const float mstar = fmaxf(fmaxf(ms[ql], ms[32 + ql]), fmaxf(ms[64 + ql], ms[96 + ql]));
+  const float f = exp2f(m - mstar);
+  if (h == 0) ms[128 + wave * 32 + ql] = lsum * f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) comb[(wave * 64 + 32 * t + acc_row(r, h)) * 33 + ql] = acc[t][r] * f;
+  __syncthreads();
+  for (int idx = tid; idx < 32 * g.D; idx += 256) {
+    const int qq = idx / g.D, d = idx - qq * g.D;
+    if (q0 + qq < g.L) {
+      const float l = ms[128 + qq] + ms[160 + qq] + ms[192 + qq] + ms[224 + qq];
+      const float o = comb[(0 * 64 + d) * 33 + qq] + comb[(1 * 64 + d) * 33 + qq] + comb[(2 * 64 + d) * 33 + qq] +
+                      comb[(3 * 64 + d) * 33 + qq];
+      O[(long long)(q0 + qq) * g.o_sl + n * g.o_sn + hd * g.D + d] = (bf16_t)(o / l);
+    }
+  }
+  if (tid < 32 && q0 + tid < g.L) {
+    const float l = ms[128 + tid] + ms[160 + tid] + ms[192 + tid] + ms[224 + tid];
+    const float ms_ = fmaxf(fmaxf(ms[tid], ms[32 + tid]), fmaxf(ms[64 + tid], ms[96 + tid]));
+    lse2[(long long)nh * g.L + q0 + tid] = ms_ + log2f(l);
+  }
+}
+
+// ---- backward, dQ ---------------------------------------------------------------------------------------
+// grid (ceil(L/32), N*H).  Also writes delta[N*H][L] = sum_d dO*O for the dK/dV kernel.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
+                                                         const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
+                                                         const bf16_t *__restrict__ O, const bf16_t *__restrict__ dO,
+                                                         const float *__restrict__ lse2, float *__restrict__ delta,
+                                                         bf16_t *__restrict__ dQ, long long dq_sl, long long dq_sn) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ql = lane & 31;
+  const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
+  const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
+  const bool qv = q < g.L;
+  const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
+  const bf16_t *Ob = O + n * g.o_sn + hd * g.D, *dOb = dO + n * g.o_sn + hd * g.D;
+  bf16_t *ks = reinterpret_cast<bf16_t *>(smem) + wave * 32 * ATT_PITCH;
+
+  bf16x8 qf[3], dof[3];
+  float dl = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    qf[j] = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
+    dof[j] = frag_tok(dOb + (long long)(qv ? q : 0) * g.o_sl, j, h, g.D, qv);
+    dl += frag_dot(dof[j], frag_tok(Ob + (long long)(qv ? q : 0) * g.o_sl, j, h, g.D, qv));
+  }
+  dl += xor32(dl);
+  if (wave == 0 && h == 0 && qv) delta[(long long)nh * g.L + q] = dl;
+  const float lse = qv ? lse2[(long long)nh * g.L + q] : 0.f;
+
+  const unsigned seed = drop_seed(g);
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
+  for (int it = 0; it < iters; ++it) {
+    const int k0 = (it * 4 + wave) * 32;
+    const int key = k0 + ql;
+    const bool kv = key < g.S;
+    __syncthreads();
+    stage_block(ks, Kb, g.k_sl, k0, g.S, g.D, lane);
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bf16x8 kf = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+      const bf16x8 vf = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+      st = MFMA(kf, qf[j], st);                             // S^T
+      dp = MFMA(vf, dof[j], dp);                            // (dO V^T)^T
+    }
+    float ds[16];
+    const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = qv && k0 + acc_row(r, h) < g.S;
+      const float p = ok ? exp2f(st[r] * g.scale_log2 - lse) : 0.f;
+      float d = dp[r];
+      if (g.drop_thresh) d = drop_hash(base + (unsigned)acc_row(r, h), seed) >= g.drop_thresh ? d * g.keep_inv : 0.f;
+      ds[r] = p * (d - dl);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const bf16x8 df = pack_regs(ds, j2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = MFMA(frag_chan(ks, t, j2, h, lane), df, acc[t]);   // dQ^T: rows = channels
+    }
+  }
+  __syncthreads();
+  float *comb = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) comb[(wave * 64 + 32 * t + acc_row(r, h)) * 33 + ql] = acc[t][r];
+  __syncthreads();
+  for (int idx = tid; idx < 32 * g.D; idx += 256) {
+    const int qq = idx / g.D, d = idx - qq * g.D;
+    if (q0 + qq < g.L) {
+      const float v = comb[(0 * 64 + d) * 33 + qq] + comb[(1 * 64 + d) * 33 + qq] + comb[(2 * 64 + d) * 33 + qq] +
+                      comb[(3 * 64 + d) * 33 + qq];
+      dQ[(long long)(q0 + qq) * dq_sl + n * dq_sn + hd * g.D + d] = (bf16_t)(v * g.scale);
+    }
+  }
+}
+
+// ---- backward, dK and dV --------------------------------------------------------------------------------
+// grid (ceil(S/32), N*H); the 4 waves split the queries.
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
+                                                           const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
+                                                           const bf16_t *__restrict__ dO, const float *__restrict__ lse2,
+                                                           const float *__restrict__ delta, bf16_t *__restrict__ dK,
+                                                           long long dk_sl, long long dk_sn, bf16_t *__restrict__ dV,
+                                                           long long dv_sl, long long dv_sn) {
+  // per wave: Q block, dO block (bf16 [32][PITCH]) and 64 floats (lse, delta); merged accumulators alias it
+  constexpr int WAVE_BYTES = 2 * 32 * ATT_PITCH * 2 + 64 * 4;
+  constexpr int COMB_BYTES = 4 * 32 * 65 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(4 * WAVE_BYTES > COMB_BYTES) ? 4 * WAVE_BYTES : COMB_BYTES];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, kl = lane & 31;
+  const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
+  const int k0 = (int)blockIdx.x * 32, key = k0 + kl;
+  const bool kv = key < g.S;
+  const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
+  const bf16_t *dOb = dO + n * g.o_sn + hd * g.D;
+  bf16_t *qs = reinterpret_cast<bf16_t *>(smem + wave * WAVE_BYTES);
+  bf16_t *dos = qs + 32 * ATT_PITCH;
+  float *rowv = reinterpret_cast<float *>(dos + 32 * ATT_PITCH);          // [0,32) lse2, [32,64) delta
+
+  bf16x8 kf[3], vf[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    kf[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+    vf[j] = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+  }
+  const unsigned seed = drop_seed(g);
+  f32x16 accv[2], acck[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accv[t][r] = acck[t][r] = 0.f;
+
+  const int nqb = (g.L + 31) >> 5, iters = (nqb + 3) >> 2;
+  for (int it = 0; it < iters; ++it) {
+    const int q0 = (it * 4 + wave) * 32;
+    const int q = q0 + kl;
+    const bool qv = q < g.L;
+    __syncthreads();
+    stage_block(qs, Qb, g.q_sl, q0, g.L, g.D, lane);
+    stage_block(dos, dOb, g.o_sl, q0, g.L, g.D, lane);
+    {
+      const int qq = q0 + (lane & 31);
+      float v = 0.f;
+      if (qq < g.L) v = (h == 0 ? lse2 : delta)[(long long)nh * g.L + qq];
+      rowv[lane] = v;
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bf16x8 qf = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
+      const bf16x8 dof = frag_tok(dOb + (long long)(qv ? q : 0) * g.o_sl, j, h, g.D, qv);
+      s = MFMA(qf, kf[j], s);                               // S: rows = queries, cols = keys
+      dp = MFMA(dof, vf[j], dp);                            // dO V^T
+    }
+    __syncthreads();
+    float pt[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, h);
+      const bool ok = kv && q0 + row < g.L;
+      const float p = ok ? exp2f(s[r] * g.scale_log2 - rowv[row]) : 0.f;
+      float d = dp[r];
+      float pk = p;
+      if (g.drop_thresh) {
+        const unsigned idx = ((unsigned)nh * (unsigned)g.L + (unsigned)(q0 + row)) * (unsigned)g.S + (unsigned)key;
+        const bool keep = drop_hash(idx, seed) >= g.drop_thresh;
+        d = keep ? d * g.keep_inv : 0.f;
+        pk = keep ? p * g.keep_inv : 0.f;
+      }
+      pt[r] = pk;
+      ds[r] = p * (d - rowv[32 + row]);
+    }
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const bf16x8 pf = pack_regs(pt, j2), df = pack_regs(ds, j2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        accv[t] = MFMA(pf, frag_chan(dos, t, j2, h, lane), accv[t]);      // dV: rows = keys, cols = channels
+        acck[t] = MFMA(df, frag_chan(qs, t, j2, h, lane), acck[t]);       // dK
+      }
+    }
+  }
+  // merge the 4 waves through one [4][32 keys][65] f32 buffer: dV first, then dK
+  float *cb = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        cb[(wave * 32 + acc_row(r, h)) * 65 + 32 * t + kl] = pass == 0 ? accv[t][r] : acck[t][r];
+    __syncthreads();
+    bf16_t *dst = pass == 0 ? dV : dK;
+    const long long sl = pass == 0 ? dv_sl : dk_sl, sn = pass == 0 ? dv_sn : dk_sn;
+    const float mul = pass == 0 ? 1.f : g.scale;
+    for (int idx = tid; idx < 32 * g.D; idx += 256) {
+      const int kk = idx / g.D, d = idx - kk * g.D;
+      if (k0 + kk < g.S) {
+        const float v = cb[(0 * 32 + kk) * 65 + d] + cb[(1 * 32 + kk) * 65 + d] + cb[(2 * 32 + kk) * 65 + d] +
+                        cb[(3 * 32 + kk) * 65 + d];
+        dst[(long long)(k0 + kk) * sl + n * sn + hd * g.D + d] = (bf16_t)(v * mul);
+      }
+    }
+  }
+}
+
+// keep mask of one call, for tests: mask[N*H][L][S] (1 = kept)
+__global__ void attn_mask_kernel(AttnArgs g, unsigned char *__restrict__ mask) {
+  const long long total = (long long)g.N * g.H * g.L * g.S;
+  const unsigned seed = drop_seed(g);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    mask[i] = !g.drop_thresh || drop_hash((unsigned)i, seed) >= g.drop_thresh;
+}
+
+static int fill_args(AttnArgs &g, int N, int H, int L, int S, int D, const long long *strides, float dropout_p,
+                     const unsigned long long *seed_ptr, unsigned salt) {
+  if (N <= 0 || H <= 0 || L <= 0 || S <= 0 || D <= 0 || (D % 4) || D > ATT_DMAX) return OMNIPQ_EINVAL;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !seed_ptr)) return OMNIPQ_EINVAL;
+  if ((long long)N * H * L * S >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
+  for (int i = 0; i < 8; ++i)
+    if (strides[i] % 4) return OMNIPQ_EINVAL;
+  g.N = N, g.H = H, g.L = L, g.S = S, g.D = D;
+  g.q_sl = strides[0], g.q_sn = strides[1], g.k_sl = strides[2], g.k_sn = strides[3];
+  g.v_sl = strides[4], g.v_sn = strides[5], g.o_sl = strides[6], g.o_sn = strides[7];
+  g.scale = 1.0f / sqrtf((float)D);
+  g.scale_log2 = g.scale * 1.4426950408889634f;
+  g.keep_inv = 1.0f / (1.0f - dropout_p);
+  double th = (double)dropout_p * 4294967296.0;
+  g.drop_thresh = dropout_p > 0.f ? (unsigned)(th < 1.0 ? 1.0 : (th > 4294967295.0 ? 4294967295.0 : th)) : 0u;
+  g.salt = salt;
+  g.seed_ptr = seed_ptr;
+  return OMNIPQ_OK;
+}
+
+}  // namespace omnipq
+
+extern "C" int omnipq_attn_fwd(int N, int H, int L, int S, int D, const void *q, const void *k, const void *v,
+                               void *o, const long long *strides, float *lse2, float dropout_p,
+                               const unsigned long long *seed_ptr, unsigned salt, void *stream) {
+  using namespace omnipq;
+  AttnArgs g;
+  if (!q || !k || !v || !o || !strides || !lse2) return OMNIPQ_EINVAL;
+  const int rc = fill_args(g, N, H, L, S, D, strides, dropout_p, seed_ptr, salt);
+  if (rc) return rc;
+  attn_fwd_kernel<<<dim3((L + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
+      g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (bf16_t *)o, lse2);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_attn_bwd(int N, int H, int L, int S, int D, const void *q, const void *k, const void *v,
+                               const void *o, const void *d_o, const long long *strides, const float *lse2,
+                               float *delta, void *dq, void *dk, void *dv, const long long *grad_strides,
+                               float dropout_p, const unsigned long long *seed_ptr, unsigned salt, void *stream) {
+  using namespace omnipq;
+  AttnArgs g;
+  if (!q || !k || !v || !o || !d_o || !strides || !lse2 || !delta || !dq || !dk || !dv || !grad_strides)
+    return OMNIPQ_EINVAL;
+  const int rc = fill_args(g, N, H, L, S, D, strides, dropout_p, seed_ptr, salt);
+  if (rc) return rc;
+  for (int i = 0; i < 6; ++i)
+    if (grad_strides[i] % 4) return OMNIPQ_EINVAL;
+  attn_bwd_dq_kernel<<<dim3((L + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
+      g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)o, (const bf16_t *)d_o, lse2, delta,
+      (bf16_t *)dq, grad_strides[0], grad_strides[1]);
+  OMNIPQ_LAUNCH_CHECK();
+  attn_bwd_dkdv_kernel<<<dim3((S + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
+      g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)d_o, lse2, delta, (bf16_t *)dk,
+      grad_strides[2], grad_strides[3], (bf16_t *)dv, grad_strides[4], grad_strides[5]);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_attn_dropout_mask(int N, int H, int L, int S, float dropout_p,
+                                        const unsigned long long *seed_ptr, unsigned salt, unsigned char *mask,
+                                        void *stream) {
+  using namespace omnipq;
+  AttnArgs g;
+  const long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!mask) return OMNIPQ_EINVAL;
+  const int rc = fill_args(g, N, H, L, S, 4, zero, dropout_p, seed_ptr, salt);
+  if (rc) return rc;
+  attn_mask_kernel<<<1024, 256, 0, (hipStream_t)stream>>>(g, mask);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

@@ -27,6 +27,7 @@ for _p in (_HERE, _ROOT, os.path.join(_ROOT, "pointnet2")):
 from backbone_module import Pointnet2Backbone  # noqa: E402
 from transformer import TransformerDecoderLayer  # noqa: E402
 from utils.pointnet_util import FPSModule  # noqa: E402
+from utils import fused_attention  # noqa: E402
 from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
 import rows_mlp  # noqa: E402
@@ -241,6 +242,8 @@ class PQ_Transformer(nn.Module):
         nn.SyncBatchNorm.convert_sync_batchnorm(self)      # in place for every child BN (:194)
 
     def forward(self, inputs):
+        if self.training and inputs['point_clouds'].is_cuda:
+            fused_attention.STATE.advance(inputs['point_clouds'].device)     # new dropout masks this step
         end_points = self.backbone(inputs['point_clouds'], {})
         seed_xyz = end_points['fp2_xyz']
         seed_features = end_points['fp2_features']

@@ -10,14 +10,20 @@ Differences that do not change results:
     projections anyway;
   * the reference never forwards `attention_type` from `forward` to the functional (:139-146), so
     its `'self'` branch (:393-394) is dead; it is accepted and ignored here too.
-The contractions (packed projections, QK^T, PV, out-proj) are dense GEMMs and run on the MFMA units
-through hipBLASLt.
+Under bf16 autocast on the GPU the attention core (scores, softmax, dropout, PV and their backward) runs on
+the hand-written kernels of csrc/attention.hip (utils/fused_attention.py); the projections are dense GEMMs.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.nn import Linear, Module
 from torch.nn.init import constant_, xavier_normal_, xavier_uniform_
 from torch.nn.parameter import Parameter
+
+from utils import fused_attention  # noqa: E402  (hand-written attention kernels; GPU bf16 only)
+
+_USE_FUSED = os.environ.get("OMNIPQ_ATTN", "fused") != "torch"
 
 
 class MultiheadAttention(Module):
@@ -73,6 +79,9 @@ class MultiheadAttention(Module):
             # One fused attention kernel (scores, softmax, dropout, PV never leave the chip) instead of
             # scale / bmm / softmax / dropout / bmm: same math, softmax(q k^T / sqrt(D)) v with dropout
             # on the probabilities (reference :375-391).
+            if _USE_FUSED and fused_attention.usable(q, k, v, H):
+                out = fused_attention.attention(q, k, v, H, self.dropout if self.training else 0.0)
+                return F.linear(out, self.out_proj.weight, self.out_proj.bias), None
             S = k.shape[0]
             qh = q.reshape(L, N, H, D).permute(1, 2, 0, 3)
             kh = k.reshape(S, N, H, D).permute(1, 2, 0, 3)
