@@ -94,16 +94,49 @@ __device__ __forceinline__ bf16x8 pack_regs(const float *p, int j2) {
   return f;
 }
 
-// Stage one wave's [32 tokens][D channels] block into its private LDS area (8-byte pieces).
-__device__ __forceinline__ void stage_block(bf16_t *lds, const bf16_t *base, long long s_tok, int t0, int T, int D,
-                                            int lane) {
-  const int ppr = D >> 2;                                     // 8-byte pieces per row
-  for (int id = lane; id < 32 * ppr; id += 64) {
-    const int tok = id / ppr, part = id - tok * ppr;
-    uint2 v = make_uint2(0u, 0u);
-    if (t0 + tok < T) v = *reinterpret_cast<const uint2 *>(base + (long long)(t0 + tok) * s_tok + part * 4);
-    *reinterpret_cast<uint2 *>(lds + tok * ATT_PITCH + part * 4) = v;
+// Staging of one wave's [32 tokens][D channels] block into its private LDS area in 8-byte pieces, split
+// into the global loads (issued one iteration ahead, results parked in registers) and the LDS stores.
+// A lane owns pieces id = lane + 64 i, i < 6 (32 * 48/4 = 384 pieces at most); token / offset per piece
+// are loop invariants.
+constexpr int ATT_NP = 6;
+struct StagePlan {
+  int tok[ATT_NP];        // token within the block, or -1 if the lane has no such piece
+  int off[ATT_NP];        // channel offset (elements)
+};
+
+__device__ __forceinline__ StagePlan stage_plan(int D, int lane) {
+  StagePlan sp;
+  const int ppr = D >> 2;
+#pragma unroll
+  for (int i = 0; i < ATT_NP; ++i) {
+    const int id = lane + 64 * i;
+    const int tok = id / ppr;
+    sp.tok[i] = id < 32 * ppr ? tok : -1;
+    sp.off[i] = (id - tok * ppr) * 4;
   }
+  return sp;
+}
+
+struct StageRegs {
+  uint2 v[ATT_NP];
+};
+
+__device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, const bf16_t *base, long long s_tok, int t0,
+                                                int T) {
+  StageRegs r;
+#pragma unroll
+  for (int i = 0; i < ATT_NP; ++i) {
+    r.v[i] = make_uint2(0u, 0u);
+    if (sp.tok[i] >= 0 && t0 + sp.tok[i] < T)
+      r.v[i] = *reinterpret_cast<const uint2 *>(base + (long long)(t0 + sp.tok[i]) * s_tok + sp.off[i]);
+  }
+  return r;
+}
+
+__device__ __forceinline__ void stage_store(const StagePlan &sp, const StageRegs &r, bf16_t *lds) {
+#pragma unroll
+  for (int i = 0; i < ATT_NP; ++i)
+    if (sp.tok[i] >= 0) *reinterpret_cast<uint2 *>(lds + sp.tok[i] * ATT_PITCH + sp.off[i]) = r.v[i];
 }
 
 // Operand with lane = channel (tile t: channel 32 t + lane&31, clamped into the staged row), contraction
@@ -116,6 +149,10 @@ __device__ __forceinline__ bf16x8 frag_chan(const bf16_t *lds, int t, int j2, in
   for (int e = 0; e < 8; ++e) f[e] = lds[acc_row(8 * j2 + e, h) * ATT_PITCH + d];
   return f;
 }
+
+// v_exp_f32 without the denormal-range fix-up of exp2f(): arguments here are <= 0 differences of scores, and a
+// result below 2^-126 flushing to zero is exactly what a softmax weight that small should do
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
@@ -147,20 +184,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
+  const StagePlan sp = stage_plan(g.D, lane);
+  // software pipeline: the K fragments and the V block of iteration it+1 are loaded while it computes
+  bf16x8 kfn[3];
+  StageRegs vn;
+  {
+    const int k0 = wave * 32, key = k0 + ql;
+    const bool kv = key < g.S;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+    vn = stage_load(sp, Vb, g.v_sl, k0, g.S);
+  }
   for (int it = 0; it < iters; ++it) {
     const int k0 = (it * 4 + wave) * 32;
-    const int key = k0 + ql;
-    const bool kv = key < g.S;
+    bf16x8 kf[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) kf[j] = kfn[j];
+    const StageRegs vc = vn;
+    if (it + 1 < iters) {
+      const int k1 = k0 + 128, key = k1 + ql;
+      const bool kv = key < g.S;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+      vn = stage_load(sp, Vb, g.v_sl, k1, g.S);
+    }
     __syncthreads();                                        // previous block's LDS reads are done
-    stage_block(vs, Vb, g.v_sl, k0, g.S, g.D, lane);
+    stage_store(sp, vc, vs);
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const bf16x8 kf = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
-      st = MFMA(kf, qf[j], st);                             // S^T: rows = keys, cols = queries
-    }
+    for (int j = 0; j < 3; ++j) st = MFMA(kf[j], qf[j], st);      // S^T: rows = keys, cols = queries
     float p[16], bm = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -170,12 +224,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
     }
     bm = fmaxf(bm, xor32(bm));
     const float m_new = fmaxf(m, bm);
-    const float alpha = exp2f(m - m_new);
+    const float alpha = fast_exp2(m - m_new);
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = k0 + acc_row(r, h) < g.S;
-      p[r] = ok ? exp2f(p[r] - m_new) : 0.f;
+      p[r] = ok ? fast_exp2(p[r] - m_new) : 0.f;
       rs += p[r];
     }
     rs += xor32(rs);
@@ -207,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
   if (h == 0) ms[wave * 32 + ql] = m;
   __syncthreads();
   const float mstar = fmaxf(fmaxf(ms[ql], ms[32 + ql]), fmaxf(ms[64 + ql], ms[96 + ql]));
-  const float f = exp2f(m - mstar);
+  const float f = fast_exp2(m - mstar);
   if (h == 0) ms[128 + wave * 32 + ql] = lsum * f;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -266,28 +320,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
+  const StagePlan sp = stage_plan(g.D, lane);
+  bf16x8 kfn[3], vfn[3];
+  StageRegs kn;
+  {
+    const int k0 = wave * 32, key = k0 + ql;
+    const bool kv = key < g.S;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+      vfn[j] = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+    }
+    kn = stage_load(sp, Kb, g.k_sl, k0, g.S);
+  }
   for (int it = 0; it < iters; ++it) {
     const int k0 = (it * 4 + wave) * 32;
-    const int key = k0 + ql;
-    const bool kv = key < g.S;
+    bf16x8 kf[3], vf[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) kf[j] = kfn[j], vf[j] = vfn[j];
+    const StageRegs kc = kn;
+    if (it + 1 < iters) {
+      const int k1 = k0 + 128, key = k1 + ql;
+      const bool kv = key < g.S;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+        vfn[j] = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+      }
+      kn = stage_load(sp, Kb, g.k_sl, k1, g.S);
+    }
     __syncthreads();
-    stage_block(ks, Kb, g.k_sl, k0, g.S, g.D, lane);
+    stage_store(sp, kc, ks);
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const bf16x8 kf = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
-      const bf16x8 vf = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
-      st = MFMA(kf, qf[j], st);                             // S^T
-      dp = MFMA(vf, dof[j], dp);                            // (dO V^T)^T
+      st = MFMA(kf[j], qf[j], st);                          // S^T
+      dp = MFMA(vf[j], dof[j], dp);                         // (dO V^T)^T
     }
     float ds[16];
     const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = qv && k0 + acc_row(r, h) < g.S;
-      const float p = ok ? exp2f(st[r] * g.scale_log2 - lse) : 0.f;
+      const float p = ok ? fast_exp2(st[r] * g.scale_log2 - lse) : 0.f;
       float d = dp[r];
       if (g.drop_thresh) d = drop_hash(base + (unsigned)acc_row(r, h), seed) >= g.drop_thresh ? d * g.keep_inv : 0.f;
       ds[r] = p * (d - dl);
@@ -318,26 +395,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
 }
 
 // ---- backward, dK and dV --------------------------------------------------------------------------------
-// grid (ceil(S/32), N*H); the 4 waves split the queries.
+// grid (ceil(S/128), N*H).  Each WAVE owns 32 keys and walks over all query blocks, so there is nothing to
+// merge; the four waves of a workgroup share the staged Q / dO block and the per-query lse / delta.
+__device__ __forceinline__ bf16x8 frag_lds_tok(const bf16_t *lds, int row, int j, int h, int D) {
+  const int d0 = 16 * j + 8 * h;
+  uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+  if (d0 < D) lo = *reinterpret_cast<const uint2 *>(lds + row * ATT_PITCH + d0);
+  if (d0 + 4 < D) hi = *reinterpret_cast<const uint2 *>(lds + row * ATT_PITCH + d0 + 4);
+  uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
                                                            const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
                                                            const bf16_t *__restrict__ dO, const float *__restrict__ lse2,
                                                            const float *__restrict__ delta, bf16_t *__restrict__ dK,
                                                            long long dk_sl, long long dk_sn, bf16_t *__restrict__ dV,
                                                            long long dv_sl, long long dv_sn) {
-  // per wave: Q block, dO block (bf16 [32][PITCH]) and 64 floats (lse, delta); merged accumulators alias it
-  constexpr int WAVE_BYTES = 2 * 32 * ATT_PITCH * 2 + 64 * 4;
-  constexpr int COMB_BYTES = 4 * 32 * 65 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(4 * WAVE_BYTES > COMB_BYTES) ? 4 * WAVE_BYTES : COMB_BYTES];
+  __shared__ __attribute__((aligned(16))) bf16_t qs[32 * ATT_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t dos[32 * ATT_PITCH];
+  __shared__ float rowv[64];                                               // [0,32) lse2, [32,64) delta
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, kl = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
-  const int k0 = (int)blockIdx.x * 32, key = k0 + kl;
+  const int k0 = ((int)blockIdx.x * 4 + wave) * 32, key = k0 + kl;
   const bool kv = key < g.S;
   const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
   const bf16_t *dOb = dO + n * g.o_sn + hd * g.D;
-  bf16_t *qs = reinterpret_cast<bf16_t *>(smem + wave * WAVE_BYTES);
-  bf16_t *dos = qs + 32 * ATT_PITCH;
-  float *rowv = reinterpret_cast<float *>(dos + 32 * ATT_PITCH);          // [0,32) lse2, [32,64) delta
 
   bf16x8 kf[3], vf[3];
 #pragma unroll
@@ -352,37 +435,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
 #pragma unroll
     for (int r = 0; r < 16; ++r) accv[t][r] = acck[t][r] = 0.f;
 
-  const int nqb = (g.L + 31) >> 5, iters = (nqb + 3) >> 2;
-  for (int it = 0; it < iters; ++it) {
-    const int q0 = (it * 4 + wave) * 32;
-    const int q = q0 + kl;
-    const bool qv = q < g.L;
-    __syncthreads();
-    stage_block(qs, Qb, g.q_sl, q0, g.L, g.D, lane);
-    stage_block(dos, dOb, g.o_sl, q0, g.L, g.D, lane);
-    {
-      const int qq = q0 + (lane & 31);
-      float v = 0.f;
-      if (qq < g.L) v = (h == 0 ? lse2 : delta)[(long long)nh * g.L + qq];
-      rowv[lane] = v;
+  // cooperative staging: 256 threads, pieces id = tid + 256 i (i < 2) of the [32][D] block
+  const int ppr = g.D >> 2;
+  int ptok[2], poff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i, tok = id / ppr;
+    ptok[i] = id < 32 * ppr ? tok : -1;
+    poff[i] = (id - tok * ppr) * 4;
+  }
+  const float *rowsrc = (tid < 32 ? lse2 : delta) + (long long)nh * g.L;
+  uint2 qn[2], dn[2];
+  float rown = 0.f;
+  auto fetch = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      qn[i] = dn[i] = make_uint2(0u, 0u);
+      if (ptok[i] >= 0 && q0 + ptok[i] < g.L) {
+        qn[i] = *reinterpret_cast<const uint2 *>(Qb + (long long)(q0 + ptok[i]) * g.q_sl + poff[i]);
+        dn[i] = *reinterpret_cast<const uint2 *>(dOb + (long long)(q0 + ptok[i]) * g.o_sl + poff[i]);
+      }
     }
+    rown = (tid < 64 && q0 + (tid & 31) < g.L) ? rowsrc[q0 + (tid & 31)] : 0.f;
+  };
+  fetch(0);
+  const int nqb = (g.L + 31) >> 5;
+  for (int it = 0; it < nqb; ++it) {
+    const int q0 = it * 32;
+    uint2 qc[2], dc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) qc[i] = qn[i], dc[i] = dn[i];
+    const float rowc = rown;
+    if (it + 1 < nqb) fetch(q0 + 32);
+    __syncthreads();                                        // the previous block has been consumed
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (ptok[i] >= 0) {
+        *reinterpret_cast<uint2 *>(qs + ptok[i] * ATT_PITCH + poff[i]) = qc[i];
+        *reinterpret_cast<uint2 *>(dos + ptok[i] * ATT_PITCH + poff[i]) = dc[i];
+      }
+    if (tid < 64) rowv[tid] = rowc;
+    __syncthreads();
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const bf16x8 qf = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
-      const bf16x8 dof = frag_tok(dOb + (long long)(qv ? q : 0) * g.o_sl, j, h, g.D, qv);
-      s = MFMA(qf, kf[j], s);                               // S: rows = queries, cols = keys
-      dp = MFMA(dof, vf[j], dp);                            // dO V^T
+      s = MFMA(frag_lds_tok(qs, kl, j, h, g.D), kf[j], s);        // S: rows = queries, cols = keys
+      dp = MFMA(frag_lds_tok(dos, kl, j, h, g.D), vf[j], dp);     // dO V^T
     }
-    __syncthreads();
     float pt[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r, h);
       const bool ok = kv && q0 + row < g.L;
-      const float p = ok ? exp2f(s[r] * g.scale_log2 - rowv[row]) : 0.f;
+      const float p = ok ? fast_exp2(s[r] * g.scale_log2 - rowv[row]) : 0.f;
       float d = dp[r];
       float pk = p;
       if (g.drop_thresh) {
@@ -404,26 +511,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
       }
     }
   }
-  // merge the 4 waves through one [4][32 keys][65] f32 buffer: dV first, then dK
-  float *cb = reinterpret_cast<float *>(smem);
+  // rows = this wave's keys (registers), cols = channels (lanes): 64-byte row segments straight to memory
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
+  for (int t = 0; t < 2; ++t) {
+    const int d = 32 * t + kl;
+    if (d < g.D) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        cb[(wave * 32 + acc_row(r, h)) * 65 + 32 * t + kl] = pass == 0 ? accv[t][r] : acck[t][r];
-    __syncthreads();
-    bf16_t *dst = pass == 0 ? dV : dK;
-    const long long sl = pass == 0 ? dv_sl : dk_sl, sn = pass == 0 ? dv_sn : dk_sn;
-    const float mul = pass == 0 ? 1.f : g.scale;
-    for (int idx = tid; idx < 32 * g.D; idx += 256) {
-      const int kk = idx / g.D, d = idx - kk * g.D;
-      if (k0 + kk < g.S) {
-        const float v = cb[(0 * 32 + kk) * 65 + d] + cb[(1 * 32 + kk) * 65 + d] + cb[(2 * 32 + kk) * 65 + d] +
-                        cb[(3 * 32 + kk) * 65 + d];
-        dst[(long long)(k0 + kk) * sl + n * sn + hd * g.D + d] = (bf16_t)(v * mul);
+      for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + acc_row(r, h);
+        if (kk < g.S) {
+          dV[(long long)kk * dv_sl + n * dv_sn + hd * g.D + d] = (bf16_t)accv[t][r];
+          dK[(long long)kk * dk_sl + n * dk_sn + hd * g.D + d] = (bf16_t)(acck[t][r] * g.scale);
+        }
       }
     }
   }
@@ -489,7 +588,7 @@ extern "C" int omnipq_attn_bwd(int N, int H, int L, int S, int D, const void *q,
       g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)o, (const bf16_t *)d_o, lse2, delta,
       (bf16_t *)dq, grad_strides[0], grad_strides[1]);
   OMNIPQ_LAUNCH_CHECK();
-  attn_bwd_dkdv_kernel<<<dim3((S + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
+  attn_bwd_dkdv_kernel<<<dim3((S + 127) / 128, N * H), 256, 0, (hipStream_t)stream>>>(
       g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)d_o, lse2, delta, (bf16_t *)dk,
       grad_strides[2], grad_strides[3], (bf16_t *)dv, grad_strides[4], grad_strides[5]);
   OMNIPQ_LAUNCH_CHECK();
