@@ -70,6 +70,9 @@ int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const
 int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);
 int omnipq_colstats_z(long long P, int C, const void *Y, double *sums, void *stream);
 
+/* sums[c] += sum_p Y[p][c] for bf16 Y [P][C], any C % 8 == 0 (bias gradients). */
+int omnipq_colsum(long long P, int C, const void *Y, double *sums, void *stream);
+
 /* Weight preparation in one pass: W f32 [cout][cin] (row pitch ldw) -> Wp bf16 [cp][k] zero-padded with its
  * columns rotated left by `rot` (SA layer 0: [xyz, feat] -> [feat, xyz]) and, if Wt != NULL, Wt bf16 [k][cp]
  * = Wp^T.  omnipq_unprep_wgrad undoes padding and rotation for the f32 weight gradient. */

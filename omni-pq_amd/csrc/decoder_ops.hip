@@ -1,0 +1,404 @@
+// Row-wise pieces of the transformer decoder layer (reference models/transformer.py:188-228):
+// residual add + dropout + LayerNorm in one pass (forward and backward), ReLU + dropout of the FFN, and the
+// position-embedding add.  One wave per row: a lane keeps its channels (float4 chunks lane, lane+64, ...)
+// in registers, row statistics are two DPP-free butterfly reductions, every global access is 16 bytes
+// (8 for bf16) per lane along the row.  The parameter gradients (dgamma, dbeta) are accumulated per lane
+// over all rows a wave visits, folded across the block's waves in LDS and added with one atomic per
+// channel per block.
+#include "common.h"
+#include "omnipq_decoder.h"
+
+namespace omnipq {
+
+typedef __bf16 bf16_t;
+constexpr int LN_MAXCH = 4;          // float4 chunks per lane: C <= 64 * 4 * 4 = 1024
+
+__device__ __forceinline__ unsigned dec_seed(const unsigned long long *seed_ptr, unsigned salt) {
+  const unsigned long long s = *seed_ptr * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (salt + 1u);
+  return (unsigned)(s >> 32) ^ (unsigned)s;
+}
+
+__device__ __forceinline__ unsigned dec_hash(unsigned idx, unsigned seed) {
+  unsigned x = idx ^ seed;
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ void unpack4(uint2 w, float *f) {
+  f[0] = __builtin_bit_cast(float, w.x << 16);
+  f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, w.y << 16);
+  f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint2 pack4(const float *f) {
+  uint2 w;
+  w.x = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[0]) |
+        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[1]) << 16);
+  w.y = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[2]) |
+        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[3]) << 16);
+  return w;
+}
+
+struct LnArgs {
+  long long R;
+  int C;
+  float eps, keep_inv;
+  unsigned thresh, salt;
+  const unsigned long long *seed_ptr;
+};
+
+// r = x + dropout(y) for this lane's chunks of one row
+__device__ __forceinline__ void load_residual(const LnArgs &g, long long row, int lane, unsigned seed,
+                                              const float *__restrict__ x, const bf16_t *__restrict__ y,
+                                              float (*r)[4]) {
+  const int nch = g.C >> 2;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + row * g.C + c * 4);
+      r[i][0] = xv.x, r[i][1] = xv.y, r[i][2] = xv.z, r[i][3] = xv.w;
+      if (y) {
+        float yv[4];
+        unpack4(*reinterpret_cast<const uint2 *>(y + row * g.C + c * 4), yv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = yv[e];
+          if (g.thresh) v = dec_hash((unsigned)(row * g.C + c * 4 + e), seed) >= g.thresh ? v * g.keep_inv : 0.f;
+          r[i][e] += v;
+        }
+      }
+    } else {
+      r[i][0] = r[i][1] = r[i][2] = r[i][3] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs g, const float *__restrict__ x,
+                                                    const bf16_t *__restrict__ y, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, float *__restrict__ out32,
+                                                    bf16_t *__restrict__ out16, const bf16_t *__restrict__ pe,
+                                                    bf16_t *__restrict__ out16_pe, float *__restrict__ mean,
+                                                    float *__restrict__ rstd) {
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const int nch = g.C >> 2;
+  const unsigned seed = g.thresh ? dec_seed(g.seed_ptr, g.salt) : 0u;
+  const float invC = 1.0f / (float)g.C;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < g.R; row += (long long)gridDim.x * 4) {
+    float r[LN_MAXCH][4];
+    load_residual(g, row, lane, seed, x, y, r);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) s += (r[i][0] + r[i][1]) + (r[i][2] + r[i][3]);
+    const float mu = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i)
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = r[i][e] - mu;
+          q += d * d;
+        }
+      }
+    const float rs = rsqrtf(wave_sum(q) * invC + g.eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 gv = *reinterpret_cast<const float4 *>(gamma + c * 4);
+        const float4 bv = *reinterpret_cast<const float4 *>(beta + c * 4);
+        float o[4];
+        o[0] = (r[i][0] - mu) * rs * gv.x + bv.x;
+        o[1] = (r[i][1] - mu) * rs * gv.y + bv.y;
+        o[2] = (r[i][2] - mu) * rs * gv.z + bv.z;
+        o[3] = (r[i][3] - mu) * rs * gv.w + bv.w;
+        if (out32) *reinterpret_cast<float4 *>(out32 + row * g.C + c * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (out16) *reinterpret_cast<uint2 *>(out16 + row * g.C + c * 4) = pack4(o);
+        if (out16_pe) {
+          float p[4];
+          unpack4(*reinterpret_cast<const uint2 *>(pe + row * g.C + c * 4), p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[e] += o[e];
+          *reinterpret_cast<uint2 *>(out16_pe + row * g.C + c * 4) = pack4(p);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs g, const float *__restrict__ x,
+                                                    const bf16_t *__restrict__ y, const float *__restrict__ gamma,
+                                                    const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                    const float *__restrict__ g32, const bf16_t *__restrict__ g16,
+                                                    const bf16_t *__restrict__ g16_pe, float *__restrict__ dx,
+                                                    bf16_t *__restrict__ dy, float *__restrict__ dgb) {
+  extern __shared__ float dyn[];                            // [4 waves][dgamma | dbeta][C]
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const int nch = g.C >> 2;
+  const unsigned seed = g.thresh ? dec_seed(g.seed_ptr, g.salt) : 0u;
+  const float invC = 1.0f / (float)g.C;
+  float ag[LN_MAXCH][4], ab[LN_MAXCH][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ag[i][e] = ab[i][e] = 0.f;
+  float gam[LN_MAXCH][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int c = lane + 64 * i;
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nch) gv = *reinterpret_cast<const float4 *>(gamma + c * 4);
+    gam[i][0] = gv.x, gam[i][1] = gv.y, gam[i][2] = gv.z, gam[i][3] = gv.w;
+  }
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < g.R; row += (long long)gridDim.x * 4) {
+    float r[LN_MAXCH][4], go[LN_MAXCH][4];
+    load_residual(g, row, lane, seed, x, y, r);
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g32) {
+          const float4 v = *reinterpret_cast<const float4 *>(g32 + row * g.C + c * 4);
+          t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+        }
+        if (g16) {
+          float u[4];
+          unpack4(*reinterpret_cast<const uint2 *>(g16 + row * g.C + c * 4), u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] += u[e];
+        }
+        if (g16_pe) {
+          float u[4];
+          unpack4(*reinterpret_cast<const uint2 *>(g16_pe + row * g.C + c * 4), u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] += u[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (r[i][e] - mu) * rs;
+          ag[i][e] += t[e] * xh;
+          ab[i][e] += t[e];
+          const float dxh = t[e] * gam[i][e];
+          go[i][e] = dxh;
+          r[i][e] = xh;
+          s1 += dxh;
+          s2 += dxh * xh;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) go[i][e] = 0.f;
+      }
+    }
+    const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = rs * (go[i][e] - m1 - r[i][e] * m2);
+        *reinterpret_cast<float4 *>(dx + row * g.C + c * 4) = make_float4(d[0], d[1], d[2], d[3]);
+        if (dy) {
+          if (g.thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              d[e] = dec_hash((unsigned)(row * g.C + c * 4 + e), seed) >= g.thresh ? d[e] * g.keep_inv : 0.f;
+          }
+          *reinterpret_cast<uint2 *>(dy + row * g.C + c * 4) = pack4(d);
+        }
+      }
+    }
+  }
+  // fold the four waves' parameter-gradient partials, one atomic per channel per block
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dyn[(wave * 2 + 0) * g.C + c * 4 + e] = ag[i][e];
+        dyn[(wave * 2 + 1) * g.C + c * 4 + e] = ab[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = (int)threadIdx.x; j < 2 * g.C; j += 256) {
+    const int which = j / g.C, c = j - which * g.C;
+    const float v = dyn[(0 * 2 + which) * g.C + c] + dyn[(1 * 2 + which) * g.C + c] + dyn[(2 * 2 + which) * g.C + c] +
+                    dyn[(3 * 2 + which) * g.C + c];
+    atomicAdd(dgb + j, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_dropout_kernel(long long n4, bf16_t *__restrict__ h, float keep_inv,
+                                                          unsigned thresh, unsigned salt,
+                                                          const unsigned long long *__restrict__ seed_ptr) {
+  const unsigned seed = thresh ? dec_seed(seed_ptr, salt) : 0u;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    float v[4];
+    unpack4(*reinterpret_cast<const uint2 *>(h + q * 4), v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e] > 0.f ? v[e] : 0.f;
+      if (thresh) t = dec_hash((unsigned)(q * 4 + e), seed) >= thresh ? t * keep_inv : 0.f;
+      v[e] = t;
+    }
+    *reinterpret_cast<uint2 *>(h + q * 4) = pack4(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(long long n4, const bf16_t *__restrict__ h,
+                                                              bf16_t *__restrict__ d, float keep_inv) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    float hv[4], dv[4];
+    unpack4(*reinterpret_cast<const uint2 *>(h + q * 4), hv);
+    unpack4(*reinterpret_cast<const uint2 *>(d + q * 4), dv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = hv[e] > 0.f ? dv[e] * keep_inv : 0.f;
+    *reinterpret_cast<uint2 *>(d + q * 4) = pack4(dv);
+  }
+}
+
+template <bool A_F32>
+__global__ __launch_bounds__(256) void add_to_bf16_kernel(long long n4, const void *__restrict__ a,
+                                                         const bf16_t *__restrict__ b, bf16_t *__restrict__ out) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    float av[4], bv[4];
+    if (A_F32) {
+      const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a) + q * 4);
+      av[0] = v.x, av[1] = v.y, av[2] = v.z, av[3] = v.w;
+    } else {
+      unpack4(*reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(a) + q * 4), av);
+    }
+    unpack4(*reinterpret_cast<const uint2 *>(b + q * 4), bv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) av[e] += bv[e];
+    *reinterpret_cast<uint2 *>(out + q * 4) = pack4(av);
+  }
+}
+
+static int drop_params(float p, const unsigned long long *seed_ptr, unsigned *thresh, float *keep_inv) {
+  if (!(p >= 0.f) || p >= 1.f || (p > 0.f && !seed_ptr)) return OMNIPQ_EINVAL;
+  double th = (double)p * 4294967296.0;
+  *thresh = p > 0.f ? (unsigned)(th < 1.0 ? 1.0 : (th > 4294967295.0 ? 4294967295.0 : th)) : 0u;
+  *keep_inv = 1.0f / (1.0f - p);
+  return OMNIPQ_OK;
+}
+
+static int rows_grid(long long R) {
+  long long b = (R + 3) / 4;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+static int flat_grid(long long n4) {
+  long long b = (n4 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace omnipq
+
+extern "C" int omnipq_add_dropout_layernorm(long long R, int C, const float *x, const void *y, const float *gamma,
+                                            const float *beta, float eps, float dropout_p,
+                                            const unsigned long long *seed_ptr, unsigned salt, float *out32,
+                                            void *out16, const void *pe, void *out16_pe, float *mean, float *rstd,
+                                            void *stream) {
+  using namespace omnipq;
+  if (R < 0 || C <= 0 || (C % 4) || C > 64 * 4 * LN_MAXCH) return OMNIPQ_EINVAL;
+  if (R == 0) return OMNIPQ_OK;
+  if (!x || !gamma || !beta || !mean || !rstd || (!pe != !out16_pe)) return OMNIPQ_EINVAL;
+  if (R * C >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
+  LnArgs g{R, C, eps, 1.f, 0u, salt, seed_ptr};
+  const int rc = drop_params(y ? dropout_p : 0.f, seed_ptr, &g.thresh, &g.keep_inv);
+  if (rc) return rc;
+  ln_fwd_kernel<<<rows_grid(R), 256, 0, (hipStream_t)stream>>>(g, x, (const bf16_t *)y, gamma, beta, out32,
+                                                              (bf16_t *)out16, (const bf16_t *)pe, (bf16_t *)out16_pe,
+                                                              mean, rstd);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_add_dropout_layernorm_bwd(long long R, int C, const float *x, const void *y, const float *gamma,
+                                                float dropout_p, const unsigned long long *seed_ptr, unsigned salt,
+                                                const float *mean, const float *rstd, const float *g32,
+                                                const void *g16, const void *g16_pe, float *dx, void *dy,
+                                                float *dgamma_dbeta, void *stream) {
+  using namespace omnipq;
+  if (R < 0 || C <= 0 || (C % 4) || C > 64 * 4 * LN_MAXCH) return OMNIPQ_EINVAL;
+  if (R == 0) return OMNIPQ_OK;
+  if (!x || !gamma || !mean || !rstd || !dx || !dgamma_dbeta || (!y != !dy)) return OMNIPQ_EINVAL;
+  if (R * C >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
+  LnArgs g{R, C, 0.f, 1.f, 0u, salt, seed_ptr};
+  const int rc = drop_params(y ? dropout_p : 0.f, seed_ptr, &g.thresh, &g.keep_inv);
+  if (rc) return rc;
+  long long blocks = (R + 3) / 4;
+  if (blocks > 256) blocks = 256;                       // each block ends with 2C atomics: keep them few
+  ln_bwd_kernel<<<(int)blocks, 256, sizeof(float) * 8 * C, (hipStream_t)stream>>>(
+      g, x, (const bf16_t *)y, gamma, mean, rstd, g32, (const bf16_t *)g16, (const bf16_t *)g16_pe, dx, (bf16_t *)dy,
+      dgamma_dbeta);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_relu_dropout(long long n, void *h, float dropout_p, const unsigned long long *seed_ptr,
+                                   unsigned salt, void *stream) {
+  using namespace omnipq;
+  if (n < 0 || (n % 4)) return OMNIPQ_EINVAL;
+  if (n == 0) return OMNIPQ_OK;
+  if (!h) return OMNIPQ_EINVAL;
+  if (n >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
+  unsigned thresh;
+  float keep_inv;
+  const int rc = drop_params(dropout_p, seed_ptr, &thresh, &keep_inv);
+  if (rc) return rc;
+  relu_dropout_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, (bf16_t *)h, keep_inv, thresh, salt,
+                                                                        seed_ptr);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_relu_dropout_bwd(long long n, const void *h, void *d, float dropout_p, void *stream) {
+  using namespace omnipq;
+  if (n < 0 || (n % 4) || !(dropout_p >= 0.f) || dropout_p >= 1.f) return OMNIPQ_EINVAL;
+  if (n == 0) return OMNIPQ_OK;
+  if (!h || !d) return OMNIPQ_EINVAL;
+  relu_dropout_bwd_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, (const bf16_t *)h, (bf16_t *)d,
+                                                                            1.0f / (1.0f - dropout_p));
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16,
+                                  void *stream) {
+  using namespace omnipq;
+  if (n < 0 || (n % 4)) return OMNIPQ_EINVAL;
+  if (n == 0) return OMNIPQ_OK;
+  if (!a || !b || !out16) return OMNIPQ_EINVAL;
+  if (a_is_f32)
+    add_to_bf16_kernel<true><<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, a, (const bf16_t *)b,
+                                                                               (bf16_t *)out16);
+  else
+    add_to_bf16_kernel<false><<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, a, (const bf16_t *)b,
+                                                                                (bf16_t *)out16);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

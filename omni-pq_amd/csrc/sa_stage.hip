@@ -267,6 +267,33 @@ __global__ void bwd_means_kernel(int n2, double invP, const double *__restrict__
   if (i < n2) st[i] = (float)(sums[i] * invP);
 }
 
+// column sums of a bf16 [P][C] matrix for any C % 8 == 0 (bias gradients of wide layers):
+// block = 32 column pieces (256 columns) x 8 row lanes; grid (ceil(C/256), row slabs); sums += (f64 atomics)
+__global__ __launch_bounds__(256) void colsum_kernel(long long P, int C, const bf16_t *__restrict__ Y,
+                                                    double *__restrict__ sums) {
+  __shared__ float red[8][256];
+  const int tid = (int)threadIdx.x, piece = (int)blockIdx.x * 32 + (tid & 31), rsub = tid >> 5;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (piece * 8 < C) {
+    for (long long p = (long long)blockIdx.y * 8 + rsub; p < P; p += (long long)gridDim.y * 8) {
+      float y[8];
+      unpack8(*reinterpret_cast<const uint4 *>(Y + (size_t)p * C + piece * 8), y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += y[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rsub][(tid & 31) * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = (int)blockIdx.x * 256 + tid;
+  if (c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][tid];
+    atomicAdd(sums + c, (double)t);
+  }
+}
+
 // weight preparation for the GEMMs, one pass: W f32 [cout][cin] (row pitch ldw) ->
 //   Wp bf16 [cp][k]   zero-padded, columns rotated left by `rot` (SA layer 0: [xyz(3), feat] -> [feat, xyz])
 //   Wt bf16 [k][cp]   its transpose (operand of the data-gradient GEMM)
@@ -812,6 +839,19 @@ extern "C" int omnipq_unprep_wgrad(int cout, int cin, int k, int rot, const floa
 extern "C" int omnipq_sums_to_f32(int C, const double *sums, float *dbeta, float *dgamma, void *stream) {
   if (C <= 0 || !sums || !dbeta || !dgamma) return OMNIPQ_EINVAL;
   sums_to_f32_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, sums, dbeta, dgamma);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// sums[c] += sum_p Y[p][c]   (bf16 [P][C], C % 8 == 0, sums zero on entry or carrying a running total)
+extern "C" int omnipq_colsum(long long P, int C, const void *Y, double *sums, void *stream) {
+  if (P < 0 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  if (!Y || !sums) return OMNIPQ_EINVAL;
+  if (P == 0) return OMNIPQ_OK;
+  long long slabs = P / 128;
+  if (slabs < 1) slabs = 1;
+  if (slabs > 64) slabs = 64;
+  colsum_kernel<<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

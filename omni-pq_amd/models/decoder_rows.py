@@ -1,0 +1,151 @@
+"""The transformer decoder layer on row-major activations and the hand-written kernels.
+
+Reference: models/transformer.py:188-228 (`TransformerDecoderLayer.forward_post`):
+    q = k = x + query_pos_embed;  x = norm1(x + dropout1(self_attn(q, k, x)))            [*]
+    x = norm2(x + dropout2(cross_attn(x + query_pos_embed, mem + key_pos_embed, mem + key_pos_embed)))
+    x = norm3(x + dropout3(linear2(dropout(relu(linear1(x))))))
+([*] the reference passes `value = q` too: its self attention projects v from the position-augmented
+tensor, and so does this file.)
+
+Layout: one token per row, rows ordered (batch, token), channels contiguous -- exactly how the tensors
+around the decoder already lie in memory (`conv1x1` / the prediction heads produce and consume (B, P, C)
+data viewed as (B, C, P)), so entering and leaving the layer costs no copies.  The residual stream is f32,
+branch outputs and GEMM operands bf16.  Per layer, forward:
+    add(x, q_pe) -> GEMM(in_proj 864) -> attention(packed qkv) -> GEMM(out_proj) -> add+dropout+LayerNorm(+q_pe)
+    -> GEMM(q) | add(mem, k_pe) -> GEMM(kv 576) -> attention(q, packed kv) -> GEMM(out_proj) -> add+dropout+LN
+    -> GEMM(2048)+bias -> relu+dropout -> GEMM(288)+bias -> add+dropout+LN
+Every node is a custom autograd Function whose backward runs the mirrored kernels (csrc/attention.hip,
+decoder_ops.hip, gemm_*.hip through `rows_mlp`).
+"""
+import ctypes
+
+import torch
+
+import dropout_state
+import rows_mlp
+from sa_fused import _call, _lib, _p, zeros_f32
+from utils import fused_attention
+
+
+class AddToBf16(torch.autograd.Function):
+    """bf16(a + b): a f32 or bf16 rows, b bf16 rows (position-embedding add)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+        _call(_lib.omnipq_add_to_bf16, a, ctypes.c_longlong(a.numel()), _p(a), int(a.dtype == torch.float32), _p(b),
+              _p(out))
+        ctx.a_dtype = a.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.a_dtype) if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None)
+
+
+class AddDropoutLayerNorm(torch.autograd.Function):
+    """(x f32, y bf16 | None, gamma, beta, eps, p, pe bf16 | None, want32, want16)
+    -> (LayerNorm(x + dropout(y)) as f32 | None, as bf16 | None, bf16(that + pe) | None)"""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, eps, p, pe, want32, want16):
+        R, C = x.shape
+        dev = x.device
+        out32 = torch.empty((R, C), device=dev, dtype=torch.float32) if want32 else None
+        out16 = torch.empty((R, C), device=dev, dtype=torch.bfloat16) if want16 else None
+        out_pe = torch.empty((R, C), device=dev, dtype=torch.bfloat16) if pe is not None else None
+        mean = torch.empty(R, device=dev, dtype=torch.float32)
+        rstd = torch.empty(R, device=dev, dtype=torch.float32)
+        drop = p > 0 and y is not None
+        seed = dropout_state.seed(dev) if drop else None
+        salt = dropout_state.next_salt() if drop else 0
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        _call(_lib.omnipq_add_dropout_layernorm, x, ctypes.c_longlong(R), C, _p(x), _p(y), _p(g32), _p(b32),
+              ctypes.c_float(eps), ctypes.c_float(p if drop else 0.0), _p(seed), salt, _p(out32), _p(out16), _p(pe),
+              _p(out_pe), _p(mean), _p(rstd))
+        ctx.save_for_backward(x, y, g32, mean, rstd)
+        ctx.cfg = (p if drop else 0.0, seed, salt, pe is not None)
+        return out32, out16, out_pe
+
+    @staticmethod
+    def backward(ctx, g32, g16, gpe):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        p, seed, salt, has_pe = ctx.cfg
+        R, C = x.shape
+        g32 = g32.contiguous() if g32 is not None else None
+        g16 = g16.contiguous() if g16 is not None else None
+        gpe = gpe.contiguous() if gpe is not None else None
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(y) if y is not None else None
+        dgb = zeros_f32(2 * C, x.device)
+        _call(_lib.omnipq_add_dropout_layernorm_bwd, x, ctypes.c_longlong(R), C, _p(x), _p(y), _p(gamma),
+              ctypes.c_float(p), _p(seed), salt, _p(mean), _p(rstd), _p(g32), _p(g16), _p(gpe), _p(dx), _p(dy), _p(dgb))
+        return dx, dy, dgb[:C], dgb[C:], None, None, (gpe if has_pe else None), None, None
+
+
+def usable(layer, query, key):
+    """bf16 autocast on the GPU, learned position embeddings present, shapes the kernels accept."""
+    if not query.is_cuda or not torch.is_autocast_enabled("cuda") or \
+            torch.get_autocast_dtype("cuda") != torch.bfloat16:
+        return False
+    if layer.self_posembed is None or layer.cross_posembed is None or layer.activation is not torch.nn.functional.relu:
+        return False
+    C = query.shape[1]
+    H = layer.self_attn.num_heads
+    D = C // H
+    if C % 32 or D * H != C or D % 4 or D > fused_attention.MAX_HEAD_DIM or layer.linear1.out_features % 32:
+        return False
+    if not layer.training and torch.is_grad_enabled():
+        return False
+    return True
+
+
+def _rows(x_bcp):
+    """(B, C, P) -> (B*P, C); free when x is a transposed view of (B, P, C) data."""
+    B, C, P = x_bcp.shape
+    return x_bcp.transpose(1, 2).reshape(B * P, C)
+
+
+def run(layer, query, key, query_pos, key_pos):
+    """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3), key_pos (B,Pk,3) -> (B,C,Pq) f32 (a view of rows)."""
+    B, C, Pq = query.shape
+    Pk = key.shape[2]
+    training = layer.training
+    sa, ca = layer.self_attn, layer.multihead_attn
+    H = sa.num_heads
+    p_attn = float(sa.dropout) if training else 0.0
+
+    def pdrop(m):
+        return float(m.p) if training else 0.0
+
+    def linear(x, w, b, **kw):
+        return rows_mlp.run(x, [rows_mlp.Layer(w, b, **kw)], training)
+
+    x32 = _rows(query).float()
+    mem16 = _rows(key).to(torch.bfloat16)
+    q_pe = _rows(layer.self_posembed(query_pos)).to(torch.bfloat16)
+    k_pe = _rows(layer.cross_posembed(key_pos)).to(torch.bfloat16)
+
+    # self attention: q = k = v = x + q_pe (transformer.py:203-205)
+    qk = AddToBf16.apply(x32, q_pe)
+    qkv = linear(qk, sa.in_proj_weight, sa.in_proj_bias)
+    att = fused_attention.PackedAttention.apply(qkv, None, Pq, Pq, B, H, p_attn)
+    y = linear(att, sa.out_proj.weight, sa.out_proj.bias)
+    x32, _, xq = AddDropoutLayerNorm.apply(x32, y, layer.norm1.weight, layer.norm1.bias, float(layer.norm1.eps),
+                                           pdrop(layer.dropout1), q_pe, True, False)
+
+    # cross attention: query x + q_pe, key = value = mem + k_pe (:208-213)
+    q = linear(xq, ca.in_proj_weight[:C], ca.in_proj_bias[:C])
+    mem_pe = AddToBf16.apply(mem16, k_pe)
+    kv = linear(mem_pe, ca.in_proj_weight[C:], ca.in_proj_bias[C:])
+    att = fused_attention.PackedAttention.apply(q, kv, Pq, Pk, B, H, float(ca.dropout) if training else 0.0)
+    y = linear(att, ca.out_proj.weight, ca.out_proj.bias)
+    x32, x16, _ = AddDropoutLayerNorm.apply(x32, y, layer.norm2.weight, layer.norm2.bias, float(layer.norm2.eps),
+                                            pdrop(layer.dropout2), None, True, True)
+
+    # feed-forward (:216-219)
+    y = rows_mlp.run(x16, [rows_mlp.Layer(layer.linear1.weight, layer.linear1.bias, relu_dropout=pdrop(layer.dropout)),
+                           rows_mlp.Layer(layer.linear2.weight, layer.linear2.bias)], training)
+    x32, _, _ = AddDropoutLayerNorm.apply(x32, y, layer.norm3.weight, layer.norm3.bias, float(layer.norm3.eps),
+                                          pdrop(layer.dropout3), None, True, False)
+    return x32.view(B, Pq, C).transpose(1, 2)

@@ -18,6 +18,9 @@ if _HERE not in sys.path:
     sys.path.append(_HERE)
 
 from utils.multi_head_attention import MultiheadAttention  # noqa: E402
+import decoder_rows  # noqa: E402
+
+_USE_ROWS = os.environ.get("OMNIPQ_DECODER", "rows") != "torch"
 
 
 def _get_activation_fn(activation):
@@ -54,6 +57,8 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, query, key, query_pos, key_pos):
         """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3), key_pos (B,Pk,3) -> (B,C,Pq)"""
+        if _USE_ROWS and decoder_rows.usable(self, query, key):
+            return decoder_rows.run(self, query, key, query_pos, key_pos)      # hand-written kernels, row-major
         q_pe = k_pe = None
         if self.self_posembed is not None and query_pos is not None:
             q_pe = self.self_posembed(query_pos).permute(2, 0, 1)

@@ -15,33 +15,7 @@ from sa_fused import _call, _lib, _p
 MAX_HEAD_DIM = 48
 
 
-class _DropoutState:
-    """Per-device 64-bit seed in device memory (a captured graph reads the CURRENT value on every replay)
-    plus a host-side call counter (`salt`) that tells apart the attention calls sharing one seed."""
-
-    def __init__(self):
-        self.seeds = {}
-        self.salt = 0
-
-    def seed(self, device):
-        t = self.seeds.get(device)
-        if t is None:
-            # drawn from torch's generator, so torch.manual_seed() governs the masks
-            t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-            self.seeds[device] = t
-        return t
-
-    def advance(self, device):
-        """New seed for the next training step; call once per forward of the model (one tiny kernel)."""
-        self.seed(device).add_(0x9E3779B97F4A7C15 >> 2)
-        self.salt = 0
-
-    def next_salt(self):
-        self.salt += 1
-        return self.salt
-
-
-STATE = _DropoutState()
+from dropout_state import STATE  # noqa: E402  (shared with the other dropout sites of the decoder)
 
 
 def usable(q, k, v, num_heads):
@@ -111,3 +85,63 @@ def dropout_mask(N, H, L, S, dropout_p, seed, salt):
     mask = torch.empty((N * H, L, S), device=seed.device, dtype=torch.uint8)
     _call(_lib.omnipq_attn_dropout_mask, mask, N, H, L, S, ctypes.c_float(dropout_p), _p(seed), salt, _p(mask))
     return mask
+
+
+class PackedAttention(torch.autograd.Function):
+    """The same kernels on ROW-MAJOR projections, rows ordered (batch, token):
+        a (N*L, 3E), b None        self attention on a packed q|k|v projection
+        a (N*L, E),  b (N*S, 2E)   cross attention, b = packed k|v projection
+    -> (N*L, E).  The gradient comes back in the same packed form (dq|dk|dv written side by side by the
+    kernels), so autograd sees one tensor in, one tensor out -- no split / cat around the call."""
+
+    @staticmethod
+    def _pointers(a, b, E, L, S):
+        if b is None:
+            base = a.data_ptr()
+            return (base, base + 2 * E, base + 4 * E), [3 * E, L * 3 * E] * 3
+        kb = b.data_ptr()
+        return (a.data_ptr(), kb, kb + 2 * E), [E, L * E, 2 * E, S * 2 * E, 2 * E, S * 2 * E]
+
+    @staticmethod
+    def forward(ctx, a, b, L, S, N, H, dropout_p):
+        E = a.shape[1] // 3 if b is None else a.shape[1]
+        D = E // H
+        (qp, kp, vp), st = PackedAttention._pointers(a, b, E, L, S)
+        o = torch.empty((N * L, E), device=a.device, dtype=torch.bfloat16)
+        lse = torch.empty((N * H, L), device=a.device, dtype=torch.float32)
+        seed = STATE.seed(a.device) if dropout_p > 0 else None
+        salt = STATE.next_salt() if dropout_p > 0 else 0
+        strides = (ctypes.c_longlong * 8)(*(st + [E, L * E]))
+        _call(_lib.omnipq_attn_fwd, a, N, H, L, S, D, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp),
+              _p(o), strides, _p(lse), ctypes.c_float(dropout_p), _p(seed), salt)
+        ctx.save_for_backward(a, b, o, lse)
+        ctx.cfg = (L, S, N, H, dropout_p, seed, salt)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        a, b, o, lse = ctx.saved_tensors
+        L, S, N, H, dropout_p, seed, salt = ctx.cfg
+        E = o.shape[1]
+        D = E // H
+        d_o = d_o.to(torch.bfloat16).contiguous()
+        (qp, kp, vp), st = PackedAttention._pointers(a, b, E, L, S)
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if b is not None else None
+        (dqp, dkp, dvp), gst = PackedAttention._pointers(da, db, E, L, S)
+        delta = torch.empty_like(lse)
+        strides = (ctypes.c_longlong * 8)(*(st + [E, L * E]))
+        gstrides = (ctypes.c_longlong * 6)(*gst)
+        _call(_lib.omnipq_attn_bwd, a, N, H, L, S, D, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp),
+              _p(o), _p(d_o), strides, _p(lse), _p(delta), ctypes.c_void_p(dqp), ctypes.c_void_p(dkp),
+              ctypes.c_void_p(dvp), gstrides, ctypes.c_float(dropout_p), _p(seed), salt)
+        return da, db, None, None, None, None, None
+
+
+def packed_usable(a, b, H):
+    E = a.shape[1] // 3 if b is None else a.shape[1]
+    D = E // H
+    ok = a.is_cuda and a.dtype == torch.bfloat16 and a.is_contiguous() and D * H == E and D % 4 == 0 and D <= MAX_HEAD_DIM
+    if b is not None:
+        ok = ok and b.dtype == torch.bfloat16 and b.is_contiguous() and b.shape[1] == 2 * E
+    return ok

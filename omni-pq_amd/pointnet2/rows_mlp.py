@@ -20,6 +20,7 @@ import ctypes
 
 import torch
 
+import dropout_state
 import sa_fused
 from sa_fused import (_allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
                       unprep_wgrad, zeros_f32, zeros_f64)
@@ -27,10 +28,12 @@ from sa_fused import (_allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_
 
 class Layer:
     """One linear layer of the stack: weight (C_out, C_in[,1[,1]]), optional bias, optional BatchNorm
-    module (BatchNorm1d/2d/SyncBatchNorm; with it a ReLU follows, as everywhere in the reference)."""
+    module (BatchNorm1d/2d/SyncBatchNorm; with it a ReLU follows, as everywhere in the reference), or --
+    without BatchNorm -- `relu_dropout=p`: ReLU then dropout(p) on the output (the decoder's feed-forward,
+    transformer.py:222; p = 0 in eval mode)."""
 
-    def __init__(self, weight, bias=None, bn=None):
-        self.weight, self.bias, self.bn = weight, bias, bn
+    def __init__(self, weight, bias=None, bn=None, relu_dropout=None):
+        self.weight, self.bias, self.bn, self.relu_dropout = weight, bias, bn, relu_dropout
 
 
 def usable(x, layers, training):
@@ -54,14 +57,23 @@ def run(x_rows, layers, training):
     spec, params = [], []
     for lay in layers:
         bn = lay.bn
-        spec.append(None if bn is None else
-                    (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
+        if bn is None and lay.relu_dropout is not None:
+            p = float(lay.relu_dropout) if training else 0.0
+            spec.append(("relu_dropout", p, dropout_state.seed(x_rows.device) if p > 0 else None,
+                         dropout_state.next_salt() if p > 0 else 0))
+        else:
+            spec.append(None if bn is None else
+                        (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
         params += [lay.weight, lay.bias, None if bn is None else bn.weight, None if bn is None else bn.bias]
     return RowsMLP.apply(x_rows, spec, bool(training), *params)
 
 
+def _is_bn(entry):
+    return entry is not None and entry[0] != "relu_dropout"
+
+
 class _L:
-    __slots__ = ("K", "C", "Cp", "Wp", "Wt", "wk", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias")
+    __slots__ = ("act", "K", "C", "Cp", "Wp", "Wt", "wk", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias")
 
 
 class RowsMLP(torch.autograd.Function):
@@ -85,7 +97,8 @@ class RowsMLP(torch.autograd.Function):
             W2 = W.detach().reshape(W.shape[0], -1)
             cout, wk = W2.shape
             lay.C, lay.K, lay.Cp = cout, K, _round_up(cout, 32)
-            lay.has_bn, lay.has_bias, lay.wk = spec[l] is not None, bias is not None, wk
+            lay.has_bn, lay.has_bias, lay.wk = _is_bn(spec[l]), bias is not None, wk
+            lay.act = spec[l] if (spec[l] is not None and not lay.has_bn) else None
             lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training)
             if lay.has_bn and lay.Cp != cout:
                 raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
@@ -127,6 +140,10 @@ class RowsMLP(torch.autograd.Function):
                 _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
                 X = lay.X
             else:
+                if lay.act is not None:
+                    _, p, seed, salt = lay.act
+                    _call(_lib.omnipq_relu_dropout, Y, ctypes.c_longlong(N * lay.Cp), _p(Y), ctypes.c_float(p),
+                          _p(seed), salt)
                 lay.X = Y
                 X = Y
             K = lay.Cp
@@ -172,9 +189,13 @@ class RowsMLP(torch.autograd.Function):
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
                 _call(_lib.omnipq_bn_bwd_apply, dcur, ctypes.c_longlong(N), lay.C, total, _p(dcur), _p(lay.Y),
                       _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums), _p(dcur))
-            elif lay.has_bias:
-                sums = zeros_f64(2, lay.Cp, dev)
-                _call(_lib.omnipq_colstats_z, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(sums))
+            elif lay.act is not None:
+                # lay.Y holds dropout(relu(.)): positive exactly where the unit was active and kept
+                _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur),
+                      ctypes.c_float(lay.act[1]))
+            if not lay.has_bn and lay.has_bias:
+                sums = zeros_f64(1, lay.Cp, dev)
+                _call(_lib.omnipq_colsum, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(sums))
                 grads[4 * l + 1] = sums[0, :lay.C].float()
             dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N)
             grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
