@@ -151,6 +151,25 @@ def sa_stage_algorithmic_bytes(batch, points, extra_channels, e):
     return total * batch
 
 
+def pmc_traffic(kind):
+    """HBM bytes from the newest committed PMC summary (`profiles/r*_<kind>_pmc_traffic.json`, written by
+    tools/pmc_traffic.py from separate rocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
+    command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{kind}_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            return json.load(fh), os.path.relpath(files[-1], REPO)
+    except (OSError, ValueError):
+        return None, None
+
+
+# C-ABI entry point -> substring of the device kernel it launches for the benchmark's shapes
+PMC_KERNEL_OF = {"omnipq_furthest_point_sampling": "fps_kernel<1024, 4, true, true>"}
+
+
 def summarize_ops(sink, steps):
     """-> {(name, args): [total_ms, calls, bytes_per_call]}"""
     table = {}
@@ -468,9 +487,18 @@ def main():
             (name, a), (ms, calls, nbytes) = max(table.items(), key=lambda kv: kv[1][0])
             avg_ms = ms / calls
             gbs = nbytes / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = None, None
+            pmc, pmc_file = pmc_traffic("bench")
+            if pmc is not None and name.split("@")[0] in PMC_KERNEL_OF:
+                for row in pmc["kernels"]:
+                    if PMC_KERNEL_OF[name.split("@")[0]] in row["kernel"] and row["launches_per_step"] > 0:
+                        traffic = row["traffic_bytes_per_step"] / row["launches_per_step"]
+                        traffic_src = pmc_file
+                        break
             rec["roofline"] = {"bound": "hbm", "kernel": name, "shape": list(a), "achieved": gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": None, "avg_ms": avg_ms, "launches_per_step": calls / timing_steps,
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "avg_ms": avg_ms, "launches_per_step": calls / timing_steps,
                                "timing": timing_note,
                                "algorithmic_bytes_per_launch": nbytes}
             native_ms = sum(v[0] for v in table.values()) / timing_steps
@@ -484,6 +512,10 @@ def main():
                                "achieved": sa_bytes / (sa_ms * 1e-3) / 1e9 if sa_ms > 0 else None,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": sa_bytes / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sa_ms > 0 else None}
+            sa_pmc, sa_file = pmc_traffic("sa_stage")
+            if sa_pmc is not None and args.batch == 8 and args.points == 40000 and args.dtype == "bf16":
+                rec["sa_stage"]["traffic"] = sa_pmc["total_traffic_bytes_per_step"]
+                rec["sa_stage"]["traffic_source"] = sa_file
             if args.breakdown:
                 for (nm, aa), (ms_, calls_, nb) in sorted(table.items(), key=lambda kv: -kv[1][0]):
                     print(f"{nm:38s} {str(aa):34s} {ms_ / timing_steps:9.3f} ms/step  x{calls_ / timing_steps:4.1f}"

@@ -13,6 +13,8 @@
 //
 // Grid: (M tiles x N tiles) x slabs; each slab contracts a contiguous range of positions into an
 // f32 partial tile, a second kernel sums the slabs (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace omnipq {
@@ -42,10 +44,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
   static_assert(STAGE_ELEMS * 2 <= CT_BYTES, "staging must fit under the C tile");
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
 
-  const int tile = (int)blockIdx.x;
+  // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8 picks the XCD and
+  // all tiles of one slab are placed on it -- the slab's rows are then fetched into ONE L2 and shared by the
+  // m_tiles * n_tiles workgroups that read them, instead of once per XCD (PMC: the kernel fetched 2x its
+  // operands before).
+  const int id = (int)blockIdx.x, tiles = g.m_tiles * g.n_tiles;
+  const int xcd = id & 7, local = id >> 3;
+  const int slab = xcd + 8 * (local / tiles), tile = local % tiles;
+  if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
   const int mt = tile / g.n_tiles, nt = tile % g.n_tiles;
   const int m0 = mt * 128, n0 = nt * 128;
-  const int pbeg = (int)blockIdx.y * g.p_chunk;
+  const int pbeg = slab * g.p_chunk;
   int pend = pbeg + g.p_chunk;
   if (pend > g.P) pend = g.P;
   const int nk = (pend - pbeg + TBK - 1) / TBK;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
         ct[row * TCPITCH + wn * 64 + j * 32 + ccol] = acc[i][j][r];
       }
   __syncthreads();
-  float *C = part + (size_t)blockIdx.y * g.M * g.N;
+  float *C = part + (size_t)slab * g.M * g.N;
   for (int q = tid; q < 128 * 32; q += 256) {
     const int row = q >> 5, piece = q & 31;
     const int gr = m0 + row, gc = n0 + piece * 4;
@@ -197,13 +206,23 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int
 
 // C[M][N] (f32) = A[P][M]^T * B[P][N]; M, N multiples of 8; lda, ldb multiples of 8.
 // `workspace` must hold omnipq_gemm_tn_workspace_floats(M, N, P) floats.
+// How many slabs to cut the position axis into: enough workgroups to fill the chip (~512, two per CU), but every
+// workgroup keeps at least kMinSteps K-steps of work -- a slab costs a 64 KB f32 tile store plus its share of
+// the reduction, which dwarfs a one- or two-step main loop on the small per-point layers (P ~ 4096).
+static int tn_slabs(int tiles, int P) {
+  static const int kMinSteps = getenv("OMNIPQ_TN_MINSTEPS") ? atoi(getenv("OMNIPQ_TN_MINSTEPS")) : 6;
+  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 512;
+  int slabs = (kTarget + tiles - 1) / tiles;
+  const int max_slabs = (P + omnipq::TBK * kMinSteps - 1) / (omnipq::TBK * kMinSteps);
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  return slabs;
+}
+
 extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
   using namespace omnipq;
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int slabs = (1024 + tiles - 1) / tiles;
-  const int max_slabs = (P + TBK - 1) / TBK;
-  if (slabs > max_slabs) slabs = max_slabs;
-  if (slabs < 1) slabs = 1;
+  const int slabs = tn_slabs(tiles, P);
   return (long long)(slabs + kReduceGroups) * M * N;
 }
 
@@ -215,13 +234,10 @@ extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, 
   if (!A || !B || !C || !workspace || (M % 8) || (N % 8) || (lda % 8) || (ldb % 8)) return OMNIPQ_EINVAL;
   TnArgs g{M, N, P, lda, ldb, 0, (M + 127) / 128, (N + 127) / 128};
   const int tiles = g.m_tiles * g.n_tiles;
-  int slabs = (1024 + tiles - 1) / tiles;
-  const int max_slabs = (P + TBK - 1) / TBK;
-  if (slabs > max_slabs) slabs = max_slabs;
-  if (slabs < 1) slabs = 1;
+  const int slabs = tn_slabs(tiles, P);
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
   const int used = P > 0 ? (P + g.p_chunk - 1) / g.p_chunk : 1;
-  dim3 grid(tiles, used);
+  dim3 grid(tiles * ((used + 7) / 8) * 8);
   gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace);
   OMNIPQ_LAUNCH_CHECK();
   const int n4 = M * N / 4;        // M, N multiples of 8
