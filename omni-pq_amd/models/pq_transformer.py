@@ -31,6 +31,7 @@ from utils import fused_attention  # noqa: E402
 from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
 import rows_mlp  # noqa: E402
+import sa_fused  # noqa: E402
 
 
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
@@ -242,6 +243,10 @@ class PQ_Transformer(nn.Module):
         nn.SyncBatchNorm.convert_sync_batchnorm(self)      # in place for every child BN (:194)
 
     def forward(self, inputs):
+        with sa_fused.deferred_counters():
+            return self._forward(inputs)
+
+    def _forward(self, inputs):
         if self.training and inputs['point_clouds'].is_cuda:
             fused_attention.STATE.advance(inputs['point_clouds'].device)     # new dropout masks this step
         end_points = self.backbone(inputs['point_clouds'], {})

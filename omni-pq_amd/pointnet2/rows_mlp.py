@@ -128,8 +128,7 @@ class RowsMLP(torch.autograd.Function):
                     _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(N) * world), _p(sums),
                           _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
                           _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(cb))
-                    if nbt is not None:
-                        nbt += 1
+                    sa_fused.bump(nbt)
                 else:
                     lay.invstd = torch.rsqrt(rv + eps)
                     shift = rm - bias.detach().float() if lay.has_bias else rm

@@ -55,6 +55,39 @@ def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+_NBT = None        # None: bump BatchNorm step counters at once; list: collect them, one multi-tensor add at exit
+
+
+def bump(nbt):
+    """num_batches_tracked += 1 (state_dict parity with torch's BatchNorm), batched when a model asks for it."""
+    if nbt is None:
+        return
+    if _NBT is None:
+        nbt += 1
+    else:
+        _NBT.append(nbt)
+
+
+class deferred_counters:
+    """Within the block, the `num_batches_tracked` increments of every BatchNorm layer run by the hand-written
+    kernels are collected and applied with ONE multi-tensor launch at exit (61 tiny launches per step otherwise)."""
+
+    def __enter__(self):
+        global _NBT
+        self.outer = _NBT
+        if _NBT is None:
+            _NBT = []
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT
+        if self.outer is None:
+            pending, _NBT = _NBT, None
+            if pending:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
 _FORCE_COLLECTIVES = False       # test hook: issue the SyncBatchNorm all-reduces even over a 1-rank group
 
 
@@ -237,8 +270,7 @@ class FusedSAStage(torch.autograd.Function):
                 _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(P) * world), _p(sums),
                       _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
                       _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(None))
-                if nbt is not None:
-                    nbt += 1
+                bump(nbt)
             else:
                 lay.Y = _gemm_nt(X, lay.Wp, P, cout, K)
                 lay.invstd = torch.rsqrt(rv + eps)
