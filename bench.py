@@ -326,6 +326,8 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             dist.barrier()
             torch.cuda.synchronize()
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        import sa_fused
+        sa_fused.reset_pools()
         graph = torch.cuda.CUDAGraph()
         captured = True
         try:

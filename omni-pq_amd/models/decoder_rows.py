@@ -106,8 +106,51 @@ def _rows(x_bcp):
     return x_bcp.transpose(1, 2).reshape(B * P, C)
 
 
-def run(layer, query, key, query_pos, key_pos):
-    """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3), key_pos (B,Pk,3) -> (B,C,Pq) f32 (a view of rows)."""
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device)
+    return s
+
+
+def key_side(layer, key, key_pos):
+    """The key / value side of a layer's cross attention: kv = in_proj[C:](mem + cross_posembed(key_pos)),
+    rows (B*Pk, 2C) bf16.  It depends on the memory only, not on the queries."""
+    C = key.shape[1]
+    ca = layer.multihead_attn
+    mem16 = _rows(key).to(torch.bfloat16)
+    k_pe = _rows(layer.cross_posembed(key_pos)).to(torch.bfloat16)
+    mem_pe = AddToBf16.apply(mem16, k_pe)
+    return rows_mlp.run(mem_pe, [rows_mlp.Layer(ca.in_proj_weight[C:], ca.in_proj_bias[C:])], layer.training)
+
+
+def precompute_key_sides(layers, key, key_pos):
+    """All layers attend to the SAME memory (models/pq_transformer.py:251-262 passes one `key` / `key_pos` to
+    every decoder layer), so their key/value projections are independent of the query chain: issue them on a
+    side stream, underneath the first layers' self attention (the kernels involved fill less than half of the
+    chip each).  Returns the list of kv tensors; the current stream is made to wait for them here-after by
+    `join_key_sides` right before the first use.  Autograd replays the same overlap in backward (a node's
+    backward runs on the stream of its forward)."""
+    cur = torch.cuda.current_stream(key.device)
+    side = _side_stream(key.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        kvs = [key_side(layer, key, key_pos) for layer in layers]
+    for kv in kvs:
+        kv.record_stream(cur)
+    return kvs
+
+
+def join_key_sides(device):
+    torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+
+
+def run(layer, query, key, query_pos, key_pos, kv=None):
+    """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3), key_pos (B,Pk,3) -> (B,C,Pq) f32 (a view of rows).
+    kv: the layer's precomputed key side (`precompute_key_sides`), or None to compute it in line."""
     B, C, Pq = query.shape
     Pk = key.shape[2]
     training = layer.training
@@ -122,9 +165,7 @@ def run(layer, query, key, query_pos, key_pos):
         return rows_mlp.run(x, [rows_mlp.Layer(w, b, **kw)], training)
 
     x32 = _rows(query).float()
-    mem16 = _rows(key).to(torch.bfloat16)
     q_pe = _rows(layer.self_posembed(query_pos)).to(torch.bfloat16)
-    k_pe = _rows(layer.cross_posembed(key_pos)).to(torch.bfloat16)
 
     # self attention: q = k = v = x + q_pe (transformer.py:203-205)
     qk = AddToBf16.apply(x32, q_pe)
@@ -136,8 +177,10 @@ def run(layer, query, key, query_pos, key_pos):
 
     # cross attention: query x + q_pe, key = value = mem + k_pe (:208-213)
     q = linear(xq, ca.in_proj_weight[:C], ca.in_proj_bias[:C])
-    mem_pe = AddToBf16.apply(mem16, k_pe)
-    kv = linear(mem_pe, ca.in_proj_weight[C:], ca.in_proj_bias[C:])
+    if kv is None:
+        kv = key_side(layer, key, key_pos)
+    else:
+        join_key_sides(query.device)
     att = fused_attention.PackedAttention.apply(q, kv, Pq, Pk, B, H, float(ca.dropout) if training else 0.0)
     y = linear(att, ca.out_proj.weight, ca.out_proj.bias)
     x32, x16, _ = AddDropoutLayerNorm.apply(x32, y, layer.norm2.weight, layer.norm2.bias, float(layer.norm2.eps),

@@ -26,12 +26,18 @@ for _p in (_HERE, _ROOT, os.path.join(_ROOT, "pointnet2")):
 
 from backbone_module import Pointnet2Backbone  # noqa: E402
 from transformer import TransformerDecoderLayer  # noqa: E402
+import transformer as transformer_mod  # noqa: E402
+import decoder_rows  # noqa: E402
 from utils.pointnet_util import FPSModule  # noqa: E402
 from utils import fused_attention  # noqa: E402
 from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
 import rows_mlp  # noqa: E402
 import sa_fused  # noqa: E402
+
+# "capture" (default): overlap the decoder's key sides on a side stream while a hipGraph is being captured (in
+# eager mode the extra stream switches cost more host time than the overlap returns); "always" / "inline"
+_OVERLAP_KEY_SIDE = os.environ.get("OMNIPQ_KEY_SIDE", "capture")
 
 
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
@@ -278,10 +284,18 @@ class PQ_Transformer(nn.Module):
         key = conv1x1(seed_features, self.decoder_key_proj)
         key_pos = seed_xyz
 
+        # every layer attends to the same memory: their key/value sides run ahead on a side stream
+        key_sides = [None] * self.num_layer
+        overlap = _OVERLAP_KEY_SIDE == "always" or \
+            (_OVERLAP_KEY_SIDE == "capture" and key.is_cuda and torch.cuda.is_current_stream_capturing())
+        if overlap and transformer_mod._USE_ROWS and \
+                all(decoder_rows.usable(layer, query_joint, key) for layer in self.decoder):
+            key_sides = decoder_rows.precompute_key_sides(list(self.decoder), key, key_pos)
+
         for i in range(self.num_layer):
             prefix = 'last_' if (i == self.num_layer - 1) else f'{i}head_'
             query_pos_joint = torch.cat([base_xyz, base_xyz_q], 1)
-            query_joint = self.decoder[i](query_joint, key, query_pos_joint, key_pos)
+            query_joint = self.decoder[i](query_joint, key, query_pos_joint, key_pos, key_sides[i])
             query = query_joint[:, :, 0:self.num_proposal]
             query_q = query_joint[:, :, self.num_proposal:]
             base_xyz, _, end_points = self.prediction_heads[i](

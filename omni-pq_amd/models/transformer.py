@@ -55,10 +55,11 @@ class TransformerDecoderLayer(nn.Module):
     def with_pos_embed(self, tensor, pos_embed: Optional[Tensor]):
         return tensor if pos_embed is None else tensor + pos_embed
 
-    def forward(self, query, key, query_pos, key_pos):
-        """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3), key_pos (B,Pk,3) -> (B,C,Pq)"""
+    def forward(self, query, key, query_pos, key_pos, key_side=None):
+        """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3), key_pos (B,Pk,3) -> (B,C,Pq).
+        key_side (extension): this layer's entry of `decoder_rows.precompute_key_sides`."""
         if _USE_ROWS and decoder_rows.usable(self, query, key):
-            return decoder_rows.run(self, query, key, query_pos, key_pos)      # hand-written kernels, row-major
+            return decoder_rows.run(self, query, key, query_pos, key_pos, key_side)   # hand-written kernels
         q_pe = k_pe = None
         if self.self_posembed is not None and query_pos is not None:
             q_pe = self.self_posembed(query_pos).permute(2, 0, 1)

@@ -139,25 +139,42 @@ def _gemm_tn(A, B, M, N, P):
 class _ZeroPool:
     """Zero-initialised scratch handed out in slices that are used once and never recycled: a chunk is
     cleared by ONE memset when it is allocated, instead of one memset per statistics buffer (a training
-    step asks for ~200 of them).  A slice keeps its chunk alive; chunks are a few hundred KB."""
+    step asks for ~200 of them).  A slice keeps its chunk alive; chunks are a few hundred KB.  One open chunk
+    per (device, stream): its memset is ordered on that stream.  Chunks opened inside a graph capture are
+    dropped when the capture state changes -- their memset node belongs to that graph only."""
 
     def __init__(self, dtype, chunk):
         self.dtype, self.chunk = dtype, chunk
-        self.buf, self.used, self.key = None, 0, None
+        self.open = {}            # (device, stream) -> [buffer, used]
+        self.capturing = False
+
+    def reset(self):
+        self.open.clear()
 
     def take(self, n, device):
-        key = (device, torch.cuda.current_stream(device).cuda_stream, torch.cuda.is_current_stream_capturing())
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing != self.capturing:
+            self.open.clear()
+            self.capturing = capturing
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
         n8 = _round_up(n, 16)
-        if self.buf is None or self.key != key or self.used + n8 > self.buf.numel():
-            self.buf = torch.zeros(max(self.chunk, n8), device=device, dtype=self.dtype)
-            self.used, self.key = 0, key
-        out = self.buf[self.used:self.used + n]
-        self.used += n8
+        slot = self.open.get(key)
+        if slot is None or slot[1] + n8 > slot[0].numel():
+            slot = [torch.zeros(max(self.chunk, n8), device=device, dtype=self.dtype), 0]
+            self.open[key] = slot
+        out = slot[0][slot[1]:slot[1] + n]
+        slot[1] += n8
         return out
 
 
 _ZEROS_F64 = _ZeroPool(torch.float64, 1 << 16)
 _ZEROS_F32 = _ZeroPool(torch.float32, 1 << 15)
+
+
+def reset_pools():
+    """Forget the open chunks (call right before starting a graph capture)."""
+    _ZEROS_F64.reset()
+    _ZEROS_F32.reset()
 
 
 def zeros_f64(rows, cols, device):
