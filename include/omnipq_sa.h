@@ -73,6 +73,19 @@ int omnipq_colstats_z(long long P, int C, const void *Y, double *sums, void *str
 /* sums[c] += sum_p Y[p][c] for bf16 Y [P][C], any C % 8 == 0 (bias gradients). */
 int omnipq_colsum(long long P, int C, const void *Y, double *sums, void *stream);
 
+/* bn_finalize + bnrelu in one launch: a/b/mean/invstd and the running statistics come out as from
+ * omnipq_bn_finalize, X = relu(a Y + b) as from omnipq_bnrelu. */
+int omnipq_bn_finalize_relu(long long P, int C, double count, const double *sums, const float *gamma,
+                            const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                            const float *conv_bias, const void *Y, void *X, float *a, float *b, float *mean,
+                            float *invstd, void *stream);
+
+/* omnipq_bn_bwd_apply with the per-channel means computed inside; dbeta_dgamma (may be NULL) = float[2][C]
+ * receiving (float) sums[0], sums[1] -- only meaningful when `sums` are this rank's own totals. */
+int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positions, const void *dX, const void *Y,
+                              const float *a, const float *b, const float *mean, const float *invstd,
+                              const double *sums, void *dY, float *dbeta_dgamma, void *stream);
+
 /* Weight preparation in one pass: W f32 [cout][cin] (row pitch ldw) -> Wp bf16 [cp][k] zero-padded with its
  * columns rotated left by `rot` (SA layer 0: [xyz, feat] -> [feat, xyz]) and, if Wt != NULL, Wt bf16 [k][cp]
  * = Wp^T.  omnipq_unprep_wgrad undoes padding and rotation for the f32 weight gradient. */

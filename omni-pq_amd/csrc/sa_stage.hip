@@ -186,6 +186,54 @@ __global__ __launch_bounds__(256) void bnrelu_kernel(long long chunks, int C, co
   }
 }
 
+// finalize + normalise + ReLU in one launch: every block derives (a, b) for all C channels from the f64
+// totals into LDS (a few hundred double operations, identical in every block), block 0 also publishes
+// a / b / mean / invstd for the backward pass and updates the running statistics.  LDS: 2C floats.
+__global__ __launch_bounds__(256) void bn_finalize_relu_kernel(long long chunks, int C, double cnt,
+                                                              const double *__restrict__ sums,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float eps, float momentum,
+                                                              float *__restrict__ running_mean,
+                                                              float *__restrict__ running_var,
+                                                              const float *__restrict__ conv_bias,
+                                                              const bf16_t *__restrict__ Y, bf16_t *__restrict__ X,
+                                                              float *__restrict__ a, float *__restrict__ b,
+                                                              float *__restrict__ mean, float *__restrict__ invstd) {
+  extern __shared__ float ab[];                              // [a | b]
+  for (int c = (int)threadIdx.x; c < C; c += 256) {
+    const double mu = sums[c] / cnt;
+    double var = sums[C + c] / cnt - mu * mu;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float av = gamma[c] * is;
+    const float bv = beta[c] - (float)mu * av;
+    ab[c] = av;
+    ab[C + c] = bv;
+    if (blockIdx.x == 0) {
+      a[c] = av;
+      b[c] = bv;
+      mean[c] = (float)mu;
+      invstd[c] = is;
+      if (running_mean) {
+        const double unbiased = cnt > 1 ? var * cnt / (cnt - 1) : var;
+        const float shift = conv_bias ? conv_bias[c] : 0.f;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mu + shift);
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const int c0 = (int)(q % cpr) * 8;
+    float y[8];
+    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = fmaxf(__builtin_fmaf(ab[c0 + e], y[e], ab[C + c0 + e]), 0.f);
+    *reinterpret_cast<uint4 *>(X + q * 8) = pack8(y);
+  }
+}
+
 // ------------------------------------------------------------------------------- pooling
 // out[bm][c] = max_s relu(a Y[(bm,s)][c] + b); arg = first s reaching it.  One lane per (bm, 8 ch).
 // Outputs are position-major ([b*m][C]); g_out of the backward kernels likewise.
@@ -261,6 +309,44 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m
 }
 
 // dY[p][c] = a[c] * (dz - S/P - yhat * T/P),  dz = (s == arg ? g_out : 0) masked by out > 0
+// bn_bwd_apply with the two small kernels around it folded in: every block turns the f64 totals into the
+// per-channel means (LDS, 2C floats); block 0 writes dbeta / dgamma (= the totals, as f32) when asked to.
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(long long chunks, int C, double invP,
+                                                                const bf16_t *__restrict__ dX,
+                                                                const bf16_t *__restrict__ Y,
+                                                                const float *__restrict__ a,
+                                                                const float *__restrict__ b,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                const double *__restrict__ sums,
+                                                                bf16_t *__restrict__ dY, float *__restrict__ dbeta_dgamma) {
+  extern __shared__ float st[];                              // [S/P | T/P]
+  for (int j = (int)threadIdx.x; j < 2 * C; j += 256) {
+    const double t = sums[j];
+    st[j] = (float)(t * invP);
+    if (dbeta_dgamma && blockIdx.x == 0) dbeta_dgamma[j] = (float)t;
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const int c0 = (int)(q % cpr) * 8;
+    float y[8], d[8], av[8], bv[8], mu[8], is[8];
+    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
+    unpack8(*reinterpret_cast<const uint4 *>(dX + q * 8), d);
+    load8f(a + c0, av);
+    load8f(b + c0, bv);
+    load8f(mean + c0, mu);
+    load8f(invstd + c0, is);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dz = __builtin_fmaf(av[e], y[e], bv[e]) > 0.f ? d[e] : 0.f;
+      const float yhat = (y[e] - mu[e]) * is[e];
+      y[e] = av[e] * (dz - st[c0 + e] - yhat * st[C + c0 + e]);
+    }
+    *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
+  }
+}
+
 // sums (f64 totals) -> per-channel means as f32:  st[c] = sum dz / P,  st[C + c] = sum dz*yhat / P
 __global__ void bwd_means_kernel(int n2, double invP, const double *__restrict__ sums, float *__restrict__ st) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -852,6 +938,41 @@ extern "C" int omnipq_colsum(long long P, int C, const void *Y, double *sums, vo
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
   colsum_kernel<<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y, sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// bn_finalize + bnrelu in one launch (see bn_finalize_relu_kernel).
+extern "C" int omnipq_bn_finalize_relu(long long P, int C, double count, const double *sums, const float *gamma,
+                                       const float *beta, float eps, float momentum, float *running_mean,
+                                       float *running_var, const float *conv_bias, const void *Y, void *X, float *a,
+                                       float *b, float *mean, float *invstd, void *stream) {
+  if (P < 0 || C <= 0 || (C % 8) || C > 4096) return OMNIPQ_EINVAL;
+  if (!sums || !gamma || !beta || !a || !b || !mean || !invstd || !Y || !X) return OMNIPQ_EINVAL;
+  const long long chunks = P * (C / 8);
+  int grid = grid_for(chunks);
+  if (grid < 1) grid = 1;                        // block 0 must run even for P == 0: it publishes a, b, ...
+  bn_finalize_relu_kernel<<<grid, 256, sizeof(float) * 2 * C, (hipStream_t)stream>>>(
+      chunks, C, count, sums, gamma, beta, eps, momentum, running_mean, running_var, conv_bias, (const bf16_t *)Y,
+      (bf16_t *)X, a, b, mean, invstd);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// omnipq_bn_bwd_apply with the mean computation and the f32 copies of the totals folded in.  dbeta_dgamma
+// (may be NULL): float[2][C] receiving sums[0] (dbeta) and sums[1] (dgamma) -- pass it only when `sums` holds
+// THIS rank's totals (single process); under a process group take the gradients before the all-reduce.
+extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positions, const void *dX, const void *Y,
+                                         const float *a, const float *b, const float *mean, const float *invstd,
+                                         const double *sums, void *dY, float *dbeta_dgamma, void *stream) {
+  if (P < 0 || C <= 0 || (C % 8) || C > 4096) return OMNIPQ_EINVAL;
+  if (!dX || !Y || !a || !b || !mean || !invstd || !sums || !dY) return OMNIPQ_EINVAL;
+  const long long chunks = P * (C / 8);
+  int grid = grid_for(chunks);
+  if (grid < 1) grid = 1;
+  bn_bwd_apply_fused_kernel<<<grid, 256, sizeof(float) * 2 * C, (hipStream_t)stream>>>(
+      chunks, C, 1.0 / total_positions, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums, (bf16_t *)dY,
+      dbeta_dgamma);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

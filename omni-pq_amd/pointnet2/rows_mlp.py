@@ -122,12 +122,13 @@ class RowsMLP(torch.autograd.Function):
                 rm, rv, nbt, momentum, eps = spec[l]
                 if training:
                     _allreduce_(sums)
-                    lay.a, lay.b = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
-                    lay.mean, lay.invstd = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+                    stats = torch.empty((4, cout), device=dev)            # a | b | mean | invstd
+                    lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
                     cb = bias.detach().float().contiguous() if lay.has_bias else None
-                    _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(N) * world), _p(sums),
-                          _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
-                          _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(cb))
+                    lay.X = torch.empty_like(Y)
+                    _call(_lib.omnipq_bn_finalize_relu, X, ctypes.c_longlong(N), cout, ctypes.c_double(float(N) * world),
+                          _p(sums), _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                          _p(rm), _p(rv), _p(cb), _p(Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd))
                     sa_fused.bump(nbt)
                 else:
                     lay.invstd = torch.rsqrt(rv + eps)
@@ -135,8 +136,9 @@ class RowsMLP(torch.autograd.Function):
                     lay.mean = shift
                     lay.a = (gamma.detach() * lay.invstd).contiguous()
                     lay.b = (beta.detach() - shift * lay.a).contiguous()
-                lay.X = torch.empty_like(Y)
-                _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
+                if not training:
+                    lay.X = torch.empty_like(Y)
+                    _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
                 X = lay.X
             else:
                 if lay.act is not None:
@@ -182,12 +184,9 @@ class RowsMLP(torch.autograd.Function):
                     sums = zeros_f64(3, lay.C, dev)
                     _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
                           _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
-                grads[4 * l + 2], grads[4 * l + 3] = affine_grads(sums, lay.C)       # local totals
-                _allreduce_(sums[:2])
+                grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums, world)
                 if lay.has_bias:
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
-                _call(_lib.omnipq_bn_bwd_apply, dcur, ctypes.c_longlong(N), lay.C, total, _p(dcur), _p(lay.Y),
-                      _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums), _p(dcur))
             elif lay.act is not None:
                 # lay.Y holds dropout(relu(.)): positive exactly where the unit was active and kept
                 _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur),

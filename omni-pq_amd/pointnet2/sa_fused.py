@@ -208,6 +208,23 @@ def unprep_wgrad(dWp, cout, cin, rot, shape):
     return dW
 
 
+def bn_backward_apply(d, lay, P, C, total, sums, world):
+    """In place: d (gradient w.r.t. the ReLU output, bf16 [P][C]) -> gradient w.r.t. the layer's pre-BN output,
+    given the BatchNorm-backward totals `sums` of THIS rank.  Returns (dgamma, dbeta), this rank's share.
+    Single process: one launch does the means, the f32 copies of the totals and the apply; under a process
+    group the totals are all-reduced in between (SyncBatchNorm), so the local gradients are taken first."""
+    if world > 1 or _FORCE_COLLECTIVES:
+        dgamma, dbeta = affine_grads(sums, C)
+        _allreduce_(sums[:2])
+        out = None
+    else:
+        out = torch.empty((2, C), device=d.device, dtype=torch.float32)
+        dgamma, dbeta = out[1], out[0]
+    _call(_lib.omnipq_bn_bwd_apply_fused, d, ctypes.c_longlong(P), C, total, _p(d), _p(lay.Y), _p(lay.a), _p(lay.b),
+          _p(lay.mean), _p(lay.invstd), _p(sums), _p(d), _p(out))
+    return dgamma, dbeta
+
+
 def affine_grads(sums, C):
     """(dgamma, dbeta) f32 from the local f64 totals [sum dz | sum dz*yhat]."""
     both = torch.empty((2, C), device=sums.device, dtype=torch.float32)
@@ -280,24 +297,33 @@ class FusedSAStage(torch.autograd.Function):
                 sums = zeros_f64(2, cout, dev)
                 lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums)         # GEMM + batch statistics
                 _allreduce_(sums)
-                lay.a = torch.empty(cout, device=dev)
-                lay.b = torch.empty(cout, device=dev)
-                lay.mean = torch.empty(cout, device=dev)
-                lay.invstd = torch.empty(cout, device=dev)
-                _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(P) * world), _p(sums),
-                      _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
-                      _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(None))
+                stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
+                lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
+                fused_relu = l < L - 1
+                if fused_relu:
+                    # finalize + normalise + ReLU in one launch
+                    lay.X = torch.empty_like(lay.Y)
+                    _call(_lib.omnipq_bn_finalize_relu, X, ctypes.c_longlong(P), cout, ctypes.c_double(float(P) * world),
+                          _p(sums), _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                          _p(rm), _p(rv), _p(None), _p(lay.Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean),
+                          _p(lay.invstd))
+                else:
+                    _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(P) * world), _p(sums),
+                          _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                          _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(None))
                 bump(nbt)
             else:
+                fused_relu = False
                 lay.Y = _gemm_nt(X, lay.Wp, P, cout, K)
                 lay.invstd = torch.rsqrt(rv + eps)
                 lay.mean = rm
                 lay.a = (gamma.detach() * lay.invstd).contiguous()
                 lay.b = (beta.detach() - rm * lay.a).contiguous()
             if l < L - 1:
-                lay.X = torch.empty_like(lay.Y)
-                _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(lay.a), _p(lay.b),
-                      _p(lay.X))
+                if not fused_relu:
+                    lay.X = torch.empty_like(lay.Y)
+                    _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(lay.a), _p(lay.b),
+                          _p(lay.X))
                 X = lay.X
             else:
                 lay.X = None
@@ -370,10 +396,8 @@ class FusedSAStage(torch.autograd.Function):
                 sums = zeros_f64(3, prev.C, dev)
                 # Wt = [K][Cout]; the BN-backward sums of the layer below come out of the same pass
                 dX = _gemm_nt_bnbwd(dY, lay.Wt, P, lay.K, lay.C, prev, sums)
-                grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = affine_grads(sums, prev.C)
-                _allreduce_(sums[:2])
-                _call(_lib.omnipq_bn_bwd_apply, dX, ctypes.c_longlong(P), prev.C, total, _p(dX), _p(prev.Y),
-                      _p(prev.a), _p(prev.b), _p(prev.mean), _p(prev.invstd), _p(sums), _p(dX))
+                grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = bn_backward_apply(
+                    dX, prev, P, prev.C, total, sums, world)
                 dY = dX
             else:
                 dX = _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)
