@@ -51,6 +51,14 @@ class Pointnet2Backbone(nn.Module):
     _plan = None
     _side = None
 
+    def __getstate__(self):
+        # streams, events and the plan's index buffers are per-instance run-time state: copies and pickles of
+        # the module (copy.deepcopy for an EMA teacher, torch.save of the whole model) start without them
+        state = self.__dict__.copy()
+        for k in ("_plan", "_side", "_plan_bufs"):
+            state.pop(k, None)
+        return state
+
     def _side_stream(self, device):
         if self._side is None or self._side.device != device:
             self._side = torch.cuda.Stream(device=device)

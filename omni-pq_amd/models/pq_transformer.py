@@ -249,7 +249,8 @@ class PQ_Transformer(nn.Module):
         nn.SyncBatchNorm.convert_sync_batchnorm(self)      # in place for every child BN (:194)
 
     def forward(self, inputs):
-        with sa_fused.deferred_counters():
+        arena = sa_fused.arena_of(self)
+        with sa_fused.deferred_counters(), arena.step(inputs['point_clouds'].device):
             return self._forward(inputs)
 
     def _forward(self, inputs):

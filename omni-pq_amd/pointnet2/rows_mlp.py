@@ -99,7 +99,7 @@ class RowsMLP(torch.autograd.Function):
             lay.C, lay.K, lay.Cp = cout, K, _round_up(cout, 32)
             lay.has_bn, lay.has_bias, lay.wk = _is_bn(spec[l]), bias is not None, wk
             lay.act = spec[l] if (spec[l] is not None and not lay.has_bn) else None
-            lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training)
+            lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training, persistent=sa_fused.is_persistent(W))
             if lay.has_bn and lay.Cp != cout:
                 raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
             sums = None

@@ -17,6 +17,7 @@ statistics are f32 per block / f64 across blocks.  This is the `bf16` compute mo
 parity mode keeps the reference's op-by-op composition (pointnet2_modules.py).
 """
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -185,12 +186,120 @@ def zeros_f32(n, device):
     return _ZEROS_F32.take(n, device)
 
 
-def prep_weight(W2, cp, k, rot=0, transpose=True):
+class WeightArena:
+    """Every weight matrix the hand-written GEMMs of a model use, prepared (padded / rotated bf16 copy and its
+    transpose) by ONE launch per step instead of one per layer.
+
+    The first forward inside `with arena.step(device):` records which matrices are asked for (`prep_weight`
+    still prepares them one by one); from then on `step()` runs `omnipq_prep_weights_all` over the recorded
+    table and `prep_weight` hands out views of the arenas.  Parameters are referenced, not copied: in-place
+    optimizer updates are picked up by the next step's launch.  A matrix that was not recorded falls back to
+    its own launch and is added for the following step."""
+
+    def __init__(self):
+        self.keys = {}            # key -> index
+        self.entries = []         # (W2 view, cout, cin, ldw, cp, k, rot)
+        self.views = []           # (Wp, Wt) per entry, valid while `active`
+        self.built = 0            # number of entries the device table covers
+        self.table = self.wp = self.wt = None
+        self.total = 0
+        self.active = False
+
+    @staticmethod
+    def _key(W2, cp, k, rot):
+        return (W2.data_ptr(), tuple(W2.shape), W2.stride(0), cp, k, rot)
+
+    def _build(self, device):
+        import numpy as np
+        rec = np.dtype([("W", "<u8"), ("wp", "<i8"), ("wt", "<i8"), ("first", "<i8"), ("cout", "<i4"), ("cin", "<i4"),
+                        ("ldw", "<i4"), ("cp", "<i4"), ("k", "<i4"), ("rot", "<i4")])
+        tab = np.zeros(len(self.entries), dtype=rec)
+        off = 0
+        for i, (W2, cout, cin, ldw, cp, k, rot) in enumerate(self.entries):
+            tab[i] = (W2.data_ptr(), off, off, off, cout, cin, ldw, cp, k, rot)
+            off += cp * k
+        self.total = off
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        self.wp = torch.empty(off, device=device, dtype=torch.bfloat16)
+        self.wt = torch.empty(off, device=device, dtype=torch.bfloat16)
+        self.views = []
+        off = 0
+        for (_, _, _, _, cp, k, _) in self.entries:
+            self.views.append((self.wp[off:off + cp * k].view(cp, k), self.wt[off:off + cp * k].view(k, cp)))
+            off += cp * k
+        self.built = len(self.entries)
+
+    def step(self, device):
+        return _ArenaStep(self, device)
+
+    def lookup(self, W2, cp, k, rot):
+        i = self.keys.get(self._key(W2, cp, k, rot))
+        if i is None or i >= self.built:
+            return None
+        return self.views[i]
+
+    def record(self, W2, cp, k, rot):
+        key = self._key(W2, cp, k, rot)
+        if key not in self.keys:
+            self.keys[key] = len(self.entries)
+            self.entries.append((W2, W2.shape[0], W2.shape[1], W2.stride(0), cp, k, rot))
+
+
+class _ArenaStep:
+    def __init__(self, arena, device):
+        self.arena, self.device = arena, device
+
+    def __enter__(self):
+        global _ARENA
+        a = self.arena
+        self.outer = _ARENA
+        if torch.device(self.device).type != "cuda":
+            return self
+        if len(a.entries) != a.built and not torch.cuda.is_current_stream_capturing():
+            a._build(self.device)              # table upload: never inside a capture
+        if a.built:
+            _call(_lib.omnipq_prep_weights_all, a.wp, a.built, ctypes.c_longlong(a.total), _p(a.table), _p(a.wp),
+                  _p(a.wt))
+        a.active = True
+        _ARENA = a
+        return self
+
+    def __exit__(self, *exc):
+        global _ARENA
+        self.arena.active = False
+        _ARENA = self.outer
+        return False
+
+
+_ARENA = None
+_ARENAS = weakref.WeakKeyDictionary()      # model -> its WeightArena (kept out of the module: copies start afresh)
+
+
+def arena_of(model):
+    arena = _ARENAS.get(model)
+    if arena is None:
+        arena = _ARENAS[model] = WeightArena()
+    return arena
+
+
+def is_persistent(W):
+    """A Parameter or a view of one: its storage (hence its address) outlives the step."""
+    root = W._base if W._base is not None else W
+    return isinstance(root, torch.nn.Parameter)
+
+
+def prep_weight(W2, cp, k, rot=0, transpose=True, persistent=False):
     """f32 (cout, cin) parameter -> bf16 [cp][k] (zero-padded, columns rotated left by rot) and its
-    transpose [k][cp], in one launch."""
+    transpose [k][cp], in one launch -- or, inside a model's `WeightArena.step()`, views of the arenas that the
+    step's single launch filled."""
     W2 = W2.detach()
     if W2.dtype != torch.float32 or W2.stride(1) != 1:
         W2 = W2.float().contiguous()
+    elif persistent and _ARENA is not None and _ARENA.active:
+        got = _ARENA.lookup(W2, cp, k, rot)
+        if got is not None:
+            return got
+        _ARENA.record(W2, cp, k, rot)
     cout, cin = W2.shape
     Wp = torch.empty((cp, k), device=W2.device, dtype=torch.bfloat16)
     Wt = torch.empty((k, cp), device=W2.device, dtype=torch.bfloat16) if transpose else None
@@ -292,7 +401,8 @@ class FusedSAStage(torch.autograd.Function):
             # aligned -- layer 0 rotates the weight columns to match
             K = kpad if l == 0 else W2.shape[1]
             lay.K, lay.C = K, cout
-            lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=training)
+            lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=training,
+                                         persistent=is_persistent(W))
             if training:
                 sums = zeros_f64(2, cout, dev)
                 lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums)         # GEMM + batch statistics
