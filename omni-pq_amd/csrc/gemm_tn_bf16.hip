@@ -5,11 +5,8 @@
 // contraction index is the SLOW axis, so the k-contiguous fragments the MFMA wants cannot be
 // fetched with one wide LDS read.  Instead of materialising transposed copies in HBM, tiles are
 // staged exactly as they lie in memory ([32 positions][128 channels], coalesced 16-byte loads,
-// ds_write_b128) and each lane assembles its 8-position fragment with eight 16-bit LDS reads: for
-// a fixed position the 32 lanes of a half-wave read 32 consecutive channels (64 contiguous bytes),
-// so the reads are conflict-free.  LDS issue (64 narrow reads per K-step per lane) is the limiter,
-// about 2x the MFMA time -- accepted, since this GEMM is a third of the MLP's flops and the
-// alternative costs an extra HBM round trip of the two largest tensors.
+// ds_write_b128) and the fragments come out of LDS through gfx950's transpose read
+// (ds_read_b64_tr_b16): two reads per 8-position fragment instead of eight 16-bit reads plus packing.
 //
 // Grid: (M tiles x N tiles) x slabs; each slab contracts a contiguous range of positions into an
 // f32 partial tile, a second kernel sums the slabs (deterministic, no atomics).
@@ -23,9 +20,12 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
 
 constexpr int TBK = 32;            // positions per K-step
-constexpr int TPITCH = 136;        // bf16 per staged row: 128 channels + 8 pad (272 B, 16-B aligned)
+constexpr int TPITCH = 144;        // bf16 per staged row: 128 channels + 16 pad (288 B: the 4 rows of a transpose read
+                                   // start 8 banks apart, so its 16 lanes touch 32 distinct banks)
 constexpr int TCPITCH = 132;       // f32 C-tile pitch
 
 struct TnArgs {
@@ -121,31 +121,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
   }
   __syncthreads();
 
-  const int fch = lane & 31, fp = (lane >> 5) * 8;
+  // Fragments through the LDS transpose read (ds_read_b64_tr_b16): the 16 lanes of a group hand in the
+  // addresses of a [4 positions][16 channels] block, 4 contiguous channels each, and get it back
+  // column-wise -- lane c receives channel c at the 4 positions, which is exactly the k-contiguous piece the
+  // MFMA operand wants.  Group g = lane >> 4 serves channels 16 (g & 1) + [0, 16) and positions
+  // 8 (g >> 1) + [0, 8) of the 32 x 16 operand tile, as two reads of 4 positions.
+  const int grp = lane >> 4, l16 = lane & 15;
+  const int tr_row = 8 * (grp >> 1) + (l16 >> 2);            // + 4 t, + 16 kk
+  const int tr_col = 16 * (grp & 1) + (l16 & 3) * 4;         // + 32 i + 64 wm / wn
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
-    const unsigned short *sa = reinterpret_cast<const unsigned short *>(stage + buf * (2 * TBK * TPITCH));
-    const unsigned short *sb = sa + TBK * TPITCH;
+    const bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
+    const bf16_t *sb = sa + TBK * TPITCH;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        unsigned short va[8], vb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int prow = (kk * 16 + fp + e) * TPITCH;
-          va[e] = sa[prow + wm * 64 + i * 32 + fch];
-          vb[e] = sb[prow + wn * 64 + i * 32 + fch];
-        }
-        uint4 pa, pb;
-        pa.x = va[0] | ((unsigned)va[1] << 16); pa.y = va[2] | ((unsigned)va[3] << 16);
-        pa.z = va[4] | ((unsigned)va[5] << 16); pa.w = va[6] | ((unsigned)va[7] << 16);
-        pb.x = vb[0] | ((unsigned)vb[1] << 16); pb.y = vb[2] | ((unsigned)vb[3] << 16);
-        pb.z = vb[4] | ((unsigned)vb[5] << 16); pb.w = vb[6] | ((unsigned)vb[7] << 16);
-        fa[i] = __builtin_bit_cast(bf16x8, pa);
-        fb[i] = __builtin_bit_cast(bf16x8, pb);
+        const bf16_t *pa = sa + (kk * 16 + tr_row) * TPITCH + wm * 64 + i * 32 + tr_col;
+        const bf16_t *pb = sb + (kk * 16 + tr_row) * TPITCH + wn * 64 + i * 32 + tr_col;
+        const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pa);
+        const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pa + 4 * TPITCH));
+        const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pb);
+        const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pb + 4 * TPITCH));
+        fa[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        fb[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
