@@ -23,6 +23,8 @@
 //     ONE wave with relaxed agent-scope loads (data-is-the-flag hand-off, no fence; cdna guide
 //     G16 R2), double-buffered by round parity.  Every spin is bounded; a give-up sets an
 //     error word that omnipq_fps_check() reports as OMNIPQ_ETIMEOUT.
+#include <stdlib.h>
+
 #include "common.h"
 
 #include <math.h>
@@ -465,6 +467,10 @@ extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *
   // up to 12 workgroups the exchange also carries the winner's coordinates (5*G polling lanes)
   const int per4 = 1024 * 4, per8 = 1024 * 8;
   const int G4 = (n + per4 - 1) / per4, G8 = (n + per8 - 1) / per8;
+  // 8 points per thread by default: a round costs the same (the cross-workgroup exchange dominates it) while
+  // the scene occupies half as many CUs -- CUs the overlapped backward pass of the previous batch can use
+  static const bool prefer8 = !(getenv("OMNIPQ_FPS_PPT") && atoi(getenv("OMNIPQ_FPS_PPT")) == 4);
+  if (prefer8 && G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);
   if (G4 <= 12) return launch_multi<4>(b, n, m, bs_mask, G4, dataset, temp, idxs, stream);
   if (G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);
   if (G4 <= 32) return launch_multi<4>(b, n, m, bs_mask, G4, dataset, temp, idxs, stream);
