@@ -92,11 +92,11 @@ int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positions, const 
 int omnipq_prep_weight(int cout, int cin, int ldw, int cp, int k, int rot, const float *W, void *Wp, void *Wt,
                        void *stream);
 /* The same for a table of matrices in one launch.  segs: device array of nseg packed 56-byte records
- *   { const float *W; int64_t wp_off, wt_off, first; int32_t cout, cin, ldw, cp, k, rot; }
- * wp_off / wt_off: element offsets of the record's outputs in the two bf16 arenas; first: running sum of cp*k
- * over the preceding records; total: sum of cp*k over all records. */
-int omnipq_prep_weights_all(int nseg, long long total, const void *segs, void *Wp_arena, void *Wt_arena,
-                            void *stream);
+ *   { const float *W; int64_t wp_off, wt_off, reserved; int32_t cout, cin, ldw, cp, k, rot; }
+ * wp_off / wt_off: element offsets of the record's outputs in the two bf16 arenas.  tiles: device array of
+ * ntiles x int32[4] = {record, first row, first column, 0}, one per 64 x 64 tile of every padded matrix. */
+int omnipq_prep_weights_all(int nseg, int ntiles, const void *segs, const int *tiles, void *Wp_arena,
+                            void *Wt_arena, void *stream);
 int omnipq_unprep_wgrad(int cout, int cin, int k, int rot, const float *dWp, float *dW, void *stream);
 
 /* dbeta[c] = (float) sums[c], dgamma[c] = (float) sums[C + c] */

@@ -400,35 +400,41 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(int cout, int cin, int
 }
 
 // All weights of a model in ONE launch: segment table (device) of PrepSeg, flat bf16 arenas for the padded
-// matrices and their transposes.  A thread owns one element of one padded matrix; its segment is found by
-// bisection over the segments' first-element indices.
+// matrices and their transposes.
 struct PrepSeg {
   const float *W;
   long long wp_off, wt_off;      // element offsets into the two arenas
-  long long first;               // index of the segment's first element in the global element numbering
+  long long reserved;
   int cout, cin, ldw, cp, k, rot;
 };
 
-__global__ __launch_bounds__(256) void prep_all_kernel(int nseg, long long total, const PrepSeg *__restrict__ segs,
+// One workgroup per 64 x 64 tile of one padded matrix (tile table on the device: segment, first row, first
+// column): coalesced reads along the source rows, coalesced writes of both the matrix and -- through an LDS
+// transpose -- its transpose.
+__global__ __launch_bounds__(256) void prep_all_kernel(const PrepSeg *__restrict__ segs, const int *__restrict__ tiles,
                                                       bf16_t *__restrict__ Wp_arena, bf16_t *__restrict__ Wt_arena) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  int lo = 0, hi = nseg - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (segs[mid].first <= i) lo = mid; else hi = mid - 1;
+  __shared__ bf16_t t[64][66];
+  const int *tl = tiles + 4 * (size_t)blockIdx.x;
+  const PrepSeg g = segs[tl[0]];
+  const int r0 = tl[1], c0 = tl[2];
+#pragma unroll 4
+  for (int e = (int)threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = r0 + (e >> 6), c = c0 + (e & 63);
+    float v = 0.f;
+    if (r < g.cout && c < g.cin) {
+      const int src = c < g.cin - g.rot ? c + g.rot : c - (g.cin - g.rot);
+      v = g.W[(size_t)r * g.ldw + src];
+    }
+    const bf16_t h = (bf16_t)v;
+    t[e >> 6][e & 63] = h;
+    if (r < g.cp && c < g.k) Wp_arena[g.wp_off + (size_t)r * g.k + c] = h;
   }
-  const PrepSeg g = segs[lo];
-  const int j = (int)(i - g.first);
-  const int r = j / g.k, c = j - r * g.k;
-  float v = 0.f;
-  if (r < g.cout && c < g.cin) {
-    const int src = c < g.cin - g.rot ? c + g.rot : c - (g.cin - g.rot);
-    v = g.W[(size_t)r * g.ldw + src];
+  __syncthreads();
+#pragma unroll 4
+  for (int e = (int)threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = c0 + (e >> 6), r = r0 + (e & 63);
+    if (r < g.cp && c < g.k) Wt_arena[g.wt_off + (size_t)c * g.cp + r] = t[e & 63][e >> 6];
   }
-  const bf16_t h = (bf16_t)v;
-  Wp_arena[g.wp_off + j] = h;
-  Wt_arena[g.wt_off + (size_t)c * g.cp + r] = h;
 }
 
 // inverse of the padding / rotation for the weight gradient: dWp f32 [cp][k] -> dW f32 [cout][cin]
@@ -1011,15 +1017,16 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
 
 // omnipq_prep_weight for a whole table of matrices in one launch.  segs: device array of nseg records
 //   { const float *W; int64 wp_off, wt_off, first; int32 cout, cin, ldw, cp, k, rot; }   (56 bytes, packed in
-// this order), `first` = running sum of cp*k over the preceding records, total = sum of all cp*k.
-extern "C" int omnipq_prep_weights_all(int nseg, long long total, const void *segs, void *Wp_arena, void *Wt_arena,
-                                       void *stream) {
+// this order; `first` is unused), tiles: device array of ntiles x int32[4] = {segment, first row, first column, 0},
+// one entry per 64 x 64 tile of every padded matrix.
+extern "C" int omnipq_prep_weights_all(int nseg, int ntiles, const void *segs, const int *tiles, void *Wp_arena,
+                                       void *Wt_arena, void *stream) {
   static_assert(sizeof(PrepSeg) == 56, "PrepSeg layout is part of the C ABI");
-  if (nseg < 0 || total < 0) return OMNIPQ_EINVAL;
-  if (nseg == 0 || total == 0) return OMNIPQ_OK;
-  if (!segs || !Wp_arena || !Wt_arena) return OMNIPQ_EINVAL;
-  prep_all_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      nseg, total, (const PrepSeg *)segs, (bf16_t *)Wp_arena, (bf16_t *)Wt_arena);
+  if (nseg < 0 || ntiles < 0) return OMNIPQ_EINVAL;
+  if (nseg == 0 || ntiles == 0) return OMNIPQ_OK;
+  if (!segs || !tiles || !Wp_arena || !Wt_arena) return OMNIPQ_EINVAL;
+  prep_all_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const PrepSeg *)segs, tiles, (bf16_t *)Wp_arena,
+                                                           (bf16_t *)Wt_arena);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

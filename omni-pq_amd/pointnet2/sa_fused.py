@@ -201,7 +201,7 @@ class WeightArena:
         self.entries = []         # (W2 view, cout, cin, ldw, cp, k, rot)
         self.views = []           # (Wp, Wt) per entry, valid while `active`
         self.built = 0            # number of entries the device table covers
-        self.table = self.wp = self.wt = None
+        self.table = self.tiles = self.wp = self.wt = None
         self.total = 0
         self.active = False
 
@@ -219,6 +219,9 @@ class WeightArena:
             tab[i] = (W2.data_ptr(), off, off, off, cout, cin, ldw, cp, k, rot)
             off += cp * k
         self.total = off
+        tiles = [(i, r0, c0, 0) for i, (_, _, _, _, cp, k, _) in enumerate(self.entries)
+                 for r0 in range(0, cp, 64) for c0 in range(0, k, 64)]
+        self.tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4).to(device)
         self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
         self.wp = torch.empty(off, device=device, dtype=torch.bfloat16)
         self.wt = torch.empty(off, device=device, dtype=torch.bfloat16)
@@ -258,8 +261,8 @@ class _ArenaStep:
         if len(a.entries) != a.built and not torch.cuda.is_current_stream_capturing():
             a._build(self.device)              # table upload: never inside a capture
         if a.built:
-            _call(_lib.omnipq_prep_weights_all, a.wp, a.built, ctypes.c_longlong(a.total), _p(a.table), _p(a.wp),
-                  _p(a.wt))
+            _call(_lib.omnipq_prep_weights_all, a.wp, a.built, int(a.tiles.shape[0]), _p(a.table), _p(a.tiles),
+                  _p(a.wp), _p(a.wt))
         a.active = True
         _ARENA = a
         return self
