@@ -139,19 +139,26 @@ __device__ __forceinline__ void stage_store(const StagePlan &sp, const StageRegs
     if (sp.tok[i] >= 0) *reinterpret_cast<uint2 *>(lds + sp.tok[i] * ATT_PITCH + sp.off[i]) = r.v[i];
 }
 
-// Operand with lane = channel (tile t: channel 32 t + lane&31, clamped into the staged row), contraction
-// index = accumulator row order of k-step j2: tokens acc_row(8 j2 + e, h), e = 0..7.
+// Operand with lane = channel (tile t: channel 32 t + lane&31), contraction index = accumulator row order of
+// k-step j2: tokens acc_row(8 j2 + e, h), e = 0..7, i.e. for a lane in half h the two runs of four consecutive
+// tokens 16 j2 + 4 h + [0,4) and 16 j2 + 8 + 4 h + [0,4).  Read through the LDS transpose read
+// (ds_read_b64_tr_b16): the 16 lanes of group g = lane >> 4 hand in the addresses of a [4 tokens][16 channels]
+// block (4 contiguous channels each) and receive it column-wise -- lane c gets channel c at the 4 tokens.
+// Group g serves channels 32 t + 16 (g & 1) + [0,16) for half h = g >> 1.  Channels past the staged row
+// (>= ATT_DMAX; they only feed output rows nobody stores) are redirected to the last valid 16-channel block.
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
 __device__ __forceinline__ bf16x8 frag_chan(const bf16_t *lds, int t, int j2, int h, int lane) {
-  int d = 32 * t + (lane & 31);
-  d = d < ATT_DMAX ? d : ATT_DMAX - 1;
-  bf16x8 f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) f[e] = lds[acc_row(8 * j2 + e, h) * ATT_PITCH + d];
-  return f;
+  const int grp = lane >> 4, l16 = lane & 15;
+  int c0 = 32 * t + 16 * (grp & 1);
+  c0 = c0 + 16 <= ATT_DMAX ? c0 : ATT_DMAX - 16;
+  const bf16_t *p = lds + (16 * j2 + 4 * h + (l16 >> 2)) * ATT_PITCH + c0 + (l16 & 3) * 4;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)p);
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(p + 8 * ATT_PITCH));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// v_exp_f32 without the denormal-range fix-up of exp2f(): arguments here are <= 0 differences of scores, and a
-// result below 2^-126 flushing to zero is exactly what a softmax weight that small should do
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
