@@ -33,11 +33,11 @@ int omnipq_add_dropout_layernorm_bwd(long long R, int C, const float *x, const v
                                      const float *mean, const float *rstd, const float *g32, const void *g16,
                                      const void *g16_pe, float *dx, void *dy, float *dgamma_dbeta, void *stream);
 
-/* h = dropout(relu(h)) in place on bf16 [n]; backward: d = (h > 0) ? d / (1-p) : 0 in place (h = the forward's
- * OUTPUT: positive exactly where the unit was active and kept). */
+/* h = dropout(relu(h)) in place on bf16 [n]; backward: out = (h > 0) ? d / (1-p) : 0 (out may be d; h = the
+ * forward's OUTPUT: positive exactly where the unit was active and kept). */
 int omnipq_relu_dropout(long long n, void *h, float dropout_p, const unsigned long long *seed_ptr, unsigned salt,
                         void *stream);
-int omnipq_relu_dropout_bwd(long long n, const void *h, void *d, float dropout_p, void *stream);
+int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d, void *out, float dropout_p, void *stream);
 
 /* out16 [n] bf16 = bf16(a + b):  a f32 or bf16 (a_is_f32), b bf16. */
 int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16, void *stream);

@@ -72,6 +72,7 @@ int omnipq_colstats_z(long long P, int C, const void *Y, double *sums, void *str
 
 /* sums[c] += sum_p Y[p][c] for bf16 Y [P][C], any C % 8 == 0 (bias gradients). */
 int omnipq_colsum(long long P, int C, const void *Y, double *sums, void *stream);
+int omnipq_colsum_f32(long long P, int C, const void *Y, float *sums, void *stream);    /* f32 accumulator */
 
 /* bn_finalize + bnrelu in one launch: a/b/mean/invstd and the running statistics come out as from
  * omnipq_bn_finalize, X = relu(a Y + b) as from omnipq_bnrelu. */
@@ -135,6 +136,13 @@ int omnipq_bn_bwd_stats_z(long long P, int C, const void *dX, const void *Y, con
 int omnipq_bn_bwd_apply(long long P, int C, double total_positions, const void *dX, const void *Y,
                         const float *a, const float *b, const float *mean, const float *invstd,
                         const double *sums, void *dY, void *stream);
+
+/* out[0] += sum_i mean(tensor_i), i < nseg <= 72: the benchmark's stand-in loss in one launch over strided
+ * views (<= 4 dims, f32 or bf16; no casts, no concatenation).  HOST arrays: ptrs[nseg] device pointers,
+ * sizes / strides [nseg][4] in elements (unused leading dims: size 1), is_bf16[nseg].  The descriptors are
+ * passed by value in the kernel arguments, so the call can be captured into a graph. */
+int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int *sizes, const int *strides, const int *is_bf16,
+                        float *out, void *stream);
 
 #ifdef __cplusplus
 }

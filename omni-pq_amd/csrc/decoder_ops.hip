@@ -268,14 +268,14 @@ __global__ __launch_bounds__(256) void relu_dropout_kernel(long long n4, bf16_t 
 }
 
 __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(long long n4, const bf16_t *__restrict__ h,
-                                                              bf16_t *__restrict__ d, float keep_inv) {
+                                                              const bf16_t *d, bf16_t *out, float keep_inv) {
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
     float hv[4], dv[4];
     unpack4(*reinterpret_cast<const uint2 *>(h + q * 4), hv);
     unpack4(*reinterpret_cast<const uint2 *>(d + q * 4), dv);
 #pragma unroll
     for (int e = 0; e < 4; ++e) dv[e] = hv[e] > 0.f ? dv[e] * keep_inv : 0.f;
-    *reinterpret_cast<uint2 *>(d + q * 4) = pack4(dv);
+    *reinterpret_cast<uint2 *>(out + q * 4) = pack4(dv);
   }
 }
 
@@ -376,13 +376,14 @@ extern "C" int omnipq_relu_dropout(long long n, void *h, float dropout_p, const 
   return OMNIPQ_OK;
 }
 
-extern "C" int omnipq_relu_dropout_bwd(long long n, const void *h, void *d, float dropout_p, void *stream) {
+extern "C" int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d, void *out, float dropout_p,
+                                       void *stream) {
   using namespace omnipq;
   if (n < 0 || (n % 4) || !(dropout_p >= 0.f) || dropout_p >= 1.f) return OMNIPQ_EINVAL;
   if (n == 0) return OMNIPQ_OK;
-  if (!h || !d) return OMNIPQ_EINVAL;
-  relu_dropout_bwd_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, (const bf16_t *)h, (bf16_t *)d,
-                                                                            1.0f / (1.0f - dropout_p));
+  if (!h || !d || !out) return OMNIPQ_EINVAL;
+  relu_dropout_bwd_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(
+      n / 4, (const bf16_t *)h, (const bf16_t *)d, (bf16_t *)out, 1.0f / (1.0f - dropout_p));
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -355,8 +355,9 @@ __global__ void bwd_means_kernel(int n2, double invP, const double *__restrict__
 
 // column sums of a bf16 [P][C] matrix for any C % 8 == 0 (bias gradients of wide layers):
 // block = 32 column pieces (256 columns) x 8 row lanes; grid (ceil(C/256), row slabs); sums += (f64 atomics)
+template <typename ACC>
 __global__ __launch_bounds__(256) void colsum_kernel(long long P, int C, const bf16_t *__restrict__ Y,
-                                                    double *__restrict__ sums) {
+                                                    ACC *__restrict__ sums) {
   __shared__ float red[8][256];
   const int tid = (int)threadIdx.x, piece = (int)blockIdx.x * 32 + (tid & 31), rsub = tid >> 5;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(long long P, int C, const b
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) t += red[r][tid];
-    atomicAdd(sums + c, (double)t);
+    atomicAdd(sums + c, (ACC)t);
   }
 }
 
@@ -975,7 +976,22 @@ extern "C" int omnipq_colsum(long long P, int C, const void *Y, double *sums, vo
   long long slabs = P / 128;
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
-  colsum_kernel<<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y, sums);
+  colsum_kernel<double><<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+                                                                                          sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// The same into f32 (a bias gradient in the parameter's own dtype: at most 64 partial sums meet per column).
+extern "C" int omnipq_colsum_f32(long long P, int C, const void *Y, float *sums, void *stream) {
+  if (P < 0 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  if (!Y || !sums) return OMNIPQ_EINVAL;
+  if (P == 0) return OMNIPQ_OK;
+  long long slabs = P / 128;
+  if (slabs < 1) slabs = 1;
+  if (slabs > 64) slabs = 64;
+  colsum_kernel<float><<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+                                                                                         sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1027,6 +1043,89 @@ extern "C" int omnipq_prep_weights_all(int nseg, int ntiles, const void *segs, c
   if (!segs || !tiles || !Wp_arena || !Wt_arena) return OMNIPQ_EINVAL;
   prep_all_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const PrepSeg *)segs, tiles, (bf16_t *)Wp_arena,
                                                            (bf16_t *)Wt_arena);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// ---- sum over a list of tensors of their means (the benchmark's stand-in loss) ------------------
+// One launch over up to 72 strided views (<= 4 dims, f32 or bf16): no casts, no concatenation.  The view
+// descriptors travel BY VALUE in the kernel arguments (3.9 KB), so the call needs no device-side table and
+// can be captured into a graph like any other launch.
+constexpr int kMeanMax = 72;
+struct MeanSeg {
+  const void *ptr;
+  int size[4], stride[4];           // elements; unused leading dims have size 1
+  int numel;
+};
+struct MeanArgs {
+  int nseg, is_bf16_lo, is_bf16_mid, is_bf16_hi;      // dtype bits of segments 0..31, 32..63, 64..71
+  int first[kMeanMax + 1];          // first chunk (4096 elements) of each segment
+  MeanSeg seg[kMeanMax];
+};
+
+__global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, float *__restrict__ out) {
+  __shared__ float red[4];
+  const int blk = (int)blockIdx.x;
+  int lo = 0, hi = a.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.first[mid] <= blk) lo = mid; else hi = mid - 1;
+  }
+  const MeanSeg &g = a.seg[lo];
+  const unsigned bits = lo < 32 ? (unsigned)a.is_bf16_lo : (lo < 64 ? (unsigned)a.is_bf16_mid : (unsigned)a.is_bf16_hi);
+  const bool bf = (bits >> (lo & 31)) & 1u;
+  const int base = (blk - a.first[lo]) * 4096;
+  float acc = 0.f;
+  for (int u = 0; u < 16; ++u) {
+    const int i = base + u * 256 + (int)threadIdx.x;
+    if (i < g.numel) {
+      int r = i;
+      const int i3 = r % g.size[3]; r /= g.size[3];
+      const int i2 = r % g.size[2]; r /= g.size[2];
+      const int i1 = r % g.size[1]; r /= g.size[1];
+      const long long off = (long long)r * g.stride[0] + (long long)i1 * g.stride[1] + (long long)i2 * g.stride[2] +
+                            (long long)i3 * g.stride[3];
+      acc += bf ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / (float)g.numel);
+}
+
+// out[0] += sum_i mean(tensor_i), i < nseg <= 72.  Host arrays: ptrs[nseg] (device pointers), sizes / strides
+// [nseg][4] (elements, unused leading dims = 1 / 0), is_bf16[nseg] (else f32).  Each tensor < 2^31 elements.
+extern "C" int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int *sizes, const int *strides,
+                                   const int *is_bf16, float *out, void *stream) {
+  static_assert(sizeof(MeanArgs) <= 4000, "MeanArgs must fit into the kernel-argument segment");
+  if (nseg < 0 || nseg > kMeanMax) return OMNIPQ_EINVAL;
+  if (nseg == 0) return OMNIPQ_OK;
+  if (!ptrs || !sizes || !strides || !is_bf16 || !out) return OMNIPQ_EINVAL;
+  MeanArgs a;
+  a.nseg = nseg;
+  unsigned bits[3] = {0u, 0u, 0u};
+  int chunk = 0;
+  for (int i = 0; i < nseg; ++i) {
+    long long n = 1;
+    for (int d = 0; d < 4; ++d) {
+      if (sizes[4 * i + d] <= 0) return OMNIPQ_EINVAL;
+      a.seg[i].size[d] = sizes[4 * i + d];
+      a.seg[i].stride[d] = strides[4 * i + d];
+      n *= sizes[4 * i + d];
+    }
+    if (!ptrs[i]) return OMNIPQ_EINVAL;
+    if (n >= (1ll << 31)) return OMNIPQ_ETOOLARGE;
+    a.seg[i].ptr = ptrs[i];
+    a.seg[i].numel = (int)n;
+    a.first[i] = chunk;
+    chunk += (int)((n + 4095) / 4096);
+    if (is_bf16[i]) bits[i >> 5] |= 1u << (i & 31);
+  }
+  a.first[nseg] = chunk;
+  a.is_bf16_lo = (int)bits[0], a.is_bf16_mid = (int)bits[1], a.is_bf16_hi = (int)bits[2];
+  sum_of_means_kernel<<<chunk, 256, 0, (hipStream_t)stream>>>(a, out);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -189,6 +189,8 @@ def run(layer, query, key, query_pos, key_pos, kv=None):
     # feed-forward (:216-219)
     y = rows_mlp.run(x16, [rows_mlp.Layer(layer.linear1.weight, layer.linear1.bias, relu_dropout=pdrop(layer.dropout)),
                            rows_mlp.Layer(layer.linear2.weight, layer.linear2.bias)], training)
-    x32, _, _ = AddDropoutLayerNorm.apply(x32, y, layer.norm3.weight, layer.norm3.bias, float(layer.norm3.eps),
-                                          pdrop(layer.dropout3), None, True, False)
-    return x32.view(B, Pq, C).transpose(1, 2)
+    x32, x16, _ = AddDropoutLayerNorm.apply(x32, y, layer.norm3.weight, layer.norm3.bias, float(layer.norm3.eps),
+                                            pdrop(layer.dropout3), None, True, True)
+    out = x32.view(B, Pq, C).transpose(1, 2)
+    out.omnipq_rows16 = x16.view(B, Pq, C)      # the same values in bf16, for consumers that run on bf16 rows
+    return out

@@ -61,12 +61,14 @@ def conv1x1(x, conv):
     return lin(rows(x), conv).view(B, K, -1).transpose(1, 2)
 
 
-def head_stack(self, net, heads):
+def head_stack(self, net, heads, net_rows=None):
     """Trunk (2 x Conv1d+BN+ReLU) and every 1x1 output head of a prediction head on (B, C, K) features.
     The output heads share one GEMM over their concatenated weights.  -> list of (B, K, C_h) tensors, i.e.
-    already in the layout the reference reaches with `.transpose(2, 1)`."""
+    already in the layout the reference reaches with `.transpose(2, 1)`.
+    net_rows: the same features as (B, K, C) data in another dtype (the decoder's bf16 rows), used instead of
+    `net` when given -- the kernels want bf16 rows anyway, this saves the cast forth and back."""
     B, K = net.shape[0], net.shape[2]
-    x = rows(net)
+    x = rows(net) if net_rows is None else net_rows.reshape(B * K, -1)
     w = torch.cat([h.weight.squeeze(-1) for h in heads], 0)
     b = torch.cat([h.bias for h in heads], 0)
     stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
@@ -157,11 +159,11 @@ class PredictHead(nn.Module):
             self._means = torch.from_numpy(np.asarray(self.mean_size_arr).astype(np.float32)).to(device)
         return self._means
 
-    def forward(self, net, base_xyz, end_points, prefix):
+    def forward(self, net, base_xyz, end_points, prefix, net_rows=None):
         obj, ctr, hcls, hres, scls, sres, sem = head_stack(self, net, (
             self.objectness_scores_head, self.center_head, self.heading_class_head,
             self.heading_residual_head, self.size_class_head, self.size_residual_head,
-            self.sem_cls_scores_head))
+            self.sem_cls_scores_head), net_rows)
         center = ctr + base_xyz
         end_points, pred_size = decode_scores(
             base_xyz, obj, center, hcls, hres, scls, sres, sem, end_points, self.num_class,
@@ -184,9 +186,9 @@ class QuadPredictHead(nn.Module):
         self.bn1 = nn.BatchNorm1d(hidden_dim)
         self.bn2 = nn.BatchNorm1d(hidden_dim)
 
-    def forward(self, net, base_xyz, end_points, prefix):
+    def forward(self, net, base_xyz, end_points, prefix, net_rows=None):
         scores, ctr, normal, size = head_stack(self, net, (
-            self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head))
+            self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head), net_rows)
         center = ctr + base_xyz
         normal = normal.div(torch.norm(normal, p=2))
         end_points[f'{prefix}quad_scores'] = scores
@@ -299,10 +301,13 @@ class PQ_Transformer(nn.Module):
             query_joint = self.decoder[i](query_joint, key, query_pos_joint, key_pos, key_sides[i])
             query = query_joint[:, :, 0:self.num_proposal]
             query_q = query_joint[:, :, self.num_proposal:]
+            rows16 = getattr(query_joint, 'omnipq_rows16', None)          # (B, P, C) bf16 twin from the row-major decoder
             base_xyz, _, end_points = self.prediction_heads[i](
-                query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix)
+                query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
+                net_rows=None if rows16 is None else rows16[:, 0:self.num_proposal])
             base_xyz_q, _, end_points = self.prediction_quad_heads[i](
-                query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix)
+                query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix,
+                net_rows=None if rows16 is None else rows16[:, self.num_proposal:])
             base_xyz = base_xyz.detach().clone()
             base_xyz_q = base_xyz_q.detach().clone()
         return end_points

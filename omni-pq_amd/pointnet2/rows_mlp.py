@@ -169,11 +169,11 @@ class RowsMLP(torch.autograd.Function):
         last = layers[-1]
         if last.Cp == last.C:
             dcur = g.to(torch.bfloat16).contiguous()
-            if dcur.data_ptr() == g.data_ptr():
-                dcur = dcur.clone()            # the BatchNorm backward below works in place
+            owned = dcur.data_ptr() != g.data_ptr()        # autograd's buffer must not be modified in place
         else:
             dcur = torch.zeros((N, last.Cp), device=dev, dtype=torch.bfloat16)
             dcur[:, :last.C] = g
+            owned = True
         dx = None
         sums = None               # BN-backward sums of the current layer if the GEMM above already produced them
         for l in range(L - 1, -1, -1):
@@ -184,30 +184,35 @@ class RowsMLP(torch.autograd.Function):
                     sums = zeros_f64(3, lay.C, dev)
                     _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
                           _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
-                grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums, world)
+                dst = dcur if owned else torch.empty_like(dcur)
+                grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums, world,
+                                                                                out=dst)
+                dcur, owned = dst, True
                 if lay.has_bias:
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
             elif lay.act is not None:
                 # lay.Y holds dropout(relu(.)): positive exactly where the unit was active and kept
-                _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur),
+                dst = dcur if owned else torch.empty_like(dcur)
+                _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur), _p(dst),
                       ctypes.c_float(lay.act[1]))
+                dcur, owned = dst, True
             if not lay.has_bn and lay.has_bias:
-                sums = zeros_f64(1, lay.Cp, dev)
-                _call(_lib.omnipq_colsum, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(sums))
-                grads[4 * l + 1] = sums[0, :lay.C].float()
+                bsum = zeros_f32(lay.Cp, dev)
+                _call(_lib.omnipq_colsum_f32, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(bsum))
+                grads[4 * l + 1] = bsum[:lay.C]
             dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N)
             grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None
             if l > 0 and layers[l - 1].has_bn:
                 sums = zeros_f64(3, lay.K, dev)
                 dprev = _gemm_nt_bnbwd(dcur, lay.Wt, N, lay.K, lay.Cp, layers[l - 1], sums)
-                dcur = dprev
+                dcur, owned = dprev, True
             elif l > 0 or ctx.needs_input_grad[0]:
                 dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
                 _call(_lib.omnipq_gemm_nt_bf16, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
                       _p(dprev), lay.K)
                 if l > 0:
-                    dcur = dprev
+                    dcur, owned = dprev, True
                 else:
                     dx = dprev[:, :cin].to(ctx.in_dtype)
         # weight gradients in the parameters' own shapes

@@ -320,20 +320,21 @@ def unprep_wgrad(dWp, cout, cin, rot, shape):
     return dW
 
 
-def bn_backward_apply(d, lay, P, C, total, sums, world):
-    """In place: d (gradient w.r.t. the ReLU output, bf16 [P][C]) -> gradient w.r.t. the layer's pre-BN output,
-    given the BatchNorm-backward totals `sums` of THIS rank.  Returns (dgamma, dbeta), this rank's share.
+def bn_backward_apply(d, lay, P, C, total, sums, world, out=None):
+    """d (gradient w.r.t. the ReLU output, bf16 [P][C]) -> gradient w.r.t. the layer's pre-BN output, written to
+    `out` (default: in place), given the BatchNorm-backward totals `sums` of THIS rank.  Returns (dgamma, dbeta),
+    this rank's share.
     Single process: one launch does the means, the f32 copies of the totals and the apply; under a process
     group the totals are all-reduced in between (SyncBatchNorm), so the local gradients are taken first."""
     if world > 1 or _FORCE_COLLECTIVES:
         dgamma, dbeta = affine_grads(sums, C)
         _allreduce_(sums[:2])
-        out = None
+        gb = None
     else:
-        out = torch.empty((2, C), device=d.device, dtype=torch.float32)
-        dgamma, dbeta = out[1], out[0]
+        gb = torch.empty((2, C), device=d.device, dtype=torch.float32)
+        dgamma, dbeta = gb[1], gb[0]
     _call(_lib.omnipq_bn_bwd_apply_fused, d, ctypes.c_longlong(P), C, total, _p(d), _p(lay.Y), _p(lay.a), _p(lay.b),
-          _p(lay.mean), _p(lay.invstd), _p(sums), _p(d), _p(out))
+          _p(lay.mean), _p(lay.invstd), _p(sums), _p(d if out is None else out), _p(gb))
     return dgamma, dbeta
 
 

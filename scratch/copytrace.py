@@ -1,0 +1,35 @@
+import sys, os, collections, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv=["bench.py","--graph","off","--no-op-timing","--no-cpu-baseline"]
+import bench, torch
+from torch.utils._python_dispatch import TorchDispatchMode
+args=bench.parse()
+dev=torch.device("cuda",0)
+import pointnet2_utils, synth
+net=bench.build_model(0).to(dev); net.train()
+pool=[synth.make_clouds(100+i,args.batch,args.points,kind="room").to(dev) for i in range(3)]
+step,_=bench.make_step(net,net,pool,args,torch.bfloat16,1)
+for i in range(3): step(i)
+torch.cuda.synchronize()
+agg=collections.defaultdict(lambda:[0,0])
+WATCH=("copy_","_to_copy","clone","cat","fill_","zeros","add","div","mul","zero_")
+class M(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out=func(*args, **(kwargs or {}))
+        name=func.__name__ if hasattr(func,"__name__") else str(func)
+        base=str(func).split(".")[1] if "." in str(func) else str(func)
+        if base in WATCH:
+            fr="?"
+            for f in reversed(traceback.extract_stack()):
+                if ("omni-pq_amd" in f.filename or f.filename.endswith("bench.py")):
+                    fr=f"{os.path.basename(f.filename)}:{f.lineno}"; break
+            n=0
+            if torch.is_tensor(out): n=out.numel()*out.element_size()
+            agg[(base,fr)][0]+=1; agg[(base,fr)][1]+=n
+        return out
+with M():
+    step(0)
+torch.cuda.synchronize()
+print("ops watched:", sum(v[0] for v in agg.values()))
+for (b,fr),(c,n) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:90]:
+    print(f"{c:5d}x {n/1e6:9.2f} MB  {b:10s} {fr}")
