@@ -22,7 +22,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     rows.sort(key=lambda r: r[1])
-    marks = [r[1] for r in rows if "fps_kernel<1024, 4, true" in r[0]]
+    marks = [r[1] for r in rows if "fps_kernel<1024, " in r[0]]
     t0, t1 = marks[-1 - steps], marks[-1]
     agg = defaultdict(lambda: [0, 0])
     busy = 0
