@@ -1055,7 +1055,7 @@ constexpr int kMeanMax = 72;
 struct MeanSeg {
   const void *ptr;
   int size[4], stride[4];           // elements; unused leading dims have size 1
-  int numel;
+  int numel;                        // < 0: the view is a permutation of a dense block -- walk it linearly (-numel)
 };
 struct MeanArgs {
   int nseg, is_bf16_lo, is_bf16_mid, is_bf16_hi;      // dtype bits of segments 0..31, 32..63, 64..71
@@ -1075,10 +1075,16 @@ __global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, flo
   const unsigned bits = lo < 32 ? (unsigned)a.is_bf16_lo : (lo < 64 ? (unsigned)a.is_bf16_mid : (unsigned)a.is_bf16_hi);
   const bool bf = (bits >> (lo & 31)) & 1u;
   const int base = (blk - a.first[lo]) * 4096;
+  const bool dense = g.numel < 0;
+  const int numel = dense ? -g.numel : g.numel;
   float acc = 0.f;
   for (int u = 0; u < 16; ++u) {
     const int i = base + u * 256 + (int)threadIdx.x;
-    if (i < g.numel) {
+    if (i < numel) {
+      if (dense) {                  // a sum does not care about the order: memory order, coalesced
+        acc += bf ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[i] : reinterpret_cast<const float *>(g.ptr)[i];
+        continue;
+      }
       int r = i;
       const int i3 = r % g.size[3]; r /= g.size[3];
       const int i2 = r % g.size[2]; r /= g.size[2];
@@ -1092,7 +1098,7 @@ __global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, flo
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / (float)g.numel);
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) / (float)numel);
 }
 
 // out[0] += sum_i mean(tensor_i), i < nseg <= 72.  Host arrays: ptrs[nseg] (device pointers), sizes / strides
@@ -1118,7 +1124,24 @@ extern "C" int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int 
     if (!ptrs[i]) return OMNIPQ_EINVAL;
     if (n >= (1ll << 31)) return OMNIPQ_ETOOLARGE;
     a.seg[i].ptr = ptrs[i];
-    a.seg[i].numel = (int)n;
+    // dense up to a permutation of the axes?  sort the non-trivial dims by stride and check they nest
+    int order[4] = {0, 1, 2, 3};
+    for (int x = 0; x < 4; ++x)
+      for (int y = x + 1; y < 4; ++y)
+        if (strides[4 * i + order[y]] > strides[4 * i + order[x]]) {
+          const int t = order[x];
+          order[x] = order[y];
+          order[y] = t;
+        }
+    long long expect = 1;
+    bool dense = true;
+    for (int x = 3; x >= 0; --x) {
+      const int d = order[x];
+      if (sizes[4 * i + d] == 1) continue;
+      if (strides[4 * i + d] != expect) dense = false;
+      expect *= sizes[4 * i + d];
+    }
+    a.seg[i].numel = dense ? -(int)n : (int)n;
     a.first[i] = chunk;
     chunk += (int)((n + 4095) / 4096);
     if (is_bf16[i]) bits[i >> 5] |= 1u << (i & 31);
