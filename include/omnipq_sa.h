@@ -137,6 +137,17 @@ int omnipq_bn_bwd_apply(long long P, int C, double total_positions, const void *
                         const float *a, const float *b, const float *mean, const float *invstd,
                         const double *sums, void *dY, void *stream);
 
+/* Feature propagation on position-major rows (pointnet2_modules.py:371-416): three_interpolate with channels
+ * contiguous.  feat bf16 [b][m][C]; idx int32 / weight f32 [b][n][3] as from omnipq_three_nn + the reference's
+ * inverse-distance weights; result bf16 into columns [col0, col0 + C) of rows [b*n][ldo].  The gradient is
+ * ADDED to dfeat f32 [b][m][C] (zero it first).  omnipq_place_rows copies a [rows][C] bf16 block into a column
+ * range of wider rows (the skip features next to the interpolated ones).  C, ldo, col0 multiples of 8. */
+int omnipq_interp_rows(int b, int n, int m, int C, const void *feat, const int *idx, const float *weight, void *out,
+                       int ldo, int col0, void *stream);
+int omnipq_interp_rows_grad(int b, int n, int m, int C, const void *g, int ldg, int col0, const int *idx,
+                            const float *weight, float *dfeat, void *stream);
+int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd, int col0, void *stream);
+
 /* out[0] += sum_i mean(tensor_i), i < nseg <= 72: the benchmark's stand-in loss in one launch over strided
  * views (<= 4 dims, f32 or bf16; no casts, no concatenation).  HOST arrays: ptrs[nseg] device pointers,
  * sizes / strides [nseg][4] in elements (unused leading dims: size 1), is_bf16[nseg].  The descriptors are

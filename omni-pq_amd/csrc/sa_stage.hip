@@ -1152,3 +1152,102 @@ extern "C" int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int 
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
+
+// ---- feature propagation on position-major rows (reference pointnet2_modules.py:371-416, interpolate_gpu.cu) ----
+// out[(b,i)][col0 + c] = sum_k w[b][i][k] * feat[b][idx[b][i][k]][c]      feat bf16 [b][m][C], out bf16 rows (pitch ldo)
+// Same arithmetic as three_interpolate (f32 weights, f32 accumulation), but with channels contiguous a
+// neighbour is ONE 16-byte read per 8 channels instead of 8 strided ones, and the result lands directly in
+// the columns of the MLP's input rows (no transpose, no concatenation pass).
+__global__ __launch_bounds__(256) void interp_rows_kernel(long long chunks, int n, int m, int C, const bf16_t *__restrict__ feat,
+                                                         const int *__restrict__ idx, const float *__restrict__ w,
+                                                         bf16_t *__restrict__ out, int ldo, int col0) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long row = q / cpr;                         // (b, i)
+    const int c0 = (int)(q - row * cpr) * 8;
+    const long long b = row / n;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = idx[row * 3 + k];
+      const float wk = w[row * 3 + k];
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4 *>(feat + ((size_t)b * m + j) * C + c0), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(wk, f[e], acc[e]);
+    }
+    *reinterpret_cast<uint4 *>(out + (size_t)row * ldo + col0 + c0) = pack8(acc);
+  }
+}
+
+// dfeat[b][idx][c] += w * g[(b,i)][col0 + c]      (f32 atomics, 8 consecutive channels per lane; dfeat zeroed)
+__global__ __launch_bounds__(256) void interp_rows_grad_kernel(long long chunks, int n, int m, int C,
+                                                              const bf16_t *__restrict__ g, int ldg, int col0,
+                                                              const int *__restrict__ idx, const float *__restrict__ w,
+                                                              float *__restrict__ dfeat) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long row = q / cpr;
+    const int c0 = (int)(q - row * cpr) * 8;
+    const long long b = row / n;
+    float gv[8];
+    unpack8(*reinterpret_cast<const uint4 *>(g + (size_t)row * ldg + col0 + c0), gv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = idx[row * 3 + k];
+      const float wk = w[row * 3 + k];
+      float *dst = dfeat + ((size_t)b * m + j) * C + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(dst + e, wk * gv[e]);
+    }
+  }
+}
+
+// copy of a bf16 row block into a column range of wider rows: dst[r][col0 + c] = src[r][c]
+__global__ __launch_bounds__(256) void place_rows_kernel(long long chunks, int C, const bf16_t *__restrict__ src,
+                                                        bf16_t *__restrict__ dst, int ldd, int col0) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long row = q / cpr;
+    const int c0 = (int)(q - row * cpr) * 8;
+    *reinterpret_cast<uint4 *>(dst + (size_t)row * ldd + col0 + c0) =
+        *reinterpret_cast<const uint4 *>(src + (size_t)row * C + c0);
+  }
+}
+
+extern "C" int omnipq_interp_rows(int b, int n, int m, int C, const void *feat, const int *idx, const float *weight,
+                                  void *out, int ldo, int col0, void *stream) {
+  if (b < 0 || n < 0 || m <= 0 || C <= 0 || (C % 8) || (ldo % 8) || (col0 % 8) || col0 < 0 || col0 + C > ldo)
+    return OMNIPQ_EINVAL;
+  const long long chunks = (long long)b * n * (C / 8);
+  if (chunks == 0) return OMNIPQ_OK;
+  if (!feat || !idx || !weight || !out) return OMNIPQ_EINVAL;
+  interp_rows_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const bf16_t *)feat, idx, weight,
+                                                                      (bf16_t *)out, ldo, col0);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_interp_rows_grad(int b, int n, int m, int C, const void *g, int ldg, int col0, const int *idx,
+                                       const float *weight, float *dfeat, void *stream) {
+  if (b < 0 || n < 0 || m <= 0 || C <= 0 || (C % 8) || (ldg % 8) || (col0 % 8) || col0 < 0 || col0 + C > ldg)
+    return OMNIPQ_EINVAL;
+  const long long chunks = (long long)b * n * (C / 8);
+  if (chunks == 0) return OMNIPQ_OK;
+  if (!g || !idx || !weight || !dfeat) return OMNIPQ_EINVAL;
+  interp_rows_grad_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const bf16_t *)g, ldg, col0,
+                                                                           idx, weight, dfeat);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd, int col0, void *stream) {
+  if (rows < 0 || C <= 0 || (C % 8) || (ldd % 8) || (col0 % 8) || col0 < 0 || col0 + C > ldd) return OMNIPQ_EINVAL;
+  const long long chunks = rows * (C / 8);
+  if (chunks == 0) return OMNIPQ_OK;
+  if (!src || !dst) return OMNIPQ_EINVAL;
+  place_rows_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, C, (const bf16_t *)src, (bf16_t *)dst, ldd,
+                                                                     col0);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

@@ -236,6 +236,11 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
+        if known is not None and known_feats.is_cuda and torch.is_autocast_enabled("cuda") and \
+                torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            out = self._forward_rows(unknown, known, unknow_feats, known_feats)
+            if out is not None:
+                return out
         if known is None:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
@@ -251,6 +256,35 @@ class PointnetFPModule(nn.Module):
         stacked = interpolated if unknow_feats is None else \
             torch.cat([interpolated, unknow_feats], dim=1)
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
+
+
+def _fp_forward_rows(self, unknown, known, unknow_feats, known_feats):
+    """bf16 mode with position-major twins on both operands (the fused SA stages and other FP modules attach
+    them): interpolation, channel concatenation and MLP entirely on rows -- no (B, C, n) round trip.  None if
+    a twin is missing or the MLP has another shape (the caller then composes the reference ops)."""
+    import sa_fused
+    B, n = unknown.shape[0], unknown.shape[1]
+    m, C2 = known.shape[1], known_feats.shape[1]
+    known_pm = sa_fused.rows16_of(known_feats, (B, m, C2))
+    skip_pm = None
+    if unknow_feats is not None:
+        skip_pm = sa_fused.rows16_of(unknow_feats, (B, n, unknow_feats.shape[1]))
+        if skip_pm is None or skip_pm.shape[2] % 8:
+            return None
+    if known_pm is None or C2 % 8:
+        return None
+    dist, idx = pointnet2_utils.three_nn(unknown, known)
+    weight = inverse_distance_weights(dist).contiguous()
+    rows_in = sa_fused.FPGatherRows.apply(known_feats, known_pm, unknow_feats, skip_pm, idx, weight)
+    y = _rows_mlp(self.mlp, rows_in)
+    if y is None:
+        return None
+    out = y.view(B, n, -1).transpose(1, 2)                             # (B, C_out, n) view of the rows
+    out.omnipq_rows16 = y.view(B, n, -1)
+    return out
+
+
+PointnetFPModule._forward_rows = _fp_forward_rows
 
 
 class PointnetLFPModuleMSG(nn.Module):

@@ -345,9 +345,13 @@ def affine_grads(sums, C):
     return both[1], both[0]
 
 
-# position-major bf16 copy of the last fused stage's output, keyed by (data_ptr, shape) of the tensor it
-# returned; consumed (and dropped) by the next fused stage if that very tensor comes in as `features`
-_PM_CACHE = {}
+def rows16_of(t, shape):
+    """The position-major bf16 twin a producer attached to `t` (attribute `omnipq_rows16`: the same values as
+    (B, n, C) bf16 data), if it is there and matches."""
+    twin = getattr(t, "omnipq_rows16", None) if t is not None else None
+    if twin is None or tuple(twin.shape) != tuple(shape) or twin.dtype != torch.bfloat16 or not twin.is_contiguous():
+        return None
+    return twin
 
 
 class _Layer:
@@ -363,13 +367,13 @@ class FusedSAStage(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg, *params):
+    def forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training, bn_cfg, *params):
         with _tagged("@sa"):
-            return FusedSAStage._forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg,
-                                         *params)
+            return FusedSAStage._forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training,
+                                         bn_cfg, *params)
 
     @staticmethod
-    def _forward(ctx, xyz, new_xyz, features, idx, radius, normalize_xyz, training, bn_cfg, *params):
+    def _forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training, bn_cfg, *params):
         dev = xyz.device
         B, N, _ = xyz.shape
         M, S = idx.shape[1], idx.shape[2]
@@ -380,12 +384,11 @@ class FusedSAStage(torch.autograd.Function):
         inv_r = (1.0 / radius) if normalize_xyz else 1.0
         world = _world() if training else 1
 
-        feat_pm = None
-        if features is not None:
-            # position-major bf16 copy [B][N][cin]; the previous fused stage left exactly that behind
-            feat_pm = _PM_CACHE.pop((features.data_ptr(), tuple(features.shape)), None)
-            if feat_pm is None:
-                feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()
+        if features is None:
+            feat_pm = None
+        elif feat_pm is None:
+            # position-major bf16 copy [B][N][cin] (a producer that has one passes it in: see run())
+            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()
         xyz_c = xyz.detach().contiguous()
         cen_c = new_xyz.detach().contiguous()
         X = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
@@ -453,8 +456,6 @@ class FusedSAStage(torch.autograd.Function):
         # the reference's, only the strides differ (no transpose pass; every consumer on this path
         # either accepts strides or wants the position-major form back)
         out = out_f32.transpose(1, 2)
-        _PM_CACHE.clear()
-        _PM_CACHE[(out.data_ptr(), tuple(out.shape))] = out_pm
 
         ctx.layers = layers
         ctx.X0 = X0
@@ -464,10 +465,12 @@ class FusedSAStage(torch.autograd.Function):
         ctx.has_features = features is not None
         ctx.feat_dtype = features.dtype if features is not None else None
         ctx.training = training
-        return out
+        twin = out_pm.view(B, M, last.C)
+        ctx.mark_non_differentiable(twin)
+        return out, twin
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, _g_twin=None):
         with _tagged("@sa"):
             return FusedSAStage._backward(ctx, g_out)
 
@@ -532,7 +535,7 @@ class FusedSAStage(torch.autograd.Function):
                 if dfeat_pm is not None:
                     d_feat = dfeat_pm.transpose(1, 2).to(ctx.feat_dtype)      # (B, cin, N) view, see forward
         ctx.layers = None
-        return (d_xyz, d_cen, d_feat, None, None, None, None, None, *grads)
+        return (d_xyz, d_cen, d_feat, None, None, None, None, None, None, *grads)
 
 
 def _bn_of(layer):
@@ -585,5 +588,43 @@ def run(module, xyz, new_xyz, features):
         conv, bn = _bn_of(layer)
         params += [conv.weight, bn.weight, bn.bias]
         bn_cfg.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
-    return FusedSAStage.apply(xyz, new_xyz, features, idx, float(module.radius), bool(module.normalize_xyz),
-                              bool(module.training), bn_cfg, *params)
+    feat_pm = None if features is None else rows16_of(features, (features.shape[0], features.shape[2], features.shape[1]))
+    out, twin = FusedSAStage.apply(xyz, new_xyz, features, feat_pm, idx, float(module.radius),
+                                   bool(module.normalize_xyz), bool(module.training), bn_cfg, *params)
+    out.omnipq_rows16 = twin        # consumers that work on bf16 rows (next SA stage, FP modules) skip their cast
+    return out
+
+
+class FPGatherRows(torch.autograd.Function):
+    """Input rows of a feature-propagation MLP, straight from position-major operands:
+        rows[(b,i)] = [ sum_k w[b,i,k] * known_pm[b, idx[b,i,k], :]  |  skip_pm[b, i, :] ]        bf16 (B*n, C2 + C1)
+    (reference pointnet2_modules.py:395-409: three_interpolate, cat along channels).  `known_feats` / `skip_feats`
+    are the (B, C, .) tensors of the reference API -- they only carry the autograd edges; the arithmetic reads
+    their bf16 twins.  Gradients come back in the (B, C, .) layout as views of position-major data."""
+
+    @staticmethod
+    def forward(ctx, known_feats, known_pm, skip_feats, skip_pm, idx, weight):
+        B, n = idx.shape[0], idx.shape[1]
+        m, C2 = known_pm.shape[1], known_pm.shape[2]
+        C1 = 0 if skip_pm is None else skip_pm.shape[2]
+        rows = torch.empty((B * n, C2 + C1), device=idx.device, dtype=torch.bfloat16)
+        _call(_lib.omnipq_interp_rows, rows, B, n, m, C2, _p(known_pm), _p(idx), _p(weight), _p(rows), C2 + C1, 0)
+        if C1:
+            _call(_lib.omnipq_place_rows, rows, ctypes.c_longlong(B * n), C1, _p(skip_pm), _p(rows), C2 + C1, C2)
+        ctx.save_for_backward(idx, weight)
+        ctx.geom = (B, n, m, C2, C1, known_feats.dtype, None if skip_feats is None else skip_feats.dtype)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, weight = ctx.saved_tensors
+        B, n, m, C2, C1, kdt, sdt = ctx.geom
+        g = g.to(torch.bfloat16).contiguous()
+        d_known = d_skip = None
+        if ctx.needs_input_grad[0]:
+            dk = torch.zeros((B, m, C2), device=g.device, dtype=torch.float32)
+            _call(_lib.omnipq_interp_rows_grad, g, B, n, m, C2, _p(g), C2 + C1, 0, _p(idx), _p(weight), _p(dk))
+            d_known = dk.to(kdt).transpose(1, 2)
+        if C1 and ctx.needs_input_grad[2]:
+            d_skip = g.view(B, n, C2 + C1)[:, :, C2:].to(sdt).transpose(1, 2)
+        return d_known, None, d_skip, None, None, None

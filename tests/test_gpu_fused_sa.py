@@ -305,3 +305,52 @@ def test_rows_mlp_matches_f32_layers(cin, widths, n):
         assert rel_l2(a.weight.grad, b.weight.grad) < 1e-1 and rel_l2(a.bias.grad, b.bias.grad) < 1e-1
         assert rel_l2(a.running_mean, b.running_mean) < 1e-2 and rel_l2(a.running_var, b.running_var) < 1e-2
         assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+
+
+def test_feature_propagation_on_rows_matches_f32_composition(monkeypatch):
+    """SA -> SA -> FP chain: under bf16 autocast the FP module takes the position-major twins of the fused SA
+    outputs (interpolation + concatenation + MLP on rows, no (B, C, n) round trip) and must agree with the f32
+    composition of the reference ops, outputs and gradients, within the bf16 tolerances of the fused SA tests."""
+    import pointnet2_modules
+    import sa_fused
+
+    class Chain(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sa1 = pointnet2_modules.PointnetSAModuleVotes(npoint=256, radius=0.5, nsample=32, mlp=[0, 64, 64, 128],
+                                                               use_xyz=True, normalize_xyz=True)
+            self.sa2 = pointnet2_modules.PointnetSAModuleVotes(npoint=64, radius=1.0, nsample=16, mlp=[128, 128, 128, 256],
+                                                               use_xyz=True, normalize_xyz=True)
+            self.fp = pointnet2_modules.PointnetFPModule(mlp=[256 + 128, 256, 96])
+
+        def forward(self, xyz):
+            x1, f1, _ = self.sa1(xyz, None)
+            x2, f2, _ = self.sa2(x1, f1)
+            return self.fp(x1, x2, f1, f2)
+
+    nets = [load_procedural(Chain(), 3).to(dev()).train() for _ in range(3)]
+    xyz = (torch.rand(4, 2048, 3, generator=torch.Generator().manual_seed(5)) * 3).to(dev())
+    monkeypatch.setenv("OMNIPQ_SA", "composed")
+    want = nets[0](xyz)                                                  # f32 op-by-op: the yardstick
+    with torch.autocast("cuda", dtype=torch.bfloat16):                   # PyTorch's own bf16 path
+        amp = nets[2](xyz)
+    monkeypatch.delenv("OMNIPQ_SA")
+    calls = []
+    orig = sa_fused.FPGatherRows.apply
+    monkeypatch.setattr(sa_fused.FPGatherRows, "apply", staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        got = nets[1](xyz)
+    assert calls, "the rows path of the FP module did not run"
+    assert got.shape == want.shape
+
+    def ok(name, g_, a_, w_, floor):
+        e_got, e_amp = rel_l2(g_.float(), w_), rel_l2(a_.float(), w_)
+        assert e_got < max(floor, 2.0 * e_amp), (name, e_got, e_amp)
+
+    ok("output", got, amp, want, 3e-2)
+    g = torch.randn(want.shape, generator=torch.Generator().manual_seed(6)).to(dev())
+    a = torch.autograd.grad(got, list(nets[1].parameters()), g.to(got.dtype))
+    b = torch.autograd.grad(want, list(nets[0].parameters()), g)
+    c = torch.autograd.grad(amp, list(nets[2].parameters()), g.to(amp.dtype))
+    for (name, _), u, v, w in zip(nets[0].named_parameters(), a, b, c):
+        ok(name, u, w, v, 8e-2)
