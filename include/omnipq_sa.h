@@ -146,6 +146,10 @@ int omnipq_interp_rows(int b, int n, int m, int C, const void *feat, const int *
                        int ldo, int col0, void *stream);
 int omnipq_interp_rows_grad(int b, int n, int m, int C, const void *g, int ldg, int col0, const int *idx,
                             const float *weight, float *dfeat, void *stream);
+/* the same gradient without atomics: offsets (b, m+1) / order (b, 3n) = omnipq_sa_build_csr(b, m, n, 3, idx, ...);
+ * writes every entry of dfeat (no zeroing needed). */
+int omnipq_interp_rows_grad_csr(int b, int n, int m, int C, const void *g, int ldg, int col0, const int *offsets,
+                                const int *order, const float *weight, float *dfeat, void *stream);
 int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd, int col0, void *stream);
 
 /* out[0] += sum_i mean(tensor_i), i < nseg <= 72: the benchmark's stand-in loss in one launch over strided

@@ -1203,6 +1203,36 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(long long chunks,
   }
 }
 
+// The same gradient without atomics: with a CSR of "which (unknown point, neighbour slot) pairs read known point j"
+// (omnipq_sa_build_csr over idx seen as b x n lists of 3), every (known point, 8-channel piece) sums its own
+// bucket and WRITES dfeat -- each gradient row is read three times, nothing is zeroed, nothing contends.
+__global__ __launch_bounds__(256) void interp_rows_grad_csr_kernel(long long items, int n3, int m, int C,
+                                                                  const int *__restrict__ offsets,
+                                                                  const int *__restrict__ order,
+                                                                  const bf16_t *__restrict__ g, int ldg, int col0,
+                                                                  const float *__restrict__ w, float *__restrict__ dfeat) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bj = q / cpr;
+    const int c0 = (int)(q - bj * cpr) * 8;
+    const long long b = bj / m;
+    const int j = (int)(bj - b * m);
+    const int beg = offsets[b * (m + 1) + j], end = offsets[b * (m + 1) + j + 1];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = beg; t < end; ++t) {
+      const long long pos = b * n3 + order[b * n3 + t];         // (unknown point, slot) = pos / 3, pos % 3
+      const float wk = w[pos];
+      float gv[8];
+      unpack8(*reinterpret_cast<const uint4 *>(g + (size_t)(pos / 3) * ldg + col0 + c0), gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(wk, gv[e], acc[e]);
+    }
+    float *dst = dfeat + (size_t)bj * C + c0;
+    *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
 // copy of a bf16 row block into a column range of wider rows: dst[r][col0 + c] = src[r][c]
 __global__ __launch_bounds__(256) void place_rows_kernel(long long chunks, int C, const bf16_t *__restrict__ src,
                                                         bf16_t *__restrict__ dst, int ldd, int col0) {
@@ -1237,6 +1267,21 @@ extern "C" int omnipq_interp_rows_grad(int b, int n, int m, int C, const void *g
   if (!g || !idx || !weight || !dfeat) return OMNIPQ_EINVAL;
   interp_rows_grad_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const bf16_t *)g, ldg, col0,
                                                                            idx, weight, dfeat);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// offsets (b, m+1) / order (b, 3n) from omnipq_sa_build_csr(b, m, n, 3, idx, ...).  Writes every entry of dfeat.
+extern "C" int omnipq_interp_rows_grad_csr(int b, int n, int m, int C, const void *g, int ldg, int col0,
+                                           const int *offsets, const int *order, const float *weight, float *dfeat,
+                                           void *stream) {
+  if (b < 0 || n < 0 || m <= 0 || C <= 0 || (C % 8) || (ldg % 8) || (col0 % 8) || col0 < 0 || col0 + C > ldg)
+    return OMNIPQ_EINVAL;
+  const long long items = (long long)b * m * (C / 8);
+  if (items == 0) return OMNIPQ_OK;
+  if (!g || !offsets || !order || !weight || !dfeat) return OMNIPQ_EINVAL;
+  interp_rows_grad_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, 3 * n, m, C, offsets, order,
+                                                                              (const bf16_t *)g, ldg, col0, weight, dfeat);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -622,8 +622,14 @@ class FPGatherRows(torch.autograd.Function):
         g = g.to(torch.bfloat16).contiguous()
         d_known = d_skip = None
         if ctx.needs_input_grad[0]:
-            dk = torch.zeros((B, m, C2), device=g.device, dtype=torch.float32)
-            _call(_lib.omnipq_interp_rows_grad, g, B, n, m, C2, _p(g), C2 + C1, 0, _p(idx), _p(weight), _p(dk))
+            # bucket the (unknown point, slot) pairs by the known point they read, then sum bucket-wise: no atomics
+            dk = torch.empty((B, m, C2), device=g.device, dtype=torch.float32)
+            offsets = torch.empty((B, m + 1), device=g.device, dtype=torch.int32)
+            order = torch.empty((B, 3 * n), device=g.device, dtype=torch.int32)
+            scratch = torch.empty((B, m), device=g.device, dtype=torch.int32)
+            _call(_lib.omnipq_sa_build_csr, g, B, m, n, 3, _p(idx), _p(offsets), _p(order), _p(scratch))
+            _call(_lib.omnipq_interp_rows_grad_csr, g, B, n, m, C2, _p(g), C2 + C1, 0, _p(offsets), _p(order), _p(weight),
+                  _p(dk))
             d_known = dk.to(kdt).transpose(1, 2)
         if C1 and ctx.needs_input_grad[2]:
             d_skip = g.view(B, n, C2 + C1)[:, :, C2:].to(sdt).transpose(1, 2)
