@@ -50,12 +50,16 @@ class Pointnet2Backbone(nn.Module):
     # furthest_point_sample inside each SA layer (reference pointnet2_modules.py:233-236).
     _plan = None
     _side = None
+    _extra = None
+    # optional extra level of the plan: {"sa2": npoint} = also sample npoint of the sa2 centres (the model's
+    # FPSModule on the seeds, pq_transformer.py:211-212, is such a coordinate-only sampling)
+    plan_extra = None
 
     def __getstate__(self):
         # streams, events and the plan's index buffers are per-instance run-time state: copies and pickles of
         # the module (copy.deepcopy for an EMA teacher, torch.save of the whole model) start without them
         state = self.__dict__.copy()
-        for k in ("_plan", "_side", "_plan_bufs"):
+        for k in ("_plan", "_side", "_plan_bufs", "_extra"):
             state.pop(k, None)
         return state
 
@@ -85,7 +89,8 @@ class Pointnet2Backbone(nn.Module):
         side = self._side_stream(pointcloud.device)
         side.wait_stream(main)
         bufs = self._plan_buffers(pointcloud)
-        plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud, "trusted": trusted}
+        plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud, "trusted": trusted,
+                "extra": None}
         ext = pointnet2_utils._ext
         with torch.cuda.stream(side), torch.no_grad():
             xyz = pointcloud[..., 0:3].contiguous()
@@ -102,6 +107,18 @@ class Pointnet2Backbone(nn.Module):
                 if name != "sa4":
                     xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
                         .transpose(1, 2).contiguous()
+                if self.plan_extra and name in self.plan_extra:
+                    extra = self.__dict__.setdefault("_plan_bufs", {}).setdefault(
+                        ("extra", name, pointcloud.shape[0], str(pointcloud.device)),
+                        torch.zeros((pointcloud.shape[0], self.plan_extra[name]), device=pointcloud.device,
+                                    dtype=torch.int32))
+                    if hasattr(ext, "set_timing_sink"):
+                        e_inds = ext.furthest_point_sampling(xyz, self.plan_extra[name], out=extra)
+                    else:
+                        e_inds = ext.furthest_point_sampling(xyz, self.plan_extra[name])
+                    e_ev = torch.cuda.Event()
+                    e_ev.record(side)
+                    plan["extra"] = (name, e_inds, e_ev)
         return plan
 
     def prefetch(self, pointcloud, trusted=False):
@@ -116,6 +133,14 @@ class Pointnet2Backbone(nn.Module):
         """Make the current stream wait for everything queued on the sampling stream."""
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+
+    def take_extra(self, name):
+        """Indices of the plan's extra level `name` for the batch just run through forward(), or None."""
+        extra, self._extra = self._extra, None
+        if extra is None or extra[0] != name:
+            return None
+        torch.cuda.current_stream(extra[1].device).wait_event(extra[2])
+        return extra[1].clone()             # the plan's buffer is reused by the next plan
 
     def _take_plan(self, pointcloud):
         if not pointcloud.is_cuda or os.environ.get("OMNIPQ_SAMPLING_PLAN", "1") == "0":
@@ -137,6 +162,9 @@ class Pointnet2Backbone(nn.Module):
         xyz, features = self._break_up_pc(pointcloud)
         plan = self._take_plan(pointcloud)
 
+        self._extra = None
+        if plan is not None and plan["extra"] is not None:
+            self._extra = plan["extra"]
         for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
             inds = None
             if plan is not None:

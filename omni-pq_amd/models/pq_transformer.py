@@ -222,6 +222,8 @@ class PQ_Transformer(nn.Module):
         self.decoder_query_proj = nn.Conv1d(288, hidden_dim, kernel_size=1)
         self.quad_decoder_query_proj = nn.Conv1d(288, hidden_dim, kernel_size=1)
         self.fps_module = FPSModule(self.num_quad_proposal)
+        # the seeds are the sa2 centres (fp2_xyz): their sampling is coordinate-only, let the plan do it
+        self.backbone.plan_extra = {"sa2": self.num_quad_proposal}
         if self.sampling != 'vote':
             raise NotImplementedError
         self.vote = VotingModule(1, 288)
@@ -263,7 +265,7 @@ class PQ_Transformer(nn.Module):
         seed_features = end_points['fp2_features']
 
         # layout branch: FPS over the seeds
-        quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features)
+        quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features, self.backbone.take_extra("sa2"))
         end_points['aggregated_sample_xyz'] = quad_xyz
 
         # object branch: vote, normalise, aggregate

@@ -21,9 +21,11 @@ class FPSModule(nn.Module):
         super().__init__()
         self.num_proposal = num_proposal
 
-    def forward(self, xyz, features):
-        """xyz (B,K,3), features (B,C,K) -> (B,P,3), (B,C,P), inds (B,P) int32"""
-        inds = pointnet2_utils.furthest_point_sample(xyz, self.num_proposal)
+    def forward(self, xyz, features, inds=None):
+        """xyz (B,K,3), features (B,C,K) -> (B,P,3), (B,C,P), inds (B,P) int32.
+        inds (extension): the sampling already done elsewhere (the backbone's sampling plan), else computed here."""
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.num_proposal)
         flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
         new_features = pointnet2_utils.gather_operation(features, inds).contiguous()
