@@ -1,0 +1,228 @@
+"""GPU, world_size 2 on ONE device (gloo carries the collectives; RCCL refuses two ranks per GPU): the
+data-parallel semantics of the hand-written path on real kernels.
+
+Two processes each run one eager training step on their own scenes; the SyncBatchNorm statistics of the fused
+SA stages and the rows engine go through `sa_fused._allreduce_`.  That must equal ONE process running all
+scenes as one batch with the loss averaged over ranks: batch statistics over all scenes, gradients averaged.
+
+* exact part -- an SA -> SA chain and a conv/BN/ReLU rows stack: same tile partition on both sides, so the two
+  evaluations agree to f32 rounding (1e-4 relative demanded, 1e-7 measured);
+* model part -- backbone + voting + a decoder layer + the object head of the real PQ_Transformer under
+  DistributedDataParallel and under `bench.FlatGradients` (the captured step's one flat all-reduce).  Here
+  the two sides partition their sums differently (64 vs 128 row tiles per rank), the BatchNorm constants move
+  by ~1e-5, and a bf16 network of 30 ReLU / max-pool layers amplifies that: a 1e-6 nudge of ONE BatchNorm
+  weight moves the same gradients by 10-20 % (measured).  So: running statistics to 1e-3,
+  DDP == flat all-reduce to 2e-2, gradients against the single process by direction (cosine >= 0.97).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO  # noqa: F401  (sys.path set-up)
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _flat_grads(net):
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float()
+                      for p in net.parameters()])
+
+
+# ---------------------------------------------------------------------------------------------- exact part
+def _toy(which, dev):
+    import pointnet2_modules
+    import rows_mlp
+    from procedural import load_procedural
+
+    class Chain(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = pointnet2_modules.PointnetSAModuleVotes(npoint=256, radius=0.5, nsample=32, mlp=[0, 64, 64, 128],
+                                                             use_xyz=True, normalize_xyz=True)
+            self.b = pointnet2_modules.PointnetSAModuleVotes(npoint=64, radius=1.0, nsample=16,
+                                                             mlp=[128, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+
+        def forward(self, xyz):
+            x1, f1, _ = self.a(xyz, None)
+            return self.b(x1, f1)[1]
+
+    class Rows(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.b1 = torch.nn.Conv1d(3, 288, 1), torch.nn.BatchNorm1d(288)
+            self.c2, self.b2 = torch.nn.Conv1d(288, 288, 1), torch.nn.BatchNorm1d(288)
+            self.c3 = torch.nn.Conv1d(288, 64, 1)
+
+        def forward(self, xyz):
+            stack = [rows_mlp.Layer(self.c1.weight, self.c1.bias, self.b1), rows_mlp.Layer(self.c2.weight, self.c2.bias, self.b2),
+                     rows_mlp.Layer(self.c3.weight, self.c3.bias)]
+            return rows_mlp.run(xyz.reshape(-1, 3), stack, True).view(xyz.shape[0], xyz.shape[1], -1)
+
+    return load_procedural({"chain": Chain, "rows": Rows}[which](), 3).to(dev).train()
+
+
+def _exact_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    per = 2
+    xyz = (torch.rand(world * per, 2048, 3, generator=torch.Generator().manual_seed(5)) * 3).to(dev)
+    refs = {}
+    if rank == 0:                                  # single process, all scenes, before a process group exists
+        for which in ("chain", "rows"):
+            net = _toy(which, dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                f = net(xyz)
+            w = torch.randn(f.shape, generator=torch.Generator().manual_seed(9)).to(dev)
+            (f.float() * w).mean().backward()
+            refs[which] = (f.detach().float().cpu(), _flat_grads(net).cpu())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        worst = {}
+        for which in ("chain", "rows"):
+            net = _toy(which, dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                f = net(xyz[rank * per:(rank + 1) * per].contiguous())
+            wfull = torch.randn((world * per,) + tuple(f.shape[1:]), generator=torch.Generator().manual_seed(9)).to(dev)
+            (f.float() * wfull[rank * per:(rank + 1) * per]).mean().backward()
+            g = _flat_grads(net)
+            dist.all_reduce(g)
+            g = (g / world).cpu()
+            if rank == 0:
+                worst[which] = (_rel(f.detach().float().cpu(), refs[which][0][:per]), _rel(g, refs[which][1]))
+        if rank == 0:
+            torch.save(worst, os.path.join(out_dir, "exact.pt"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_syncbn_semantics_are_exact_on_matching_tile_partitions(tmp_path):
+    mp.spawn(_exact_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    worst = torch.load(tmp_path / "exact.pt")
+    for which, (fwd, grad) in worst.items():
+        assert fwd < 1e-4 and grad < 1e-4, (which, fwd, grad)
+
+
+# ---------------------------------------------------------------------------------------------- model part
+POINTS = 8192
+
+
+class Sub(torch.nn.Module):
+    """The parts of the model that are continuous in their inputs: backbone (4 fused SA stages + 2 FP modules)
+    -> voting module -> one decoder layer (queries = the first 512 seeds) -> the object prediction head.  Left out:
+    the vote aggregation, whose furthest-point sampling on LEARNED coordinates turns last-bit differences of
+    the votes into different samples (the model-level tests pin the votes for the same reason), and the quad
+    head, which divides its normals by their norm over the WHOLE batch (pq_transformer.py:119) -- a coupling
+    across scenes that is not data parallel in the reference either."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, inputs):
+        net = self.net
+        ep = net.backbone(inputs["point_clouds"], {})
+        xyz, feat = ep["fp2_xyz"], ep["fp2_features"]
+        vote_xyz, vote_feat = net.vote(xyz, feat)
+        from pq_transformer import conv1x1
+        query = conv1x1(feat[:, :, :512].contiguous(), net.decoder_query_proj)
+        key = conv1x1(feat, net.decoder_key_proj)
+        out = net.decoder[0](query, key, xyz[:, :512].contiguous(), xyz)
+        ends = {}
+        _, _, ends = net.prediction_heads[0](out[:, :, :256], base_xyz=xyz[:, :256], end_points=ends, prefix="o_")
+        ends.update(vote_xyz=vote_xyz, vote_feat=vote_feat, dec=out, seed=feat)
+        return ends
+
+
+def _build(dev):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    torch.manual_seed(7)
+    net = Sub(bench.build_model(0)).to(dev).train()
+    for m in net.modules():                       # dropout off: the two evaluations must see the same function
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+            m.dropout = 0.0
+    return net
+
+
+def _loss(ep):
+    keys = sorted(k for k, v in ep.items() if torch.is_tensor(v) and v.is_floating_point() and v.requires_grad)
+    return sum(ep[k].float().mean() for k in keys)
+
+
+def _model_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401
+    import synth
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    scenes = synth.make_clouds(21, world, POINTS, kind="room").to(dev)
+
+    def running(net):
+        return torch.cat([b.reshape(-1).float() for n, b in net.named_buffers() if "running" in n]).cpu()
+
+    if rank == 0:                                  # the yardstick: one process, both scenes
+        net = _build(dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ep = net({"point_clouds": scenes})
+        _loss(ep).backward()          # mean over a batch of two == (mean_0 + mean_1) / 2 for every end_point
+        ref, ref_stats = _flat_grads(net).cpu(), running(net)
+        del net, ep
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = _build(dev)
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False,
+                                                        find_unused_parameters=True)    # Sub leaves layers out
+        mine = scenes[rank:rank + 1].contiguous()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ep = ddp({"point_clouds": mine})
+        _loss(ep).backward()
+        got, stats = _flat_grads(net).cpu(), running(net)
+
+        sys.path.insert(0, os.path.dirname(HERE))
+        import bench
+        plain = _build(dev)                        # the captured step's data parallelism: one flat all-reduce
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ep2 = plain({"point_clouds": mine})
+        _loss(ep2).backward()
+        bench.FlatGradients(plain, world).reduce()
+        got_flat = _flat_grads(plain).cpu()
+        if rank == 0:
+            cos = float((got.double() * ref.double()).sum() / (got.double().norm() * ref.double().norm()))
+            res = {"cosine_vs_single": cos, "rel_vs_single": _rel(got, ref), "flat_vs_ddp": _rel(got_flat, got),
+                   "stats": _rel(stats, ref_stats)}
+            print("two-rank result", res, flush=True)
+            torch.save(res, os.path.join(out_dir, "result.pt"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_track_one_process_with_both_scenes(tmp_path):
+    mp.spawn(_model_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = torch.load(tmp_path / "result.pt")
+    assert res["stats"] < 1e-3, res
+    assert res["flat_vs_ddp"] < 2e-2, res
+    assert res["cosine_vs_single"] > 0.97, res
