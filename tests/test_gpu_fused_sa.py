@@ -354,3 +354,51 @@ def test_feature_propagation_on_rows_matches_f32_composition(monkeypatch):
     c = torch.autograd.grad(amp, list(nets[2].parameters()), g.to(amp.dtype))
     for (name, _), u, v, w in zip(nets[0].named_parameters(), a, b, c):
         ok(name, u, w, v, 8e-2)
+
+
+@pytest.mark.parametrize("B,n,m,C,extra", [(2, 300, 70, 64, 0), (3, 1024, 512, 512, 256), (1, 5, 3, 8, 8)])
+def test_interp_rows_kernels_match_torch(B, n, m, C, extra):
+    """Feature propagation on rows: interpolation into a column range, both gradient kernels (atomics / CSR of
+    readers), the column placement and the column sums, against plain PyTorch on the same bf16 operands."""
+    gen = torch.Generator().manual_seed(B + n + m + C)
+    feat = torch.randn(B, m, C, generator=gen).to(torch.bfloat16).to(dev())
+    idx = torch.randint(0, m, (B, n, 3), generator=gen).to(torch.int32).to(dev())
+    w = torch.rand(B, n, 3, generator=gen)
+    w = (w / w.sum(-1, keepdim=True)).to(dev())
+    ld = C + extra
+    rows = torch.zeros(B * n, ld, device=dev(), dtype=torch.bfloat16)
+    capi.ok("omnipq_interp_rows", B, n, m, C, capi.P(feat), capi.P(idx), capi.P(w), capi.P(rows), ld, 0)
+    gathered = torch.stack([feat[b][idx[b].long()] for b in range(B)]).float()          # (B, n, 3, C)
+    want = (gathered * w.unsqueeze(-1)).sum(2).reshape(B * n, C)
+    assert float((rows[:, :C].float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6
+    if extra:
+        skip = torch.randn(B * n, extra, generator=gen).to(torch.bfloat16).to(dev())
+        capi.ok("omnipq_place_rows", ctypes.c_longlong(B * n), extra, capi.P(skip), capi.P(rows), ld, C)
+        assert torch.equal(rows[:, C:], skip)
+        assert float((rows[:, :C].float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6
+    # gradient: dfeat[b][j] = sum over (i, k) with idx[b,i,k] == j of w[b,i,k] * g[(b,i)]
+    g = torch.randn(B * n, ld, generator=gen).to(torch.bfloat16).to(dev())
+    ref = torch.zeros(B, m, C, device=dev())
+    for b in range(B):
+        contrib = (g[b * n:(b + 1) * n, :C].float().unsqueeze(1) * w[b].unsqueeze(-1)).reshape(n * 3, C)
+        ref[b].index_add_(0, idx[b].reshape(-1).long(), contrib)
+    d1 = torch.zeros(B, m, C, device=dev())
+    capi.ok("omnipq_interp_rows_grad", B, n, m, C, capi.P(g), ld, 0, capi.P(idx), capi.P(w), capi.P(d1))
+    offsets = torch.empty(B, m + 1, device=dev(), dtype=torch.int32)
+    order = torch.empty(B, 3 * n, device=dev(), dtype=torch.int32)
+    scratch = torch.empty(B, m, device=dev(), dtype=torch.int32)
+    capi.ok("omnipq_sa_build_csr", B, m, n, 3, capi.P(idx), capi.P(offsets), capi.P(order), capi.P(scratch))
+    d2 = torch.full((B, m, C), float("nan"), device=dev())
+    capi.ok("omnipq_interp_rows_grad_csr", B, n, m, C, capi.P(g), ld, 0, capi.P(offsets), capi.P(order), capi.P(w),
+            capi.P(d2))
+    for d in (d1, d2):
+        assert torch.isfinite(d).all()
+        assert rel_l2(d, ref) < 1e-5
+    # column sums (bias gradients), both accumulator types; they ADD to what is there
+    s64 = torch.ones(ld, device=dev(), dtype=torch.float64)
+    s32 = torch.ones(ld, device=dev())
+    capi.ok("omnipq_colsum", ctypes.c_longlong(B * n), ld, capi.P(g), capi.P(s64))
+    capi.ok("omnipq_colsum_f32", ctypes.c_longlong(B * n), ld, capi.P(g), capi.P(s32))
+    tot = g.double().sum(0) + 1.0
+    assert float((s64 - tot).abs().max()) < 1e-4 * (1 + float(tot.abs().max()))
+    assert float((s32.double() - tot).abs().max()) < 1e-3 * (1 + float(tot.abs().max()))
