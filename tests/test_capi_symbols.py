@@ -27,3 +27,47 @@ def test_host_helpers_without_gpu(built_lib):
                                    40000, 50000, 80000, 1 << 20]:
         assert lib.omnipq_opt_n_threads(n) == oracle_ext.opt_n_threads(n), n
     assert lib.omnipq_opt_n_threads(40000) == 512 and lib.omnipq_opt_n_threads(100) == 64
+
+
+def test_argument_validation_needs_no_gpu(built_lib):
+    """Every entry point rejects malformed arguments with OMNIPQ_EINVAL / OMNIPQ_ETOOLARGE BEFORE it touches the
+    device (the reference's wrappers `exit(-1)` from inside the launch, cuda_utils.h:35-44).  Pointers below
+    are never dereferenced: validation comes first."""
+    lib = capi.lib()
+    EINVAL, ETOOLARGE = 10001, 10002
+    p = ctypes.c_void_p(0x1000)                       # "some non-null pointer"
+    null = ctypes.c_void_p(0)
+    f = ctypes.c_float
+    ll = ctypes.c_longlong
+    strides = (ll * 8)(288, 2304, 288, 2304, 288, 2304, 288, 2304)
+    # attention: head dim not a multiple of 4 / too wide, dropout outside [0, 1), problem beyond 32-bit indexing
+    assert lib.omnipq_attn_fwd(8, 8, 256, 256, 37, p, p, p, p, strides, p, f(0.0), null, 0, null) == EINVAL
+    assert lib.omnipq_attn_fwd(8, 8, 256, 256, 52, p, p, p, p, strides, p, f(0.0), null, 0, null) == EINVAL
+    assert lib.omnipq_attn_fwd(8, 8, 256, 256, 36, p, p, p, p, strides, p, f(1.0), p, 0, null) == EINVAL
+    assert lib.omnipq_attn_fwd(8, 8, 256, 256, 36, p, p, p, p, strides, p, f(0.1), null, 0, null) == EINVAL   # no seed
+    assert lib.omnipq_attn_fwd(64, 16, 4096, 4096, 36, p, p, p, p, strides, p, f(0.0), null, 0, null) == ETOOLARGE
+    # GEMMs: contraction length must be a multiple of the K step, leading dimensions of 8
+    assert lib.omnipq_gemm_nt_bf16(128, 128, 33, p, 40, p, 40, p, 128, null) == EINVAL
+    assert lib.omnipq_gemm_nt_bf16_stats(128, 128, 32, p, 32, p, 32, p, 128, null, null, null, null) == EINVAL  # no sums
+    assert lib.omnipq_gemm_tn_bf16(100, 128, 64, p, 100, p, 128, p, p, null) == EINVAL                          # M % 8
+    lib.omnipq_gemm_nt_stats_workspace_floats.restype = ll
+    assert lib.omnipq_gemm_nt_stats_workspace_floats(64 * 128, 256) == 0
+    assert lib.omnipq_gemm_nt_stats_workspace_floats(64 * 128 + 1, 256) == 65 * 2 * 256
+    # row kernels
+    assert lib.omnipq_add_dropout_layernorm(ll(10), 290, p, p, p, p, f(1e-5), f(0.0), null, 0, p, p, null, null, p, p,
+                                            null) == EINVAL                                                   # C % 4
+    assert lib.omnipq_add_dropout_layernorm(ll(10), 288, p, p, p, p, f(1e-5), f(0.0), null, 0, p, p, p, null, p, p,
+                                            null) == EINVAL                                     # pe without its output
+    assert lib.omnipq_relu_dropout(ll(10), p, f(0.0), null, 0, null) == EINVAL                                 # n % 4
+    assert lib.omnipq_interp_rows(2, 10, 5, 64, p, p, p, p, 64, 8, null) == EINVAL             # columns do not fit
+    assert lib.omnipq_place_rows(ll(10), 64, p, p, 100, 0, null) == EINVAL                               # pitch % 8
+    assert lib.omnipq_colsum_f32(ll(10), 12, p, p, null) == EINVAL
+    # loss helper: more views than the kernel-argument table holds
+    ptrs = (ctypes.c_void_p * 73)(*([0x1000] * 73))
+    ones = (ctypes.c_int * (73 * 4))(*([1] * 73 * 4))
+    flags = (ctypes.c_int * 73)()
+    assert lib.omnipq_sum_of_means(73, ptrs, ones, ones, flags, p, null) == EINVAL
+    # zero-sized problems are no-ops that succeed without a device
+    assert lib.omnipq_gemm_nt_bf16(0, 128, 32, p, 32, p, 32, p, 128, null) == 0
+    assert lib.omnipq_interp_rows(0, 10, 5, 64, p, p, p, p, 64, 0, null) == 0
+    assert lib.omnipq_relu_dropout(ll(0), p, f(0.0), null, 0, null) == 0
