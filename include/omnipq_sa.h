@@ -49,6 +49,9 @@ int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int lda, const 
 long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                         float *workspace, void *stream);
+/* the same, and colsum[m] += sum_p A[p][m] (f32): weight AND bias gradient of a linear layer from one pass */
+int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
+                               float *workspace, float *colsum, void *stream);
 
 /* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares
  * of the bf16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of

@@ -35,9 +35,12 @@ struct TnArgs {
   int m_tiles, n_tiles;
 };
 
+// colsum (may be NULL): float[M], receives (ADDED, f32 atomics) the column sums of A over all positions --
+// the bias gradient that goes with a weight gradient dW = dY^T X, taken from the A tiles the kernel stages
+// anyway (workgroups of the first N-tile only), instead of a separate pass over dY.
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
-                                                        float *__restrict__ part) {
+                                                        float *__restrict__ part, float *__restrict__ colsum) {
   constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 17408 bf16 = 34 KB
   constexpr int CT_BYTES = 128 * TCPITCH * 4;                  // 66 KB
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES];
@@ -86,7 +89,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
   // Unconditional 16-byte loads from clamped addresses, then an AND mask for positions past the slab
   // (those must contribute zero to the contraction).  A ?: against zero would be split by hipcc into
   // predicated dword loads.  Channel pieces past M / N only feed C entries that are never stored.
+  const bool do_colsum = colsum != nullptr && nt == 0;
   uint4 ra[2], rb[2];
+  float csum[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[i][e] = 0.f;
   int acol[2], bcol[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -103,6 +112,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
       rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)pc * g.ldb + bcol[i]);
       ra[i].x &= keep; ra[i].y &= keep; ra[i].z &= keep; ra[i].w &= keep;
       rb[i].x &= keep; rb[i].y &= keep; rb[i].z &= keep; rb[i].w &= keep;
+      if (do_colsum) {
+        const unsigned w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          csum[i][2 * e] += __builtin_bit_cast(float, w[e] << 16);
+          csum[i][2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        }
+      }
     }
   };
   auto store_tiles = [&](int buf) {
@@ -158,6 +175,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
     __syncthreads();
   }
 
+  if (do_colsum) {
+    // thread (row group tid >> 4, piece tid & 15) holds the sums of its positions for 8 channels (both chunks cover
+    // the same piece): fold the 16 row groups through LDS, one atomic per channel
+    float *red = reinterpret_cast<float *>(smem);            // [16][128]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = csum[0][e] + csum[1][e];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < g.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+      atomicAdd(colsum + m0 + tid, t);
+    }
+    __syncthreads();
+  }
   float *ct = reinterpret_cast<float *>(smem);
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
 #pragma unroll
@@ -227,8 +260,24 @@ extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
   return (long long)(slabs + kReduceGroups) * M * N;
 }
 
+static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
+                        float *workspace, float *colsum, void *stream);
+
 extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                    float *C, float *workspace, void *stream) {
+  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, nullptr, stream);
+}
+
+// The same, and colsum[m] += sum_p A[p][m] (f32, zero or a running total on entry): weight and bias gradient
+// of a linear layer from one pass over dY.
+extern "C" int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
+                                          float *C, float *workspace, float *colsum, void *stream) {
+  if (!colsum) return OMNIPQ_EINVAL;
+  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, stream);
+}
+
+static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
+                        float *workspace, float *colsum, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || P < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -239,7 +288,7 @@ extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, 
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
   const int used = P > 0 ? (P + g.p_chunk - 1) / g.p_chunk : 1;
   dim3 grid(tiles * ((used + 7) / 8) * 8);
-  gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace);
+  gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace, colsum);
   OMNIPQ_LAUNCH_CHECK();
   const int n4 = M * N / 4;        // M, N multiples of 8
   const f32x4 *part = reinterpret_cast<const f32x4 *>(workspace);

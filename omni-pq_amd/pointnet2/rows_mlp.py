@@ -196,11 +196,11 @@ class RowsMLP(torch.autograd.Function):
                 _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur), _p(dst),
                       ctypes.c_float(lay.act[1]))
                 dcur, owned = dst, True
+            bsum = None
             if not lay.has_bn and lay.has_bias:
-                bsum = zeros_f32(lay.Cp, dev)
-                _call(_lib.omnipq_colsum_f32, dcur, ctypes.c_longlong(N), lay.Cp, _p(dcur), _p(bsum))
+                bsum = zeros_f32(lay.Cp, dev)                # bias gradient: column sums of dY, from the same pass
                 grads[4 * l + 1] = bsum[:lay.C]
-            dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N)
+            dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum)
             grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None
             if l > 0 and layers[l - 1].has_bn:

@@ -129,11 +129,14 @@ def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     return C
 
 
-def _gemm_tn(A, B, M, N, P):
-    """f32 C[M][N] = A[P][M]^T B[P][N]"""
+def _gemm_tn(A, B, M, N, P, colsum=None):
+    """f32 C[M][N] = A[P][M]^T B[P][N]; colsum (f32 [M], zero on entry): also += column sums of A"""
     C = torch.empty((M, N), device=A.device, dtype=torch.float32)
     ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=A.device, dtype=torch.float32)
-    _call(_lib.omnipq_gemm_tn_bf16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
+    if colsum is None:
+        _call(_lib.omnipq_gemm_tn_bf16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
+    else:
+        _call(_lib.omnipq_gemm_tn_bf16_colsum, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws), _p(colsum))
     return C
 
 

@@ -111,6 +111,13 @@ def test_gemm_tn_matches_torch(P, M, N):
     capi.ok("omnipq_gemm_tn_bf16", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C), capi.P(ws))
     want = A.float().t() @ B.float()
     assert rel_l2(C, want) < 1e-5          # exact bf16 products, f32 accumulation: only summation order differs
+    # the variant that also returns the column sums of A (bias gradient), added to what is there
+    C2 = torch.full((M, N), float("nan"), device=dev())
+    cs = torch.ones(M, device=dev())
+    capi.ok("omnipq_gemm_tn_bf16_colsum", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C2), capi.P(ws), capi.P(cs))
+    assert rel_l2(C2, want) < 1e-5
+    tot = A.double().sum(0) + 1.0
+    assert float((cs.double() - tot).abs().max()) < 1e-4 * (1 + float(tot.abs().max()))
 
 
 def _sa_pair(spec, seed):
