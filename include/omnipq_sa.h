@@ -44,6 +44,12 @@ int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void 
 /* C = A B^T + bias[n] (f32 bias added before the bf16 rounding) */
 int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                              int ldc, const float *bias, void *stream);
+/* C = A B^T + bias (bias may be NULL) with a workspace of omnipq_gemm_nt_workspace_floats(M, N, K) floats (0 for
+ * most shapes): long contractions over few tiles (K >= 1024, <= 128 tiles) are split over several workgroups per
+ * tile and combined in f32 before the single rounding to bf16.  Requires ldc == N when it splits. */
+long long omnipq_gemm_nt_workspace_floats(int M, int N, int K);
+int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+                           const float *bias, float *workspace, void *stream);
 
 /* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
 long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);

@@ -314,7 +314,64 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int n, int slabs, co
   out[i] = s;
 }
 
+// split-K epilogue for bf16 outputs: out[i] = bf16(sum_z part[z][i] + bias[i % N]), 4 elements per lane
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(long long n4, int N, int slabs,
+                                                                const f32x4 *__restrict__ part,
+                                                                const float *__restrict__ bias,
+                                                                bf16_t *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = part[i];
+  for (int z = 1; z < slabs; ++z) s += part[(size_t)z * n4 + i];
+  if (bias) {
+    const int c = (int)((i * 4) % N);                       // N % 4 == 0: the four lanes share a row
+    s[0] += bias[c], s[1] += bias[c + 1], s[2] += bias[c + 2], s[3] += bias[c + 3];
+  }
+  uint2 w;
+  w.x = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[0]) |
+        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[1]) << 16);
+  w.y = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[2]) |
+        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[3]) << 16);
+  *reinterpret_cast<uint2 *>(out + i * 4) = w;
+}
+
 }  // namespace omnipq
+
+// Long contractions over few tiles (the decoder's 2048-wide feed-forward: 96 tiles, 64 K-steps each) are
+// latency bound: split K over `slabs` workgroups per tile into f32 partials (workspace: slabs * M * N floats),
+// then one pass sums them, adds the bias and rounds to bf16.
+static int gemm_nt_splitk_slabs(int M, int N, int K) {
+  const int tiles = ((M + omnipq::GBM - 1) / omnipq::GBM) * ((N + omnipq::GBN - 1) / omnipq::GBN);
+  if (K < 1024 || tiles > 128) return 1;
+  int slabs = 512 / tiles;
+  if (slabs > K / 256) slabs = K / 256;                      // >= 8 K-steps per slab
+  if (slabs > 8) slabs = 8;
+  return slabs < 2 ? 1 : slabs;
+}
+
+extern "C" long long omnipq_gemm_nt_workspace_floats(int M, int N, int K) {
+  const int slabs = gemm_nt_splitk_slabs(M, N, K);
+  return slabs > 1 ? (long long)slabs * M * N : 0;
+}
+
+static int gemm_nt_splitk_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+                               const float *bias, float *workspace, int slabs, void *stream) {
+  using namespace omnipq;
+  if (ldc != N || (N % 4)) return OMNIPQ_EINVAL;
+  int k_chunk = ((K / GBK + slabs - 1) / slabs) * GBK;
+  const int used = (K + k_chunk - 1) / k_chunk;
+  GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, used);
+  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
+                                                           nullptr);
+  OMNIPQ_LAUNCH_CHECK();
+  const long long n4 = (long long)M * N / 4;
+  splitk_reduce_bf16_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      n4, N, used, reinterpret_cast<const f32x4 *>(workspace), bias, (bf16_t *)C);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
 
 // C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.
 extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
@@ -415,6 +472,26 @@ extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int 
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// C = A B^T + bias (bias may be NULL) with an optional workspace of omnipq_gemm_nt_workspace_floats(M, N, K)
+// floats: when that is non-zero and the workspace is given, the contraction is split over several workgroups
+// per tile (same result up to f32 summation order, one rounding to bf16 at the end).
+extern "C" int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+                                      int ldc, const float *bias, float *workspace, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  const int slabs = gemm_nt_splitk_slabs(M, N, K);
+  if (slabs > 1 && workspace && ldc == N)
+    return gemm_nt_splitk_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, workspace, slabs, stream);
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);

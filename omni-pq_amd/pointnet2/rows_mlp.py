@@ -114,9 +114,9 @@ class RowsMLP(torch.autograd.Function):
                 bp = bias.detach().float()
                 if lay.Cp != cout:
                     bp = torch.nn.functional.pad(bp, (0, lay.Cp - cout))
-                _call(_lib.omnipq_gemm_nt_bf16_bias, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp, _p(bp))
+                sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K, bias=bp)
             else:
-                _call(_lib.omnipq_gemm_nt_bf16, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp)
+                sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K)
             lay.Y = Y
             if lay.has_bn:
                 rm, rv, nbt, momentum, eps = spec[l]
@@ -209,8 +209,7 @@ class RowsMLP(torch.autograd.Function):
                 dcur, owned = dprev, True
             elif l > 0 or ctx.needs_input_grad[0]:
                 dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
-                _call(_lib.omnipq_gemm_nt_bf16, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
-                      _p(dprev), lay.K)
+                sa_fused.gemm_nt_into(dcur, lay.Wt, dprev, N, lay.K, lay.Cp)
                 if l > 0:
                     dcur, owned = dprev, True
                 else:

@@ -28,6 +28,7 @@ _ext = pointnet2_utils._load_ext()      # always the product binding, whatever p
 _lib = _ext._lib
 _lib.omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
 _lib.omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
+_lib.omnipq_gemm_nt_workspace_floats.restype = ctypes.c_longlong
 
 
 def _p(t):
@@ -107,6 +108,14 @@ def _gemm_nt(A, B, M, N, K):
     C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
     _call(_lib.omnipq_gemm_nt_bf16, A, M, N, K, _p(A), K, _p(B), K, _p(C), N)
     return C
+
+
+def gemm_nt_into(A, B, C, M, N, K, bias=None):
+    """C (bf16 [M][N], preallocated) = A[M][K] B[N][K]^T (+ bias); long contractions over few tiles get a
+    split-K workspace."""
+    n_ws = int(_lib.omnipq_gemm_nt_workspace_floats(M, N, K))
+    ws = torch.empty((n_ws,), device=A.device, dtype=torch.float32) if n_ws else None
+    _call(_lib.omnipq_gemm_nt_bf16_ws, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(ws))
 
 
 def _gemm_nt_stats(A, B, M, N, K, sums, bias=None):

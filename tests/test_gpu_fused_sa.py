@@ -43,6 +43,28 @@ def test_gemm_nt_matches_torch(M, N, K):
     assert rel_l2(C.float(), want) < 3e-3
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(4096, 288, 2048, True), (2048, 288, 1024, False), (300, 96, 4096, True),
+                                        (4096, 2048, 288, True)])
+def test_gemm_nt_split_k_matches_single_pass(M, N, K, bias):
+    """Long contractions over few tiles are split over K; the result equals the single-pass kernel up to the bf16
+    rounding of sums taken in a different f32 order."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+    B = (torch.randn((N, K), generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev())
+    bvec = torch.randn(N, generator=gen).to(dev()) if bias else None
+    capi.lib().omnipq_gemm_nt_workspace_floats.restype = ctypes.c_longlong
+    n_ws = int(capi.lib().omnipq_gemm_nt_workspace_floats(M, N, K))
+    assert (n_ws > 0) == (K >= 1024)
+    ws = torch.empty(max(n_ws, 1), device=dev())
+    C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    capi.ok("omnipq_gemm_nt_bf16_ws", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N,
+            capi.P(bvec) if bias else ctypes.c_void_p(0), capi.P(ws))
+    want = A.float() @ B.float().t() + (bvec if bias else 0.0)
+    assert torch.isfinite(C.float()).all()
+    assert float((C.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    assert rel_l2(C.float(), want) < 3e-3
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(100, 128, 32, False), (2048, 288, 288, False), (8192, 64, 64, True),
                                         (8193, 128, 128, False), (40000, 256, 32, False), (300, 544, 96, True)])
 def test_gemm_nt_stats_epilogue(M, N, K, bias):
