@@ -458,7 +458,11 @@ __global__ void sums_to_f32_kernel(int C, const double *__restrict__ sums, float
   }
 }
 
-__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, int m, int s, int C,
+// One lane per (ball, 8 channels): the ball's gradient / argmax / pooled value and the channel constants are
+// loaded ONCE, then the lane streams the ball's s rows (the position-major layout keeps them adjacent).  The
+// per-position form re-read those per-ball vectors s times from L2 and ran at 2.5 TB/s; this one is bound by
+// the Y read + dY write alone.
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, int m, int s, int C,
                                                             const bf16_t *__restrict__ Y,
                                                             const float *__restrict__ a,
                                                             const float *__restrict__ mean,
@@ -469,29 +473,39 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long chunks, i
                                                             const unsigned char *__restrict__ arg,
                                                             bf16_t *__restrict__ dY) {
   const int cpr = C >> 3;
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
-    const long long p = q / cpr;
-    const int c0 = (int)(q - p * cpr) * 8;
-    const long long bm = p / s;
-    const int t = (int)(p - bm * s);
-    float y[8], o[8], av[8], mu[8], is[8], gg[8], Sv[8], Tv[8];
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bm = q / cpr;
+    const int c0 = (int)(q - bm * cpr) * 8;
+    float o[8], av[8], mu[8], is[8], gg[8], Sv[8], Tv[8];
     load8f(st + c0, Sv);
     load8f(st + C + c0, Tv);
     load8f(g_out + (size_t)bm * C + c0, gg);
-    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
     unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + c0), o);
     load8f(a + c0, av);
     load8f(mean + c0, mu);
     load8f(invstd + c0, is);
     const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(arg + (size_t)bm * C + c0);
+    int hit_t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const bool hit = (int)((packed >> (8 * e)) & 0xFF) == t && o[e] > 0.f;
-      const float dz = hit ? gg[e] : 0.f;
-      const float yhat = (y[e] - mu[e]) * is[e];
-      y[e] = av[e] * (dz - Sv[e] - yhat * Tv[e]);
+      hit_t[e] = o[e] > 0.f ? (int)((packed >> (8 * e)) & 0xFF) : -1;      // the sample that receives the gradient
+      Sv[e] *= av[e];                                                        // a * S/P
+      Tv[e] *= av[e] * is[e];                                                // a * invstd * T/P
+      gg[e] *= av[e];
     }
-    *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
+    const bf16_t *src = Y + ((size_t)bm * s) * C + c0;
+    bf16_t *dst = dY + ((size_t)bm * s) * C + c0;
+    for (int t = 0; t < s; ++t) {
+      float y[8];
+      unpack8(*reinterpret_cast<const uint4 *>(src + (size_t)t * C), y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // a (dz - S/P - yhat T/P) with yhat = (y - mean) invstd
+        const float dz = hit_t[e] == t ? gg[e] : 0.f;
+        y[e] = dz - Sv[e] - (y[e] - mu[e]) * Tv[e];
+      }
+      *reinterpret_cast<uint4 *>(dst + (size_t)t * C) = pack8(y);
+    }
   }
 }
 
@@ -832,8 +846,9 @@ extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total
   if (!Y || !a || !mean || !invstd || !sums || !g_out || !out_pm || !arg || !dY) return OMNIPQ_EINVAL;
   float *st = means_scratch(sums, C);
   bwd_means_kernel<<<(2 * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(2 * C, 1.0 / total_positions, sums, st);
-  pool_bwd_apply_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, m, s, C, (const bf16_t *)Y, a, mean, invstd, st, g_out, (const bf16_t *)out_pm, arg, (bf16_t *)dY);
+  const long long items = chunks / s;                   // (ball, 8-channel piece)
+  pool_bwd_apply_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
+      items, m, s, C, (const bf16_t *)Y, a, mean, invstd, st, g_out, (const bf16_t *)out_pm, arg, (bf16_t *)dY);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
