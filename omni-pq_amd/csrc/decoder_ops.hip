@@ -5,6 +5,8 @@
 // (8 for bf16) per lane along the row.  The parameter gradients (dgamma, dbeta) are accumulated per lane
 // over all rows a wave visits, folded across the block's waves in LDS and added with one atomic per
 // channel per block.
+#include <stdlib.h>
+
 #include "common.h"
 #include "omnipq_decoder.h"
 
@@ -351,7 +353,8 @@ extern "C" int omnipq_add_dropout_layernorm_bwd(long long R, int C, const float 
   const int rc = drop_params(y ? dropout_p : 0.f, seed_ptr, &g.thresh, &g.keep_inv);
   if (rc) return rc;
   long long blocks = (R + 3) / 4;
-  if (blocks > 256) blocks = 256;                       // each block ends with 2C atomics: keep them few
+  static const long long cap = getenv("OMNIPQ_LN_BLOCKS") ? atoll(getenv("OMNIPQ_LN_BLOCKS")) : 512;
+  if (blocks > cap) blocks = cap;                       // each block ends with 2C atomics; 512 blocks measured best (parallelism vs atomics)
   ln_bwd_kernel<<<(int)blocks, 256, sizeof(float) * 8 * C, (hipStream_t)stream>>>(
       g, x, (const bf16_t *)y, gamma, mean, rstd, g32, (const bf16_t *)g16, (const bf16_t *)g16_pe, dx, (bf16_t *)dy,
       dgamma_dbeta);
