@@ -223,29 +223,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
 #pragma unroll
     for (int j = 0; j < 3; ++j) st = MFMA(kf[j], qf[j], st);      // S^T: rows = keys, cols = queries
     float p[16], bm = -1e30f;
+    const bool full = k0 + 32 <= g.S;                       // wave-uniform: no key of this block is out of range
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool ok = k0 + acc_row(r, h) < g.S;
-      p[r] = ok ? st[r] * g.scale_log2 : -1e30f;
-      bm = fmaxf(bm, p[r]);
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, st[r]);   // the scale is positive: max first, scale once
+      bm *= g.scale_log2;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = k0 + acc_row(r, h) < g.S;
+        p[r] = ok ? st[r] * g.scale_log2 : -1e30f;
+        bm = fmaxf(bm, p[r]);
+      }
     }
     bm = fmaxf(bm, xor32(bm));
     const float m_new = fmaxf(m, bm);
     const float alpha = fast_exp2(m - m_new);
     float rs = 0.f;
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool ok = k0 + acc_row(r, h) < g.S;
-      p[r] = ok ? fast_exp2(p[r] - m_new) : 0.f;
-      rs += p[r];
+      for (int r = 0; r < 16; ++r) {
+        p[r] = fast_exp2(__builtin_fmaf(st[r], g.scale_log2, -m_new));
+        rs += p[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = k0 + acc_row(r, h) < g.S;
+        p[r] = ok ? fast_exp2(p[r] - m_new) : 0.f;
+        rs += p[r];
+      }
     }
     rs += xor32(rs);
     lsum = lsum * alpha + rs;
+    // rescale the running output only when some query of the wave saw a new maximum (after the first blocks
+    // that is rare; the 32 multiplies and the accumulator round trip are a tenth of the loop)
+    if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+    }
     m = m_new;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
     if (g.drop_thresh) {
       const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
 #pragma unroll
@@ -368,10 +387,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
     }
     float ds[16];
     const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
+    const bool full = q0 + 32 <= g.L && k0 + 32 <= g.S;    // wave-uniform: nothing of this tile is out of range
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool ok = qv && k0 + acc_row(r, h) < g.S;
-      const float p = ok ? fast_exp2(st[r] * g.scale_log2 - lse) : 0.f;
+      float p = fast_exp2(__builtin_fmaf(st[r], g.scale_log2, -lse));
+      if (!full) p = (qv && k0 + acc_row(r, h) < g.S) ? p : 0.f;
       float d = dp[r];
       if (g.drop_thresh) d = drop_hash(base + (unsigned)acc_row(r, h), seed) >= g.drop_thresh ? d * g.keep_inv : 0.f;
       ds[r] = p * (d - dl);
@@ -492,11 +512,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
       dp = MFMA(frag_lds_tok(dos, kl, j, h, g.D), vf[j], dp);     // dO V^T
     }
     float pt[16], ds[16];
+    const bool full = q0 + 32 <= g.L && k0 + 32 <= g.S;    // wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r, h);
-      const bool ok = kv && q0 + row < g.L;
-      const float p = ok ? fast_exp2(s[r] * g.scale_log2 - rowv[row]) : 0.f;
+      float p = fast_exp2(__builtin_fmaf(s[r], g.scale_log2, -rowv[row]));
+      if (!full) p = (kv && q0 + row < g.L) ? p : 0.f;
       float d = dp[r];
       float pk = p;
       if (g.drop_thresh) {
