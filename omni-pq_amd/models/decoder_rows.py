@@ -118,13 +118,17 @@ def _side_stream(device):
 
 def key_side(layer, key, key_pos):
     """The key / value side of a layer's cross attention: kv = in_proj[C:](mem + cross_posembed(key_pos)),
-    rows (B*Pk, 2C) bf16.  It depends on the memory only, not on the queries."""
+    rows (B*Pk, 2C) bf16.  It depends on the memory only, not on the queries.  -> (kv, (W_q, b_q))"""
     C = key.shape[1]
     ca = layer.multihead_attn
     mem16 = _rows(key).to(torch.bfloat16)
     k_pe = _rows(layer.cross_posembed(key_pos)).to(torch.bfloat16)
     mem_pe = AddToBf16.apply(mem16, k_pe)
-    return rows_mlp.run(mem_pe, [rows_mlp.Layer(ca.in_proj_weight[C:], ca.in_proj_bias[C:])], layer.training)
+    # ONE split of the packed projection (its backward is one cat; two slices would each zero-fill and copy a
+    # full-size gradient and add them up); the query part travels with the result to run()
+    wq, wkv = torch.split(ca.in_proj_weight, [C, 2 * C])
+    bq, bkv = torch.split(ca.in_proj_bias, [C, 2 * C])
+    return rows_mlp.run(mem_pe, [rows_mlp.Layer(wkv, bkv)], layer.training), (wq, bq)
 
 
 def precompute_key_sides(layers, key, key_pos):
@@ -139,7 +143,7 @@ def precompute_key_sides(layers, key, key_pos):
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         kvs = [key_side(layer, key, key_pos) for layer in layers]
-    for kv in kvs:
+    for kv, _ in kvs:
         kv.record_stream(cur)
     return kvs
 
@@ -176,11 +180,12 @@ def run(layer, query, key, query_pos, key_pos, kv=None):
                                            pdrop(layer.dropout1), q_pe, True, False)
 
     # cross attention: query x + q_pe, key = value = mem + k_pe (:208-213)
-    q = linear(xq, ca.in_proj_weight[:C], ca.in_proj_bias[:C])
     if kv is None:
         kv = key_side(layer, key, key_pos)
     else:
         join_key_sides(query.device)
+    kv, (wq, bq) = kv
+    q = linear(xq, wq, bq)
     att = fused_attention.PackedAttention.apply(q, kv, Pq, Pk, B, H, float(ca.dropout) if training else 0.0)
     y = linear(att, ca.out_proj.weight, ca.out_proj.bias)
     x32, x16, _ = AddDropoutLayerNorm.apply(x32, y, layer.norm2.weight, layer.norm2.bias, float(layer.norm2.eps),

@@ -301,15 +301,18 @@ class PQ_Transformer(nn.Module):
             prefix = 'last_' if (i == self.num_layer - 1) else f'{i}head_'
             query_pos_joint = torch.cat([base_xyz, base_xyz_q], 1)
             query_joint = self.decoder[i](query_joint, key, query_pos_joint, key_pos, key_sides[i])
-            query = query_joint[:, :, 0:self.num_proposal]
-            query_q = query_joint[:, :, self.num_proposal:]
+            n_obj, n_quad = self.num_proposal, query_joint.shape[2] - self.num_proposal
+            query, query_q = torch.split(query_joint, [n_obj, n_quad], dim=2)     # one cat in backward
             rows16 = getattr(query_joint, 'omnipq_rows16', None)          # (B, P, C) bf16 twin from the row-major decoder
+            rows_obj = rows_quad = None
+            if rows16 is not None:
+                rows_obj, rows_quad = torch.split(rows16, [n_obj, n_quad], dim=1)
             base_xyz, _, end_points = self.prediction_heads[i](
                 query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
-                net_rows=None if rows16 is None else rows16[:, 0:self.num_proposal])
+                net_rows=rows_obj)
             base_xyz_q, _, end_points = self.prediction_quad_heads[i](
                 query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix,
-                net_rows=None if rows16 is None else rows16[:, self.num_proposal:])
+                net_rows=rows_quad)
             base_xyz = base_xyz.detach().clone()
             base_xyz_q = base_xyz_q.detach().clone()
         return end_points

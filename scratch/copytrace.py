@@ -18,7 +18,7 @@ class M(TorchDispatchMode):
         out=func(*args, **(kwargs or {}))
         name=func.__name__ if hasattr(func,"__name__") else str(func)
         base=str(func).split(".")[1] if "." in str(func) else str(func)
-        if base in WATCH:
+        if torch.is_tensor(out) and out.is_cuda and base not in ("view","_unsafe_view","transpose","t","slice","select","unsqueeze","squeeze","expand","as_strided","detach","alias","permute","reshape","empty","empty_like","empty_strided","split","split_with_sizes","unbind","narrow","_reshape_alias","view_as","lift_fresh","chunk","record_stream","is_same_size","contiguous"):
             fr="?"
             for f in reversed(traceback.extract_stack()):
                 if ("omni-pq_amd" in f.filename or f.filename.endswith("bench.py")):
@@ -31,5 +31,8 @@ with M():
     step(0)
 torch.cuda.synchronize()
 print("ops watched:", sum(v[0] for v in agg.values()))
-for (b,fr),(c,n) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:90]:
+byfile=collections.defaultdict(int)
+for (b,fr),(c,n) in agg.items(): byfile[fr.split(":")[0]]+=c
+print(sorted(byfile.items(), key=lambda kv:-kv[1]))
+for (b,fr),(c,n) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:70]:
     print(f"{c:5d}x {n/1e6:9.2f} MB  {b:10s} {fr}")
