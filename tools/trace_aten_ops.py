@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Which source lines of the model still issue PyTorch (aten) GPU ops in one eager training step?  A TorchDispatchMode
+logs every op with the innermost repo frame; used to hunt stray casts / copies / zero-fills.  Run on a GPU box."""
 import sys, os, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv=["bench.py","--graph","off","--no-op-timing","--no-cpu-baseline"]
