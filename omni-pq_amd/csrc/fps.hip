@@ -458,8 +458,10 @@ extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *
   const int bs_mask = omnipq_opt_n_threads(n) - 1;
 
   if (n <= 256) return launch_single<256, 1>(b, n, m, bs_mask, dataset, temp, idxs, stream);
-  if (n <= 512) return launch_single<256, 2>(b, n, m, bs_mask, dataset, temp, idxs, stream);
-  if (n <= 1024) return launch_single<256, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
+  // (measured per round at b = 8: 512 threads x 1-2 points beat 256 x 2-4 by ~7 %, 64-128 threads x 8-16 are
+  // 25-65 % slower, 1024 x 1 is slower again: the per-lane update is short, the block argmax grows with waves)
+  if (n <= 512) return launch_single<512, 1>(b, n, m, bs_mask, dataset, temp, idxs, stream);
+  if (n <= 1024) return launch_single<512, 2>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 2048) return launch_single<512, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 4096) return launch_single<1024, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_single<1024, 8>(b, n, m, bs_mask, dataset, temp, idxs, stream);
