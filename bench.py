@@ -59,6 +59,10 @@ def parse():
                          "collectives replay correctly from a graph on this node (else eager DDP)")
     ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--breakdown", action="store_true", help="print a per-operator table to stderr")
+    ap.add_argument("--mean-teacher", action="store_true",
+                    help="SURVEY 8f-1: time the reference's mean-teacher step structure instead of the headline "
+                         "metric -- student fwd+bwd, teacher (EMA model, train mode, no grad) forward on its own "
+                         "batch, EMA update of all parameters (train.py:480-491,576)")
     return ap.parse_args()
 
 
@@ -311,23 +315,38 @@ class FlatGradients:
             off += n
 
 
-def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_graph=False):
+EMA_DECAY, EMA_STEP = 0.999, 100_000          # steady state of train.py:437: alpha = min(1 - 1/(step+1), 0.999) = 0.999
+
+
+def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_graph=False, teacher=None,
+              teacher_pool=None):
     """-> (step(i) -> loss tensor, launch mode string).  Eager: forward, loss, prefetch of the next
     batch's sampling, backward.  Graph: the same sequence captured once and replayed -- always for a
     single process; under torch.distributed only when `dist_graph` (the probe passed), with the
     SyncBatchNorm all-reduces and the flat gradient all-reduce inside the graph."""
+    def teacher_forward(batch):
+        with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            return teacher({"point_clouds": batch})            # train mode, no grad (train.py:462,490-491)
+
     def step(i):
         for p in net.parameters():
             p.grad = None
         with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             ep = model({"point_clouds": pool[i % len(pool)]})
             loss = loss_of(ep)
+        if teacher is not None:
+            teacher_forward(teacher_pool[i % len(teacher_pool)])
         if not args.no_prefetch:
             # software pipelining across steps: the NEXT batch's furthest-point sampling (coordinates
             # only) runs on a side stream underneath this batch's backward.  Every step still does
             # one batch worth of sampling inside the timed region.
             net.prefetch({"point_clouds": pool[(i + 1) % len(pool)]})
+            if teacher is not None:
+                teacher.prefetch({"point_clouds": teacher_pool[(i + 1) % len(teacher_pool)]})
         loss.backward()
+        if teacher is not None:
+            import ema
+            ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)       # train.py:576
         return loss
 
     use_graph = args.graph in ("on", "auto") and (not distributed or dist_graph)
@@ -341,6 +360,8 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         # the buffers inside the timed region.
         cur = pool[0].clone()
         nxt = pool[0].clone()
+        cur_t = teacher_pool[0].clone() if teacher is not None else None
+        nxt_t = teacher_pool[0].clone() if teacher is not None else None
 
         def graph_body():
             for p in net.parameters():
@@ -348,10 +369,18 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 ep = model({"point_clouds": cur})
                 loss = loss_of(ep)
+            if teacher is not None:
+                teacher_forward(cur_t)
             if not args.no_prefetch:
                 net.prefetch({"point_clouds": nxt}, trusted=True)
+                if teacher is not None:
+                    teacher.prefetch({"point_clouds": nxt_t}, trusted=True)
             loss.backward()
             net.join_prefetch()
+            if teacher is not None:
+                teacher.join_prefetch()
+                import ema
+                ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)
             if flat is not None:
                 flat.reduce()
             return loss
@@ -359,10 +388,17 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         def feed(i):
             cur.copy_(nxt)
             nxt.copy_(pool[(i + 1) % len(pool)])
+            if teacher is not None:
+                cur_t.copy_(nxt_t)
+                nxt_t.copy_(teacher_pool[(i + 1) % len(teacher_pool)])
 
         nxt.copy_(pool[0])
+        if teacher is not None:
+            nxt_t.copy_(teacher_pool[0])
         if not args.no_prefetch:
             net.prefetch({"point_clouds": nxt}, trusted=True)      # plan of the first batch
+            if teacher is not None:
+                teacher.prefetch({"point_clouds": nxt_t}, trusted=True)
         for i in range(max(args.warmup, 3)):          # eager warm-up: allocator, workspaces, autotuning
             feed(i)
             graph_body()
@@ -455,15 +491,25 @@ def main():
     pool = [synth.make_clouds(100 + i, args.batch, args.points, extra_channels=args.extra_channels,
                               kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
 
+    teacher = teacher_pool = None
+    if args.mean_teacher:
+        import copy
+        teacher = copy.deepcopy(net)                      # train.py:357-358 builds it the same way, then ...
+        for p in teacher.parameters():
+            p.detach_()                                   # ... train.py:340-342
+        teacher.train()
+        teacher_pool = [synth.make_clouds(200 + i, args.batch, args.points, extra_channels=args.extra_channels,
+                                          kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
     try:
-        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, dist_graph)
+        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, dist_graph, teacher,
+                                      teacher_pool)
     except GraphUnavailable:
         dist_graph = False
         for p in net.parameters():
             p.grad = None
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
         args.graph = "off"
-        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, False)
+        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, False, teacher, teacher_pool)
     use_graph = launch_mode != "eager"
 
     def fence():
@@ -492,7 +538,8 @@ def main():
         # right after the timed region from eager steps over the same batches (same kernels, same
         # shapes; rocprofv3 of this command sees both and its averages agree).
         eager_args = argparse.Namespace(**{**vars(args), "graph": "off"})
-        eager_step, _ = make_step(net, model, pool, eager_args, amp_dtype, world)
+        eager_step, _ = make_step(net, model, pool, eager_args, amp_dtype, world, teacher=teacher,
+                                  teacher_pool=teacher_pool)
         eager_step(0)
         fence()
         sink = []
@@ -514,7 +561,9 @@ def main():
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
-            "metric": "scenes/sec fwd+bwd, 40k-pt ScanNet clouds, batch 8/GPU",
+            "metric": ("scenes/sec fwd+bwd, 40k-pt ScanNet clouds, batch 8/GPU" if not args.mean_teacher else
+                       "student scenes/sec, mean-teacher step (student fwd+bwd + teacher fwd + EMA), 40k-pt clouds, "
+                       "batch 8+8/GPU"),
             "value": scenes / dt_max, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

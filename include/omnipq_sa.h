@@ -168,6 +168,13 @@ int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd
 int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int *sizes, const int *strides, const int *is_bf16,
                         float *out, void *stream);
 
+/* Mean-teacher weight averaging (reference train.py:435-439): ema = alpha * ema + beta * param over a whole model
+ * pair in one launch.  segs: device array of nseg packed 24-byte records { float *ema; const float *param;
+ * int64_t numel; }; chunks: device array of nchunks x int32[2] = {record, chunk of 4096 elements}.  Rounded like
+ * the reference's two in-place ops (mul_, then add_ with a scalar multiplier). */
+int omnipq_ema_update(int nseg, int nchunks, const void *segs, const int *chunks, float alpha, float beta,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -347,31 +347,60 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------
+// Exchange slots of the multi-workgroup kernel.  One block per (device, STREAM): launches on one stream run one
+// after the other and may share it, launches on different streams may overlap (a model and its EMA teacher
+// each prefetching their sampling plan) and must not see each other's granules.  The give-up flag is one word
+// per device.
 struct FpsWorkspace {
+  hipStream_t stream = nullptr;
   unsigned long long *slots = nullptr;
-  int *err = nullptr;
   size_t slot_bytes = 0;
+  int *err = nullptr;            // the device's flag (shared by its workspaces)
+};
+
+constexpr int kMaxStreams = 16;
+struct DeviceWorkspaces {
+  int *err = nullptr;
+  int used = 0;
+  FpsWorkspace per[kMaxStreams];
 };
 
 static std::mutex g_ws_mutex;
-static FpsWorkspace g_ws[64];
+static DeviceWorkspaces g_ws[64];
 
-static int get_workspace(size_t slot_bytes, FpsWorkspace **out) {
+static int get_workspace(size_t slot_bytes, hipStream_t stream, FpsWorkspace **out) {
   int dev = 0;
   OMNIPQ_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return OMNIPQ_EINVAL;
   std::lock_guard<std::mutex> lock(g_ws_mutex);
-  FpsWorkspace &ws = g_ws[dev];
-  if (ws.slot_bytes < slot_bytes) {
+  DeviceWorkspaces &d = g_ws[dev];
+  if (!d.err) {
+    void *p = nullptr;
+    OMNIPQ_HIP(hipMalloc(&p, 256));
+    OMNIPQ_HIP(hipMemset(p, 0, 256));
+    d.err = (int *)p;
+  }
+  FpsWorkspace *ws = nullptr;
+  for (int i = 0; i < d.used; ++i)
+    if (d.per[i].stream == stream) ws = &d.per[i];
+  if (!ws) {
+    // streams come and go; when the table is full the oldest entry is handed to the newcomer (its launches
+    // were queued long ago and the memset below is ordered behind nothing of theirs -- so give it a new block)
+    const int i = d.used < kMaxStreams ? d.used++ : 0;
+    ws = &d.per[i];
+    *ws = FpsWorkspace();
+    ws->stream = stream;
+  }
+  ws->err = d.err;
+  if (ws->slot_bytes < slot_bytes) {
     // grow-only; the old block is deliberately leaked to in-flight launches
     void *p = nullptr;
-    OMNIPQ_HIP(hipMalloc(&p, slot_bytes + 256));
-    ws.slots = (unsigned long long *)p;
-    ws.err = (int *)((char *)p + slot_bytes);
-    ws.slot_bytes = slot_bytes;
-    OMNIPQ_HIP(hipMemset(p, 0, slot_bytes + 256));
+    OMNIPQ_HIP(hipMalloc(&p, slot_bytes));
+    OMNIPQ_HIP(hipMemset(p, 0, slot_bytes));
+    ws->slots = (unsigned long long *)p;
+    ws->slot_bytes = slot_bytes;
   }
-  *out = &ws;
+  *out = ws;
   return OMNIPQ_OK;
 }
 
@@ -394,7 +423,7 @@ static int launch_multi(int b, int n, int m, int bs_mask, int G, const float *da
   if (chunk > b) chunk = b;
   const size_t slot_bytes = (size_t)2 * chunk * 5 * G * sizeof(unsigned long long);
   FpsWorkspace *ws = nullptr;
-  int rc = get_workspace(slot_bytes, &ws);
+  int rc = get_workspace(slot_bytes, stream, &ws);
   if (rc) return rc;
   for (int s0 = 0; s0 < b; s0 += chunk) {
     const int ns = (b - s0 < chunk) ? (b - s0) : chunk;
@@ -434,13 +463,18 @@ extern "C" int omnipq_fps_check(void *stream) {
   using namespace omnipq;
   int dev = 0;
   OMNIPQ_HIP(hipGetDevice(&dev));
-  FpsWorkspace &ws = g_ws[dev];
-  if (!ws.err) return OMNIPQ_OK;
+  if (dev < 0 || dev >= 64) return OMNIPQ_EINVAL;
+  int *err = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    err = g_ws[dev].err;
+  }
+  if (!err) return OMNIPQ_OK;
   int flag = 0;
-  OMNIPQ_HIP(hipMemcpyAsync(&flag, ws.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  OMNIPQ_HIP(hipMemcpyAsync(&flag, err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   OMNIPQ_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (flag) {
-    OMNIPQ_HIP(hipMemsetAsync(ws.err, 0, sizeof(int), (hipStream_t)stream));
+    OMNIPQ_HIP(hipMemsetAsync(err, 0, sizeof(int), (hipStream_t)stream));
     return OMNIPQ_ETIMEOUT;
   }
   return OMNIPQ_OK;

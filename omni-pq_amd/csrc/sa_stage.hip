@@ -1311,3 +1311,42 @@ extern "C" int omnipq_place_rows(long long rows, int C, const void *src, void *d
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
+
+// ---- mean-teacher weight averaging (reference train.py:435-439) ---------------------------------
+// ema = alpha * ema + (1 - alpha) * param over ALL parameter tensors of a model pair in one launch: device
+// table of segments, one workgroup per 4096 elements (chunk table).  Rounded like the reference's two in-place
+// CUDA ops: t = ema * alpha (rounded to f32), then ema = fma(beta, param, t) -- what nvcc's default contraction
+// makes of add_'s `a + alpha * b`.
+struct EmaSeg {
+  float *ema;
+  const float *param;
+  long long numel;
+};
+
+__global__ __launch_bounds__(256) void ema_update_kernel(const EmaSeg *__restrict__ segs, const int *__restrict__ chunks,
+                                                        float alpha, float beta) {
+  const int *ck = chunks + 2 * (size_t)blockIdx.x;
+  const EmaSeg g = segs[ck[0]];
+  const long long base = (long long)ck[1] * 4096;
+#pragma unroll 4
+  for (int u = 0; u < 16; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i < g.numel) {
+      const float t = g.ema[i] * alpha;
+      g.ema[i] = __builtin_fmaf(beta, g.param[i], t);
+    }
+  }
+}
+
+// segs: device array of nseg records { float *ema; const float *param; int64 numel; } (24 bytes); chunks: device
+// array of nchunks x int32[2] = {record, chunk of 4096 elements}.
+extern "C" int omnipq_ema_update(int nseg, int nchunks, const void *segs, const int *chunks, float alpha, float beta,
+                                 void *stream) {
+  static_assert(sizeof(EmaSeg) == 24, "EmaSeg layout is part of the C ABI");
+  if (nseg < 0 || nchunks < 0) return OMNIPQ_EINVAL;
+  if (nseg == 0 || nchunks == 0) return OMNIPQ_OK;
+  if (!segs || !chunks) return OMNIPQ_EINVAL;
+  ema_update_kernel<<<nchunks, 256, 0, (hipStream_t)stream>>>((const EmaSeg *)segs, chunks, alpha, beta);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

@@ -74,3 +74,38 @@ def test_sum_of_means_matches_torch_on_strided_views():
     w = torch.autograd.grad(want, ts)
     for a, b in zip(g, w):
         assert torch.allclose(a.float(), b.float(), rtol=1e-2, atol=1e-7)
+
+
+def test_ema_update_matches_the_oracle():
+    """Mean-teacher weight averaging (train.py:435-439) of a whole model pair in one launch == the oracle's
+    restatement, to one f32 ulp; the table follows in-place updates; CPU parameters are refused."""
+    import copy
+    import sys
+    import numpy as np
+    sys.path.insert(0, REPO)
+    import bench
+    import ema
+    from oracle import step_oracle
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    student = bench.build_model(0).to(dev)
+    teacher = copy.deepcopy(student)
+    for p in teacher.parameters():
+        p.detach_()                                             # train.py:340-342
+    with torch.no_grad():
+        for p in student.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    for step in (0, 3, 4000):
+        want = [e.detach().cpu().numpy().copy() for e in teacher.parameters()]
+        a_want = step_oracle.update_ema_variables(want, [p.detach().cpu().numpy() for p in student.parameters()], 0.999, step)
+        a = ema.update_ema_variables(student, teacher, 0.999, step)
+        assert a == a_want
+        for e, w in zip(teacher.parameters(), want):
+            g = e.detach().cpu().numpy()
+            assert np.all(np.abs(g - w) <= np.spacing(np.abs(w))), step
+        with torch.no_grad():                                   # an optimizer step in place: same table next time
+            for p in student.parameters():
+                p.mul_(1.001)
+    assert len(ema._TABLES) == 1
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ema.update_ema_variables(torch.nn.Linear(2, 2), torch.nn.Linear(2, 2), 0.999, 1)

@@ -291,3 +291,25 @@ def test_sampling_plan_and_prefetch_do_not_change_results(monkeypatch):
         assert torch.equal(got0[k], want[0][k]), k
         assert torch.equal(got1[k], want[1][k]), k
         assert torch.equal(got1b[k], want[1][k]), k
+
+
+def test_fps_on_two_streams_at_once():
+    """Two multi-workgroup FPS launches in flight on different streams (a model and its EMA teacher prefetching
+    their sampling plans) must not share exchange slots: both equal their sequential results."""
+    import pointnet2_utils
+    ext = pointnet2_utils._load_ext()
+    dev = torch.device("cuda", 0)
+    a = synth.make_clouds(31, 4, 40000, kind="room").to(dev)[..., :3].contiguous()
+    b = synth.make_clouds(32, 4, 40000, kind="room").to(dev)[..., :3].contiguous()
+    want_a = ext.furthest_point_sampling(a, 1024).clone()
+    want_b = ext.furthest_point_sampling(b, 1024).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            got_a = ext.furthest_point_sampling(a, 1024)
+        with torch.cuda.stream(s2):
+            got_b = ext.furthest_point_sampling(b, 1024)
+        torch.cuda.synchronize()
+        assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+    ext.fps_check()

@@ -259,3 +259,28 @@ def test_everything_before_the_votes_needs_no_forcing(oracle_backend):
         check_summary(ep[k], fx["outputs"]["ep." + k], k, 0.0)
     for k in ("sa1_features", "sa4_features", "fp2_features", "seed_features", "vote_xyz", "vote_features"):
         check_summary(ep[k], fx["outputs"]["ep." + k], k, 1e-4)
+
+
+def test_ema_oracle_matches_the_reference_statements():
+    """oracle/step_oracle.update_ema_variables against the three statements of train.py:435-439 executed by
+    PyTorch on CPU (the reference's function itself cannot be imported: train.py parses the command line and
+    pulls in the dataset stack at import).  Agreement to one f32 ulp: CPU add_ may or may not fuse."""
+    import numpy as np
+    from oracle import step_oracle
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(288, 288), (288,), (2048, 288), (1,), (97, 288, 1)]
+    for step, alpha in [(0, 0.999), (1, 0.999), (5, 0.999), (5000, 0.999), (10, 0.5)]:
+        params = [torch.randn(s, generator=gen) for s in shapes]
+        emas = [torch.randn(s, generator=gen) for s in shapes]
+        got = [e.numpy().copy() for e in emas]
+        a = step_oracle.update_ema_variables(got, [p.numpy() for p in params], alpha, step)
+        a_ref = min(1 - 1 / (step + 1), alpha)                               # train.py:437
+        assert a == a_ref
+        for e, p, g in zip(emas, params, got):
+            e.mul_(a_ref).add_(p, alpha=1 - a_ref)                           # train.py:439
+            ulp = np.spacing(np.abs(e.numpy()).astype(np.float32))
+            assert np.all(np.abs(g - e.numpy()) <= ulp), (step, alpha)
+    # step 0: alpha = 0 -> the teacher becomes a copy of the student
+    e0 = [np.ones((4,), np.float32)]
+    step_oracle.update_ema_variables(e0, [np.full((4,), 3.0, np.float32)], 0.999, 0)
+    assert np.array_equal(e0[0], np.full((4,), 3.0, np.float32))
