@@ -29,6 +29,7 @@
 
 #include <math.h>
 #include <mutex>
+#include <unordered_map>
 
 namespace omnipq {
 
@@ -350,19 +351,18 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
 // Exchange slots of the multi-workgroup kernel.  One block per (device, STREAM): launches on one stream run one
 // after the other and may share it, launches on different streams may overlap (a model and its EMA teacher
 // each prefetching their sampling plan) and must not see each other's granules.  The give-up flag is one word
-// per device.
+// per device.  Blocks are never cleared from the host: every launch zeroes the part it uses ON ITS OWN STREAM
+// (a null-stream hipMemset is not ordered against the non-blocking streams PyTorch launches on and can land in
+// the middle of a running exchange).
 struct FpsWorkspace {
-  hipStream_t stream = nullptr;
   unsigned long long *slots = nullptr;
   size_t slot_bytes = 0;
   int *err = nullptr;            // the device's flag (shared by its workspaces)
 };
 
-constexpr int kMaxStreams = 16;
 struct DeviceWorkspaces {
   int *err = nullptr;
-  int used = 0;
-  FpsWorkspace per[kMaxStreams];
+  std::unordered_map<hipStream_t, FpsWorkspace> per;      // stream handles are few and recycled by their pools
 };
 
 static std::mutex g_ws_mutex;
@@ -375,28 +375,19 @@ static int get_workspace(size_t slot_bytes, hipStream_t stream, FpsWorkspace **o
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   DeviceWorkspaces &d = g_ws[dev];
   if (!d.err) {
+    // once per device and process, before the first launch: cleared and waited for
     void *p = nullptr;
     OMNIPQ_HIP(hipMalloc(&p, 256));
     OMNIPQ_HIP(hipMemset(p, 0, 256));
+    OMNIPQ_HIP(hipDeviceSynchronize());
     d.err = (int *)p;
   }
-  FpsWorkspace *ws = nullptr;
-  for (int i = 0; i < d.used; ++i)
-    if (d.per[i].stream == stream) ws = &d.per[i];
-  if (!ws) {
-    // streams come and go; when the table is full the oldest entry is handed to the newcomer (its launches
-    // were queued long ago and the memset below is ordered behind nothing of theirs -- so give it a new block)
-    const int i = d.used < kMaxStreams ? d.used++ : 0;
-    ws = &d.per[i];
-    *ws = FpsWorkspace();
-    ws->stream = stream;
-  }
+  FpsWorkspace *ws = &d.per[stream];
   ws->err = d.err;
   if (ws->slot_bytes < slot_bytes) {
     // grow-only; the old block is deliberately leaked to in-flight launches
     void *p = nullptr;
     OMNIPQ_HIP(hipMalloc(&p, slot_bytes));
-    OMNIPQ_HIP(hipMemset(p, 0, slot_bytes));
     ws->slots = (unsigned long long *)p;
     ws->slot_bytes = slot_bytes;
   }
