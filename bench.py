@@ -328,6 +328,17 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             return teacher({"point_clouds": batch})            # train mode, no grad (train.py:462,490-491)
 
+    # DistributedDataParallel (the eager multi-rank fallback) needs the per-parameter hooks: no deferral there
+    defer = os.environ.get("OMNIPQ_DEFER_WGRADS", "1") != "0" and not (distributed and not dist_graph)
+
+    def backward(loss):
+        if defer:
+            import sa_fused
+            with sa_fused.deferred_wgrads():         # ~115 small weight gradients as one grouped launch
+                loss.backward()
+        else:
+            loss.backward()
+
     def step(i):
         for p in net.parameters():
             p.grad = None
@@ -343,7 +354,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             net.prefetch({"point_clouds": pool[(i + 1) % len(pool)]})
             if teacher is not None:
                 teacher.prefetch({"point_clouds": teacher_pool[(i + 1) % len(teacher_pool)]})
-        loss.backward()
+        backward(loss)
         if teacher is not None:
             import ema
             ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)       # train.py:576
@@ -375,7 +386,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
                 net.prefetch({"point_clouds": nxt}, trusted=True)
                 if teacher is not None:
                     teacher.prefetch({"point_clouds": nxt_t}, trusted=True)
-            loss.backward()
+            backward(loss)
             net.join_prefetch()
             if teacher is not None:
                 teacher.join_prefetch()

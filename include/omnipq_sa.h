@@ -59,6 +59,24 @@ int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void 
 int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                                float *workspace, float *colsum, void *stream);
 
+/* Many independent weight gradients in ONE grid plus ONE reduction (the ~115 small dW = dY^T X of the per-point
+ * MLPs outside the SA stages: torch autograd runs them one by one, `loss.backward()` of train.py:571; nothing
+ * reads a weight gradient before the optimizer, so the host collects them during backward and launches them
+ * together).  Problem i: C = A^T B as above, then out[r][c] (+)= C[r][c] for r < out_rows, c < out_cols (the crop
+ * of the padded rows / columns into the parameter's own shape, row pitch out_ld); colsum as above.  `probs` is
+ * HOST memory (read during the call only); workspace: omnipq_gemm_tn_grouped_workspace_floats() floats. */
+typedef struct {
+  const void *A, *B;
+  float *colsum;
+  float *out;
+  int M, N, P, lda, ldb;
+  int out_rows, out_cols, out_ld;
+  int flags;                 /* bit 0: add to out */
+  int pad_;
+} omnipq_tn_problem;
+long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);
+int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
+
 /* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares
  * of the bf16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of
  * omnipq_gemm_nt_stats_workspace_floats(M, N) elements (0 for few rows: then it may be NULL). */

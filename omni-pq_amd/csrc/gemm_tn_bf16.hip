@@ -38,9 +38,8 @@ struct TnArgs {
 // colsum (may be NULL): float[M], receives (ADDED, f32 atomics) the column sums of A over all positions --
 // the bias gradient that goes with a weight gradient dW = dY^T X, taken from the A tiles the kernel stages
 // anyway (workgroups of the first N-tile only), instead of a separate pass over dY.
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
-                                                        const bf16_t *__restrict__ B,
-                                                        float *__restrict__ part, float *__restrict__ colsum) {
+__device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
+                                        float *__restrict__ part, float *__restrict__ colsum, const int id) {
   constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 17408 bf16 = 34 KB
   constexpr int CT_BYTES = 128 * TCPITCH * 4;                  // 66 KB
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES];
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
   // all tiles of one slab are placed on it -- the slab's rows are then fetched into ONE L2 and shared by the
   // m_tiles * n_tiles workgroups that read them, instead of once per XCD (PMC: the kernel fetched 2x its
   // operands before).
-  const int id = (int)blockIdx.x, tiles = g.m_tiles * g.n_tiles;
+  const int tiles = g.m_tiles * g.n_tiles;
   const int xcd = id & 7, local = id >> 3;
   const int slab = xcd + 8 * (local / tiles), tile = local % tiles;
   if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
@@ -213,6 +212,77 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t 
   }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
+                                                        const bf16_t *__restrict__ B,
+                                                        float *__restrict__ part, float *__restrict__ colsum) {
+  tn_tile(g, A, B, part, colsum, (int)blockIdx.x);
+}
+
+// ---- grouped launch: many independent weight gradients in one grid ------------------------------------------
+// The per-point MLPs outside the SA stages (decoder projections, feed-forward, heads, position embeddings,
+// voting, feature propagation) produce ~115 weight gradients per step of 9..48 tiles each: launched one by one
+// every GEMM is a 10-25 us bubble of launch latency, ramp and tail plus two reduction launches.  Nothing
+// depends on a weight gradient until the optimizer, so they are collected during backward and run here as ONE
+// grid (descriptors by value in the kernel arguments, <= kGroupMax per launch), followed by ONE reduction that
+// also crops the padded rows / columns and writes the gradient in the parameter's own shape.
+constexpr int kGroupMax = 36;
+struct TnGroupItem {
+  const bf16_t *A, *B;
+  float *part, *colsum, *out;
+  int M, N, P, lda, ldb, p_chunk, m_tiles, n_tiles;
+  int wg_begin;                 // first workgroup of this problem (multiple of 8: the XCD mapping above stays valid)
+  int slabs;                    // slabs in use
+  int out_rows, out_cols, out_ld;
+  int blk_begin;                // first block of this problem in the reduction grid
+  int flags;                    // bit 0: add to `out` instead of overwriting it
+  int pad_;
+};
+struct TnGroupArgs {
+  int n;
+  int pad_;
+  TnGroupItem item[kGroupMax];
+};
+static_assert(sizeof(TnGroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupArgs a) {
+  const int id = (int)blockIdx.x;
+  int lo = 0, hi = a.n - 1;          // last item with wg_begin <= id
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.item[mid].wg_begin <= id) lo = mid; else hi = mid - 1;
+  }
+  const TnGroupItem &it = a.item[lo];
+  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles};
+  tn_tile(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin);
+}
+
+// out[r][c] (+)= sum over slabs of part[z][r][c], r < out_rows, c < out_cols: fixed order, no atomics
+__global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(TnGroupArgs a) {
+  const int blk = (int)blockIdx.x;
+  int lo = 0, hi = a.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.item[mid].blk_begin <= blk) lo = mid; else hi = mid - 1;
+  }
+  const TnGroupItem &it = a.item[lo];
+  const int e = (blk - it.blk_begin) * 256 + (int)threadIdx.x;
+  if (e >= it.out_rows * it.out_cols) return;
+  const int r = e / it.out_cols, c = e - r * it.out_cols;
+  const float *src = it.part + (size_t)r * it.N + c;
+  const size_t mn = (size_t)it.M * it.N;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 3 < it.slabs; z += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += src[(size_t)(z + u) * mn];
+  }
+  for (; z < it.slabs; ++z) acc[0] += src[(size_t)z * mn];
+  float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  float *dst = it.out + (size_t)r * it.out_ld + c;
+  if (it.flags & 1) v += *dst;
+  *dst = v;
+}
+
 // out[g][i] = sum over slabs z == g (mod groups) of part[z][i], four floats per lane, eight loads in
 // flight per lane.  Two passes (slabs -> kReduceGroups -> 1) keep every pass wide enough to fill the
 // chip while the summation order stays fixed (deterministic, no atomics).
@@ -304,5 +374,84 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
                                                                                reinterpret_cast<f32x4 *>(C));
   }
   OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// ---- grouped weight gradients ---------------------------------------------------------------------------
+// Mirrors include/omnipq_sa.h: omnipq_tn_problem.
+struct omnipq_tn_problem_ {
+  const void *A, *B;        // bf16 [P][M] (pitch lda), [P][N] (pitch ldb)
+  float *colsum;            // NULL or float[M]: += column sums of A
+  float *out;               // f32 [out_rows][out_cols], pitch out_ld: the cropped C
+  int M, N, P, lda, ldb;
+  int out_rows, out_cols, out_ld;
+  int flags;                // bit 0: out += C
+  int pad_;
+};
+
+static int tng_chunk() {
+  // positions per workgroup in the grouped launch: the grid is full anyway, so workgroups are cut for balance
+  // (a few thousand of them), not to create parallelism
+  static const int steps = getenv("OMNIPQ_TNG_STEPS") ? atoi(getenv("OMNIPQ_TNG_STEPS")) : 16;
+  return omnipq::TBK * (steps < 1 ? 1 : steps);
+}
+
+static int tng_slabs(int P) {
+  const int c = tng_chunk();
+  const int s = (P + c - 1) / c;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs_) {
+  const omnipq_tn_problem_ *pr = (const omnipq_tn_problem_ *)probs_;
+  long long total = 0;
+  for (int i = 0; i < nprob; ++i) total += (long long)tng_slabs(pr[i].P) * pr[i].M * pr[i].N;
+  return total;
+}
+
+extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *workspace, void *stream) {
+  using namespace omnipq;
+  const omnipq_tn_problem_ *pr = (const omnipq_tn_problem_ *)probs_;
+  if (nprob < 0 || (nprob > 0 && (!pr || !workspace))) return OMNIPQ_EINVAL;
+  for (int i = 0; i < nprob; ++i) {
+    const omnipq_tn_problem_ &q = pr[i];
+    if (q.M <= 0 || q.N <= 0 || q.P < 0 || (q.P > 0 && (!q.A || !q.B)) || !q.out || (q.M % 8) || (q.N % 8) || (q.lda % 8) || (q.ldb % 8) ||
+        q.out_rows <= 0 || q.out_cols <= 0 || q.out_rows > q.M || q.out_cols > q.N || q.out_ld < q.out_cols)
+      return OMNIPQ_EINVAL;
+  }
+  float *ws = workspace;
+  for (int first = 0; first < nprob; first += kGroupMax) {
+    TnGroupArgs a;
+    a.n = nprob - first < kGroupMax ? nprob - first : kGroupMax;
+    a.pad_ = 0;
+    int wg = 0, blk = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const omnipq_tn_problem_ &q = pr[first + i];
+      TnGroupItem &it = a.item[i];
+      it.A = (const bf16_t *)q.A;
+      it.B = (const bf16_t *)q.B;
+      it.part = ws;
+      it.colsum = q.colsum;
+      it.out = q.out;
+      it.M = q.M; it.N = q.N; it.P = q.P; it.lda = q.lda; it.ldb = q.ldb;
+      it.m_tiles = (q.M + 127) / 128;
+      it.n_tiles = (q.N + 127) / 128;
+      const int slabs = tng_slabs(q.P);
+      it.p_chunk = (((q.P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
+      it.slabs = q.P > 0 ? (q.P + it.p_chunk - 1) / it.p_chunk : 1;
+      it.wg_begin = wg;
+      wg += it.m_tiles * it.n_tiles * ((it.slabs + 7) / 8) * 8;
+      it.out_rows = q.out_rows; it.out_cols = q.out_cols; it.out_ld = q.out_ld;
+      it.blk_begin = blk;
+      blk += (q.out_rows * q.out_cols + 255) / 256;
+      it.flags = q.flags;
+      it.pad_ = 0;
+      ws += (size_t)slabs * q.M * q.N;
+    }
+    gemm_tn_grouped_kernel<<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
+    OMNIPQ_LAUNCH_CHECK();
+    tn_grouped_reduce_kernel<<<dim3(blk), 256, 0, (hipStream_t)stream>>>(a);
+    OMNIPQ_LAUNCH_CHECK();
+  }
   return OMNIPQ_OK;
 }

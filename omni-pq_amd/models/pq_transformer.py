@@ -69,8 +69,8 @@ def head_stack(self, net, heads, net_rows=None):
     `net` when given -- the kernels want bf16 rows anyway, this saves the cast forth and back."""
     B, K = net.shape[0], net.shape[2]
     x = rows(net) if net_rows is None else net_rows.reshape(B * K, -1)
-    w = torch.cat([h.weight.squeeze(-1) for h in heads], 0)
-    b = torch.cat([h.bias for h in heads], 0)
+    w = sa_fused.cat_params([h.weight.squeeze(-1) for h in heads])
+    b = sa_fused.cat_params([h.bias for h in heads])
     stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
              rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2), rows_mlp.Layer(w, b)]
     if rows_mlp.usable(x, stack, self.training):

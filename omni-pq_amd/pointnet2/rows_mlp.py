@@ -151,6 +151,10 @@ class RowsMLP(torch.autograd.Function):
             layers.append(lay)
         ctx.layers, ctx.X0, ctx.geom = layers, X0, (N, cin, world)
         ctx.wshapes = [tuple(params[4 * l].shape) for l in range(L)]
+        # where the weight / bias gradients may be written directly (sa_fused.deferred_wgrads)
+        ctx.targets = [(sa_fused.grad_target(params[4 * l]),
+                        None if params[4 * l + 1] is None else sa_fused.grad_target(params[4 * l + 1]))
+                       for l in range(L)] if training else None
         ctx.training = training
         ctx.in_dtype = x.dtype
         last = layers[-1]
@@ -176,6 +180,7 @@ class RowsMLP(torch.autograd.Function):
             owned = True
         dx = None
         sums = None               # BN-backward sums of the current layer if the GEMM above already produced them
+        dfr = sa_fused.deferred_wgrads.active
         for l in range(L - 1, -1, -1):
             lay = layers[l]
             Xin = layers[l - 1].X if l > 0 else ctx.X0
@@ -196,12 +201,19 @@ class RowsMLP(torch.autograd.Function):
                 _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur), _p(dst),
                       ctypes.c_float(lay.act[1]))
                 dcur, owned = dst, True
-            bsum = None
-            if not lay.has_bn and lay.has_bias:
-                bsum = zeros_f32(lay.Cp, dev)                # bias gradient: column sums of dY, from the same pass
-                grads[4 * l + 1] = bsum[:lay.C]
-            dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum)
-            grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
+            want_bias = not lay.has_bn and lay.has_bias
+            wt, bt = ctx.targets[l] if (dfr is not None and ctx.targets is not None) else (None, None)
+            if wt is not None and ctx.needs_input_grad[3 + 4 * l] and (
+                    not want_bias or (sa_fused.bias_target_ok(bt, lay.C, lay.Cp) and ctx.needs_input_grad[4 + 4 * l])):
+                # collected; computed with all the others when the deferred_wgrads block ends
+                dfr.add(dcur, Xin, lay.Cp, lay.K, N, wt, (lay.C, lay.wk), bt if want_bias else None)
+            else:
+                bsum = None
+                if want_bias:
+                    bsum = zeros_f32(lay.Cp, dev)            # bias gradient: column sums of dY, from the same pass
+                    grads[4 * l + 1] = bsum[:lay.C]
+                dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum)
+                grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None
             if l > 0 and layers[l - 1].has_bn:
                 sums = zeros_f64(3, lay.K, dev)

@@ -149,6 +149,173 @@ def _gemm_tn(A, B, M, N, P, colsum=None):
     return C
 
 
+class _TnProblem(ctypes.Structure):
+    """include/omnipq_sa.h: omnipq_tn_problem"""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
+                ("out_rows", ctypes.c_int), ("out_cols", ctypes.c_int), ("out_ld", ctypes.c_int),
+                ("flags", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+_lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
+
+
+def cat_params(tensors, dim=0):
+    """torch.cat of parameters along dim 0 (the output heads of a prediction head share one GEMM) that remembers
+    its parts, so that `deferred_wgrads` can hand each part its rows of the joint gradient."""
+    assert dim == 0
+    out = torch.cat(tensors, 0)
+    parts, r = [], 0
+    for t in tensors:
+        parts.append((t, r, r + t.shape[0]))
+        r += t.shape[0]
+    out.omnipq_parts = parts
+    return out
+
+
+def grad_target(t):
+    """Where a gradient of `t` may be written behind autograd's back, or None:
+    ("param", parameter, element offset)   `t` is a leaf Parameter or a contiguous view of a contiguous one (a row
+                                           range of a packed projection weight);
+    ("parts", [(tensor, r0, r1), ...])     `t` = cat_params(...) of such tensors (each part owns rows r0:r1)."""
+    if t is None:
+        return None
+    if isinstance(t, torch.nn.Parameter):
+        return ("param", t, 0) if t.is_contiguous() and t.requires_grad else None
+    parts = getattr(t, "omnipq_parts", None)
+    if parts is not None:
+        sub = [(grad_target(q), r0, r1) for q, r0, r1 in parts]
+        if all(g is not None and g[0] == "param" for g, _, _ in sub):
+            return ("parts", [(g[1], g[2], r0, r1) for g, r0, r1 in sub])
+        return None
+    base = t._base
+    if isinstance(base, torch.nn.Parameter) and base.requires_grad and base.is_contiguous() and t.is_contiguous():
+        return ("param", base, t.storage_offset() - base.storage_offset())
+    return None
+
+
+def bias_target_ok(bt, C, Cp):
+    """The kernel adds Cp (padded) column sums: straight into a row range of a packed bias only if nothing is
+    padded; whole parameters and concatenations get a scratch vector and take views of it."""
+    return bt is not None and (Cp == C or bt[0] == "parts" or (bt[2] == 0 and bt[1].numel() == C))
+
+
+class deferred_wgrads:
+    """`with deferred_wgrads(): loss.backward()` -- inside the block the rows engine does not launch the weight
+    (and bias) gradient of a linear layer whose weight is a Parameter (a row range of one, or a cat_params of
+    several) when its turn comes in backward: it records the operands, returns no gradient to autograd, and at
+    exit ALL recorded gradients are computed by one grouped launch (csrc/gemm_tn_bf16.hip) and stored /
+    accumulated into `.grad` exactly as AccumulateGrad would have done.  Nothing reads a weight gradient before
+    the optimizer, so the result is the same; what changes is ~350 launches of 5-25 us becoming a handful.
+    Tensor hooks on those parameters do not fire (DistributedDataParallel relies on them: do not combine the
+    two)."""
+    active = None
+
+    def __enter__(self):
+        if deferred_wgrads.active is not None:
+            raise RuntimeError("deferred_wgrads blocks do not nest")
+        self.items = []             # (dY, X, M, N, P, weight target, (cout, cin), bias target | None)
+        deferred_wgrads.active = self
+        return self
+
+    def add(self, dY, X, M, N, P, wt, crop, bt):
+        self.items.append((dY, X, M, N, P, wt, crop, bt))
+
+    def __exit__(self, et, ev, tb):
+        deferred_wgrads.active = None
+        if et is None:
+            self.flush()
+        self.items = None
+        return False
+
+    def flush(self):
+        items = self.items
+        if not items:
+            return
+        dev = items[0][0].device
+        whole = {}              # id(param) -> [param, f32 buffer of its shape, offsets written so far]
+        pieces = []             # (param, f32 view of a scratch buffer) assigned / accumulated afterwards
+        again = []              # (destination view, scratch): second use of the same weight in the graph
+
+        def buffer_of(param, full):
+            ent = whole.get(id(param))
+            if ent is None:
+                # a gradient assembled from several row ranges starts from zero; one written whole needs no clearing
+                buf = (torch.empty if full else torch.zeros)(param.shape, device=param.device, dtype=torch.float32)
+                ent = whole[id(param)] = [param, buf, set()]
+            return ent
+
+        probs = (_TnProblem * len(items))()
+        for i, (dY, X, M, N, P, wt, (cout, cin), bt) in enumerate(items):
+            q = probs[i]
+            q.A, q.B = dY.data_ptr(), X.data_ptr()
+            q.M, q.N, q.P, q.lda, q.ldb = M, N, P, dY.stride(0), X.stride(0)
+            q.out_rows, q.out_cols, q.out_ld, q.flags, q.colsum = cout, cin, cin, 0, 0
+            if wt[0] == "param":
+                _, wp, woff = wt
+                ent = buffer_of(wp, woff == 0 and cout * cin == wp.numel())
+                if woff in ent[2]:
+                    # the same weight used twice in the graph: its second gradient goes to a buffer of its own and
+                    # is added afterwards (two problems of one grid must not touch the same output)
+                    extra = torch.empty(cout * cin, device=dev, dtype=torch.float32)
+                    again.append((ent[1].view(-1)[woff:woff + cout * cin], extra))
+                    q.out = extra.data_ptr()
+                else:
+                    ent[2].add(woff)
+                    q.out = ent[1].data_ptr() + 4 * woff
+            else:
+                scratch = torch.empty((cout, cin), device=dev, dtype=torch.float32)
+                q.out = scratch.data_ptr()
+                for wp, woff, r0, r1 in wt[1]:
+                    self._piece(pieces, whole, wp, woff, scratch[r0:r1])
+            if bt is None:
+                continue
+            if bt[0] == "param" and not (bt[2] == 0 and bt[1].numel() == cout):
+                bent = buffer_of(bt[1], False)       # row range of a packed bias (M == cout: nothing padded)
+                bent[2].add(bt[2])
+                q.colsum = bent[1].data_ptr() + 4 * bt[2]
+                continue
+            scratch = zeros_f32(M, dev)              # column sums are ADDED by the kernel: from zero
+            q.colsum = scratch.data_ptr()
+            if bt[0] == "param":
+                self._piece(pieces, whole, bt[1], 0, scratch[:cout])
+            else:
+                for bp, boff, r0, r1 in bt[1]:
+                    self._piece(pieces, whole, bp, boff, scratch[r0:r1])
+        ws = torch.empty((int(_lib.omnipq_gemm_tn_grouped_workspace_floats(len(items), ctypes.byref(probs))),),
+                         device=dev, dtype=torch.float32)
+        _call(_lib.omnipq_gemm_tn_grouped, ws, len(items), ctypes.byref(probs), _p(ws))
+        for dst, extra in again:
+            dst.add_(extra)
+        for param, view in pieces:
+            if param is None:                        # rows of a scratch result into a buffer assigned below
+                view[0].add_(view[1].reshape(-1))
+        for param, buf, _ in whole.values():
+            self._accumulate(param, buf)
+        for param, view in pieces:
+            if param is not None:
+                self._accumulate(param, view.view(param.shape))
+
+    @staticmethod
+    def _piece(pieces, whole, param, off, view):
+        """`view` (rows of a scratch result) is the gradient of param's elements [off, off + view.numel())."""
+        if off == 0 and view.numel() == param.numel() and id(param) not in whole:
+            pieces.append((param, view))
+        else:
+            ent = whole.get(id(param))
+            if ent is None:
+                ent = whole[id(param)] = [param, torch.zeros(param.shape, device=param.device, dtype=torch.float32), set()]
+            pieces.append((None, (ent[1].view(-1)[off:off + view.numel()], view)))
+
+    @staticmethod
+    def _accumulate(param, g):
+        g = g if param.dtype == torch.float32 else g.to(param.dtype)
+        if param.grad is None:
+            param.grad = g
+        else:
+            param.grad.add_(g)
+
+
 class _ZeroPool:
     """Zero-initialised scratch handed out in slices that are used once and never recycled: a chunk is
     cleared by ONE memset when it is allocated, instead of one memset per statistics buffer (a training

@@ -184,3 +184,124 @@ def test_decoder_layer_rows_matches_torch_path(train):
         # furthest from the output: gate flips and the BatchNorm cancellation leave them the noisiest
         tol = 1e-1 if "posembed" in n else 5e-2
         assert rel_l2(u, v) < tol, (n, rel_l2(u, v))
+
+
+def test_grouped_weight_gradients_match_torch():
+    """omnipq_gemm_tn_grouped: many dW = dY^T X in one grid, cropped into the parameter's shape, with column
+    sums, against f64 torch on the same bf16 operands (f32 accumulation: 1e-5 relative)."""
+    import sa_fused
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(288, 288, 2048, 288, 288), (864, 288, 4096, 864, 288), (288, 32, 4096, 288, 3), (2048, 288, 1000, 2048, 288),
+              (32, 2048, 33, 18, 2048), (288, 288, 0, 288, 288)] * 8           # 48 problems: more than one launch
+    probs = (sa_fused._TnProblem * len(shapes))()
+    keep, want = [], []
+    for i, (M, N, P, rows, cols) in enumerate(shapes):
+        A = torch.randn(max(P, 1), M, generator=gen).to(torch.bfloat16).to(dev())[:P]
+        B = torch.randn(max(P, 1), N, generator=gen).to(torch.bfloat16).to(dev())[:P]
+        out = torch.full((rows, cols + 2), 7.0, device=dev())                  # pitch wider than the crop
+        cs = torch.zeros(M, device=dev()) if i % 2 == 0 else None
+        q = probs[i]
+        q.A, q.B, q.out, q.colsum = A.data_ptr(), B.data_ptr(), out.data_ptr(), 0 if cs is None else cs.data_ptr()
+        q.M, q.N, q.P, q.lda, q.ldb = M, N, P, M, N
+        q.out_rows, q.out_cols, q.out_ld, q.flags = rows, cols, cols + 2, (1 if i % 3 == 0 else 0)
+        keep.append((A, B, out, cs))
+        full = A.double().t() @ B.double()
+        want.append((full[:rows, :cols] + (7.0 if i % 3 == 0 else 0.0), A.double().sum(0)))
+    n = int(sa_fused._lib.omnipq_gemm_tn_grouped_workspace_floats(len(shapes), ctypes.byref(probs)))
+    ws = torch.empty(n, device=dev())
+    sa_fused._call(sa_fused._lib.omnipq_gemm_tn_grouped, ws, len(shapes), ctypes.byref(probs), sa_fused._p(ws))
+    torch.cuda.synchronize()
+    for (A, B, out, cs), (w, wc), (M, N, P, rows, cols) in zip(keep, want, shapes):
+        scale = float(w.abs().max()) + 1.0
+        assert float((out[:, :cols].double() - w).abs().max()) < 1e-5 * scale * max(P, 1) ** 0.5, (M, N, P)
+        assert bool((out[:, cols:] == 7.0).all())                              # nothing outside the crop
+        if cs is not None:
+            assert float((cs.double() - wc).abs().max()) < 1e-4 * (float(wc.abs().max()) + 1.0)
+
+
+def test_deferred_weight_gradients_equal_the_immediate_ones():
+    """sa_fused.deferred_wgrads: a decoder layer's parameter gradients (packed projection weights reached through
+    row-range views, biases, position-embedding convs) collected during backward and computed by the grouped
+    launch equal the ones autograd accumulates call by call (f32 sums in a different order: 1e-5 relative); the
+    gradients w.r.t. the inputs are the same bits."""
+    import sa_fused
+    import transformer
+    from pq_transformer import PositionEmbeddingLearned
+    torch.manual_seed(0)
+    B, C, Pq, Pk = 4, 288, 96, 200
+    layer = transformer.TransformerDecoderLayer(C, 8, 512, dropout=0.0, self_posembed=PositionEmbeddingLearned(3, C),
+                                                cross_posembed=PositionEmbeddingLearned(3, C)).to(dev())
+    layer.train()
+    query = torch.randn(B, Pq, C, device=dev()).transpose(1, 2).requires_grad_(True)
+    key = torch.randn(B, Pk, C, device=dev()).transpose(1, 2).requires_grad_(True)
+    qpos, kpos = torch.rand(B, Pq, 3, device=dev()), torch.rand(B, Pk, 3, device=dev())
+    g = torch.randn(B, C, Pq, device=dev())
+    state = {k: v.clone() for k, v in layer.state_dict().items()}
+
+    def run(deferred, twice=False):
+        layer.load_state_dict(state)
+        for t in [query, key] + list(layer.parameters()):
+            t.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = layer(query, key, qpos, kpos)
+            if twice:
+                out = out + layer(query, key, qpos, kpos)              # every weight used twice in the graph
+        if deferred:
+            with sa_fused.deferred_wgrads() as d:
+                out.backward(g)
+                assert len(d.items) == (22 if twice else 11), len(d.items)     # every linear layer of the decoder layer
+        else:
+            out.backward(g)
+        return {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}, query.grad.clone(), key.grad.clone()
+
+    for twice in (False, True):
+        now, qn, kn = run(False, twice)
+        later, ql, kl = run(True, twice)
+        assert set(now) == set(later)
+        assert torch.equal(qn, ql) and torch.equal(kn, kl)
+        for n in now:
+            assert now[n].shape == later[n].shape and later[n].dtype == torch.float32
+            assert rel_l2(later[n], now[n]) < 1e-5, (n, rel_l2(later[n], now[n]))
+    # an exception inside the block discards what was collected and leaves no block open
+    with pytest.raises(ZeroDivisionError):
+        with sa_fused.deferred_wgrads():
+            1 / 0
+    assert sa_fused.deferred_wgrads.active is None
+
+
+def test_deferred_gradients_of_concatenated_heads():
+    """The output heads of a prediction head share one GEMM over sa_fused.cat_params(weights): deferred, each head
+    receives its rows of the joint gradient (weights and biases, widths that are no multiple of 32), equal to
+    what autograd's CatBackward hands out call by call."""
+    import rows_mlp
+    import sa_fused
+    torch.manual_seed(1)
+    convs = [torch.nn.Conv1d(288, c, 1).to(dev()) for c in (2, 3, 12, 12, 18, 54, 18)]
+    trunk = torch.nn.Conv1d(288, 288, 1).to(dev())
+    bn = torch.nn.BatchNorm1d(288).to(dev())
+    x = torch.randn(2048, 288, device=dev()).to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(2048, sum(c.out_channels for c in convs), device=dev()).to(torch.bfloat16)
+    params = [trunk.weight, trunk.bias, bn.weight, bn.bias] + [t for c in convs for t in (c.weight, c.bias)]
+    state = {k: v.clone() for k, v in bn.state_dict().items()}
+
+    def run(deferred):
+        bn.load_state_dict(state)
+        for t in [x] + params:
+            t.grad = None
+        w = sa_fused.cat_params([c.weight.squeeze(-1) for c in convs])
+        b = sa_fused.cat_params([c.bias for c in convs])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = rows_mlp.run(x, [rows_mlp.Layer(trunk.weight, trunk.bias, bn), rows_mlp.Layer(w, b)], True)
+        if deferred:
+            with sa_fused.deferred_wgrads() as d:
+                y.backward(g)
+                assert len(d.items) == 2
+        else:
+            y.backward(g)
+        return [None if t.grad is None else t.grad.clone() for t in [x] + params]
+
+    now, later = run(False), run(True)
+    assert torch.equal(now[0], later[0])
+    for t, u, v in zip(params, now[1:], later[1:]):
+        assert u is not None and v is not None and v.shape == t.shape
+        assert rel_l2(v, u) < 1e-5 or float((v - u).abs().max()) < 1e-6, rel_l2(v, u)
