@@ -26,7 +26,6 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 constexpr int TBK = 32;            // positions per K-step
 constexpr int TPITCH = 144;        // bf16 per staged row: 128 channels + 16 pad (288 B: the 4 rows of a transpose read
                                    // start 8 banks apart, so its 16 lanes touch 32 distinct banks)
-constexpr int TCPITCH = 132;       // f32 C-tile pitch
 
 struct TnArgs {
   int M, N, P;        // C is M x N; P positions
@@ -40,10 +39,9 @@ struct TnArgs {
 // anyway (workgroups of the first N-tile only), instead of a separate pass over dY.
 __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
                                         float *__restrict__ part, float *__restrict__ colsum, const int id) {
-  constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 17408 bf16 = 34 KB
-  constexpr int CT_BYTES = 128 * TCPITCH * 4;                  // 66 KB
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES];
-  static_assert(STAGE_ELEMS * 2 <= CT_BYTES, "staging must fit under the C tile");
+  constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 18432 bf16 = 36 KB: four workgroups per CU
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_ELEMS * 2];
+  static_assert(16 * 128 * 4 <= STAGE_ELEMS * 2, "the column-sum fold aliases the staging buffers");
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
 
   // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8 picks the XCD and
@@ -90,11 +88,9 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
   // predicated dword loads.  Channel pieces past M / N only feed C entries that are never stored.
   const bool do_colsum = colsum != nullptr && nt == 0;
   uint4 ra[2], rb[2];
-  float csum[2][8];
+  float csum[8];               // both chunks of a thread cover the same 8 channels
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) csum[i][e] = 0.f;
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   int acol[2], bcol[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -115,8 +111,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
         const unsigned w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          csum[i][2 * e] += __builtin_bit_cast(float, w[e] << 16);
-          csum[i][2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+          csum[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+          csum[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
         }
       }
     }
@@ -180,7 +176,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
     float *red = reinterpret_cast<float *>(smem);            // [16][128]
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = csum[0][e] + csum[1][e];
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = csum[e];
     __syncthreads();
     if (tid < 128 && m0 + tid < g.M) {
       float t = 0.f;
@@ -190,29 +186,26 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
     }
     __syncthreads();
   }
-  float *ct = reinterpret_cast<float *>(smem);
+  // The f32 partial tile goes straight from the accumulators to memory: in the MFMA's C layout the 32 lanes of
+  // a half wave hold 32 consecutive columns of one row (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)),
+  // i.e. every store instruction writes two full 128-byte lines -- no transposition through LDS, which keeps the
+  // kernel's LDS at the 36 KB of staging.
+  float *C = part + (size_t)slab * g.M * g.N;
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      const int gc = n0 + wn * 64 + j * 32 + ccol;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
-        ct[row * TCPITCH + wn * 64 + j * 32 + ccol] = acc[i][j][r];
+        const int gr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+        if (gr < g.M && gc < g.N) C[(size_t)gr * g.N + gc] = acc[i][j][r];
       }
-  __syncthreads();
-  float *C = part + (size_t)slab * g.M * g.N;
-  for (int q = tid; q < 128 * 32; q += 256) {
-    const int row = q >> 5, piece = q & 31;
-    const int gr = m0 + row, gc = n0 + piece * 4;
-    if (gr < g.M && gc < g.N)
-      *reinterpret_cast<f32x4 *>(C + (size_t)gr * g.N + gc) =
-          *reinterpret_cast<const f32x4 *>(ct + row * TCPITCH + piece * 4);
-  }
+    }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
+__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         float *__restrict__ part, float *__restrict__ colsum) {
   tn_tile(g, A, B, part, colsum, (int)blockIdx.x);
@@ -244,7 +237,7 @@ struct TnGroupArgs {
 };
 static_assert(sizeof(TnGroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupArgs a) {
+__global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) {
   const int id = (int)blockIdx.x;
   int lo = 0, hi = a.n - 1;          // last item with wg_begin <= id
   while (lo < hi) {
@@ -310,12 +303,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int
 
 // C[M][N] (f32) = A[P][M]^T * B[P][N]; M, N multiples of 8; lda, ldb multiples of 8.
 // `workspace` must hold omnipq_gemm_tn_workspace_floats(M, N, P) floats.
-// How many slabs to cut the position axis into: enough workgroups to fill the chip (~512, two per CU), but every
-// workgroup keeps at least kMinSteps K-steps of work -- a slab costs a 64 KB f32 tile store plus its share of
-// the reduction, which dwarfs a one- or two-step main loop on the small per-point layers (P ~ 4096).
+// How many slabs to cut the position axis into: enough workgroups to fill the chip (~1024, four per CU: the
+// kernel is bound by the latency of its global loads, measured 232 -> 156 us on 512 x 256 x 262144 when the C
+// tile left LDS and occupancy doubled), but every workgroup keeps at least kMinSteps K-steps of work -- a slab
+// costs a 64 KB f32 tile store plus its share of the reduction, which dwarfs a one- or two-step main loop on
+// the small per-point layers (P ~ 4096).
 static int tn_slabs(int tiles, int P) {
   static const int kMinSteps = getenv("OMNIPQ_TN_MINSTEPS") ? atoi(getenv("OMNIPQ_TN_MINSTEPS")) : 6;
-  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 512;
+  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 1024;
   int slabs = (kTarget + tiles - 1) / tiles;
   const int max_slabs = (P + omnipq::TBK * kMinSteps - 1) / (omnipq::TBK * kMinSteps);
   if (slabs > max_slabs) slabs = max_slabs;
