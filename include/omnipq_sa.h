@@ -73,8 +73,22 @@ typedef struct {
   int out_rows, out_cols, out_ld;
   int flags;                 /* bit 0: add to out */
   int pad_;
+  const float *ba, *bb;      /* both NULL, or float[N]: B stands for relu(ba .* B + bb) (see ..._affine below) */
 } omnipq_tn_problem;
 long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);
+
+/* Conv + BatchNorm + ReLU stacks without the activation tensors: the GEMM that consumes X = relu(bn(Y)) reads the
+ * pre-BatchNorm output Y of the layer below and applies relu(a[k] * y + b[k]) (rounded to bf16 -- the values
+ * omnipq_bnrelu would have stored) between its global load and its LDS store.  Replaces the separate
+ * normalise+ReLU pass of pytorch_utils.py:39-64 (BatchNorm2d, ReLU after every Conv2d) and the write + read of X.
+ *   ..._nt_..._affine:  C = relu(a_in .* A + b_in) B^T (+ bias); sums != NULL: also the BatchNorm statistics of C
+ *                       (sums / workspace as omnipq_gemm_nt_bf16_stats)
+ *   ..._tn_..._affine:  C = A^T relu(ba .* B + bb) (+ colsum as omnipq_gemm_tn_bf16_colsum, may be NULL) */
+int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in, const float *b_in,
+                               const void *B, int ldb, void *C, int ldc, const float *bias, double *sums,
+                               float *workspace, void *stream);
+int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
+                               const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
 
 /* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares

@@ -51,13 +51,29 @@ struct BnBwdEpilogue {
   const float *a, *b, *mean, *invstd;
 };
 
-template <bool OUT_F32, int STATS = 0>
+// AFF: the A operand is the pre-BatchNorm output Y of the layer below and the kernel multiplies
+// relu(a[k] * Y[m][k] + b[k]) (rounded to bf16, exactly what the normalise+ReLU kernel would have stored) -- the
+// transform is applied between the global load and the LDS store of each tile, so the activations X = relu(bn(Y))
+// of a conv+BN+ReLU stack are never written to or read from memory.
+struct AffineIn {
+  const float *a, *b;       // [K]
+};
+
+__device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
+  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
+  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, __builtin_bit_cast(float, w & 0xffff0000u), b1), 0.f);
+  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+}
+
+template <bool OUT_F32, int STATS = 0, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
                                                         void *__restrict__ stats_out = nullptr,
-                                                        BnBwdEpilogue bn = BnBwdEpilogue()) {
+                                                        BnBwdEpilogue bn = BnBwdEpilogue(),
+                                                        AffineIn aff = AffineIn()) {
   // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
   constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
   constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
@@ -108,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   uint4 ra[2], rb[2];
+  f32x4 fa4[2], fb4[2];              // AFF: a, b of this thread's 8 channels of the K-step (both chunks share them)
   auto load_tiles = [&](int kt) {
     const int koff = kt * GBK;     // whole K-steps only: K and k_chunk are multiples of GBK
 #pragma unroll
@@ -115,10 +132,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       ra[i] = ldg16(ga[i] + koff);
       rb[i] = ldg16(gb[i] + koff);
     }
+    if (AFF) {
+      const int k0 = kbeg + koff + skc[0] * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        fa4[h] = *reinterpret_cast<const f32x4 *>(aff.a + k0 + 4 * h);
+        fb4[h] = *reinterpret_cast<const f32x4 *>(aff.b + k0 + 4 * h);
+      }
+    }
   };
   auto store_tiles = [&](int buf) {
     bf16_t *sa = stage + buf * (2 * 128 * GPITCH);
     bf16_t *sb = sa + 128 * GPITCH;
+    if (AFF) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ra[i].x = affine_relu_pair(ra[i].x, fa4[0][0], fb4[0][0], fa4[0][1], fb4[0][1]);
+        ra[i].y = affine_relu_pair(ra[i].y, fa4[0][2], fb4[0][2], fa4[0][3], fb4[0][3]);
+        ra[i].z = affine_relu_pair(ra[i].z, fa4[1][0], fb4[1][0], fa4[1][1], fb4[1][1]);
+        ra[i].w = affine_relu_pair(ra[i].w, fa4[1][2], fb4[1][2], fa4[1][3], fb4[1][3]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<uint4 *>(sa + srow[i] * GPITCH + skc[i] * 8) = ra[i];
@@ -418,6 +452,44 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
   if (!workspace) return OMNIPQ_EINVAL;
   gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
                                                               workspace);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  if (slabs < 1) slabs = 1;
+  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
+                                                                                    sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// C = relu(a_in .* A + b_in) B^T (+ bias), the A operand transformed on the fly (see AffineIn); with `sums`
+// (double[2][N], zero on entry) also the BatchNorm statistics of C as in omnipq_gemm_nt_bf16_stats.
+extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in,
+                                          const float *b_in, const void *B, int ldb, void *C, int ldc,
+                                          const float *bias, double *sums, float *workspace, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !a_in || !b_in || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  const AffineIn aff{a_in, b_in};
+  if (!sums) {
+    gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                      bias, nullptr, BnBwdEpilogue(), aff);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (g.m_tiles <= kStatsDirectTiles) {
+    gemm_nt_kernel<false, 1, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                      bias, sums, BnBwdEpilogue(), aff);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (!workspace) return OMNIPQ_EINVAL;
+  gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+                                                                    workspace, BnBwdEpilogue(), aff);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;

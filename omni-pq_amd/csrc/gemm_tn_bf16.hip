@@ -12,6 +12,8 @@
 // f32 partial tile, a second kernel sums the slabs (deterministic, no atomics).
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace omnipq {
@@ -37,8 +39,20 @@ struct TnArgs {
 // colsum (may be NULL): float[M], receives (ADDED, f32 atomics) the column sums of A over all positions --
 // the bias gradient that goes with a weight gradient dW = dY^T X, taken from the A tiles the kernel stages
 // anyway (workgroups of the first N-tile only), instead of a separate pass over dY.
+// AFFB: the B operand is the pre-BatchNorm output Y of the layer below and the kernel contracts against
+// relu(ba[n] * Y[p][n] + bb[n]) rounded to bf16 -- the activations that layer's normalise+ReLU pass would have
+// stored, rebuilt between the global load and the LDS store (see gemm_bf16.hip: AffineIn).
+__device__ __forceinline__ unsigned tn_affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
+  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
+  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, __builtin_bit_cast(float, w & 0xffff0000u), b1), 0.f);
+  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+}
+
+template <bool AFFB>
 __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
-                                        float *__restrict__ part, float *__restrict__ colsum, const int id) {
+                                        float *__restrict__ part, float *__restrict__ colsum, const int id,
+                                        const float *__restrict__ ba = nullptr, const float *__restrict__ bb = nullptr) {
   constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 18432 bf16 = 36 KB: four workgroups per CU
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_ELEMS * 2];
   static_assert(16 * 128 * 4 <= STAGE_ELEMS * 2, "the column-sum fold aliases the staging buffers");
@@ -97,16 +111,41 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
     acol[i] = aok[i] ? m0 + sc8[i] * 8 : 0;
     bcol[i] = bok[i] ? n0 + sc8[i] * 8 : 0;
   }
+  float fa8[8], fb8[8];        // AFFB: a, b of this thread's 8 B channels (the same for both chunks)
+  if (AFFB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fa8[e] = ba[bcol[0] + e];
+      fb8[e] = bb[bcol[0] + e];
+    }
+  }
+  // Everything that CONSUMES the loaded registers (tail mask, column sums, the affine transform) happens in
+  // store_tiles, i.e. after the MFMAs of the current K-step: the loads stay in flight underneath them.
+  unsigned keep[2];
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = pbeg + kt * TBK + spos[i];
-      const unsigned keep = p < pend ? 0xFFFFFFFFu : 0u;
+      keep[i] = p < pend ? 0xFFFFFFFFu : 0u;
       const int pc = p < pend ? p : g.P - 1;
       ra[i] = *reinterpret_cast<const uint4 *>(A + (size_t)pc * g.lda + acol[i]);
       rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)pc * g.ldb + bcol[i]);
-      ra[i].x &= keep; ra[i].y &= keep; ra[i].z &= keep; ra[i].w &= keep;
-      rb[i].x &= keep; rb[i].y &= keep; rb[i].z &= keep; rb[i].w &= keep;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
+    bf16_t *sb = sa + TBK * TPITCH;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (AFFB) {
+        rb[i].x = tn_affine_relu_pair(rb[i].x, fa8[0], fb8[0], fa8[1], fb8[1]);
+        rb[i].y = tn_affine_relu_pair(rb[i].y, fa8[2], fb8[2], fa8[3], fb8[3]);
+        rb[i].z = tn_affine_relu_pair(rb[i].z, fa8[4], fb8[4], fa8[5], fb8[5]);
+        rb[i].w = tn_affine_relu_pair(rb[i].w, fa8[6], fb8[6], fa8[7], fb8[7]);
+      }
+      const unsigned k = keep[i];
+      ra[i].x &= k; ra[i].y &= k; ra[i].z &= k; ra[i].w &= k;
+      rb[i].x &= k; rb[i].y &= k; rb[i].z &= k; rb[i].w &= k;
       if (do_colsum) {
         const unsigned w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
@@ -115,13 +154,6 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
           csum[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
         }
       }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
-    bf16_t *sb = sa + TBK * TPITCH;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<uint4 *>(sa + spos[i] * TPITCH + sc8[i] * 8) = ra[i];
       *reinterpret_cast<uint4 *>(sb + spos[i] * TPITCH + sc8[i] * 8) = rb[i];
     }
@@ -208,7 +240,15 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
 __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         float *__restrict__ part, float *__restrict__ colsum) {
-  tn_tile(g, A, B, part, colsum, (int)blockIdx.x);
+  tn_tile<false>(g, A, B, part, colsum, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_tn_affine_kernel(TnArgs g, const bf16_t *__restrict__ A,
+                                                               const bf16_t *__restrict__ B,
+                                                               float *__restrict__ part, float *__restrict__ colsum,
+                                                               const float *__restrict__ ba,
+                                                               const float *__restrict__ bb) {
+  tn_tile<true>(g, A, B, part, colsum, (int)blockIdx.x, ba, bb);
 }
 
 // ---- grouped launch: many independent weight gradients in one grid ------------------------------------------
@@ -218,10 +258,11 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const bf16_t 
 // depends on a weight gradient until the optimizer, so they are collected during backward and run here as ONE
 // grid (descriptors by value in the kernel arguments, <= kGroupMax per launch), followed by ONE reduction that
 // also crops the padded rows / columns and writes the gradient in the parameter's own shape.
-constexpr int kGroupMax = 36;
+constexpr int kGroupMax = 32;
 struct TnGroupItem {
   const bf16_t *A, *B;
   float *part, *colsum, *out;
+  const float *ba, *bb;         // AFFB launches only
   int M, N, P, lda, ldb, p_chunk, m_tiles, n_tiles;
   int wg_begin;                 // first workgroup of this problem (multiple of 8: the XCD mapping above stays valid)
   int slabs;                    // slabs in use
@@ -237,7 +278,8 @@ struct TnGroupArgs {
 };
 static_assert(sizeof(TnGroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) {
+template <bool AFFB>
+__global__ __launch_bounds__(256, AFFB ? 3 : 4) void gemm_tn_grouped_kernel(TnGroupArgs a) {
   const int id = (int)blockIdx.x;
   int lo = 0, hi = a.n - 1;          // last item with wg_begin <= id
   while (lo < hi) {
@@ -246,7 +288,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) 
   }
   const TnGroupItem &it = a.item[lo];
   const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles};
-  tn_tile(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin);
+  tn_tile<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
 }
 
 // out[r][c] (+)= sum over slabs of part[z][r][c], r < out_rows, c < out_cols: fixed order, no atomics
@@ -326,11 +368,11 @@ extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
 }
 
 static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
-                        float *workspace, float *colsum, void *stream);
+                        float *workspace, float *colsum, const float *ba, const float *bb, void *stream);
 
 extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                    float *C, float *workspace, void *stream) {
-  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, nullptr, stream);
+  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, nullptr, nullptr, nullptr, stream);
 }
 
 // The same, and colsum[m] += sum_p A[p][m] (f32, zero or a running total on entry): weight and bias gradient
@@ -338,11 +380,20 @@ extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, 
 extern "C" int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                           float *C, float *workspace, float *colsum, void *stream) {
   if (!colsum) return OMNIPQ_EINVAL;
-  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, stream);
+  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, nullptr, nullptr, stream);
+}
+
+// C = A^T relu(ba .* B + bb): the B operand (activations of a conv+BN+ReLU layer) rebuilt from that layer's
+// pre-BatchNorm output on the fly; colsum may be NULL.
+extern "C" int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
+                                          const float *ba, const float *bb, float *C, float *workspace,
+                                          float *colsum, void *stream) {
+  if (!ba || !bb) return OMNIPQ_EINVAL;
+  return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, ba, bb, stream);
 }
 
 static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
-                        float *workspace, float *colsum, void *stream) {
+                        float *workspace, float *colsum, const float *ba, const float *bb, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || P < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -353,7 +404,11 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
   const int used = P > 0 ? (P + g.p_chunk - 1) / g.p_chunk : 1;
   dim3 grid(tiles * ((used + 7) / 8) * 8);
-  gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace, colsum);
+  if (ba)
+    gemm_tn_affine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
+                                                               colsum, ba, bb);
+  else
+    gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace, colsum);
   OMNIPQ_LAUNCH_CHECK();
   const int n4 = M * N / 4;        // M, N multiples of 8
   const f32x4 *part = reinterpret_cast<const f32x4 *>(workspace);
@@ -382,6 +437,7 @@ struct omnipq_tn_problem_ {
   int out_rows, out_cols, out_ld;
   int flags;                // bit 0: out += C
   int pad_;
+  const float *ba, *bb;     // NULL, or: B stands for relu(ba .* B + bb)
 };
 
 static int tng_chunk() {
@@ -411,42 +467,61 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
   for (int i = 0; i < nprob; ++i) {
     const omnipq_tn_problem_ &q = pr[i];
     if (q.M <= 0 || q.N <= 0 || q.P < 0 || (q.P > 0 && (!q.A || !q.B)) || !q.out || (q.M % 8) || (q.N % 8) || (q.lda % 8) || (q.ldb % 8) ||
-        q.out_rows <= 0 || q.out_cols <= 0 || q.out_rows > q.M || q.out_cols > q.N || q.out_ld < q.out_cols)
+        q.out_rows <= 0 || q.out_cols <= 0 || q.out_rows > q.M || q.out_cols > q.N || q.out_ld < q.out_cols ||
+        ((q.ba != nullptr) != (q.bb != nullptr)))
       return OMNIPQ_EINVAL;
   }
-  float *ws = workspace;
-  for (int first = 0; first < nprob; first += kGroupMax) {
-    TnGroupArgs a;
-    a.n = nprob - first < kGroupMax ? nprob - first : kGroupMax;
-    a.pad_ = 0;
-    int wg = 0, blk = 0;
-    for (int i = 0; i < a.n; ++i) {
-      const omnipq_tn_problem_ &q = pr[first + i];
-      TnGroupItem &it = a.item[i];
-      it.A = (const bf16_t *)q.A;
-      it.B = (const bf16_t *)q.B;
-      it.part = ws;
-      it.colsum = q.colsum;
-      it.out = q.out;
-      it.M = q.M; it.N = q.N; it.P = q.P; it.lda = q.lda; it.ldb = q.ldb;
-      it.m_tiles = (q.M + 127) / 128;
-      it.n_tiles = (q.N + 127) / 128;
-      const int slabs = tng_slabs(q.P);
-      it.p_chunk = (((q.P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
-      it.slabs = q.P > 0 ? (q.P + it.p_chunk - 1) / it.p_chunk : 1;
-      it.wg_begin = wg;
-      wg += it.m_tiles * it.n_tiles * ((it.slabs + 7) / 8) * 8;
-      it.out_rows = q.out_rows; it.out_cols = q.out_cols; it.out_ld = q.out_ld;
-      it.blk_begin = blk;
-      blk += (q.out_rows * q.out_cols + 255) / 256;
-      it.flags = q.flags;
-      it.pad_ = 0;
-      ws += (size_t)slabs * q.M * q.N;
+  // workspace offsets follow the problem order (as omnipq_gemm_tn_grouped_workspace_floats counts them)
+  size_t off = 0;
+  static thread_local std::vector<size_t> ws_off;
+  ws_off.resize(nprob);
+  for (int i = 0; i < nprob; ++i) {
+    ws_off[i] = off;
+    off += (size_t)tng_slabs(pr[i].P) * pr[i].M * pr[i].N;
+  }
+  for (int pass = 0; pass < 2; ++pass) {              // plain problems, then the ones with a transformed B operand
+    int next = 0;
+    for (;;) {
+      TnGroupArgs a;
+      a.n = 0;
+      a.pad_ = 0;
+      int wg = 0, blk = 0;
+      while (next < nprob && a.n < kGroupMax) {
+        const omnipq_tn_problem_ &q = pr[next];
+        if ((q.ba != nullptr) == (pass == 1)) {
+          TnGroupItem &it = a.item[a.n++];
+          it.A = (const bf16_t *)q.A;
+          it.B = (const bf16_t *)q.B;
+          it.part = workspace + ws_off[next];
+          it.colsum = q.colsum;
+          it.out = q.out;
+          it.ba = q.ba;
+          it.bb = q.bb;
+          it.M = q.M; it.N = q.N; it.P = q.P; it.lda = q.lda; it.ldb = q.ldb;
+          it.m_tiles = (q.M + 127) / 128;
+          it.n_tiles = (q.N + 127) / 128;
+          const int slabs = tng_slabs(q.P);
+          it.p_chunk = (((q.P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
+          it.slabs = q.P > 0 ? (q.P + it.p_chunk - 1) / it.p_chunk : 1;
+          it.wg_begin = wg;
+          wg += it.m_tiles * it.n_tiles * ((it.slabs + 7) / 8) * 8;
+          it.out_rows = q.out_rows; it.out_cols = q.out_cols; it.out_ld = q.out_ld;
+          it.blk_begin = blk;
+          blk += (q.out_rows * q.out_cols + 255) / 256;
+          it.flags = q.flags;
+          it.pad_ = 0;
+        }
+        ++next;
+      }
+      if (a.n == 0) break;
+      if (pass == 0)
+        gemm_tn_grouped_kernel<false><<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
+      else
+        gemm_tn_grouped_kernel<true><<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
+      OMNIPQ_LAUNCH_CHECK();
+      tn_grouped_reduce_kernel<<<dim3(blk), 256, 0, (hipStream_t)stream>>>(a);
+      OMNIPQ_LAUNCH_CHECK();
     }
-    gemm_tn_grouped_kernel<<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
-    OMNIPQ_LAUNCH_CHECK();
-    tn_grouped_reduce_kernel<<<dim3(blk), 256, 0, (hipStream_t)stream>>>(a);
-    OMNIPQ_LAUNCH_CHECK();
   }
   return OMNIPQ_OK;
 }

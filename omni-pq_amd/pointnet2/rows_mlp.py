@@ -103,20 +103,24 @@ class RowsMLP(torch.autograd.Function):
             if lay.has_bn and lay.Cp != cout:
                 raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
             sums = None
+            below = layers[-1] if (X is None) else None      # the layer below kept only (Y, a, b): see sa_fused
             if lay.has_bn and training:
                 sums = zeros_f64(2, cout, dev)
-                Y = _gemm_nt_stats(X, lay.Wp, N, lay.Cp, K, sums)
+                if below is not None:
+                    Y = sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, sums=sums)
+                else:
+                    Y = _gemm_nt_stats(X, lay.Wp, N, lay.Cp, K, sums)
             else:
                 Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
-            if sums is not None:
-                pass
-            elif lay.has_bias and not lay.has_bn:
-                bp = bias.detach().float()
-                if lay.Cp != cout:
-                    bp = torch.nn.functional.pad(bp, (0, lay.Cp - cout))
-                sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K, bias=bp)
-            else:
-                sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K)
+                bp = None
+                if lay.has_bias and not lay.has_bn:
+                    bp = bias.detach().float()
+                    if lay.Cp != cout:
+                        bp = torch.nn.functional.pad(bp, (0, lay.Cp - cout))
+                if below is not None:
+                    sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, bias=bp, out=Y)
+                else:
+                    sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K, bias=bp)
             lay.Y = Y
             if lay.has_bn:
                 rm, rv, nbt, momentum, eps = spec[l]
@@ -125,10 +129,18 @@ class RowsMLP(torch.autograd.Function):
                     stats = torch.empty((4, cout), device=dev)            # a | b | mean | invstd
                     lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
                     cb = bias.detach().float().contiguous() if lay.has_bias else None
-                    lay.X = torch.empty_like(Y)
-                    _call(_lib.omnipq_bn_finalize_relu, X, ctypes.c_longlong(N), cout, ctypes.c_double(float(N) * world),
-                          _p(sums), _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
-                          _p(rm), _p(rv), _p(cb), _p(Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd))
+                    if l < L - 1 and sa_fused.affine_pays(N, params[4 * (l + 1)].shape[0]):
+                        # relu(bn(Y)) is never stored: the next layer's GEMM and this layer's consumers in backward
+                        # rebuild it from (Y, a, b) while staging their operand
+                        _call(_lib.omnipq_bn_finalize, Y, cout, ctypes.c_double(float(N) * world), _p(sums),
+                              _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                              _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(cb))
+                        lay.X = None
+                    else:
+                        lay.X = torch.empty_like(Y)
+                        _call(_lib.omnipq_bn_finalize_relu, Y, ctypes.c_longlong(N), cout, ctypes.c_double(float(N) * world),
+                              _p(sums), _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
+                              _p(rm), _p(rv), _p(cb), _p(Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd))
                     sa_fused.bump(nbt)
                 else:
                     lay.invstd = torch.rsqrt(rv + eps)
@@ -138,7 +150,7 @@ class RowsMLP(torch.autograd.Function):
                     lay.b = (beta.detach() - shift * lay.a).contiguous()
                 if not training:
                     lay.X = torch.empty_like(Y)
-                    _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
+                    _call(_lib.omnipq_bnrelu, Y, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
                 X = lay.X
             else:
                 if lay.act is not None:
@@ -184,6 +196,10 @@ class RowsMLP(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             lay = layers[l]
             Xin = layers[l - 1].X if l > 0 else ctx.X0
+            below = None
+            if Xin is None:                    # rebuilt from the layer's pre-BN output inside the GEMM
+                below = layers[l - 1]
+                Xin = below.Y
             if lay.has_bn:
                 if sums is None:
                     sums = zeros_f64(3, lay.C, dev)
@@ -206,13 +222,13 @@ class RowsMLP(torch.autograd.Function):
             if wt is not None and ctx.needs_input_grad[3 + 4 * l] and (
                     not want_bias or (sa_fused.bias_target_ok(bt, lay.C, lay.Cp) and ctx.needs_input_grad[4 + 4 * l])):
                 # collected; computed with all the others when the deferred_wgrads block ends
-                dfr.add(dcur, Xin, lay.Cp, lay.K, N, wt, (lay.C, lay.wk), bt if want_bias else None)
+                dfr.add(dcur, Xin, lay.Cp, lay.K, N, wt, (lay.C, lay.wk), bt if want_bias else None, below)
             else:
                 bsum = None
                 if want_bias:
                     bsum = zeros_f32(lay.Cp, dev)            # bias gradient: column sums of dY, from the same pass
                     grads[4 * l + 1] = bsum[:lay.C]
-                dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum)
+                dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum, below=below)
                 grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None
             if l > 0 and layers[l - 1].has_bn:

@@ -17,6 +17,7 @@ statistics are f32 per block / f64 across blocks.  This is the `bf16` compute mo
 parity mode keeps the reference's op-by-op composition (pointnet2_modules.py).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -127,6 +128,38 @@ def _gemm_nt_stats(A, B, M, N, K, sums, bias=None):
     return C
 
 
+# Conv+BN+ReLU stacks without stored activations: the consumer GEMMs rebuild X = relu(a y + b) from the layer's
+# pre-BN output while staging their operand (csrc: AffineIn / AFFB).  OMNIPQ_AFFINE=0 restores the separate
+# normalise+ReLU pass (kept for the parity tests and A/B timing).
+AFFINE_OPERANDS = os.environ.get("OMNIPQ_AFFINE", "1") != "0"
+
+
+def affine_pays(P, N):
+    """Rebuilding relu(bn(Y)) inside the consumer GEMMs costs VALU work per staged element, once per N-tile of the
+    consumer (measured, P x 128 rows: +62 us on the forward GEMM and +12 us on the weight gradient against a 100 us
+    normalise+ReLU pass at P = 1 M, N = 128; but +47 and +50 us against 40 us at P = 262 k, N = 512).  It pays where
+    the consumer has one or two N-tiles over many positions (sa1), and on the small per-point stacks where a launch
+    costs more than the transform (P <= 16 k rows: heads, position embeddings, voting, FP)."""
+    mode = os.environ.get("OMNIPQ_AFFINE", "1")
+    if not AFFINE_OPERANDS:
+        return False
+    if mode == "all":
+        return True
+    return P <= 16384 or (P >= (1 << 19) and N <= 256)
+
+
+def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None):
+    """bf16 C = relu(below.a * Y + below.b) Bw^T (+ bias); sums (f64 [2][N], zero on entry): also C's statistics."""
+    C = torch.empty((M, N), device=Y.device, dtype=torch.bfloat16) if out is None else out
+    ws = None
+    if sums is not None:
+        n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
+        ws = torch.empty((n_ws,), device=Y.device, dtype=torch.float32) if n_ws else None
+    _call(_lib.omnipq_gemm_nt_bf16_affine, Y, M, N, K, _p(Y), K, _p(below.a), _p(below.b), _p(Bw), K, _p(C), N,
+          _p(bias), _p(sums), _p(ws))
+    return C
+
+
 def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     """dX = dY Wt^T (bf16 [M][N]) and, in the same pass, the BatchNorm-backward sums of the layer `below`
     (its pre-BN output Y and constants a, b, mean, invstd) into sums (f64 [>=2][N], zero on entry)."""
@@ -138,11 +171,15 @@ def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     return C
 
 
-def _gemm_tn(A, B, M, N, P, colsum=None):
-    """f32 C[M][N] = A[P][M]^T B[P][N]; colsum (f32 [M], zero on entry): also += column sums of A"""
+def _gemm_tn(A, B, M, N, P, colsum=None, below=None):
+    """f32 C[M][N] = A[P][M]^T B[P][N]; colsum (f32 [M], zero on entry): also += column sums of A;
+    below: B is that layer's pre-BN output and stands for relu(below.a * B + below.b)"""
     C = torch.empty((M, N), device=A.device, dtype=torch.float32)
     ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=A.device, dtype=torch.float32)
-    if colsum is None:
+    if below is not None:
+        _call(_lib.omnipq_gemm_tn_bf16_affine, A, M, N, P, _p(A), M, _p(B), N, _p(below.a), _p(below.b), _p(C), _p(ws),
+              _p(colsum))
+    elif colsum is None:
         _call(_lib.omnipq_gemm_tn_bf16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
     else:
         _call(_lib.omnipq_gemm_tn_bf16_colsum, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws), _p(colsum))
@@ -154,7 +191,7 @@ class _TnProblem(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
                 ("out_rows", ctypes.c_int), ("out_cols", ctypes.c_int), ("out_ld", ctypes.c_int),
-                ("flags", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p)]
 
 
 _lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
@@ -218,8 +255,9 @@ class deferred_wgrads:
         deferred_wgrads.active = self
         return self
 
-    def add(self, dY, X, M, N, P, wt, crop, bt):
-        self.items.append((dY, X, M, N, P, wt, crop, bt))
+    def add(self, dY, X, M, N, P, wt, crop, bt, below=None):
+        """below: X is that layer's pre-BN output and stands for relu(below.a * X + below.b)"""
+        self.items.append((dY, X, M, N, P, wt, crop, bt, None if below is None else (below.a, below.b)))
 
     def __exit__(self, et, ev, tb):
         deferred_wgrads.active = None
@@ -246,9 +284,10 @@ class deferred_wgrads:
             return ent
 
         probs = (_TnProblem * len(items))()
-        for i, (dY, X, M, N, P, wt, (cout, cin), bt) in enumerate(items):
+        for i, (dY, X, M, N, P, wt, (cout, cin), bt, aff) in enumerate(items):
             q = probs[i]
             q.A, q.B = dY.data_ptr(), X.data_ptr()
+            q.ba, q.bb = (0, 0) if aff is None else (aff[0].data_ptr(), aff[1].data_ptr())
             q.M, q.N, q.P, q.lda, q.ldb = M, N, P, dY.stride(0), X.stride(0)
             q.out_rows, q.out_cols, q.out_ld, q.flags, q.colsum = cout, cin, cin, 0, 0
             if wt[0] == "param":
@@ -591,11 +630,16 @@ class FusedSAStage(torch.autograd.Function):
                                          persistent=is_persistent(W))
             if training:
                 sums = zeros_f64(2, cout, dev)
-                lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums)         # GEMM + batch statistics
+                if l > 0 and X is None:
+                    # the layer below never stored relu(bn(Y)): this GEMM rebuilds it while staging its operand
+                    lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums)
+                else:
+                    lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums)     # GEMM + batch statistics
                 _allreduce_(sums)
                 stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
                 lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
-                fused_relu = l < L - 1
+                keep_y_only = l < L - 1 and affine_pays(P, params[3 * (l + 1)].shape[0])
+                fused_relu = l < L - 1 and not keep_y_only
                 if fused_relu:
                     # finalize + normalise + ReLU in one launch
                     lay.X = torch.empty_like(lay.Y)
@@ -604,7 +648,7 @@ class FusedSAStage(torch.autograd.Function):
                           _p(rm), _p(rv), _p(None), _p(lay.Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean),
                           _p(lay.invstd))
                 else:
-                    _call(_lib.omnipq_bn_finalize, X, cout, ctypes.c_double(float(P) * world), _p(sums),
+                    _call(_lib.omnipq_bn_finalize, lay.Y, cout, ctypes.c_double(float(P) * world), _p(sums),
                           _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
                           _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(None))
                 bump(nbt)
@@ -615,10 +659,12 @@ class FusedSAStage(torch.autograd.Function):
                 lay.mean = rm
                 lay.a = (gamma.detach() * lay.invstd).contiguous()
                 lay.b = (beta.detach() - rm * lay.a).contiguous()
-            if l < L - 1:
+            if l < L - 1 and training and keep_y_only:
+                lay.X = X = None            # consumers take (Y, a, b)
+            elif l < L - 1:
                 if not fused_relu:
                     lay.X = torch.empty_like(lay.Y)
-                    _call(_lib.omnipq_bnrelu, X, ctypes.c_longlong(P), cout, _p(lay.Y), _p(lay.a), _p(lay.b),
+                    _call(_lib.omnipq_bnrelu, lay.Y, ctypes.c_longlong(P), cout, _p(lay.Y), _p(lay.a), _p(lay.b),
                           _p(lay.X))
                 X = lay.X
             else:
@@ -629,7 +675,7 @@ class FusedSAStage(torch.autograd.Function):
         out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
         out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
         arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
-        _call(_lib.omnipq_sa_pool, X, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm),
+        _call(_lib.omnipq_sa_pool, last.Y, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm),
               _p(arg))
         # reference layout (B, C, M) as a VIEW of the position-major result: values, shape and dtype are
         # the reference's, only the strides differ (no transpose pass; every consumer on this path
@@ -679,8 +725,10 @@ class FusedSAStage(torch.autograd.Function):
         d_feat = d_xyz = d_cen = None
         for l in range(L - 1, -1, -1):
             lay = layers[l]
-            Xin = layers[l - 1].X if l > 0 else ctx.X0
-            dWp = _gemm_tn(dY, Xin, lay.C, lay.K, P)                        # [Cout][K]
+            if l > 0 and layers[l - 1].X is None:
+                dWp = _gemm_tn(dY, layers[l - 1].Y, lay.C, lay.K, P, below=layers[l - 1])
+            else:
+                dWp = _gemm_tn(dY, layers[l - 1].X if l > 0 else ctx.X0, lay.C, lay.K, P)      # [Cout][K]
             wk = cin + 3 if l == 0 else lay.K
             grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
             need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \

@@ -431,3 +431,107 @@ def test_interp_rows_kernels_match_torch(B, n, m, C, extra):
     tot = g.double().sum(0) + 1.0
     assert float((s64 - tot).abs().max()) < 1e-4 * (1 + float(tot.abs().max()))
     assert float((s32.double() - tot).abs().max()) < 1e-3 * (1 + float(tot.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K,stats,bias", [(100, 128, 32, True, False), (2048, 288, 288, True, True),
+                                             (8320, 128, 256, True, False), (4096, 96, 288, False, True),
+                                             (333, 544, 64, False, False)])
+def test_gemm_nt_affine_operand_equals_the_materialised_activations(M, N, K, stats, bias):
+    """relu(a * Y + b) built inside the GEMM's operand staging == omnipq_bnrelu followed by the plain GEMM: the same
+    bf16 activations enter the MFMAs, so outputs (and the statistics epilogue) are the same bits."""
+    gen = torch.Generator().manual_seed(M + N + K + 7)
+    Y = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+    W = (torch.randn((N, K), generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev())
+    a = (0.5 + torch.rand(K, generator=gen)).to(dev()) * torch.where(torch.rand(K, generator=gen) < 0.2, -1.0, 1.0).to(dev())
+    b = (0.3 * torch.randn(K, generator=gen)).to(dev())
+    bvec = torch.randn(N, generator=gen).to(dev()) if bias else None
+    X = torch.empty_like(Y)
+    capi.ok("omnipq_bnrelu", ctypes.c_longlong(M), K, capi.P(Y), capi.P(a), capi.P(b), capi.P(X))
+    want = torch.empty((M, N), device=dev(), dtype=torch.bfloat16)
+    null = ctypes.c_void_p(0)
+    capi.lib().omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
+    ws = torch.empty(max(int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N)), 1), device=dev())
+    want_sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+    if stats:
+        capi.ok("omnipq_gemm_nt_bf16_stats", M, N, K, capi.P(X), K, capi.P(W), K, capi.P(want), N,
+                capi.P(bvec) if bias else null, capi.P(want_sums), capi.P(ws))
+    else:
+        capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(X), K, capi.P(W), K, capi.P(want), N,
+                capi.P(bvec) if bias else null)
+    got = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+    capi.ok("omnipq_gemm_nt_bf16_affine", M, N, K, capi.P(Y), K, capi.P(a), capi.P(b), capi.P(W), K, capi.P(got), N,
+            capi.P(bvec) if bias else null, capi.P(sums) if stats else null, capi.P(ws))
+    assert torch.equal(got, want)
+    if stats:
+        scale = want_sums.abs().max(dim=1, keepdim=True).values + 1e-3
+        assert float(((sums - want_sums).abs() / scale).max()) < 1e-6
+    # and against f64 torch on the rounded activations
+    ref = X.double() @ W.double().t() + (bvec.double() if bias else 0.0)
+    assert float((got.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("P,M,N,colsum", [(1000, 72, 40, False), (8192, 256, 128, True), (5000, 288, 320, True),
+                                          (33, 128, 32, False)])
+def test_gemm_tn_affine_operand_equals_the_materialised_activations(P, M, N, colsum):
+    gen = torch.Generator().manual_seed(P + M + N + 3)
+    dY = torch.randn((P, M), generator=gen).to(torch.bfloat16).to(dev())
+    Y = torch.randn((P, N), generator=gen).to(torch.bfloat16).to(dev())
+    a = (0.5 + torch.rand(N, generator=gen)).to(dev()) * torch.where(torch.rand(N, generator=gen) < 0.2, -1.0, 1.0).to(dev())
+    b = (0.3 * torch.randn(N, generator=gen)).to(dev())
+    X = torch.empty_like(Y)
+    capi.ok("omnipq_bnrelu", ctypes.c_longlong(P), N, capi.P(Y), capi.P(a), capi.P(b), capi.P(X))
+    capi.lib().omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
+    ws = torch.empty(int(capi.lib().omnipq_gemm_tn_workspace_floats(M, N, P)), device=dev())
+    want = torch.empty((M, N), device=dev())
+    capi.ok("omnipq_gemm_tn_bf16", M, N, P, capi.P(dY), M, capi.P(X), N, capi.P(want), capi.P(ws))
+    got = torch.full((M, N), float("nan"), device=dev())
+    cs = torch.zeros(M, device=dev()) if colsum else None
+    capi.ok("omnipq_gemm_tn_bf16_affine", M, N, P, capi.P(dY), M, capi.P(Y), N, capi.P(a), capi.P(b), capi.P(got),
+            capi.P(ws), capi.P(cs) if colsum else ctypes.c_void_p(0))
+    assert torch.equal(got, want)
+    ref = dY.double().t() @ X.double()
+    assert float((got.double() - ref).abs().max()) < 1e-5 * (float(ref.abs().max()) + 1.0) * P ** 0.5
+    if colsum:
+        assert float((cs.double() - dY.double().sum(0)).abs().max()) < 1e-4 * (float(dY.double().sum(0).abs().max()) + 1.0)
+
+
+def test_stacks_without_stored_activations_equal_the_materialised_dataflow(monkeypatch):
+    """sa_fused.AFFINE_OPERANDS: rows_mlp stacks and the fused SA stage with relu(bn(Y)) rebuilt inside the consumer
+    GEMMs give the outputs, input gradients and parameter gradients of the dataflow that stores the activations
+    (the same bf16 values enter every MFMA; only f32 summation orders of the deferred paths may differ)."""
+    import rows_mlp
+    import sa_fused
+    torch.manual_seed(5)
+    d = dev()
+    lins = [torch.nn.Conv1d(288, 288, 1).to(d), torch.nn.Conv1d(288, 288, 1).to(d), torch.nn.Conv1d(288, 97, 1).to(d)]
+    bns = [torch.nn.BatchNorm1d(288).to(d), torch.nn.BatchNorm1d(288).to(d), None]
+    for bn in bns[:2]:
+        with torch.no_grad():
+            bn.weight.uniform_(-1.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(4096, 288, device=d).requires_grad_(True)
+    g = torch.randn(4096, 97, device=d).to(torch.bfloat16)
+    params = [t for l_ in lins for t in (l_.weight, l_.bias)] + [t for bn in bns[:2] for t in (bn.weight, bn.bias)]
+    state = [{k: v.clone() for k, v in bn.state_dict().items()} for bn in bns[:2]]
+
+    def run(flag):
+        monkeypatch.setattr(sa_fused, "AFFINE_OPERANDS", flag)
+        for bn, st in zip(bns[:2], state):
+            bn.load_state_dict(st)
+        for t in [x] + params:
+            t.grad = None
+        stack = [rows_mlp.Layer(l_.weight, l_.bias, bn) for l_, bn in zip(lins, bns)]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = rows_mlp.run(x, stack, True)
+        y.backward(g)
+        return y.detach().clone(), [t.grad.clone() for t in [x] + params], [bn.running_var.clone() for bn in bns[:2]]
+
+    y1, g1, rv1 = run(True)
+    y0, g0, rv0 = run(False)
+    assert torch.equal(y1, y0)
+    assert torch.equal(g1[0], g0[0])                 # input gradient: same bits
+    for u, v in zip(g1[1:], g0[1:]):                 # f32 atomics (bias column sums) and f64 atomics (BN sums) may
+        assert rel_l2(u, v) < 1e-6                   # land in a different order from run to run
+    for u, v in zip(rv1, rv0):
+        assert rel_l2(u, v) < 1e-6
