@@ -53,10 +53,14 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
+    ap.add_argument("--eager-dp", default="flat", choices=["flat", "ddp"],
+                    help="data parallelism of EAGER multi-rank steps (the fallback when RCCL cannot be captured): "
+                         "flat = SyncBN all-reduces + one flat gradient all-reduce after backward, as in the captured "
+                         "step; ddp = torch DistributedDataParallel (train.py:382)")
     ap.add_argument("--graph", default="auto", choices=["auto", "off", "on"],
                     help="replay the whole fwd+bwd step from a captured hipGraph; auto = on for a single "
                          "process and, under torch.distributed, on iff tools/rccl_graph_probe.py shows that RCCL "
-                         "collectives replay correctly from a graph on this node (else eager DDP)")
+                         "collectives replay correctly from a graph on this node (else eager, see --eager-dp)")
     ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--breakdown", action="store_true", help="print a per-operator table to stderr")
     ap.add_argument("--mean-teacher", action="store_true",
@@ -319,7 +323,7 @@ EMA_DECAY, EMA_STEP = 0.999, 100_000          # steady state of train.py:437: al
 
 
 def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_graph=False, teacher=None,
-              teacher_pool=None):
+              teacher_pool=None, ddp=False):
     """-> (step(i) -> loss tensor, launch mode string).  Eager: forward, loss, prefetch of the next
     batch's sampling, backward.  Graph: the same sequence captured once and replayed -- always for a
     single process; under torch.distributed only when `dist_graph` (the probe passed), with the
@@ -328,8 +332,10 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             return teacher({"point_clouds": batch})            # train mode, no grad (train.py:462,490-491)
 
-    # DistributedDataParallel (the eager multi-rank fallback) needs the per-parameter hooks: no deferral there
-    defer = os.environ.get("OMNIPQ_DEFER_WGRADS", "1") != "0" and not (distributed and not dist_graph)
+    # DistributedDataParallel (--eager-dp ddp) needs the per-parameter hooks: no deferral there
+    defer = os.environ.get("OMNIPQ_DEFER_WGRADS", "1") != "0" and not ddp
+    # eager multi-rank steps without DDP: the same single flat all-reduce as in the captured step
+    flat_eager = FlatGradients(net, world) if (distributed and not ddp) else None
 
     def backward(loss):
         if defer:
@@ -355,6 +361,8 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             if teacher is not None:
                 teacher.prefetch({"point_clouds": teacher_pool[(i + 1) % len(teacher_pool)]})
         backward(loss)
+        if flat_eager is not None:
+            flat_eager.reduce()
         if teacher is not None:
             import ema
             ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)       # train.py:576
@@ -490,12 +498,13 @@ def main():
     model = net
     distributed = world > 1 or force_dist
     dist_graph = distributed and probe_ok and args.graph != "off"
-    if distributed and dist_graph:
-        for p in net.parameters():             # what DDP's constructor does: rank 0's initial weights everywhere
-            dist.broadcast(p.data, 0)
-    elif distributed:
+    ddp = distributed and not dist_graph and args.eager_dp == "ddp"
+    if ddp:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank],
                                                           broadcast_buffers=False)   # train.py:382
+    elif distributed:
+        for p in net.parameters():             # what DDP's constructor does: rank 0's initial weights everywhere
+            dist.broadcast(p.data, 0)
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
 
     # a small pool of distinct batches, resident in HBM before anything is timed
@@ -513,14 +522,17 @@ def main():
                                           kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
     try:
         step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, dist_graph, teacher,
-                                      teacher_pool)
+                                      teacher_pool, ddp)
     except GraphUnavailable:
         dist_graph = False
         for p in net.parameters():
             p.grad = None
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
+        ddp = args.eager_dp == "ddp"
+        if ddp:
+            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
         args.graph = "off"
-        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, False, teacher, teacher_pool)
+        step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, False, teacher, teacher_pool,
+                                      ddp)
     use_graph = launch_mode != "eager"
 
     def fence():
@@ -582,8 +594,9 @@ def main():
             "data_parallel": (None if not distributed else
                               "SyncBN + one flat gradient all-reduce, all inside the graph (RCCL graph probe passed)"
                               if use_graph else
-                              "DistributedDataParallel, eager" + (" (RCCL graph probe passed)" if probe_ok else
-                                                                  " (RCCL graph probe failed or skipped)")),
+                              ("DistributedDataParallel, eager" if ddp else
+                               "SyncBN + one flat gradient all-reduce after backward, eager launches") +
+                              (" (RCCL graph probe passed)" if probe_ok else " (RCCL graph probe failed or skipped)")),
             "config": {"workload": f"BASELINE configs[1]: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
                                    f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,
