@@ -1,0 +1,51 @@
+#!/bin/bash
+# Regenerates everything under profiles/ for one round.  Run ON A GPU BOX from the repo root:
+#     gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r01'
+# then, back in the container (gpurun_out/ has been merged):
+#     bash tools/refresh_profiles.sh r01 --collect
+# Passes (each its own process, as MI355X_MICROARCH.md prescribes: PMC never together with other traces):
+#   1. bench.py, default flags                        -> the bench line
+#   2. rocprofv3 --kernel-trace --stats, bench.py     -> per-kernel durations of the hipGraph replays
+#   3. rocprofv3 --kernel-trace --stats, --graph off  -> the same for eager launches
+#   4./5. rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on bench.py --graph off (whole step)
+#   6./7. the same two counters on tools/sa_stage_run.py (the five SA stages only)
+set -u
+TAG=${1:-r01}
+R=$(pwd)
+OUT=$R/gpurun_out/refresh
+if [ "${2:-}" != "--collect" ]; then
+  mkdir -p $OUT
+  cd /tmp && export TMPDIR=/tmp
+  python $R/bench.py > $OUT/bench.log 2>&1
+  tail -1 $OUT/bench.log > $OUT/bench_line.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/graph -o g -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline > $OUT/graph.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eager -o e -- python $R/bench.py --graph off --steps 6 --warmup 2 --no-cpu-baseline --no-op-timing > $OUT/eager.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/bench.py --no-cpu-baseline --no-op-timing --graph off --steps 3 --warmup 2 > $OUT/pmc_$c.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/sapmc_$c -o pmc -- python $R/tools/sa_stage_run.py --steps 3 > $OUT/sapmc_$c.log 2>&1
+  done
+  # keep what travels back small: per-kernel traces are reduced on the box
+  for m in graph eager; do
+    D=$(dirname $(find $OUT/$m -name "*_kernel_trace.csv" | head -1))
+    python $R/tools/rocprof_summary.py $D $([ $m = graph ] && echo 6 || echo 4) $OUT/${m}_steady.csv $OUT/${m}_summary.md
+    cp $(find $OUT/$m -name "*_kernel_stats.csv" | head -1) $OUT/${m}_kernel_stats_raw.csv
+    rm -rf $OUT/$m
+  done
+  for c in FETCH_SIZE WRITE_SIZE; do
+    for p in pmc sapmc; do
+      find $OUT/${p}_$c -name "*kernel_trace.csv" -delete
+    done
+  done
+  du -sh $OUT
+  exit 0
+fi
+P=$R/profiles
+cp $OUT/bench_line.json $P/${TAG}_bench_line.json
+cp $OUT/graph_steady.csv $P/${TAG}_bench_graph_steady_kernel_stats.csv
+cp $OUT/graph_summary.md $P/${TAG}_bench_graph_summary.md
+cp $OUT/graph_kernel_stats_raw.csv $P/${TAG}_bench_graph_rocprofv3_kernel_stats_raw.csv
+cp $OUT/eager_steady.csv $P/${TAG}_bench_eager_steady_kernel_stats.csv
+cp $OUT/eager_summary.md $P/${TAG}_bench_eager_summary.md
+cp $OUT/eager_kernel_stats_raw.csv $P/${TAG}_bench_eager_rocprofv3_kernel_stats_raw.csv
+python $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE 0.4 3 $P/${TAG}_bench_pmc_traffic.json $P/${TAG}_bench_pmc_traffic.md
+python $R/tools/pmc_traffic.py $OUT/sapmc_FETCH_SIZE $OUT/sapmc_WRITE_SIZE 0.4 3 $P/${TAG}_sa_stage_pmc_traffic.json $P/${TAG}_sa_stage_pmc_traffic.md
