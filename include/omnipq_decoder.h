@@ -42,6 +42,23 @@ int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d, void *out
 /* out16 [n] bf16 = bf16(a + b):  a f32 or bf16 (a_is_f32), b bf16. */
 int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16, void *stream);
 
+/* Object prediction head after its output GEMM (models/pq_transformer.py:35-59 `decode_scores`, :86-89): row
+ * r = (batch, proposal), y[r] = [objectness 2 | centre 3 | heading scores nh | heading residuals nh | size scores ns |
+ * size residuals 3 ns | semantic scores ncls] in bf16 (pitch ldy).  One launch writes the ten `end_points` tensors:
+ * outs[10] = { objectness bf16 [R][2], center f32 [R][3] (= y + base), heading_scores bf16 [R][nh],
+ * heading_residuals_normalized bf16 [R][nh], heading_residuals bf16 [R][nh] (x hr_scale = pi / nh), size_scores bf16
+ * [R][ns], size_residuals_normalized bf16 [R][ns][3], size_residuals f32 [R][ns][3] (x means), pred_size f32 [R][3]
+ * (= (residual + mean)[argmax size_scores], first maximum as torch.argmax), sem_cls_scores bf16 [R][ncls] }.
+ * `outs` is a HOST array of device pointers. */
+int omnipq_head_decode(int R, int nh, int ns, int ncls, const void *y, int ldy, const float *base, const float *means,
+                       float hr_scale, void *const *outs, void *stream);
+/* Its gradient: dy (bf16 [R][lddy]) from the ten output gradients (HOST arrays in the order above: device pointer or
+ * NULL, strides [10][4] in elements for the logical shape [B][K][n1][n2] with 0 for broadcast dimensions, n2, dtype
+ * flag), dbase (f32 [R][3] or NULL) = the centre gradient.  R = B * K. */
+int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, const void *y, int ldy, const float *means,
+                           float hr_scale, const void *const *gptr, const int *gstrides, const int *gn2,
+                           const int *g_is_bf16, void *dy, int lddy, float *dbase, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

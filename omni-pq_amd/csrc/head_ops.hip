@@ -1,0 +1,179 @@
+// Prediction-head decode (reference models/pq_transformer.py:35-59 `decode_scores` and :86-89): everything
+// between the output GEMM of an object head and its `end_points` entries, and the gradient of all of it, as one
+// launch each.  The reference (and a straight PyTorch port) spends ~25 tiny kernels per head and direction on it
+// (split, centre offset, residual scaling, mean-size decode, arg-max gather, and in backward zero-fill + scatter,
+// a concatenation of the split gradients and the accumulation adds): 7 heads per step.
+//
+// Row r = (batch, proposal); y[r] = [objectness 2 | centre 3 | heading scores nh | heading residuals nh |
+// size scores ns | size residuals 3 ns | semantic scores ncls]  (bf16, the order of PredictHead's heads).
+#include "common.h"
+
+namespace omnipq {
+
+typedef __bf16 bf16_t;
+
+struct HeadOut {
+  bf16_t *obj;      // [R][2]
+  float *center;    // [R][3]   = y_centre + base_xyz
+  bf16_t *hs;       // [R][nh]
+  bf16_t *hrn;      // [R][nh]
+  bf16_t *hr;       // [R][nh]  = hrn * (pi / nh)
+  bf16_t *ss;       // [R][ns]
+  bf16_t *srn;      // [R][ns][3]
+  float *sr;        // [R][ns][3] = srn * mean_size
+  float *pred;      // [R][3]     = (sr + mean_size)[argmax ss]
+  bf16_t *sem;      // [R][ncls]
+};
+
+__device__ __forceinline__ int head_argmax(const bf16_t *scores, int ns) {
+  // torch.argmax: the first maximum
+  int best = 0;
+  float bv = (float)scores[0];
+  for (int c = 1; c < ns; ++c) {
+    const float v = (float)scores[c];
+    if (v > bv) {
+      bv = v;
+      best = c;
+    }
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns, int ncls, const bf16_t *__restrict__ y,
+                                                         int ldy, const float *__restrict__ base,
+                                                         const float *__restrict__ means, float hr_scale, HeadOut o) {
+  const int r = (int)blockIdx.x;
+  const bf16_t *row = y + (size_t)r * ldy;
+  const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
+  const int ctot = c_sem + ncls;
+  __shared__ int s_pick;
+  if (threadIdx.x == 0) s_pick = head_argmax(row + c_ss, ns);
+  __syncthreads();
+  const int pick = s_pick;
+  for (int c = (int)threadIdx.x; c < ctot; c += (int)blockDim.x) {
+    const bf16_t v = row[c];
+    if (c < c_ctr) {
+      o.obj[(size_t)r * 2 + c] = v;
+    } else if (c < c_hs) {
+      const int k = c - c_ctr;
+      o.center[(size_t)r * 3 + k] = (float)v + base[(size_t)r * 3 + k];
+    } else if (c < c_hr) {
+      o.hs[(size_t)r * nh + (c - c_hs)] = v;
+    } else if (c < c_ss) {
+      const int k = c - c_hr;
+      o.hrn[(size_t)r * nh + k] = v;
+      o.hr[(size_t)r * nh + k] = (bf16_t)((float)v * hr_scale);
+    } else if (c < c_sr) {
+      o.ss[(size_t)r * ns + (c - c_ss)] = v;
+    } else if (c < c_sem) {
+      const int k = c - c_sr;                      // = 3 * cluster + axis
+      o.srn[(size_t)r * 3 * ns + k] = v;
+      const float res = (float)v * means[k];
+      o.sr[(size_t)r * 3 * ns + k] = res;
+      if (k / 3 == pick) o.pred[(size_t)r * 3 + (k - 3 * pick)] = res + means[k];
+    } else {
+      o.sem[(size_t)r * ncls + (c - c_sem)] = v;
+    }
+  }
+}
+
+// One incoming gradient: logical shape [B][K][n1][n2] (n1 * n2 = the output's width), strides in elements
+// (0 for broadcast dimensions), bf16 or f32; ptr == NULL: no gradient.
+struct HeadGrad {
+  const void *ptr;
+  int sb, sk, s1, s2;
+  int n2;
+  int is_bf16;
+};
+struct HeadGrads {
+  HeadGrad g[10];       // obj, center, hs, hrn, hr, ss, srn, sr, pred, sem
+};
+
+__device__ __forceinline__ float head_grad_at(const HeadGrad &g, int b, int k, int j) {
+  if (!g.ptr) return 0.f;
+  const int j1 = j / g.n2, j2 = j - j1 * g.n2;
+  const long long off = (long long)b * g.sb + (long long)k * g.sk + (long long)j1 * g.s1 + (long long)j2 * g.s2;
+  return g.is_bf16 ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
+}
+
+__global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int nh, int ns, int ncls,
+                                                             const bf16_t *__restrict__ y, int ldy,
+                                                             const float *__restrict__ means, float hr_scale,
+                                                             HeadGrads gs, bf16_t *__restrict__ dy, int lddy,
+                                                             float *__restrict__ dbase) {
+  const int r = (int)blockIdx.x;
+  const int b = r / K, k = r - b * K;
+  const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
+  const int ctot = c_sem + ncls;
+  __shared__ int s_pick;
+  if (threadIdx.x == 0) s_pick = head_argmax(y + (size_t)r * ldy + c_ss, ns);
+  __syncthreads();
+  const int pick = s_pick;
+  for (int c = (int)threadIdx.x; c < ctot; c += (int)blockDim.x) {
+    float d;
+    if (c < c_ctr) {
+      d = head_grad_at(gs.g[0], b, k, c);
+    } else if (c < c_hs) {
+      d = head_grad_at(gs.g[1], b, k, c - c_ctr);
+      if (dbase) dbase[(size_t)r * 3 + (c - c_ctr)] = d;
+    } else if (c < c_hr) {
+      d = head_grad_at(gs.g[2], b, k, c - c_hs);
+    } else if (c < c_ss) {
+      d = head_grad_at(gs.g[3], b, k, c - c_hr) + head_grad_at(gs.g[4], b, k, c - c_hr) * hr_scale;
+    } else if (c < c_sr) {
+      d = head_grad_at(gs.g[5], b, k, c - c_ss);
+    } else if (c < c_sem) {
+      const int j = c - c_sr;
+      float through = head_grad_at(gs.g[7], b, k, j);
+      if (j / 3 == pick) through += head_grad_at(gs.g[8], b, k, j - 3 * pick);
+      d = head_grad_at(gs.g[6], b, k, j) + through * means[j];
+    } else {
+      d = head_grad_at(gs.g[9], b, k, c - c_sem);
+    }
+    dy[(size_t)r * lddy + c] = (bf16_t)d;
+  }
+}
+
+}  // namespace omnipq
+
+// outs: the ten output pointers in HeadOut order.
+extern "C" int omnipq_head_decode(int R, int nh, int ns, int ncls, const void *y, int ldy, const float *base,
+                                  const float *means, float hr_scale, void *const *outs, void *stream) {
+  using namespace omnipq;
+  if (R < 0 || nh < 1 || ns < 1 || ncls < 1) return OMNIPQ_EINVAL;
+  if (R == 0) return OMNIPQ_OK;
+  if (!y || !base || !means || !outs || ldy < 5 + 2 * nh + 4 * ns + ncls) return OMNIPQ_EINVAL;
+  for (int i = 0; i < 10; ++i)
+    if (!outs[i]) return OMNIPQ_EINVAL;
+  HeadOut o{(bf16_t *)outs[0], (float *)outs[1], (bf16_t *)outs[2], (bf16_t *)outs[3], (bf16_t *)outs[4],
+            (bf16_t *)outs[5], (bf16_t *)outs[6], (float *)outs[7], (float *)outs[8], (bf16_t *)outs[9]};
+  head_decode_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, nh, ns, ncls, (const bf16_t *)y, ldy, base, means, hr_scale,
+                                                         o);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// grads: HOST arrays of 10 entries in HeadOut order: gptr (device pointers, NULL = no gradient), gstrides[10][4]
+// (elements; logical shape [B][K][n1][n2]), gn2[10], g_is_bf16[10].  dy: bf16 [R][lddy >= width]; dbase: f32
+// [R][3] or NULL.  R = B * K.
+extern "C" int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, const void *y, int ldy,
+                                      const float *means, float hr_scale, const void *const *gptr,
+                                      const int *gstrides, const int *gn2, const int *g_is_bf16, void *dy, int lddy,
+                                      float *dbase, void *stream) {
+  using namespace omnipq;
+  if (R < 0 || K < 1 || nh < 1 || ns < 1 || ncls < 1) return OMNIPQ_EINVAL;
+  if (R == 0) return OMNIPQ_OK;
+  const int width = 5 + 2 * nh + 4 * ns + ncls;
+  if (!y || !means || !gptr || !gstrides || !gn2 || !g_is_bf16 || !dy || ldy < width || lddy < width || (R % K))
+    return OMNIPQ_EINVAL;
+  HeadGrads gs;
+  for (int i = 0; i < 10; ++i) {
+    if (gn2[i] < 1) return OMNIPQ_EINVAL;
+    gs.g[i] = HeadGrad{gptr[i], gstrides[4 * i], gstrides[4 * i + 1], gstrides[4 * i + 2], gstrides[4 * i + 3], gn2[i],
+                       g_is_bf16[i]};
+  }
+  head_decode_bwd_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, K, nh, ns, ncls, (const bf16_t *)y, ldy, means, hr_scale,
+                                                             gs, (bf16_t *)dy, lddy, dbase);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

@@ -61,7 +61,7 @@ def conv1x1(x, conv):
     return lin(rows(x), conv).view(B, K, -1).transpose(1, 2)
 
 
-def head_stack(self, net, heads, net_rows=None):
+def head_stack(self, net, heads, net_rows=None, raw=False):
     """Trunk (2 x Conv1d+BN+ReLU) and every 1x1 output head of a prediction head on (B, C, K) features.
     The output heads share one GEMM over their concatenated weights.  -> list of (B, K, C_h) tensors, i.e.
     already in the layout the reference reaches with `.transpose(2, 1)`.
@@ -79,7 +79,70 @@ def head_stack(self, net, heads, net_rows=None):
         x = F.relu(self.bn1(lin(x, self.conv1)))
         x = F.relu(self.bn2(lin(x, self.conv2)))
         y = F.linear(x, w, b)
+    if raw:
+        return y                                                   # (B*K, sum of head widths) rows
     return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
+
+
+_FUSED_DECODE = os.environ.get("OMNIPQ_HEAD_DECODE", "fused") != "torch"
+
+
+class HeadDecode(torch.autograd.Function):
+    """Everything between the object head's output GEMM and its `end_points` entries (reference :35-59, :86-89) in
+    one launch, and the gradient of all of it in another (csrc/head_ops.hip): y (B*K, 5 + 2 nh + 4 ns + ncls) bf16
+    rows -> objectness, center (= offset + base_xyz), heading scores / residuals (normalised and scaled), size
+    scores / residuals (normalised and times the mean sizes), pred_size (arg-max cluster), semantic scores.
+    Same values and dtypes as the op-by-op composition below it in `decode_scores`."""
+
+    @staticmethod
+    def forward(ctx, y, base_xyz, means, nh, ns, ncls):
+        import ctypes
+        B, K, _ = base_xyz.shape
+        R = B * K
+        dev = y.device
+        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape == (R, 5 + 2 * nh + 4 * ns + ncls)
+        base = base_xyz.detach().float().contiguous()
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        outs = [torch.empty((B, K, 2), **bf), torch.empty((B, K, 3), **f32), torch.empty((B, K, nh), **bf),
+                torch.empty((B, K, nh), **bf), torch.empty((B, K, nh), **bf), torch.empty((B, K, ns), **bf),
+                torch.empty((B, K, ns, 3), **bf), torch.empty((B, K, ns, 3), **f32), torch.empty((B, K, 3), **f32),
+                torch.empty((B, K, ncls), **bf)]
+        scale = float(np.float32(np.pi / nh))
+        ptrs = (ctypes.c_void_p * 10)(*[o.data_ptr() for o in outs])
+        sa_fused._call(sa_fused._lib.omnipq_head_decode, y, R, nh, ns, ncls, sa_fused._p(y), y.stride(0),
+                       sa_fused._p(base), sa_fused._p(means), ctypes.c_float(scale), ptrs)
+        ctx.save_for_backward(y, means)
+        ctx.geom = (B, K, nh, ns, ncls, scale)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        y, means = ctx.saved_tensors
+        B, K, nh, ns, ncls, scale = ctx.geom
+        R = B * K
+        n2 = [1, 1, 1, 1, 1, 1, 3, 3, 1, 1]
+        ptrs, strides, flags = [], [], []
+        for g, last in zip(gs, n2):
+            if g is None:
+                ptrs.append(None)
+                strides += [0, 0, 0, 0]
+                flags.append(0)
+                continue
+            if g.dtype not in (torch.float32, torch.bfloat16):
+                g = g.float()
+            st = list(g.stride())
+            ptrs.append(g.data_ptr())
+            strides += st if len(st) == 4 else st + [0]          # [B][K][n1]([n2])
+            flags.append(int(g.dtype == torch.bfloat16))
+        dy = torch.empty((R, y.shape[1]), device=y.device, dtype=torch.bfloat16)
+        dbase = torch.empty((B, K, 3), device=y.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        sa_fused._call(sa_fused._lib.omnipq_head_decode_bwd, y, R, K, nh, ns, ncls, sa_fused._p(y), y.stride(0),
+                       sa_fused._p(means), ctypes.c_float(scale), (ctypes.c_void_p * 10)(*ptrs),
+                       (ctypes.c_int * 40)(*strides), (ctypes.c_int * 10)(*n2), (ctypes.c_int * 10)(*flags),
+                       sa_fused._p(dy), dy.stride(0), sa_fused._p(dbase))
+        return dy, dbase, None, None, None, None
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -160,10 +223,22 @@ class PredictHead(nn.Module):
         return self._means
 
     def forward(self, net, base_xyz, end_points, prefix, net_rows=None):
-        obj, ctr, hcls, hres, scls, sres, sem = head_stack(self, net, (
-            self.objectness_scores_head, self.center_head, self.heading_class_head,
-            self.heading_residual_head, self.size_class_head, self.size_residual_head,
-            self.sem_cls_scores_head), net_rows)
+        heads = (self.objectness_scores_head, self.center_head, self.heading_class_head,
+                 self.heading_residual_head, self.size_class_head, self.size_residual_head,
+                 self.sem_cls_scores_head)
+        y = head_stack(self, net, heads, net_rows, raw=True)
+        B, K = net.shape[0], net.shape[2]
+        if _FUSED_DECODE and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1:
+            means = self._mean_sizes(net.device)
+            (obj, center, hcls, hres, hres_scaled, scls, sres, sres_scaled, pred_size, sem) = HeadDecode.apply(
+                y, base_xyz, means, self.num_heading_bin, self.num_size_cluster, self.num_class)
+            for key, val in (("objectness_scores", obj), ("center", center), ("heading_scores", hcls),
+                             ("heading_residuals_normalized", hres), ("heading_residuals", hres_scaled),
+                             ("size_scores", scls), ("size_residuals_normalized", sres),
+                             ("size_residuals", sres_scaled), ("pred_size", pred_size), ("sem_cls_scores", sem)):
+                end_points[f'{prefix}{key}'] = val
+            return center, pred_size, end_points
+        obj, ctr, hcls, hres, scls, sres, sem = torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2)
         center = ctr + base_xyz
         end_points, pred_size = decode_scores(
             base_xyz, obj, center, hcls, hres, scls, sres, sem, end_points, self.num_class,

@@ -305,3 +305,52 @@ def test_deferred_gradients_of_concatenated_heads():
     for t, u, v in zip(params, now[1:], later[1:]):
         assert u is not None and v is not None and v.shape == t.shape
         assert rel_l2(v, u) < 1e-5 or float((v - u).abs().max()) < 1e-6, rel_l2(v, u)
+
+
+def test_head_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
+    """PredictHead with the fused decode (csrc/head_ops.hip: one launch forward, one backward) against the same
+    head with `decode_scores` op by op (reference pq_transformer.py:35-59): the ten end_points entries are the same
+    bits and dtypes; gradients (dense f32 / bf16 and broadcast ones, as a mean-style loss produces) agree to bf16
+    rounding of the row gradient."""
+    import pq_transformer as pq
+    torch.manual_seed(3)
+    B, K, C = 4, 256, 288
+    means = (torch.rand(18, 3) + 0.2).numpy()
+    head = pq.PredictHead(C, 1, 18, 18, means).to(dev())
+    head.train()
+    net = torch.randn(B, C, K, device=dev()).requires_grad_(True)
+    base = torch.randn(B, K, 3, device=dev()).requires_grad_(True)
+    params = list(head.parameters())
+    state = {k: v.clone() for k, v in head.state_dict().items()}
+
+    def run(fused, broadcast):
+        monkeypatch.setattr(pq, "_FUSED_DECODE", fused)
+        head.load_state_dict(state)
+        for t in [net, base] + params:
+            t.grad = None
+        ep = {}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            center, pred, ep = head(net, base, ep, "x_")
+        keys = sorted(ep)
+        gen = torch.Generator().manual_seed(9)
+        loss = 0.0
+        for k in keys:
+            v = ep[k]
+            if broadcast:
+                loss = loss + v.float().mean() * (1 + len(k) % 3)
+            else:
+                w = torch.randn(v.shape, generator=gen).to(dev())
+                loss = loss + (v.float() * w).sum()
+        loss.backward()
+        return {k: ep[k].detach().clone() for k in keys}, [t.grad.clone() for t in [net, base] + params]
+
+    for broadcast in (False, True):
+        e1, g1 = run(True, broadcast)
+        e0, g0 = run(False, broadcast)
+        assert list(e1) == list(e0) and len(e1) == 10
+        for k in e0:
+            assert e1[k].dtype == e0[k].dtype and e1[k].shape == e0[k].shape, k
+            assert torch.equal(e1[k], e0[k]), k
+        assert torch.equal(g1[1], g0[1])                         # base_xyz: the centre gradient itself
+        for u, v in zip(g1, g0):
+            assert rel_l2(u, v) < 2e-2, rel_l2(u, v)
