@@ -84,6 +84,26 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
     return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
 
 
+def _grad_descriptors(gs, n2):
+    """(device pointers | None, flat strides [len][4], dtype flags) of incoming gradients of logical shape
+    [B][K][n1]([n2]); keeps converted tensors alive through the returned list."""
+    ptrs, strides, flags, keep = [], [], [], []
+    for g, last in zip(gs, n2):
+        if g is None:
+            ptrs.append(None)
+            strides += [0, 0, 0, 0]
+            flags.append(0)
+            continue
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        keep.append(g)
+        st = list(g.stride())
+        ptrs.append(g.data_ptr())
+        strides += st if len(st) == 4 else st + [0]
+        flags.append(int(g.dtype == torch.bfloat16))
+    return ptrs, strides, flags, keep
+
+
 _FUSED_DECODE = os.environ.get("OMNIPQ_HEAD_DECODE", "fused") != "torch"
 
 
@@ -123,19 +143,7 @@ class HeadDecode(torch.autograd.Function):
         B, K, nh, ns, ncls, scale = ctx.geom
         R = B * K
         n2 = [1, 1, 1, 1, 1, 1, 3, 3, 1, 1]
-        ptrs, strides, flags = [], [], []
-        for g, last in zip(gs, n2):
-            if g is None:
-                ptrs.append(None)
-                strides += [0, 0, 0, 0]
-                flags.append(0)
-                continue
-            if g.dtype not in (torch.float32, torch.bfloat16):
-                g = g.float()
-            st = list(g.stride())
-            ptrs.append(g.data_ptr())
-            strides += st if len(st) == 4 else st + [0]          # [B][K][n1]([n2])
-            flags.append(int(g.dtype == torch.bfloat16))
+        ptrs, strides, flags, _keep = _grad_descriptors(gs, n2)
         dy = torch.empty((R, y.shape[1]), device=y.device, dtype=torch.bfloat16)
         dbase = torch.empty((B, K, 3), device=y.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         sa_fused._call(sa_fused._lib.omnipq_head_decode_bwd, y, R, K, nh, ns, ncls, sa_fused._p(y), y.stride(0),
@@ -143,6 +151,43 @@ class HeadDecode(torch.autograd.Function):
                        (ctypes.c_int * 40)(*strides), (ctypes.c_int * 10)(*n2), (ctypes.c_int * 10)(*flags),
                        sa_fused._p(dy), dy.stride(0), sa_fused._p(dbase))
         return dy, dbase, None, None, None, None
+
+
+class QuadDecode(torch.autograd.Function):
+    """The quad head after its output GEMM (reference :105-120) in one launch each way: y (B*K, 10) bf16 rows ->
+    quad_scores, quad_center (= offset + base_xyz), normal_vector (divided by the 2-norm of the WHOLE tensor, as the
+    reference does), quad_size."""
+
+    @staticmethod
+    def forward(ctx, y, base_xyz):
+        import ctypes
+        B, K, _ = base_xyz.shape
+        R = B * K
+        dev = y.device
+        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape == (R, 10)
+        base = base_xyz.detach().float().contiguous()
+        outs = [torch.empty((B, K, 2), device=dev, dtype=torch.bfloat16), torch.empty((B, K, 3), device=dev),
+                torch.empty((B, K, 3), device=dev, dtype=torch.bfloat16),
+                torch.empty((B, K, 2), device=dev, dtype=torch.bfloat16)]
+        norm = torch.empty(1, device=dev)
+        sa_fused._call(sa_fused._lib.omnipq_quad_decode, y, R, sa_fused._p(y), y.stride(0), sa_fused._p(base),
+                       (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs]), sa_fused._p(norm))
+        ctx.save_for_backward(y, norm)
+        ctx.geom = (B, K)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        y, norm = ctx.saved_tensors
+        B, K = ctx.geom
+        ptrs, strides, flags, _keep = _grad_descriptors(gs, [1, 1, 1, 1])
+        dy = torch.empty((B * K, 10), device=y.device, dtype=torch.bfloat16)
+        dbase = torch.empty((B, K, 3), device=y.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        sa_fused._call(sa_fused._lib.omnipq_quad_decode_bwd, y, B * K, K, sa_fused._p(y), y.stride(0), sa_fused._p(norm),
+                       (ctypes.c_void_p * 4)(*ptrs), (ctypes.c_int * 16)(*strides), (ctypes.c_int * 4)(*flags),
+                       sa_fused._p(dy), dy.stride(0), sa_fused._p(dbase))
+        return dy, dbase
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -262,8 +307,17 @@ class QuadPredictHead(nn.Module):
         self.bn2 = nn.BatchNorm1d(hidden_dim)
 
     def forward(self, net, base_xyz, end_points, prefix, net_rows=None):
-        scores, ctr, normal, size = head_stack(self, net, (
-            self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head), net_rows)
+        heads = (self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head)
+        y = head_stack(self, net, heads, net_rows, raw=True)
+        B, K = net.shape[0], net.shape[2]
+        if _FUSED_DECODE and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1:
+            scores, center, normal, size = QuadDecode.apply(y, base_xyz)
+            end_points[f'{prefix}quad_scores'] = scores
+            end_points[f'{prefix}quad_center'] = center
+            end_points[f'{prefix}normal_vector'] = normal
+            end_points[f'{prefix}quad_size'] = size
+            return center, size, end_points
+        scores, ctr, normal, size = torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2)
         center = ctr + base_xyz
         normal = normal.div(torch.norm(normal, p=2))
         end_points[f'{prefix}quad_scores'] = scores

@@ -354,3 +354,51 @@ def test_head_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
         assert torch.equal(g1[1], g0[1])                         # base_xyz: the centre gradient itself
         for u, v in zip(g1, g0):
             assert rel_l2(u, v) < 2e-2, rel_l2(u, v)
+
+
+def test_quad_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
+    """QuadPredictHead with the fused decode against the op-by-op composition (reference pq_transformer.py:105-120,
+    normal divided by the 2-norm of the whole tensor): scores / centre / size are the same bits, the normal agrees to
+    one bf16 ulp (the norm is summed in a different order before its rounding to bf16), gradients to bf16 rounding."""
+    import pq_transformer as pq
+    torch.manual_seed(4)
+    B, K, C = 4, 256, 288
+    head = pq.QuadPredictHead(C).to(dev())
+    head.train()
+    net = torch.randn(B, C, K, device=dev()).requires_grad_(True)
+    base = torch.randn(B, K, 3, device=dev()).requires_grad_(True)
+    params = list(head.parameters())
+    state = {k: v.clone() for k, v in head.state_dict().items()}
+
+    def run(fused, broadcast):
+        monkeypatch.setattr(pq, "_FUSED_DECODE", fused)
+        head.load_state_dict(state)
+        for t in [net, base] + params:
+            t.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            center, size, ep = head(net, base, {}, "x_")
+        keys = sorted(ep)
+        gen = torch.Generator().manual_seed(9)
+        loss = 0.0
+        for k in keys:
+            v = ep[k]
+            if broadcast:
+                loss = loss + v.float().mean() * (1 + len(k) % 3)
+            else:
+                loss = loss + (v.float() * torch.randn(v.shape, generator=gen).to(dev())).sum()
+        loss.backward()
+        return {k: ep[k].detach().clone() for k in keys}, [t.grad.clone() for t in [net, base] + params]
+
+    for broadcast in (False, True):
+        e1, g1 = run(True, broadcast)
+        e0, g0 = run(False, broadcast)
+        assert list(e1) == list(e0) == ["x_normal_vector", "x_quad_center", "x_quad_scores", "x_quad_size"]
+        for k in e0:
+            assert e1[k].dtype == e0[k].dtype and e1[k].shape == e0[k].shape, k
+            if k == "x_normal_vector":
+                a, b = e1[k].float(), e0[k].float()
+                assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+            else:
+                assert torch.equal(e1[k], e0[k]), k
+        for u, v in zip(g1, g0):
+            assert rel_l2(u, v) < 2e-2, rel_l2(u, v)
