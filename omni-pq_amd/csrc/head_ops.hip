@@ -132,6 +132,7 @@ __global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int 
     }
     dy[(size_t)r * lddy + c] = (bf16_t)d;
   }
+  for (int c = ctot + (int)threadIdx.x; c < lddy; c += (int)blockDim.x) dy[(size_t)r * lddy + c] = (bf16_t)0.f;
 }
 
 // ---- layout-quad head (reference :94-121): y[r] = [scores 2 | centre 3 | normal 3 | size 2] ----------------------
@@ -202,6 +203,8 @@ __global__ __launch_bounds__(1024) void quad_decode_bwd_kernel(int R, int K, con
     else d = head_grad_at(gs.g[3], b, k, c - 8);
     dy[(size_t)r * lddy + c] = (bf16_t)d;
   }
+  for (int i = (int)threadIdx.x; i < R * (lddy - 10); i += (int)blockDim.x)       // padding columns: zeros
+    dy[(size_t)(i / (lddy - 10)) * lddy + 10 + i % (lddy - 10)] = (bf16_t)0.f;
 }
 
 }  // namespace omnipq

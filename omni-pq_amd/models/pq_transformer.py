@@ -52,6 +52,9 @@ def rows(x):
 
 def lin(x2d, conv):
     """kernel-size-1 Conv1d applied to rows: (N, C_in) -> (N, C_out)"""
+    stack = [rows_mlp.Layer(conv.weight, conv.bias)]
+    if rows_mlp.usable(x2d, stack, conv.training):
+        return rows_mlp.run(x2d, stack, conv.training)          # bf16 MFMA GEMM, weight gradient deferrable
     return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
 
 
@@ -70,17 +73,19 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
     B, K = net.shape[0], net.shape[2]
     x = rows(net) if net_rows is None else net_rows.reshape(B * K, -1)
     w = sa_fused.cat_params([h.weight.squeeze(-1) for h in heads])
-    b = sa_fused.cat_params([h.bias for h in heads])
     stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
-             rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2), rows_mlp.Layer(w, b)]
+             rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2), rows_mlp.Layer(w, None)]
     if rows_mlp.usable(x, stack, self.training):
-        y = rows_mlp.run(x, stack, self.training)                  # hand-written MFMA / BN kernels
+        # hand-written MFMA / BN kernels; with `raw` the consumer takes the kernels' zero-padded rows as they are
+        width = w.shape[0]
+        stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=(width + 31) // 32 * 32 if raw else None)
+        y = rows_mlp.run(x, stack, self.training, padded=raw)
     else:
         x = F.relu(self.bn1(lin(x, self.conv1)))
         x = F.relu(self.bn2(lin(x, self.conv2)))
-        y = F.linear(x, w, b)
+        y = F.linear(x, w, torch.cat([h.bias for h in heads], 0))
     if raw:
-        return y                                                   # (B*K, sum of head widths) rows
+        return y                                         # (B*K, >= sum of head widths) rows
     return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
 
 
@@ -120,7 +125,7 @@ class HeadDecode(torch.autograd.Function):
         B, K, _ = base_xyz.shape
         R = B * K
         dev = y.device
-        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape == (R, 5 + 2 * nh + 4 * ns + ncls)
+        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape[0] == R and y.shape[1] >= 5 + 2 * nh + 4 * ns + ncls
         base = base_xyz.detach().float().contiguous()
         bf = dict(device=dev, dtype=torch.bfloat16)
         f32 = dict(device=dev, dtype=torch.float32)
@@ -164,7 +169,7 @@ class QuadDecode(torch.autograd.Function):
         B, K, _ = base_xyz.shape
         R = B * K
         dev = y.device
-        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape == (R, 10)
+        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape[0] == R and y.shape[1] >= 10
         base = base_xyz.detach().float().contiguous()
         outs = [torch.empty((B, K, 2), device=dev, dtype=torch.bfloat16), torch.empty((B, K, 3), device=dev),
                 torch.empty((B, K, 3), device=dev, dtype=torch.bfloat16),
@@ -182,7 +187,7 @@ class QuadDecode(torch.autograd.Function):
         y, norm = ctx.saved_tensors
         B, K = ctx.geom
         ptrs, strides, flags, _keep = _grad_descriptors(gs, [1, 1, 1, 1])
-        dy = torch.empty((B * K, 10), device=y.device, dtype=torch.bfloat16)
+        dy = torch.empty((B * K, y.shape[1]), device=y.device, dtype=torch.bfloat16)
         dbase = torch.empty((B, K, 3), device=y.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         sa_fused._call(sa_fused._lib.omnipq_quad_decode_bwd, y, B * K, K, sa_fused._p(y), y.stride(0), sa_fused._p(norm),
                        (ctypes.c_void_p * 4)(*ptrs), (ctypes.c_int * 16)(*strides), (ctypes.c_int * 4)(*flags),
@@ -283,7 +288,8 @@ class PredictHead(nn.Module):
                              ("size_residuals", sres_scaled), ("pred_size", pred_size), ("sem_cls_scores", sem)):
                 end_points[f'{prefix}{key}'] = val
             return center, pred_size, end_points
-        obj, ctr, hcls, hres, scls, sres, sem = torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2)
+        widths = [h.out_channels for h in heads]
+        obj, ctr, hcls, hres, scls, sres, sem = torch.split(y[:, :sum(widths)].reshape(B, K, -1), widths, dim=2)
         center = ctr + base_xyz
         end_points, pred_size = decode_scores(
             base_xyz, obj, center, hcls, hres, scls, sres, sem, end_points, self.num_class,
@@ -317,7 +323,7 @@ class QuadPredictHead(nn.Module):
             end_points[f'{prefix}normal_vector'] = normal
             end_points[f'{prefix}quad_size'] = size
             return center, size, end_points
-        scores, ctr, normal, size = torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2)
+        scores, ctr, normal, size = torch.split(y[:, :10].reshape(B, K, -1), [h.out_channels for h in heads], dim=2)
         center = ctr + base_xyz
         normal = normal.div(torch.norm(normal, p=2))
         end_points[f'{prefix}quad_scores'] = scores

@@ -52,8 +52,10 @@ def usable(x, layers, training):
     return True
 
 
-def run(x_rows, layers, training):
-    """x_rows (N, C_in) -> (N, C_out of the last layer), bf16."""
+def run(x_rows, layers, training, padded=False):
+    """x_rows (N, C_in) -> (N, C_out of the last layer), bf16.  padded: return the kernels' own (N, C_out rounded
+    up to 32) buffer instead of the slice -- the extra columns are exact zeros (zero weight rows and bias), and a
+    consumer that hands back a gradient of that shape saves the stack a zero-fill and a copy."""
     spec, params = [], []
     for lay in layers:
         bn = lay.bn
@@ -65,7 +67,7 @@ def run(x_rows, layers, training):
             spec.append(None if bn is None else
                         (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
         params += [lay.weight, lay.bias, None if bn is None else bn.weight, None if bn is None else bn.bias]
-    return RowsMLP.apply(x_rows, spec, bool(training), *params)
+    return RowsMLP.apply(x_rows, (spec, bool(padded)), bool(training), *params)
 
 
 def _is_bn(entry):
@@ -79,6 +81,7 @@ class _L:
 class RowsMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, spec, training, *params):
+        spec, padded = spec
         dev = x.device
         N, cin = x.shape
         L = len(spec)
@@ -87,8 +90,7 @@ class RowsMLP(torch.autograd.Function):
         if K == cin:
             X = x.detach().to(torch.bfloat16).contiguous()
         else:
-            X = torch.zeros((N, K), device=dev, dtype=torch.bfloat16)
-            X[:, :cin] = x.detach()
+            X = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (0, K - cin))
         X0 = X
         layers = []
         for l in range(L):
@@ -114,9 +116,9 @@ class RowsMLP(torch.autograd.Function):
                 Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
                 bp = None
                 if lay.has_bias and not lay.has_bn:
-                    bp = bias.detach().float()
-                    if lay.Cp != cout:
-                        bp = torch.nn.functional.pad(bp, (0, lay.Cp - cout))
+                    bp = bias.detach().float()                 # may come zero-padded already (cat_params(pad_to=))
+                    if bp.shape[0] < lay.Cp:
+                        bp = torch.nn.functional.pad(bp, (0, lay.Cp - bp.shape[0]))
                 if below is not None:
                     sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, bias=bp, out=Y)
                 else:
@@ -163,6 +165,7 @@ class RowsMLP(torch.autograd.Function):
             layers.append(lay)
         ctx.layers, ctx.X0, ctx.geom = layers, X0, (N, cin, world)
         ctx.wshapes = [tuple(params[4 * l].shape) for l in range(L)]
+        ctx.nbias = [0 if params[4 * l + 1] is None else params[4 * l + 1].shape[0] for l in range(L)]
         # where the weight / bias gradients may be written directly (sa_fused.deferred_wgrads)
         ctx.targets = [(sa_fused.grad_target(params[4 * l]),
                         None if params[4 * l + 1] is None else sa_fused.grad_target(params[4 * l + 1]))
@@ -170,7 +173,8 @@ class RowsMLP(torch.autograd.Function):
         ctx.training = training
         ctx.in_dtype = x.dtype
         last = layers[-1]
-        return X if last.Cp == last.C else X[:, :last.C]
+        ctx.padded = padded
+        return X if (padded or last.Cp == last.C) else X[:, :last.C]
 
     @staticmethod
     def backward(ctx, g):
@@ -183,7 +187,7 @@ class RowsMLP(torch.autograd.Function):
         total = ctypes.c_double(float(N) * world)
         grads = [None] * (4 * L)
         last = layers[-1]
-        if last.Cp == last.C:
+        if last.Cp == last.C or ctx.padded:
             dcur = g.to(torch.bfloat16).contiguous()
             owned = dcur.data_ptr() != g.data_ptr()        # autograd's buffer must not be modified in place
         else:
@@ -227,7 +231,7 @@ class RowsMLP(torch.autograd.Function):
                 bsum = None
                 if want_bias:
                     bsum = zeros_f32(lay.Cp, dev)            # bias gradient: column sums of dY, from the same pass
-                    grads[4 * l + 1] = bsum[:lay.C]
+                    grads[4 * l + 1] = bsum[:ctx.nbias[l]]
                 dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum, below=below)
                 grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None

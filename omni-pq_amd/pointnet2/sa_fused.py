@@ -197,11 +197,23 @@ class _TnProblem(ctypes.Structure):
 _lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
 
 
-def cat_params(tensors, dim=0):
+_ZERO_TAILS = {}
+
+
+def cat_params(tensors, dim=0, pad_to=None):
     """torch.cat of parameters along dim 0 (the output heads of a prediction head share one GEMM) that remembers
-    its parts, so that `deferred_wgrads` can hand each part its rows of the joint gradient."""
+    its parts, so that `deferred_wgrads` can hand each part its rows of the joint gradient.  pad_to: append zeros up
+    to that many rows in the same launch (a bias vector for a padded GEMM)."""
     assert dim == 0
-    out = torch.cat(tensors, 0)
+    rows = sum(t.shape[0] for t in tensors)
+    if pad_to is not None and pad_to > rows:
+        tail = _ZERO_TAILS.get((tensors[0].device, tensors[0].dtype))
+        if tail is None or tail.numel() < pad_to - rows:
+            tail = _ZERO_TAILS[(tensors[0].device, tensors[0].dtype)] = torch.zeros(
+                max(64, pad_to - rows), device=tensors[0].device, dtype=tensors[0].dtype)
+        out = torch.cat(list(tensors) + [tail[:pad_to - rows]], 0)
+    else:
+        out = torch.cat(tensors, 0)
     parts, r = [], 0
     for t in tensors:
         parts.append((t, r, r + t.shape[0]))
@@ -275,11 +287,26 @@ class deferred_wgrads:
         pieces = []             # (param, f32 view of a scratch buffer) assigned / accumulated afterwards
         again = []              # (destination view, scratch): second use of the same weight in the graph
 
-        def buffer_of(param, full):
+        # which packed weights are covered completely by the row ranges collected (q | k,v of a cross-attention):
+        # those buffers need no clearing
+        covered = {}
+        for (_, _, _, _, _, wt, (cout, cin), _, _) in items:
+            if wt[0] == "param":
+                covered.setdefault(id(wt[1]), {})[wt[2]] = cout * cin
+        complete = {k for k, v in covered.items() if sum(v.values()) == next(
+            it[5][1] for it in items if it[5][0] == "param" and id(it[5][1]) == k).numel()}
+
+        def buffer_of(param, full, pooled=False):
             ent = whole.get(id(param))
             if ent is None:
-                # a gradient assembled from several row ranges starts from zero; one written whole needs no clearing
-                buf = (torch.empty if full else torch.zeros)(param.shape, device=param.device, dtype=torch.float32)
+                # a gradient assembled from several row ranges starts from zero unless they cover it; one written
+                # whole needs no clearing; small vectors that the kernel ADDS to come from the zero pool
+                if full or id(param) in complete:
+                    buf = torch.empty(param.shape, device=param.device, dtype=torch.float32)
+                elif pooled:
+                    buf = zeros_f32(param.numel(), param.device).view(param.shape)
+                else:
+                    buf = torch.zeros(param.shape, device=param.device, dtype=torch.float32)
                 ent = whole[id(param)] = [param, buf, set()]
             return ent
 
@@ -310,7 +337,7 @@ class deferred_wgrads:
             if bt is None:
                 continue
             if bt[0] == "param" and not (bt[2] == 0 and bt[1].numel() == cout):
-                bent = buffer_of(bt[1], False)       # row range of a packed bias (M == cout: nothing padded)
+                bent = buffer_of(bt[1], False, pooled=True)       # row range of a packed bias (M == cout: nothing padded)
                 bent[2].add(bt[2])
                 q.colsum = bent[1].data_ptr() + 4 * bt[2]
                 continue
