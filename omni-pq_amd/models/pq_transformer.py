@@ -209,7 +209,11 @@ class PositionEmbeddingLearned(nn.Module):
     def forward(self, xyz):
         head = self.position_embedding_head
         B, P, _ = xyz.shape
-        x = xyz.reshape(B * P, -1)
+        x = getattr(xyz, "omnipq_rows2d", None)      # the same positions embedded by several layers (the decoder's
+        if x is None or x.shape != (B * P, xyz.shape[2]):   # key side): one row view, so rows_mlp prepares it once
+            x = xyz.reshape(B * P, -1)
+            if not xyz.requires_grad:
+                xyz.omnipq_rows2d = x
         stack = [rows_mlp.Layer(head[0].weight, head[0].bias, head[1]), rows_mlp.Layer(head[3].weight, head[3].bias)]
         if rows_mlp.usable(x, stack, self.training):
             x = rows_mlp.run(x, stack, self.training)
@@ -416,8 +420,9 @@ class PQ_Transformer(nn.Module):
                                               end_points=end_points, prefix='proposal_')
         center_q, _, end_points = self.quad_proposal(quad_feature, base_xyz=quad_xyz,
                                                      end_points=end_points, prefix='proposal_')
-        base_xyz = center.detach().clone()
-        base_xyz_q = center_q.detach().clone()
+        # the reference clones here (:236-237); nothing writes into these tensors afterwards, a detached alias suffices
+        base_xyz = center.detach()
+        base_xyz_q = center_q.detach()
 
         query_joint = torch.cat([conv1x1(cluster_feature, self.decoder_query_proj),
                                  conv1x1(quad_feature, self.quad_decoder_query_proj)], -1)
@@ -448,8 +453,8 @@ class PQ_Transformer(nn.Module):
             base_xyz_q, _, end_points = self.prediction_quad_heads[i](
                 query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix,
                 net_rows=rows_quad)
-            base_xyz = base_xyz.detach().clone()
-            base_xyz_q = base_xyz_q.detach().clone()
+            base_xyz = base_xyz.detach()
+            base_xyz_q = base_xyz_q.detach()
         return end_points
 
     def prefetch(self, inputs, trusted=False):

@@ -87,10 +87,19 @@ class RowsMLP(torch.autograd.Function):
         L = len(spec)
         world = _world() if training else 1
         K = _round_up(cin, 32)
-        if K == cin:
-            X = x.detach().to(torch.bfloat16).contiguous()
+        cached = getattr(x, "omnipq_rows_in", None)     # the same input tensor feeding several stacks (the decoder's
+        if cached is not None and cached.shape == (N, K):   # key positions: one embedding per layer) is prepared once
+            X = cached
         else:
-            X = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (0, K - cin))
+            if K == cin:
+                X = x.detach().to(torch.bfloat16).contiguous()
+            else:
+                X = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (0, K - cin))
+            if X.data_ptr() != x.data_ptr() and not x.requires_grad:
+                try:
+                    x.omnipq_rows_in = X            # inputs without gradient only: constants of the forward pass
+                except Exception:
+                    pass
         X0 = X
         layers = []
         for l in range(L):
