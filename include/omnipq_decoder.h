@@ -62,7 +62,7 @@ int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, const void *y
 /* Layout-quad head after its output GEMM (models/pq_transformer.py:94-121): y[r] = [scores 2 | centre 3 | normal 3 |
  * size 2] bf16; outs[4] = { quad_scores bf16 [R][2], quad_center f32 [R][3] (= y + base), normal_vector bf16 [R][3]
  * (= y / ||all normals||_2: the reference divides by the norm of the WHOLE tensor, :112-113), quad_size bf16 [R][2] };
- * norm: one float, the (bf16-rounded) norm, kept for the backward call.  One workgroup each (the tensors are R x 10). */
+ * norm: one float, the (bf16-rounded) norm, kept for the backward call. */
 int omnipq_quad_decode(int R, const void *y, int ldy, const float *base, void *const *outs, float *norm, void *stream);
 int omnipq_quad_decode_bwd(int R, int K, const void *y, int ldy, const float *norm, const void *const *gptr,
                            const int *gstrides, const int *g_is_bf16, void *dy, int lddy, float *dbase, void *stream);

@@ -136,8 +136,7 @@ __global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int 
 }
 
 // ---- layout-quad head (reference :94-121): y[r] = [scores 2 | centre 3 | normal 3 | size 2] ----------------------
-// The normal is divided by the 2-norm of the WHOLE (B, K, 3) tensor (reference :112-113, batch-coupled); that is
-// one grid-wide sum, and the tensors are tiny (R x 10), so forward and backward are ONE workgroup each.
+// The normal is divided by the 2-norm of the WHOLE (B, K, 3) tensor (reference :112-113, batch-coupled).
 struct QuadOut {
   bf16_t *scores;   // [R][2]
   float *center;    // [R][3]
@@ -145,31 +144,36 @@ struct QuadOut {
   bf16_t *size;     // [R][2]
 };
 
-__device__ __forceinline__ float block_sum_1024(float v, float *red) {
+// Every workgroup takes kQuadRows rows and first derives the tensor-wide sum ITSELF (R x 3 values out of L2, the
+// same order in every workgroup, so all of them use the same norm): no second launch, no grid barrier.
+constexpr int kQuadRows = 32;
+
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  float t = 0.f;
-  for (int w = 0; w < (int)blockDim.x / 64; ++w) t += red[w];
-  return t;
+  return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(1024) void quad_decode_kernel(int R, const bf16_t *__restrict__ y, int ldy,
-                                                          const float *__restrict__ base, QuadOut o,
-                                                          float *__restrict__ norm_out) {
-  __shared__ float red[16];
+__global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *__restrict__ y, int ldy,
+                                                         const float *__restrict__ base, QuadOut o,
+                                                         float *__restrict__ norm_out) {
+  __shared__ float red[4];
   float ss = 0.f;
-  for (int i = (int)threadIdx.x; i < R * 3; i += (int)blockDim.x) {
-    const float v = (float)y[(size_t)(i / 3) * ldy + 5 + i % 3];
+  for (int i = (int)threadIdx.x; i < R * 3; i += 256) {
+    const int r = i / 3;
+    const float v = (float)y[(size_t)r * ldy + 5 + (i - 3 * r)];
     ss = __builtin_fmaf(v, v, ss);
   }
   // torch.norm of a bf16 tensor returns a bf16 scalar: the division below uses that rounded value
-  const float nrm = (float)(bf16_t)__builtin_sqrtf(block_sum_1024(ss, red));
-  if (threadIdx.x == 0) *norm_out = nrm;
-  for (int i = (int)threadIdx.x; i < R * 10; i += (int)blockDim.x) {
-    const int r = i / 10, c = i - r * 10;
+  const float nrm = (float)(bf16_t)__builtin_sqrtf(block_sum_256(ss, red));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *norm_out = nrm;
+  const int r0 = (int)blockIdx.x * kQuadRows;
+  for (int i = (int)threadIdx.x; i < kQuadRows * 10; i += 256) {
+    const int r = r0 + i / 10, c = i % 10;
+    if (r >= R) break;
     const bf16_t v = y[(size_t)r * ldy + c];
     if (c < 2) o.scores[r * 2 + c] = v;
     else if (c < 5) o.center[r * 3 + (c - 2)] = (float)v + base[r * 3 + (c - 2)];
@@ -178,33 +182,33 @@ __global__ __launch_bounds__(1024) void quad_decode_kernel(int R, const bf16_t *
   }
 }
 
-__global__ __launch_bounds__(1024) void quad_decode_bwd_kernel(int R, int K, const bf16_t *__restrict__ y, int ldy,
-                                                              const float *__restrict__ norm_in, HeadGrads gs,
-                                                              bf16_t *__restrict__ dy, int lddy,
-                                                              float *__restrict__ dbase) {
-  __shared__ float red[16];
+__global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, const bf16_t *__restrict__ y, int ldy,
+                                                             const float *__restrict__ norm_in, HeadGrads gs,
+                                                             bf16_t *__restrict__ dy, int lddy,
+                                                             float *__restrict__ dbase) {
+  __shared__ float red[4];
   const float nrm = *norm_in;
   // out = x / n, n = ||x||:  dx = g / n - x * (sum g x) / n^3
   float dot = 0.f;
-  for (int i = (int)threadIdx.x; i < R * 3; i += (int)blockDim.x) {
+  for (int i = (int)threadIdx.x; i < R * 3; i += 256) {
     const int r = i / 3, c = i - r * 3;
     dot = __builtin_fmaf(head_grad_at(gs.g[2], r / K, r % K, c), (float)y[(size_t)r * ldy + 5 + c], dot);
   }
-  const float s = block_sum_1024(dot, red) / (nrm * nrm * nrm);
-  for (int i = (int)threadIdx.x; i < R * 10; i += (int)blockDim.x) {
-    const int r = i / 10, c = i - r * 10;
+  const float s = block_sum_256(dot, red) / (nrm * nrm * nrm);
+  const int r0 = (int)blockIdx.x * kQuadRows;
+  for (int i = (int)threadIdx.x; i < kQuadRows * lddy; i += 256) {
+    const int r = r0 + i / lddy, c = i % lddy;
+    if (r >= R) break;
     const int b = r / K, k = r - b * K;
-    float d;
+    float d = 0.f;                                   // padding columns: zeros
     if (c < 2) d = head_grad_at(gs.g[0], b, k, c);
     else if (c < 5) {
       d = head_grad_at(gs.g[1], b, k, c - 2);
       if (dbase) dbase[r * 3 + (c - 2)] = d;
     } else if (c < 8) d = head_grad_at(gs.g[2], b, k, c - 5) / nrm - (float)y[(size_t)r * ldy + c] * s;
-    else d = head_grad_at(gs.g[3], b, k, c - 8);
+    else if (c < 10) d = head_grad_at(gs.g[3], b, k, c - 8);
     dy[(size_t)r * lddy + c] = (bf16_t)d;
   }
-  for (int i = (int)threadIdx.x; i < R * (lddy - 10); i += (int)blockDim.x)       // padding columns: zeros
-    dy[(size_t)(i / (lddy - 10)) * lddy + 10 + i % (lddy - 10)] = (bf16_t)0.f;
 }
 
 }  // namespace omnipq
@@ -220,7 +224,7 @@ extern "C" int omnipq_quad_decode(int R, const void *y, int ldy, const float *ba
   for (int i = 0; i < 4; ++i)
     if (!outs[i]) return OMNIPQ_EINVAL;
   QuadOut o{(bf16_t *)outs[0], (float *)outs[1], (bf16_t *)outs[2], (bf16_t *)outs[3]};
-  quad_decode_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(R, (const bf16_t *)y, ldy, base, o, norm);
+  quad_decode_kernel<<<(R + kQuadRows - 1) / kQuadRows, 256, 0, (hipStream_t)stream>>>(R, (const bf16_t *)y, ldy, base, o, norm);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -239,7 +243,7 @@ extern "C" int omnipq_quad_decode_bwd(int R, int K, const void *y, int ldy, cons
   for (int i = 0; i < 4; ++i)
     gs.g[i] = HeadGrad{gptr[i], gstrides[4 * i], gstrides[4 * i + 1], gstrides[4 * i + 2], gstrides[4 * i + 3], 1,
                        g_is_bf16[i]};
-  quad_decode_bwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(R, K, (const bf16_t *)y, ldy, norm, gs, (bf16_t *)dy, lddy,
+  quad_decode_bwd_kernel<<<(R + kQuadRows - 1) / kQuadRows, 256, 0, (hipStream_t)stream>>>(R, K, (const bf16_t *)y, ldy, norm, gs, (bf16_t *)dy, lddy,
                                                               dbase);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
