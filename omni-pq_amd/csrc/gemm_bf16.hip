@@ -328,14 +328,17 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(int m_tiles, int n2
   const int t0 = (int)blockIdx.y * per;
   int t1 = t0 + per;
   if (t1 > m_tiles) t1 = m_tiles;
-  float acc0 = 0.f, acc1 = 0.f;
+  // eight independent loads in flight per lane: the loop is a chain of L2 / HBM round trips otherwise
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int t = t0;
-  for (; t + 1 < t1; t += 2) {
-    acc0 += part[(size_t)t * n2 + j];
-    acc1 += part[(size_t)(t + 1) * n2 + j];
+  for (; t + 7 < t1; t += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(t + u) * n2 + j];
   }
-  if (t < t1) acc0 += part[(size_t)t * n2 + j];
-  if (t0 < t1) atomicAdd(sums + j, (double)acc0 + (double)acc1);
+  for (; t < t1; ++t) acc[0] += part[(size_t)t * n2 + j];
+  if (t0 < t1)
+    atomicAdd(sums + j, ((double)acc[0] + (double)acc[1]) + ((double)acc[2] + (double)acc[3]) +
+                            (((double)acc[4] + (double)acc[5]) + ((double)acc[6] + (double)acc[7])));
 }
 
 // sums the split-K slabs:  out[i] = sum_z part[z][i]

@@ -157,22 +157,31 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+__device__ __forceinline__ float quad_grad_at(const HeadGrad &g, int b, int k, int c) {      // n2 == 1: no division
+  if (!g.ptr) return 0.f;
+  const long long off = (long long)b * g.sb + (long long)k * g.sk + (long long)c * g.s1;
+  return g.is_bf16 ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
+}
+
 __global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *__restrict__ y, int ldy,
                                                          const float *__restrict__ base, QuadOut o,
                                                          float *__restrict__ norm_out) {
   __shared__ float red[4];
   float ss = 0.f;
-  for (int i = (int)threadIdx.x; i < R * 3; i += 256) {
-    const int r = i / 3;
-    const float v = (float)y[(size_t)r * ldy + 5 + (i - 3 * r)];
-    ss = __builtin_fmaf(v, v, ss);
+  for (int r = (int)threadIdx.x; r < R; r += 256) {
+    const bf16_t *row = y + (size_t)r * ldy + 5;
+    const float a = (float)row[0], b = (float)row[1], c = (float)row[2];
+    ss = __builtin_fmaf(a, a, ss);
+    ss = __builtin_fmaf(b, b, ss);
+    ss = __builtin_fmaf(c, c, ss);
   }
   // torch.norm of a bf16 tensor returns a bf16 scalar: the division below uses that rounded value
   const float nrm = (float)(bf16_t)__builtin_sqrtf(block_sum_256(ss, red));
   if (blockIdx.x == 0 && threadIdx.x == 0) *norm_out = nrm;
-  const int r0 = (int)blockIdx.x * kQuadRows;
-  for (int i = (int)threadIdx.x; i < kQuadRows * 10; i += 256) {
-    const int r = r0 + i / 10, c = i % 10;
+  const int c = (int)threadIdx.x & 15;
+  if (c >= 10) return;
+  for (int rr = (int)threadIdx.x >> 4; rr < kQuadRows; rr += 16) {
+    const int r = (int)blockIdx.x * kQuadRows + rr;
     if (r >= R) break;
     const bf16_t v = y[(size_t)r * ldy + c];
     if (c < 2) o.scores[r * 2 + c] = v;
@@ -190,24 +199,28 @@ __global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, cons
   const float nrm = *norm_in;
   // out = x / n, n = ||x||:  dx = g / n - x * (sum g x) / n^3
   float dot = 0.f;
-  for (int i = (int)threadIdx.x; i < R * 3; i += 256) {
-    const int r = i / 3, c = i - r * 3;
-    dot = __builtin_fmaf(head_grad_at(gs.g[2], r / K, r % K, c), (float)y[(size_t)r * ldy + 5 + c], dot);
+  for (int r = (int)threadIdx.x; r < R; r += 256) {
+    const int b = r / K, k = r - b * K;
+    const bf16_t *row = y + (size_t)r * ldy + 5;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dot = __builtin_fmaf(quad_grad_at(gs.g[2], b, k, c), (float)row[c], dot);
   }
   const float s = block_sum_256(dot, red) / (nrm * nrm * nrm);
-  const int r0 = (int)blockIdx.x * kQuadRows;
-  for (int i = (int)threadIdx.x; i < kQuadRows * lddy; i += 256) {
-    const int r = r0 + i / lddy, c = i % lddy;
+  const int c0 = (int)threadIdx.x & 15;
+  for (int rr = (int)threadIdx.x >> 4; rr < kQuadRows; rr += 16) {
+    const int r = (int)blockIdx.x * kQuadRows + rr;
     if (r >= R) break;
     const int b = r / K, k = r - b * K;
-    float d = 0.f;                                   // padding columns: zeros
-    if (c < 2) d = head_grad_at(gs.g[0], b, k, c);
-    else if (c < 5) {
-      d = head_grad_at(gs.g[1], b, k, c - 2);
-      if (dbase) dbase[r * 3 + (c - 2)] = d;
-    } else if (c < 8) d = head_grad_at(gs.g[2], b, k, c - 5) / nrm - (float)y[(size_t)r * ldy + c] * s;
-    else if (c < 10) d = head_grad_at(gs.g[3], b, k, c - 8);
-    dy[(size_t)r * lddy + c] = (bf16_t)d;
+    for (int c = c0; c < lddy; c += 16) {
+      float d = 0.f;                                 // padding columns: zeros
+      if (c < 2) d = quad_grad_at(gs.g[0], b, k, c);
+      else if (c < 5) {
+        d = quad_grad_at(gs.g[1], b, k, c - 2);
+        if (dbase) dbase[r * 3 + (c - 2)] = d;
+      } else if (c < 8) d = quad_grad_at(gs.g[2], b, k, c - 5) / nrm - (float)y[(size_t)r * ldy + c] * s;
+      else if (c < 10) d = quad_grad_at(gs.g[3], b, k, c - 8);
+      dy[(size_t)r * lddy + c] = (bf16_t)d;
+    }
   }
 }
 
