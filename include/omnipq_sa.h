@@ -87,6 +87,15 @@ long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);
 int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in, const float *b_in,
                                const void *B, int ldb, void *C, int ldc, const float *bias, double *sums,
                                float *workspace, void *stream);
+/* ..._bnaffine: as ..._nt_..._affine, with the BatchNorm finalize of the layer that produced A folded into the
+ * prologue (replaces one omnipq_bn_finalize launch per BatchNorm layer): a / b are derived from that layer's totals
+ * fin_sums (double[2][K] over `count` rows, all-reduced by the caller under SyncBatchNorm) and stored with mean /
+ * invstd for the backward pass; running statistics and conv_bias as in omnipq_bn_finalize (may be NULL). */
+int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
+                                 const float *gamma, const float *beta, float eps, float momentum,
+                                 float *running_mean, float *running_var, const float *conv_bias, float *a_out,
+                                 float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
+                                 int ldc, const float *bias, double *sums, float *workspace, void *stream);
 int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);

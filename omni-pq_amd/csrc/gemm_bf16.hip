@@ -56,8 +56,18 @@ struct BnBwdEpilogue {
 // transform is applied between the global load and the LDS store of each tile, so the activations X = relu(bn(Y))
 // of a conv+BN+ReLU stack are never written to or read from memory.
 struct AffineIn {
-  const float *a, *b;       // [K]
+  const float *a, *b;       // [K]: read when `sums` is NULL
+  // Optional: the BatchNorm finalize of the layer below, folded into this kernel's prologue (one tiny launch per
+  // BatchNorm layer otherwise).  Every workgroup derives a / b of all K channels from the f64 totals into LDS;
+  // workgroup 0 also stores a, b, mean, invstd for the backward pass and updates the running statistics.
+  const double *sums;       // [2][K] sum, sum of squares over `count` rows
+  const float *gamma, *beta, *conv_bias;
+  float *running_mean, *running_var;
+  float *a_out, *b_out, *mean_out, *invstd_out;
+  double count;
+  float eps, momentum;
 };
+constexpr int kAffMaxK = 1024;
 
 __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
   const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
@@ -80,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   constexpr int LDS_BYTES = (STAGE_ELEMS * 2 > CT_BYTES) ? STAGE_ELEMS * 2 : CT_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
+  __shared__ __attribute__((aligned(16))) float s_aff[AFF ? 2 * kAffMaxK : 4];       // a | b of the A operand's channels
 
   // XCD-aware tile order: id % 8 picks the XCD, the N-tiles of one M-tile stay on it
   const int id = (int)blockIdx.x;
@@ -123,8 +134,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  if (AFF) {
+    const bool first = blockIdx.x == 0 && blockIdx.z == 0;
+    for (int c = tid; c < g.K; c += 256) {
+      float av, bv;
+      if (aff.sums) {
+        const double mu = aff.sums[c] / aff.count;
+        double var = aff.sums[g.K + c] / aff.count - mu * mu;
+        if (var < 0) var = 0;
+        const float is = (float)(1.0 / sqrt(var + (double)aff.eps));
+        av = aff.gamma[c] * is;
+        bv = aff.beta[c] - (float)mu * av;
+        if (first) {
+          aff.a_out[c] = av;
+          aff.b_out[c] = bv;
+          aff.mean_out[c] = (float)mu;
+          aff.invstd_out[c] = is;
+          if (aff.running_mean) {
+            const double unbiased = aff.count > 1 ? var * aff.count / (aff.count - 1) : var;
+            const float shift = aff.conv_bias ? aff.conv_bias[c] : 0.f;
+            aff.running_mean[c] = (1.f - aff.momentum) * aff.running_mean[c] + aff.momentum * ((float)mu + shift);
+            aff.running_var[c] = (1.f - aff.momentum) * aff.running_var[c] + aff.momentum * (float)unbiased;
+          }
+        }
+      } else {
+        av = aff.a[c];
+        bv = aff.b[c];
+      }
+      s_aff[c] = av;
+      s_aff[kAffMaxK + c] = bv;
+    }
+    __syncthreads();
+  }
+
   uint4 ra[2], rb[2];
-  f32x4 fa4[2], fb4[2];              // AFF: a, b of this thread's 8 channels of the K-step (both chunks share them)
   auto load_tiles = [&](int kt) {
     const int koff = kt * GBK;     // whole K-steps only: K and k_chunk are multiples of GBK
 #pragma unroll
@@ -132,19 +175,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       ra[i] = ldg16(ga[i] + koff);
       rb[i] = ldg16(gb[i] + koff);
     }
-    if (AFF) {
-      const int k0 = kbeg + koff + skc[0] * 8;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        fa4[h] = *reinterpret_cast<const f32x4 *>(aff.a + k0 + 4 * h);
-        fb4[h] = *reinterpret_cast<const f32x4 *>(aff.b + k0 + 4 * h);
-      }
-    }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int kt) {
     bf16_t *sa = stage + buf * (2 * 128 * GPITCH);
     bf16_t *sb = sa + 128 * GPITCH;
     if (AFF) {
+      // a, b of this thread's 8 channels of K-step kt (both chunks share them): four LDS reads
+      const int k0 = kbeg + kt * GBK + skc[0] * 8;
+      f32x4 fa4[2], fb4[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        fa4[h] = *reinterpret_cast<const f32x4 *>(s_aff + k0 + 4 * h);
+        fb4[h] = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0 + 4 * h);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         ra[i].x = affine_relu_pair(ra[i].x, fa4[0][0], fb4[0][0], fa4[0][1], fb4[0][1]);
@@ -162,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
 
   if (nk > 0) {
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(0, 0);
   }
   __syncthreads();
 
@@ -186,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    if (kt + 1 < nk) store_tiles(buf ^ 1, kt + 1);
     __syncthreads();
   }
 
@@ -465,19 +508,16 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
   return OMNIPQ_OK;
 }
 
-// C = relu(a_in .* A + b_in) B^T (+ bias), the A operand transformed on the fly (see AffineIn); with `sums`
-// (double[2][N], zero on entry) also the BatchNorm statistics of C as in omnipq_gemm_nt_bf16_stats.
-extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in,
-                                          const float *b_in, const void *B, int ldb, void *C, int ldc,
-                                          const float *bias, double *sums, float *workspace, void *stream) {
+static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, const omnipq::AffineIn &aff, const void *B,
+                               int ldb, void *C, int ldc, const float *bias, double *sums, float *workspace,
+                               void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
-  if (!A || !B || !C || !a_in || !b_in || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8) || K > kAffMaxK) return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  const AffineIn aff{a_in, b_in};
   if (!sums) {
     gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
                                                                       bias, nullptr, BnBwdEpilogue(), aff);
@@ -501,6 +541,47 @@ extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, in
                                                                                     sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
+}
+
+// C = relu(a_in .* A + b_in) B^T (+ bias), the A operand transformed on the fly (see AffineIn); with `sums`
+// (double[2][N], zero on entry) also the BatchNorm statistics of C as in omnipq_gemm_nt_bf16_stats.
+extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in,
+                                          const float *b_in, const void *B, int ldb, void *C, int ldc,
+                                          const float *bias, double *sums, float *workspace, void *stream) {
+  if (!a_in || !b_in) return OMNIPQ_EINVAL;
+  omnipq::AffineIn aff{};
+  aff.a = a_in;
+  aff.b = b_in;
+  return gemm_nt_affine_impl(M, N, K, A, lda, aff, B, ldb, C, ldc, bias, sums, workspace, stream);
+}
+
+// The same with the BatchNorm finalize of the layer that produced A folded in: a / b are DERIVED here from that
+// layer's totals fin_sums (double[2][K] over `count` rows; all-reduced by the caller under SyncBatchNorm), gamma,
+// beta -- and stored, with mean / invstd, into a_out .. invstd_out for the backward pass; running_mean / running_var
+// (may be NULL) get the momentum update, conv_bias (may be NULL) as in omnipq_bn_finalize.
+extern "C" int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums,
+                                            double count, const float *gamma, const float *beta, float eps,
+                                            float momentum, float *running_mean, float *running_var,
+                                            const float *conv_bias, float *a_out, float *b_out, float *mean_out,
+                                            float *invstd_out, const void *B, int ldb, void *C, int ldc,
+                                            const float *bias, double *sums, float *workspace, void *stream) {
+  if (!fin_sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out || !(count > 0)) return OMNIPQ_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
+  omnipq::AffineIn aff{};
+  aff.sums = fin_sums;
+  aff.gamma = gamma;
+  aff.beta = beta;
+  aff.conv_bias = conv_bias;
+  aff.running_mean = running_mean;
+  aff.running_var = running_var;
+  aff.a_out = a_out;
+  aff.b_out = b_out;
+  aff.mean_out = mean_out;
+  aff.invstd_out = invstd_out;
+  aff.count = count;
+  aff.eps = eps;
+  aff.momentum = momentum;
+  return gemm_nt_affine_impl(M, N, K, A, lda, aff, B, ldb, C, ldc, bias, sums, workspace, stream);
 }
 
 // Data-gradient GEMM of a conv+BN+ReLU stack with the BatchNorm-backward sums of the layer BELOW folded in:

@@ -75,7 +75,7 @@ def _is_bn(entry):
 
 
 class _L:
-    __slots__ = ("act", "K", "C", "Cp", "Wp", "Wt", "wk", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias")
+    __slots__ = ("act", "K", "C", "Cp", "Wp", "Wt", "wk", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias", "fin")
 
 
 class RowsMLP(torch.autograd.Function):
@@ -110,6 +110,7 @@ class RowsMLP(torch.autograd.Function):
             lay.C, lay.K, lay.Cp = cout, K, _round_up(cout, 32)
             lay.has_bn, lay.has_bias, lay.wk = _is_bn(spec[l]), bias is not None, wk
             lay.act = spec[l] if (spec[l] is not None and not lay.has_bn) else None
+            lay.fin = None
             lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training, persistent=sa_fused.is_persistent(W))
             if lay.has_bn and lay.Cp != cout:
                 raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
@@ -143,9 +144,8 @@ class RowsMLP(torch.autograd.Function):
                     if l < L - 1 and sa_fused.affine_pays(N, params[4 * (l + 1)].shape[0]):
                         # relu(bn(Y)) is never stored: the next layer's GEMM and this layer's consumers in backward
                         # rebuild it from (Y, a, b) while staging their operand
-                        _call(_lib.omnipq_bn_finalize, Y, cout, ctypes.c_double(float(N) * world), _p(sums),
-                              _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
-                              _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(cb))
+                        # ... and the finalize itself happens in the prologue of that GEMM (sa_fused.gemm_nt_affine)
+                        lay.fin = (sums, float(N) * world, gamma.detach(), beta.detach(), eps, momentum, rm, rv, cb)
                         lay.X = None
                     else:
                         lay.X = torch.empty_like(Y)

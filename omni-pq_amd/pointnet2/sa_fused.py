@@ -155,6 +155,16 @@ def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None):
     if sums is not None:
         n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
         ws = torch.empty((n_ws,), device=Y.device, dtype=torch.float32) if n_ws else None
+    fin = getattr(below, "fin", None)
+    if fin is not None:
+        # the layer below has not been finalised yet: this GEMM's prologue derives a / b from its totals (and stores
+        # them, with mean / invstd and the running-statistics update) -- one launch less per BatchNorm layer
+        fsums, count, gamma, beta, eps, momentum, rm, rv, cb = fin
+        below.fin = None
+        _call(_lib.omnipq_gemm_nt_bf16_bnaffine, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count), _p(gamma),
+              _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm), _p(rv), _p(cb), _p(below.a), _p(below.b),
+              _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(bias), _p(sums), _p(ws))
+        return C
     _call(_lib.omnipq_gemm_nt_bf16_affine, Y, M, N, K, _p(Y), K, _p(below.a), _p(below.b), _p(Bw), K, _p(C), N,
           _p(bias), _p(sums), _p(ws))
     return C
@@ -601,7 +611,7 @@ def rows16_of(t, shape):
 
 class _Layer:
     """Per-layer constants and saved tensors of one conv+BN+ReLU."""
-    __slots__ = ("K", "C", "Wp", "Wt", "a", "b", "mean", "invstd", "Y", "X")
+    __slots__ = ("K", "C", "Wp", "Wt", "a", "b", "mean", "invstd", "Y", "X", "fin")
 
 
 class FusedSAStage(torch.autograd.Function):
@@ -667,10 +677,14 @@ class FusedSAStage(torch.autograd.Function):
                 lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
                 keep_y_only = l < L - 1 and affine_pays(P, params[3 * (l + 1)].shape[0])
                 fused_relu = l < L - 1 and not keep_y_only
-                if fused_relu:
+                lay.fin = None
+                if keep_y_only:
+                    # finalised inside the prologue of the GEMM that consumes (Y, a, b): see gemm_nt_affine
+                    lay.fin = (sums, float(P) * world, gamma.detach(), beta.detach(), eps, momentum, rm, rv, None)
+                elif fused_relu:
                     # finalize + normalise + ReLU in one launch
                     lay.X = torch.empty_like(lay.Y)
-                    _call(_lib.omnipq_bn_finalize_relu, X, ctypes.c_longlong(P), cout, ctypes.c_double(float(P) * world),
+                    _call(_lib.omnipq_bn_finalize_relu, lay.Y, ctypes.c_longlong(P), cout, ctypes.c_double(float(P) * world),
                           _p(sums), _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
                           _p(rm), _p(rv), _p(None), _p(lay.Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean),
                           _p(lay.invstd))
