@@ -136,16 +136,18 @@ AFFINE_OPERANDS = os.environ.get("OMNIPQ_AFFINE", "1") != "0"
 
 def affine_pays(P, N):
     """Rebuilding relu(bn(Y)) inside the consumer GEMMs costs VALU work per staged element, once per N-tile of the
-    consumer (measured, P x 128 rows: +62 us on the forward GEMM and +12 us on the weight gradient against a 100 us
-    normalise+ReLU pass at P = 1 M, N = 128; but +47 and +50 us against 40 us at P = 262 k, N = 512).  It pays where
-    the consumer has one or two N-tiles over many positions (sa1), and on the small per-point stacks where a launch
-    costs more than the transform (P <= 16 k rows: heads, position embeddings, voting, FP)."""
-    mode = os.environ.get("OMNIPQ_AFFINE", "1")
+    consumer; it saves the normalise+ReLU pass (a read and a write of the layer) and, with the finalize folded into
+    the consumer's prologue, two launches per BatchNorm layer.  Measured on P x K rows (forward GEMM with the
+    transform vs without | the pass it replaces): P = 1 M, K = 128, N = 128: +53 us | 106 us; N = 256: +46 | 106;
+    P = 262 k, K = 256, N = 256: +18 | 40; N = 512: +34 | 40; P = 65 k, N = 512: +9 | 11; 4096 x 288 x 288: +2 | 6.
+    So it pays everywhere on this model (with the scale / shift vectors in LDS; when they were fetched per K-step it
+    lost on the wide layers).  OMNIPQ_AFFINE=selective restores the narrower policy of that time, =0 the stored
+    dataflow."""
     if not AFFINE_OPERANDS:
         return False
-    if mode == "all":
-        return True
-    return P <= 16384 or (P >= (1 << 19) and N <= 256)
+    if os.environ.get("OMNIPQ_AFFINE", "1") == "selective":
+        return P <= 16384 or (P >= (1 << 19) and N <= 256)
+    return True
 
 
 def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None):
