@@ -111,13 +111,16 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
     acol[i] = aok[i] ? m0 + sc8[i] * 8 : 0;
     bcol[i] = bok[i] ? n0 + sc8[i] * 8 : 0;
   }
-  float fa8[8], fb8[8];        // AFFB: a, b of this thread's 8 B channels (the same for both chunks)
+  // AFFB: a, b of the tile's 128 B channels live in LDS (1 KB) and are re-read at every K-step: holding this
+  // thread's sixteen values in registers costs the fourth workgroup per CU (139 VGPRs)
+  __shared__ __attribute__((aligned(16))) float s_ab[AFFB ? 256 : 4];
   if (AFFB) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      fa8[e] = ba[bcol[0] + e];
-      fb8[e] = bb[bcol[0] + e];
+    if (tid < 128) {
+      const int c = n0 + tid < g.N ? n0 + tid : 0;
+      s_ab[tid] = ba[c];
+      s_ab[128 + tid] = bb[c];
     }
+    __syncthreads();
   }
   // Everything that CONSUMES the loaded registers (tail mask, column sums, the affine transform) happens in
   // store_tiles, i.e. after the MFMAs of the current K-step: the loads stay in flight underneath them.
@@ -138,10 +141,12 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (AFFB) {
-        rb[i].x = tn_affine_relu_pair(rb[i].x, fa8[0], fb8[0], fa8[1], fb8[1]);
-        rb[i].y = tn_affine_relu_pair(rb[i].y, fa8[2], fb8[2], fa8[3], fb8[3]);
-        rb[i].z = tn_affine_relu_pair(rb[i].z, fa8[4], fb8[4], fa8[5], fb8[5]);
-        rb[i].w = tn_affine_relu_pair(rb[i].w, fa8[6], fb8[6], fa8[7], fb8[7]);
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_ab + sc8[i] * 8), a1 = *reinterpret_cast<const f32x4 *>(s_ab + sc8[i] * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_ab + 128 + sc8[i] * 8), b1 = *reinterpret_cast<const f32x4 *>(s_ab + 128 + sc8[i] * 8 + 4);
+        rb[i].x = tn_affine_relu_pair(rb[i].x, a0[0], b0[0], a0[1], b0[1]);
+        rb[i].y = tn_affine_relu_pair(rb[i].y, a0[2], b0[2], a0[3], b0[3]);
+        rb[i].z = tn_affine_relu_pair(rb[i].z, a1[0], b1[0], a1[1], b1[1]);
+        rb[i].w = tn_affine_relu_pair(rb[i].w, a1[2], b1[2], a1[3], b1[3]);
       }
       const unsigned k = keep[i];
       ra[i].x &= k; ra[i].y &= k; ra[i].z &= k; ra[i].w &= k;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const bf16_t 
   tn_tile<false>(g, A, B, part, colsum, (int)blockIdx.x);
 }
 
-__global__ __launch_bounds__(256, 3) void gemm_tn_affine_kernel(TnArgs g, const bf16_t *__restrict__ A,
+__global__ __launch_bounds__(256, 4) void gemm_tn_affine_kernel(TnArgs g, const bf16_t *__restrict__ A,
                                                                const bf16_t *__restrict__ B,
                                                                float *__restrict__ part, float *__restrict__ colsum,
                                                                const float *__restrict__ ba,
@@ -279,7 +284,7 @@ struct TnGroupArgs {
 static_assert(sizeof(TnGroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool AFFB>
-__global__ __launch_bounds__(256, AFFB ? 3 : 4) void gemm_tn_grouped_kernel(TnGroupArgs a) {
+__global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) {
   const int id = (int)blockIdx.x;
   int lo = 0, hi = a.n - 1;          // last item with wg_begin <= id
   while (lo < hi) {
