@@ -657,6 +657,53 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(long long P, int n, int m
   }
 }
 
+// The three steps in ONE launch for n <= kCsrLdsMax source points: one workgroup per scene keeps the counters in
+// LDS (LDS atomics instead of contended global ones: the 8 x 32768 positions of sa2 took 54 + 63 us in the two
+// global-atomic kernels), scans them in place and fills `order` from LDS cursors.  A memset, three launches and
+// b * n scratch counters less per call.
+constexpr int kCsrLdsMax = 8192;
+
+__global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, const int *__restrict__ idx,
+                                                            int *__restrict__ offsets, int *__restrict__ order) {
+  __shared__ int cnt[kCsrLdsMax];
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int b = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  idx += (size_t)b * ms;
+  for (int k = tid; k < n; k += 1024) cnt[k] = 0;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int p = tid; p < ms; p += 1024) atomicAdd(&cnt[idx[p]], 1);
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int k = base + tid;
+    const int v = k < n ? cnt[k] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int wo = 0;
+    for (int w = 0; w < wave; ++w) wo += wsum[w];
+    const int excl = carry + wo + x - v;
+    if (k < n) {
+      offsets[(size_t)b * (n + 1) + k] = excl;
+      cnt[k] = excl;                       // becomes the fill cursor
+    }
+    __syncthreads();
+    if (tid == 1023) carry = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) offsets[(size_t)b * (n + 1) + n] = carry;
+  for (int p = tid; p < ms; p += 1024) {
+    const int slot = atomicAdd(&cnt[idx[p]], 1);
+    order[(size_t)b * ms + slot] = p;
+  }
+}
+
 // dfeat[b][k][c0..c0+8) = sum over the bucket of dX[p][c0..c0+8)   (one lane per (b, k, 8 channels));
 // the lane of the coordinate piece accumulates dxyz[b][k] = inv_r * sum dX[p][cin..cin+3).
 __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, int n, int ms, int cin, int kpad,
@@ -920,6 +967,11 @@ extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, i
   if (!idx || !offsets || !order || !scratch) return OMNIPQ_EINVAL;
   const long long P = (long long)b * m * s;
   const int ms = m * s;
+  if (n <= omnipq::kCsrLdsMax && b <= 65535) {
+    omnipq::csr_build_lds_kernel<<<b, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
   OMNIPQ_HIP(hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)b * n, (hipStream_t)stream));
   if (P > 0) {
     csr_count_kernel<<<grid_for(P), 256, 0, (hipStream_t)stream>>>(P, n, ms, idx, scratch);
