@@ -87,6 +87,14 @@ int omnipq_ball_query(int b, int n, int m, float radius, int nsample,
                       const float *new_xyz, const float *xyz, int *idx,
                       void *stream);
 
+/* The same output through a uniform hash grid (extension; no counterpart in the reference): cells of edge >= radius,
+ * candidates from the 27 cells around a centre, the nsample smallest indices inside the ball = the reference's
+ * first-found-in-index-order.  For large clouds (sa1: 40 000 points) where the brute-force walk dominates.
+ * workspace: omnipq_ball_query_grid_workspace_bytes(b, n) bytes of device memory. */
+long long omnipq_ball_query_grid_workspace_bytes(int b, int n);
+int omnipq_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                           int *idx, void *workspace, void *stream);
+
 /* replaces group_points_kernel_wrapper (group_points.cpp:11-13).
  *   points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
 int omnipq_group_points(int b, int c, int n, int npoints, int nsample,

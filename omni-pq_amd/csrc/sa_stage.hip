@@ -673,7 +673,17 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, cons
   for (int k = tid; k < n; k += 1024) cnt[k] = 0;
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int p = tid; p < ms; p += 1024) atomicAdd(&cnt[idx[p]], 1);
+  // sixteen independent loads in flight per thread: with one workgroup per scene the loop is otherwise a chain of
+  // global-load round trips (measured 59 us for 40 000 entries with one load at a time)
+  constexpr int U = 16;
+  for (int p = tid; p < ms; p += U * 1024) {
+    int k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (k[u] >= 0) atomicAdd(&cnt[k[u]], 1);
+  }
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int k = base + tid;
@@ -698,9 +708,15 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, cons
     __syncthreads();
   }
   if (tid == 0) offsets[(size_t)b * (n + 1) + n] = carry;
-  for (int p = tid; p < ms; p += 1024) {
-    const int slot = atomicAdd(&cnt[idx[p]], 1);
-    order[(size_t)b * ms + slot] = p;
+  for (int p = tid; p < ms; p += U * 1024) {
+    int k[U], slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) slot[u] = k[u] >= 0 ? atomicAdd(&cnt[k[u]], 1) : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (k[u] >= 0) order[(size_t)b * ms + slot[u]] = p + u * 1024;
   }
 }
 

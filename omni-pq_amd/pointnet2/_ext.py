@@ -177,6 +177,10 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+_BQ_GRID_MIN = int(os.environ.get("OMNIPQ_BQ_GRID_MIN", "8192"))      # points per scene from which the grid pays
+_lib.omnipq_ball_query_grid_workspace_bytes.restype = ctypes.c_longlong
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """(B,M,3), (B,N,3) -> (B,M,nsample) i32   [ball_query.cpp:16-40]"""
     _check(new_xyz, "new_xyz", torch.float32)
@@ -185,6 +189,13 @@ def ball_query(new_xyz, xyz, radius, nsample):
     b, n = xyz.shape[0], xyz.shape[1]
     m = new_xyz.shape[1]
     idx = torch.empty((b, m, int(nsample)), device=new_xyz.device, dtype=torch.int32)
+    if n >= _BQ_GRID_MIN and radius > 0 and b <= 65535:
+        # large clouds: the same indices through a hash grid (csrc/ball_query.hip) instead of n tests per centre
+        ws = torch.empty((int(_lib.omnipq_ball_query_grid_workspace_bytes(b, n)),), device=new_xyz.device,
+                         dtype=torch.uint8)
+        _run(_lib.omnipq_ball_query_grid, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
+             _ptr(xyz), _ptr(idx), _ptr(ws))
+        return idx
     _run(_lib.omnipq_ball_query, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
          _ptr(xyz), _ptr(idx))
     return idx

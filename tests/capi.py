@@ -69,6 +69,17 @@ def ball_query(new_xyz, xyz, radius, nsample):
     return idx
 
 
+def ball_query_grid(new_xyz, xyz, radius, nsample):
+    """the hash-grid variant of omnipq_ball_query: must give the same indices"""
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.full((b, m, nsample), -7, device=xyz.device, dtype=torch.int32)   # NOT zero-filled
+    lib().omnipq_ball_query_grid_workspace_bytes.restype = ctypes.c_longlong
+    ws = torch.empty(max(int(lib().omnipq_ball_query_grid_workspace_bytes(b, n)), 16), device=xyz.device, dtype=torch.uint8)
+    ok("omnipq_ball_query_grid", b, n, m, ctypes.c_float(radius), nsample, P(new_xyz), P(xyz), P(idx), P(ws))
+    return idx
+
+
 def group_points(points, idx):
     b, c, n = points.shape
     _, m, s = idx.shape

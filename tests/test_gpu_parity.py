@@ -125,6 +125,39 @@ def test_ball_query_index_exact(kind, b, n, m, radius, nsample):
     assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("kind,b,n,m,radius,nsample", BQ_CASES + [("room", 8, 40000, 2048, 0.2, 64),
+                                                                  ("uniform", 2, 5000, 500, 3.0, 16),
+                                                                  ("room", 2, 20000, 256, 2.5, 2000)])
+def test_ball_query_through_the_hash_grid_gives_the_same_indices(kind, b, n, m, radius, nsample):
+    """omnipq_ball_query_grid == omnipq_ball_query (== the oracle where the oracle is quick): same strict radius,
+    the nsample smallest indices in order, first hit repeated in the tail, zeros for empty balls -- including balls
+    with more hits than the kernel's hit list holds (radius 2.5 / 3.0: the per-centre fallback), duplicate points
+    and centres far outside the cloud."""
+    xyz = cloud(kind, 9, b, n)
+    centres = xyz[:, torch.randperm(n, generator=torch.Generator().manual_seed(1))[:m]].contiguous()
+    if kind == "adv":
+        centres[:, 0] = 50.0
+        centres[:, 1] = -40.0
+    brute = capi.ball_query(centres.to(dev()), xyz.to(dev()), radius, nsample)
+    grid = capi.ball_query_grid(centres.to(dev()), xyz.to(dev()), radius, nsample)
+    assert torch.equal(grid, brute)
+    if b * n * m <= 2 * 4096 * 1024:
+        assert torch.equal(grid.cpu(), oracle_ext.ball_query(centres, xyz, radius, nsample))
+
+
+def test_ball_query_grid_boundary_and_cell_edges():
+    """Points exactly at the radius stay out (strict <), points a hair inside stay in even when they sit across a
+    cell edge from the centre; negative coordinates; a centre whose 27 cells are all empty."""
+    r = 0.5
+    xyz = torch.zeros(1, 12, 3)
+    xyz[0, :, 0] = torch.tensor([0.0, 0.5, 0.25, 0.5, 1.0, 0.499999, 0.5, 0.125, -0.499999, -0.5, 0.50005, -0.50005])
+    centres = torch.tensor([[[0.0, 0.0, 0.0], [0.50004, 0.0, 0.0], [-0.25, 0.0, 0.0], [100.0, 100.0, 100.0]]])
+    want = oracle_ext.ball_query(centres, xyz, r, 8)
+    got = capi.ball_query_grid(centres.to(dev()), xyz.to(dev()), r, 8)
+    assert torch.equal(got.cpu(), want)
+    assert want[0, 3].tolist() == [0] * 8
+
+
 def test_ball_query_radius_boundary_is_strict():
     """d2 == radius^2 exactly must be OUT (ball_query_gpu.cu:35 `d2 < radius2`)."""
     xyz = torch.zeros(1, 8, 3)
