@@ -1,0 +1,76 @@
+"""Input side: the reference's host sub-sampling, and the one-batch-ahead host -> device pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO  # noqa: F401  (sys.path set-up)
+
+
+def test_random_sampling_follows_the_reference_statement():
+    """utils/pc_util.py:36-44: choices = np.random.choice(N, num_sample, replace=(N < num_sample) unless given)."""
+    import input_pipeline as ip
+    pc = np.arange(50 * 4, dtype=np.float32).reshape(50, 4)
+    np.random.seed(5)
+    want = np.random.choice(50, 20, replace=False)
+    np.random.seed(5)
+    got, choices = ip.random_sampling(pc, 20, return_choices=True)
+    assert np.array_equal(choices, want) and np.array_equal(got, pc[want]) and len(set(choices)) == 20
+    np.random.seed(6)
+    want = np.random.choice(50, 80, replace=True)          # fewer rows than requested: with replacement
+    np.random.seed(6)
+    assert np.array_equal(ip.random_sampling(pc, 80), pc[want])
+    np.random.seed(7)
+    want = np.random.choice(50, 20, replace=True)
+    np.random.seed(7)
+    assert np.array_equal(ip.random_sampling(pc, 20, replace=True), pc[want])
+
+
+def test_pipeline_refuses_the_cpu():
+    import input_pipeline as ip
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ip.InputPipeline(object(), "cpu")
+
+
+@pytest.mark.gpu
+def test_pipeline_delivers_the_batches_and_their_sampling_plans():
+    """Three batches pushed one ahead of their pop: the tensors arrive intact, slots are recycled only after use, and
+    a model fed from the pipeline produces the indices of the plain `.to(device)` path (the prefetched sampling
+    plan is the one forward() consumes)."""
+    import input_pipeline as ip
+    import synth
+    from backbone_module import Pointnet2Backbone
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    backbone = Pointnet2Backbone(input_feature_dim=0).to(dev).eval()
+
+    class Net:                                   # the model-level prefetch API on top of the backbone
+        def prefetch(self, inputs):
+            backbone.prefetch(inputs["point_clouds"])
+
+    host = [synth.make_clouds(40 + i, 2, 8192, kind="room") for i in range(4)]
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in backbone(h.to(dev)).items() if "inds" in k} for h in host]
+    pipe = ip.InputPipeline(Net(), dev, slots=3)
+    pipe.push(host[0])
+    got = []
+    for i in range(4):
+        pc = pipe.pop()
+        assert backbone._plan is not None and backbone._plan["src"] is pc        # the plan of THIS batch is waiting
+        with torch.no_grad():
+            out = backbone(pc)
+        assert backbone._plan is None                                           # ... and forward() consumed it
+        if i + 1 < 4:
+            pipe.push(host[i + 1])
+        assert torch.equal(pc.cpu(), host[i])
+        got.append({k: v.clone() for k, v in out.items() if "inds" in k})
+    assert len(pipe) == 0
+    for a, b in zip(got, want):
+        assert a.keys() == b.keys() and len(a) >= 3
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    with pytest.raises(RuntimeError):
+        pipe.pop()
+    pipe.push(host[0])
+    pipe.push(host[1])
+    with pytest.raises(RuntimeError, match="overwrite"):
+        pipe.push(host[2])
