@@ -253,8 +253,10 @@ extern "C" int omnipq_ball_query_grid(int b, int n, int m, float radius, int nsa
   int *order = offsets + (size_t)b * (kBqBuckets + 1);
   float *sorted = (float *)(order + (size_t)b * n);
   const float radius2 = radius * radius;  // ball_query_gpu.cu:27 (f32 product)
-  const float inv_h = 1.0f / (radius * 1.0001f);      // cell edge a little above the radius: rounding in x * inv_h
-                                                      // can never put a point of the ball two cells away
+  // Cell edge 0.1 % above the radius.  A point passes the f32 test d2 < r2 only if |dx| <= r (1 + ~1e-6), and
+  // fl(x * inv_h) is off by <= |x / h| * 2^-23 cells on either side: with the margin of 1e-3 cells a point of the
+  // ball can never land two cells away while |x| / h < ~4000 (800 m at r = 0.2; scenes are a few metres).
+  const float inv_h = 1.0f / (radius * 1.001f);
   const long long total = (long long)b * n;
   bq_cell_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(total, inv_h, xyz, bucket);
   OMNIPQ_LAUNCH_CHECK();
