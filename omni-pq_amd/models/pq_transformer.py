@@ -110,6 +110,7 @@ def _grad_descriptors(gs, n2):
 
 
 _FUSED_DECODE = os.environ.get("OMNIPQ_HEAD_DECODE", "fused") != "torch"
+_WGRAD_SIDE = os.environ.get("OMNIPQ_WGRAD_SIDE", "1") != "0"
 
 
 class HeadDecode(torch.autograd.Function):
@@ -402,6 +403,12 @@ class PQ_Transformer(nn.Module):
         end_points = self.backbone(inputs['point_clouds'], {})
         seed_xyz = end_points['fp2_xyz']
         seed_features = end_points['fp2_features']
+        if _WGRAD_SIDE and seed_features.is_cuda and seed_features.requires_grad:
+            # backward: when the gradient reaches this point the decoder, the heads and the voting module are done --
+            # their collected weight gradients (sa_fused.deferred_wgrads) start on the sampling stream underneath the
+            # backbone's backward pass
+            seed_features = sa_fused.WgradFlushPoint.apply(
+                seed_features, lambda dev=seed_features.device: self.backbone._side_stream(dev))
 
         # layout branch: FPS over the seeds
         quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features, self.backbone.take_extra("sa2"))

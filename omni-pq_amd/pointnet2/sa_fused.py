@@ -287,8 +287,28 @@ class deferred_wgrads:
         deferred_wgrads.active = None
         if et is None:
             self.flush()
+            for st in getattr(self, "_side_streams", ()):          # early flushes: .grad is complete after the block
+                torch.cuda.current_stream(st.device).wait_stream(st)
         self.items = None
+        self._inflight = None
         return False
+
+    def flush_on(self, stream):
+        """Compute what has been collected so far on `stream` (ordered after the current stream), e.g. the decoder's
+        and heads' gradients underneath the backbone's backward pass.  Operands stay referenced until the block
+        ends (they were allocated on the current stream's pool)."""
+        if not self.items:
+            return
+        cur = torch.cuda.current_stream(stream.device)
+        stream.wait_stream(cur)
+        self.__dict__.setdefault("_inflight", []).extend(self.items)
+        streams = self.__dict__.setdefault("_side_streams", [])
+        if stream not in streams:
+            streams.append(stream)
+        with torch.cuda.stream(stream):
+            self.flush()
+        self.items = []
+
 
     def flush(self):
         items = self.items
@@ -392,6 +412,25 @@ class deferred_wgrads:
             param.grad = g
         else:
             param.grad.add_(g)
+
+
+class WgradFlushPoint(torch.autograd.Function):
+    """Identity in forward; when the gradient comes back through it inside a `deferred_wgrads` block, everything
+    collected so far is launched on the side stream `stream_of()` returns (None: nothing happens)."""
+
+    @staticmethod
+    def forward(ctx, x, stream_of):
+        ctx.stream_of = stream_of
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        dfr = deferred_wgrads.active
+        if dfr is not None and g.is_cuda:
+            st = ctx.stream_of()
+            if st is not None:
+                dfr.flush_on(st)
+        return g, None
 
 
 class _ZeroPool:

@@ -535,3 +535,48 @@ def test_stacks_without_stored_activations_equal_the_materialised_dataflow(monke
         assert rel_l2(u, v) < 1e-6                   # land in a different order from run to run
     for u, v in zip(rv1, rv0):
         assert rel_l2(u, v) < 1e-6
+
+
+def test_weight_gradients_flushed_on_the_side_stream_are_the_same(monkeypatch):
+    """pq_transformer._WGRAD_SIDE: the decoder's / heads' collected weight gradients start on the sampling stream
+    when the gradient reaches the backbone (sa_fused.WgradFlushPoint) instead of at the end of backward.  Every
+    problem is computed by the same kernel with the same partition either way: against the same graph with the
+    early flush switched off, all parameter gradients agree to the run-to-run noise of the step (f64 / f32 atomics
+    in the statistics; the flush point itself re-associates the bf16 sum of the seed features' gradients, which
+    moves the ill-conditioned BatchNorm shifts of the backbone by a few percent -- hence not compared across
+    graphs), and the early flush really happens."""
+    import bench
+    import pq_transformer as pq
+    import sa_fused
+    from test_oracle_golden import zero_dropout
+    flushed = []
+    orig = sa_fused.deferred_wgrads.flush_on
+
+    def spy(self, stream):
+        flushed.append(len(self.items))
+        return orig(self, stream)
+
+    monkeypatch.setattr(pq, "_WGRAD_SIDE", True)
+
+    def run():
+        torch.manual_seed(7)
+        net = bench.build_model(0).to(dev()).train()
+        zero_dropout(net)
+        pc = synth.make_clouds(70, 2, 8192, kind="room").to(dev())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = bench.loss_of(net({"point_clouds": pc}))
+        with sa_fused.deferred_wgrads():
+            loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.float().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    monkeypatch.setattr(sa_fused.deferred_wgrads, "flush_on", lambda self, stream: None)      # all at the end
+    base = run()
+    again = run()
+    monkeypatch.setattr(sa_fused.deferred_wgrads, "flush_on", spy)
+    side = run()
+    assert flushed and flushed[0] >= 80                       # the decoder and head stacks were launched early
+    assert side.keys() == base.keys()
+    noise = max(rel_l2(again[n], base[n]) for n in base)
+    worst = max(rel_l2(side[n], base[n]) for n in base)
+    assert worst <= max(3.0 * noise, 1e-5), (worst, noise)
