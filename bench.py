@@ -296,6 +296,13 @@ class GraphUnavailable(RuntimeError):
     """Raised on EVERY rank when any rank could not capture the step."""
 
 
+def workload_name(args):
+    """Which BASELINE.json configuration the arguments correspond to."""
+    key = (args.batch, args.points, args.extra_channels)
+    return {(8, 40000, 0): "BASELINE configs[1]", (4, 50000, 6): "BASELINE configs[3]",
+            (16, 80000, 0): "BASELINE configs[4] (in bf16)"}.get(key, "custom configuration")
+
+
 class FlatGradients:
     """Data parallelism for the captured step: after backward every rank's gradients are packed into one
     flat f32 buffer, summed with ONE all-reduce over RCCL and averaged -- what DistributedDataParallel's
@@ -584,9 +591,10 @@ def main():
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
-            "metric": ("scenes/sec fwd+bwd, 40k-pt ScanNet clouds, batch 8/GPU" if not args.mean_teacher else
-                       "student scenes/sec, mean-teacher step (student fwd+bwd + teacher fwd + EMA), 40k-pt clouds, "
-                       "batch 8+8/GPU"),
+            "metric": ((f"scenes/sec fwd+bwd, {args.points // 1000}k-pt ScanNet clouds, batch {args.batch}/GPU")
+                       if not args.mean_teacher else
+                       (f"student scenes/sec, mean-teacher step (student fwd+bwd + teacher fwd + EMA), "
+                        f"{args.points // 1000}k-pt clouds, batch {args.batch}+{args.batch}/GPU")),
             "value": scenes / dt_max, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -597,7 +605,7 @@ def main():
                               ("DistributedDataParallel, eager" if ddp else
                                "SyncBN + one flat gradient all-reduce after backward, eager launches") +
                               (" (RCCL graph probe passed)" if probe_ok else " (RCCL graph probe failed or skipped)")),
-            "config": {"workload": f"BASELINE configs[1]: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
+            "config": {"workload": f"{workload_name(args)}: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
                                    f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,
                        "parallelism": f"dp{world}"},
