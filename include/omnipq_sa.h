@@ -96,6 +96,26 @@ int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, int lda, co
                                  float *running_mean, float *running_var, const float *conv_bias, float *a_out,
                                  float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
                                  int ldc, const float *bias, double *sums, float *workspace, void *stream);
+/* Max-pool without re-reading the layer: the ..._pool variants of the statistics GEMMs also record, per ball of `s`
+ * consecutive rows (s divides 128 and M) and column, the maximum and minimum of the stored outputs and the first row
+ * attaining each (ymax / ymin bf16 [M/s][N], amax / amin uint8 [M/s][N]); once the BatchNorm constants exist,
+ * omnipq_sa_pool_select takes relu(a y* + b) with y* = max where a >= 0, min where a < 0 -- the max-pool of
+ * pointnet2_modules.py:259-262 over relu(bn(.)) -- and writes what omnipq_sa_pool writes (out_f32 / out_pm / arg) plus
+ * ysel = y*; omnipq_sa_pool_bwd_stats_sel is omnipq_sa_pool_bwd_stats reading ysel instead of gathering from Y. */
+int omnipq_gemm_nt_bf16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+                                   const float *bias, double *sums, float *workspace, int s, void *ymax, void *ymin,
+                                   unsigned char *amax, unsigned char *amin, void *stream);
+int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
+                                      const float *gamma, const float *beta, float eps, float momentum,
+                                      float *running_mean, float *running_var, const float *conv_bias, float *a_out,
+                                      float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
+                                      int ldc, const float *bias, double *sums, float *workspace, int s, void *ymax,
+                                      void *ymin, unsigned char *amax, unsigned char *amin, void *stream);
+int omnipq_sa_pool_select(long long BM, int C, const void *ymax, const void *ymin, const unsigned char *amax,
+                          const unsigned char *amin, const float *a, const float *bshift, float *out_f32, void *out_pm,
+                          unsigned char *arg, void *ysel, void *stream);
+int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
+                                 const float *g_out, const void *out_pm, double *sums, void *stream);
 int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);

@@ -76,6 +76,18 @@ __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float
          ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
 }
 
+// Ball extrema (statistics variants only, s > 0): the rows of C are grouped positions, `s` consecutive rows form a
+// ball (s divides 128, so balls never straddle tiles).  The max-pool over a ball of relu(a y + b) is relu(a y* + b)
+// with y* the ball's MAXIMUM of y where a >= 0 and its MINIMUM where a < 0 -- but a and b exist only after this
+// GEMM's statistics are complete.  So the epilogue records, per (ball, column), max and min of the rounded outputs
+// and the FIRST row that attains each (the tie rule of the pooling pass), from the C tile that sits in LDS anyway;
+// omnipq_sa_pool_select then picks per column.  The pooling pass never reads Y again.
+struct PoolOut {
+  int s;
+  bf16_t *ymax, *ymin;            // [M / s][N]
+  unsigned char *amax, *amin;     // [M / s][N] row within the ball
+};
+
 template <bool OUT_F32, int STATS = 0, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
@@ -83,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
                                                         const float *__restrict__ bias,
                                                         void *__restrict__ stats_out = nullptr,
                                                         BnBwdEpilogue bn = BnBwdEpilogue(),
-                                                        AffineIn aff = AffineIn()) {
+                                                        AffineIn aff = AffineIn(),
+                                                        PoolOut pool = PoolOut()) {
   // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
   constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
   constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
@@ -338,6 +351,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         }
       }
     }
+    if ((STATS == 1 || STATS == 2) && pool.s > 0) {
+      const int col = tid & 127, gc = n0 + col;
+      const int balls = 128 / pool.s;
+      if (gc < g.N) {
+        for (int ball = tid >> 7; ball < balls; ball += 2) {
+          const int r0 = ball * pool.s;
+          if (m0 + r0 >= g.M) break;
+          float hi = -INFINITY, lo = INFINITY;
+          int ihi = 0, ilo = 0;
+          for (int r = 0; r < pool.s; ++r) {
+            const float v = (float)ct[(r0 + r) * GCPITCH + col];
+            if (v > hi) { hi = v; ihi = r; }
+            if (v < lo) { lo = v; ilo = r; }
+          }
+          const size_t o = (size_t)((m0 + r0) / pool.s) * g.N + gc;
+          pool.ymax[o] = (bf16_t)hi;
+          pool.ymin[o] = (bf16_t)lo;
+          pool.amax[o] = (unsigned char)ihi;
+          pool.amin[o] = (unsigned char)ilo;
+        }
+      }
+    }
     if (STATS) {
       __syncthreads();                     // the C tile is dead: reuse it as [16 row groups][2][128] floats
       float *red = reinterpret_cast<float *>(smem);
@@ -510,7 +545,7 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
 
 static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, const omnipq::AffineIn &aff, const void *B,
                                int ldb, void *C, int ldc, const float *bias, double *sums, float *workspace,
-                               void *stream) {
+                               void *stream, const omnipq::PoolOut &pool = omnipq::PoolOut()) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -526,13 +561,13 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
   }
   if (g.m_tiles <= kStatsDirectTiles) {
     gemm_nt_kernel<false, 1, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
-                                                                      bias, sums, BnBwdEpilogue(), aff);
+                                                                      bias, sums, BnBwdEpilogue(), aff, pool);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
   gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
-                                                                    workspace, BnBwdEpilogue(), aff);
+                                                                    workspace, BnBwdEpilogue(), aff, pool);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -559,6 +594,22 @@ extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, in
 // layer's totals fin_sums (double[2][K] over `count` rows; all-reduced by the caller under SyncBatchNorm), gamma,
 // beta -- and stored, with mean / invstd, into a_out .. invstd_out for the backward pass; running_mean / running_var
 // (may be NULL) get the momentum update, conv_bias (may be NULL) as in omnipq_bn_finalize.
+static int pool_out_check(int M, int N, int s, void *ymax, void *ymin, unsigned char *amax, unsigned char *amin,
+                          omnipq::PoolOut *out) {
+  if (s <= 0 || (128 % s) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
+  *out = omnipq::PoolOut{s, (omnipq::bf16_t *)ymax, (omnipq::bf16_t *)ymin, amax, amin};
+  (void)N;
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums,
+                                                 double count, const float *gamma, const float *beta, float eps,
+                                                 float momentum, float *running_mean, float *running_var,
+                                                 const float *conv_bias, float *a_out, float *b_out, float *mean_out,
+                                                 float *invstd_out, const void *B, int ldb, void *C, int ldc,
+                                                 const float *bias, double *sums, float *workspace, int s, void *ymax,
+                                                 void *ymin, unsigned char *amax, unsigned char *amin, void *stream);
+
 extern "C" int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums,
                                             double count, const float *gamma, const float *beta, float eps,
                                             float momentum, float *running_mean, float *running_var,
@@ -582,6 +633,72 @@ extern "C" int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, 
   aff.eps = eps;
   aff.momentum = momentum;
   return gemm_nt_affine_impl(M, N, K, A, lda, aff, B, ldb, C, ldc, bias, sums, workspace, stream);
+}
+
+// ..._bnaffine plus the ball extrema of C (see PoolOut): s rows per ball (s divides 128 and M); ymax / ymin bf16
+// [M / s][N], amax / amin uint8 [M / s][N].  `sums` is required (the statistics variants carry the extra pass).
+extern "C" int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums,
+                                                 double count, const float *gamma, const float *beta, float eps,
+                                                 float momentum, float *running_mean, float *running_var,
+                                                 const float *conv_bias, float *a_out, float *b_out, float *mean_out,
+                                                 float *invstd_out, const void *B, int ldb, void *C, int ldc,
+                                                 const float *bias, double *sums, float *workspace, int s, void *ymax,
+                                                 void *ymin, unsigned char *amax, unsigned char *amin, void *stream) {
+  if (!fin_sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out || !(count > 0) || !sums)
+    return OMNIPQ_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
+  omnipq::PoolOut pool;
+  const int rc = pool_out_check(M, N, s, ymax, ymin, amax, amin, &pool);
+  if (rc) return rc;
+  omnipq::AffineIn aff{};
+  aff.sums = fin_sums;
+  aff.gamma = gamma;
+  aff.beta = beta;
+  aff.conv_bias = conv_bias;
+  aff.running_mean = running_mean;
+  aff.running_var = running_var;
+  aff.a_out = a_out;
+  aff.b_out = b_out;
+  aff.mean_out = mean_out;
+  aff.invstd_out = invstd_out;
+  aff.count = count;
+  aff.eps = eps;
+  aff.momentum = momentum;
+  return gemm_nt_affine_impl(M, N, K, A, lda, aff, B, ldb, C, ldc, bias, sums, workspace, stream, pool);
+}
+
+// omnipq_gemm_nt_bf16_stats plus the ball extrema of C (see PoolOut).
+extern "C" int omnipq_gemm_nt_bf16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                              void *C, int ldc, const float *bias, double *sums, float *workspace,
+                                              int s, void *ymax, void *ymin, unsigned char *amax, unsigned char *amin,
+                                              void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !sums || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  PoolOut pool;
+  const int rc = pool_out_check(M, N, s, ymax, ymin, amax, amin, &pool);
+  if (rc) return rc;
+  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  if (g.m_tiles <= kStatsDirectTiles) {
+    gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+                                                                sums, BnBwdEpilogue(), AffineIn(), pool);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (!workspace) return OMNIPQ_EINVAL;
+  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+                                                              workspace, BnBwdEpilogue(), AffineIn(), pool);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  if (slabs < 1) slabs = 1;
+  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
+                                                                                    sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
 }
 
 // Data-gradient GEMM of a conv+BN+ReLU stack with the BatchNorm-backward sums of the layer BELOW folded in:

@@ -272,6 +272,77 @@ __global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s
   }
 }
 
+// Max-pool from the ball extrema a statistics GEMM recorded (gemm_bf16.hip: PoolOut): per (ball, channel) the pooled
+// value is relu(a y* + b) with y* = the ball's maximum of y where a >= 0, its minimum where a < 0; `arg` = the first
+// row attaining it (row 0 when the result is clamped to 0, as pool_kernel's strict '>' leaves it), ysel = y* (what
+// the backward statistics need of Y).  8 channels per lane.
+__global__ __launch_bounds__(256) void pool_select_kernel(long long items, int C, const bf16_t *__restrict__ ymax,
+                                                         const bf16_t *__restrict__ ymin,
+                                                         const unsigned char *__restrict__ amax,
+                                                         const unsigned char *__restrict__ amin,
+                                                         const float *__restrict__ a, const float *__restrict__ b,
+                                                         float *__restrict__ out_f32, bf16_t *__restrict__ out_pm,
+                                                         unsigned char *__restrict__ arg, bf16_t *__restrict__ ysel) {
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bm = q / cpr;
+    const int c0 = (int)(q - bm * cpr) * 8;
+    const size_t o = (size_t)bm * C + c0;
+    float av[8], bv[8], hi[8], lo[8], best[8], sel[8];
+    load8f(a + c0, av);
+    load8f(b + c0, bv);
+    unpack8(*reinterpret_cast<const uint4 *>(ymax + o), hi);
+    unpack8(*reinterpret_cast<const uint4 *>(ymin + o), lo);
+    const unsigned long long ph = *reinterpret_cast<const unsigned long long *>(amax + o);
+    const unsigned long long pl = *reinterpret_cast<const unsigned long long *>(amin + o);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool up = av[e] >= 0.f;
+      sel[e] = up ? hi[e] : lo[e];
+      best[e] = fmaxf(__builtin_fmaf(av[e], sel[e], bv[e]), 0.f);
+      const unsigned long long t = ((up ? ph : pl) >> (8 * e)) & 0xFF;
+      packed |= (best[e] > 0.f ? t : 0ull) << (8 * e);
+    }
+    *reinterpret_cast<uint4 *>(out_pm + o) = pack8(best);
+    *reinterpret_cast<uint4 *>(ysel + o) = pack8(sel);
+    *reinterpret_cast<unsigned long long *>(arg + o) = packed;
+    float *of = out_f32 + o;
+    *reinterpret_cast<float4 *>(of) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<float4 *>(of + 4) = make_float4(best[4], best[5], best[6], best[7]);
+  }
+}
+
+// pool_bwd_stats_kernel with y at the arg-max position taken from `ysel` instead of a gather out of Y
+__global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, int C, const bf16_t *__restrict__ ysel,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                const float *__restrict__ g_out,
+                                                                const bf16_t *__restrict__ out_pm,
+                                                                double *__restrict__ sums) {
+  int cgs, rpb, cg, rsub;
+  row_partition(C, cgs, rpb, cg, rsub);
+  float u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rsub < rpb) {
+    float mu[8], is[8];
+    load8f(mean + cg * 8, mu);
+    load8f(invstd + cg * 8, is);
+    for (long long bm = (long long)blockIdx.x * rpb + rsub; bm < BM; bm += (long long)gridDim.x * rpb) {
+      float o[8], gg[8], y[8];
+      unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + cg * 8), o);
+      unpack8(*reinterpret_cast<const uint4 *>(ysel + (size_t)bm * C + cg * 8), y);
+      load8f(g_out + (size_t)bm * C + cg * 8, gg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = o[e] > 0.f ? gg[e] : 0.f;
+        u[e] += g;
+        v[e] = __builtin_fmaf(g, (y[e] - mu[e]) * is[e], v[e]);
+      }
+    }
+  }
+  fold_and_publish<kMaxC>(u, v, cg, rsub, rpb, cgs, C, sums);
+}
+
 // dz lives only at the argmax position of every (bm, c):  dz = g_out[b][c][m] if out > 0.
 // sums[0][c] = sum dz, sums[1][c] = sum dz * yhat  with yhat = (y - mean) * invstd at that position.
 __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m, int s, int C,
@@ -879,6 +950,32 @@ extern "C" int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const f
   if (!Y || !a || !bshift || !out_f32 || !out_pm || !arg) return OMNIPQ_EINVAL;
   pool_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, m, s, C, (const bf16_t *)Y, a, bshift, out_f32,
                                                               (bf16_t *)out_pm, arg);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool_select(long long BM, int C, const void *ymax, const void *ymin, const unsigned char *amax,
+                                     const unsigned char *amin, const float *a, const float *bshift, float *out_f32,
+                                     void *out_pm, unsigned char *arg, void *ysel, void *stream) {
+  if (BM < 0 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  const long long items = BM * (C / 8);
+  if (items == 0) return OMNIPQ_OK;
+  if (!ymax || !ymin || !amax || !amin || !a || !bshift || !out_f32 || !out_pm || !arg || !ysel) return OMNIPQ_EINVAL;
+  pool_select_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, C, (const bf16_t *)ymax, (const bf16_t *)ymin,
+                                                                     amax, amin, a, bshift, out_f32, (bf16_t *)out_pm, arg,
+                                                                     (bf16_t *)ysel);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
+                                            const float *g_out, const void *out_pm, double *sums, void *stream) {
+  if (BM < 0 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
+  if (!ysel || !mean || !invstd || !g_out || !out_pm || !sums) return OMNIPQ_EINVAL;
+  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (BM == 0) return OMNIPQ_OK;
+  pool_bwd_stats_sel_kernel<<<stats_grid(BM, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+      BM, C, (const bf16_t *)ysel, mean, invstd, g_out, (const bf16_t *)out_pm, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -119,11 +119,17 @@ def gemm_nt_into(A, B, C, M, N, K, bias=None):
     _call(_lib.omnipq_gemm_nt_bf16_ws, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(ws))
 
 
-def _gemm_nt_stats(A, B, M, N, K, sums, bias=None):
-    """bf16 C = A B^T and, in the same pass, sums (f64 [2][N], zero on entry) += column sum / sum of squares."""
+def _gemm_nt_stats(A, B, M, N, K, sums, bias=None, pool=None):
+    """bf16 C = A B^T and, in the same pass, sums (f64 [2][N], zero on entry) += column sum / sum of squares;
+    pool = (S, ymax, ymin, amax, amin): also the extrema of every ball of S rows (csrc/gemm_bf16.hip: PoolOut)."""
     C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
     n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
     ws = torch.empty((n_ws,), device=A.device, dtype=torch.float32) if n_ws else None
+    if pool is not None:
+        S, ymax, ymin, amax, amin = pool
+        _call(_lib.omnipq_gemm_nt_bf16_stats_pool, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws),
+              S, _p(ymax), _p(ymin), _p(amax), _p(amin))
+        return C
     _call(_lib.omnipq_gemm_nt_bf16_stats, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws))
     return C
 
@@ -150,7 +156,10 @@ def affine_pays(P, N):
     return True
 
 
-def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None):
+POOL_EPILOGUE = os.environ.get("OMNIPQ_POOL_EPILOGUE", "1") != "0"
+
+
+def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None):
     """bf16 C = relu(below.a * Y + below.b) Bw^T (+ bias); sums (f64 [2][N], zero on entry): also C's statistics."""
     C = torch.empty((M, N), device=Y.device, dtype=torch.bfloat16) if out is None else out
     ws = None
@@ -163,10 +172,19 @@ def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None):
         # them, with mean / invstd and the running-statistics update) -- one launch less per BatchNorm layer
         fsums, count, gamma, beta, eps, momentum, rm, rv, cb = fin
         below.fin = None
+        if pool is not None:
+            S, ymax, ymin, amax, amin = pool
+            _call(_lib.omnipq_gemm_nt_bf16_bnaffine_pool, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count),
+                  _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm), _p(rv), _p(cb), _p(below.a),
+                  _p(below.b), _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(bias), _p(sums), _p(ws), S,
+                  _p(ymax), _p(ymin), _p(amax), _p(amin))
+            return C
         _call(_lib.omnipq_gemm_nt_bf16_bnaffine, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count), _p(gamma),
               _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm), _p(rv), _p(cb), _p(below.a), _p(below.b),
               _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(bias), _p(sums), _p(ws))
         return C
+    if pool is not None:
+        raise RuntimeError("gemm_nt_affine: ball extrema need the layer below to be finalised in the prologue")
     _call(_lib.omnipq_gemm_nt_bf16_affine, Y, M, N, K, _p(Y), K, _p(below.a), _p(below.b), _p(Bw), K, _p(C), N,
           _p(bias), _p(sums), _p(ws))
     return C
@@ -693,6 +711,7 @@ class FusedSAStage(torch.autograd.Function):
 
         layers = []
         X0 = X
+        pool = None
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             rm, rv, nbt, momentum, eps = bn_cfg[l]
@@ -708,11 +727,17 @@ class FusedSAStage(torch.autograd.Function):
                                          persistent=is_persistent(W))
             if training:
                 sums = zeros_f64(2, cout, dev)
+                pool = None
+                if l == L - 1 and POOL_EPILOGUE and 128 % S == 0 and (X is not None or layers[l - 1].fin is not None):
+                    # the last layer's GEMM also records every ball's extrema: the pooling pass below needs no Y
+                    ext16 = torch.empty((2, B * M, cout), device=dev, dtype=torch.bfloat16)
+                    ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
+                    pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
                 if l > 0 and X is None:
                     # the layer below never stored relu(bn(Y)): this GEMM rebuilds it while staging its operand
-                    lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums)
+                    lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums, pool=pool)
                 else:
-                    lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums)     # GEMM + batch statistics
+                    lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums, pool=pool)     # GEMM + batch statistics
                 _allreduce_(sums)
                 stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
                 lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
@@ -757,8 +782,14 @@ class FusedSAStage(torch.autograd.Function):
         out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
         out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
         arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
-        _call(_lib.omnipq_sa_pool, last.Y, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm),
-              _p(arg))
+        ysel = None
+        if training and pool is not None:
+            ysel = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+            _call(_lib.omnipq_sa_pool_select, last.Y, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
+                  _p(pool[3]), _p(pool[4]), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
+        else:
+            _call(_lib.omnipq_sa_pool, last.Y, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32),
+                  _p(out_pm), _p(arg))
         # reference layout (B, C, M) as a VIEW of the position-major result: values, shape and dtype are
         # the reference's, only the strides differ (no transpose pass; every consumer on this path
         # either accepts strides or wants the position-major form back)
@@ -768,7 +799,7 @@ class FusedSAStage(torch.autograd.Function):
         ctx.X0 = X0
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
         ctx.idx = idx
-        ctx.out_pm, ctx.arg = out_pm, arg
+        ctx.out_pm, ctx.arg, ctx.ysel = out_pm, arg, ysel
         ctx.has_features = features is not None
         ctx.feat_dtype = features.dtype if features is not None else None
         ctx.training = training
@@ -795,8 +826,12 @@ class FusedSAStage(torch.autograd.Function):
 
         last = layers[-1]
         sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
-        _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
-              _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
+        if ctx.ysel is not None:
+            _call(_lib.omnipq_sa_pool_bwd_stats_sel, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
+                  _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums))
+        else:
+            _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
+                  _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
         # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
         grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
         _allreduce_(sums[:2])

@@ -580,3 +580,57 @@ def test_weight_gradients_flushed_on_the_side_stream_are_the_same(monkeypatch):
     noise = max(rel_l2(again[n], base[n]) for n in base)
     worst = max(rel_l2(side[n], base[n]) for n in base)
     assert worst <= max(3.0 * noise, 1e-5), (worst, noise)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(2048, 256, 128, 64), (8192 + 256, 128, 64, 16), (4096, 288, 96, 32)])
+def test_ball_extrema_epilogue_and_pool_select_equal_the_pooling_pass(M, N, K, S):
+    """The statistics GEMM's ball extrema + omnipq_sa_pool_select == omnipq_sa_pool on the stored outputs (values,
+    bf16 twin, arg-max rows where the result is positive), for positive, negative and zero BatchNorm scales; and
+    omnipq_sa_pool_bwd_stats_sel == omnipq_sa_pool_bwd_stats."""
+    gen = torch.Generator().manual_seed(M + N + S)
+    A = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+    W = (torch.randn((N, K), generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev())
+    a = (0.5 + torch.rand(N, generator=gen)) * torch.where(torch.rand(N, generator=gen) < 0.3, -1.0, 1.0)
+    a[:3] = torch.tensor([0.0, 1.0, -1.0])
+    a = a.to(dev())
+    b = (0.4 * torch.randn(N, generator=gen)).to(dev())
+    BM = M // S
+    null = ctypes.c_void_p(0)
+    capi.lib().omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
+    ws = torch.empty(max(int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N)), 1), device=dev())
+    Y = torch.empty((M, N), device=dev(), dtype=torch.bfloat16)
+    sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+    ext16 = torch.full((2, BM, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    ext8 = torch.full((2, BM, N), 255, device=dev(), dtype=torch.uint8)
+    capi.ok("omnipq_gemm_nt_bf16_stats_pool", M, N, K, capi.P(A), K, capi.P(W), K, capi.P(Y), N, null, capi.P(sums),
+            capi.P(ws), S, capi.P(ext16[0]), capi.P(ext16[1]), capi.P(ext8[0]), capi.P(ext8[1]))
+    Yb = Y.float().view(BM, S, N)
+    assert torch.equal(ext16[0].float(), Yb.max(1).values) and torch.equal(ext16[1].float(), Yb.min(1).values)
+    first_max = (Yb == Yb.max(1, keepdim=True).values).float().argmax(1)
+    assert torch.equal(ext8[0].long(), first_max)
+    want32 = torch.empty((BM, N), device=dev())
+    want16 = torch.empty((BM, N), device=dev(), dtype=torch.bfloat16)
+    want_arg = torch.empty((BM, N), device=dev(), dtype=torch.uint8)
+    capi.ok("omnipq_sa_pool", 1, BM, S, N, capi.P(Y), capi.P(a), capi.P(b), capi.P(want32), capi.P(want16), capi.P(want_arg))
+    got32, got16 = torch.empty_like(want32), torch.empty_like(want16)
+    got_arg, ysel = torch.empty_like(want_arg), torch.empty_like(want16)
+    capi.ok("omnipq_sa_pool_select", ctypes.c_longlong(BM), N, capi.P(ext16[0]), capi.P(ext16[1]), capi.P(ext8[0]),
+            capi.P(ext8[1]), capi.P(a), capi.P(b), capi.P(got32), capi.P(got16), capi.P(got_arg), capi.P(ysel))
+    assert torch.equal(got32, want32) and torch.equal(got16, want16)
+    live = (want32 > 0) & (a != 0)[None, :]          # clamped results route no gradient; a == 0 ties every row
+    assert torch.equal(got_arg[live], want_arg[live])
+    assert bool((got_arg[want32 == 0] == 0).all())
+    picked = torch.gather(Yb, 1, got_arg.long().unsqueeze(1)).squeeze(1)
+    assert torch.equal(ysel.float()[live], picked[live])
+    # backward statistics from the selection
+    mean = (0.1 * torch.randn(N, generator=gen)).to(dev())
+    invstd = (0.5 + torch.rand(N, generator=gen)).to(dev())
+    g = torch.randn((BM, N), generator=gen).to(dev())
+    s0 = torch.empty((3, N), device=dev(), dtype=torch.float64)
+    s1 = torch.empty((3, N), device=dev(), dtype=torch.float64)
+    capi.ok("omnipq_sa_pool_bwd_stats", 1, BM, S, N, capi.P(Y), capi.P(mean), capi.P(invstd), capi.P(g), capi.P(want16),
+            capi.P(got_arg), capi.P(s0))
+    capi.ok("omnipq_sa_pool_bwd_stats_sel", ctypes.c_longlong(BM), N, capi.P(ysel), capi.P(mean), capi.P(invstd), capi.P(g),
+            capi.P(got16), capi.P(s1))
+    scale = s0[:2].abs().max(dim=1, keepdim=True).values + 1e-3
+    assert float(((s1[:2] - s0[:2]).abs() / scale).max()) < 1e-6
