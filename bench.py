@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
                  at N=1 only -- a reported baseline, not a target.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -232,6 +233,37 @@ def summarize_ops(sink, steps):
         row[0] += ms
         row[1] += 1
     return table
+
+
+def stage_breakdown(table, steps):
+    """SURVEY 8d's per-stage split of the native launches (event-timed, eager): kernel time per step in ms.  Stages
+    overlap in the captured step (sampling runs under backward), so the parts add up to more than ms_per_step."""
+    groups = collections.OrderedDict((k, 0.0) for k in (
+        "fps", "ball_query", "sa_stage (gather, MLP GEMMs, BN, pool, scatter)", "feature_propagation", "attention",
+        "decoder row kernels (LayerNorm, dropout)", "rows engine (heads, decoder projections / FFN, voting, embeddings)",
+        "head decode", "other native"))
+    for (nm, _), v in table.items():
+        base, sa = nm.split("@")[0], nm.endswith("@sa")
+        if base == "omnipq_furthest_point_sampling":
+            k = "fps"
+        elif base.startswith("omnipq_ball_query"):
+            k = "ball_query"
+        elif sa or base in ("omnipq_group_points", "omnipq_group_points_grad"):
+            k = "sa_stage (gather, MLP GEMMs, BN, pool, scatter)"
+        elif base.startswith(("omnipq_three_", "omnipq_interp_rows", "omnipq_place_rows")):
+            k = "feature_propagation"
+        elif base.startswith("omnipq_attn"):
+            k = "attention"
+        elif base.startswith(("omnipq_add_dropout_layernorm", "omnipq_relu_dropout", "omnipq_add_to_bf16")):
+            k = "decoder row kernels (LayerNorm, dropout)"
+        elif base.startswith(("omnipq_head_decode", "omnipq_quad_decode")):
+            k = "head decode"
+        elif base.startswith(("omnipq_gemm", "omnipq_bn", "omnipq_colsum", "omnipq_prep", "omnipq_unprep", "omnipq_sums")):
+            k = "rows engine (heads, decoder projections / FFN, voting, embeddings)"
+        else:
+            k = "other native"
+        groups[k] += v[0] / steps
+    return {k: round(v, 3) for k, v in groups.items()}
 
 
 def cpu_baseline(args):
@@ -631,6 +663,12 @@ def main():
                                "algorithmic_bytes_per_launch": nbytes}
             native_ms = sum(v[0] for v in table.values()) / timing_steps
             rec["native_ops_ms_per_step"] = native_ms
+            if name.split("@")[0] == "omnipq_furthest_point_sampling":
+                # latency bound by construction (m - 1 dependent argmax rounds): SURVEY 8d asks for rounds/s too
+                rec["roofline"]["rounds_per_s"] = (a[2] - 1) / (avg_ms * 1e-3)
+                rec["roofline"]["note"] = ("furthest-point sampling: 2047 dependent rounds over 40 000 points per scene, "
+                                           "2.6 us per round; off the critical path (next batch's plan, side stream)")
+            rec["breakdown_ms_per_step"] = stage_breakdown(table, timing_steps)
             # the stage BASELINE.json's target is quoted on: every kernel of the five SA layers, fwd+bwd
             sa_ms = sum(v[0] for (nm, _), v in table.items()
                         if nm.endswith("@sa") or nm in ("omnipq_group_points", "omnipq_group_points_grad")) / timing_steps
