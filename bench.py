@@ -583,9 +583,6 @@ def main():
         step(i)
     fence()
     sink = None
-    if not args.no_op_timing and not use_graph:
-        sink = []
-        ext.set_timing_sink(sink)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -593,14 +590,16 @@ def main():
     dt = time.perf_counter() - t0
     ext.set_timing_sink(None)
     ext.fps_check()
-    timing_note = "events around every C-ABI launch inside the timed region"
+    timing_note = ""
     timing_steps = args.steps
-    if use_graph and not args.no_op_timing:
-        # A graph replay cannot host events, so the per-kernel durations for the roofline are taken
-        # right after the timed region from eager steps over the same batches (same kernels, same
-        # shapes; rocprofv3 of this command sees both and its averages agree).
+    if not args.no_op_timing:
+        # A graph replay cannot host events (and in eager mode two events per launch cost a third of the step on the
+        # host), so the per-kernel durations for the roofline are taken right after the timed region from eager
+        # steps over the same batches (same kernels, same shapes; rocprofv3 of this command sees both and its
+        # averages agree).  Under torch.distributed they are this rank's own steps (SyncBN collectives included,
+        # no gradient all-reduce).
         eager_args = argparse.Namespace(**{**vars(args), "graph": "off"})
-        eager_step, _ = make_step(net, model, pool, eager_args, amp_dtype, world, teacher=teacher,
+        eager_step, _ = make_step(net, net, pool, eager_args, amp_dtype, world, teacher=teacher,
                                   teacher_pool=teacher_pool)
         eager_step(0)
         fence()
@@ -612,7 +611,7 @@ def main():
         fence()
         ext.set_timing_sink(None)
         timing_note = (f"events around every C-ABI launch in {timing_steps} eager steps run right after the timed "
-                       "hipGraph replays (a replay cannot host events)")
+                       + ("hipGraph replays (a replay cannot host events)" if use_graph else "steps"))
     assert torch.isfinite(loss.detach()).item(), "non-finite loss"
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
