@@ -27,8 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GPITCH = 40;                 // bf16 elements per staged row (32 + 8 pad) = 80 B
-constexpr int GCPITCH = 136;               // bf16 C-tile pitch (128 + 8) = 272 B
-constexpr int GCPITCH_F32 = 132;           // f32 C-tile pitch
 
 struct GemmArgs {
   int M, N, K;          // C is M x N, contraction length K (all operands row-major, K contiguous)
@@ -88,7 +86,12 @@ struct PoolOut {
   unsigned char *amax, *amin;     // [M / s][N] row within the ball
 };
 
-template <bool OUT_F32, int STATS = 0, bool AFF = false>
+// T: tile edge, 128 (four waves x 2 x 2 MFMA blocks) or 64 (four waves x one block).  The per-point layers outside
+// the SA stages have 96..200 tiles of 128 x 128 and 9 K-steps: one wave per SIMD on a third of the chip, each issuing
+// its 8 MFMAs per K-step back to back (0.21 of the 0.36 us a K-step takes) -- they are bound by the MFMA issue of ONE
+// wave, not by loads (three K-steps of register prefetch changed nothing).  64 x 64 tiles put four times as many
+// waves to work, 2 MFMAs per step each.
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
@@ -97,9 +100,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
                                                         BnBwdEpilogue bn = BnBwdEpilogue(),
                                                         AffineIn aff = AffineIn(),
                                                         PoolOut pool = PoolOut()) {
-  // staging: [2 buffers][A | B][128 rows][GPITCH]; the C tile aliases it after the main loop
-  constexpr int STAGE_ELEMS = 2 * 2 * 128 * GPITCH;                       // 20480 bf16 = 40 KB
-  constexpr int CT_BYTES = OUT_F32 ? 128 * GCPITCH_F32 * 4 : 128 * GCPITCH * 2;
+  static_assert(T == 128 || T == 64, "tile edge");
+  constexpr int NI = T / 64;                   // 32 x 32 MFMA blocks per wave and dimension
+  constexpr int CP = T + 8, CPF = T + 4;       // C-tile pitches (bf16 / f32 elements)
+  constexpr int PIECES = T / 8;                // 16-byte pieces per bf16 row of the C tile
+  constexpr int RG = 256 / PIECES;             // row groups of the store loop
+  // staging: [2 buffers][A | B][T rows][GPITCH]; the C tile aliases it after the main loop
+  constexpr int STAGE_ELEMS = 2 * 2 * T * GPITCH;                         // T = 128: 20480 bf16 = 40 KB
+  constexpr int CT_BYTES = OUT_F32 ? T * CPF * 4 : T * CP * 2;
   constexpr int LDS_BYTES = (STAGE_ELEMS * 2 > CT_BYTES) ? STAGE_ELEMS * 2 : CT_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   const int mt = xcd + 8 * (local / g.n_tiles);
   const int nt = local % g.n_tiles;
   if (mt >= g.m_tiles) return;
-  const int m0 = mt * GBM, n0 = nt * GBN;
+  const int m0 = mt * T, n0 = nt * T;
   const int kbeg = (int)blockIdx.z * g.k_chunk;
   int kend = kbeg + g.k_chunk;
   if (kend > g.K) kend = g.K;
@@ -125,10 +133,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   // Rows past M (or N) are clamped to the last valid row instead of being zero-filled: whatever they
   // contribute lands in C rows / columns that are never stored, and the loads stay unconditional
   // 16-byte loads (a select against zero makes hipcc split them into predicated dword loads).
-  int srow[2], skc[2];
-  const bf16_t *ga[2], *gb[2];
+  int srow[NI], skc[NI];
+  const bf16_t *ga[NI], *gb[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int q = tid + i * 256;
     srow[i] = q >> 2;
     skc[i] = q & 3;
@@ -139,11 +147,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     gb[i] = B + (size_t)br * g.ldb + kbeg + skc[i] * 8;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -180,18 +188,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     __syncthreads();
   }
 
-  uint4 ra[2], rb[2];
+  uint4 ra[NI], rb[NI];
   auto load_tiles = [&](int kt) {
     const int koff = kt * GBK;     // whole K-steps only: K and k_chunk are multiples of GBK
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       ra[i] = ldg16(ga[i] + koff);
       rb[i] = ldg16(gb[i] + koff);
     }
   };
   auto store_tiles = [&](int buf, int kt) {
-    bf16_t *sa = stage + buf * (2 * 128 * GPITCH);
-    bf16_t *sb = sa + 128 * GPITCH;
+    bf16_t *sa = stage + buf * (2 * T * GPITCH);
+    bf16_t *sb = sa + T * GPITCH;
     if (AFF) {
       // a, b of this thread's 8 channels of K-step kt (both chunks share them): four LDS reads
       const int k0 = kbeg + kt * GBK + skc[0] * 8;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         fb4[h] = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0 + 4 * h);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
         ra[i].x = affine_relu_pair(ra[i].x, fa4[0][0], fb4[0][0], fa4[0][1], fb4[0][1]);
         ra[i].y = affine_relu_pair(ra[i].y, fa4[0][2], fb4[0][2], fa4[0][3], fb4[0][3]);
         ra[i].z = affine_relu_pair(ra[i].z, fa4[1][0], fb4[1][0], fa4[1][1], fb4[1][1]);
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       *reinterpret_cast<uint4 *>(sa + srow[i] * GPITCH + skc[i] * 8) = ra[i];
       *reinterpret_cast<uint4 *>(sb + srow[i] * GPITCH + skc[i] * 8) = rb[i];
     }
@@ -226,20 +234,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
-    const bf16_t *sa = stage + buf * (2 * 128 * GPITCH);
-    const bf16_t *sb = sa + 128 * GPITCH;
+    const bf16_t *sa = stage + buf * (2 * T * GPITCH);
+    const bf16_t *sb = sa + T * GPITCH;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[NI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8 *>(sa + (wm * 64 + i * 32 + frow) * GPITCH + kk * 16 + fk);
-        fb[i] = *reinterpret_cast<const bf16x8 *>(sb + (wn * 64 + i * 32 + frow) * GPITCH + kk * 16 + fk);
+      for (int i = 0; i < NI; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8 *>(sa + (wm * (T / 2) + i * 32 + frow) * GPITCH + kk * 16 + fk);
+        fb[i] = *reinterpret_cast<const bf16x8 *>(sb + (wn * (T / 2) + i * 32 + frow) * GPITCH + kk * 16 + fk);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1, kt + 1);
@@ -252,22 +260,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   if (OUT_F32) {
     float *ct = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
-          ct[row * GCPITCH_F32 + wn * 64 + j * 32 + ccol] = acc[i][j][r];
+          const int row = wm * (T / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+          ct[row * CPF + wn * (T / 2) + j * 32 + ccol] = acc[i][j][r];
         }
     __syncthreads();
     float *C = reinterpret_cast<float *>(Cout) + (size_t)blockIdx.z * g.M * g.ldc;
-    // 128 rows x 32 float4 pieces
-    for (int q = tid; q < 128 * 32; q += 256) {
-      const int row = q >> 5, piece = q & 31;
+    // T rows x T / 4 float4 pieces
+    for (int q = tid; q < T * (T / 4); q += 256) {
+      const int row = q / (T / 4), piece = q % (T / 4);
       const int gr = m0 + row, gc = n0 + piece * 4;
       if (gr < g.M && gc < g.N) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(ct + row * GCPITCH_F32 + piece * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ct + row * CPF + piece * 4);
         *reinterpret_cast<f32x4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 4
       }
     }
@@ -277,18 +285,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     // (c, c+1) of row r, the odd lane with (c-1, c) of row r+1 -> 32 ds_write_b32 instead of 64 b16.
     unsigned *ct32 = reinterpret_cast<unsigned *>(smem);
     const bool odd = lane & 1;
-    float bcol[2] = {0.f, 0.f};            // per-column bias (f32, added before the single bf16 rounding)
+    float bcol[NI];                        // per-column bias (f32, added before the single bf16 rounding)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bcol[j] = 0.f;
     if (bias) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = n0 + wn * 64 + j * 32 + ccol;
+      for (int j = 0; j < NI; ++j) {
+        const int c = n0 + wn * (T / 2) + j * 32 + ccol;
         bcol[j] = c < g.N ? bias[c] : 0.f;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const float mine0 = acc[i][j][r] + bcol[j], mine1 = acc[i][j][r + 1] + bcol[j];
@@ -298,19 +308,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
           const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
           const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
                                   ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
-          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0 + (odd ? 1 : 0);
-          const int col = wn * 64 + j * 32 + (ccol & ~1);
-          ct32[(row * GCPITCH + col) >> 1] = packed;
+          const int row = wm * (T / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + crow0 + (odd ? 1 : 0);
+          const int col = wn * (T / 2) + j * 32 + (ccol & ~1);
+          ct32[(row * CP + col) >> 1] = packed;
         }
     const bf16_t *ct = reinterpret_cast<const bf16_t *>(smem);
     __syncthreads();
     bf16_t *C = reinterpret_cast<bf16_t *>(Cout);
-    float cs[8], cs2[8];                   // this thread's 8 columns (piece = tid & 15), rows tid>>4 + 16*it
+    float cs[8], cs2[8];                   // this thread's 8 columns (piece = tid % PIECES), rows tid / PIECES + RG * it
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cs2[e] = 0.f;
     float av[8], bv[8], mu[8], is[8];
     if (STATS >= 3) {
-      int c0 = n0 + (tid & 15) * 8;
+      int c0 = n0 + (tid % PIECES) * 8;
       c0 = c0 < g.N ? c0 : 0;              // columns past N are never accumulated
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -320,11 +330,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         is[e] = bn.invstd[c0 + e];
       }
     }
-    for (int q = tid; q < 128 * 16; q += 256) {
-      const int row = q >> 4, piece = q & 15;
+    for (int q = tid; q < T * PIECES; q += 256) {
+      const int row = q / PIECES, piece = q % PIECES;
       const int gr = m0 + row, gc = n0 + piece * 8;
       if (gr < g.M && gc < g.N) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * GCPITCH + piece * 8);
+        const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * CP + piece * 8);
         *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
         if (STATS >= 3) {
           const uint4 yv = *reinterpret_cast<const uint4 *>(bn.Y + (size_t)gr * g.ldc + gc);
@@ -352,16 +362,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
     }
     if ((STATS == 1 || STATS == 2) && pool.s > 0) {
-      const int col = tid & 127, gc = n0 + col;
-      const int balls = 128 / pool.s;
+      const int col = tid % T, gc = n0 + col;
+      const int balls = T / pool.s;
       if (gc < g.N) {
-        for (int ball = tid >> 7; ball < balls; ball += 2) {
+        for (int ball = tid / T; ball < balls; ball += 256 / T) {
           const int r0 = ball * pool.s;
           if (m0 + r0 >= g.M) break;
           float hi = -INFINITY, lo = INFINITY;
           int ihi = 0, ilo = 0;
           for (int r = 0; r < pool.s; ++r) {
-            const float v = (float)ct[(r0 + r) * GCPITCH + col];
+            const float v = (float)ct[(r0 + r) * CP + col];
             if (v > hi) { hi = v; ihi = r; }
             if (v < lo) { lo = v; ilo = r; }
           }
@@ -374,20 +384,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
     }
     if (STATS) {
-      __syncthreads();                     // the C tile is dead: reuse it as [16 row groups][2][128] floats
+      __syncthreads();                     // the C tile is dead: reuse it as [RG row groups][2][T] floats
+      static_assert(RG * 2 * T * 4 <= LDS_BYTES, "statistics fold must fit under the staging buffers");
       float *red = reinterpret_cast<float *>(smem);
-      const int rg = tid >> 4, piece = tid & 15;
+      const int rg = tid / PIECES, piece = tid % PIECES;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(rg * 2 + 0) * 128 + piece * 8 + e] = cs[e];
-        red[(rg * 2 + 1) * 128 + piece * 8 + e] = cs2[e];
+        red[(rg * 2 + 0) * T + piece * 8 + e] = cs[e];
+        red[(rg * 2 + 1) * T + piece * 8 + e] = cs2[e];
       }
       __syncthreads();
-      const int which = tid >> 7, col = tid & 127;
+      const int which = tid / T, col = tid % T;
       float tot = 0.f;
+      if (tid < 2 * T) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot += red[(r * 2 + which) * 128 + col];
-      if (n0 + col < g.N) {
+        for (int r = 0; r < RG; ++r) tot += red[(r * 2 + which) * T + col];
+      }
+      if (tid < 2 * T && n0 + col < g.N) {
         if (STATS == 1 || STATS == 3)
           atomicAdd(reinterpret_cast<double *>(stats_out) + (size_t)which * g.N + n0 + col, (double)tot);
         else
@@ -488,6 +501,21 @@ static int gemm_nt_splitk_bf16(int M, int N, int K, const void *A, int lda, cons
   return OMNIPQ_OK;
 }
 
+// Few 128 x 128 tiles (the per-point layers outside the SA stages): 64 x 64 tiles, see the kernel's comment on T.
+// OMNIPQ_GEMM_SMALL: 0 never, 1 (default) when at most 256 big tiles would be launched, 2 always.
+static bool gemm_nt_small_tiles(int M, int N) {
+  static const int mode = getenv("OMNIPQ_GEMM_SMALL") ? atoi(getenv("OMNIPQ_GEMM_SMALL")) : 1;
+  if (mode != 1) return mode == 2;
+  static const int limit = getenv("OMNIPQ_GEMM_SMALL_TILES") ? atoi(getenv("OMNIPQ_GEMM_SMALL_TILES")) : 256;
+  return (long long)((M + 127) / 128) * ((N + 127) / 128) <= limit;
+}
+
+static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int ldc, int T) {
+  return omnipq::GemmArgs{M, N, K, lda, ldb, ldc, K, (M + T - 1) / T, (N + T - 1) / T};
+}
+
+static dim3 gemm_nt_grid(const omnipq::GemmArgs &g) { return dim3(((g.m_tiles + 7) / 8) * 8 * g.n_tiles, 1, 1); }
+
 // C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.
 extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                    void *C, int ldc, void *stream) {
@@ -495,10 +523,15 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
-  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
-  const int groups = (g.m_tiles + 7) / 8;
-  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
+  if (gemm_nt_small_tiles(M, N)) {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
+    gemm_nt_kernel<false, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+        g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
+  } else {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                          nullptr);
+  }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -525,8 +558,14 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   if (g.m_tiles <= kStatsDirectTiles) {
-    gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
-                                                                sums);
+    if (gemm_nt_small_tiles(M, N)) {
+      const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
+      gemm_nt_kernel<false, 1, false, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
+          gs, (const bf16_t *)A, (const bf16_t *)B, C, bias, sums);
+    } else {
+      gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+                                                                  sums);
+    }
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
@@ -553,9 +592,21 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  const bool small = pool.s == 0 && gemm_nt_small_tiles(M, N);
+  const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
   if (!sums) {
-    gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
-                                                                      bias, nullptr, BnBwdEpilogue(), aff);
+    if (small)
+      gemm_nt_kernel<false, 0, true, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
+          gs, (const bf16_t *)A, (const bf16_t *)B, C, bias, nullptr, BnBwdEpilogue(), aff);
+    else
+      gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                        bias, nullptr, BnBwdEpilogue(), aff);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (g.m_tiles <= kStatsDirectTiles && small) {
+    gemm_nt_kernel<false, 1, true, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
+        gs, (const bf16_t *)A, (const bf16_t *)B, C, bias, sums, BnBwdEpilogue(), aff);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
@@ -720,8 +771,14 @@ extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   BnBwdEpilogue bn{(const bf16_t *)Y, a, b, mean, invstd};
   if (g.m_tiles <= kStatsDirectTiles) {
-    gemm_nt_kernel<false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
-                                                                nullptr, sums, bn);
+    if (gemm_nt_small_tiles(M, N)) {
+      const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
+      gemm_nt_kernel<false, 3, false, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
+          gs, (const bf16_t *)A, (const bf16_t *)B, C, nullptr, sums, bn);
+    } else {
+      gemm_nt_kernel<false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                  nullptr, sums, bn);
+    }
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
@@ -745,10 +802,15 @@ extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int 
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
-  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
-  const int groups = (g.m_tiles + 7) / 8;
-  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+  if (gemm_nt_small_tiles(M, N)) {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
+    gemm_nt_kernel<false, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+        g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+  } else {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                          bias);
+  }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -765,10 +827,15 @@ extern "C" int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int ld
   const int slabs = gemm_nt_splitk_slabs(M, N, K);
   if (slabs > 1 && workspace && ldc == N)
     return gemm_nt_splitk_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, workspace, slabs, stream);
-  GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
-  const int groups = (g.m_tiles + 7) / 8;
-  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+  if (gemm_nt_small_tiles(M, N)) {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
+    gemm_nt_kernel<false, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+        g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+  } else {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                          bias);
+  }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
