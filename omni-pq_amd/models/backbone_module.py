@@ -92,6 +92,14 @@ class Pointnet2Backbone(nn.Module):
         plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud, "trusted": trusted,
                 "extra": None}
         ext = pointnet2_utils._ext
+        if not torch.cuda.is_current_stream_capturing():
+            # The cloud and the persistent index buffers come from the caller's stream's pool but are read / written
+            # by the sampling stream: if either dies while a plan is still running (a model dropped right after a
+            # prefetch -- seen in the test-suite as FPS indices landing in the next test's fresh tensor), the
+            # allocator must not hand the block out before the sampling stream is done with it.
+            pointcloud.record_stream(side)
+            for buf in bufs:
+                buf.record_stream(side)
         with torch.cuda.stream(side), torch.no_grad():
             xyz = pointcloud[..., 0:3].contiguous()
             for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
@@ -112,6 +120,8 @@ class Pointnet2Backbone(nn.Module):
                         ("extra", name, pointcloud.shape[0], str(pointcloud.device)),
                         torch.zeros((pointcloud.shape[0], self.plan_extra[name]), device=pointcloud.device,
                                     dtype=torch.int32))
+                    if not torch.cuda.is_current_stream_capturing():
+                        extra.record_stream(side)
                     if hasattr(ext, "set_timing_sink"):
                         e_inds = ext.furthest_point_sampling(xyz, self.plan_extra[name], out=extra)
                     else:

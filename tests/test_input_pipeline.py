@@ -74,3 +74,10 @@ def test_pipeline_delivers_the_batches_and_their_sampling_plans():
     pipe.push(host[1])
     with pytest.raises(RuntimeError, match="overwrite"):
         pipe.push(host[2])
+    # Two sampling plans are still running on the side stream when the backbone (and its index buffers) go out of
+    # scope here: Pointnet2Backbone records its buffers on that stream, so the blocks cannot be handed to the
+    # next allocation while the sampling kernels still write into them.
+    del backbone, pipe
+    fresh = [torch.full((2, 2048), -7, device=dev, dtype=torch.int32) for _ in range(8)]
+    torch.cuda.synchronize()
+    assert all(bool((t == -7).all()) for t in fresh)
