@@ -98,3 +98,29 @@ def test_synth_generators_are_deterministic_and_sharded():
     assert a.shape == (2, 256, 9) and torch.equal(a[1], b[0])
     adv = synth.adversarial_cloud(0, 1, 640)
     assert (adv[0, 0] == 0).all() and float(adv[0, -1, 0]) == 50.0
+
+
+def test_bench_accounting_helpers(built_lib):
+    """bench.py's host-side bookkeeping: SURVEY 8d's algorithmic bytes of the SA stages, the per-stage grouping of
+    the timed launches and the workload names -- no GPU involved."""
+    import argparse
+    import bench
+    # SURVEY 8d: fwd+bwd of the five SA stages = 3165.7 MB / scene at e = 4, half of the feature bytes at e = 2
+    per_scene = bench.sa_stage_algorithmic_bytes(1, 40000, 0, 4) / 1e6
+    assert abs(per_scene - 3165.7) < 3.0, per_scene
+    assert bench.sa_stage_algorithmic_bytes(8, 40000, 0, 2) == 12673789952
+    table = {("omnipq_furthest_point_sampling", (8, 40000, 2048)): [10.0, 2, 0],
+             ("omnipq_gemm_nt_bf16_stats@sa", (1, 2, 3)): [4.0, 4, 0],
+             ("omnipq_ball_query_grid@sa", (1,)): [1.0, 2, 0],
+             ("omnipq_gemm_nt_bf16", (4096, 288, 288)): [6.0, 20, 0],
+             ("omnipq_attn_fwd", (8,)): [2.0, 2, 0],
+             ("omnipq_head_decode", (2048,)): [0.5, 2, 0]}
+    got = bench.stage_breakdown(table, 2)
+    assert got["fps"] == 5.0 and got["ball_query"] == 0.5 and got["attention"] == 1.0 and got["head decode"] == 0.25
+    assert got["sa_stage (gather, MLP GEMMs, BN, pool, scatter)"] == 2.0
+    assert got["rows engine (heads, decoder projections / FFN, voting, embeddings)"] == 3.0
+    assert abs(sum(got.values()) - sum(v[0] for v in table.values()) / 2) < 1e-9
+    ns = argparse.Namespace
+    assert bench.workload_name(ns(batch=8, points=40000, extra_channels=0)) == "BASELINE configs[1]"
+    assert bench.workload_name(ns(batch=4, points=50000, extra_channels=6)) == "BASELINE configs[3]"
+    assert bench.workload_name(ns(batch=2, points=1000, extra_channels=0)) == "custom configuration"
