@@ -307,8 +307,11 @@ class deferred_wgrads:
             self.flush()
             for st in getattr(self, "_side_streams", ()):          # early flushes: .grad is complete after the block
                 torch.cuda.current_stream(st.device).wait_stream(st)
+            for param, g in getattr(self, "_assign", ()):
+                self._accumulate(param, g)
         self.items = None
         self._inflight = None
+        self._assign = None
         return False
 
     def flush_on(self, stream):
@@ -406,11 +409,14 @@ class deferred_wgrads:
         for param, view in pieces:
             if param is None:                        # rows of a scratch result into a buffer assigned below
                 view[0].add_(view[1].reshape(-1))
+        # `.grad` is touched only when the block ends (after the side streams have been joined): autograd may still
+        # accumulate into the same parameter later in this backward pass, on the caller's stream
+        assign = self.__dict__.setdefault("_assign", [])
         for param, buf, _ in whole.values():
-            self._accumulate(param, buf)
+            assign.append((param, buf))
         for param, view in pieces:
             if param is not None:
-                self._accumulate(param, view.view(param.shape))
+                assign.append((param, view.view(param.shape)))
 
     @staticmethod
     def _piece(pieces, whole, param, off, view):
