@@ -50,7 +50,8 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(REPO, "include", "omnipq_pointops.h"))
+    inc = os.path.join(REPO, "include")
+    headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     objs = []
     procs = []
     for src in sources():

@@ -227,6 +227,109 @@ class _TnProblem(ctypes.Structure):
 _lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
 
 
+class _RowGemmDesc(ctypes.Structure):
+    """include/omnipq_chain.h: omnipq_rowgemm_desc"""
+    _fields_ = [("P", ctypes.c_longlong), ("N", ctypes.c_int), ("K", ctypes.c_int), ("a_kind", ctypes.c_int),
+                ("epi_kind", ctypes.c_int),
+                ("A0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("arg", ctypes.c_void_p), ("lda", ctypes.c_int),
+                ("n", ctypes.c_int), ("m", ctypes.c_int), ("s", ctypes.c_int), ("cin", ctypes.c_int),
+                ("xyz", ctypes.c_void_p), ("new_xyz", ctypes.c_void_p), ("idx", ctypes.c_void_p),
+                ("inv_r", ctypes.c_float), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("a_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("fin_sums", ctypes.c_void_p),
+                ("fin_count", ctypes.c_double), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("conv_bias", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
+                ("a_out", ctypes.c_void_p), ("b_out", ctypes.c_void_p), ("mean_out", ctypes.c_void_p),
+                ("invstd_out", ctypes.c_void_p),
+                ("bwd_sums", ctypes.c_void_p), ("inv_count", ctypes.c_double), ("bn_a", ctypes.c_void_p),
+                ("bn_mean", ctypes.c_void_p), ("bn_invstd", ctypes.c_void_p), ("gb_out", ctypes.c_void_p),
+                ("B", ctypes.c_void_p), ("ldb", ctypes.c_int),
+                ("C", ctypes.c_void_p), ("ldc", ctypes.c_int),
+                ("pool_s", ctypes.c_int), ("sums", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("ymax", ctypes.c_void_p), ("ymin", ctypes.c_void_p), ("amax", ctypes.c_void_p), ("amin", ctypes.c_void_p),
+                ("below_Y", ctypes.c_void_p), ("below_a", ctypes.c_void_p), ("below_b", ctypes.c_void_p),
+                ("below_mean", ctypes.c_void_p), ("below_invstd", ctypes.c_void_p)]
+
+
+class _TnGenDesc(ctypes.Structure):
+    """include/omnipq_chain.h: omnipq_tn_gen_desc"""
+    _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_longlong), ("a_kind", ctypes.c_int),
+                ("b_kind", ctypes.c_int), ("A0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("arg", ctypes.c_void_p),
+                ("lda", ctypes.c_int), ("s", ctypes.c_int), ("bwd_sums", ctypes.c_void_p), ("inv_count", ctypes.c_double),
+                ("bn_a", ctypes.c_void_p), ("bn_mean", ctypes.c_void_p), ("bn_invstd", ctypes.c_void_p),
+                ("B0", ctypes.c_void_p), ("ldb", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p),
+                ("C", ctypes.c_void_p), ("workspace", ctypes.c_void_p)]
+
+
+A_PLAIN, A_AFFINE, A_GATHER, A_DY, A_DY3 = 0, 1, 2, 3, 4
+E_STORE, E_STORE_STATS, E_STORE_BNBWD = 0, 1, 2
+_lib.omnipq_sa_rowgemm_workspace_floats.restype = ctypes.c_longlong
+_lib.omnipq_sa_rowgemm_workspace_floats.argtypes = [ctypes.c_longlong, ctypes.c_int]
+
+# Row-tile GEMMs with operand generators (csrc/sa_chain.hip), OMNIPQ_SA_CHAIN=1.  Measured on the benchmark configuration
+# (tools/chain_check.py, round 2): 6.1 ms for the five SA stages against 5.7 ms for the per-layer kernels above -- the passes
+# it removes (gather, pool / BatchNorm backward apply) are paid back by two operand streams per generated gradient and by
+# load / compute / store phases that do not overlap inside a persistent workgroup (DESIGN.md section 4) -- so it is opt-in.
+CHAIN = os.environ.get("OMNIPQ_SA_CHAIN", "0") == "1"
+
+
+def _chain_kpad(cin):
+    """Padded width of the grouped rows [features(cin), xyz(3), 0...] for the row-tile GEMM: a multiple of 32 whose
+    K-step count the kernel covers in at most two chunks of 8 / 9 / 10 steps (csrc/sa_chain.hip: rowgemm_ks)."""
+    steps = (cin + 3 + 31) // 32
+    while True:
+        if steps in (1, 4, 8, 9, 10) or any(steps % k == 0 and steps // k <= 2 for k in (10, 9, 8)):
+            return steps * 32
+        steps += 1
+
+
+_lib.omnipq_pack_b_elems.restype = ctypes.c_longlong
+
+
+def pack_b(W, N, K):
+    """bf16 [N][K] weights -> the fragment order omnipq_sa_rowgemm reads (csrc/sa_chain.hip: pack_b_kernel)"""
+    out = torch.empty((int(_lib.omnipq_pack_b_elems(N, K)),), device=W.device, dtype=torch.bfloat16)
+    _call(_lib.omnipq_pack_b, W, N, K, _p(W), W.stride(0), _p(out))
+    return out
+
+
+def _rowgemm(anchor, **kw):
+    """One omnipq_sa_rowgemm launch; keyword arguments are descriptor fields (tensors are passed as such).  `B` is
+    the row-major bf16 weight [N][K] (packed here) unless `B_packed` is given."""
+    d = _RowGemmDesc()
+    keep = []
+    if "B_packed" in kw:
+        kw["B"] = kw.pop("B_packed")
+    elif isinstance(kw.get("B"), torch.Tensor):
+        kw["B"] = pack_b(kw["B"], kw["N"], kw["K"])
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(d, k, v)
+    if d.epi_kind != E_STORE and not d.workspace:
+        n_ws = int(_lib.omnipq_sa_rowgemm_workspace_floats(d.P, d.N))
+        if n_ws:
+            ws = torch.empty((n_ws,), device=anchor.device, dtype=torch.float32)
+            keep.append(ws)
+            d.workspace = ws.data_ptr()
+    _call(_lib.omnipq_sa_rowgemm, anchor, ctypes.byref(d))
+
+
+def _tn_gen(anchor, M, N, P, **kw):
+    """f32 C[M][N] = genA^T genB (csrc/sa_chain.hip: omnipq_gemm_tn_gen)"""
+    C = torch.empty((M, N), device=anchor.device, dtype=torch.float32)
+    ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=anchor.device, dtype=torch.float32)
+    d = _TnGenDesc()
+    d.M, d.N, d.P = M, N, P
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(d, k, v)
+    d.C, d.workspace = C.data_ptr(), ws.data_ptr()
+    _call(_lib.omnipq_gemm_tn_gen, anchor, ctypes.byref(d))
+    return C
+
+
 _ZERO_TAILS = {}
 
 
@@ -703,6 +806,10 @@ class FusedSAStage(torch.autograd.Function):
         kpad = _round_up(cin + 3, 32)
         inv_r = (1.0 / radius) if normalize_xyz else 1.0
         world = _world() if training else 1
+        if CHAIN and training and 64 % S == 0 and kpad <= 640 and L >= 1 and \
+                all(params[3 * l].shape[0] <= 512 for l in range(L)):
+            return FusedSAStage._forward_chain(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz,
+                                               bn_cfg, *params)
 
         if features is None:
             feat_pm = None
@@ -803,6 +910,7 @@ class FusedSAStage(torch.autograd.Function):
 
         ctx.layers = layers
         ctx.X0 = X0
+        ctx.chain = None
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
         ctx.idx = idx
         ctx.out_pm, ctx.arg, ctx.ysel = out_pm, arg, ysel
@@ -814,8 +922,186 @@ class FusedSAStage(torch.autograd.Function):
         return out, twin
 
     @staticmethod
+    def _forward_chain(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, bn_cfg, *params):
+        """Training-mode forward on the row-tile GEMMs with operand generators (csrc/sa_chain.hip): the grouped
+        tensor X0 and the activations relu(bn(Y_l)) are generated while the consumer GEMM stages its operand; what
+        is stored per layer is the pre-BN output Y_l (the backward pass needs it)."""
+        dev = xyz.device
+        B, N, _ = xyz.shape
+        M, S = idx.shape[1], idx.shape[2]
+        P = B * M * S
+        L = len(params) // 3
+        cin = 0 if features is None else features.shape[1]
+        kpad = _chain_kpad(cin)
+        inv_r = (1.0 / radius) if normalize_xyz else 1.0
+        world = _world()
+        if features is None:
+            feat_pm = None
+        elif feat_pm is None:
+            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()
+        xyz_c = xyz.detach().contiguous()
+        cen_c = new_xyz.detach().contiguous()
+
+        layers = []
+        pool = None
+        for l in range(L):
+            W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+            rm, rv, nbt, momentum, eps = bn_cfg[l]
+            lay = _Layer()
+            W2 = W.detach().reshape(W.shape[0], -1)
+            cout = W2.shape[0]
+            K = kpad if l == 0 else W2.shape[1]
+            lay.K, lay.C = K, cout
+            lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=True,
+                                         persistent=is_persistent(W))
+            sums = zeros_f64(2, cout, dev)
+            lay.Y = torch.empty((P, cout), device=dev, dtype=torch.bfloat16)
+            stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
+            lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
+            kw = dict(P=P, N=cout, K=K, epi_kind=E_STORE_STATS, B=lay.Wp, ldb=K, C=lay.Y, ldc=cout, sums=sums)
+            if l == L - 1:
+                ext16 = torch.empty((2, B * M, cout), device=dev, dtype=torch.bfloat16)
+                ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
+                pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
+                kw.update(pool_s=S, ymax=ext16[0], ymin=ext16[1], amax=ext8[0], amin=ext8[1])
+            if l == 0:
+                kw.update(a_kind=A_GATHER, A0=feat_pm, n=N, m=M, s=S, cin=cin, xyz=xyz_c, new_xyz=cen_c, idx=idx,
+                          inv_r=inv_r)
+            else:
+                prev = layers[l - 1]
+                fsums, count, pg, pb, peps, pmom, prm, prv, _ = prev.fin
+                prev.fin = None
+                kw.update(a_kind=A_AFFINE, A0=prev.Y, lda=prev.C, fin_sums=fsums, fin_count=count, gamma=pg, beta=pb,
+                          eps=peps, momentum=pmom, running_mean=prm, running_var=prv, a_out=prev.a, b_out=prev.b,
+                          mean_out=prev.mean, invstd_out=prev.invstd)
+            _rowgemm(xyz_c, **kw)
+            _allreduce_(sums)
+            lay.X = None
+            lay.fin = (sums, float(P) * world, gamma.detach(), beta.detach(), eps, momentum, rm, rv, None)
+            bump(nbt)
+            layers.append(lay)
+
+        last = layers[-1]
+        fsums, count, pg, pb, peps, pmom, prm, prv, _ = last.fin
+        last.fin = None
+        _call(_lib.omnipq_bn_finalize, last.Y, last.C, ctypes.c_double(count), _p(fsums), _p(pg), _p(pb),
+              ctypes.c_float(peps), ctypes.c_float(pmom), _p(prm), _p(prv), _p(last.a), _p(last.b), _p(last.mean),
+              _p(last.invstd), _p(None))
+        out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
+        out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+        arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
+        ysel = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+        _call(_lib.omnipq_sa_pool_select, last.Y, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
+              _p(pool[3]), _p(pool[4]), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
+        out = out_f32.transpose(1, 2)
+
+        ctx.layers = layers
+        ctx.X0 = None
+        ctx.chain = (xyz_c, cen_c, feat_pm)
+        ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
+        ctx.idx = idx
+        ctx.out_pm, ctx.arg, ctx.ysel = out_pm, arg, ysel
+        ctx.has_features = features is not None
+        ctx.feat_dtype = features.dtype if features is not None else None
+        ctx.training = True
+        twin = out_pm.view(B, M, last.C)
+        ctx.mark_non_differentiable(twin)
+        return out, twin
+
+    @staticmethod
+    def _backward_chain(ctx, g_out):
+        """Backward of _forward_chain: neither the max-pool gradient nor any BatchNorm-backward result dY_l is
+        written -- the weight- and data-gradient GEMMs of layer l generate dY_l = alpha dz_l + beta Y_l + gamma while
+        staging it (dz_L from the per-ball gradient and arg-max, dz_l<L = the masked ReLU gradient the layer above
+        stored), and the data-gradient GEMM's epilogue stores dz_{l-1} and its BatchNorm-backward totals."""
+        B, N, M, S, P, cin, kpad, inv_r, world = ctx.geom
+        layers = ctx.layers
+        L = len(layers)
+        dev = g_out.device
+        g_out = g_out.float().transpose(1, 2).contiguous()      # position-major [B*M][C] (no-op for a view)
+        inv_count = 1.0 / (float(P) * world)
+        grads = [None] * (3 * L)
+        sync = world > 1 or _FORCE_COLLECTIVES
+        xyz_c, cen_c, feat_pm = ctx.chain
+
+        last = layers[-1]
+        sums = torch.empty((2, last.C), device=dev, dtype=torch.float64)
+        gz = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+        _call(_lib.omnipq_sa_pool_bwd_stats_gz, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
+              _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), _p(gz))
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \
+            (ctx.has_features and ctx.needs_input_grad[2])
+        X0 = None
+        d_feat = d_xyz = d_cen = None
+        dz = None
+        for l in range(L - 1, -1, -1):
+            lay = layers[l]
+            # dgamma / dbeta of layer l are this rank's totals (DDP averages them): taken before the all-reduce
+            gb = None
+            if sync or (l == 0 and not need_in):
+                grads[3 * l + 1], grads[3 * l + 2] = affine_grads(sums, lay.C)
+                _allreduce_(sums)
+            else:
+                gb = torch.empty((2, lay.C), device=dev, dtype=torch.float32)
+                grads[3 * l + 1], grads[3 * l + 2] = gb[1], gb[0]
+            if l == L - 1:
+                akw = dict(a_kind=A_DY3, A0=gz, A1=lay.Y, arg=ctx.arg, lda=lay.C, s=S)
+            else:
+                akw = dict(a_kind=A_DY, A0=dz, A1=lay.Y, lda=lay.C)
+            akw.update(bwd_sums=sums, inv_count=inv_count, bn_a=lay.a, bn_mean=lay.mean, bn_invstd=lay.invstd)
+            # weight gradient dW_l = dY_l^T X_{l-1}
+            if l > 0:
+                prev = layers[l - 1]
+                dWp = _tn_gen(lay.Y, lay.C, lay.K, P, b_kind=A_AFFINE, B0=prev.Y, ldb=prev.C, ba=prev.a, bb=prev.b, **akw)
+            else:
+                X0 = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
+                _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
+                      _p(ctx.idx), _p(feat_pm), _p(X0))
+                dWp = _tn_gen(lay.Y, lay.C, lay.K, P, b_kind=A_PLAIN, B0=X0, ldb=kpad, **akw)
+            wk = cin + 3 if l == 0 else lay.K
+            grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
+            if l == 0 and not need_in:
+                break
+            if l > 0:
+                prev = layers[l - 1]
+                nsums = zeros_f64(2, prev.C, dev)
+                dzn = torch.empty((P, prev.C), device=dev, dtype=torch.bfloat16)
+                _rowgemm(lay.Y, P=P, N=prev.C, K=lay.C, epi_kind=E_STORE_BNBWD, B=lay.Wt, ldb=lay.C, C=dzn, ldc=prev.C,
+                         sums=nsums, below_Y=prev.Y, below_a=prev.a, below_b=prev.b, below_mean=prev.mean,
+                         below_invstd=prev.invstd, gb_out=gb, **akw)
+                dz, sums = dzn, nsums
+            else:
+                dX = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
+                # at most 512 columns per launch (sa3 / sa4: 544 = 256 + 288)
+                c0 = 0
+                while c0 < kpad:
+                    nc = kpad - c0 if kpad - c0 <= 512 else _round_up((kpad - c0) // 2, 32)
+                    _rowgemm(lay.Y, P=P, N=nc, K=lay.C, epi_kind=E_STORE, B=lay.Wt[c0:c0 + nc],
+                             ldb=lay.C, C=dX.data_ptr() + 2 * c0, ldc=kpad, gb_out=gb if c0 == 0 else None, **akw)
+                    c0 += nc
+                want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+                dfeat_pm = torch.empty((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
+                    else None
+                if want_xyz:
+                    d_xyz = torch.empty((B, N, 3), device=dev)
+                    d_cen = torch.empty((B, M, 3), device=dev)
+                offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
+                order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
+                scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
+                _call(_lib.omnipq_sa_build_csr, dX, B, N, M, S, _p(ctx.idx), _p(offsets), _p(order), _p(scratch))
+                _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
+                      _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
+                if dfeat_pm is not None:
+                    d_feat = dfeat_pm.transpose(1, 2).to(ctx.feat_dtype)
+        ctx.layers = None
+        ctx.chain = None
+        return (d_xyz, d_cen, d_feat, None, None, None, None, None, None, *grads)
+
+    @staticmethod
     def backward(ctx, g_out, _g_twin=None):
         with _tagged("@sa"):
+            if getattr(ctx, "chain", None) is not None:
+                return FusedSAStage._backward_chain(ctx, g_out)
             return FusedSAStage._backward(ctx, g_out)
 
     @staticmethod

@@ -1,0 +1,121 @@
+#!/usr/bin/env python
+"""A/B of the set-abstraction stage: row-tile GEMMs with operand generators (sa_fused.CHAIN = True) against the
+per-layer kernels (False) on the benchmark configuration -- outputs, gradients, and event-timed stage time.
+
+    python tools/chain_check.py [--batch 8] [--points 40000] [--steps 5]
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("omni-pq_amd", "omni-pq_amd/pointnet2", "omni-pq_amd/models"):
+    sys.path.insert(0, os.path.join(REPO, p))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--points", type=int, default=40000)
+    ap.add_argument("--extra", type=int, default=0)
+    args = ap.parse_args()
+    import pointnet2_utils
+    import sa_fused
+    import synth
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    net = bench.build_model(args.extra).to(dev).train()
+    bb = net.backbone
+    pc = synth.make_clouds(100, args.batch, args.points, extra_channels=args.extra, kind="room").to(dev)
+    xyz = pc[..., :3].contiguous()
+    feat0 = pc[..., 3:].transpose(1, 2).contiguous() if args.extra else None
+    stages = [bb.sa1, bb.sa2, bb.sa3, bb.sa4]
+    inds, cur = [], xyz
+    for sa in stages:
+        i = pointnet2_utils.furthest_point_sample(cur, sa.npoint)
+        inds.append(i)
+        cur = pointnet2_utils.gather_operation(cur.transpose(1, 2).contiguous(), i).transpose(1, 2).contiguous()
+    seed_xyz = torch.rand(args.batch, 1024, 3, device=dev) * 4
+    seed_feat = torch.randn(args.batch, 288, 1024, device=dev, requires_grad=True)
+    vote_inds = pointnet2_utils.furthest_point_sample(seed_xyz, net.vote_aggregation.npoint)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    ups = None
+
+    def step(keep=False):
+        nonlocal ups
+        for p in net.parameters():
+            p.grad = None
+        seed_feat.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            x, f = xyz, feat0
+            outs = []
+            for sa, i in zip(stages, inds):
+                x, f, _ = sa(x, f, i)
+                outs.append(f)
+            _, vf, _ = net.vote_aggregation(seed_xyz, seed_feat, vote_inds)
+            outs.append(vf)
+            if ups is None:
+                ups = [torch.randn(o.shape, device=dev, generator=gen) for o in outs]
+            loss = sum((o.float() * u).sum() for o, u in zip(outs, ups))
+        loss.backward()
+        if keep:
+            grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+            grads["seed_feat"] = seed_feat.grad.detach().clone()
+            return [o.detach().float().clone() for o in outs], grads
+
+    res = {}
+    for mode in (False, True):
+        sa_fused.CHAIN = mode
+        # running statistics must start equal in both modes
+        torch.manual_seed(1)
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        res[mode] = step(keep=True)
+        torch.cuda.synchronize()
+    names = ["sa1", "sa2", "sa3", "sa4", "vote"]
+    ok = True
+    for n, a, b in zip(names, res[False][0], res[True][0]):
+        d = (a - b).abs().max().item()
+        print(f"out {n}: max|diff| {d:.3e}  max|ref| {a.abs().max().item():.3e}  equal={torch.equal(a, b)}")
+        ok &= d <= 2e-2 * a.abs().max().item()
+    worst = 0.0
+    for k in sorted(res[False][1]):
+        a, b = res[False][1][k].float().flatten(), res[True][1][k].float().flatten()
+        rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        worst = max(worst, rel)
+        if rel > 2e-2 or cos < 0.999:
+            print(f"grad {k}: rel-L2 {rel:.3e} cos {cos:.6f} |ref| {a.norm().item():.3e}")
+    print(f"grads: worst rel-L2 {worst:.3e} over {len(res[False][1])} tensors")
+    ok &= worst < 5e-2
+    print("PARITY", "OK" if ok else "FAIL")
+
+    ext = pointnet2_utils._ext
+    for mode in (False, True):
+        sa_fused.CHAIN = mode
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        sink = []
+        ext.set_timing_sink(sink)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ext.set_timing_sink(None)
+        tot = {}
+        for name, _, e0, e1 in sink:
+            tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+        sa_ms = sum(v for k, v in tot.items() if k.endswith("@sa")) / args.steps
+        print(f"CHAIN={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
+        for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]:
+            print(f"    {k:50s} {v / args.steps * 1e3:9.1f} us/step")
+
+
+if __name__ == "__main__":
+    main()
