@@ -65,6 +65,13 @@ int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset,
  * indices of that launch are then garbage), else 0.  The reference has no counterpart (its FPS never
  * leaves one block); callers that cannot tolerate silent corruption call this once per step. */
 int omnipq_fps_check(void *stream);
+/* The same flag WITHOUT synchronising (it lives in pinned, device-mapped host memory): OMNIPQ_ETIMEOUT if any
+ * multi-workgroup launch on the current device has given up since the last poll / check, else 0.  The Python
+ * binding polls at every sampling call and at the start of every model forward, so a timeout raises at the next
+ * call instead of passing silently.  omnipq_fps_init allocates the flag and caches the residency figure that
+ * sizes the multi-workgroup launches (occupancy query); call it once per device outside any stream capture. */
+int omnipq_fps_poll(void);
+int omnipq_fps_init(void);
 
 /* replaces gather_points_kernel_wrapper (sampling.cpp:11-13).
  *   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */

@@ -25,6 +25,8 @@
 //     error word that omnipq_fps_check() reports as OMNIPQ_ETIMEOUT.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 #include <math.h>
@@ -361,7 +363,9 @@ struct FpsWorkspace {
 };
 
 struct DeviceWorkspaces {
-  int *err = nullptr;
+  int *err = nullptr;                 // device view of the flag
+  volatile int *err_host = nullptr;   // host view (pinned, mapped)
+  int resident = 0;                   // 1024-thread sampling workgroups the device keeps resident at once
   std::unordered_map<hipStream_t, FpsWorkspace> per;      // stream handles are few and recycled by their pools
 };
 
@@ -375,12 +379,17 @@ static int get_workspace(size_t slot_bytes, hipStream_t stream, FpsWorkspace **o
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   DeviceWorkspaces &d = g_ws[dev];
   if (!d.err) {
-    // once per device and process, before the first launch: cleared and waited for
+    // once per device and process, before the first launch (omnipq_fps_init does it outside any stream capture).
+    // The flag lives in pinned, device-mapped HOST memory: the kernel's give-up store lands where the host can
+    // read it at any time without synchronising (omnipq_fps_poll), so a timeout surfaces at the NEXT call
+    // instead of only when someone asks with omnipq_fps_check.
     void *p = nullptr;
-    OMNIPQ_HIP(hipMalloc(&p, 256));
-    OMNIPQ_HIP(hipMemset(p, 0, 256));
-    OMNIPQ_HIP(hipDeviceSynchronize());
-    d.err = (int *)p;
+    OMNIPQ_HIP(hipHostMalloc(&p, 256, hipHostMallocMapped));
+    memset(p, 0, 256);
+    void *dp = nullptr;
+    OMNIPQ_HIP(hipHostGetDevicePointer(&dp, p, 0));
+    d.err_host = (volatile int *)p;
+    d.err = (int *)dp;
   }
   FpsWorkspace *ws = &d.per[stream];
   ws->err = d.err;
@@ -393,6 +402,26 @@ static int get_workspace(size_t slot_bytes, hipStream_t stream, FpsWorkspace **o
   }
   *out = ws;
   return OMNIPQ_OK;
+}
+
+static int fps_resident_blocks() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 224;
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (g_ws[dev].resident) return g_ws[dev].resident;
+  }
+  int per_cu = 1, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_kernel<1024, 8, true, true>, 1024, 0) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  if (per_cu > 1) per_cu = 1;         // MI355X_MICROARCH.md: the query can be one block per CU high; never count on a second
+  const int r = per_cu * cus;
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  g_ws[dev].resident = r;
+  return r;
 }
 
 template <int THREADS, int PPT>
@@ -408,8 +437,10 @@ template <int PPT>
 static int launch_multi(int b, int n, int m, int bs_mask, int G, const float *dataset, float *temp,
                         int *idxs, hipStream_t stream) {
   constexpr int THREADS = 1024;
-  // all G workgroups of a scene must be co-resident: at most ~one workgroup per CU
-  int chunk = 224 / G;
+  // all G workgroups of a scene must be co-resident: what the occupancy query says the device holds, minus an
+  // eighth for whatever else runs next to the sampling stream (256 CUs x 1 workgroup -> 224, the constant this
+  // replaces)
+  int chunk = fps_resident_blocks() * 7 / 8 / G;
   if (chunk < 1) chunk = 1;
   if (chunk > b) chunk = b;
   const size_t slot_bytes = (size_t)2 * chunk * 5 * G * sizeof(unsigned long long);
@@ -450,6 +481,37 @@ extern "C" int omnipq_opt_n_threads(int work_size) {
 // Reads (and clears) the device-side give-up flag of the last multi-workgroup FPS launches
 // on the current device.  Synchronises `stream`.  Used by tests and by callers that want a
 // hard error instead of garbage after OMNIPQ_ETIMEOUT conditions.
+// Allocates the per-device timeout flag (pinned host memory) and caches the residency figure.  Call once per device
+// outside any stream capture (pointnet2._ext does at its first GPU call); everything else in the sampling path is
+// capture-safe afterwards except workspace GROWTH, which a warm-up call at the largest batch takes care of.
+extern "C" int omnipq_fps_init(void) {
+  using namespace omnipq;
+  FpsWorkspace *ws = nullptr;
+  const int rc = get_workspace(0, nullptr, &ws);
+  if (rc) return rc;
+  (void)fps_resident_blocks();
+  return OMNIPQ_OK;
+}
+
+// Non-blocking: OMNIPQ_ETIMEOUT if a multi-workgroup sampling launch on the current device has given up since the
+// flag was last cleared (its indices are garbage), else OMNIPQ_OK.  Reads one word of pinned host memory; clears it.
+extern "C" int omnipq_fps_poll(void) {
+  using namespace omnipq;
+  int dev = 0;
+  OMNIPQ_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return OMNIPQ_EINVAL;
+  volatile int *eh = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    eh = g_ws[dev].err_host;
+  }
+  if (eh && *eh) {
+    *eh = 0;
+    return OMNIPQ_ETIMEOUT;
+  }
+  return OMNIPQ_OK;
+}
+
 extern "C" int omnipq_fps_check(void *stream) {
   using namespace omnipq;
   int dev = 0;
@@ -461,14 +523,8 @@ extern "C" int omnipq_fps_check(void *stream) {
     err = g_ws[dev].err;
   }
   if (!err) return OMNIPQ_OK;
-  int flag = 0;
-  OMNIPQ_HIP(hipMemcpyAsync(&flag, err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   OMNIPQ_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (flag) {
-    OMNIPQ_HIP(hipMemsetAsync(err, 0, sizeof(int), (hipStream_t)stream));
-    return OMNIPQ_ETIMEOUT;
-  }
-  return OMNIPQ_OK;
+  return omnipq_fps_poll();
 }
 
 extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset,

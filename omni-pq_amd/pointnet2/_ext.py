@@ -122,11 +122,34 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+_fps_ready = set()
+
+
+def fps_poll():
+    """Raise if a multi-workgroup FPS launch on the current device has reported a hand-off timeout since the last
+    poll (non-blocking: the flag is pinned host memory the kernel writes through)."""
+    rc = _lib.omnipq_fps_poll()
+    if rc != 0:
+        raise RuntimeError(f"furthest point sampling: {_lib.omnipq_error_string(rc).decode()} ({rc}) -- a "
+                           "multi-workgroup launch gave up waiting for its sibling workgroups; its indices are invalid")
+
+
+def _fps_prepare(device):
+    if device.index not in _fps_ready:
+        with torch.cuda.device(device):
+            rc = _lib.omnipq_fps_init()            # allocations happen here, outside any stream capture
+        if rc != 0:
+            raise RuntimeError(f"omnipq_fps_init failed: {_lib.omnipq_error_string(rc).decode()} ({rc})")
+        _fps_ready.add(device.index)
+    fps_poll()
+
+
 def furthest_point_sampling(points, nsamples, out=None):
     """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:72-93].  `out` (extension): write into an existing
     int32 tensor instead of allocating one."""
     _check(points, "points", torch.float32)
     _need_gpu(points)
+    _fps_prepare(points.device)
     b, n = points.shape[0], points.shape[1]
     if out is None:
         out = torch.zeros((b, int(nsamples)), device=points.device, dtype=torch.int32)

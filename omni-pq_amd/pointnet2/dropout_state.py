@@ -2,29 +2,58 @@
 LayerNorm branches, feed-forward activations).
 
 The 64-bit seed lives in DEVICE memory -- a captured hipGraph reads the current value on every replay -- and
-is advanced once per training step (`advance`, one tiny kernel); the host-side `salt` counter tells apart the
-dropout sites that share one seed.  The first seed is drawn from torch's generator, so `torch.manual_seed`
+is advanced once per forward pass of the model (`advance`: one in-place add on the persistent counter plus one
+copy that the forward and its backward keep); the host-side `salt` counter tells apart the dropout sites that
+share one seed.  The first seed is drawn from torch's generator, so `torch.manual_seed`
 governs the masks.
 """
 import torch
 
 
 class _DropoutState:
+    """`state[device]`: the persistent 64-bit counter (static address: a captured hipGraph advances it on every replay).
+    `cur[device]`: the seed of the forward pass in progress -- an IMMUTABLE copy taken by `advance`, which is what the
+    kernels of that forward and of ITS backward read.  A later forward (the no-grad teacher of the mean-teacher step,
+    train.py:489-491, or a second micro-batch under gradient accumulation) advances the counter and takes its own copy;
+    it can no longer change the masks an earlier forward's backward pass rebuilds."""
+
     def __init__(self):
-        self.seeds = {}
+        self.state = {}
+        self.cur = {}
         self.salt = 0
+
+    def _state(self, device):
+        t = self.state.get(device)
+        if t is None:
+            t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+            self.state[device] = t
+        return t
 
     def seed(self, device):
         device = torch.device(device)
-        t = self.seeds.get(device)
+        t = self.cur.get(device)
         if t is None:
-            t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-            self.seeds[device] = t
+            t = self.cur[device] = self._state(device).clone()
         return t
 
     def advance(self, device):
         """New seed for the next training step; call once per forward of the model."""
-        self.seed(device).add_(0x9E3779B97F4A7C15 >> 2)
+        device = torch.device(device)
+        st = self._state(device)
+        st.add_(0x9E3779B97F4A7C15 >> 2)
+        self.cur[device] = st.clone()
+        self.salt = 0
+
+    def set_state(self, device, value):
+        """(tests) restart the counter from a known value"""
+        device = torch.device(device)
+        self._state(device).fill_(int(value))
+        self.cur.pop(device, None)
+
+    def reset(self):
+        """(tests) forget every counter: the next use draws a new one from torch's generator"""
+        self.state.clear()
+        self.cur.clear()
         self.salt = 0
 
     def next_salt(self):

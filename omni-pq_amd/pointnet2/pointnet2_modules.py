@@ -222,6 +222,11 @@ def inverse_distance_weights(dist):
     return recip / torch.sum(recip, dim=2, keepdim=True)
 
 
+def _rows_enabled():
+    import rows_mlp
+    return rows_mlp.enabled()
+
+
 class PointnetFPModule(nn.Module):
     """Feature propagation: 3-NN inverse-distance interpolation of `known_feats` onto the
     `unknown` points, concatenated with their skip features, then a SharedMLP.
@@ -237,7 +242,7 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         if known is not None and known_feats.is_cuda and torch.is_autocast_enabled("cuda") and \
-                torch.get_autocast_dtype("cuda") == torch.bfloat16:
+                torch.get_autocast_dtype("cuda") == torch.bfloat16 and _rows_enabled():
             out = self._forward_rows(unknown, known, unknow_feats, known_feats)
             if out is not None:
                 return out

@@ -17,6 +17,7 @@ mean accounts for it (and its gradient is exactly zero).
 Used under `torch.autocast("cuda", dtype=torch.bfloat16)`; otherwise callers keep PyTorch's f32 layers.
 """
 import ctypes
+import os
 
 import torch
 
@@ -36,8 +37,16 @@ class Layer:
         self.weight, self.bias, self.bn, self.relu_dropout = weight, bias, bn, relu_dropout
 
 
+def enabled():
+    """OMNIPQ_ROWS=torch keeps every per-point MLP on PyTorch's own kernels (A/B runs and the parity tests that put
+    torch's bf16 autocast next to the hand-written path)."""
+    return os.environ.get("OMNIPQ_ROWS", "rows") != "torch"
+
+
 def usable(x, layers, training):
     """bf16 autocast on a GPU, training-mode BN (or no grad in eval), widths the kernels accept."""
+    if not enabled():
+        return False
     if not x.is_cuda or not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.bfloat16:
         return False
     for lay in layers:
@@ -48,6 +57,8 @@ def usable(x, layers, training):
             if lay.weight.shape[0] % 32 or lay.weight.shape[0] > 640:      # kernel limits (multiples of the K step)
                 return False
             if not training and torch.is_grad_enabled():
+                return False
+            if sa_fused.bn_syncs(bn) is None:            # SyncBatchNorm on a custom process group: torch's own path
                 return False
     return True
 
@@ -67,7 +78,11 @@ def run(x_rows, layers, training, padded=False):
             spec.append(None if bn is None else
                         (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
         params += [lay.weight, lay.bias, None if bn is None else bn.weight, None if bn is None else bn.bias]
-    return RowsMLP.apply(x_rows, (spec, bool(padded)), bool(training), *params)
+    # SyncBatchNorm semantics (statistics over all ranks) only where the layers ARE SyncBatchNorm; a stack of plain
+    # BatchNorm layers keeps per-rank statistics under DDP, as torch's does
+    bns = [lay.bn for lay in layers if lay.bn is not None]
+    sync = bool(bns) and all(bool(sa_fused.bn_syncs(bn)) for bn in bns)
+    return RowsMLP.apply(x_rows, (spec, bool(padded), sync), bool(training), *params)
 
 
 def _is_bn(entry):
@@ -81,15 +96,18 @@ class _L:
 class RowsMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, spec, training, *params):
-        spec, padded = spec
+        spec, padded, sync = spec
         dev = x.device
         N, cin = x.shape
         L = len(spec)
-        world = _world() if training else 1
+        world = _world() if (training and sync) else 1
         K = _round_up(cin, 32)
-        cached = getattr(x, "omnipq_rows_in", None)     # the same input tensor feeding several stacks (the decoder's
-        if cached is not None and cached.shape == (N, K):   # key positions: one embedding per layer) is prepared once
-            X = cached
+        # the same input tensor feeding several stacks (the decoder's key positions: one embedding per layer) is prepared
+        # once; the copy is tied to the tensor's version counter, so an input updated in place (a static buffer refilled
+        # with copy_) is converted again instead of feeding stale rows
+        cached = getattr(x, "omnipq_rows_in", None)
+        if cached is not None and cached[0] == x._version and cached[1].shape == (N, K):
+            X = cached[1]
         else:
             if K == cin:
                 X = x.detach().to(torch.bfloat16).contiguous()
@@ -97,7 +115,7 @@ class RowsMLP(torch.autograd.Function):
                 X = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (0, K - cin))
             if X.data_ptr() != x.data_ptr() and not x.requires_grad:
                 try:
-                    x.omnipq_rows_in = X            # inputs without gradient only: constants of the forward pass
+                    x.omnipq_rows_in = (x._version, X)    # inputs without gradient only: constants of the forward pass
                 except Exception:
                     pass
         X0 = X
@@ -137,7 +155,7 @@ class RowsMLP(torch.autograd.Function):
             if lay.has_bn:
                 rm, rv, nbt, momentum, eps = spec[l]
                 if training:
-                    _allreduce_(sums)
+                    _allreduce_(sums, world)
                     stats = torch.empty((4, cout), device=dev)            # a | b | mean | invstd
                     lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
                     cb = bias.detach().float().contiguous() if lay.has_bias else None

@@ -54,6 +54,9 @@ class _tagged:
         _ext.timing_tag = self.prev
 
 
+_SYNC = True       # set by run() per stage: do this stage's BatchNorm layers synchronise across ranks (SyncBatchNorm)?
+
+
 def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -94,8 +97,12 @@ class deferred_counters:
 _FORCE_COLLECTIVES = False       # test hook: issue the SyncBatchNorm all-reduces even over a 1-rank group
 
 
-def _allreduce_(sums):
-    if _world() > 1 or (_FORCE_COLLECTIVES and dist.is_initialized()):
+def _allreduce_(sums, world=None):
+    """SyncBatchNorm's statistics exchange; `world` = the participant count the caller computed (1: this layer keeps
+    per-rank statistics -- a plain BatchNorm under DDP)."""
+    if world is None:
+        world = _world()
+    if world > 1 or (_FORCE_COLLECTIVES and dist.is_initialized()):
         dist.all_reduce(sums)
     return sums
 
@@ -408,9 +415,12 @@ class deferred_wgrads:
         deferred_wgrads.active = None
         if et is None:
             self.flush()
-            for st in getattr(self, "_side_streams", ()):          # early flushes: .grad is complete after the block
-                torch.cuda.current_stream(st.device).wait_stream(st)
-            for param, g in getattr(self, "_assign", ()):
+        # early flushes run on side streams: join them on BOTH paths (after an exception their launches must not
+        # outlive the operands this block releases below)
+        for st in getattr(self, "_side_streams", ()):
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        if et is None:
+            for param, g in getattr(self, "_assign", ()):          # .grad is complete after the block
                 self._accumulate(param, g)
         self.items = None
         self._inflight = None
@@ -751,7 +761,7 @@ def bn_backward_apply(d, lay, P, C, total, sums, world, out=None):
     group the totals are all-reduced in between (SyncBatchNorm), so the local gradients are taken first."""
     if world > 1 or _FORCE_COLLECTIVES:
         dgamma, dbeta = affine_grads(sums, C)
-        _allreduce_(sums[:2])
+        _allreduce_(sums[:2], world)
         gb = None
     else:
         gb = torch.empty((2, C), device=d.device, dtype=torch.float32)
@@ -802,20 +812,23 @@ class FusedSAStage(torch.autograd.Function):
         M, S = idx.shape[1], idx.shape[2]
         P = B * M * S
         L = len(params) // 3
-        cin = 0 if features is None else features.shape[1]
+        cin_raw = 0 if features is None else features.shape[1]
+        cin = _round_up(cin_raw, 8)       # feature rows are moved in 16-byte pieces: 6 extra input channels (rgb + normals,
+                                          # BASELINE configs[3]) travel as 8, the two extra columns and weight columns zero
         kpad = _round_up(cin + 3, 32)
         inv_r = (1.0 / radius) if normalize_xyz else 1.0
-        world = _world() if training else 1
-        if CHAIN and training and 64 % S == 0 and kpad <= 640 and L >= 1 and \
+        world = _world() if (training and _SYNC) else 1
+        if CHAIN and training and 64 % S == 0 and kpad <= 640 and L >= 1 and cin == cin_raw and \
                 all(params[3 * l].shape[0] <= 512 for l in range(L)):
             return FusedSAStage._forward_chain(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz,
                                                bn_cfg, *params)
 
         if features is None:
             feat_pm = None
-        elif feat_pm is None:
+        elif feat_pm is None or cin != cin_raw:
             # position-major bf16 copy [B][N][cin] (a producer that has one passes it in: see run())
-            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()
+            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16)
+            feat_pm = torch.nn.functional.pad(feat_pm, (0, cin - cin_raw)) if cin != cin_raw else feat_pm.contiguous()
         xyz_c = xyz.detach().contiguous()
         cen_c = new_xyz.detach().contiguous()
         X = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
@@ -831,13 +844,16 @@ class FusedSAStage(torch.autograd.Function):
             lay = _Layer()
             W2 = W.detach().reshape(W.shape[0], -1)
             cout = W2.shape[0]
+            padded_w = l == 0 and cin != cin_raw
+            if padded_w:
+                W2 = torch.nn.functional.pad(W2, (0, cin - cin_raw))     # zero columns for the padded feature channels
             # the reference concatenates [xyz(3), features(cin)] (pointnet2_utils.py:357-359); the
             # gathered rows are [features(cin), xyz(3), 0-pad] so that feature pieces stay 16-byte
             # aligned -- layer 0 rotates the weight columns to match
             K = kpad if l == 0 else W2.shape[1]
             lay.K, lay.C = K, cout
             lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=training,
-                                         persistent=is_persistent(W))
+                                         persistent=is_persistent(W) and not padded_w)
             if training:
                 sums = zeros_f64(2, cout, dev)
                 pool = None
@@ -851,7 +867,7 @@ class FusedSAStage(torch.autograd.Function):
                     lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums, pool=pool)
                 else:
                     lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums, pool=pool)     # GEMM + batch statistics
-                _allreduce_(sums)
+                _allreduce_(sums, world)
                 stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
                 lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
                 keep_y_only = l < L - 1 and affine_pays(P, params[3 * (l + 1)].shape[0])
@@ -911,6 +927,7 @@ class FusedSAStage(torch.autograd.Function):
         ctx.layers = layers
         ctx.X0 = X0
         ctx.chain = None
+        ctx.cin_raw = cin_raw
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
         ctx.idx = idx
         ctx.out_pm, ctx.arg, ctx.ysel = out_pm, arg, ysel
@@ -934,7 +951,7 @@ class FusedSAStage(torch.autograd.Function):
         cin = 0 if features is None else features.shape[1]
         kpad = _chain_kpad(cin)
         inv_r = (1.0 / radius) if normalize_xyz else 1.0
-        world = _world()
+        world = _world() if _SYNC else 1
         if features is None:
             feat_pm = None
         elif feat_pm is None:
@@ -975,7 +992,7 @@ class FusedSAStage(torch.autograd.Function):
                           eps=peps, momentum=pmom, running_mean=prm, running_var=prv, a_out=prev.a, b_out=prev.b,
                           mean_out=prev.mean, invstd_out=prev.invstd)
             _rowgemm(xyz_c, **kw)
-            _allreduce_(sums)
+            _allreduce_(sums, world)
             lay.X = None
             lay.fin = (sums, float(P) * world, gamma.detach(), beta.detach(), eps, momentum, rm, rv, None)
             bump(nbt)
@@ -998,6 +1015,7 @@ class FusedSAStage(torch.autograd.Function):
         ctx.layers = layers
         ctx.X0 = None
         ctx.chain = (xyz_c, cen_c, feat_pm)
+        ctx.cin_raw = cin
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
         ctx.idx = idx
         ctx.out_pm, ctx.arg, ctx.ysel = out_pm, arg, ysel
@@ -1040,7 +1058,7 @@ class FusedSAStage(torch.autograd.Function):
             gb = None
             if sync or (l == 0 and not need_in):
                 grads[3 * l + 1], grads[3 * l + 2] = affine_grads(sums, lay.C)
-                _allreduce_(sums)
+                _allreduce_(sums, world)
             else:
                 gb = torch.empty((2, lay.C), device=dev, dtype=torch.float32)
                 grads[3 * l + 1], grads[3 * l + 2] = gb[1], gb[0]
@@ -1126,7 +1144,7 @@ class FusedSAStage(torch.autograd.Function):
                   _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
         # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
         grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
-        _allreduce_(sums[:2])
+        _allreduce_(sums[:2], world)
         dY = torch.empty_like(last.Y)
         _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
               _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
@@ -1140,6 +1158,8 @@ class FusedSAStage(torch.autograd.Function):
                 dWp = _gemm_tn(dY, layers[l - 1].X if l > 0 else ctx.X0, lay.C, lay.K, P)      # [Cout][K]
             wk = cin + 3 if l == 0 else lay.K
             grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
+            if l == 0 and ctx.cin_raw != cin:
+                grads[0] = grads[0][:, :ctx.cin_raw + 3].contiguous()       # drop the padded feature columns
             need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \
                 (ctx.has_features and ctx.needs_input_grad[2])
             if l == 0 and not need_in:
@@ -1169,7 +1189,7 @@ class FusedSAStage(torch.autograd.Function):
                 _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
                       _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
                 if dfeat_pm is not None:
-                    d_feat = dfeat_pm.transpose(1, 2).to(ctx.feat_dtype)      # (B, cin, N) view, see forward
+                    d_feat = dfeat_pm[..., :ctx.cin_raw].transpose(1, 2).to(ctx.feat_dtype)      # (B, cin, N) view, see forward
         ctx.layers = None
         return (d_xyz, d_cen, d_feat, None, None, None, None, None, None, *grads)
 
@@ -1191,6 +1211,18 @@ def _bn_of(layer):
     return conv, bn
 
 
+def bn_syncs(bn):
+    """Do the hand-written kernels have to all-reduce this layer's statistics?  Only for a SyncBatchNorm on the default
+    process group (what nn.SyncBatchNorm.convert_sync_batchnorm produces, reference pq_transformer.py:194); a plain
+    BatchNorm keeps per-rank statistics under DDP exactly as torch's does.  A custom process group is not supported by
+    the kernels' collectives: None = use the composed path."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm):
+        return False
+    if getattr(bn, "process_group", None) is not None:
+        return None
+    return True
+
+
 def eligible(module, xyz, features):
     """Can `module` (a PointnetSAModuleVotes) run its group+MLP+pool on the fused kernels?"""
     if not xyz.is_cuda or module.npoint is None or module.pooling != "max":
@@ -1200,15 +1232,15 @@ def eligible(module, xyz, features):
         return False
     if module.nsample > 255 or len(module.mlp_module) == 0:
         return False
-    if features is not None and (features.shape[1] % 8):
-        return False
     for layer in module.mlp_module:
         got = _bn_of(layer)
         if got is None:
             return False
-        conv, _ = got
+        conv, bn = got
         # widths are contraction lengths of the data-gradient GEMM: multiples of the 32-wide K step
         if conv.out_channels % 32 or conv.out_channels > 640:
+            return False
+        if bn_syncs(bn) is None:
             return False
     if not module.training and torch.is_grad_enabled():
         return False
@@ -1224,6 +1256,8 @@ def run(module, xyz, new_xyz, features):
         conv, bn = _bn_of(layer)
         params += [conv.weight, bn.weight, bn.bias]
         bn_cfg.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
+    global _SYNC
+    _SYNC = all(bool(bn_syncs(_bn_of(layer)[1])) for layer in module.mlp_module)
     feat_pm = None if features is None else rows16_of(features, (features.shape[0], features.shape[2], features.shape[1]))
     out, twin = FusedSAStage.apply(xyz, new_xyz, features, feat_pm, idx, float(module.radius),
                                    bool(module.normalize_xyz), bool(module.training), bn_cfg, *params)

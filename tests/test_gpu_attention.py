@@ -87,7 +87,7 @@ def test_attention_dropout_mask_is_consistent_forward_and_backward():
     L, S, N, H, D, p = 96, 200, 2, 4, 36, 0.25
     _, q, k, v = make_qkv(L, S, N, H, D, 3)
     torch.manual_seed(7)
-    fused_attention.STATE.seeds.clear()
+    fused_attention.STATE.reset()
     fused_attention.STATE.advance(dev())
     out = fused_attention.attention(q, k, v, H, p)
     salt = fused_attention.STATE.salt
@@ -113,6 +113,33 @@ def test_attention_dropout_mask_is_consistent_forward_and_backward():
     fused_attention.STATE.advance(dev())
     m3 = fused_attention.dropout_mask(N, H, L, S, p, fused_attention.STATE.seed(dev()), salt)
     assert 0.3 < float((m3 == mask).float().mean()) < 0.8
+
+
+def test_backward_rebuilds_the_masks_of_its_own_forward():
+    """Mean-teacher order (reference train.py:489-491): student forward, then a train-mode no-grad teacher forward that
+    advances the dropout seed, then the student's backward.  The backward kernels rebuild the masks from the seed
+    tensor their forward saw -- an immutable per-forward copy -- so the gradients equal those of a run without the
+    teacher in between (they did not while one device tensor was advanced in place)."""
+    from utils import fused_attention
+    L, S, N, H, D, p = 64, 128, 2, 4, 36, 0.3
+    _, q, k, v = make_qkv(L, S, N, H, D, 5)
+    g = torch.randn((L, N, H * D), generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).to(dev())
+
+    def student(with_teacher):
+        fused_attention.STATE.set_state(dev(), 123456789)
+        fused_attention.STATE.advance(dev())
+        out = fused_attention.attention(q, k, v, H, p)
+        if with_teacher:
+            fused_attention.STATE.advance(dev())
+            with torch.no_grad():
+                fused_attention.attention(q, k, v, H, p)
+        return out, torch.autograd.grad(out, [q, k, v], g)
+
+    out_a, grads_a = student(False)
+    out_b, grads_b = student(True)
+    assert torch.equal(out_a, out_b)
+    for a, b in zip(grads_a, grads_b):
+        assert rel_l2(a, b) < 1e-6, rel_l2(a, b)
 
 
 def test_multihead_attention_module_uses_the_kernels_under_autocast():

@@ -74,7 +74,10 @@ def _toy(which, dev):
                      rows_mlp.Layer(self.c3.weight, self.c3.bias)]
             return rows_mlp.run(xyz.reshape(-1, 3), stack, True).view(xyz.shape[0], xyz.shape[1], -1)
 
-    return load_procedural({"chain": Chain, "rows": Rows}[which](), 3).to(dev).train()
+    # SyncBatchNorm as the reference converts every BatchNorm (pq_transformer.py:194): the hand-written kernels exchange
+    # statistics across ranks for SyncBatchNorm layers only -- a plain BatchNorm keeps per-rank statistics, like torch's
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm({"chain": Chain, "rows": Rows}[which]())
+    return load_procedural(net, 3).to(dev).train()
 
 
 def _exact_worker(rank, world, port, out_dir):

@@ -51,7 +51,7 @@ def test_add_dropout_layernorm_matches_torch(R, C, p, with_pe):
     pe = torch.randn(R, C, generator=gen).to(torch.bfloat16).to(dev()).requires_grad_(True) if with_pe else None
     gamma = (1 + 0.3 * torch.randn(C, generator=gen)).to(dev()).requires_grad_(True)
     beta = (0.2 * torch.randn(C, generator=gen)).to(dev()).requires_grad_(True)
-    dropout_state.STATE.seeds.clear()
+    dropout_state.STATE.reset()
     torch.manual_seed(3)
     salt = 17
     mask = _mask_from_probe(R, C, p, salt) if p > 0 else torch.ones(R, C, dtype=torch.bool, device=dev())
@@ -91,7 +91,7 @@ def test_relu_dropout_rows_layer_matches_torch():
     import dropout_state
     import rows_mlp
     torch.manual_seed(5)
-    dropout_state.STATE.seeds.clear()
+    dropout_state.STATE.reset()
     N, cin, hid, cout, p = 1000, 96, 256, 64, 0.25
     x = torch.randn(N, cin, device=dev()).to(torch.bfloat16).requires_grad_(True)
     l1 = torch.nn.Linear(cin, hid).to(dev())
