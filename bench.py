@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-scenes", type=int, default=2)
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-sample-scenes", type=int, default=0, help="scenes per CPU-baseline step (0: the batch size)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up)")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="thread count tried next to 'all cores'")
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
     ap.add_argument("--eager-dp", default="flat", choices=["flat", "ddp"],
@@ -205,6 +206,42 @@ def sa_stage_algorithmic_bytes(batch, points, extra_channels, e):
     return total * batch
 
 
+def pmc_mfma(kind):
+    """MFMA-busy from the newest committed matrix-core counter summary (`profiles/r*_<kind>_pmc_mfma.json`, written by
+    tools/pmc_mfma.py from a rocprofv3 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16`
+    pass of this command).  None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{kind}_pmc_mfma.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            return json.load(fh), os.path.relpath(files[-1], REPO)
+    except (OSError, ValueError):
+        return None, None
+
+
+def hbm_copy_ceiling(dev, mib=1024, reps=6):
+    """Measured device-to-device copy rate, GB/s counting bytes read + bytes written (BASELINE.md section 3 asks for
+    the measured ceiling next to the 8 TB/s datasheet peak).  1 GiB source, 1 GiB destination: four times the 256 MiB
+    Infinity Cache, so neither side is served on-die."""
+    n = mib * (1 << 20) // 4
+    src = torch.empty(n, device=dev, dtype=torch.float32).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(reps):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    return best
+
+
 def pmc_traffic(kind):
     """HBM bytes from the newest committed PMC summary (`profiles/r*_<kind>_pmc_traffic.json`, written by
     tools/pmc_traffic.py from separate rocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
@@ -275,19 +312,32 @@ def cpu_baseline(args):
     saved = pointnet2_utils._ext
     pointnet2_utils._ext = oracle_ext
     try:
-        # a 2-scene step has far less parallel slack than a 256-thread host offers; beyond ~32
-        # threads PyTorch's CPU convs and the OpenMP loops only fight over the memory system
-        cores = min(os.cpu_count() or 1, args.cpu_threads)
-        torch.set_num_threads(cores)
-        oracle_ext.set_num_threads(cores)
-        b = args.cpu_sample_scenes
+        # the benchmark's own shape (B scenes x N points), one warm-up step, then >= 3 timed steps,
+        # scenes/s = B / median.  Threads: min(hardware threads, --cpu-threads = 32).  "All cores" was measured on the
+        # round-2 GPU box (AMD EPYC 9575F, 256 hardware threads): ONE 8-scene step took 330.8 s on 256 threads against
+        # 9.6 s on 32 -- PyTorch's CPU convolutions and the oracle's OpenMP loops fight over the memory system -- so the
+        # baseline uses the setting that makes it FASTER (--cpu-threads 0 asks for all of them).
+        b = args.cpu_sample_scenes or args.batch
         net = build_model(args.extra_channels)
         net.train()
         pc = synth.make_clouds(2, b, args.points, extra_channels=args.extra_channels, kind="room")
-        t0 = time.perf_counter()
-        ep = net({"point_clouds": pc})
-        loss_of(ep).backward()
-        dt = time.perf_counter() - t0
+
+        def one_step():
+            for p in net.parameters():
+                p.grad = None
+            t0 = time.perf_counter()
+            ep = net({"point_clouds": pc})
+            loss_of(ep).backward()
+            return time.perf_counter() - t0
+
+        cores = os.cpu_count() or 1
+        if args.cpu_threads > 0:
+            cores = min(cores, args.cpu_threads)
+        torch.set_num_threads(cores)
+        oracle_ext.set_num_threads(cores)
+        warm = one_step()
+        times = sorted(one_step() for _ in range(args.cpu_steps))
+        dt = times[len(times) // 2]
         cpu_name = "unknown"
         try:
             with open("/proc/cpuinfo") as f:
@@ -298,8 +348,10 @@ def cpu_baseline(args):
         except OSError:
             pass
         return {"value": b / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-                "sample": f"1 fwd+bwd step, {b} scenes x {args.points} pts, fp32, oracle C ops + PyTorch CPU, "
-                          f"{dt:.1f} s on {cpu_name}"}
+                "sample": f"median of {args.cpu_steps} fwd+bwd steps after 1 warm-up, {b} scenes x {args.points} pts, fp32, "
+                          f"oracle C ops + PyTorch CPU, {dt:.1f} s/step (warm-up step {warm:.1f} s) on {cpu_name}, "
+                          f"{cores} of {os.cpu_count()} hardware threads (all 256 measured 34x slower: DESIGN.md); "
+                          f"baseline only"}
     finally:
         pointnet2_utils._ext = saved
 
@@ -654,33 +706,64 @@ def main():
                         traffic = row["traffic_bytes_per_step"] / row["launches_per_step"]
                         traffic_src = pmc_file
                         break
-            rec["roofline"] = {"bound": "hbm", "kernel": name, "shape": list(a), "achieved": gbs,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": traffic, "traffic_source": traffic_src,
-                               "avg_ms": avg_ms, "launches_per_step": calls / timing_steps,
-                               "timing": timing_note,
-                               "algorithmic_bytes_per_launch": nbytes}
+            dominant = {"kernel": name, "shape": list(a), "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": traffic_src, "avg_ms": avg_ms,
+                        "launches_per_step": calls / timing_steps, "algorithmic_bytes_per_launch": nbytes}
             native_ms = sum(v[0] for v in table.values()) / timing_steps
             rec["native_ops_ms_per_step"] = native_ms
             if name.split("@")[0] == "omnipq_furthest_point_sampling":
                 # latency bound by construction (m - 1 dependent argmax rounds): SURVEY 8d asks for rounds/s too
-                rec["roofline"]["rounds_per_s"] = (a[2] - 1) / (avg_ms * 1e-3)
-                rec["roofline"]["note"] = ("furthest-point sampling: 2047 dependent rounds over 40 000 points per scene, "
-                                           "2.6 us per round; off the critical path (next batch's plan, side stream)")
+                dominant["rounds_per_s"] = (a[2] - 1) / (avg_ms * 1e-3)
+                dominant["us_per_round"] = avg_ms * 1e3 / (a[2] - 1)
+                dominant["note"] = ("furthest-point sampling: m - 1 dependent argmax rounds over n points per scene; "
+                                    "latency bound, so its HBM fraction says nothing; off the critical path (next "
+                                    "batch's plan, side stream)")
             rec["breakdown_ms_per_step"] = stage_breakdown(table, timing_steps)
             # the stage BASELINE.json's target is quoted on: every kernel of the five SA layers, fwd+bwd
-            sa_ms = sum(v[0] for (nm, _), v in table.items()
-                        if nm.endswith("@sa") or nm in ("omnipq_group_points", "omnipq_group_points_grad")) / timing_steps
+            sa_rows = {nm: v for (nm, _), v in table.items()
+                       if nm.endswith("@sa") or nm in ("omnipq_group_points", "omnipq_group_points_grad")}
+            sa_by_kernel = {}
+            for (nm, _), v in table.items():
+                if nm in sa_rows:
+                    sa_by_kernel[nm.split("@")[0]] = sa_by_kernel.get(nm.split("@")[0], 0.0) + v[0] / timing_steps
+            sa_ms = sum(sa_by_kernel.values())
             e = 4 if args.dtype == "fp32" else 2
             sa_bytes = sa_stage_algorithmic_bytes(args.batch, args.points, args.extra_channels, e)
-            rec["sa_stage"] = {"ms_per_step": sa_ms, "algorithmic_bytes": sa_bytes, "feature_bytes": e,
-                               "achieved": sa_bytes / (sa_ms * 1e-3) / 1e9 if sa_ms > 0 else None,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": sa_bytes / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sa_ms > 0 else None}
+            sa_gbs = sa_bytes / (sa_ms * 1e-3) / 1e9 if sa_ms > 0 else None
+            ceiling = hbm_copy_ceiling(dev)
+            # `roofline`: the SA stage (ball query + group + shared MLP + pool, fwd+bwd, of sa1..sa4 and the vote
+            # aggregation) -- the stage north_star's >= 60 % target is quoted on -- as ONE unit: algorithmic bytes of
+            # SURVEY 8d over the event-timed duration of all its kernels.
+            rec["roofline"] = {"bound": "hbm", "kernel": "SA stage (all kernels of the five set-abstraction layers, fwd+bwd)",
+                               "achieved": sa_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": sa_gbs / HBM_PEAK_GBS if sa_gbs else None,
+                               "traffic": None, "traffic_source": None,
+                               "avg_ms": sa_ms, "algorithmic_bytes_per_launch": sa_bytes, "feature_bytes": e,
+                               "kernels_ms_per_step": {k: round(v, 4) for k, v in
+                                                       sorted(sa_by_kernel.items(), key=lambda kv: -kv[1])},
+                               "hbm_copy_ceiling_gbs": ceiling,
+                               "frac_of_copy_ceiling": sa_gbs / ceiling if sa_gbs else None,
+                               "timing": timing_note,
+                               "largest_kernel": dominant}
             sa_pmc, sa_file = pmc_traffic("sa_stage")
             if sa_pmc is not None and args.batch == 8 and args.points == 40000 and args.dtype == "bf16":
-                rec["sa_stage"]["traffic"] = sa_pmc["total_traffic_bytes_per_step"]
-                rec["sa_stage"]["traffic_source"] = sa_file
+                rec["roofline"]["traffic"] = sa_pmc["total_traffic_bytes_per_step"]
+                rec["roofline"]["traffic_source"] = sa_file
+            mf, mf_file = pmc_mfma("bench")
+            sa_mf, sa_mf_file = pmc_mfma("sa_stage")
+            if mf is not None:
+                rec["mfma"] = {"busy_frac_whole_step": mf["mfma_busy_frac_over_all_dispatches"],
+                               "bf16_mfma_gflop_per_step": mf["bf16_mfma_flops_per_step"] / 1e9,
+                               "peak_tflops_dense_bf16": 2500.0, "source": mf_file,
+                               "busy_frac_sa_stage": None if sa_mf is None else sa_mf["mfma_busy_frac_over_all_dispatches"],
+                               "source_sa_stage": sa_mf_file,
+                               "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) from a separate rocprofv3 "
+                                       "counter pass of this command (tools/pmc_mfma.py)"}
+            rec["hbm_copy_ceiling_gbs"] = ceiling
+            rec["sa_stage"] = {k: rec["roofline"][k] for k in ("avg_ms", "achieved", "peak", "unit", "frac", "traffic",
+                                                                "traffic_source", "feature_bytes")}
+            rec["sa_stage"]["ms_per_step"] = sa_ms
+            rec["sa_stage"]["algorithmic_bytes"] = sa_bytes
             if args.breakdown:
                 for (nm, aa), (ms_, calls_, nb) in sorted(table.items(), key=lambda kv: -kv[1][0]):
                     print(f"{nm:38s} {str(aa):34s} {ms_ / timing_steps:9.3f} ms/step  x{calls_ / timing_steps:4.1f}"

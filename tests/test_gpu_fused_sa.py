@@ -166,7 +166,18 @@ SA_SPECS = [
 
 @pytest.mark.parametrize("spec,n,cin", SA_SPECS)
 def test_fused_sa_stage_matches_f32_composition(spec, n, cin, monkeypatch):
-    B = 2
+    _fused_vs_f32(spec, n, cin, 2, monkeypatch)
+
+
+def test_fused_sa_stage_config4_50k_points_six_extra_channels(monkeypatch):
+    """BASELINE configs[3]: ARKitScenes-like clouds of 50 000 points with 6 extra input channels (rgb + normals), batch 4
+    per GPU -- sa1 with a 9-channel first layer (the 6 feature channels travel padded to 8) and the hash-grid ball
+    query at 50 000 points, against the f32 op-by-op composition."""
+    spec = dict(npoint=2048, radius=0.2, nsample=64, mlp=[6, 64, 64, 128], use_xyz=True, normalize_xyz=True)
+    _fused_vs_f32(spec, 50000, 6, 4, monkeypatch)
+
+
+def _fused_vs_f32(spec, n, cin, B, monkeypatch):
     xyz = synth.make_clouds(41, B, n, kind="room").to(dev())
     feats = None
     if cin:

@@ -246,6 +246,19 @@ def test_full_size_properties_config2():
     assert bool(has_self[not_full].all()) and int(not_full.sum()) > 1000
 
 
+def test_config4_ball_query_50k_points_matches_oracle():
+    """BASELINE configs[3] (50 000-point clouds): brute force and hash grid against the oracle, index-exact."""
+    pc = synth.make_clouds(1004, 2, 50000, extra_channels=6, kind="room")
+    xyz_cpu = pc[..., :3].contiguous()
+    xyz = xyz_cpu.to(dev())
+    inds, _ = capi.fps(xyz, 2048)
+    assert torch.equal(inds.cpu(), oracle_ext.furthest_point_sampling(xyz_cpu, 2048))
+    centres = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    want = oracle_ext.ball_query(centres.cpu(), xyz_cpu, 0.2, 64)
+    assert torch.equal(capi.ball_query(centres, xyz, 0.2, 64).cpu(), want)
+    assert torch.equal(capi.ball_query_grid(centres, xyz, 0.2, 64).cpu(), want)
+
+
 # --------------------------------------------------------------------------- layers and model vs fixtures
 @pytest.mark.parametrize("name", ["ops_room512", "ops_room4096", "ops_adv600", "ops_adv2048"])
 def test_ops_through_python_layers_match_reference_fixture(name):

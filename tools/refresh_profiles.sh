@@ -9,6 +9,7 @@
 #   3. rocprofv3 --kernel-trace --stats, --graph off  -> the same for eager launches
 #   4./5. rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on bench.py --graph off (whole step)
 #   6./7. the same two counters on tools/sa_stage_run.py (the five SA stages only)
+#   8./9. SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE / SQ_INSTS_VALU_MFMA_MOPS_BF16 on both (MFMA-busy, tools/pmc_mfma.py)
 set -u
 TAG=${1:-r01}
 R=$(pwd)
@@ -24,6 +25,11 @@ if [ "${2:-}" != "--collect" ]; then
     timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/bench.py --no-cpu-baseline --no-op-timing --graph off --steps 3 --warmup 2 > $OUT/pmc_$c.log 2>&1
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/sapmc_$c -o pmc -- python $R/tools/sa_stage_run.py --steps 3 > $OUT/sapmc_$c.log 2>&1
   done
+  # 8./9. matrix-core counters (their own passes: PMC never together with other counters' domains): whole step and SA stages
+  MF="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16"
+  timeout 900 rocprofv3 --kernel-trace --pmc $MF --output-format csv -d $OUT/pmc_MFMA -o pmc -- python $R/bench.py --no-cpu-baseline --no-op-timing --graph off --steps 3 --warmup 2 > $OUT/pmc_MFMA.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $MF --output-format csv -d $OUT/sapmc_MFMA -o pmc -- python $R/tools/sa_stage_run.py --steps 3 > $OUT/sapmc_MFMA.log 2>&1
+  for p in pmc sapmc; do find $OUT/${p}_MFMA -name "*kernel_trace.csv" -delete; done
   # keep what travels back small: per-kernel traces are reduced on the box
   for m in graph eager; do
     D=$(dirname $(find $OUT/$m -name "*_kernel_trace.csv" | head -1))
@@ -49,3 +55,5 @@ cp $OUT/eager_summary.md $P/${TAG}_bench_eager_summary.md
 cp $OUT/eager_kernel_stats_raw.csv $P/${TAG}_bench_eager_rocprofv3_kernel_stats_raw.csv
 python $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE 0.4 3 $P/${TAG}_bench_pmc_traffic.json $P/${TAG}_bench_pmc_traffic.md
 python $R/tools/pmc_traffic.py $OUT/sapmc_FETCH_SIZE $OUT/sapmc_WRITE_SIZE 0.4 3 $P/${TAG}_sa_stage_pmc_traffic.json $P/${TAG}_sa_stage_pmc_traffic.md
+python $R/tools/pmc_mfma.py $OUT/pmc_MFMA 0.4 3 $P/${TAG}_bench_pmc_mfma.json $P/${TAG}_bench_pmc_mfma.md
+python $R/tools/pmc_mfma.py $OUT/sapmc_MFMA 0.4 3 $P/${TAG}_sa_stage_pmc_mfma.json $P/${TAG}_sa_stage_pmc_mfma.md
