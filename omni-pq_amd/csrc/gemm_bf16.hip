@@ -91,7 +91,10 @@ struct PoolOut {
 // its 8 MFMAs per K-step back to back (0.21 of the 0.36 us a K-step takes) -- they are bound by the MFMA issue of ONE
 // wave, not by loads (three K-steps of register prefetch changed nothing).  64 x 64 tiles put four times as many
 // waves to work, 2 MFMAs per step each.
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128>
+// PF2: operand tiles are fetched TWO K-steps ahead (two named register sets, the loop unrolled by two): with one step of
+// prefetch and two or three workgroups per CU a K-step lasts as long as a global load takes to come back (the SA layers'
+// 8-step contractions ran at 13 % MFMA utilisation: 16 us per 128 x 128 tile against 0.85 us of matrix work).
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
@@ -189,51 +192,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   }
 
   uint4 ra[NI], rb[NI];
-  auto load_tiles = [&](int kt) {
-    const int koff = kt * GBK;     // whole K-steps only: K and k_chunk are multiples of GBK
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      ra[i] = ldg16(ga[i] + koff);
-      rb[i] = ldg16(gb[i] + koff);
-    }
-  };
-  auto store_tiles = [&](int buf, int kt) {
-    bf16_t *sa = stage + buf * (2 * T * GPITCH);
-    bf16_t *sb = sa + T * GPITCH;
-    if (AFF) {
-      // a, b of this thread's 8 channels of K-step kt (both chunks share them): four LDS reads
-      const int k0 = kbeg + kt * GBK + skc[0] * 8;
-      f32x4 fa4[2], fb4[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        fa4[h] = *reinterpret_cast<const f32x4 *>(s_aff + k0 + 4 * h);
-        fb4[h] = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0 + 4 * h);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        ra[i].x = affine_relu_pair(ra[i].x, fa4[0][0], fb4[0][0], fa4[0][1], fb4[0][1]);
-        ra[i].y = affine_relu_pair(ra[i].y, fa4[0][2], fb4[0][2], fa4[0][3], fb4[0][3]);
-        ra[i].z = affine_relu_pair(ra[i].z, fa4[1][0], fb4[1][0], fa4[1][1], fb4[1][1]);
-        ra[i].w = affine_relu_pair(ra[i].w, fa4[1][2], fb4[1][2], fa4[1][3], fb4[1][3]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      *reinterpret_cast<uint4 *>(sa + srow[i] * GPITCH + skc[i] * 8) = ra[i];
-      *reinterpret_cast<uint4 *>(sb + srow[i] * GPITCH + skc[i] * 8) = rb[i];
-    }
-  };
-
-  if (nk > 0) {
-    load_tiles(0);
-    store_tiles(0, 0);
+  uint4 ra2[NI], rb2[NI];            // second register set (PF2)
+#define OMNIPQ_LOAD_TILES(RA, RB, KT)                                 \
+  {                                                                   \
+    const int koff_ = (KT) * GBK;                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {               \
+      RA[i_] = ldg16(ga[i_] + koff_);                                 \
+      RB[i_] = ldg16(gb[i_] + koff_);                                 \
+    }                                                                 \
   }
-  __syncthreads();
+#define OMNIPQ_STORE_TILES(RA, RB, BUF, KT)                                                             \
+  {                                                                                                     \
+    bf16_t *sa_ = stage + (BUF) * (2 * T * GPITCH);                                                     \
+    bf16_t *sb_ = sa_ + T * GPITCH;                                                                     \
+    if (AFF) {                                                                                          \
+      /* a, b of this thread's 8 channels of K-step KT (both chunks share them): four LDS reads */      \
+      const int k0_ = kbeg + (KT) * GBK + skc[0] * 8;                                                   \
+      f32x4 fa4_[2], fb4_[2];                                                                           \
+      _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                \
+        fa4_[h_] = *reinterpret_cast<const f32x4 *>(s_aff + k0_ + 4 * h_);                              \
+        fb4_[h_] = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0_ + 4 * h_);                   \
+      }                                                                                                 \
+      _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                               \
+        RA[i_].x = affine_relu_pair(RA[i_].x, fa4_[0][0], fb4_[0][0], fa4_[0][1], fb4_[0][1]);          \
+        RA[i_].y = affine_relu_pair(RA[i_].y, fa4_[0][2], fb4_[0][2], fa4_[0][3], fb4_[0][3]);          \
+        RA[i_].z = affine_relu_pair(RA[i_].z, fa4_[1][0], fb4_[1][0], fa4_[1][1], fb4_[1][1]);          \
+        RA[i_].w = affine_relu_pair(RA[i_].w, fa4_[1][2], fb4_[1][2], fa4_[1][3], fb4_[1][3]);          \
+      }                                                                                                 \
+    }                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                                 \
+      *reinterpret_cast<uint4 *>(sa_ + srow[i_] * GPITCH + skc[i_] * 8) = RA[i_];                       \
+      *reinterpret_cast<uint4 *>(sb_ + srow[i_] * GPITCH + skc[i_] * 8) = RB[i_];                       \
+    }                                                                                                   \
+  }
 
   const int frow = lane & 31, fk = (lane >> 5) * 8;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+  auto mma_step = [&](int buf) {
     const bf16_t *sa = stage + buf * (2 * T * GPITCH);
     const bf16_t *sb = sa + T * GPITCH;
 #pragma unroll
@@ -250,9 +244,39 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1, kt + 1);
-    __syncthreads();
+  };
+
+  if (nk > 0) {
+    OMNIPQ_LOAD_TILES(ra, rb, 0)
+    OMNIPQ_STORE_TILES(ra, rb, 0, 0)
   }
+  if (PF2 && nk > 1) OMNIPQ_LOAD_TILES(ra2, rb2, 1)
+  __syncthreads();
+
+  if (!PF2) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) OMNIPQ_LOAD_TILES(ra, rb, kt + 1)
+      mma_step(buf);
+      if (kt + 1 < nk) OMNIPQ_STORE_TILES(ra, rb, buf ^ 1, kt + 1)
+      __syncthreads();
+    }
+  } else {
+    // even step kt (buffer 0): set 1 holds step kt + 1, set 0 takes the loads of step kt + 2; odd step the other way
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) OMNIPQ_LOAD_TILES(ra, rb, kt + 2)
+      mma_step(0);
+      if (kt + 1 < nk) OMNIPQ_STORE_TILES(ra2, rb2, 1, kt + 1)
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) OMNIPQ_LOAD_TILES(ra2, rb2, kt + 3)
+      mma_step(1);
+      if (kt + 2 < nk) OMNIPQ_STORE_TILES(ra, rb, 0, kt + 2)
+      __syncthreads();
+    }
+  }
+#undef OMNIPQ_LOAD_TILES
+#undef OMNIPQ_STORE_TILES
 
   // ---- epilogue: accumulators -> LDS (row-major C tile) -> 16-byte row stores ----------------
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -510,6 +534,14 @@ static bool gemm_nt_small_tiles(int M, int N) {
   return (long long)((M + 127) / 128) * ((N + 127) / 128) <= limit;
 }
 
+// OMNIPQ_GEMM_PF2=1: two-step operand prefetch in the plain 128 x 128-tile kernel.  Measured (round 2): SLOWER on the
+// large SA shapes (262144 x 512 x 256: 177 vs 144 us; 1 M x 256 x 128: 239 vs 193) -- the extra register set costs the
+// third workgroup per CU, which hides more latency than the deeper prefetch does -- slightly faster on 4096-row shapes.
+static bool gemm_nt_pf2() {
+  static const bool on = getenv("OMNIPQ_GEMM_PF2") ? atoi(getenv("OMNIPQ_GEMM_PF2")) != 0 : false;
+  return on;
+}
+
 static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int ldc, int T) {
   return omnipq::GemmArgs{M, N, K, lda, ldb, ldc, K, (M + T - 1) / T, (N + T - 1) / T};
 }
@@ -529,8 +561,12 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
         g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
-                                                                          nullptr);
+    if (gemm_nt_pf2())
+      gemm_nt_kernel<false, 0, false, 128, true><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+          g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
+    else
+      gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                            nullptr);
   }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;

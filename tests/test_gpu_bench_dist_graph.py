@@ -1,0 +1,28 @@
+"""GPU: the data-parallel launch path of bench.py -- RCCL collectives (SyncBatchNorm statistics + the flat gradient
+all-reduce) captured INSIDE the hipGraph of the whole step and replayed -- exercised on one GPU with a 1-rank process
+group (OMNIPQ_BENCH_FORCE_DIST=1), so that every round's driver run covers the graph-with-collectives path that the
+8-GPU scaling run depends on (reference: DistributedDataParallel + SyncBatchNorm, train.py:382, pq_transformer.py:194).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_step_with_rccl_collectives_captures_and_replays():
+    env = dict(os.environ, OMNIPQ_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-op-timing", "--points", "20000", "--batch", "4"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    # the probe passed and the captured step holds the collectives
+    assert rec["launch"] == "hipGraph replay", rec["launch"]
+    assert rec["data_parallel"] and "inside the graph" in rec["data_parallel"], rec["data_parallel"]
