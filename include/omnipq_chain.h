@@ -34,12 +34,13 @@
 extern "C" {
 #endif
 
-enum { OMNIPQ_A_PLAIN = 0, OMNIPQ_A_AFFINE = 1, OMNIPQ_A_GATHER = 2, OMNIPQ_A_DY = 3, OMNIPQ_A_DY3 = 4 };
-enum { OMNIPQ_E_STORE = 0, OMNIPQ_E_STORE_STATS = 1, OMNIPQ_E_STORE_BNBWD = 2 };
+enum { OMNIPQ_A_PLAIN = 0, OMNIPQ_A_AFFINE = 1, OMNIPQ_A_GATHER = 2, OMNIPQ_A_DY = 3, OMNIPQ_A_DY3 = 4, OMNIPQ_A_POOLX = 5 };
+enum { OMNIPQ_E_STORE = 0, OMNIPQ_E_STORE_STATS = 1, OMNIPQ_E_STORE_BNBWD = 2,
+       OMNIPQ_E_STATS_REG = 3 /* internal: STORE_STATS with C == NULL, folded in registers (chosen by the library) */ };
 
 typedef struct {
   long long P;              /* rows */
-  int N, K;                 /* output columns (multiple of 8, <= 512), contraction length (multiple of 32, <= 640) */
+  int N, K;                 /* output columns (multiple of 8, <= 512), contraction length (multiple of 32, <= 1024) */
   int a_kind, epi_kind;
 
   /* ---- A operand ---- */
@@ -72,12 +73,20 @@ typedef struct {
   const float *bn_a, *bn_mean, *bn_invstd;
   float *gb_out;
 
+  /* POOLX (the max-pool + BatchNorm backward of the LAST layer without its output Y_L or any gradient tensor of that
+   * shape, see omnipq_sa_pool_algebra): columns [0, split) are the pooled gradient dz (A0 = gz [P / s][lda], arg, s as for
+   * DY3, unscaled), columns [split, K) are relu(a_in .* A1 + b_in), A1 = the pre-BN output of the layer below [P][lda1];
+   * crow (may be NULL) = float[N] added to every row of the product before rounding.  split must be a multiple of the
+   * kernel's K chunk (128 columns for the shapes this is used on). */
+  int split, lda1;
+  const float *crow;
+
   /* ---- B operand: the weights [N][K] FRAGMENT-PACKED by omnipq_pack_b (ldb is ignored) ---- */
   const void *B;
   int ldb;
 
   /* ---- output ---- */
-  void *C;                  /* bf16 [P][ldc] */
+  void *C;                  /* bf16 [P][ldc]; NULL with STORE_STATS: statistics / ball extrema only, nothing stored */
   int ldc;
 
   /* ---- epilogue ---- */
@@ -117,9 +126,29 @@ typedef struct {
   const float *ba, *bb;
   float *C;
   float *workspace;
+  /* POOLX (a_kind): M = split + N; output rows [0, split) = dz^T X with dz generated from (A0 = gz, arg, s), rows
+   * [split, M) = X^T X, X = relu(ba .* B0 + bb) (b_kind must be AFFINE); bcolsum (may be NULL) = float[N], zero on
+   * entry, receives the column sums of X. */
+  int split;
+  float *bcolsum;
 } omnipq_tn_gen_desc;
 
 int omnipq_gemm_tn_gen(const omnipq_tn_gen_desc *d, void *stream);
+
+/* The last layer's max-pool + BatchNorm backward WITHOUT its output Y_L (= X W^T) or any gradient tensor of that shape
+ * (reference: autograd of max_pool2d / BatchNorm2d / Conv2d, pointnet2_modules.py:251-262, pytorch_utils.py:11-36):
+ *   dX = (dz .* a) W - X H + c,   H = W^T diag(a is m2) W,   c = sum_k (mu a is m2 - a m1)[k] W[k][:]
+ *   dW = diag(a) [ dz^T X - m1 cs^T - diag(m2 is) (W G - mu cs^T) ],   G = X^T X,  cs = column sums of X
+ * with dz the pooled gradient (one row per ball and channel), m1 = sums[0] * inv_count, m2 = sums[1] * inv_count.
+ * omnipq_sa_pool_alg_consts writes the extended B operand of the dX product, bf16 [Cin][C + Cin] row-major (row n:
+ * a[k] W[k][n] for k < C, then -H[j][n]) -- to be packed with omnipq_pack_b and used with OMNIPQ_A_POOLX -- and c
+ * (float[Cin]); omnipq_sa_pool_alg_dw turns ext = [dz^T X ; X^T X] (omnipq_gemm_tn_gen, POOLX) and cs into dW
+ * (f32 [C][Cin]).  W is the layer's f32 weight [C][Cin]; a / mean / invstd its BatchNorm constants. */
+int omnipq_sa_pool_alg_consts(int C, int Cin, const float *W, const float *a, const float *mean, const float *invstd,
+                              const double *sums, double inv_count, void *Bext, float *crow, void *stream);
+int omnipq_sa_pool_alg_dw(int C, int Cin, const float *W, const float *a, const float *mean, const float *invstd,
+                          const double *sums, double inv_count, const float *ext, const float *cs, float *dW,
+                          void *stream);
 
 /* omnipq_sa_pool_bwd_stats_sel (omnipq_sa.h) that also writes gz[bm][c] = (out_pm > 0 ? g_out : 0) as bf16: the
  * per-ball gradient the DY3 generator scatters to the arg-max row. */

@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 
 constexpr int RK = 32;              // K-step
 constexpr int RPITCH = 40;          // bf16 per staged row (80 B)
-constexpr int kTabK = 640;          // channels the per-channel constant table holds
+constexpr int kTabK = 1024;         // largest contraction length (the per-channel constant tables live in dynamic LDS)
 
 __device__ __forceinline__ unsigned short c_f2bf(float x) { return __builtin_bit_cast(unsigned short, (bf16_t)x); }
 __device__ __forceinline__ float c_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
@@ -187,11 +187,13 @@ struct RowDev {
   float inv_r;
   AffineSrc aff;
   DySrc dy;
+  int split, lda1;           // POOLX: columns [0, split) = pooled gradient (A0 = gz, arg), [split, K) = relu(a A1 + b), A1 pitch lda1
+  const float *crow;         // POOLX: per-column constant added to the product before rounding (may be NULL)
   // B
   const bf16_t *B;
   int ldb;
   // C
-  bf16_t *C;
+  bf16_t *C;                 // NULL: the product is not stored (statistics / ball extrema only)
   int ldc;
   // epilogue
   int pool_s;
@@ -247,24 +249,27 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
   constexpr int NT = L::NT, KC = L::KC, AP = L::AP, CP = L::CP;
   constexpr int PIECES = NT / 8;                      // 16-byte pieces per C row
   constexpr int RG = NTHR / PIECES;                   // row groups of the store loop
-  constexpr bool HAS_TAB = AGEN == OMNIPQ_A_AFFINE || AGEN == OMNIPQ_A_DY || AGEN == OMNIPQ_A_DY3;
+  constexpr bool POOLX = AGEN == OMNIPQ_A_POOLX;
+  constexpr bool HAS_TAB = AGEN == OMNIPQ_A_AFFINE || AGEN == OMNIPQ_A_DY || AGEN == OMNIPQ_A_DY3 || POOLX;
   constexpr bool DYK = AGEN == OMNIPQ_A_DY || AGEN == OMNIPQ_A_DY3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *At = reinterpret_cast<bf16_t *>(smem);
   bf16_t *bst = reinterpret_cast<bf16_t *>(smem + L::A_BYTES);
-  float *s_tab = reinterpret_cast<float *>(smem + L::A_BYTES + L::B_BYTES);        // AFFINE: [2][K]; DY: [3][K]
-  const int tabk = d.K;                                                            // stride between the table's rows
-  float *s_stat = s_tab + (AGEN == OMNIPQ_A_AFFINE ? 2 : DYK ? 3 : 0) * tabk;      // [2][N]
+  constexpr bool REGEPI = EPI == OMNIPQ_E_STATS_REG;       // statistics / ball extrema straight from the accumulators
+  float *s_tab = reinterpret_cast<float *>(smem + L::A_BYTES + (REGEPI ? 0 : L::B_BYTES));        // AFFINE: [2][K]; DY: [3][K]
+  const int tabk = POOLX ? d.K - d.split : d.K;                                    // stride between the table's rows
+  float *s_stat = s_tab + ((AGEN == OMNIPQ_A_AFFINE || POOLX) ? 2 : DYK ? 3 : 0) * tabk;      // [2][N]
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wn = tid >> 6;
   const bool first_wg = blockIdx.x == 0;
 
   if (AGEN == OMNIPQ_A_AFFINE) build_affine_table(s_tab, tabk, d.K, d.aff, first_wg, tid, NTHR);
+  if (POOLX) build_affine_table(s_tab, tabk, tabk, d.aff, first_wg, tid, NTHR);
   if (DYK) build_dy_table(s_tab, tabk, 0, d.K, d.K, d.dy, first_wg, tid, NTHR);
-  if (EPI != OMNIPQ_E_STORE)
+  if (EPI != OMNIPQ_E_STORE && !REGEPI)
     for (int c = tid; c < 2 * d.N; c += NTHR) s_stat[c] = 0.f;
-  if (HAS_TAB || EPI != OMNIPQ_E_STORE) __syncthreads();
+  if (HAS_TAB || (EPI != OMNIPQ_E_STORE && !REGEPI)) __syncthreads();
 
   // ---- A staging assignment: row tid >> 2 of the tile, 16-byte piece (tid & 3) of every K-step ---------------
   const int arow = tid >> 2, apiece = tid & 3;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
   auto tile_of = [&](int j) -> int { return (int)blockIdx.x + (j / d.chunks) * (int)gridDim.x; };
   // raw operand pieces of the work item being fetched
   uint4 ra0[KS], ra1[DYK ? KS : 1];
-  uint2 rarg[AGEN == OMNIPQ_A_DY3 ? KS : 1];
+  uint2 rarg[(AGEN == OMNIPQ_A_DY3 || POOLX) ? KS : 1];
   float gx[6];               // GATHER: xyz of the neighbour and of the centre (the thread that owns the xyz piece)
   int rsrow = 0;             // DY3: row of the fetched item within its ball
   int gk = 0, gk_next = 0;   // GATHER: neighbour index of the item being fetched / of the one after it
@@ -312,6 +317,22 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
         ra1[i] = *reinterpret_cast<const uint4 *>(s1 + i * RK);
         rarg[i] = *reinterpret_cast<const uint2 *>(sa + i * RK);
       }
+    } else if (POOLX) {
+      if (kbase < d.split) {                          // pooled-gradient columns: per-ball rows (L2-resident)
+        const long long ball = p / d.s;
+        rsrow = (int)(p - ball * d.s);
+        const bf16_t *s0 = d.A0 + (size_t)ball * d.lda + kbase;
+        const unsigned char *sa = d.arg + (size_t)ball * d.lda + kbase;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          ra0[i] = *reinterpret_cast<const uint4 *>(s0 + i * RK);
+          rarg[i] = *reinterpret_cast<const uint2 *>(sa + i * RK);
+        }
+      } else {                                        // activation columns of the layer below
+        const bf16_t *s1 = d.A1 + (size_t)p * d.lda1 + (kbase - d.split);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) ra0[i] = *reinterpret_cast<const uint4 *>(s1 + i * RK);
+      }
     } else {   // GATHER
       const long long bm = p / d.s;
       const int b = (int)(bm / d.m);
@@ -343,6 +364,10 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
       if (AGEN == OMNIPQ_A_DY) va = dy8(ra0[i], ra1[i], s_tab + k0, s_tab + tabk + k0, s_tab + 2 * tabk + k0);
       if (AGEN == OMNIPQ_A_DY3)
         va = dy8(pool_dz8(rarg[i], ra0[i], rsrow), ra1[i], s_tab + k0, s_tab + tabk + k0, s_tab + 2 * tabk + k0);
+      if (POOLX) {
+        if (kch < d.split) va = pool_dz8(rarg[i], ra0[i], rsrow);
+        else va = affine_relu8(ra0[i], s_tab + (k0 - d.split), s_tab + tabk + (k0 - d.split));
+      }
       if (AGEN == OMNIPQ_A_GATHER) {
         if (k0 == d.cin) {
           va.x = c_pack((gx[0] - gx[3]) * d.inv_r, (gx[1] - gx[4]) * d.inv_r);
@@ -368,6 +393,9 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
   if (items > 0) fetch(0);
 
   f32x16 acc[2][NP];
+  float rsum[NP], rsq[NP];           // REGEPI: this lane's column (wn 32 NP + j 32 + (lane & 31)), rows of its half wave
+#pragma unroll
+  for (int j = 0; j < NP; ++j) rsum[j] = rsq[j] = 0.f;
   for (; item < items; ++item) {
     const int tile = tile_of(item), chunk = item % d.chunks;
     const long long m0 = (long long)tile * TR;
@@ -455,19 +483,97 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
         continue;
       }
 
+      if (REGEPI) {
+        // ---- register epilogue: nothing is stored.  Per column (one lane per column and half wave: col = lane & 31, rows
+        // (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32-row block) the sums of the ROUNDED products and, per ball of
+        // pool_s rows, their extrema with the first row attaining each -- what the LDS epilogue derives from the stored
+        // tile, without the tile, its barriers or its LDS (the A tile is then all the LDS a workgroup holds).
+        const int h = lane >> 5, ccol = lane & 31;
+        const bool tail = m0 + TR > d.P;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int gc = n0 + wn * 32 * NP + j * 32 + ccol;
+          float vmax[4], vmin[4];                      // per quarter block (8 rows of this lane's 16 -> balls of 16 rows)
+          int imax[4], imin[4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {           // rows [16 hb, 16 hb + 16) of block i
+              float hi = -INFINITY, lo = INFINITY;
+              int ihi = 0, ilo = 0;
+#pragma unroll
+              for (int rr = 0; rr < 8; ++rr) {
+                const int r = hb * 8 + rr;
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                // branch-free: rounded value (what a stored tile would hold); rows past P (last tile only) count as absent
+                const float v = (float)(bf16_t)acc[i][j][r];
+                const bool live = !tail || m0 + row < d.P;
+                const float vs = live ? v : 0.f;
+                rsum[j] += vs;
+                rsq[j] = __builtin_fmaf(vs, vs, rsq[j]);
+                const float vh = live ? v : -INFINITY, vl = live ? v : INFINITY;
+                ihi = vh > hi ? row : ihi;             // strict: the first row attaining the extremum stays
+                ilo = vl < lo ? row : ilo;
+                hi = __builtin_fmaxf(hi, vh);
+                lo = __builtin_fminf(lo, vl);
+              }
+              vmax[i * 2 + hb] = hi; imax[i * 2 + hb] = ihi;
+              vmin[i * 2 + hb] = lo; imin[i * 2 + hb] = ilo;
+            }
+          if (d.pool_s > 0) {
+            // combine the two half waves (rows 4 h + ...): larger value wins, equal values -> smaller row
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float ohi = __shfl_xor(vmax[q], 32), olo = __shfl_xor(vmin[q], 32);
+              const int oih = __shfl_xor(imax[q], 32), oil = __shfl_xor(imin[q], 32);
+              if (ohi > vmax[q] || (ohi == vmax[q] && oih < imax[q])) { vmax[q] = ohi; imax[q] = oih; }
+              if (olo < vmin[q] || (olo == vmin[q] && oil < imin[q])) { vmin[q] = olo; imin[q] = oil; }
+            }
+            // quarters of 16 rows -> balls of pool_s rows (16, 32 or 64); earlier quarters hold smaller rows
+            const int per = d.pool_s >> 4;             // quarters per ball: 1, 2, 4
+            if (h == 0 && gc < d.N) {
+              for (int b0 = 0; b0 < 4; b0 += per) {
+                float hi = vmax[b0], lo = vmin[b0];
+                int ihi = imax[b0], ilo = imin[b0];
+                for (int q = b0 + 1; q < b0 + per; ++q) {
+                  if (vmax[q] > hi) { hi = vmax[q]; ihi = imax[q]; }
+                  if (vmin[q] < lo) { lo = vmin[q]; ilo = imin[q]; }
+                }
+                const long long r0 = m0 + b0 * 16;
+                if (r0 < d.P) {
+                  const size_t o = (size_t)(r0 / d.pool_s) * d.N + gc;
+                  d.ymax[o] = (bf16_t)hi;
+                  d.ymin[o] = (bf16_t)lo;
+                  d.amax[o] = (unsigned char)(ihi - b0 * 16);
+                  d.amin[o] = (unsigned char)(ilo - b0 * 16);
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();                               // every wave is done with the A tile
+        continue;
+      }
+
       // ---- epilogue: accumulators -> LDS (row-major bf16 C tile) -> 16-byte row stores ----
       if (d.debug & 4) { __syncthreads(); continue; }
       {
         unsigned *ct32 = reinterpret_cast<unsigned *>(bst);
         const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
         const bool odd = lane & 1;
+        float cadd[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int gc = n0 + wn * 32 * NP + j * 32 + ccol;
+          cadd[j] = (POOLX && d.crow && gc < d.N) ? d.crow[gc] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < NP; ++j)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              const float mine0 = acc[i][j][r], mine1 = acc[i][j][r + 1];
+              const float mine0 = acc[i][j][r] + cadd[j], mine1 = acc[i][j][r + 1] + cadd[j];
               const float give = odd ? mine0 : mine1;
               const float got = __builtin_bit_cast(
                   float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -528,7 +634,7 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
               cs2[2 * e + 1] += hi * hi;
             }
           }
-          *reinterpret_cast<uint4 *>(d.C + (size_t)gr * d.ldc + scol) = v;
+          if (d.C) *reinterpret_cast<uint4 *>(d.C + (size_t)gr * d.ldc + scol) = v;
         }
         if (EPI != OMNIPQ_E_STORE) {
 #pragma unroll
@@ -588,7 +694,23 @@ __global__ __launch_bounds__(NTHR, 2) void rowgemm_kernel(const RowDev d) {
     }
   }
 
-  if (EPI != OMNIPQ_E_STORE) {
+  if (REGEPI) {
+    // one lane per column and half wave holds that half's totals of all this workgroup's tiles
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const float s0 = rsum[j] + __shfl_xor(rsum[j], 32), s1 = rsq[j] + __shfl_xor(rsq[j], 32);
+      const int gc = wn * 32 * NP + j * 32 + (lane & 31);
+      if ((lane >> 5) == 0 && gc < d.N) {
+        if (d.stats_direct) {
+          atomicAdd(d.sums + gc, (double)s0);
+          atomicAdd(d.sums + d.N + gc, (double)s1);
+        } else {
+          d.part[(size_t)blockIdx.x * 2 * d.N + gc] = s0;
+          d.part[(size_t)blockIdx.x * 2 * d.N + d.N + gc] = s1;
+        }
+      }
+    }
+  } else if (EPI != OMNIPQ_E_STORE) {
     for (int c = tid; c < 2 * d.N; c += NTHR) {
       const float tot = s_stat[c];
       if (d.stats_direct)
@@ -638,6 +760,8 @@ struct TnGenDev {
   const bf16_t *B0;
   const float *ba, *bb;
   float *part;
+  int split;                 // POOLX: output rows [0, split) = dz^T X, rows [split, M) = X^T X (X = the B operand)
+  float *bcolsum;            // POOLX: float[N] += column sums of the B operand (zero on entry)
 };
 
 template <int AK, int BKIND>
@@ -645,7 +769,8 @@ __global__ __launch_bounds__(256, 3) void tn_gen_kernel(const TnGenDev g) {
   constexpr int STAGE_ELEMS = 2 * 2 * GTK * GTPITCH;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_ELEMS * 2];
   __shared__ __attribute__((aligned(16))) float s_ab[BKIND == OMNIPQ_A_AFFINE ? 256 : 4];
-  __shared__ __attribute__((aligned(16))) float s_dy[(AK == OMNIPQ_A_DY || AK == OMNIPQ_A_DY3) ? 384 : 4];
+  __shared__ __attribute__((aligned(16))) float s_dy[(AK == OMNIPQ_A_DY || AK == OMNIPQ_A_DY3) ? 384
+                                                     : AK == OMNIPQ_A_POOLX ? 256 : 4];
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
 
   const int id = (int)blockIdx.x;
@@ -672,7 +797,17 @@ __global__ __launch_bounds__(256, 3) void tn_gen_kernel(const TnGenDev g) {
     }
   }
   if (AK == OMNIPQ_A_DY || AK == OMNIPQ_A_DY3) build_dy_table(s_dy, 128, m0, 128, g.M, g.dy, false, tid, 256);
-  if (BKIND == OMNIPQ_A_AFFINE || AK == OMNIPQ_A_DY || AK == OMNIPQ_A_DY3) __syncthreads();
+  const bool gram = AK == OMNIPQ_A_POOLX && m0 >= g.split;       // this M-tile contracts the B operand with itself
+  if (AK == OMNIPQ_A_POOLX && gram && tid < 128) {
+    const int c = m0 - g.split + tid < g.N ? m0 - g.split + tid : 0;
+    s_dy[tid] = g.ba[c];
+    s_dy[128 + tid] = g.bb[c];
+  }
+  if (BKIND == OMNIPQ_A_AFFINE || AK == OMNIPQ_A_DY || AK == OMNIPQ_A_DY3 || AK == OMNIPQ_A_POOLX) __syncthreads();
+  const bool do_bsum = AK == OMNIPQ_A_POOLX && mt == 0 && g.bcolsum != nullptr;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
   int spos[2], sc8[2], acol[2], bcol[2];
 #pragma unroll
@@ -707,6 +842,17 @@ __global__ __launch_bounds__(256, 3) void tn_gen_kernel(const TnGenDev g) {
       } else if (AK == OMNIPQ_A_DY) {
         ra[i] = *reinterpret_cast<const uint4 *>(g.A0 + (size_t)pc * g.lda + acol[i]);
         ry[i] = *reinterpret_cast<const uint4 *>(g.A1 + (size_t)pc * g.lda + acol[i]);
+      } else if (AK == OMNIPQ_A_POOLX) {
+        if (gram) {
+          int c = m0 - g.split + sc8[i] * 8;
+          c = c < g.N ? c : 0;
+          ra[i] = *reinterpret_cast<const uint4 *>(g.B0 + (size_t)pc * g.ldb + c);
+        } else {
+          const long long ball = pc / g.s;
+          srow[i] = (int)(pc - ball * g.s);
+          ra[i] = *reinterpret_cast<const uint4 *>(g.A0 + (size_t)ball * g.lda + acol[i]);
+          rg[i] = *reinterpret_cast<const uint2 *>(g.arg + (size_t)ball * g.lda + acol[i]);
+        }
       } else {
         const long long ball = pc / g.s;
         srow[i] = (int)(pc - ball * g.s);
@@ -727,9 +873,19 @@ __global__ __launch_bounds__(256, 3) void tn_gen_kernel(const TnGenDev g) {
       if (AK == OMNIPQ_A_DY) va = dy8(ra[i], ry[i], s_dy + sc8[i] * 8, s_dy + 128 + sc8[i] * 8, s_dy + 256 + sc8[i] * 8);
       if (AK == OMNIPQ_A_DY3)
         va = dy8(pool_dz8(rg[i], ra[i], srow[i]), ry[i], s_dy + sc8[i] * 8, s_dy + 128 + sc8[i] * 8, s_dy + 256 + sc8[i] * 8);
+      if (AK == OMNIPQ_A_POOLX)
+        va = gram ? affine_relu8(ra[i], s_dy + sc8[i] * 8, s_dy + 128 + sc8[i] * 8) : pool_dz8(rg[i], ra[i], srow[i]);
       const unsigned k = keep[i];
       va.x &= k; va.y &= k; va.z &= k; va.w &= k;
       vb.x &= k; vb.y &= k; vb.z &= k; vb.w &= k;
+      if (do_bsum) {
+        const unsigned w[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bsum[2 * e] += c_lo(w[e]);
+          bsum[2 * e + 1] += c_hi(w[e]);
+        }
+      }
       *reinterpret_cast<uint4 *>(sa + spos[i] * GTPITCH + sc8[i] * 8) = va;
       *reinterpret_cast<uint4 *>(sb + spos[i] * GTPITCH + sc8[i] * 8) = vb;
     }
@@ -773,6 +929,22 @@ __global__ __launch_bounds__(256, 3) void tn_gen_kernel(const TnGenDev g) {
     __syncthreads();
   }
 
+  if (do_bsum) {
+    // thread (row group tid >> 4, piece tid & 15) holds the sums of its positions for 8 columns of B (both chunks cover the
+    // same piece): fold the 16 row groups through LDS, one atomic per column
+    float *red = reinterpret_cast<float *>(smem);            // [16][128]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < g.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+      atomicAdd(g.bcolsum + n0 + tid, t);
+    }
+    __syncthreads();
+  }
   float *C = g.part + (size_t)slab * g.M * g.N;
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
 #pragma unroll
@@ -859,6 +1031,63 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_gz_kernel(long long BM, in
 
 }  // namespace omnipq
 
+namespace omnipq {
+
+// ---- max-pool + BatchNorm backward of the LAST layer of a stage without Y_L or any gradient tensor of its shape ----
+// With dz the pooled gradient (non-zero at one row per ball and channel), yhat = (Y_L - mu) is, Y_L = X W^T:
+//   dY = a (dz - m1 - yhat m2),   m1 = sum dz / P,  m2 = sum dz yhat / P                       (BatchNorm backward)
+//   dX = dY W      = (dz .* a) W - X H + c,     H = W^T diag(s) W,  s = a is m2,   c = sum_k (mu s - a m1)[k] W[k][:]
+//   dW = dY^T X    = diag(a) [ dz^T X - m1 cs^T - diag(m2 is) (W G - mu cs^T) ],    G = X^T X,  cs = column sums of X
+// so the two big products need dz (generated from the per-ball gradient and arg-max) and X only: Y_L is never stored
+// (forward) nor read (backward), dY never exists.  pool_alg_consts builds the extended B operand of the dX product
+// (row n: [a[k] W[k][n] for k < C | -H[j][n] for j < Cin]) and c; pool_alg_dw finishes dW from S = dz^T X, G and cs.
+__global__ __launch_bounds__(128) void pool_alg_consts_kernel(int C, int Cin, const float *__restrict__ W,
+                                                             const float *__restrict__ a, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd,
+                                                             const double *__restrict__ sums, double inv_count,
+                                                             bf16_t *__restrict__ Bext, float *__restrict__ crow) {
+  // block j < Cin: column j of H and the slice k = j, j + Cin, ... of the scaled weights; block Cin: the constant row
+  const int j = (int)blockIdx.x;
+  const int K = C + Cin;
+  for (int n = (int)threadIdx.x; n < Cin; n += 128) {
+    if (j < Cin) {
+      float h = 0.f;
+      for (int k = 0; k < C; ++k) {
+        const float sk = a[k] * invstd[k] * (float)(sums[C + k] * inv_count);
+        h = __builtin_fmaf(sk * W[(size_t)k * Cin + j], W[(size_t)k * Cin + n], h);
+      }
+      Bext[(size_t)n * K + C + j] = (bf16_t)(-h);
+      for (int k = j; k < C; k += Cin) Bext[(size_t)n * K + k] = (bf16_t)(a[k] * W[(size_t)k * Cin + n]);
+    } else {
+      float c = 0.f;
+      for (int k = 0; k < C; ++k) {
+        const float m1 = (float)(sums[k] * inv_count), m2 = (float)(sums[C + k] * inv_count);
+        c = __builtin_fmaf(mean[k] * a[k] * invstd[k] * m2 - a[k] * m1, W[(size_t)k * Cin + n], c);
+      }
+      crow[n] = c;
+    }
+  }
+}
+
+// ext = f32 [(C + Cin)][Cin]: rows [0, C) = S = dz^T X, rows [C, C + Cin) = G = X^T X; cs = float[Cin]
+__global__ __launch_bounds__(128) void pool_alg_dw_kernel(int C, int Cin, const float *__restrict__ W,
+                                                         const float *__restrict__ a, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd,
+                                                         const double *__restrict__ sums, double inv_count,
+                                                         const float *__restrict__ ext, const float *__restrict__ cs,
+                                                         float *__restrict__ dW) {
+  const int c = (int)blockIdx.x;
+  const float m1 = (float)(sums[c] * inv_count), m2 = (float)(sums[C + c] * inv_count);
+  const float *G = ext + (size_t)C * Cin;
+  for (int j = (int)threadIdx.x; j < Cin; j += 128) {
+    float wg = 0.f;
+    for (int i = 0; i < Cin; ++i) wg = __builtin_fmaf(W[(size_t)c * Cin + i], G[(size_t)i * Cin + j], wg);
+    dW[(size_t)c * Cin + j] = a[c] * (ext[(size_t)c * Cin + j] - m1 * cs[j] - m2 * invstd[c] * (wg - mean[c] * cs[j]));
+  }
+}
+
+}  // namespace omnipq
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -889,9 +1118,10 @@ static int rowgemm_np(int N) { return N <= 128 ? 1 : 2; }
 
 static size_t rowgemm_lds(int np, int ks, int a_kind, int epi, int K, int N) {
   const size_t a = (size_t)omnipq::TR * (omnipq::RK * ks + 8) * 2;
-  const size_t c = (size_t)omnipq::TR * (128 * np + 8) * 2;
-  const int tabs = a_kind == OMNIPQ_A_AFFINE ? 2 : (a_kind == OMNIPQ_A_DY || a_kind == OMNIPQ_A_DY3) ? 3 : 0;
-  return a + c + (size_t)tabs * K * 4 + (epi == OMNIPQ_E_STORE ? 0 : (size_t)2 * N * 4);
+  const size_t c = epi == OMNIPQ_E_STATS_REG ? 0 : (size_t)omnipq::TR * (128 * np + 8) * 2;
+  const int tabs = (a_kind == OMNIPQ_A_AFFINE || a_kind == OMNIPQ_A_POOLX) ? 2
+                   : (a_kind == OMNIPQ_A_DY || a_kind == OMNIPQ_A_DY3) ? 3 : 0;
+  return a + c + (size_t)tabs * K * 4 + ((epi == OMNIPQ_E_STORE || epi == OMNIPQ_E_STATS_REG) ? 0 : (size_t)2 * N * 4);
 }
 
 // persistent grid: workgroups per CU by LDS footprint (256-thread workgroups; at most 4 per CU are worth having)
@@ -949,12 +1179,13 @@ static int rowgemm_go(const RowDev &d, int grid, hipStream_t st) {
 
 template <int NP, int KS, int AGEN>
 static int rowgemm_launch_epi(const RowDev &d, int epi, int grid, hipStream_t st) {
-  constexpr bool dyk = AGEN == OMNIPQ_A_DY || AGEN == OMNIPQ_A_DY3;
+  constexpr bool dyk = AGEN == OMNIPQ_A_DY || AGEN == OMNIPQ_A_DY3 || AGEN == OMNIPQ_A_POOLX;
   if (epi == OMNIPQ_E_STORE) return rowgemm_go<NP, KS, AGEN, OMNIPQ_E_STORE>(d, grid, st);
   if constexpr (dyk) {
     if (epi == OMNIPQ_E_STORE_BNBWD) return rowgemm_go<NP, KS, AGEN, OMNIPQ_E_STORE_BNBWD>(d, grid, st);
   } else {
     if (epi == OMNIPQ_E_STORE_STATS) return rowgemm_go<NP, KS, AGEN, OMNIPQ_E_STORE_STATS>(d, grid, st);
+    if (epi == OMNIPQ_E_STATS_REG) return rowgemm_go<NP, KS, AGEN, OMNIPQ_E_STATS_REG>(d, grid, st);
   }
   return OMNIPQ_EINVAL;            // combination not instantiated (statistics go with forward operands, BNBWD with DY)
 }
@@ -967,6 +1198,7 @@ static int rowgemm_launch_a(const RowDev &d, int a_kind, int epi, int grid, hipS
     case OMNIPQ_A_GATHER: return rowgemm_launch_epi<NP, KS, OMNIPQ_A_GATHER>(d, epi, grid, st);
     case OMNIPQ_A_DY: return rowgemm_launch_epi<NP, KS, OMNIPQ_A_DY>(d, epi, grid, st);
     case OMNIPQ_A_DY3: return rowgemm_launch_epi<NP, KS, OMNIPQ_A_DY3>(d, epi, grid, st);
+    case OMNIPQ_A_POOLX: return rowgemm_launch_epi<NP, KS, OMNIPQ_A_POOLX>(d, epi, grid, st);
   }
   return OMNIPQ_EINVAL;
 }
@@ -988,8 +1220,9 @@ extern "C" int omnipq_sa_rowgemm(const omnipq_rowgemm_desc *q, void *stream) {
   if (!q) return OMNIPQ_EINVAL;
   if (q->P < 0 || q->N < 0 || q->K < 0) return OMNIPQ_EINVAL;
   if (q->P == 0 || q->N == 0) return OMNIPQ_OK;
-  if (q->N > kStatN || (q->N % 8) || (q->K % RK) || q->K == 0 || q->K > kTabK || !q->B || !q->C || (q->ldc % 8) || q->ldc < q->N)
+  if (q->N > kStatN || (q->N % 8) || (q->K % RK) || q->K == 0 || q->K > kTabK || !q->B || (q->ldc % 8) || q->ldc < q->N)
     return OMNIPQ_EINVAL;
+  if (!q->C && q->epi_kind != OMNIPQ_E_STORE_STATS) return OMNIPQ_EINVAL;      // only the statistics pass may skip the store
   RowDev d{};
   d.P = q->P;
   d.N = q->N;
@@ -1029,6 +1262,17 @@ extern "C" int omnipq_sa_rowgemm(const omnipq_rowgemm_desc *q, void *stream) {
           (q->cin > 0 && !q->A0) || q->K < q->cin + 8 || q->P != (q->P / ((long long)q->m * q->s)) * q->m * q->s)
         return OMNIPQ_EINVAL;
       break;
+    case OMNIPQ_A_POOLX:
+      if (!q->A0 || !q->A1 || !q->arg || q->s <= 0 || q->s > 255 || (q->P % q->s) || (q->lda % 8) || (q->lda1 % 8) ||
+          q->split <= 0 || q->split >= q->K || q->lda < q->split || q->lda1 < q->K - q->split || !q->a_in || !q->b_in ||
+          (q->split % (RK * ks)))
+        return OMNIPQ_EINVAL;
+      d.aff = AffineSrc{q->a_in, q->b_in, nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, 0.f, 0.f};
+      d.split = q->split;
+      d.lda1 = q->lda1;
+      d.crow = q->crow;
+      break;
     case OMNIPQ_A_DY3:
       if (!q->arg || q->s <= 0 || q->s > 255 || (q->P % q->s)) return OMNIPQ_EINVAL;
       /* fall through */
@@ -1044,7 +1288,9 @@ extern "C" int omnipq_sa_rowgemm(const omnipq_rowgemm_desc *q, void *stream) {
   d.ldb = q->ldb;
   d.C = (bf16_t *)q->C;
   d.ldc = q->ldc;
-  const int grid = rowgemm_grid(q->P, q->N, q->K, q->a_kind, q->epi_kind);
+  const bool reg_epi = q->epi_kind == OMNIPQ_E_STORE_STATS && !q->C && d.npass == 1 &&
+                       (q->pool_s == 0 || q->pool_s == 16 || q->pool_s == 32 || q->pool_s == 64);
+  const int grid = rowgemm_grid(q->P, q->N, q->K, q->a_kind, reg_epi ? OMNIPQ_E_STATS_REG : q->epi_kind);
   d.stats_direct = grid <= kChainStatsDirect;
   d.sums = q->sums;
   d.part = q->workspace;
@@ -1069,10 +1315,16 @@ extern "C" int omnipq_sa_rowgemm(const omnipq_rowgemm_desc *q, void *stream) {
     d.below_invstd = q->below_invstd;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int rc = np == 1 ? rowgemm_launch_ks<1>(d, ks, q->a_kind, q->epi_kind, grid, st)
-                         : rowgemm_launch_ks<2>(d, ks, q->a_kind, q->epi_kind, grid, st);
+  // nothing to store and balls the register epilogue can fold (16 / 32 / 64 rows): statistics and extrema come
+  // straight from the accumulators, no C tile in LDS
+  int epi = q->epi_kind;
+  if (epi == OMNIPQ_E_STORE_STATS && !q->C && d.npass == 1 &&
+      (d.pool_s == 0 || d.pool_s == 16 || d.pool_s == 32 || d.pool_s == 64))
+    epi = OMNIPQ_E_STATS_REG;
+  const int rc = np == 1 ? rowgemm_launch_ks<1>(d, ks, q->a_kind, epi, grid, st)
+                         : rowgemm_launch_ks<2>(d, ks, q->a_kind, epi, grid, st);
   if (rc) return rc;
-  if (q->epi_kind != OMNIPQ_E_STORE && !d.stats_direct) {
+  if (q->epi_kind != OMNIPQ_E_STORE && !d.stats_direct) {      // (the register epilogue writes the same partials)
     int slabs = grid / 64;
     if (slabs < 1) slabs = 1;
     chain_partial_reduce_kernel<<<dim3((2 * q->N + 255) / 256, slabs), 256, 0, st>>>(grid, 2 * q->N, q->workspace,
@@ -1114,7 +1366,11 @@ extern "C" int omnipq_gemm_tn_gen(const omnipq_tn_gen_desc *q, void *stream) {
   if (!q->A0 || !q->B0 || !q->C || !q->workspace || (q->M % 8) || (q->N % 8) || (q->lda % 8) || (q->ldb % 8) || q->P > 0x7fffffffLL)
     return OMNIPQ_EINVAL;
   if (q->b_kind == OMNIPQ_A_AFFINE && (!q->ba || !q->bb)) return OMNIPQ_EINVAL;
-  if (q->a_kind == OMNIPQ_A_DY || q->a_kind == OMNIPQ_A_DY3) {
+  if (q->a_kind == OMNIPQ_A_POOLX) {
+    if (!q->arg || q->s <= 0 || q->s > 255 || (q->P % q->s) || q->b_kind != OMNIPQ_A_AFFINE || q->split <= 0 ||
+        (q->split % 128) || q->M != q->split + q->N || (q->N % 8))
+      return OMNIPQ_EINVAL;
+  } else if (q->a_kind == OMNIPQ_A_DY || q->a_kind == OMNIPQ_A_DY3) {
     if (!q->A1 || !q->bwd_sums || !q->bn_a || !q->bn_mean || !q->bn_invstd) return OMNIPQ_EINVAL;
     if (q->a_kind == OMNIPQ_A_DY3 && (!q->arg || q->s <= 0 || q->s > 255 || (q->P % q->s))) return OMNIPQ_EINVAL;
   } else if (q->a_kind != OMNIPQ_A_PLAIN) {
@@ -1137,12 +1393,18 @@ extern "C" int omnipq_gemm_tn_gen(const omnipq_tn_gen_desc *q, void *stream) {
   g.B0 = (const bf16_t *)q->B0;
   g.ba = q->ba; g.bb = q->bb;
   g.part = q->workspace;
+  g.split = q->split;
+  g.bcolsum = q->bcolsum;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(tiles * ((used + 7) / 8) * 8);
   int rc;
   switch (q->a_kind) {
     case OMNIPQ_A_PLAIN: rc = tn_gen_launch<OMNIPQ_A_PLAIN>(g, q->b_kind, grid, st); break;
     case OMNIPQ_A_DY: rc = tn_gen_launch<OMNIPQ_A_DY>(g, q->b_kind, grid, st); break;
+    case OMNIPQ_A_POOLX:
+      tn_gen_kernel<OMNIPQ_A_POOLX, OMNIPQ_A_AFFINE><<<grid, 256, 0, st>>>(g);
+      rc = hipGetLastError() == hipSuccess ? OMNIPQ_OK : OMNIPQ_EINVAL;
+      break;
     default: rc = tn_gen_launch<OMNIPQ_A_DY3>(g, q->b_kind, grid, st); break;
   }
   if (rc) return rc;
@@ -1158,6 +1420,27 @@ extern "C" int omnipq_gemm_tn_gen(const omnipq_tn_gen_desc *q, void *stream) {
   } else {
     chain_slab_reduce_kernel<<<dim3((n4 + 255) / 256, 1), 256, 0, st>>>(n4, used, 1, part, reinterpret_cast<f32x4 *>(q->C));
   }
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool_alg_consts(int C, int Cin, const float *W, const float *a, const float *mean,
+                                         const float *invstd, const double *sums, double inv_count, void *Bext,
+                                         float *crow, void *stream) {
+  using namespace omnipq;
+  if (C <= 0 || Cin <= 0 || !W || !a || !mean || !invstd || !sums || !Bext || !crow) return OMNIPQ_EINVAL;
+  pool_alg_consts_kernel<<<Cin + 1, 128, 0, (hipStream_t)stream>>>(C, Cin, W, a, mean, invstd, sums, inv_count,
+                                                                   (bf16_t *)Bext, crow);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_sa_pool_alg_dw(int C, int Cin, const float *W, const float *a, const float *mean,
+                                     const float *invstd, const double *sums, double inv_count, const float *ext,
+                                     const float *cs, float *dW, void *stream) {
+  using namespace omnipq;
+  if (C <= 0 || Cin <= 0 || !W || !a || !mean || !invstd || !sums || !ext || !cs || !dW) return OMNIPQ_EINVAL;
+  pool_alg_dw_kernel<<<C, 128, 0, (hipStream_t)stream>>>(C, Cin, W, a, mean, invstd, sums, inv_count, ext, cs, dW);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

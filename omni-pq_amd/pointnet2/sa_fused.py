@@ -249,6 +249,7 @@ class _RowGemmDesc(ctypes.Structure):
                 ("invstd_out", ctypes.c_void_p),
                 ("bwd_sums", ctypes.c_void_p), ("inv_count", ctypes.c_double), ("bn_a", ctypes.c_void_p),
                 ("bn_mean", ctypes.c_void_p), ("bn_invstd", ctypes.c_void_p), ("gb_out", ctypes.c_void_p),
+                ("split", ctypes.c_int), ("lda1", ctypes.c_int), ("crow", ctypes.c_void_p),
                 ("B", ctypes.c_void_p), ("ldb", ctypes.c_int),
                 ("C", ctypes.c_void_p), ("ldc", ctypes.c_int),
                 ("pool_s", ctypes.c_int), ("sums", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
@@ -264,10 +265,11 @@ class _TnGenDesc(ctypes.Structure):
                 ("lda", ctypes.c_int), ("s", ctypes.c_int), ("bwd_sums", ctypes.c_void_p), ("inv_count", ctypes.c_double),
                 ("bn_a", ctypes.c_void_p), ("bn_mean", ctypes.c_void_p), ("bn_invstd", ctypes.c_void_p),
                 ("B0", ctypes.c_void_p), ("ldb", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p),
-                ("C", ctypes.c_void_p), ("workspace", ctypes.c_void_p)]
+                ("C", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("split", ctypes.c_int),
+                ("bcolsum", ctypes.c_void_p)]
 
 
-A_PLAIN, A_AFFINE, A_GATHER, A_DY, A_DY3 = 0, 1, 2, 3, 4
+A_PLAIN, A_AFFINE, A_GATHER, A_DY, A_DY3, A_POOLX = 0, 1, 2, 3, 4, 5
 E_STORE, E_STORE_STATS, E_STORE_BNBWD = 0, 1, 2
 _lib.omnipq_sa_rowgemm_workspace_floats.restype = ctypes.c_longlong
 _lib.omnipq_sa_rowgemm_workspace_floats.argtypes = [ctypes.c_longlong, ctypes.c_int]
@@ -277,6 +279,35 @@ _lib.omnipq_sa_rowgemm_workspace_floats.argtypes = [ctypes.c_longlong, ctypes.c_
 # it removes (gather, pool / BatchNorm backward apply) are paid back by two operand streams per generated gradient and by
 # load / compute / store phases that do not overlap inside a persistent workgroup -- so it is opt-in.
 CHAIN = os.environ.get("OMNIPQ_SA_CHAIN", "0") == "1"
+
+
+# Last layer of a large, narrow stage (sa1: 1 M positions, 128 -> 256 channels -- HBM bound) without its output: the forward
+# GEMM records statistics and ball extrema and stores nothing; the backward pass runs on the algebraic form of
+# include/omnipq_chain.h (omnipq_sa_pool_alg_*): neither Y_L nor dY_L ever exists (2.7 GB less HBM traffic per step on sa1).
+# Opt-in (OMNIPQ_SA_ALGEBRA=1): numerically equivalent (tests/test_gpu_chain.py; gradients within 7e-3 of the stored
+# dataflow on the benchmark stage) but not faster yet -- measured round 2 on sa1: forward 288 us (was 310), weight
+# gradient 335 (185), data gradient 358 (216 + 203 for the pool backward it absorbs), 125 us of small kernels: the
+# per-element epilogue work (statistics, ball extrema) and the generated operands are VALU bound where the stored
+# dataflow was HBM bound.
+ALGEBRA = os.environ.get("OMNIPQ_SA_ALGEBRA", "0") == "1"
+ALGEBRA_MIN_ROWS = int(os.environ.get("OMNIPQ_SA_ALGEBRA_MIN_ROWS", str(1 << 19)))
+
+
+def _rowgemm_ks(K):
+    steps = K // 32
+    for ks in (10, 9, 8, 4, 1):
+        if steps % ks == 0:
+            return ks
+    return 1
+
+
+def algebra_ok(P, S, c_last, c_below):
+    """May the last layer (c_below -> c_last channels over P grouped positions, balls of S rows) take the algebraic path?
+    Worth it where the layer is bandwidth bound (many rows, few channels); the extended products need split = c_last to be
+    a multiple of the row-tile GEMM's K chunk and of the weight-gradient GEMM's 128-wide tiles."""
+    if not ALGEBRA or P < ALGEBRA_MIN_ROWS or 64 % S or c_last > 512 or c_below > 256 or c_last % 128 or c_below % 8:
+        return False
+    return c_last % (32 * _rowgemm_ks(c_last + c_below)) == 0 and c_last + c_below <= 1024
 
 
 def _chain_kpad(cin):
@@ -862,7 +893,21 @@ class FusedSAStage(torch.autograd.Function):
                     ext16 = torch.empty((2, B * M, cout), device=dev, dtype=torch.bfloat16)
                     ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
                     pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
-                if l > 0 and X is None:
+                alg = l == L - 1 and l > 0 and X is None and pool is not None and layers[l - 1].fin is not None and \
+                    algebra_ok(P, S, cout, K)
+                if alg:
+                    # statistics and ball extrema only: the layer's output is never stored (see ALGEBRA above)
+                    prev = layers[l - 1]
+                    fsums, count, pg, pb, peps, pmom, prm, prv, _ = prev.fin
+                    prev.fin = None
+                    _rowgemm(prev.Y, P=P, N=cout, K=K, a_kind=A_AFFINE, epi_kind=E_STORE_STATS, A0=prev.Y, lda=prev.C,
+                             fin_sums=fsums, fin_count=count, gamma=pg, beta=pb, eps=peps, momentum=pmom,
+                             running_mean=prm, running_var=prv, a_out=prev.a, b_out=prev.b, mean_out=prev.mean,
+                             invstd_out=prev.invstd, B=lay.Wp, ldb=K, ldc=cout, sums=sums, pool_s=S, ymax=pool[1],
+                             ymin=pool[2], amax=pool[3], amin=pool[4])
+                    lay.Y = None
+                    ctx.alg_w = W2 if W2.dtype == torch.float32 and W2.is_contiguous() else W2.float().contiguous()
+                elif l > 0 and X is None:
                     # the layer below never stored relu(bn(Y)): this GEMM rebuilds it while staging its operand
                     lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums, pool=pool)
                 else:
@@ -884,7 +929,7 @@ class FusedSAStage(torch.autograd.Function):
                           _p(rm), _p(rv), _p(None), _p(lay.Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean),
                           _p(lay.invstd))
                 else:
-                    _call(_lib.omnipq_bn_finalize, lay.Y, cout, ctypes.c_double(float(P) * world), _p(sums),
+                    _call(_lib.omnipq_bn_finalize, sums, cout, ctypes.c_double(float(P) * world), _p(sums),
                           _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
                           _p(rm), _p(rv), _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(None))
                 bump(nbt)
@@ -914,7 +959,7 @@ class FusedSAStage(torch.autograd.Function):
         ysel = None
         if training and pool is not None:
             ysel = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
-            _call(_lib.omnipq_sa_pool_select, last.Y, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
+            _call(_lib.omnipq_sa_pool_select, out_pm, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
                   _p(pool[3]), _p(pool[4]), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
         else:
             _call(_lib.omnipq_sa_pool, last.Y, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32),
@@ -1135,22 +1180,56 @@ class FusedSAStage(torch.autograd.Function):
         grads = [None] * (3 * L)
 
         last = layers[-1]
-        sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
-        if ctx.ysel is not None:
+        top = L - 1                  # first layer the generic loop below handles
+        if last.Y is None:
+            # ---- algebraic last layer (see ALGEBRA): dW_L and dz_{L-1} from (per-ball gradient, arg-max, X_{L-1}) --------
+            prev = layers[L - 2]
+            C, Cin = last.C, prev.C
+            sums = torch.empty((2, C), device=dev, dtype=torch.float64)
+            gz = torch.empty((B * M, C), device=dev, dtype=torch.bfloat16)
+            _call(_lib.omnipq_sa_pool_bwd_stats_gz, g_out, ctypes.c_longlong(B * M), C, _p(ctx.ysel), _p(last.mean),
+                  _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), _p(gz))
+            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, C)      # local totals, before the all-reduce
+            _allreduce_(sums, world)
+            inv_count = ctypes.c_double(1.0 / (float(P) * world))
+            bext = torch.empty((Cin, C + Cin), device=dev, dtype=torch.bfloat16)
+            crow = torch.empty((Cin,), device=dev, dtype=torch.float32)
+            _call(_lib.omnipq_sa_pool_alg_consts, bext, C, Cin, _p(ctx.alg_w), _p(last.a), _p(last.mean), _p(last.invstd),
+                  _p(sums), inv_count, _p(bext), _p(crow))
+            cs = zeros_f32(Cin, dev)
+            ext = _tn_gen(prev.Y, C + Cin, Cin, P, a_kind=A_POOLX, b_kind=A_AFFINE, A0=gz, arg=ctx.arg, lda=C, s=S, split=C,
+                          B0=prev.Y, ldb=Cin, ba=prev.a, bb=prev.b, bcolsum=cs)
+            dW = torch.empty((C, Cin, 1, 1), device=dev, dtype=torch.float32)
+            _call(_lib.omnipq_sa_pool_alg_dw, dW, C, Cin, _p(ctx.alg_w), _p(last.a), _p(last.mean), _p(last.invstd), _p(sums),
+                  inv_count, _p(ext), _p(cs), _p(dW))
+            grads[3 * (L - 1)] = dW
+            nsums = zeros_f64(3, Cin, dev)
+            dY = torch.empty((P, Cin), device=dev, dtype=torch.bfloat16)
+            _rowgemm(prev.Y, P=P, N=Cin, K=C + Cin, a_kind=A_POOLX, epi_kind=E_STORE_BNBWD, A0=gz, A1=prev.Y, arg=ctx.arg,
+                     lda=C, lda1=Cin, s=S, split=C, a_in=prev.a, b_in=prev.b, crow=crow, B=bext, ldb=C + Cin, C=dY, ldc=Cin,
+                     sums=nsums, below_Y=prev.Y, below_a=prev.a, below_b=prev.b, below_mean=prev.mean,
+                     below_invstd=prev.invstd)
+            grads[3 * (L - 2) + 1], grads[3 * (L - 2) + 2] = bn_backward_apply(dY, prev, P, Cin, total, nsums, world)
+            ctx.alg_w = None
+            top = L - 2
+        elif ctx.ysel is not None:
+            sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
             _call(_lib.omnipq_sa_pool_bwd_stats_sel, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
                   _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums))
         else:
+            sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
             _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
                   _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
-        # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
-        grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
-        _allreduce_(sums[:2], world)
-        dY = torch.empty_like(last.Y)
-        _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
-              _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
+        if last.Y is not None:
+            # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
+            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
+            _allreduce_(sums[:2], world)
+            dY = torch.empty_like(last.Y)
+            _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
+                  _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
 
         d_feat = d_xyz = d_cen = None
-        for l in range(L - 1, -1, -1):
+        for l in range(top, -1, -1):
             lay = layers[l]
             if l > 0 and layers[l - 1].X is None:
                 dWp = _gemm_tn(dY, layers[l - 1].Y, lay.C, lay.K, P, below=layers[l - 1])

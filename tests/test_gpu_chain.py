@@ -142,6 +142,16 @@ def test_rowgemm_affine_stats_pool(P, N, K, S):
     first_hi = (balls == hi[:, None, :]).float().argmax(1)
     first_lo = (balls == lo[:, None, :]).float().argmax(1)
     assert torch.equal(amax.long(), first_hi) and torch.equal(amin.long(), first_lo)
+    # the same pass without a destination (C = NULL): statistics and extrema only, folded in registers where the
+    # library can (one pass over N, balls of 16 / 32 / 64 rows) -- the same extrema, the same sums
+    sums2 = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+    e16 = torch.full((2, P // S, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    e8 = torch.full((2, P // S, N), 255, device=dev(), dtype=torch.uint8)
+    rowgemm(P=P, N=N, K=K, a_kind=A_AFFINE, epi_kind=E_STORE_STATS, A0=Yin, lda=K, a_in=outs[0], b_in=outs[1], B=W, ldb=K,
+            ldc=N, sums=sums2, pool_s=S, ymax=e16[0], ymin=e16[1], amax=e8[0], amin=e8[1])
+    assert torch.equal(e16[0], ymax) and torch.equal(e16[1], ymin)
+    assert torch.equal(e8[0], amax) and torch.equal(e8[1], amin)
+    assert torch.allclose(sums2, sums, rtol=1e-5, atol=1e-3 * float(cf.abs().max()))
 
 
 @pytest.mark.parametrize("B,n,m,S,cin,N", [(2, 500, 64, 32, 0, 128), (2, 300, 40, 16, 256, 256), (1, 1000, 24, 64, 8, 128),
@@ -266,3 +276,52 @@ def test_tn_gen_dy_and_plain(P, M, N):
     assert rel_l2(dW, want) < 2e-3
     plain = tn_gen(M, N, P, a_kind=A_PLAIN, b_kind=A_PLAIN, A0=dY, lda=M, B0=X, ldb=N)
     assert rel_l2(plain, want) < 1e-5
+
+
+@pytest.mark.parametrize("BM,S,C,Cin", [(16, 64, 256, 128), (64, 32, 512, 256), (40, 16, 256, 128)])
+def test_pool_algebra_backward_without_the_last_layers_output(BM, S, C, Cin):
+    """Max-pool + BatchNorm backward of the last layer from (per-ball gradient, arg-max, X) alone -- the extended
+    products of omnipq_chain.h (POOLX) against the explicit chain dY = a (dz - m1 - yhat m2), dX = dY W, dW = dY^T X with
+    Y = X W^T materialised in f32."""
+    from sa_fused import A_POOLX
+    gen = torch.Generator().manual_seed(BM * 7 + C)
+    P = BM * S
+    Yb, ab, _, _ = _bn_case(P, Cin, gen)                       # layer below: pre-BN output and scale
+    bb = (torch.randn(Cin, generator=gen) * 0.5).to(dev())
+    X = bf(torch.relu(ab * Yb.float() + bb))
+    W = (torch.randn((C, Cin), generator=gen) / Cin ** 0.5).to(dev())
+    Y = X.float() @ bf(W).float().t()
+    mu = Y.double().mean(0).float()
+    inv = (1.0 / torch.sqrt(Y.double().var(0, unbiased=False) + 1e-5)).float()
+    a = ((torch.rand(C, generator=gen) * 2 - 0.5).to(dev()) * inv)
+    arg = torch.randint(0, S, (BM, C), generator=gen, dtype=torch.uint8).to(dev())
+    gz = bf(torch.randn((BM, C), generator=gen) * (torch.rand((BM, C), generator=gen) > 0.3)).to(dev())
+    dz = torch.zeros((BM, S, C), device=dev())
+    dz.scatter_(1, arg.long()[:, None, :], gz.float()[:, None, :])
+    dz = dz.view(P, C)
+    yhat = (Y.double() - mu.double()) * inv.double()
+    sums = torch.stack([dz.double().sum(0), (dz.double() * yhat).sum(0)]).contiguous()
+    m1, m2 = (sums[0] / P).float(), (sums[1] / P).float()
+    dY = a * (dz - m1 - yhat.float() * m2)
+    dX_ref = dY @ bf(W).float()
+    dW_ref = dY.t() @ X.float()
+
+    lib = capi.lib()
+    Bext = torch.full((Cin, C + Cin), float("nan"), device=dev(), dtype=torch.bfloat16)
+    crow = torch.empty(Cin, device=dev())
+    capi.ok("omnipq_sa_pool_alg_consts", C, Cin, capi.P(W), capi.P(a), capi.P(mu), capi.P(inv), capi.P(sums),
+            ctypes.c_double(1.0 / P), capi.P(Bext), capi.P(crow))
+    dX = torch.full((P, Cin), float("nan"), device=dev(), dtype=torch.bfloat16)
+    rowgemm(P=P, N=Cin, K=C + Cin, a_kind=A_POOLX, epi_kind=E_STORE, A0=gz, A1=Yb, arg=arg, lda=C, lda1=Cin, s=S,
+            split=C, a_in=ab, b_in=bb, crow=crow, B=Bext, ldb=C + Cin, C=dX, ldc=Cin)
+    assert rel_l2(dX, dX_ref) < 1.5e-2, rel_l2(dX, dX_ref)
+    cs = torch.zeros(Cin, device=dev())
+    ext = tn_gen(C + Cin, Cin, P, a_kind=A_POOLX, b_kind=A_AFFINE, A0=gz, arg=arg, lda=C, s=S, split=C, B0=Yb, ldb=Cin,
+                 ba=ab, bb=bb, bcolsum=cs)
+    assert rel_l2(ext[:C], dz.t() @ X.float()) < 2e-3
+    assert rel_l2(ext[C:], X.float().t() @ X.float()) < 2e-3
+    assert rel_l2(cs, X.float().sum(0)) < 1e-4
+    dW = torch.full((C, Cin), float("nan"), device=dev())
+    capi.ok("omnipq_sa_pool_alg_dw", C, Cin, capi.P(W), capi.P(a), capi.P(mu), capi.P(inv), capi.P(sums),
+            ctypes.c_double(1.0 / P), capi.P(ext), capi.P(cs), capi.P(dW))
+    assert rel_l2(dW, dW_ref) < 1.5e-2, rel_l2(dW, dW_ref)

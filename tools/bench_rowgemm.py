@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Times omnipq_sa_rowgemm alone on the shapes of the benchmark configuration (event-timed, L2-cold rotation of
+"""(arguments: groups of P N K kind epi pool_s nostore)  Times omnipq_sa_rowgemm alone on the shapes of the benchmark configuration (event-timed, L2-cold rotation of
 buffers is NOT attempted: operands are hundreds of MB).  OMNIPQ_ROWGEMM_DEBUG=<bits> ablates parts of the kernel.
 
     python tools/bench_rowgemm.py [P N K kind epi]...
@@ -16,7 +16,7 @@ import torch  # noqa: E402
 import sa_fused as sf  # noqa: E402
 
 
-def run(P, N, K, kind, epi, reps=5):
+def run(P, N, K, kind, epi, pool_s=0, nostore=0, reps=5):
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
     A = torch.randn((P, K), device=dev, generator=g).to(torch.bfloat16)
@@ -27,6 +27,12 @@ def run(P, N, K, kind, epi, reps=5):
     sums = torch.zeros((2, N), device=dev, dtype=torch.float64)
     vec = torch.rand(max(K, N), device=dev) + 0.5
     kw = dict(P=P, N=N, K=K, a_kind=kind, epi_kind=epi, A0=A, lda=K, B_packed=Bp, C=C, ldc=N, sums=sums)
+    if nostore:
+        kw.pop("C")
+    if pool_s:
+        e16 = torch.empty((2, P // pool_s, N), device=dev, dtype=torch.bfloat16)
+        e8 = torch.empty((2, P // pool_s, N), device=dev, dtype=torch.uint8)
+        kw.update(pool_s=pool_s, ymax=e16[0], ymin=e16[1], amax=e8[0], amin=e8[1])
     if kind == sf.A_AFFINE:
         kw.update(a_in=vec, b_in=vec)
     if kind in (sf.A_DY, sf.A_DY3):
@@ -50,7 +56,7 @@ def run(P, N, K, kind, epi, reps=5):
     us = e0.elapsed_time(e1) / reps * 1e3
     flops = 2.0 * P * N * K
     byts = 2.0 * P * (K * (2 if kind in (sf.A_DY, sf.A_DY3) else 1) + N * (2 if epi == sf.E_STORE_BNBWD else 1))
-    print(f"P={P} N={N} K={K} kind={kind} epi={epi}: {us:8.1f} us  {flops / us / 1e6:7.1f} TF  {byts / us / 1e6:6.2f} TB/s")
+    print(f"P={P} N={N} K={K} kind={kind} epi={epi} pool={pool_s} nostore={nostore}: {us:8.1f} us  {flops / us / 1e6:7.1f} TF  {byts / us / 1e6:6.2f} TB/s")
 
 
 if __name__ == "__main__":
@@ -59,6 +65,6 @@ if __name__ == "__main__":
              (1048576, 128, 128, sf.A_DY, sf.E_STORE_BNBWD), (262144, 256, 256, sf.A_PLAIN, sf.E_STORE)]
     if len(sys.argv) > 1:
         v = [int(x) for x in sys.argv[1:]]
-        cases = [tuple(v[i:i + 5]) for i in range(0, len(v), 5)]
+        cases = [tuple(v[i:i + 7]) for i in range(0, len(v), 7)]
     for c in cases:
         run(*c)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--extra", type=int, default=0)
+    ap.add_argument("--flag", default="CHAIN", help="sa_fused switch to A/B: CHAIN or ALGEBRA")
     args = ap.parse_args()
     import pointnet2_utils
     import sa_fused
@@ -70,7 +71,7 @@ def main():
 
     res = {}
     for mode in (False, True):
-        sa_fused.CHAIN = mode
+        setattr(sa_fused, args.flag, mode)
         # running statistics must start equal in both modes
         torch.manual_seed(1)
         for m in net.modules():
@@ -98,7 +99,7 @@ def main():
 
     ext = pointnet2_utils._ext
     for mode in (False, True):
-        sa_fused.CHAIN = mode
+        setattr(sa_fused, args.flag, mode)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -112,7 +113,7 @@ def main():
         for name, _, e0, e1 in sink:
             tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
         sa_ms = sum(v for k, v in tot.items() if k.endswith("@sa")) / args.steps
-        print(f"CHAIN={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
+        print(f"{args.flag}={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
         for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]:
             print(f"    {k:50s} {v / args.steps * 1e3:9.1f} us/step")
 
