@@ -1460,7 +1460,7 @@ extern "C" int omnipq_sa_pool_bwd_stats_gz(long long BM, int C, const void *ysel
     if (per_lane > 32) per_lane = 32;
     blocks = (BM + rpb * per_lane - 1) / (rpb * per_lane);
   }
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 128) blocks = 128;            // every block ends with 2C contended f64 atomics (see omnipq_sa_pool_bwd_stats_sel)
   if (hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), (hipStream_t)stream) != hipSuccess) return OMNIPQ_EINVAL;
   pool_bwd_stats_gz_kernel<<<(int)blocks, 256, (size_t)2 * rpb * C * sizeof(float), (hipStream_t)stream>>>(
       BM, C, rpb, (const bf16_t *)ysel, mean, invstd, g_out, (const bf16_t *)out_pm, sums, (bf16_t *)gz);

@@ -807,8 +807,27 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
     if (coord ? dxyz == nullptr : dfeat == nullptr) continue;
     const int beg = offsets[(size_t)b * (n + 1) + k], end = offsets[(size_t)b * (n + 1) + k + 1];
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = beg; t < end; ++t) {
-      const size_t p = (size_t)b * ms + order[(size_t)b * ms + t];
+    // four bucket entries per trip: index loads first, then the four row loads (one entry at a time the loop is a chain
+    // of two dependent round trips per 16 bytes: 149 us for the 151 MB of sa2)
+    const int *ord = order + (size_t)b * ms;
+    int t = beg;
+    for (; t + 3 < end; t += 4) {
+      int o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = ord[t + u];
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(dX + ((size_t)b * ms + o[u]) * kpad + c8 * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float d[8];
+        unpack8(v[u], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += d[e];
+      }
+    }
+    for (; t < end; ++t) {
+      const size_t p = (size_t)b * ms + ord[t];
       float d[8];
       unpack8(*reinterpret_cast<const uint4 *>(dX + p * kpad + c8 * 8), d);
 #pragma unroll
@@ -974,7 +993,11 @@ extern "C" int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *yse
   if (!ysel || !mean || !invstd || !g_out || !out_pm || !sums) return OMNIPQ_EINVAL;
   OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (BM == 0) return OMNIPQ_OK;
-  pool_bwd_stats_sel_kernel<<<stats_grid(BM, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+  // few blocks: each ends with 2C f64 atomics on the same 2C addresses, and with 512 blocks those 262 144 contended
+  // atomics cost more (27 us) than streaming the 32 MB of per-ball data (8 us)
+  int blocks = stats_grid(BM, C);
+  if (blocks > 128) blocks = 128;
+  pool_bwd_stats_sel_kernel<<<blocks, 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
       BM, C, (const bf16_t *)ysel, mean, invstd, g_out, (const bf16_t *)out_pm, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
