@@ -7,7 +7,7 @@
 
 Definitions (MI355X_MICROARCH.md, rocprofv3 -L `MfmaUtil`): SQ_VALU_MFMA_BUSY_CYCLES counts, summed over the SIMDs, the
 cycles a SIMD's matrix pipe is busy (32 per v_mfma_f32_32x32x16_bf16); GRBM_GUI_ACTIVE the cycles the GPU was active
-during the dispatch.  MFMA-busy = BUSY_CYCLES / (GUI_ACTIVE x 1024 SIMDs): the fraction of the chip's matrix-pipe
+during the dispatch (summed over the 8 XCDs in the CSV).  MFMA-busy = BUSY_CYCLES / (GUI_ACTIVE / 8 x 1024 SIMDs): the fraction of the chip's matrix-pipe
 cycles the kernel used while it ran.  SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 = bf16 MFMA FLOPs executed; divided by the
 dense peak (2.5 PFLOP/s) and the dispatch's duration it gives the same fraction by another route.
 Counter passes run the chip at a lower clock than un-profiled runs (same guide): fractions, not absolute times.
@@ -20,6 +20,10 @@ import os
 import sys
 
 SIMDS = 256 * 4
+XCDS = 8      # the CSV holds ONE value per dispatch and counter: the sum over the counter's instances.  GRBM_GUI_ACTIVE has
+              # one instance per XCD (8), each counting the whole dispatch (checked against End - Start timestamps: a
+              # 27.5 us dispatch reports 589 596 = 8 x 73.7 k cycles), so the active-cycle figure is that sum / 8
+              # (rocprofv3's own MfmaUtil uses reduce(GRBM_GUI_ACTIVE, max) for the same reason)
 
 
 def main():
@@ -39,7 +43,7 @@ def main():
         busy, act, mops = busy[skip:], act[skip:], mops[skip:]
         if not act:
             continue
-        b, a, m = sum(busy), sum(act), sum(mops)
+        b, a, m = sum(busy), sum(act) / XCDS, sum(mops)
         tot_busy, tot_active, tot_mops = tot_busy + b, tot_active + a, tot_mops + m
         rows.append({"kernel": k, "launches_per_step": len(act) / steps, "mfma_busy_cycles_per_step": b / steps,
                      "gui_active_cycles_per_step": a / steps, "bf16_mfma_flops_per_step": m * 512 / steps,
@@ -49,7 +53,7 @@ def main():
     json.dump({"mfma_busy_frac_over_all_dispatches": overall, "bf16_mfma_flops_per_step": tot_mops * 512 / steps,
                "kernels": rows}, open(out_json, "w"), indent=1)
     with open(out_md, "w") as fh:
-        fh.write(f"MFMA-busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x {SIMDS} SIMDs)) over all dispatches of a step: "
+        fh.write(f"MFMA-busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x {SIMDS} SIMDs)) over all dispatches of a step: "
                  f"{100 * overall:.2f} %; bf16 MFMA work {tot_mops * 512 / steps / 1e9:.1f} GFLOP per step\n\n")
         fh.write("| kernel | launches/step | MFMA-busy % while it runs | share of the step's MFMA cycles % | bf16 GFLOP/step |\n"
                  "|---|---|---|---|---|\n")
