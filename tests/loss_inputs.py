@@ -1,0 +1,145 @@
+"""Seeded inputs of the supervised loss (`get_loss`): an `end_points` dictionary with the keys and shapes
+the reference's training step hands to its criterion (train.py:497-503: the model's outputs for the labelled half of the
+batch merged with the labels of scannet_detection_dataset.py:256-304).
+
+Used by tests/golden/make_golden_get_loss.py (which runs the REFERENCE on it) and by the tests (which run the oracle and
+the HIP path on the very same arrays): everything comes from numpy's frozen `RandomState` streams, so the fixture only
+has to hold the expected outputs.
+
+The scene is built so that every branch of the loss is exercised: proposals inside the NEAR radius of a ground-truth
+centre, between NEAR and FAR (masked out), beyond FAR, nearest to a padded (all-zero) ground-truth slot; doors / windows /
+pictures / curtains among the assigned classes; wall quads with boxes poking through them (a positive physical-constraint
+loss and a non-zero collision count).
+"""
+import numpy as np
+
+NUM_CLASS = 18
+NUM_HEADING_BIN = 1
+NUM_SIZE_CLUSTER = 18
+MAX_NUM_OBJ = 64           # scannet_detection_dataset.py:29
+MAX_NUM_QUAD = 32          # scannet_detection_dataset.py:30
+
+# Class mean box sizes: NOT the dataset's table (that file belongs to the reference) -- a synthetic one of the same shape
+# and dtype (float64, as np.load returns it there: model_util_scannet.py:30), sizes between 0.3 and 2 m.
+MEAN_SIZE_ARR = (0.3 + 1.7 * np.random.RandomState(77).rand(NUM_SIZE_CLUSTER, 3)).astype(np.float64)
+
+PREDICTION_KEYS = ("objectness_scores", "center", "heading_scores", "heading_residuals_normalized", "size_scores",
+                   "size_residuals_normalized", "sem_cls_scores", "quad_scores", "quad_center", "normal_vector",
+                   "quad_size")
+
+
+class Config:
+    """The four attributes of ScannetDatasetConfig the loss reads (model_util_scannet.py:14-35)."""
+    num_class = NUM_CLASS
+    num_heading_bin = NUM_HEADING_BIN
+    num_size_cluster = NUM_SIZE_CLUSTER
+    mean_size_arr = MEAN_SIZE_ARR
+
+
+def prefixes(num_layer=6):
+    return ["proposal_", "last_"] + [f"{i}head_" for i in range(num_layer - 1)]
+
+
+def make(seed, B=2, K=256, KQ=256, num_seed=1024, N=4096, num_layer=6):
+    """-> (labels: dict of numpy arrays, predictions: dict of float32 numpy arrays -- the differentiable leaves)."""
+    rs = np.random.RandomState(seed)
+    f32 = np.float32
+    room = np.array([6.0, 5.0, 2.6])
+    lab, pred = {}, {}
+
+    # ---- ground-truth boxes: n_b real ones, the rest zero padding
+    n_box = rs.randint(8, 24, size=B)
+    center = np.zeros((B, MAX_NUM_OBJ, 3))
+    size_cls = np.zeros((B, MAX_NUM_OBJ), dtype=np.int64)
+    size_res = np.zeros((B, MAX_NUM_OBJ, 3))
+    sem_cls = np.zeros((B, MAX_NUM_OBJ), dtype=np.int64)
+    for b in range(B):
+        n = n_box[b]
+        c = rs.rand(n, 3) * room
+        hug = rs.rand(n) < 0.5                              # half of the boxes hug a wall
+        wall = rs.randint(0, 4, size=n)
+        off = 0.05 + 0.25 * rs.rand(n)
+        c[:, 0] = np.where(hug & (wall == 0), off, c[:, 0])
+        c[:, 0] = np.where(hug & (wall == 1), room[0] - off, c[:, 0])
+        c[:, 1] = np.where(hug & (wall == 2), off, c[:, 1])
+        c[:, 1] = np.where(hug & (wall == 3), room[1] - off, c[:, 1])
+        center[b, :n] = c
+        cls = rs.randint(0, NUM_CLASS, size=n)
+        cls[:4] = [5, 6, 8, 11][: min(4, n)]                # door, window, picture, curtain: excluded from the pc loss
+        sem_cls[b, :n] = cls
+        size_cls[b, :n] = cls
+        size_res[b, :n] = 0.2 * rs.randn(n, 3) * MEAN_SIZE_ARR[cls]
+    lab["center_label"] = center.astype(f32)
+    lab["heading_class_label"] = np.zeros((B, MAX_NUM_OBJ), dtype=np.int64)
+    lab["heading_residual_label"] = np.zeros((B, MAX_NUM_OBJ), dtype=f32)
+    lab["size_class_label"] = size_cls
+    lab["size_residual_label"] = size_res.astype(f32)
+    lab["sem_cls_label"] = sem_cls
+    lab["num_gt_boxes"] = n_box.reshape(B, 1).astype(np.int64)
+
+    # ---- ground-truth quads: the four walls, a few partitions, zero padding
+    n_quad = rs.randint(5, 9, size=B)
+    q_center = np.zeros((B, MAX_NUM_QUAD, 3))
+    q_normal = np.zeros((B, MAX_NUM_QUAD, 3))
+    q_size = np.zeros((B, MAX_NUM_QUAD, 2))
+    for b in range(B):
+        walls_c = [[0, room[1] / 2, 1.3], [room[0], room[1] / 2, 1.3], [room[0] / 2, 0, 1.3], [room[0] / 2, room[1], 1.3]]
+        walls_n = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0]]
+        walls_s = [[room[1], 2.6], [room[1], 2.6], [room[0], 2.6], [room[0], 2.6]]
+        for k in range(4, n_quad[b]):
+            ang = rs.rand() * 2 * np.pi
+            walls_c.append([1 + 4 * rs.rand(), 1 + 3 * rs.rand(), 1.3])
+            walls_n.append([np.cos(ang), np.sin(ang), 0.0])
+            walls_s.append([1 + rs.rand(), 2.6])
+        q_center[b, : n_quad[b]] = walls_c
+        q_normal[b, : n_quad[b]] = walls_n
+        q_size[b, : n_quad[b]] = walls_s
+    lab["gt_quad_centers"] = q_center.astype(f32)
+    lab["gt_normal_vectors"] = q_normal.astype(f32)
+    lab["gt_quad_sizes"] = q_size.astype(f32)
+    lab["num_gt_quads"] = n_quad.reshape(B, 1).astype(np.int64)
+
+    # ---- votes
+    lab["vote_label"] = (0.4 * rs.randn(B, N, 9)).astype(f32)
+    lab["vote_label_mask"] = (rs.rand(B, N) < 0.4).astype(np.int64)
+    lab["seed_inds"] = np.stack([rs.permutation(N)[:num_seed] for _ in range(B)]).astype(np.int32)
+    lab["seed_xyz"] = (rs.rand(B, num_seed, 3) * room).astype(f32)
+    pred["vote_xyz"] = (lab["seed_xyz"] + 0.3 * rs.randn(B, num_seed, 3)).astype(f32)
+
+    # ---- cluster centres the assignment is made from (model outputs, not differentiated through by the loss)
+    def around(gt, n_real, count, spread_near, spread_mid):
+        out = rs.rand(B, count, 3) * room
+        for b in range(B):
+            pick = rs.randint(0, n_real[b], size=count)
+            kind = rs.rand(count)
+            near = gt[b, pick] + spread_near * rs.randn(count, 3)
+            mid = gt[b, pick] + spread_mid * rs.randn(count, 3)
+            out[b] = np.where((kind < 0.45)[:, None], near, np.where((kind < 0.7)[:, None], mid, out[b]))
+            out[b, -6:] = 0.05 * rs.randn(6, 3)              # nearest to the zero padding
+        return out.astype(f32)
+
+    lab["aggregated_vote_xyz"] = around(center, n_box, K, 0.08, 0.3)
+    lab["aggregated_sample_xyz"] = around(q_center, n_quad, KQ, 0.08, 0.3)
+
+    # ---- head outputs for the seven prefixes
+    d_obj = ((lab["aggregated_vote_xyz"][:, :, None, :] - lab["center_label"][:, None, :, :]) ** 2).sum(-1)
+    near_obj = d_obj.argmin(-1)
+    d_quad = ((lab["aggregated_sample_xyz"][:, :, None, :] - lab["gt_quad_centers"][:, None, :, :]) ** 2).sum(-1)
+    near_quad = d_quad.argmin(-1)
+    bi = np.arange(B)[:, None]
+    for p in prefixes(num_layer):
+        pred[p + "objectness_scores"] = rs.randn(B, K, 2).astype(f32)
+        pred[p + "center"] = (center[bi, near_obj] + 0.15 * rs.randn(B, K, 3)).astype(f32)
+        pred[p + "heading_scores"] = rs.randn(B, K, NUM_HEADING_BIN).astype(f32)
+        pred[p + "heading_residuals_normalized"] = (0.3 * rs.randn(B, K, NUM_HEADING_BIN)).astype(f32)
+        sc = rs.randn(B, K, NUM_SIZE_CLUSTER)
+        sc[bi, np.arange(K)[None, :], size_cls[bi, near_obj]] += 2.0
+        pred[p + "size_scores"] = sc.astype(f32)
+        pred[p + "size_residuals_normalized"] = (0.3 * rs.randn(B, K, NUM_SIZE_CLUSTER, 3)).astype(f32)
+        pred[p + "sem_cls_scores"] = rs.randn(B, K, NUM_CLASS).astype(f32)
+        pred[p + "quad_scores"] = rs.randn(B, KQ, 2).astype(f32)
+        pred[p + "quad_center"] = (q_center[bi, near_quad] + 0.1 * rs.randn(B, KQ, 3)).astype(f32)
+        nv = q_normal[bi, near_quad] + 0.1 * rs.randn(B, KQ, 3)
+        pred[p + "normal_vector"] = (nv / np.maximum(np.linalg.norm(nv, axis=-1, keepdims=True), 0.2)).astype(f32)
+        pred[p + "quad_size"] = (q_size[bi, near_quad] + 0.1 * rs.randn(B, KQ, 2)).astype(f32)
+    return lab, pred
