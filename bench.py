@@ -69,7 +69,19 @@ def parse():
                     help="SURVEY 8f-1: time the reference's mean-teacher step structure instead of the headline "
                          "metric -- student fwd+bwd, teacher (EMA model, train mode, no grad) forward on its own "
                          "batch, EMA update of all parameters (train.py:480-491,576)")
+    ap.add_argument("--loss", default="means", choices=["means", "supervised"],
+                    help="means (headline, SURVEY 8d): sum of the means of every float output; supervised (SURVEY 8f-2): "
+                         "the reference's get_loss (models/loss_helper_pq.py:412-486, physical-constraint term included) on "
+                         "synthetic labels in the data loader's format, computed by the HIP row kernels")
     return ap.parse_args()
+
+
+class LossConfig:
+    """The attributes of ScannetDatasetConfig that get_loss reads (scannet/model_util_scannet.py:14-35)."""
+    num_class = 18
+    num_heading_bin = 1
+    num_size_cluster = 18
+    mean_size_arr = None
 
 
 def mean_size_arr():
@@ -414,7 +426,7 @@ EMA_DECAY, EMA_STEP = 0.999, 100_000          # steady state of train.py:437: al
 
 
 def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_graph=False, teacher=None,
-              teacher_pool=None, ddp=False):
+              teacher_pool=None, ddp=False, labels_pool=None):
     """-> (step(i) -> loss tensor, launch mode string).  Eager: forward, loss, prefetch of the next
     batch's sampling, backward.  Graph: the same sequence captured once and replayed -- always for a
     single process; under torch.distributed only when `dist_graph` (the probe passed), with the
@@ -427,6 +439,14 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
     defer = os.environ.get("OMNIPQ_DEFER_WGRADS", "1") != "0" and not ddp
     # eager multi-rank steps without DDP: the same single flat all-reduce as in the captured step
     flat_eager = FlatGradients(net, world) if (distributed and not ddp) else None
+
+    def criterion(ep, labels):
+        if labels is None:
+            return loss_of(ep)
+        import loss_helper_pq
+        gt = dict(ep)                                   # train.py:497-503: outputs + labels of the batch -> criterion
+        gt.update(labels)
+        return loss_helper_pq.get_loss(gt, LossConfig, pc_loss=True)[0]
 
     def backward(loss):
         if defer:
@@ -441,7 +461,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             p.grad = None
         with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             ep = model({"point_clouds": pool[i % len(pool)]})
-            loss = loss_of(ep)
+            loss = criterion(ep, labels_pool[i % len(pool)] if labels_pool is not None else None)
         if teacher is not None:
             teacher_forward(teacher_pool[i % len(teacher_pool)])
         if not args.no_prefetch:
@@ -472,13 +492,14 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         nxt = pool[0].clone()
         cur_t = teacher_pool[0].clone() if teacher is not None else None
         nxt_t = teacher_pool[0].clone() if teacher is not None else None
+        lab_cur = {k: v.clone() for k, v in labels_pool[0].items()} if labels_pool is not None else None
 
         def graph_body():
             for p in net.parameters():
                 p.grad = None
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 ep = model({"point_clouds": cur})
-                loss = loss_of(ep)
+                loss = criterion(ep, lab_cur)
             if teacher is not None:
                 teacher_forward(cur_t)
             if not args.no_prefetch:
@@ -498,6 +519,9 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         def feed(i):
             cur.copy_(nxt)
             nxt.copy_(pool[(i + 1) % len(pool)])
+            if lab_cur is not None:
+                for k, v in labels_pool[i % len(pool)].items():
+                    lab_cur[k].copy_(v)
             if teacher is not None:
                 cur_t.copy_(nxt_t)
                 nxt_t.copy_(teacher_pool[(i + 1) % len(teacher_pool)])
@@ -611,9 +635,14 @@ def main():
         teacher.train()
         teacher_pool = [synth.make_clouds(200 + i, args.batch, args.points, extra_channels=args.extra_channels,
                                           kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
+    labels_pool = None
+    if args.loss == "supervised":
+        LossConfig.mean_size_arr = mean_size_arr()
+        labels_pool = [{k: v.to(dev) for k, v in synth.make_labels(pc, 300 + i, mean_size_arr=mean_size_arr()).items()}
+                       for i, pc in enumerate(pool)]
     try:
         step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, dist_graph, teacher,
-                                      teacher_pool, ddp)
+                                      teacher_pool, ddp, labels_pool)
     except GraphUnavailable:
         dist_graph = False
         for p in net.parameters():
@@ -623,7 +652,7 @@ def main():
             model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
         args.graph = "off"
         step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, False, teacher, teacher_pool,
-                                      ddp)
+                                      ddp, labels_pool)
     use_graph = launch_mode != "eager"
 
     def fence():
@@ -652,7 +681,7 @@ def main():
         # no gradient all-reduce).
         eager_args = argparse.Namespace(**{**vars(args), "graph": "off"})
         eager_step, _ = make_step(net, net, pool, eager_args, amp_dtype, world, teacher=teacher,
-                                  teacher_pool=teacher_pool)
+                                  teacher_pool=teacher_pool, labels_pool=labels_pool)
         eager_step(0)
         fence()
         sink = []
@@ -691,7 +720,9 @@ def main():
             "config": {"workload": f"{workload_name(args)}: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
                                    f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "loss": ("sum of output means (SURVEY 8d)" if args.loss == "means" else
+                                "get_loss, supervised, synthetic labels (SURVEY 8f-2)")},
         }
         if sink:
             table = summarize_ops(sink, timing_steps)

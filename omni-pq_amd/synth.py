@@ -105,3 +105,59 @@ def adversarial_cloud(seed, batch, n):
     k = min(lat.shape[0], n // 4)
     pts[:, 5 * q:5 * q + k] = lat[:k] + 0.5
     return pts.contiguous()
+
+
+def make_labels(point_clouds, seed, max_obj=64, max_quad=32, num_class=18, mean_size_arr=None):
+    """Synthetic supervision for `point_clouds` (B, N, 3+C) in the format of the reference's data loader
+    (scannet/scannet_detection_dataset.py:256-304: MAX_NUM_OBJ = 64 box slots, MAX_NUM_QUAD = 32 quad slots, zero padded):
+    8-23 boxes per scene centred on points of the cloud, point votes towards the nearest box centre within 0.6 m, the four
+    walls of the cloud's xy bounding box plus up to four partitions as quads.  -> dict of CPU tensors with the keys
+    `get_loss` reads (models/loss_helper_pq.py:412-486)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    xyz = point_clouds[..., :3].cpu().numpy().astype(np.float64)
+    B, N, _ = xyz.shape
+    if mean_size_arr is None:
+        mean_size_arr = np.full((num_class, 3), 0.8)
+    out = {"center_label": np.zeros((B, max_obj, 3), np.float32),
+           "heading_class_label": np.zeros((B, max_obj), np.int64),
+           "heading_residual_label": np.zeros((B, max_obj), np.float32),
+           "size_class_label": np.zeros((B, max_obj), np.int64),
+           "size_residual_label": np.zeros((B, max_obj, 3), np.float32),
+           "sem_cls_label": np.zeros((B, max_obj), np.int64),
+           "num_gt_boxes": np.zeros((B, 1), np.int64),
+           "vote_label": np.zeros((B, N, 9), np.float32),
+           "vote_label_mask": np.zeros((B, N), np.int64),
+           "gt_quad_centers": np.zeros((B, max_quad, 3), np.float32),
+           "gt_normal_vectors": np.zeros((B, max_quad, 3), np.float32),
+           "gt_quad_sizes": np.zeros((B, max_quad, 2), np.float32),
+           "num_gt_quads": np.zeros((B, 1), np.int64)}
+    for b in range(B):
+        n = int(rs.randint(8, 24))
+        centres = xyz[b, rs.choice(N, n, replace=False)]
+        cls = rs.randint(0, num_class, size=n)
+        out["center_label"][b, :n] = centres
+        out["size_class_label"][b, :n] = cls
+        out["sem_cls_label"][b, :n] = cls
+        out["size_residual_label"][b, :n] = 0.15 * rs.randn(n, 3) * mean_size_arr[cls]
+        out["num_gt_boxes"][b, 0] = n
+        d = ((xyz[b][:, None, :] - centres[None]) ** 2).sum(-1)
+        near = d.argmin(1)
+        inside = d.min(1) < 0.36
+        vote = (centres[near] - xyz[b]) * inside[:, None]
+        out["vote_label"][b] = np.tile(vote, (1, 3))
+        out["vote_label_mask"][b] = inside
+        lo, hi = xyz[b, :, :2].min(0), xyz[b, :, :2].max(0)
+        mid, ext = (lo + hi) / 2, hi - lo
+        qc = [[lo[0], mid[1], 1.3], [hi[0], mid[1], 1.3], [mid[0], lo[1], 1.3], [mid[0], hi[1], 1.3]]
+        qn = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0]]
+        qs = [[ext[1], 2.6], [ext[1], 2.6], [ext[0], 2.6], [ext[0], 2.6]]
+        for _ in range(int(rs.randint(0, 5))):
+            ang = rs.rand() * 2 * np.pi
+            qc.append([mid[0] + (rs.rand() - 0.5) * ext[0] * 0.6, mid[1] + (rs.rand() - 0.5) * ext[1] * 0.6, 1.3])
+            qn.append([np.cos(ang), np.sin(ang), 0.0])
+            qs.append([1 + rs.rand(), 2.6])
+        m = len(qc)
+        out["gt_quad_centers"][b, :m], out["gt_normal_vectors"][b, :m], out["gt_quad_sizes"][b, :m] = qc, qn, qs
+        out["num_gt_quads"][b, 0] = m
+    return {k: torch.from_numpy(v) for k, v in out.items()}

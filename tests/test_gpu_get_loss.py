@@ -156,3 +156,34 @@ def test_empty_scene_has_zero_terms_and_finite_gradients():
     assert float(ep["collisions"]) == 0.0 and int(ep["last_objectness_label"].sum()) == 0
     for k, leaf in leaves.items():
         assert leaf.grad is None or bool(torch.isfinite(leaf.grad).all()), k
+
+
+def test_model_outputs_go_through_get_loss_like_in_the_training_step():
+    """train.py:489-503 on synthetic data: model forward, the labels of the batch merged into end_points, get_loss,
+    backward.  The loss of the HIP path must equal the oracle's on the same (detached) model outputs, and every parameter
+    must receive a finite gradient."""
+    import bench
+    import synth
+    from oracle import get_loss_oracle
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    net = bench.build_model(0).to(dev).train()
+    pc = synth.make_clouds(700, 2, 8192, kind="room")
+    labels = synth.make_labels(pc, 701, mean_size_arr=bench.mean_size_arr())
+    bench.LossConfig.mean_size_arr = bench.mean_size_arr()
+    ep = net({"point_clouds": pc.to(dev)})
+    gt = dict(ep)
+    gt.update({k: v.to(dev) for k, v in labels.items()})
+    loss, gt = hip().get_loss(gt, bench.LossConfig, pc_loss=True)
+    loss.backward()
+    missing = [n for n, p in net.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+    assert not missing, missing[:5]
+    assert int(gt["last_objectness_label"].sum()) > 0 and int(gt["last_quad_label"].sum()) > 0      # the scene has positives
+    cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in ep.items()}
+    cpu.update(labels)
+    want, cpu = get_loss_oracle.get_loss(cpu, bench.LossConfig, pc_loss=True)
+    assert float(loss) == pytest.approx(float(want), rel=5e-5)
+    for k in ("vote_loss", "objectness_loss", "box_loss", "sem_cls_loss_sum", "quad_score_loss_sum", "quad_loss_sum",
+              "physical_constraints_loss"):
+        assert float(gt[k]) == pytest.approx(float(cpu[k]), rel=5e-5, abs=1e-6), k
+    assert float(gt["collisions"]) == float(cpu["collisions"])
