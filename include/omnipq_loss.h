@@ -36,8 +36,9 @@ int omnipq_nn_distance_grad(int b, int n, int m, int c, int mode, float delta, c
 
 /* Nearest ground truth + NEAR / FAR labelling of every query point (:60-71 objects, :207-217 quads):
  *   d = min_j |query - gt_j|^2 (first j on ties), e = sqrt(d + 1e-6)
- *   label = e < near && j < num_gt[b];  mask = e < near || e > far;  assignment = label ? j : k2 - 1
- * query (b, k, 3) f32, gt (b, k2, 3) f32, num_gt (b) int64 -> label (b, k) int64, mask (b, k) f32, assignment (b, k) int64,
+ *   label = e < near && j < num_gt[b][i];  mask = e < near || e > far;  assignment = label ? j : k2 - 1
+ * query (b, k, 3) f32, gt (b, k2, 3) f32, num_gt (b, k) int64 (the data loader ships the count once per scene for boxes and
+ * once per proposal for quads, scannet_detection_dataset.py:266,301; the caller broadcasts) -> label (b, k) int64, mask (b, k) f32, assignment (b, k) int64,
  * counts float[2] = (sum label, sum mask) (overwritten). */
 int omnipq_loss_assign(int b, int k, int k2, const float *query, const float *gt, const long long *num_gt, float near_thr,
                        float far_thr, long long *label, float *mask, long long *assignment, float *counts, void *stream);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_assign_kernel(int k, int k2
     }
   }
   const float e = sqrtf(best + 1e-6f);
-  const bool lab = in && e < near_thr && (long long)bi < num_gt[b];
+  const bool lab = in && e < near_thr && (long long)bi < num_gt[(size_t)b * k + (in ? i : 0)];
   const bool m = in && (e < near_thr || e > far_thr);
   if (in) {
     label[(size_t)b * k + i] = lab ? 1 : 0;

@@ -128,11 +128,12 @@ def _assign(query, gt, num_gt):
     """-> label (B,K) int64, mask (B,K) f32, assignment (B,K) int64, counts f32[2] = (sum label, sum mask)."""
     q = _f32(query, "query points")
     g = _f32(gt[:, :, 0:3], "ground-truth centres")
-    n = _i64(num_gt, "num_gt").reshape(-1)
     B, K, _ = q.shape
     K2 = g.shape[1]
-    if n.numel() != B or g.shape[0] != B:
+    n = _gpu(num_gt, "num_gt").detach().long()
+    if g.shape[0] != B or n.shape[0] != B or n.numel() not in (B, B * K):
         raise ValueError("loss_helper_pq: batch sizes of the query points, ground truth and counts differ")
+    n = n.reshape(B, -1).expand(B, K).contiguous()        # (B, 1) for boxes, (B, K) for quads in the data loader's format
     label = torch.empty((B, K), device=q.device, dtype=torch.int64)
     assignment = torch.empty((B, K), device=q.device, dtype=torch.int64)
     mask = torch.empty((B, K), device=q.device, dtype=torch.float32)

@@ -131,7 +131,9 @@ def make_labels(point_clouds, seed, max_obj=64, max_quad=32, num_class=18, mean_
            "gt_quad_centers": np.zeros((B, max_quad, 3), np.float32),
            "gt_normal_vectors": np.zeros((B, max_quad, 3), np.float32),
            "gt_quad_sizes": np.zeros((B, max_quad, 2), np.float32),
-           "num_gt_quads": np.zeros((B, 1), np.int64)}
+           "num_gt_quads": np.zeros((B, 256), np.int64),           # the count once per quad proposal (dataset :301-304)
+           "num_total_quads": np.zeros((B, 256), np.int64),
+           "horizontal_quads": np.zeros((B, 4, 4, 3), np.float32)}
     for b in range(B):
         n = int(rs.randint(8, 24))
         centres = xyz[b, rs.choice(N, n, replace=False)]
@@ -159,5 +161,9 @@ def make_labels(point_clouds, seed, max_obj=64, max_quad=32, num_class=18, mean_
             qs.append([1 + rs.rand(), 2.6])
         m = len(qc)
         out["gt_quad_centers"][b, :m], out["gt_normal_vectors"][b, :m], out["gt_quad_sizes"][b, :m] = qc, qn, qs
-        out["num_gt_quads"][b, 0] = m
+        out["num_gt_quads"][b, :] = m
+        out["num_total_quads"][b, :] = m + 2                        # + floor and ceiling
+        ring = np.array([[lo[0], lo[1]], [hi[0], lo[1]], [lo[0], hi[1]], [hi[0], hi[1]]])
+        out["horizontal_quads"][b, 0] = np.concatenate([ring, np.full((4, 1), 2.6)], 1)
+        out["horizontal_quads"][b, 1] = np.concatenate([ring, np.zeros((4, 1))], 1)
     return {k: torch.from_numpy(v) for k, v in out.items()}

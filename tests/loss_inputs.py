@@ -143,3 +143,51 @@ def make(seed, B=2, K=256, KQ=256, num_seed=1024, N=4096, num_layer=6):
         pred[p + "normal_vector"] = (nv / np.maximum(np.linalg.norm(nv, axis=-1, keepdims=True), 0.2)).astype(f32)
         pred[p + "quad_size"] = (q_size[bi, near_quad] + 0.1 * rs.randn(B, KQ, 2)).astype(f32)
     return lab, pred
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Inputs of the evaluation-side consumer (parse_quad_predictions / parse_quad_groundtruths / QUADAPCalculator)
+EVAL_CONFIG = {'remove_empty_box': False, 'use_3d_nms': True, 'nms_iou': 0.25, 'use_old_type_nms': False, 'cls_nms': True,
+               'per_class_proposal': True, 'conf_thresh': 0.0, 'quad_thresh': 0.5}       # train.py:392-395
+
+
+def make_eval(seed, B=2, KQ=256, two_walls_scene=True):
+    """-> dict of numpy arrays: `last_quad_center / last_normal_vector / last_quad_size / last_quad_scores` (B, KQ, .) and the
+    ground truth in the data loader's format (scannet_detection_dataset.py:286-310): gt_quad_centers / gt_normal_vectors
+    (B, 32, 3), gt_quad_sizes (B, 32, 2), num_gt_quads / num_total_quads (B, 256) (the count repeated once per quad
+    proposal), horizontal_quads (B, 4, 4, 3).  Predictions near a ground-truth quad score high, so NMS keeps roughly one
+    per wall; with `two_walls_scene` scene 0 has exactly two confident quads (the case in which QUADAPCalculator also
+    scores the ceiling and floor it deduces from the walls)."""
+    lab, pred = make(seed, B=B, K=8, KQ=KQ, num_seed=8, N=16)
+    rs = np.random.RandomState(seed + 1000)
+    f32 = np.float32
+    out = {k: lab[k] for k in ("gt_quad_centers", "gt_normal_vectors", "gt_quad_sizes")}
+    n_gt = lab["num_gt_quads"][:, 0]
+    out["num_gt_quads"] = np.repeat(n_gt[:, None], 256, axis=1).astype(np.int64)
+    out["num_total_quads"] = np.repeat((n_gt + 2)[:, None], 256, axis=1).astype(np.int64)     # + floor and ceiling
+    center, normal, size = pred["last_quad_center"].copy(), pred["last_normal_vector"].copy(), pred["last_quad_size"].copy()
+    d = ((lab["aggregated_sample_xyz"][:, :, None, :] - lab["gt_quad_centers"][:, None, :, :]) ** 2).sum(-1)
+    near = np.sqrt(d.min(-1)) < 0.3
+    real = d.argmin(-1) < n_gt[:, None]
+    scores = rs.randn(B, KQ, 2).astype(f32)
+    scores[..., 1] += np.where(near & real, 3.0, -2.0).astype(f32)
+    horizontal = np.zeros((B, 4, 4, 3), f32)
+    if two_walls_scene:
+        scores[0] = np.array([3.0, -3.0], f32) + 0.1 * rs.randn(KQ, 2).astype(f32)           # nothing confident ...
+        for j, g in enumerate((0, 2)):                                                        # ... but two walls
+            center[0, j] = lab["gt_quad_centers"][0, g] + 0.02 * rs.randn(3)
+            normal[0, j] = lab["gt_normal_vectors"][0, g] + 0.02 * rs.randn(3)
+            size[0, j] = lab["gt_quad_sizes"][0, g] + 0.02 * rs.randn(2)
+            scores[0, j] = [-2.0, 2.5 + j]
+    out.update({"last_quad_center": center.astype(f32), "last_normal_vector": normal.astype(f32),
+                "last_quad_size": size.astype(f32), "last_quad_scores": scores, "horizontal_quads": horizontal})
+    return out
+
+
+def fill_horizontal_from_walls(ep, verts4):
+    """Ground-truth ceiling and floor for scene 0 of `make_eval(two_walls_scene=True)`: the corners of its two confident
+    quads (verts4: their (4, 3) corner arrays in prediction order), slightly displaced."""
+    a, b = np.asarray(verts4[0], np.float32), np.asarray(verts4[1], np.float32)
+    ep["horizontal_quads"][0, 0] = np.stack([a[0], a[1], b[0], b[1]]) + 0.01
+    ep["horizontal_quads"][0, 1] = np.stack([a[2], a[3], b[2], b[3]]) - 0.01
+    return ep
