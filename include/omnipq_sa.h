@@ -135,6 +135,38 @@ int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const
                               int ldc, const void *Y, const float *a, const float *b, const float *mean,
                               const float *invstd, double *sums, float *workspace, void *stream);
 
+/* ---- The first layer of a coordinates-only stage WITHOUT its output (sa1: Conv2d 3 -> C0 + BatchNorm + ReLU over all
+ * grouped positions; reference pointnet2_modules.py:243-257, pytorch_utils.py:11-36).  y[p][c] = W0[c] . x0[p] is three
+ * FMAs: its consumers recompute it from the grouped coordinates X0 (bf16 [P][ldx], columns 0..2, ldx % 4 == 0: the
+ * omnipq_sa_gather output with kpad = 8) and the layer's prepared weights W0 (bf16 [C0][ldw0], columns 0..2), and the
+ * layer's BatchNorm statistics / weight gradient follow from the first two moments of x0.  Nothing of shape [P][C0] is
+ * written or read for this layer in either direction.
+ *   omnipq_sa_xyz_moments    mom = double[12]: S1 = sum_p x0 (3), M2 = sum_p x0 x0^T (3 x 3 row major)
+ *   omnipq_sa_xyz_stats      sums = double[2][C0]: sum_p y_c = W0[c] . S1, sum_p y_c^2 = W0[c]^T M2 W0[c]
+ *   omnipq_gemm_nt_bf16_xyz_bnaffine   the SECOND layer's GEMM: C = relu(a .* (X0 W0^T) + b) B^T + its statistics, a / b
+ *                            from fin_sums exactly as omnipq_gemm_nt_bf16_bnaffine (K = C0 <= 256, M > 8192 rows)
+ *   omnipq_gemm_nt_bf16_xyz_bnbwd      the data-gradient GEMM INTO the first layer reduced to five column sums
+ *                            sums5 = double[5][N = C0] (zero on entry): sum dz, sum dz yhat, sum dz x0_0..2 with
+ *                            dz = (A B^T) * [a y + b > 0]; workspace omnipq_gemm_nt_xyz_workspace_floats(M, N)
+ *   omnipq_gemm_tn_bf16_xyz_affine     the second layer's weight gradient C = A^T relu(ba .* (X0 W0^T) + bb)
+ *   omnipq_sa_xyz_bwd        dW0 f32 [C0][3] from sums5 (rows 0, 1 global under SyncBatchNorm, inv_count = 1 / global
+ *                            positions), the moments and the layer's a / mean / invstd */
+int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, double *mom, void *stream);
+int omnipq_sa_xyz_stats(int C, const void *W0, int ldw0, const double *mom, double *sums, void *stream);
+int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
+                                     const double *fin_sums, double count, const float *gamma, const float *beta,
+                                     float eps, float momentum, float *running_mean, float *running_var, float *a_out,
+                                     float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
+                                     int ldc, double *sums, float *workspace, void *stream);
+long long omnipq_gemm_nt_xyz_workspace_floats(int M, int N);
+int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, const void *X0,
+                                  int ldx, const void *W0, int ldw0, const float *a, const float *b, const float *mean,
+                                  const float *invstd, double *sums5, float *workspace, void *stream);
+int omnipq_gemm_tn_bf16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx, const void *W0,
+                                   int ldw0, const float *ba, const float *bb, float *C, float *workspace, void *stream);
+int omnipq_sa_xyz_bwd(int C, const void *W0, int ldw0, const double *mom, const double *sums5, const float *a,
+                      const float *mean, const float *invstd, double inv_count, float *dW, void *stream);
+
 /* sums[0][c] = sum_p Y[p][c], sums[1][c] = sum_p Y[p][c]^2  (f64, zeroed by the call; the _z variant
  * trusts the caller that sums[0..2C) is already zero and saves the memset launch). */
 int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);

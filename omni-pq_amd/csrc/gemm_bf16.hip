@@ -86,6 +86,27 @@ struct PoolOut {
   unsigned char *amax, *amin;     // [M / s][N] row within the ball
 };
 
+// XG: the FIRST layer of a stage whose input is coordinates only (sa1: conv 3 -> C0) is never materialised.  Its pre-BN
+// output y[p][c] = W0[c] . x0[p] costs three FMAs, so every consumer recomputes it from the grouped coordinates x0 (bf16
+// [P][ldx], columns 0..2) and the layer's prepared weights W0 (bf16 [C0][ldw], columns 0..2), held in LDS as f32:
+//   XG = 1 (with AFF): the A operand relu(a[k] y[m][k] + b[k]) is GENERATED while the tile is staged -- no global load of A;
+//   XG = 2 (with STATS = 4): the BatchNorm-backward epilogue recomputes y for the ReLU mask and yhat, accumulates FIVE
+//          column sums (dz, dz yhat, dz x0_0, dz x0_1, dz x0_2) into float[m_tiles][5][N] partials and stores NOTHING: the
+//          layer has no input gradient, and its weight gradient follows from these sums and the moments of x0
+//          (omnipq_sa_xyz_bwd), so neither dz nor the BatchNorm-backward result of the layer ever exists.
+struct XyzGen {
+  const bf16_t *X0;
+  int ldx;
+  const bf16_t *W0;
+  int ldw;
+};
+constexpr int kXgMaxC = 256;
+
+__device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+}
+
 // T: tile edge, 128 (four waves x 2 x 2 MFMA blocks) or 64 (four waves x one block).  The per-point layers outside
 // the SA stages have 96..200 tiles of 128 x 128 and 9 K-steps: one wave per SIMD on a third of the chip, each issuing
 // its 8 MFMAs per K-step back to back (0.21 of the 0.36 us a K-step takes) -- they are bound by the MFMA issue of ONE
@@ -94,7 +115,7 @@ struct PoolOut {
 // PF2: operand tiles are fetched TWO K-steps ahead (two named register sets, the loop unrolled by two): with one step of
 // prefetch and two or three workgroups per CU a K-step lasts as long as a global load takes to come back (the SA layers'
 // 8-step contractions ran at 13 % MFMA utilisation: 16 us per 128 x 128 tile against 0.85 us of matrix work).
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false>
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
@@ -102,8 +123,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
                                                         void *__restrict__ stats_out = nullptr,
                                                         BnBwdEpilogue bn = BnBwdEpilogue(),
                                                         AffineIn aff = AffineIn(),
-                                                        PoolOut pool = PoolOut()) {
+                                                        PoolOut pool = PoolOut(),
+                                                        XyzGen xg = XyzGen()) {
   static_assert(T == 128 || T == 64, "tile edge");
+  static_assert(XG == 0 || (XG == 1 && AFF && T == 128 && !PF2) || (XG == 2 && STATS == 4 && T == 128), "XG variants");
+  constexpr int NS = XG == 2 ? 5 : 2;          // column sums per statistics epilogue
   constexpr int NI = T / 64;                   // 32 x 32 MFMA blocks per wave and dimension
   constexpr int CP = T + 8, CPF = T + 4;       // C-tile pitches (bf16 / f32 elements)
   constexpr int PIECES = T / 8;                // 16-byte pieces per bf16 row of the C tile
@@ -115,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
   __shared__ __attribute__((aligned(16))) float s_aff[AFF ? 2 * kAffMaxK : 4];       // a | b of the A operand's channels
+  __shared__ __attribute__((aligned(16))) f32x4 s_w0[XG ? kXgMaxC : 1];              // W0[c][0..2] as f32
 
   // XCD-aware tile order: id % 8 picks the XCD, the N-tiles of one M-tile stay on it
   const int id = (int)blockIdx.x;
@@ -158,6 +183,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float x0r[NI][3];                            // XG = 1: the coordinates of this thread's staged rows
+  if (XG == 2) {
+    for (int c = tid; c < g.N; c += 256) {
+      const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
+      s_w0[c] = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                      __builtin_bit_cast(float, w.y << 16), 0.f};
+    }
+    __syncthreads();
+  }
+  if (XG == 1) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int ar = m0 + srow[i];
+      ar = ar < g.M ? ar : g.M - 1;
+      const uint2 v = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)ar * xg.ldx);
+      x0r[i][0] = __builtin_bit_cast(float, v.x << 16);
+      x0r[i][1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+      x0r[i][2] = __builtin_bit_cast(float, v.y << 16);
+    }
+  }
   if (AFF) {
     const bool first = blockIdx.x == 0 && blockIdx.z == 0;
     for (int c = tid; c < g.K; c += 256) {
@@ -187,6 +232,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
       s_aff[c] = av;
       s_aff[kAffMaxK + c] = bv;
+      if (XG == 1) {
+        // relu(a (W0 . x0) + b) = relu((a W0) . x0 + b): one table entry (a w0, a w1, a w2, b) per channel
+        const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
+        s_w0[c] = f32x4{av * __builtin_bit_cast(float, w.x << 16), av * __builtin_bit_cast(float, w.x & 0xffff0000u),
+                        av * __builtin_bit_cast(float, w.y << 16), bv};
+      }
     }
     __syncthreads();
   }
@@ -197,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   {                                                                   \
     const int koff_ = (KT) * GBK;                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {               \
-      RA[i_] = ldg16(ga[i_] + koff_);                                 \
+      if (XG != 1) RA[i_] = ldg16(ga[i_] + koff_);                    \
       RB[i_] = ldg16(gb[i_] + koff_);                                 \
     }                                                                 \
   }
@@ -213,11 +264,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         fa4_[h_] = *reinterpret_cast<const f32x4 *>(s_aff + k0_ + 4 * h_);                              \
         fb4_[h_] = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0_ + 4 * h_);                   \
       }                                                                                                 \
+      if (XG == 1) {                                                                                    \
+        /* relu((a W0)[k] . x0[row] + b[k]) for the 8 channels of this K-step, rounded like the stored activations */ \
+        f32x4 w_[8];                                                                                    \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) w_[e_] = s_w0[k0_ + e_];                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                             \
+          float y_[8];                                                                                  \
+          _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_)                                              \
+            y_[e_] = __builtin_fmaxf(__builtin_fmaf(w_[e_][2], x0r[i_][2], __builtin_fmaf(w_[e_][1], x0r[i_][1], \
+                         __builtin_fmaf(w_[e_][0], x0r[i_][0], w_[e_][3]))), 0.f);                       \
+          RA[i_].x = xg_pack2(y_[0], y_[1]);                                                            \
+          RA[i_].y = xg_pack2(y_[2], y_[3]);                                                            \
+          RA[i_].z = xg_pack2(y_[4], y_[5]);                                                            \
+          RA[i_].w = xg_pack2(y_[6], y_[7]);                                                            \
+        }                                                                                               \
+      } else {                                                                                          \
       _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                               \
         RA[i_].x = affine_relu_pair(RA[i_].x, fa4_[0][0], fb4_[0][0], fa4_[0][1], fb4_[0][1]);          \
         RA[i_].y = affine_relu_pair(RA[i_].y, fa4_[0][2], fb4_[0][2], fa4_[0][3], fb4_[0][3]);          \
         RA[i_].z = affine_relu_pair(RA[i_].z, fa4_[1][0], fb4_[1][0], fa4_[1][1], fb4_[1][1]);          \
         RA[i_].w = affine_relu_pair(RA[i_].w, fa4_[1][2], fb4_[1][2], fa4_[1][3], fb4_[1][3]);          \
+      }                                                                                                 \
       }                                                                                                 \
     }                                                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                                 \
@@ -343,6 +410,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cs2[e] = 0.f;
     float av[8], bv[8], mu[8], is[8];
+    float cx[XG == 2 ? 3 : 1][8];          // XG = 2: sums of dz * x0_c
+    f32x4 wcol[XG == 2 ? 8 : 1];           // XG = 2: W0 of this thread's 8 columns
     if (STATS >= 3) {
       int c0 = n0 + (tid % PIECES) * 8;
       c0 = c0 < g.N ? c0 : 0;              // columns past N are never accumulated
@@ -352,6 +421,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         bv[e] = bn.b[c0 + e];
         mu[e] = bn.mean[c0 + e];
         is[e] = bn.invstd[c0 + e];
+        if (XG == 2) {
+          wcol[e] = s_w0[c0 + e];
+          cx[0][e] = cx[1][e] = cx[2][e] = 0.f;
+        }
       }
     }
     for (int q = tid; q < T * PIECES; q += 256) {
@@ -359,8 +432,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       const int gr = m0 + row, gc = n0 + piece * 8;
       if (gr < g.M && gc < g.N) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * CP + piece * 8);
-        *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
-        if (STATS >= 3) {
+        if (XG != 2) *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
+        if (XG == 2) {
+          const uint2 xv = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)gr * xg.ldx);
+          const float x0 = __builtin_bit_cast(float, xv.x << 16), x1 = __builtin_bit_cast(float, xv.x & 0xffff0000u);
+          const float x2 = __builtin_bit_cast(float, xv.y << 16);
+          const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+            const float y = __builtin_fmaf(wcol[e][2], x2, __builtin_fmaf(wcol[e][1], x1, wcol[e][0] * x0));
+            const float dz = __builtin_fmaf(av[e], y, bv[e]) > 0.f ? d : 0.f;
+            cs[e] += dz;
+            cs2[e] = __builtin_fmaf(dz, (y - mu[e]) * is[e], cs2[e]);
+            cx[0][e] = __builtin_fmaf(dz, x0, cx[0][e]);
+            cx[1][e] = __builtin_fmaf(dz, x1, cx[1][e]);
+            cx[2][e] = __builtin_fmaf(dz, x2, cx[2][e]);
+          }
+        } else if (STATS >= 3) {
           const uint4 yv = *reinterpret_cast<const uint4 *>(bn.Y + (size_t)gr * g.ldc + gc);
           const unsigned w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
@@ -408,27 +497,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
     }
     if (STATS) {
-      __syncthreads();                     // the C tile is dead: reuse it as [RG row groups][2][T] floats
-      static_assert(RG * 2 * T * 4 <= LDS_BYTES, "statistics fold must fit under the staging buffers");
+      __syncthreads();                     // the C tile is dead: reuse it as [RG row groups][NS][T] floats
+      static_assert(RG * NS * T * 4 <= LDS_BYTES, "statistics fold must fit under the staging buffers");
       float *red = reinterpret_cast<float *>(smem);
       const int rg = tid / PIECES, piece = tid % PIECES;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(rg * 2 + 0) * T + piece * 8 + e] = cs[e];
-        red[(rg * 2 + 1) * T + piece * 8 + e] = cs2[e];
+        red[(rg * NS + 0) * T + piece * 8 + e] = cs[e];
+        red[(rg * NS + 1) * T + piece * 8 + e] = cs2[e];
+        if (XG == 2) {
+          red[(rg * NS + 2) * T + piece * 8 + e] = cx[0][e];
+          red[(rg * NS + 3) * T + piece * 8 + e] = cx[1][e];
+          red[(rg * NS + 4) * T + piece * 8 + e] = cx[2][e];
+        }
       }
       __syncthreads();
-      const int which = tid / T, col = tid % T;
-      float tot = 0.f;
-      if (tid < 2 * T) {
+      const int col = tid % T;
+      for (int which = tid / T; which < NS; which += 256 / T) {
+        float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < RG; ++r) tot += red[(r * 2 + which) * T + col];
-      }
-      if (tid < 2 * T && n0 + col < g.N) {
-        if (STATS == 1 || STATS == 3)
-          atomicAdd(reinterpret_cast<double *>(stats_out) + (size_t)which * g.N + n0 + col, (double)tot);
-        else
-          reinterpret_cast<float *>(stats_out)[((size_t)mt * 2 + which) * g.N + n0 + col] = tot;
+        for (int r = 0; r < RG; ++r) tot += red[(r * NS + which) * T + col];
+        if (n0 + col < g.N) {
+          if (STATS == 1 || STATS == 3)
+            atomicAdd(reinterpret_cast<double *>(stats_out) + (size_t)which * g.N + n0 + col, (double)tot);
+          else
+            reinterpret_cast<float *>(stats_out)[((size_t)mt * NS + which) * g.N + n0 + col] = tot;
+        }
       }
     }
   }
@@ -827,6 +921,90 @@ extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int
   if (slabs < 1) slabs = 1;
   partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
                                                                                     sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+
+// ---- first layer of a coordinates-only stage, never materialised (see XyzGen) -------------------------------------
+extern "C" long long omnipq_gemm_nt_xyz_workspace_floats(int M, int N) {
+  const long long m_tiles = (M + omnipq::GBM - 1) / omnipq::GBM;
+  return m_tiles * 5 * (long long)N;
+}
+
+// C[M][N] = relu(a .* (X0 W0^T) + b) B^T with the statistics of C (as omnipq_gemm_nt_bf16_bnaffine: a / b derived from
+// fin_sums = the first layer's totals, which come from omnipq_sa_xyz_stats).  X0 bf16 [M][ldx] (columns 0..2), W0 bf16
+// [K][ldw0] (columns 0..2), K <= 256, M > 64 * 128 (the partial-sum path), workspace omnipq_gemm_nt_stats_workspace_floats.
+extern "C" int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
+                                                const double *fin_sums, double count, const float *gamma,
+                                                const float *beta, float eps, float momentum, float *running_mean,
+                                                float *running_var, float *a_out, float *b_out, float *mean_out,
+                                                float *invstd_out, const void *B, int ldb, void *C, int ldc, double *sums,
+                                                float *workspace, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!X0 || !W0 || !B || !C || !sums || !workspace || (K % GBK) || (N % 8) || (ldb % 8) || (ldc % 8) || K > kXgMaxC ||
+      (ldx % 4) || (ldw0 % 4) || ldx < 3 || ldw0 < 3)
+    return OMNIPQ_EINVAL;
+  if (!fin_sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out || !(count > 0)) return OMNIPQ_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, 0, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+  AffineIn aff{};
+  aff.sums = fin_sums;
+  aff.gamma = gamma;
+  aff.beta = beta;
+  aff.running_mean = running_mean;
+  aff.running_var = running_var;
+  aff.a_out = a_out;
+  aff.b_out = b_out;
+  aff.mean_out = mean_out;
+  aff.invstd_out = invstd_out;
+  aff.count = count;
+  aff.eps = eps;
+  aff.momentum = momentum;
+  const XyzGen xg{(const bf16_t *)X0, ldx, (const bf16_t *)W0, ldw0};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  gemm_nt_kernel<false, 2, true, 128, false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
+      g, (const bf16_t *)B, (const bf16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
+                                                                                    sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// The data-gradient GEMM into that first layer, reduced to what is needed of it: with dX = A B^T (A = dY of the layer
+// above [M][K], B = its transposed weights [N][K]), y = X0 W0^T, dz = dX * [a y + b > 0]:
+//   sums5[0][n] = sum dz, [1] = sum dz (y - mean) invstd, [2 + c] = sum dz x0_c   (double[5][N], zero on entry)
+// Nothing of size M x N is written.  N <= 256, M > 64 * 128, workspace omnipq_gemm_nt_xyz_workspace_floats(M, N).
+extern "C" int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                             const void *X0, int ldx, const void *W0, int ldw0, const float *a,
+                                             const float *b, const float *mean, const float *invstd, double *sums5,
+                                             float *workspace, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !X0 || !W0 || !sums5 || !workspace || !a || !b || !mean || !invstd) return OMNIPQ_EINVAL;
+  if ((K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || N > kXgMaxC || (ldx % 4) || (ldw0 % 4) || ldx < 3 || ldw0 < 3)
+    return OMNIPQ_EINVAL;
+  GemmArgs g{M, N, K, lda, ldb, N, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+  const XyzGen xg{(const bf16_t *)X0, ldx, (const bf16_t *)W0, ldw0};
+  const BnBwdEpilogue bn{nullptr, a, b, mean, invstd};
+  const int groups = (g.m_tiles + 7) / 8;
+  dim3 grid(groups * 8 * g.n_tiles, 1, 1);
+  gemm_nt_kernel<false, 4, false, 128, false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
+      g, (const bf16_t *)A, (const bf16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  partial_reduce_kernel<<<dim3((5 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 5 * N, workspace,
+                                                                                    sums5);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -49,10 +49,25 @@ __device__ __forceinline__ unsigned tn_affine_relu_pair(unsigned w, float a0, fl
          ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
 }
 
-template <bool AFFB>
+// XGB (with AFFB): the layer below is the never-materialised first layer of a coordinates-only stage (gemm_bf16.hip:
+// XyzGen): B points at the grouped coordinates x0 (bf16 [P][ldb], columns 0..2) and its pre-BN output is recomputed as
+// y[p][n] = W0[n] . x0[p] from the layer's prepared weights W0 (bf16 [N][ldw0], columns 0..2) before the affine + ReLU.
+struct TnXyz {
+  const bf16_t *W0;
+  int ldw;
+};
+
+__device__ __forceinline__ unsigned tn_pack2(float lo, float hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+}
+
+template <bool AFFB, bool XGB = false>
 __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
                                         float *__restrict__ part, float *__restrict__ colsum, const int id,
-                                        const float *__restrict__ ba = nullptr, const float *__restrict__ bb = nullptr) {
+                                        const float *__restrict__ ba = nullptr, const float *__restrict__ bb = nullptr,
+                                        const TnXyz xg = TnXyz()) {
+  static_assert(!XGB || AFFB, "XGB generates the operand the affine transform is applied to");
   constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 18432 bf16 = 36 KB: four workgroups per CU
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_ELEMS * 2];
   static_assert(16 * 128 * 4 <= STAGE_ELEMS * 2, "the column-sum fold aliases the staging buffers");
@@ -114,11 +129,19 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
   // AFFB: a, b of the tile's 128 B channels live in LDS (1 KB) and are re-read at every K-step: holding this
   // thread's sixteen values in registers costs the fourth workgroup per CU (139 VGPRs)
   __shared__ __attribute__((aligned(16))) float s_ab[AFFB ? 256 : 4];
+  __shared__ __attribute__((aligned(16))) f32x4 s_w0[XGB ? 128 : 1];
   if (AFFB) {
     if (tid < 128) {
       const int c = n0 + tid < g.N ? n0 + tid : 0;
       s_ab[tid] = ba[c];
       s_ab[128 + tid] = bb[c];
+      if (XGB) {
+        // relu(a (W0 . x0) + b) = relu((a W0) . x0 + b): one table entry (a w0, a w1, a w2, b) per channel
+        const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
+        const float av = ba[c];
+        s_w0[tid] = f32x4{av * __builtin_bit_cast(float, w.x << 16), av * __builtin_bit_cast(float, w.x & 0xffff0000u),
+                          av * __builtin_bit_cast(float, w.y << 16), bb[c]};
+      }
     }
     __syncthreads();
   }
@@ -132,15 +155,38 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
       keep[i] = p < pend ? 0xFFFFFFFFu : 0u;
       const int pc = p < pend ? p : g.P - 1;
       ra[i] = *reinterpret_cast<const uint4 *>(A + (size_t)pc * g.lda + acol[i]);
-      rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)pc * g.ldb + bcol[i]);
+      if (XGB) {
+        const uint2 xv = *reinterpret_cast<const uint2 *>(B + (size_t)pc * g.ldb);       // x0[p][0..2]
+        rb[i].x = xv.x;
+        rb[i].y = xv.y;
+      } else {
+        rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)pc * g.ldb + bcol[i]);
+      }
     }
   };
   auto store_tiles = [&](int buf) {
     bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
     bf16_t *sb = sa + TBK * TPITCH;
+    f32x4 wx[XGB ? 8 : 1];               // both chunks of a thread cover the same eight channels
+    if (XGB) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wx[e] = s_w0[sc8[0] * 8 + e];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (AFFB) {
+      if (XGB) {
+        const float x0 = __builtin_bit_cast(float, rb[i].x << 16), x1 = __builtin_bit_cast(float, rb[i].x & 0xffff0000u);
+        const float x2 = __builtin_bit_cast(float, rb[i].y << 16);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          y[e] = __builtin_fmaxf(
+              __builtin_fmaf(wx[e][2], x2, __builtin_fmaf(wx[e][1], x1, __builtin_fmaf(wx[e][0], x0, wx[e][3]))), 0.f);
+        rb[i].x = tn_pack2(y[0], y[1]);
+        rb[i].y = tn_pack2(y[2], y[3]);
+        rb[i].z = tn_pack2(y[4], y[5]);
+        rb[i].w = tn_pack2(y[6], y[7]);
+      } else if (AFFB) {
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_ab + sc8[i] * 8), a1 = *reinterpret_cast<const f32x4 *>(s_ab + sc8[i] * 8 + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_ab + 128 + sc8[i] * 8), b1 = *reinterpret_cast<const f32x4 *>(s_ab + 128 + sc8[i] * 8 + 4);
         rb[i].x = tn_affine_relu_pair(rb[i].x, a0[0], b0[0], a0[1], b0[1]);
@@ -254,6 +300,13 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_affine_kernel(TnArgs g, const 
                                                                const float *__restrict__ ba,
                                                                const float *__restrict__ bb) {
   tn_tile<true>(g, A, B, part, colsum, (int)blockIdx.x, ba, bb);
+}
+
+__global__ __launch_bounds__(256, 4) void gemm_tn_xyz_kernel(TnArgs g, const bf16_t *__restrict__ A,
+                                                            const bf16_t *__restrict__ X0,
+                                                            float *__restrict__ part, const float *__restrict__ ba,
+                                                            const float *__restrict__ bb, TnXyz xg) {
+  tn_tile<true, true>(g, A, X0, part, nullptr, (int)blockIdx.x, ba, bb, xg);
 }
 
 // ---- grouped launch: many independent weight gradients in one grid ------------------------------------------
@@ -373,7 +426,8 @@ extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
 }
 
 static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
-                        float *workspace, float *colsum, const float *ba, const float *bb, void *stream);
+                        float *workspace, float *colsum, const float *ba, const float *bb, void *stream,
+                        const void *W0 = nullptr, int ldw0 = 0);
 
 extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                    float *C, float *workspace, void *stream) {
@@ -397,19 +451,32 @@ extern "C" int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, in
   return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, ba, bb, stream);
 }
 
+// C = A^T relu(ba .* (X0 W0^T) + bb): the weight gradient of the layer ABOVE a never-materialised first layer (see TnXyz).
+// X0 bf16 [P][ldx] (columns 0..2), W0 bf16 [N][ldw0] (columns 0..2).
+extern "C" int omnipq_gemm_tn_bf16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx,
+                                              const void *W0, int ldw0, const float *ba, const float *bb, float *C,
+                                              float *workspace, void *stream) {
+  if (!ba || !bb || !W0 || (ldx % 4) || (ldw0 % 4) || ldx < 3 || ldw0 < 3) return OMNIPQ_EINVAL;
+  return gemm_tn_impl(M, N, P, A, lda, X0, ldx, C, workspace, nullptr, ba, bb, stream, W0, ldw0);
+}
+
 static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
-                        float *workspace, float *colsum, const float *ba, const float *bb, void *stream) {
+                        float *workspace, float *colsum, const float *ba, const float *bb, void *stream,
+                        const void *W0, int ldw0) {
   using namespace omnipq;
   if (M < 0 || N < 0 || P < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
-  if (!A || !B || !C || !workspace || (M % 8) || (N % 8) || (lda % 8) || (ldb % 8)) return OMNIPQ_EINVAL;
+  if (!A || !B || !C || !workspace || (M % 8) || (N % 8) || (lda % 8) || (!W0 && (ldb % 8))) return OMNIPQ_EINVAL;
   TnArgs g{M, N, P, lda, ldb, 0, (M + 127) / 128, (N + 127) / 128};
   const int tiles = g.m_tiles * g.n_tiles;
   const int slabs = tn_slabs(tiles, P);
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
   const int used = P > 0 ? (P + g.p_chunk - 1) / g.p_chunk : 1;
   dim3 grid(tiles * ((used + 7) / 8) * 8);
-  if (ba)
+  if (W0)
+    gemm_tn_xyz_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace, ba, bb,
+                                                            TnXyz{(const bf16_t *)W0, ldw0});
+  else if (ba)
     gemm_tn_affine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
                                                                colsum, ba, bb);
   else

@@ -38,6 +38,23 @@ import sa_fused  # noqa: E402
 # "capture" (default): overlap the decoder's key sides on a side stream while a hipGraph is being captured (in
 # eager mode the extra stream switches cost more host time than the overlap returns); "always" / "inline"
 _OVERLAP_KEY_SIDE = os.environ.get("OMNIPQ_KEY_SIDE", "capture")
+# The object head and the quad head of a decoder layer are independent of each other, and in BACKWARD independent of the
+# decoder chain too (the centres they hand to the next layer are detached, :236-237 of the reference): each runs on its own
+# side stream, so in a captured step the backward passes of the 14 heads (a few kernels of 64-128 workgroups each) lie
+# underneath the decoder's backward instead of in front of it.  MEASURED (MI355X, config 2, hipGraph replay): 19.7 ms per
+# step with the head streams against 13.8 ms without -- every cross-stream edge of a captured graph costs tens of
+# microseconds at replay on this runtime, and the 12 forks / joins of the forward plus the ones autograd mirrors in backward
+# outweigh the ~1 ms of head kernels they hide.  Hence "off" by default; "capture": only while a hipGraph is being captured;
+# "always".
+_OVERLAP_HEADS = os.environ.get("OMNIPQ_HEAD_STREAMS", "off")
+_HEAD_STREAMS = {}
+
+
+def _head_streams(device):
+    st = _HEAD_STREAMS.get(device)
+    if st is None:
+        st = _HEAD_STREAMS[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return st
 
 
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
@@ -454,12 +471,36 @@ class PQ_Transformer(nn.Module):
             rows_obj = rows_quad = None
             if rows16 is not None:
                 rows_obj, rows_quad = torch.split(rows16, [n_obj, n_quad], dim=1)
-            base_xyz, _, end_points = self.prediction_heads[i](
-                query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
-                net_rows=rows_obj)
-            base_xyz_q, _, end_points = self.prediction_quad_heads[i](
-                query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix,
-                net_rows=rows_quad)
+            head_overlap = query.is_cuda and (_OVERLAP_HEADS == "always" or (
+                _OVERLAP_HEADS == "capture" and torch.cuda.is_current_stream_capturing()))
+            if head_overlap:
+                cur = torch.cuda.current_stream(query.device)
+                known = set(end_points.keys())
+                for st, head, q, xyz, rows in zip(_head_streams(query.device),
+                                                  (self.prediction_heads[i], self.prediction_quad_heads[i]),
+                                                  (query, query_q), (cluster_xyz, quad_xyz), (rows_obj, rows_quad)):
+                    st.wait_stream(cur)
+                    for t in (q, rows, query_joint, rows16):
+                        if t is not None:
+                            t.record_stream(st)
+                    with torch.cuda.stream(st):
+                        centre, _, end_points = head(q, base_xyz=xyz, end_points=end_points, prefix=prefix, net_rows=rows)
+                    if head is self.prediction_heads[i]:
+                        base_xyz = centre
+                    else:
+                        base_xyz_q = centre
+                for st in _head_streams(query.device):
+                    cur.wait_stream(st)                 # the next layer's query positions are these heads' centres
+                for k, v in end_points.items():
+                    if k not in known and torch.is_tensor(v):
+                        v.record_stream(cur)
+            else:
+                base_xyz, _, end_points = self.prediction_heads[i](
+                    query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
+                    net_rows=rows_obj)
+                base_xyz_q, _, end_points = self.prediction_quad_heads[i](
+                    query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix,
+                    net_rows=rows_quad)
             base_xyz = base_xyz.detach()
             base_xyz_q = base_xyz_q.detach()
         return end_points

@@ -197,6 +197,34 @@ def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=N
     return C
 
 
+# The first layer of a coordinates-only stage (sa1: conv 3 -> 128 over 1 M grouped positions) without its output: its
+# consumers recompute y = W0 . x0 from the grouped coordinates (three FMAs per element), its BatchNorm statistics and its
+# weight gradient follow from the moments of x0 (csrc/xyz_layer.hip, gemm_bf16.hip: XyzGen).  Per step on sa1 this removes
+# one write and four reads of Y1, the write and read of dz1, of dY1, and two GEMM launches: 2.4 GB of 7.8 GB.
+# OMNIPQ_SA_XYZGEN=0 restores the stored first layer.
+XYZGEN = os.environ.get("OMNIPQ_SA_XYZGEN", "1") != "0"
+xyzgen_uses = 0            # forwards that took the path (tests check that it is the one that ran)
+_lib.omnipq_gemm_nt_xyz_workspace_floats.restype = ctypes.c_longlong
+
+
+def xyzgen_ok(P, L, c0, needs_input_grad):
+    """first layer generated from coordinates: training, no features, at least three layers (the second is not the pooled
+    one), more than 64 row tiles (the kernels' partial-sum path), no gradient into the coordinates"""
+    return XYZGEN and L >= 3 and P > 64 * 128 and c0 <= 256 and c0 % 8 == 0 and not needs_input_grad
+
+
+def gemm_nt_xyz(X0c, below, Bw, M, N, K, sums):
+    """bf16 C = relu(bn(X0c W0^T)) Bw^T + its statistics: `below` is the never-materialised first layer (Wp, fin)."""
+    C = torch.empty((M, N), device=X0c.device, dtype=torch.bfloat16)
+    ws = torch.empty((int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N)),), device=X0c.device, dtype=torch.float32)
+    fsums, count, gamma, beta, eps, momentum, rm, rv, _ = below.fin
+    below.fin = None
+    _call(_lib.omnipq_gemm_nt_bf16_xyz_bnaffine, X0c, M, N, K, _p(X0c), X0c.shape[1], _p(below.Wp), below.Wp.shape[1],
+          _p(fsums), ctypes.c_double(count), _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm),
+          _p(rv), _p(below.a), _p(below.b), _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(sums), _p(ws))
+    return C
+
+
 def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     """dX = dY Wt^T (bf16 [M][N]) and, in the same pass, the BatchNorm-backward sums of the layer `below`
     (its pre-BN output Y and constants a, b, mean, invstd) into sums (f64 [>=2][N], zero on entry)."""
@@ -820,7 +848,7 @@ def rows16_of(t, shape):
 
 class _Layer:
     """Per-layer constants and saved tensors of one conv+BN+ReLU."""
-    __slots__ = ("K", "C", "Wp", "Wt", "a", "b", "mean", "invstd", "Y", "X", "fin")
+    __slots__ = ("K", "C", "Wp", "Wt", "a", "b", "mean", "invstd", "Y", "X", "fin", "mom")
 
 
 class FusedSAStage(torch.autograd.Function):
@@ -862,8 +890,15 @@ class FusedSAStage(torch.autograd.Function):
             feat_pm = torch.nn.functional.pad(feat_pm, (0, cin - cin_raw)) if cin != cin_raw else feat_pm.contiguous()
         xyz_c = xyz.detach().contiguous()
         cen_c = new_xyz.detach().contiguous()
-        X = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
-        _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
+        xgen = training and features is None and xyzgen_ok(
+            P, L, params[0].shape[0], ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and \
+            affine_pays(P, params[3].shape[0])
+        xpad = 8 if xgen else kpad          # only the coordinates travel: 16 bytes per grouped position
+        if xgen:
+            global xyzgen_uses
+            xyzgen_uses += 1
+        X = torch.empty((P, xpad), device=dev, dtype=torch.bfloat16)
+        _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, xpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
               _p(idx), _p(feat_pm), _p(X))
 
         layers = []
@@ -895,7 +930,15 @@ class FusedSAStage(torch.autograd.Function):
                     pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
                 alg = l == L - 1 and l > 0 and X is None and pool is not None and layers[l - 1].fin is not None and \
                     algebra_ok(P, S, cout, K)
-                if alg:
+                if xgen and l == 0:
+                    # never materialised (see XYZGEN): statistics from the moments of the grouped coordinates
+                    lay.mom = torch.empty((12,), device=dev, dtype=torch.float64)
+                    _call(_lib.omnipq_sa_xyz_moments, X, ctypes.c_longlong(P), _p(X), xpad, _p(lay.mom))
+                    _call(_lib.omnipq_sa_xyz_stats, X, cout, _p(lay.Wp), K, _p(lay.mom), _p(sums))
+                    lay.Y = None
+                elif xgen and l == 1:
+                    lay.Y = gemm_nt_xyz(X0, layers[0], lay.Wp, P, cout, K, sums)
+                elif alg:
                     # statistics and ball extrema only: the layer's output is never stored (see ALGEBRA above)
                     prev = layers[l - 1]
                     fsums, count, pg, pb, peps, pmom, prm, prv, _ = prev.fin
@@ -915,7 +958,7 @@ class FusedSAStage(torch.autograd.Function):
                 _allreduce_(sums, world)
                 stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
                 lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
-                keep_y_only = l < L - 1 and affine_pays(P, params[3 * (l + 1)].shape[0])
+                keep_y_only = l < L - 1 and (affine_pays(P, params[3 * (l + 1)].shape[0]) or (xgen and l == 0))
                 fused_relu = l < L - 1 and not keep_y_only
                 lay.fin = None
                 if keep_y_only:
@@ -971,6 +1014,7 @@ class FusedSAStage(torch.autograd.Function):
 
         ctx.layers = layers
         ctx.X0 = X0
+        ctx.xgen = xgen
         ctx.chain = None
         ctx.cin_raw = cin_raw
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
@@ -1231,6 +1275,31 @@ class FusedSAStage(torch.autograd.Function):
         d_feat = d_xyz = d_cen = None
         for l in range(top, -1, -1):
             lay = layers[l]
+            if l == 1 and getattr(ctx, "xgen", False):
+                # the layer below is the never-materialised first layer (see XYZGEN): this layer's weight gradient
+                # contracts against activations rebuilt from the grouped coordinates, and the data-gradient GEMM is
+                # reduced to the five column sums the first layer's dW / dgamma / dbeta follow from
+                prev = layers[0]
+                X0c = ctx.X0
+                dWp = torch.empty((lay.C, lay.K), device=dev, dtype=torch.float32)
+                ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(lay.C, lay.K, P)),), device=dev,
+                                 dtype=torch.float32)
+                _call(_lib.omnipq_gemm_tn_bf16_xyz_affine, dY, lay.C, lay.K, P, _p(dY), lay.C, _p(X0c), X0c.shape[1],
+                      _p(prev.Wp), prev.Wp.shape[1], _p(prev.a), _p(prev.b), _p(dWp), _p(ws))
+                grads[3] = unprep_wgrad(dWp, lay.C, lay.K, 0, (lay.C, lay.K, 1, 1))
+                sums5 = zeros_f64(5, prev.C, dev)
+                ws5 = torch.empty((int(_lib.omnipq_gemm_nt_xyz_workspace_floats(P, prev.C)),), device=dev,
+                                  dtype=torch.float32)
+                _call(_lib.omnipq_gemm_nt_bf16_xyz_bnbwd, dY, P, prev.C, lay.C, _p(dY), lay.C, _p(lay.Wt), lay.C, _p(X0c),
+                      X0c.shape[1], _p(prev.Wp), prev.Wp.shape[1], _p(prev.a), _p(prev.b), _p(prev.mean), _p(prev.invstd),
+                      _p(sums5), _p(ws5))
+                grads[1], grads[2] = affine_grads(sums5, prev.C)            # this rank's dgamma / dbeta
+                _allreduce_(sums5[:2], world)
+                dW0 = torch.empty((prev.C, 3, 1, 1), device=dev, dtype=torch.float32)
+                _call(_lib.omnipq_sa_xyz_bwd, dY, prev.C, _p(prev.Wp), prev.Wp.shape[1], _p(prev.mom), _p(sums5), _p(prev.a),
+                      _p(prev.mean), _p(prev.invstd), ctypes.c_double(1.0 / (float(P) * world)), _p(dW0))
+                grads[0] = dW0
+                break
             if l > 0 and layers[l - 1].X is None:
                 dWp = _gemm_tn(dY, layers[l - 1].Y, lay.C, lay.K, P, below=layers[l - 1])
             else:

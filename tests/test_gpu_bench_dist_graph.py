@@ -14,15 +14,23 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_step_with_rccl_collectives_captures_and_replays():
-    env = dict(os.environ, OMNIPQ_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0",
+def run_bench(port):
+    env = dict(os.environ, OMNIPQ_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2",
                           "--no-cpu-baseline", "--no-op-timing", "--points", "20000", "--batch", "4"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+
+def test_step_with_rccl_collectives_captures_and_replays():
+    rec, err = run_bench(29641)
+    if rec["launch"] != "hipGraph replay":
+        # the capture is gated by a probe in a child process with its own rendezvous and time limit
+        # (tools/rccl_graph_probe.py); on a box that is still paging the image in it can time out once: one retry
+        rec, err = run_bench(29647)
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     # the probe passed and the captured step holds the collectives
-    assert rec["launch"] == "hipGraph replay", rec["launch"]
+    assert rec["launch"] == "hipGraph replay", (rec["launch"], err[-1500:])
     assert rec["data_parallel"] and "inside the graph" in rec["data_parallel"], rec["data_parallel"]
