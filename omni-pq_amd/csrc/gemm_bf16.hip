@@ -115,7 +115,14 @@ __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
 // PF2: operand tiles are fetched TWO K-steps ahead (two named register sets, the loop unrolled by two): with one step of
 // prefetch and two or three workgroups per CU a K-step lasts as long as a global load takes to come back (the SA layers'
 // 8-step contractions ran at 13 % MFMA utilisation: 16 us per 128 x 128 tile against 0.85 us of matrix work).
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0>
+// KRES (T = 64, K <= 320, no split): the per-point layers outside the SA stages are 64..320 workgroups of nine K-steps, and
+// with one step of prefetch every K-step lasts as long as a load from L2 takes to come back (~0.5 us): the main loop is nine
+// round trips.  Here ALL K-steps of both operand tiles are requested at once (18 loads of 16 bytes per lane in flight), put
+// into LDS in one go (dynamic LDS: 2 x 64 x (K + 8) bf16, 76 KB at K = 288), and the nine MFMA steps run back to back
+// behind ONE barrier.
+constexpr int kResMaxSteps = 10;
+
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0, bool KRES = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
                                                         XyzGen xg = XyzGen()) {
   static_assert(T == 128 || T == 64, "tile edge");
   static_assert(XG == 0 || (XG == 1 && AFF && T == 128 && !PF2) || (XG == 2 && STATS == 4 && T == 128), "XG variants");
+  static_assert(!KRES || (T == 64 && !PF2 && XG == 0 && !OUT_F32), "KRES variants");
   constexpr int NS = XG == 2 ? 5 : 2;          // column sums per statistics epilogue
   constexpr int NI = T / 64;                   // 32 x 32 MFMA blocks per wave and dimension
   constexpr int CP = T + 8, CPF = T + 4;       // C-tile pitches (bf16 / f32 elements)
@@ -136,7 +144,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   constexpr int STAGE_ELEMS = 2 * 2 * T * GPITCH;                         // T = 128: 20480 bf16 = 40 KB
   constexpr int CT_BYTES = OUT_F32 ? T * CPF * 4 : T * CP * 2;
   constexpr int LDS_BYTES = (STAGE_ELEMS * 2 > CT_BYTES) ? STAGE_ELEMS * 2 : CT_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char static_smem[KRES ? 16 : LDS_BYTES];
+  unsigned char *const smem = KRES ? dyn_smem : static_smem;
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
   __shared__ __attribute__((aligned(16))) float s_aff[AFF ? 2 * kAffMaxK : 4];       // a | b of the A operand's channels
   __shared__ __attribute__((aligned(16))) f32x4 s_w0[XG ? kXgMaxC : 1];              // W0[c][0..2] as f32
@@ -313,6 +323,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
     }
   };
 
+  if (KRES) {
+    const int KP = nk * GBK + 8;               // row pitch: same residue mod 128 bytes as GPITCH, conflict-free b128 reads
+    bf16_t *sa = stage, *sb = stage + T * KP;
+    uint4 qa[kResMaxSteps], qb[kResMaxSteps];
+#pragma unroll
+    for (int kt = 0; kt < kResMaxSteps; ++kt)
+      if (kt < nk) {
+        qa[kt] = ldg16(ga[0] + kt * GBK);
+        qb[kt] = ldg16(gb[0] + kt * GBK);
+      }
+#pragma unroll
+    for (int kt = 0; kt < kResMaxSteps; ++kt)
+      if (kt < nk) {
+        if (AFF) {
+          const int k0 = kbeg + kt * GBK + skc[0] * 8;
+          const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(s_aff + k0), fa1 = *reinterpret_cast<const f32x4 *>(s_aff + k0 + 4);
+          const f32x4 fb0 = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0);
+          const f32x4 fb1 = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0 + 4);
+          qa[kt].x = affine_relu_pair(qa[kt].x, fa0[0], fb0[0], fa0[1], fb0[1]);
+          qa[kt].y = affine_relu_pair(qa[kt].y, fa0[2], fb0[2], fa0[3], fb0[3]);
+          qa[kt].z = affine_relu_pair(qa[kt].z, fa1[0], fb1[0], fa1[1], fb1[1]);
+          qa[kt].w = affine_relu_pair(qa[kt].w, fa1[2], fb1[2], fa1[3], fb1[3]);
+        }
+        *reinterpret_cast<uint4 *>(sa + srow[0] * KP + kt * GBK + skc[0] * 8) = qa[kt];
+        *reinterpret_cast<uint4 *>(sb + srow[0] * KP + kt * GBK + skc[0] * 8) = qb[kt];
+      }
+    __syncthreads();
+    const bf16_t *pa = sa + (wm * (T / 2) + frow) * KP + fk;
+    const bf16_t *pb = sb + (wn * (T / 2) + frow) * KP + fk;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(pa + kt * GBK + kk * 16);
+        const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(pb + kt * GBK + kk * 16);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][0], 0, 0, 0);
+      }
+    }
+    __syncthreads();                             // the C tile aliases the operand tiles
+  } else {
   if (nk > 0) {
     OMNIPQ_LOAD_TILES(ra, rb, 0)
     OMNIPQ_STORE_TILES(ra, rb, 0, 0)
@@ -341,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       if (kt + 2 < nk) OMNIPQ_STORE_TILES(ra, rb, 0, kt + 2)
       __syncthreads();
     }
+  }
   }
 #undef OMNIPQ_LOAD_TILES
 #undef OMNIPQ_STORE_TILES
@@ -642,6 +692,31 @@ static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int 
 
 static dim3 gemm_nt_grid(const omnipq::GemmArgs &g) { return dim3(((g.m_tiles + 7) / 8) * 8 * g.n_tiles, 1, 1); }
 
+// 64 x 64-tile launches: the K-resident variant (see KRES) whenever the contraction fits, OMNIPQ_GEMM_KRES=0 to compare
+static bool gemm_nt_kres(int K) {
+  static const bool on = !(getenv("OMNIPQ_GEMM_KRES") && atoi(getenv("OMNIPQ_GEMM_KRES")) == 0);
+  return on && K <= omnipq::kResMaxSteps * omnipq::GBK;
+}
+
+template <int STATS, bool AFF>
+static void launch_small(const omnipq::GemmArgs &g, const void *A, const void *B, void *C, const float *bias, void *stats,
+                         const omnipq::BnBwdEpilogue &bn, const omnipq::AffineIn &aff, void *stream) {
+  using namespace omnipq;
+  if (gemm_nt_kres(g.K)) {
+    auto kern = gemm_nt_kernel<false, STATS, AFF, 64, false, 0, true>;
+    static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)prepared;
+    int lds = 2 * 64 * (g.K + 8) * 2;
+    if (lds < 20480) lds = 20480;                // the C tile / statistics fold alias the operand tiles
+    kern<<<gemm_nt_grid(g), 256, lds, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn,
+                                                             aff, PoolOut(), XyzGen());
+  } else {
+    gemm_nt_kernel<false, STATS, AFF, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+        g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff, PoolOut(), XyzGen());
+  }
+}
+
 // C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.
 extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                    void *C, int ldc, void *stream) {
@@ -651,8 +726,7 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
   if (gemm_nt_small_tiles(M, N)) {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
-    gemm_nt_kernel<false, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
-        g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
+    launch_small<0, false>(g, A, B, C, nullptr, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
     if (gemm_nt_pf2())
@@ -690,8 +764,7 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
   if (g.m_tiles <= kStatsDirectTiles) {
     if (gemm_nt_small_tiles(M, N)) {
       const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
-      gemm_nt_kernel<false, 1, false, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
-          gs, (const bf16_t *)A, (const bf16_t *)B, C, bias, sums);
+      launch_small<1, false>(gs, A, B, C, bias, sums, BnBwdEpilogue(), AffineIn(), stream);
     } else {
       gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
                                                                   sums);
@@ -726,8 +799,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
   const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
   if (!sums) {
     if (small)
-      gemm_nt_kernel<false, 0, true, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
-          gs, (const bf16_t *)A, (const bf16_t *)B, C, bias, nullptr, BnBwdEpilogue(), aff);
+      launch_small<0, true>(gs, A, B, C, bias, nullptr, BnBwdEpilogue(), aff, stream);
     else
       gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
                                                                         bias, nullptr, BnBwdEpilogue(), aff);
@@ -735,8 +807,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
     return OMNIPQ_OK;
   }
   if (g.m_tiles <= kStatsDirectTiles && small) {
-    gemm_nt_kernel<false, 1, true, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
-        gs, (const bf16_t *)A, (const bf16_t *)B, C, bias, sums, BnBwdEpilogue(), aff);
+    launch_small<1, true>(gs, A, B, C, bias, sums, BnBwdEpilogue(), aff, stream);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
@@ -903,8 +974,7 @@ extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int
   if (g.m_tiles <= kStatsDirectTiles) {
     if (gemm_nt_small_tiles(M, N)) {
       const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
-      gemm_nt_kernel<false, 3, false, 64><<<gemm_nt_grid(gs), 256, 0, (hipStream_t)stream>>>(
-          gs, (const bf16_t *)A, (const bf16_t *)B, C, nullptr, sums, bn);
+      launch_small<3, false>(gs, A, B, C, nullptr, sums, bn, AffineIn(), stream);
     } else {
       gemm_nt_kernel<false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
                                                                   nullptr, sums, bn);
@@ -1018,8 +1088,7 @@ extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int 
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
   if (gemm_nt_small_tiles(M, N)) {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
-    gemm_nt_kernel<false, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
-        g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+    launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
     gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
@@ -1043,8 +1112,7 @@ extern "C" int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int ld
     return gemm_nt_splitk_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, workspace, slabs, stream);
   if (gemm_nt_small_tiles(M, N)) {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
-    gemm_nt_kernel<false, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
-        g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+    launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
     gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
