@@ -41,6 +41,9 @@ int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d, void *out
 
 /* out16 [n] bf16 = bf16(a + b):  a f32 or bf16 (a_is_f32), b bf16. */
 int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16, void *stream);
+/* x f32 / bf16 [n][cin] with row pitch ldx -> out16 bf16 [n][k], columns cin .. k-1 zero (a narrow input widened to the row
+ * GEMMs' operand width: torch's .to(bf16) + F.pad is three launches) */
+int omnipq_pad_rows_bf16(long long n, int cin, int k, long long ldx, const void *x, int x_is_f32, void *out16, void *stream);
 
 /* Object prediction head after its output GEMM (models/pq_transformer.py:35-59 `decode_scores`, :86-89): row
  * r = (batch, proposal), y[r] = [objectness 2 | centre 3 | heading scores nh | heading residuals nh | size scores ns |

@@ -391,6 +391,38 @@ extern "C" int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d
   return OMNIPQ_OK;
 }
 
+namespace omnipq {
+// rows f32 / bf16 [n][cin] (row pitch ldx elements) -> bf16 [n][k], columns cin..k-1 zero: the operand the row GEMMs want
+// from a narrow input (3 coordinates -> 32 columns), in one launch instead of cast + zero fill + strided copy
+template <bool F32>
+__global__ __launch_bounds__(256) void pad_rows_bf16_kernel(long long total, int cin, int k, long long ldx,
+                                                            const void *__restrict__ x, bf16_t *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i / k;
+  const int c = (int)(i - r * k);
+  float v = 0.f;
+  if (c < cin) v = F32 ? reinterpret_cast<const float *>(x)[r * ldx + c] : (float)reinterpret_cast<const bf16_t *>(x)[r * ldx + c];
+  out[i] = (bf16_t)v;
+}
+}  // namespace omnipq
+
+extern "C" int omnipq_pad_rows_bf16(long long n, int cin, int k, long long ldx, const void *x, int x_is_f32, void *out16,
+                                    void *stream) {
+  using namespace omnipq;
+  if (n < 0 || cin < 0 || k < cin || k <= 0 || ldx < cin) return OMNIPQ_EINVAL;
+  if (n == 0) return OMNIPQ_OK;
+  if (!x || !out16) return OMNIPQ_EINVAL;
+  const long long total = n * k;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (x_is_f32)
+    pad_rows_bf16_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(total, cin, k, ldx, x, (bf16_t *)out16);
+  else
+    pad_rows_bf16_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(total, cin, k, ldx, x, (bf16_t *)out16);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
 extern "C" int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16,
                                   void *stream) {
   using namespace omnipq;

@@ -171,8 +171,15 @@ def run(layer, query, key, query_pos, key_pos, kv=None):
     x32 = _rows(query).float()
     q_pe = _rows(layer.self_posembed(query_pos)).to(torch.bfloat16)
 
-    # self attention: q = k = v = x + q_pe (transformer.py:203-205)
-    qk = AddToBf16.apply(x32, q_pe)
+    # self attention: q = k = v = x + q_pe (transformer.py:203-205).  When the previous layer left its bf16 twin the sum is
+    # formed from that: the gradient of this branch then reaches the twin as the bf16 tensor it is (added to the twin's other
+    # gradients inside that layer's LayerNorm backward kernel) instead of a cast to f32 and an f32 add into x32's gradient
+    x16_in = getattr(query, "omnipq_rows16", None)
+    if x16_in is not None and x16_in.is_contiguous() and tuple(x16_in.shape) == (B, Pq, C) and \
+            x16_in.requires_grad == x32.requires_grad:
+        qk = AddToBf16.apply(x16_in.view(B * Pq, C), q_pe)
+    else:
+        qk = AddToBf16.apply(x32, q_pe)
     qkv = linear(qk, sa.in_proj_weight, sa.in_proj_bias)
     att = fused_attention.PackedAttention.apply(qkv, None, Pq, Pq, B, H, p_attn)
     y = linear(att, sa.out_proj.weight, sa.out_proj.bias)

@@ -81,6 +81,17 @@ def conv1x1(x, conv):
     return lin(rows(x), conv).view(B, K, -1).transpose(1, 2)
 
 
+_JOINT_HEADS = os.environ.get("OMNIPQ_JOINT_HEADS", "1") != "0"
+
+
+def _rows_of(heads):
+    out, r = [], 0
+    for h in heads:
+        out.append((h, r, r + h.weight.shape[0]))
+        r += h.weight.shape[0]
+    return out
+
+
 def head_stack(self, net, heads, net_rows=None, raw=False):
     """Trunk (2 x Conv1d+BN+ReLU) and every 1x1 output head of a prediction head on (B, C, K) features.
     The output heads share one GEMM over their concatenated weights.  -> list of (B, K, C_h) tensors, i.e.
@@ -89,13 +100,24 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
     `net` when given -- the kernels want bf16 rows anyway, this saves the cast forth and back."""
     B, K = net.shape[0], net.shape[2]
     x = rows(net) if net_rows is None else net_rows.reshape(B * K, -1)
-    w = sa_fused.cat_params([h.weight.squeeze(-1) for h in heads])
+    # the output heads' weights / biases live as row ranges of one joint matrix / vector (re-seated once, then only pointer
+    # checks): the concatenation every step cost two copy launches per prediction head
+    if _JOINT_HEADS and net.is_cuda:
+        w = sa_fused.joint_params(self, "w", [h.weight for h in heads]).squeeze(-1)
+        w.omnipq_parts = [(h.weight, r0, r1) for (_, r0, r1), h in zip(_rows_of(heads), heads)]
+        w.omnipq_persistent = True                       # the joint buffer's address outlives the step: weight arena
+    else:
+        w = sa_fused.cat_params([h.weight.squeeze(-1) for h in heads])
     stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
              rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2), rows_mlp.Layer(w, None)]
     if rows_mlp.usable(x, stack, self.training):
         # hand-written MFMA / BN kernels; with `raw` the consumer takes the kernels' zero-padded rows as they are
         width = w.shape[0]
-        stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=(width + 31) // 32 * 32 if raw else None)
+        pad_to = (width + 31) // 32 * 32 if raw else None
+        if _JOINT_HEADS and net.is_cuda:
+            stack[2].bias = sa_fused.joint_params(self, "b_raw" if raw else "b", [h.bias for h in heads], pad_to=pad_to)
+        else:
+            stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=pad_to)
         y = rows_mlp.run(x, stack, self.training, padded=raw)
     else:
         x = F.relu(self.bn1(lin(x, self.conv1)))

@@ -111,6 +111,10 @@ class RowsMLP(torch.autograd.Function):
         else:
             if K == cin:
                 X = x.detach().to(torch.bfloat16).contiguous()
+            elif x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1:
+                X = torch.empty((N, K), device=x.device, dtype=torch.bfloat16)          # cast + zero padding in one launch
+                _call(_lib.omnipq_pad_rows_bf16, x, ctypes.c_longlong(N), cin, K, ctypes.c_longlong(x.stride(0)), _p(x),
+                      int(x.dtype == torch.float32), _p(X))
             else:
                 X = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (0, K - cin))
             if X.data_ptr() != x.data_ptr() and not x.requires_grad:

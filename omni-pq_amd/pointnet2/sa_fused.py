@@ -421,6 +421,76 @@ def cat_params(tensors, dim=0, pad_to=None):
     return out
 
 
+class _JointRows(torch.autograd.Function):
+    """The joint buffer as the concatenation of its parts for autograd: no kernel in either direction (forward returns the
+    buffer the parameters already live in, backward hands each parameter its rows of the joint gradient as a view)."""
+
+    @staticmethod
+    def forward(ctx, joint, *parts):
+        ctx.meta = [(p.shape, p.shape[0]) for p in parts]
+        # inside deferred_wgrads the consumer returns no gradient for the joint matrix: an undefined gradient must stay
+        # undefined (the default would hand this node a zero tensor, and every parameter a zero .grad to be added to later)
+        ctx.set_materialize_grads(False)
+        return joint.view(joint.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * (1 + len(ctx.meta))
+        out, r = [], 0
+        for shape, n in ctx.meta:
+            out.append(g[r:r + n].reshape(shape))
+            r += n
+        return (None, *out)
+
+
+def joint_params(owner, name, params, pad_to=None):
+    """cat_params without the per-step copy: the parameters (the 1x1 output heads of a prediction head, which share one
+    GEMM) are re-seated ONCE as row ranges of a joint buffer kept on `owner` -- `param.data` becomes a view of it, so
+    optimizer steps, load_state_dict and the EMA update write straight into the joint matrix -- and every later call only
+    checks the pointers.  A module moved or copied since (`.to()`, deepcopy) fails the check and is re-seated.  The result
+    carries the same `omnipq_parts` as cat_params (deferred weight gradients find their targets) and, outside
+    `deferred_wgrads`, routes the joint gradient back to the parameters through autograd as views.
+    pad_to: rows of zeros appended once (a bias vector for a padded GEMM)."""
+    cache = owner.__dict__.setdefault("_omnipq_joint", {})
+    rows = sum(p.shape[0] for p in params)
+    total = pad_to if (pad_to is not None and pad_to > rows) else rows
+    inner = tuple(params[0].shape[1:])
+    width = 1
+    for d in inner:
+        width *= d
+    joint = cache.get(name)
+
+    def seated():
+        if joint is None or joint.shape[0] != total or joint.device != params[0].device or joint.dtype != params[0].dtype:
+            return False
+        off = 0
+        for p in params:
+            if not p.is_contiguous() or tuple(p.shape[1:]) != inner or \
+                    p.data_ptr() != joint.data_ptr() + off * width * joint.element_size():
+                return False
+            off += p.shape[0]
+        return True
+
+    if not seated():
+        with torch.no_grad():
+            joint = torch.zeros((total,) + inner, device=params[0].device, dtype=params[0].dtype)
+            off = 0
+            for p in params:
+                joint[off:off + p.shape[0]].copy_(p.detach())
+                p.data = joint[off:off + p.shape[0]]
+                off += p.shape[0]
+        cache[name] = joint
+    flat = [p for p in params]
+    out = _JointRows.apply(joint, *flat) if torch.is_grad_enabled() and any(p.requires_grad for p in flat) else joint
+    parts, r = [], 0
+    for p in params:
+        parts.append((p, r, r + p.shape[0]))
+        r += p.shape[0]
+    out.omnipq_parts = parts
+    return out
+
+
 def grad_target(t):
     """Where a gradient of `t` may be written behind autograd's back, or None:
     ("param", parameter, element offset)   `t` is a leaf Parameter or a contiguous view of a contiguous one (a row
@@ -778,7 +848,9 @@ def arena_of(model):
 
 
 def is_persistent(W):
-    """A Parameter or a view of one: its storage (hence its address) outlives the step."""
+    """A Parameter, a view of one, or a joint_params buffer: its storage (hence its address) outlives the step."""
+    if getattr(W, "omnipq_persistent", False):
+        return True
     root = W._base if W._base is not None else W
     return isinstance(root, torch.nn.Parameter)
 

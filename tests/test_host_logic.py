@@ -124,3 +124,47 @@ def test_bench_accounting_helpers(built_lib):
     assert bench.workload_name(ns(batch=8, points=40000, extra_channels=0)) == "BASELINE configs[1]"
     assert bench.workload_name(ns(batch=4, points=50000, extra_channels=6)) == "BASELINE configs[3]"
     assert bench.workload_name(ns(batch=2, points=1000, extra_channels=0)) == "custom configuration"
+
+
+def test_joint_params_reseat_once_and_stay_consistent():
+    """sa_fused.joint_params: the output heads of a prediction head as row ranges of one joint matrix -- seated once, then only
+    pointer checks; optimizer steps, load_state_dict and deepcopy keep working on the separate Parameters."""
+    import copy
+    import sa_fused
+
+    class Owner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.heads = torch.nn.ModuleList(torch.nn.Conv1d(16, n, 1) for n in (2, 3, 5))
+
+    own = Owner()
+    before = [h.weight.detach().clone() for h in own.heads]
+    w = sa_fused.joint_params(own, "w", [h.weight for h in own.heads])
+    joint = own._omnipq_joint["w"]
+    assert tuple(w.shape) == (10, 16, 1) and torch.equal(w.detach(), torch.cat(before))
+    assert sa_fused.joint_params(own, "w", [h.weight for h in own.heads]).data_ptr() == joint.data_ptr()   # no second copy
+    assert w.omnipq_parts[1][0] is own.heads[1].weight and w.omnipq_parts[1][1:] == (2, 5)
+    # gradients reach the separate Parameters through autograd (outside deferred_wgrads) ...
+    (w * torch.arange(10.0).view(10, 1, 1)).sum().backward()
+    assert torch.equal(own.heads[1].weight.grad, torch.arange(2.0, 5.0).view(3, 1, 1).expand(3, 16, 1))
+    # ... an optimizer step on them lands in the joint matrix, and so does load_state_dict
+    torch.optim.SGD(own.parameters(), lr=1.0).step()
+    assert torch.equal(joint[2:5], own.heads[1].weight.detach()) and not torch.equal(joint[2:5], before[1])
+    state = {k: torch.full_like(v, 0.25) for k, v in own.state_dict().items()}
+    own.load_state_dict(state)
+    assert float(joint.min()) == 0.25 and float(joint.max()) == 0.25
+    assert sa_fused.joint_params(own, "w", [h.weight for h in own.heads]).data_ptr() == joint.data_ptr()
+    # a copy of the module has its own storage: it is re-seated on first use, the original is untouched
+    twin = copy.deepcopy(own)
+    twin.__dict__.pop("_omnipq_joint", None)
+    w2 = sa_fused.joint_params(twin, "w", [h.weight for h in twin.heads])
+    assert w2.data_ptr() != joint.data_ptr() and torch.equal(w2.detach(), joint)
+    # padded bias vector: zeros appended once
+    b = sa_fused.joint_params(own, "b", [h.bias for h in own.heads], pad_to=32)
+    assert tuple(b.shape) == (32,) and float(b[10:].abs().sum()) == 0.0
+    # an undefined gradient stays undefined (deferred weight gradients): no zero .grad is materialised
+    for p in own.parameters():
+        p.grad = None
+    x = sa_fused.joint_params(own, "w", [h.weight for h in own.heads])
+    (x.detach().sum() + own.heads[0].bias.sum()).backward()
+    assert all(h.weight.grad is None for h in own.heads)
