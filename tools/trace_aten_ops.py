@@ -15,6 +15,7 @@ step,_=bench.make_step(net,net,pool,args,torch.bfloat16,1)
 for i in range(3): step(i)
 torch.cuda.synchronize()
 agg=collections.defaultdict(lambda:[0,0])
+shapes=collections.Counter()
 WATCH=("copy_","_to_copy","clone","cat","fill_","zeros","add","div","mul","zero_")
 class M(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -29,6 +30,8 @@ class M(TorchDispatchMode):
             n=0
             if torch.is_tensor(out): n=out.numel()*out.element_size()
             agg[(base,fr)][0]+=1; agg[(base,fr)][1]+=n
+            if fr=="?" and os.environ.get("TRACE_SHAPES"):
+                shapes[(base,tuple(out.shape),str(out.dtype).replace("torch.",""))]+=1
         return out
 with M():
     step(0)
@@ -39,3 +42,8 @@ for (b,fr),(c,n) in agg.items(): byfile[fr.split(":")[0]]+=c
 print(sorted(byfile.items(), key=lambda kv:-kv[1]))
 for (b,fr),(c,n) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:70]:
     print(f"{c:5d}x {n/1e6:9.2f} MB  {b:10s} {fr}")
+
+if shapes:
+    print("ops issued from autograd's backward (no repo frame), by shape:")
+    for (b,sh,dt),c in shapes.most_common(40):
+        print(f"{c:5d}x  {b:10s} {dt:9s} {sh}")
