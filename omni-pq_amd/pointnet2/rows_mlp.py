@@ -235,15 +235,27 @@ class RowsMLP(torch.autograd.Function):
             if Xin is None:                    # rebuilt from the layer's pre-BN output inside the GEMM
                 below = layers[l - 1]
                 Xin = below.Y
+            fused = None                       # (dprev, next sums): the data-gradient GEMM already ran, with dY generated
             if lay.has_bn:
                 if sums is None:
                     sums = zeros_f64(3, lay.C, dev)
                     _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
                           _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
-                dst = dcur if owned else torch.empty_like(dcur)
-                grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums, world,
-                                                                                out=dst)
-                dcur, owned = dst, True
+                follows = l > 0 or ctx.needs_input_grad[0]
+                if sa_fused.DYGEN and follows and lay.Cp == lay.C and lay.C <= sa_fused.DYGEN_MAX_K and lay.Y is not None:
+                    # BatchNorm backward generated inside the data-gradient GEMM (no apply pass): dY comes back for the
+                    # weight gradient below
+                    below_bn = layers[l - 1] if (l > 0 and layers[l - 1].has_bn) else None
+                    nsums = zeros_f64(3, lay.K, dev) if below_bn is not None else None
+                    dprev, dcur, grads[4 * l + 2], grads[4 * l + 3] = sa_fused.gemm_nt_dygen(
+                        dcur, lay, N, sums, world, lay.Wt, lay.K, below=below_bn, below_sums=nsums)
+                    owned = True
+                    fused = (dprev, nsums)
+                else:
+                    dst = dcur if owned else torch.empty_like(dcur)
+                    grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums,
+                                                                                    world, out=dst)
+                    dcur, owned = dst, True
                 if lay.has_bias:
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
             elif lay.act is not None:
@@ -266,7 +278,13 @@ class RowsMLP(torch.autograd.Function):
                 dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum, below=below)
                 grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None
-            if l > 0 and layers[l - 1].has_bn:
+            if fused is not None:
+                dprev, sums = fused
+                if l > 0:
+                    dcur, owned = dprev, True
+                else:
+                    dx = dprev[:, :cin].to(ctx.in_dtype)
+            elif l > 0 and layers[l - 1].has_bn:
                 sums = zeros_f64(3, lay.K, dev)
                 dprev = _gemm_nt_bnbwd(dcur, lay.Wt, N, lay.K, lay.Cp, layers[l - 1], sums)
                 dcur, owned = dprev, True

@@ -236,6 +236,47 @@ def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     return C
 
 
+# BatchNorm backward without its own pass: the data-gradient GEMM of a conv+BN+ReLU layer generates dY = a (dz - mean(dz) -
+# yhat mean(dz yhat)) from (dX, Y) while it stages its operand and stores it for the weight gradient (csrc/gemm_bf16.hip:
+# DyGen).  OPT-IN (OMNIPQ_DYGEN=rows: the per-point stacks outside the SA stages, =all: the SA stages too), because measured
+# on MI355X, config 2, it does not pay: 28 apply launches of 9 us go, but the data-gradient GEMMs of the small stacks grow
+# from 10 to 15 us (prologue with the f64 totals, a second operand stream, every N-tile workgroup regenerating its rows: 5 x
+# at N = 288), and inside the SA stages the generator sits in the latency-critical K loop of the 128 x 128 tiles
+# (262144 x 256 x 256: 182 us against 112 + 42 for GEMM + apply).  Whole step as a hipGraph replay: 13.25 ms (rows),
+# 13.20 (all) against 13.12-13.16 with the separate apply pass.
+_DYGEN_MODE = os.environ.get("OMNIPQ_DYGEN", "0")
+DYGEN = _DYGEN_MODE in ("rows", "all", "1")
+DYGEN_SA = _DYGEN_MODE == "all"
+DYGEN_MAX_K = 512
+
+
+def gemm_nt_dygen(dX, lay, P, sums, world, Wt, N, below=None, below_sums=None):
+    """-> (dX_below bf16 [P][N], dY bf16 [P][C], dgamma, dbeta): the BatchNorm backward of `lay` (constants, pre-BN output
+    lay.Y, totals `sums` of THIS rank) fused into its data-gradient GEMM against Wt [N][C]; with `below`, the BN-backward
+    sums of that layer come out of the epilogue into below_sums (zero on entry)."""
+    C = lay.C
+    dev = dX.device
+    if world > 1 or _FORCE_COLLECTIVES:
+        dgamma, dbeta = affine_grads(sums, C)
+        _allreduce_(sums[:2], world)
+        gb = None
+    else:
+        gb = torch.empty((2, C), device=dev, dtype=torch.float32)
+        dgamma, dbeta = gb[1], gb[0]
+    dY = torch.empty((P, C), device=dev, dtype=torch.bfloat16)
+    out = torch.empty((P, N), device=dev, dtype=torch.bfloat16)
+    ws = None
+    if below is not None:
+        n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(P, N))
+        ws = torch.empty((n_ws,), device=dev, dtype=torch.float32) if n_ws else None
+    _call(_lib.omnipq_gemm_nt_bf16_dygen, dX, P, N, C, _p(dX), _p(lay.Y), C, _p(lay.a), _p(lay.b), _p(lay.mean),
+          _p(lay.invstd), _p(sums), ctypes.c_double(1.0 / (float(P) * world)), _p(dY), _p(gb), _p(Wt), C, _p(out), N,
+          _p(None if below is None else below.Y), _p(None if below is None else below.a),
+          _p(None if below is None else below.b), _p(None if below is None else below.mean),
+          _p(None if below is None else below.invstd), _p(below_sums), _p(ws))
+    return out, dY, dgamma, dbeta
+
+
 def _gemm_tn(A, B, M, N, P, colsum=None, below=None):
     """f32 C[M][N] = A[P][M]^T B[P][N]; colsum (f32 [M], zero on entry): also += column sums of A;
     below: B is that layer's pre-BN output and stands for relu(below.a * B + below.b)"""
@@ -1345,9 +1386,30 @@ class FusedSAStage(torch.autograd.Function):
                   _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
 
         d_feat = d_xyz = d_cen = None
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (ctx.has_features and ctx.needs_input_grad[2])
+        xgen = getattr(ctx, "xgen", False)
+        pend = None                  # BatchNorm-backward totals of layer l when `dY` still holds dX (gradient w.r.t. its ReLU output)
         for l in range(top, -1, -1):
             lay = layers[l]
-            if l == 1 and getattr(ctx, "xgen", False):
+            dX_in = None             # the data gradient of this layer, if the fused GEMM below already produced it
+            if pend is not None:
+                follows = l > 0 or need_in
+                if DYGEN_SA and follows and lay.C <= DYGEN_MAX_K and not (xgen and l == 1):
+                    # BatchNorm backward generated inside this layer's data-gradient GEMM (DyGen): no apply pass
+                    prev = layers[l - 1] if l > 0 else None
+                    nsums = zeros_f64(3, prev.C, dev) if (prev is not None and not (xgen and l - 1 == 0)) else None
+                    if l > 0 and nsums is None:
+                        prev = None                      # cannot happen: l == 1 under xgen is excluded above
+                    dX_in, dY, grads[3 * l + 1], grads[3 * l + 2] = gemm_nt_dygen(
+                        dY, lay, P, pend, world, lay.Wt, lay.K, below=prev, below_sums=nsums)
+                    pend = nsums
+                else:
+                    grads[3 * l + 1], grads[3 * l + 2] = bn_backward_apply(dY, lay, P, lay.C, total, pend, world)
+                    pend = None
+                fused_here = dX_in is not None
+            else:
+                fused_here = False
+            if l == 1 and xgen:
                 # the layer below is the never-materialised first layer (see XYZGEN): this layer's weight gradient
                 # contracts against activations rebuilt from the grouped coordinates, and the data-gradient GEMM is
                 # reduced to the five column sums the first layer's dW / dgamma / dbeta follow from
@@ -1380,20 +1442,18 @@ class FusedSAStage(torch.autograd.Function):
             grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
             if l == 0 and ctx.cin_raw != cin:
                 grads[0] = grads[0][:, :ctx.cin_raw + 3].contiguous()       # drop the padded feature columns
-            need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \
-                (ctx.has_features and ctx.needs_input_grad[2])
             if l == 0 and not need_in:
                 break
             if l > 0:
-                prev = layers[l - 1]
-                sums = zeros_f64(3, prev.C, dev)
-                # Wt = [K][Cout]; the BN-backward sums of the layer below come out of the same pass
-                dX = _gemm_nt_bnbwd(dY, lay.Wt, P, lay.K, lay.C, prev, sums)
-                grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = bn_backward_apply(
-                    dX, prev, P, prev.C, total, sums, world)
-                dY = dX
+                if fused_here:
+                    dY = dX_in                                   # dX of layer l - 1; its totals are `pend`
+                else:
+                    prev = layers[l - 1]
+                    pend = zeros_f64(3, prev.C, dev)
+                    # Wt = [K][Cout]; the BN-backward sums of the layer below come out of the same pass
+                    dY = _gemm_nt_bnbwd(dY, lay.Wt, P, lay.K, lay.C, prev, pend)
             else:
-                dX = _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)
+                dX = dX_in if fused_here else _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)
                 want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
                 dfeat_pm = torch.empty((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
                     else None
