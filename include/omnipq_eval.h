@@ -34,6 +34,23 @@ int omnipq_parse_quads(int b, int k, const float *quad_center, const float *norm
 int omnipq_nms3d(int b, int k, const double *aabb, const float *score, const unsigned char *valid,
                  double overlap_threshold, int old_type, unsigned char *keep, void *stream);
 
+/* The same with suppression restricted to boxes of the same class (utils/nms.py:115-158 `nms_3d_faster_samecls`):
+ * cls (b, k) int32.  2D suppression (`nms_2d_faster`, :44-75) is this kernel on extents whose second axis is [0, 1]. */
+int omnipq_nms3d_samecls(int b, int k, const double *aabb, const float *score, const unsigned char *valid, const int *cls,
+                         double overlap_threshold, int old_type, unsigned char *keep, void *stream);
+
+/* Corners (n, 8, 3) f64 in the upright-camera frame and extents (n, 6) f64 of n oriented boxes, utils/box_util.py:218-233
+ * `get_3d_box(box_size, heading_angle, center)`: center (n, 3) f32 in the depth frame (flipped here as
+ * ap_helper_pq.py:24-32 does), size (n, 3) f64 (l, w, h), heading (n) f32 or NULL (axis aligned).  For the object half of
+ * the evaluation (models/ap_helper_pq.py:73-266 `parse_predictions`, `parse_groundtruths`). */
+int omnipq_box_corners(long long n, const float *center, const double *size, const float *heading, double *corners8,
+                       double *aabb, void *stream);
+
+/* nonempty (b, k) u8 = the box holds at least min_points of its scene's points xyz (b, n, 3) -- `remove_empty_box`,
+ * ap_helper_pq.py:127-139, where every box costs a Delaunay triangulation and a point-location query over the scene. */
+int omnipq_points_in_boxes(int b, int n, int k, const float *xyz, const float *center, const double *size,
+                           const float *heading, int min_points, unsigned char *nonempty, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

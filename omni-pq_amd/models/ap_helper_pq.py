@@ -1,7 +1,10 @@
 """Evaluation-side consumer of the layout branch -- the reference's `models/ap_helper_pq.py` quad half on the kernels of
 csrc/eval_ops.hip.  Same names, arguments and return values:
 
-    parse_quad_predictions(end_points, config_dict, prefix="")      ap_helper_pq.py:323-460
+    parse_predictions(end_points, config_dict, prefix="")           ap_helper_pq.py:73-236
+    parse_groundtruths(end_points, config_dict)                     :239-281
+    APCalculator(ap_iou_thresh, class2type_map)                     :520-575   (step / compute_metrics / reset)
+    parse_quad_predictions(end_points, config_dict, prefix="")      :323-460
     parse_quad_groundtruths(end_points, config_dict)                :462-517
     QUADAPCalculator(ap_iou_thresh, class2type_map, logger, logger_i)   :579-742   (step / compute_metrics / compute_F1 / reset)
 
@@ -125,6 +128,204 @@ def parse_quad_groundtruths(end_points, config_dict):
     return batch_gt_map_cls, batch_gt_corners_list
 
 
+# ------------------------------------------------------------------------------------------------------- object boxes
+def _heading_rule(dataset_config):
+    """How the dataset config turns (heading class, residual) into an angle: ScanNet's returns 0 for everything (axis-aligned
+    boxes, scannet/model_util_scannet.py:49-53), SUN RGB-D style configs return class * 2 pi / N + residual folded into
+    (-pi, pi].  Probed once per config object; anything else is refused rather than guessed."""
+    rule = getattr(dataset_config, "_omnipq_heading_rule", None)
+    if rule is None:
+        nb = int(dataset_config.num_heading_bin)
+        probe = [float(dataset_config.class2angle(np.int64(c), np.float32(r))) for c, r in ((0, 0.25), (max(nb - 1, 0), -0.1))]
+        if all(v == 0.0 for v in probe):
+            rule = "zero"
+        else:
+            per = 2 * np.pi / nb
+            want = []
+            for c, r in ((0, 0.25), (max(nb - 1, 0), -0.1)):
+                a = c * per + r
+                want.append(a - 2 * np.pi if a > np.pi else a)
+            if np.allclose(probe, want, atol=1e-6):
+                rule = "bins"
+            else:
+                raise NotImplementedError("ap_helper_pq: unknown class2angle convention of the dataset config")
+        try:
+            dataset_config._omnipq_heading_rule = rule
+        except Exception:
+            pass
+    return rule
+
+
+def _box_params(center, heading_cls, heading_res, size_cls, size_res, dataset_config):
+    """(B,K,.) device tensors -> center f32 (B,K,3), size f64 (B,K,3) = class2size, heading f32 (B,K) | None."""
+    means = torch.from_numpy(np.asarray(dataset_config.mean_size_arr, dtype=np.float64)).to(center.device)
+    size = means[size_cls] + size_res.double()
+    heading = None
+    if _heading_rule(dataset_config) == "bins":
+        per = 2 * np.pi / int(dataset_config.num_heading_bin)
+        ang = heading_cls.double() * per + heading_res.double()
+        heading = torch.where(ang > np.pi, ang - 2 * np.pi, ang).float().contiguous()
+    return center.detach().float().contiguous(), size.contiguous(), heading
+
+
+def _corners(center, size, heading):
+    B, K, _ = center.shape
+    corners8 = torch.empty((B, K, 8, 3), device=center.device, dtype=torch.float64)
+    aabb = torch.empty((B, K, 6), device=center.device, dtype=torch.float64)
+    null = ctypes.c_void_p(0)
+    _ext._run(_lib.omnipq_box_corners, center, ctypes.c_longlong(B * K), _ext._ptr(center), _ext._ptr(size),
+              null if heading is None else _ext._ptr(heading), _ext._ptr(corners8), _ext._ptr(aabb))
+    return corners8, aabb
+
+
+def parse_predictions(end_points, config_dict, prefix=""):
+    """ Parse predictions to OBB parameters and suppress overlapping boxes
+
+    Args:
+        end_points: dict
+            {point_clouds, center, heading_scores, heading_residuals,
+            size_scores, size_residuals, sem_cls_scores, objectness_scores} under `prefix`
+        config_dict: dict
+            {dataset_config, remove_empty_box, use_3d_nms, nms_iou,
+            use_old_type_nms, cls_nms, conf_thresh, per_class_proposal}
+
+    Returns:
+        batch_pred_map_cls: a list of len == batch size (BS)
+            [pred_list_i], i = 0, 1, ..., BS-1
+            where pred_list_i = [(pred_sem_cls, box corners (8,3), box_score)_j]
+        pred_mask: (BS, K) numpy array, 1 for the boxes NMS kept
+    """
+    DC = config_dict['dataset_config']
+    center = _f32(end_points[f'{prefix}center'], 'center')
+    heading_cls = torch.argmax(end_points[f'{prefix}heading_scores'], -1)
+    heading_res = torch.gather(end_points[f'{prefix}heading_residuals'].detach(), 2, heading_cls.unsqueeze(-1)).squeeze(2)
+    size_cls = torch.argmax(end_points[f'{prefix}size_scores'], -1)
+    size_res = torch.gather(end_points[f'{prefix}size_residuals'].detach(), 2,
+                            size_cls[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+    sem_scores = end_points[f'{prefix}sem_cls_scores'].detach().float()
+    pred_sem_cls = torch.argmax(sem_scores, -1)
+    center, size, heading = _box_params(center, heading_cls, heading_res, size_cls, size_res, DC)
+    corners8_t, aabb = _corners(center, size, heading)
+    B, K = center.shape[:2]
+    dev = center.device
+    null = ctypes.c_void_p(0)
+
+    valid = None
+    if config_dict['remove_empty_box']:
+        pc = _f32(end_points['point_clouds'][:, :, 0:3], 'point_clouds')
+        valid = torch.empty((B, K), device=dev, dtype=torch.uint8)
+        _ext._run(_lib.omnipq_points_in_boxes, pc, B, pc.shape[1], K, _ext._ptr(pc), _ext._ptr(center), _ext._ptr(size),
+                  null if heading is None else _ext._ptr(heading), 5, _ext._ptr(valid))
+    obj_prob_t = torch.sigmoid(end_points[f'{prefix}objectness_scores'].detach().float())[:, :, 1].contiguous()
+    keep = torch.empty((B, K), device=dev, dtype=torch.uint8)
+    vptr = null if valid is None else _ext._ptr(valid)
+    thr, old = ctypes.c_double(float(config_dict['nms_iou'])), int(bool(config_dict['use_old_type_nms']))
+    if not config_dict['use_3d_nms']:
+        # bird's-eye-view suppression on (x, z) extents: the 3D kernel with a unit second axis
+        flat = aabb.clone()
+        flat[..., 1] = 0.0
+        flat[..., 4] = 1.0
+        _ext._run(_lib.omnipq_nms3d, center, B, K, _ext._ptr(flat), _ext._ptr(obj_prob_t), vptr, thr, old, _ext._ptr(keep))
+    elif not config_dict['cls_nms']:
+        _ext._run(_lib.omnipq_nms3d, center, B, K, _ext._ptr(aabb), _ext._ptr(obj_prob_t), vptr, thr, old, _ext._ptr(keep))
+    else:
+        cls32 = pred_sem_cls.int().contiguous()
+        _ext._run(_lib.omnipq_nms3d_samecls, center, B, K, _ext._ptr(aabb), _ext._ptr(obj_prob_t), vptr, _ext._ptr(cls32),
+                  thr, old, _ext._ptr(keep))
+
+    # one transfer per array; the ragged lists are host data by nature
+    corners8 = corners8_t.cpu().numpy()
+    keep_h = keep.cpu().numpy().astype(bool)
+    obj_prob = obj_prob_t.cpu().numpy()
+    sem_probs = torch.softmax(sem_scores, -1).cpu().numpy()
+    sem_cls_h = pred_sem_cls.cpu().numpy()
+    if config_dict['use_3d_nms'] and not config_dict['cls_nms']:
+        assert all(keep_h[i].any() for i in range(B))                     # the reference asserts len(pick) > 0 here only
+    pred_mask = keep_h.astype(np.float64)
+    conf = config_dict['conf_thresh']
+    batch_pred_map_cls = []
+    for i in range(B):
+        sel = [j for j in range(K) if keep_h[i, j] and obj_prob[i, j] > conf]
+        if config_dict['per_class_proposal']:
+            batch_pred_map_cls.append([(ii, corners8[i, j], sem_probs[i, j, ii] * obj_prob[i, j])
+                                       for ii in range(DC.num_class) for j in sel])
+        else:
+            batch_pred_map_cls.append([(int(sem_cls_h[i, j]), corners8[i, j], obj_prob[i, j]) for j in sel])
+    return batch_pred_map_cls, pred_mask
+
+
+def parse_groundtruths(end_points, config_dict):
+    """ Parse groundtruth labels to OBB parameters.
+
+    Returns:
+        batch_gt_map_cls: a list of len == batch_size (BS) of [(gt_sem_cls, box corners (8,3))_j] over the boxes whose
+        box_label_mask is 1
+    """
+    DC = config_dict['dataset_config']
+    center = _f32(end_points['center_label'][:, :, 0:3], 'center_label')
+    center, size, heading = _box_params(center, end_points['heading_class_label'].long(),
+                                        end_points['heading_residual_label'].float(),
+                                        end_points['size_class_label'].long(), end_points['size_residual_label'].float(), DC)
+    corners8 = _corners(center, size, heading)[0].cpu().numpy()
+    mask = end_points['box_label_mask'].detach().cpu().numpy()
+    sem = end_points['sem_cls_label'].detach().cpu().numpy()
+    B, K2 = mask.shape
+    batch_gt_map_cls = [[(int(sem[i, j]), corners8[i, j]) for j in range(K2) if mask[i, j] == 1] for i in range(B)]
+    end_points['batch_gt_map_cls'] = batch_gt_map_cls
+    return batch_gt_map_cls
+
+
+class APCalculator(object):
+    ''' Calculating Average Precision '''
+
+    def __init__(self, ap_iou_thresh=0.25, class2type_map=None):
+        """
+        Args:
+            ap_iou_thresh: float between 0 and 1.0
+                IoU threshold to judge whether a prediction is positive.
+            class2type_map: [optional] dict {class_int:class_name}
+        """
+        self.ap_iou_thresh = ap_iou_thresh
+        self.class2type_map = class2type_map
+        self.reset()
+
+    def step(self, batch_pred_map_cls, batch_gt_map_cls):
+        """ Accumulate one batch of prediction and groundtruth (the outputs of the two parse functions). """
+        bsize = len(batch_pred_map_cls)
+        assert (bsize == len(batch_gt_map_cls))
+        for i in range(bsize):
+            self.gt_map_cls[self.scan_cnt] = batch_gt_map_cls[i]
+            self.pred_map_cls[self.scan_cnt] = batch_pred_map_cls[i]
+            self.scan_cnt += 1
+
+    def compute_metrics(self):
+        """ Use accumulated predictions and groundtruths to compute Average Precision. """
+        rec, prec, ap = eval_det.eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=self.ap_iou_thresh,
+                                          get_iou_func=eval_det.get_iou_obb)
+        return _metrics_dict(rec, ap, self.class2type_map)
+
+    def reset(self):
+        self.gt_map_cls = {}          # {scan_id: [(classname, bbox)]}
+        self.pred_map_cls = {}        # {scan_id: [(classname, bbox, score)]}
+        self.scan_cnt = 0
+
+
+def _metrics_dict(rec, ap, class2type_map):
+    ret_dict = {}
+    for key in sorted(ap.keys()):
+        clsname = class2type_map[key] if class2type_map else str(key)
+        ret_dict['%s Average Precision' % (clsname)] = ap[key]
+    ret_dict['mAP'] = np.mean(list(ap.values()))
+    rec_list = []
+    for key in sorted(ap.keys()):
+        clsname = class2type_map[key] if class2type_map else str(key)
+        last = rec[key][-1] if np.ndim(rec[key]) and len(rec[key]) else 0
+        ret_dict['%s Recall' % (clsname)] = last
+        rec_list.append(last)
+    ret_dict['AR'] = np.mean(rec_list)
+    return ret_dict
+
+
 class QUADAPCalculator(object):
     ''' Average precision and F1 of the predicted layout quads, accumulated over the scans of an evaluation run '''
 
@@ -159,19 +360,7 @@ class QUADAPCalculator(object):
         """ Average precision / recall of the accumulated quads as oriented boxes (IoU of get_iou_obb). """
         rec, prec, ap = eval_det.eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=self.ap_iou_thresh,
                                           get_iou_func=eval_det.get_iou_obb)
-        ret_dict = {}
-        for key in sorted(ap.keys()):
-            clsname = self.class2type_map[key] if self.class2type_map else str(key)
-            ret_dict['%s Average Precision' % (clsname)] = ap[key]
-        ret_dict['mAP'] = np.mean(list(ap.values()))
-        rec_list = []
-        for key in sorted(ap.keys()):
-            clsname = self.class2type_map[key] if self.class2type_map else str(key)
-            last = rec[key][-1] if np.ndim(rec[key]) and len(rec[key]) else 0
-            ret_dict['%s Recall' % (clsname)] = last
-            rec_list.append(last)
-        ret_dict['AR'] = np.mean(rec_list)
-        return ret_dict
+        return _metrics_dict(rec, ap, self.class2type_map)
 
     def reset(self):
         self.gt_map_cls = {}          # {scan_id: [(classname, bbox)]}

@@ -76,3 +76,60 @@ def nms_3d(aabb, score, overlap_threshold, old_type=False, valid=None):
         o = inter / vol if old_type else inter / (vol[i] + vol - inter)
         alive &= ~(o > overlap_threshold)
     return keep
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# object half: models/ap_helper_pq.py:73-266 (parse_predictions, parse_groundtruths), utils/nms.py:44-75,115-158
+def box_corners(center, size, heading=None):
+    """center (..., 3) f32 depth frame, size (..., 3) f64 (l, w, h), heading (...) f32 | None -> corners8 (..., 8, 3) f64 in
+    the upright-camera frame, aabb (..., 6) f64   (utils/box_util.py:218-233 after flip_axis_to_camera)."""
+    center = np.asarray(center, np.float32)
+    size = np.asarray(size, np.float64)
+    ang = np.zeros(center.shape[:-1], np.float32) if heading is None else np.asarray(heading, np.float32)
+    c = np.cos(ang).astype(np.float32).astype(np.float64)
+    s = np.sin(ang).astype(np.float32).astype(np.float64)
+    cam = np.stack([center[..., 0], -center[..., 2], center[..., 1]], -1).astype(np.float64)
+    sx = np.array([1, 1, -1, -1, 1, 1, -1, -1]) / 2.0
+    sy = np.array([1, 1, 1, 1, -1, -1, -1, -1]) / 2.0
+    sz = np.array([1, -1, -1, 1, 1, -1, -1, 1]) / 2.0
+    x, y, z = size[..., 0:1] * sx, size[..., 2:3] * sy, size[..., 1:2] * sz
+    corners = np.stack([c[..., None] * x + s[..., None] * z + cam[..., None, 0], y + cam[..., None, 1],
+                        -s[..., None] * x + c[..., None] * z + cam[..., None, 2]], -1)
+    return corners, np.concatenate([corners.min(-2), corners.max(-2)], -1)
+
+
+def points_in_boxes(xyz, center, size, heading=None, min_points=5):
+    """xyz (B,N,3), center (B,K,3), size (B,K,3) -> (B,K) bool: at least min_points of the scene's points inside the box."""
+    xyz = np.asarray(xyz, np.float32)
+    center = np.asarray(center, np.float32)
+    half = (np.asarray(size, np.float64) / 2).astype(np.float32)
+    ang = np.zeros(center.shape[:-1], np.float32) if heading is None else np.asarray(heading, np.float32)
+    c, s = np.cos(ang), np.sin(ang)
+    out = np.zeros(center.shape[:2], bool)
+    for b in range(center.shape[0]):
+        d = xyz[b][None, :, :] - center[b][:, None, :]                       # (K,N,3)
+        u = c[b][:, None] * d[..., 0] - s[b][:, None] * d[..., 1]
+        v = s[b][:, None] * d[..., 0] + c[b][:, None] * d[..., 1]
+        inside = (np.abs(u) <= half[b][:, None, 0]) & (np.abs(v) <= half[b][:, None, 1]) & \
+            (np.abs(d[..., 2]) <= half[b][:, None, 2])
+        out[b] = inside.sum(1) >= min_points
+    return out
+
+
+def nms_3d_samecls(aabb, score, cls, overlap_threshold, old_type=False, valid=None):
+    """nms_3d with suppression between boxes of the same class only (utils/nms.py:115-158)."""
+    K = aabb.shape[0]
+    alive = np.ones(K, bool) if valid is None else np.asarray(valid, bool).copy()
+    keep = np.zeros(K, bool)
+    vol = (aabb[:, 3] - aabb[:, 0]) * (aabb[:, 4] - aabb[:, 1]) * (aabb[:, 5] - aabb[:, 2])
+    for i in sorted(range(K), key=lambda j: (score[j], j), reverse=True):
+        if not alive[i]:
+            continue
+        keep[i] = True
+        alive[i] = False
+        lo = np.maximum(aabb[i, :3], aabb[:, :3])
+        hi = np.minimum(aabb[i, 3:], aabb[:, 3:])
+        inter = np.prod(np.maximum(0.0, hi - lo), axis=1)
+        o = inter / vol if old_type else inter / (vol[i] + vol - inter)
+        alive &= ~((o > overlap_threshold) & (np.asarray(cls) == cls[i]))
+    return keep

@@ -191,3 +191,69 @@ def fill_horizontal_from_walls(ep, verts4):
     ep["horizontal_quads"][0, 0] = np.stack([a[0], a[1], b[0], b[1]]) + 0.01
     ep["horizontal_quads"][0, 1] = np.stack([a[2], a[3], b[2], b[3]]) - 0.01
     return ep
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Inputs of the object half of the evaluation (parse_predictions / parse_groundtruths / APCalculator)
+class EvalDatasetConfig:
+    """What parse_predictions reads of ScannetDatasetConfig (scannet/model_util_scannet.py:14-62): class counts, the class
+    mean sizes (synthetic here, see MEAN_SIZE_ARR) and the two decoding methods -- ScanNet boxes are axis aligned, so
+    class2angle returns 0 for everything (:49-53) and class2size adds the class mean (:60-62)."""
+    num_class = NUM_CLASS
+    num_heading_bin = NUM_HEADING_BIN
+    num_size_cluster = NUM_SIZE_CLUSTER
+    mean_size_arr = MEAN_SIZE_ARR
+
+    def class2angle(self, pred_cls, residual, to_label_format=True):
+        return 0
+
+    def class2size(self, pred_cls, residual):
+        return self.mean_size_arr[pred_cls, :] + residual
+
+
+def make_eval_boxes(seed, B=3, K=256, N=4096):
+    """-> dict of numpy arrays: the `last_` object predictions in the form parse_predictions reads them (un-normalised
+    residuals), the scene points, and the ground-truth boxes with their mask.  Classes are dealt round-robin over the
+    batch's ground-truth boxes (>= 24 of them) so that every class has a ground truth: the reference's recall is 0 / 0
+    for a class that only occurs among the predictions."""
+    lab, pred = make(seed, B=B, K=K, KQ=8, num_seed=8, N=16)
+    rs = np.random.RandomState(seed + 2000)
+    f32 = np.float32
+    dealt = 0
+    for b in range(B):
+        for j in range(int(lab["num_gt_boxes"][b, 0])):
+            lab["sem_cls_label"][b, j] = lab["size_class_label"][b, j] = dealt % NUM_CLASS
+            dealt += 1
+    out = {k: lab[k] for k in ("center_label", "heading_class_label", "heading_residual_label", "size_class_label",
+                               "size_residual_label", "sem_cls_label")}
+    n_box = lab["num_gt_boxes"][:, 0]
+    out["box_label_mask"] = (np.arange(MAX_NUM_OBJ)[None, :] < n_box[:, None]).astype(f32)
+    out["last_center"] = pred["last_center"]
+    out["last_heading_scores"] = pred["last_heading_scores"]
+    out["last_heading_residuals"] = (pred["last_heading_residuals_normalized"] * (np.pi / NUM_HEADING_BIN)).astype(f32)
+    out["last_size_scores"] = pred["last_size_scores"]
+    out["last_size_residuals"] = (pred["last_size_residuals_normalized"] * MEAN_SIZE_ARR[None, None]).astype(f32)
+    # semantic scores favour the class of the nearest ground truth, objectness the proposals near one
+    d = ((lab["aggregated_vote_xyz"][:, :, None, :] - lab["center_label"][:, None, :, :]) ** 2).sum(-1)
+    near, idx = np.sqrt(d.min(-1)) < 0.3, d.argmin(-1)
+    sem = rs.randn(B, K, NUM_CLASS)
+    sem[np.arange(B)[:, None], np.arange(K)[None, :], lab["sem_cls_label"][np.arange(B)[:, None], idx]] += 2.5
+    out["last_sem_cls_scores"] = sem.astype(f32)
+    obj = rs.randn(B, K, 2)
+    obj[..., 1] += np.where(near & (idx < n_box[:, None]), 2.5, -1.5)
+    out["last_objectness_scores"] = obj.astype(f32)
+    # scene points: a cloud around every ground-truth box plus clutter, so that some predicted boxes are empty
+    pts = rs.rand(B, N, 3) * np.array([6.0, 5.0, 2.6])
+    for b in range(B):
+        m = N // 2
+        pick = rs.randint(0, n_box[b], size=m)
+        pts[b, :m] = lab["center_label"][b, pick] + 0.25 * rs.randn(m, 3)
+    out["point_clouds"] = pts.astype(f32)
+    return out
+
+
+def eval_config(**overrides):
+    cfg = dict(EVAL_CONFIG)
+    cfg["dataset_config"] = EvalDatasetConfig()
+    cfg.update(overrides)
+    return cfg
