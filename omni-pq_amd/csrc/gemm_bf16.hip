@@ -37,6 +37,23 @@ struct GemmArgs {
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
+#ifdef OMNIPQ_NT_TRACE
+// Debug build only (tools/nt_trace.py): cycle stamps of a workgroup's phases, thread 0 of the first 4096 workgroups.
+__device__ long long g_nt_trace[4096 * 8];
+__device__ __forceinline__ long long nt_now() {
+  long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define NT_STAMP(slot)                                                                    \
+  {                                                                                       \
+    const long long now_ = nt_now();                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_nt_trace[blockIdx.x * 8 + (slot)] = now_; \
+  }
+#else
+#define NT_STAMP(slot)
+#endif
+
 // STATS (bf16 output only): per-column sum and sum of squares of the ROUNDED tile values, folded into the
 // store loop -- the BatchNorm statistics of the layer without a second pass over the tensor.
 //   1: atomically added to stats_out = double[2][N]          (few M-tiles: little contention)
@@ -161,7 +178,7 @@ constexpr int kResMaxSteps = 10;
 
 template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0, bool KRES = false,
           bool DYG = false>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
@@ -188,8 +205,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   __shared__ __attribute__((aligned(16))) unsigned char static_smem[KRES ? 16 : LDS_BYTES];
   unsigned char *const smem = KRES ? dyn_smem : static_smem;
   bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
-  __shared__ __attribute__((aligned(16))) float s_aff[AFF ? 2 * kAffMaxK : 4];       // a | b of the A operand's channels
-  __shared__ __attribute__((aligned(16))) f32x4 s_w0[XG ? kXgMaxC : 1];              // W0[c][0..2] as f32
+  // a | b of the A operand's channels.  T = 128 (PADTAB): the table lives in the 16 padding bytes of the staging rows
+  // (512 rows x 4 floats = the 2 x 1024 entries exactly; a in rows 0..255, b in rows 256..511), which nothing else
+  // writes before the C tile takes the buffer over -- 8 KB less LDS, so four workgroups fit a CU instead of three.
+  constexpr bool PADTAB = AFF && T == 128 && !KRES;
+  static_assert(!PADTAB || (GPITCH == 40 && kAffMaxK == 1024), "table-in-padding layout");
+  __shared__ __attribute__((aligned(16))) float s_aff_mem[(AFF && !PADTAB) ? 2 * kAffMaxK : 4];
+  float *const s_aff = PADTAB ? reinterpret_cast<float *>(smem) + 16 : s_aff_mem;
+  // entry c of table h (0: a, 1: b); c a multiple of 4 when read as f32x4
+  auto aff_at = [&](int h, int c) -> float * {
+    return PADTAB ? s_aff + (h * 256 + (c >> 2)) * (GPITCH / 2) + (c & 3) : s_aff + h * kAffMaxK + c;
+  };
+  // W0[c][0..2] as f32.  XG = 1 with the table in the padding: entry c IS the padding of staging row c (the a | b
+  // table is not used by that variant, its folded (a w0, a w1, a w2, b) entries carry both).
+  constexpr bool PADW0 = PADTAB && XG == 1;
+  static_assert(!PADW0 || kXgMaxC <= 512, "one staging row per channel");
+  __shared__ __attribute__((aligned(16))) f32x4 s_w0_mem[(XG && !PADW0) ? kXgMaxC : 1];
+  auto w0_at = [&](int c) -> f32x4 * {
+    return PADW0 ? reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + c * (GPITCH / 2) + 16) : s_w0_mem + c;
+  };
   __shared__ __attribute__((aligned(16))) f32x4 s_dy[DYG ? kDyMaxK : 1];              // (a, b, beta', gamma') per A channel
 
   // XCD-aware tile order: id % 8 picks the XCD, the N-tiles of one M-tile stay on it
@@ -207,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  NT_STAMP(0);
 
   // staging assignment: chunk q = tid + i*256 -> row q>>2, 16-byte piece q&3
   // Rows past M (or N) are clamped to the last valid row instead of being zero-filled: whatever they
@@ -238,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   if (XG == 2) {
     for (int c = tid; c < g.N; c += 256) {
       const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
-      s_w0[c] = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+      *w0_at(c) = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
                       __builtin_bit_cast(float, w.y << 16), 0.f};
     }
     __syncthreads();
@@ -298,18 +333,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         av = aff.a[c];
         bv = aff.b[c];
       }
-      s_aff[c] = av;
-      s_aff[kAffMaxK + c] = bv;
+      if (!PADW0) {
+        *aff_at(0, c) = av;
+        *aff_at(1, c) = bv;
+      }
       if (XG == 1) {
         // relu(a (W0 . x0) + b) = relu((a W0) . x0 + b): one table entry (a w0, a w1, a w2, b) per channel
         const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
-        s_w0[c] = f32x4{av * __builtin_bit_cast(float, w.x << 16), av * __builtin_bit_cast(float, w.x & 0xffff0000u),
+        *w0_at(c) = f32x4{av * __builtin_bit_cast(float, w.x << 16), av * __builtin_bit_cast(float, w.x & 0xffff0000u),
                         av * __builtin_bit_cast(float, w.y << 16), bv};
       }
     }
     __syncthreads();
   }
 
+  NT_STAMP(1);
   uint4 ra[NI], rb[NI];
   uint4 ra2[NI], rb2[NI];            // second register set (PF2)
   uint4 ry[DYG ? NI : 1];            // DYG: the Y tile that goes with ra
@@ -340,13 +378,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       const int k0_ = kbeg + (KT) * GBK + skc[0] * 8;                                                   \
       f32x4 fa4_[2], fb4_[2];                                                                           \
       _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                \
-        fa4_[h_] = *reinterpret_cast<const f32x4 *>(s_aff + k0_ + 4 * h_);                              \
-        fb4_[h_] = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0_ + 4 * h_);                   \
+        fa4_[h_] = *reinterpret_cast<const f32x4 *>(aff_at(0, k0_ + 4 * h_));                           \
+        fb4_[h_] = *reinterpret_cast<const f32x4 *>(aff_at(1, k0_ + 4 * h_));                           \
       }                                                                                                 \
       if (XG == 1) {                                                                                    \
         /* relu((a W0)[k] . x0[row] + b[k]) for the 8 channels of this K-step, rounded like the stored activations */ \
         f32x4 w_[8];                                                                                    \
-        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) w_[e_] = s_w0[k0_ + e_];                       \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) w_[e_] = *w0_at(k0_ + e_);                     \
         _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                             \
           float y_[8];                                                                                  \
           _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_)                                              \
@@ -409,9 +447,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       if (kt < nk) {
         if (AFF) {
           const int k0 = kbeg + kt * GBK + skc[0] * 8;
-          const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(s_aff + k0), fa1 = *reinterpret_cast<const f32x4 *>(s_aff + k0 + 4);
-          const f32x4 fb0 = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0);
-          const f32x4 fb1 = *reinterpret_cast<const f32x4 *>(s_aff + kAffMaxK + k0 + 4);
+          const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(aff_at(0, k0)), fa1 = *reinterpret_cast<const f32x4 *>(aff_at(0, k0 + 4));
+          const f32x4 fb0 = *reinterpret_cast<const f32x4 *>(aff_at(1, k0));
+          const f32x4 fb1 = *reinterpret_cast<const f32x4 *>(aff_at(1, k0 + 4));
           qa[kt].x = affine_relu_pair(qa[kt].x, fa0[0], fb0[0], fa0[1], fb0[1]);
           qa[kt].y = affine_relu_pair(qa[kt].y, fa0[2], fb0[2], fa0[3], fb0[3]);
           qa[kt].z = affine_relu_pair(qa[kt].z, fa1[0], fb1[0], fa1[1], fb1[1]);
@@ -444,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
   }
   if (PF2 && nk > 1) OMNIPQ_LOAD_TILES(ra2, rb2, 1)
   __syncthreads();
+  NT_STAMP(2);
 
   if (!PF2) {
     for (int kt = 0; kt < nk; ++kt) {
@@ -471,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
 #undef OMNIPQ_LOAD_TILES
 #undef OMNIPQ_STORE_TILES
 
+  NT_STAMP(3);
   // ---- epilogue: accumulators -> LDS (row-major C tile) -> 16-byte row stores ----------------
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
@@ -531,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         }
     const bf16_t *ct = reinterpret_cast<const bf16_t *>(smem);
     __syncthreads();
+    NT_STAMP(4);
     bf16_t *C = reinterpret_cast<bf16_t *>(Cout);
     float cs[8], cs2[8];                   // this thread's 8 columns (piece = tid % PIECES), rows tid / PIECES + RG * it
 #pragma unroll
@@ -548,12 +589,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         mu[e] = bn.mean[c0 + e];
         is[e] = bn.invstd[c0 + e];
         if (XG == 2) {
-          wcol[e] = s_w0[c0 + e];
+          wcol[e] = *w0_at(c0 + e);
           cx[0][e] = cx[1][e] = cx[2][e] = 0.f;
         }
       }
     }
-    for (int q = tid; q < T * PIECES; q += 256) {
+    // STATS >= 3 reads the layer's pre-BN output next to every piece of the tile: all of a thread's pieces are requested
+    // BEFORE the loop (one trip of latency instead of one per iteration: the loop was 8 us of a 24 us tile)
+    constexpr int ITERS = T * PIECES / 256;
+    uint4 ypre[(STATS >= 3 && XG != 2) ? ITERS : 1];
+    if (STATS >= 3 && XG != 2) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int q = tid + it * 256;
+        const int row = q / PIECES, piece = q % PIECES;
+        int gr = m0 + row, gc = n0 + piece * 8;
+        gr = gr < g.M ? gr : g.M - 1;                     // clamped: the value is only used under the bounds test below
+        gc = gc < g.N ? gc : 0;
+        ypre[it] = *reinterpret_cast<const uint4 *>(bn.Y + (size_t)gr * g.ldc + gc);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int q = tid + it * 256;
       const int row = q / PIECES, piece = q % PIECES;
       const int gr = m0 + row, gc = n0 + piece * 8;
       if (gr < g.M && gc < g.N) {
@@ -576,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
             cx[2][e] = __builtin_fmaf(dz, x2, cx[2][e]);
           }
         } else if (STATS >= 3) {
-          const uint4 yv = *reinterpret_cast<const uint4 *>(bn.Y + (size_t)gr * g.ldc + gc);
+          const uint4 yv = ypre[it];
           const unsigned w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -600,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         }
       }
     }
+    NT_STAMP(5);
     if ((STATS == 1 || STATS == 2) && pool.s > 0) {
       const int col = tid % T, gc = n0 + col;
       const int balls = T / pool.s;
@@ -622,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
         }
       }
     }
+    NT_STAMP(6);
     if (STATS) {
       __syncthreads();                     // the C tile is dead: reuse it as [RG row groups][NS][T] floats
       static_assert(RG * NS * T * 4 <= LDS_BYTES, "statistics fold must fit under the staging buffers");
@@ -652,7 +712,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g, const bf16_
       }
     }
   }
+  NT_STAMP(7);
 }
+
+#ifdef OMNIPQ_NT_TRACE
+}  // namespace omnipq
+extern "C" int omnipq_debug_read_nt_trace(long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(omnipq::g_nt_trace), sizeof(long long) * 4096 * 8);
+}
+namespace omnipq {
+#endif
 
 // sums[j] += sum over the M-tiles of part[t][j],  j in [0, 2N): grid (ceil(2N/256), slabs)
 __global__ __launch_bounds__(256) void partial_reduce_kernel(int m_tiles, int n2, const float *__restrict__ part,
