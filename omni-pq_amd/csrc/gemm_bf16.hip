@@ -16,6 +16,8 @@
 // The C tile leaves through LDS so that global stores are 16 B per lane along rows.
 // blockIdx is remapped so that the N-tiles of one M-tile run on the same XCD (A-tile re-reads hit
 // that XCD's L2 instead of going back to HBM once per N-tile).
+#include <type_traits>
+
 #include "common.h"
 
 namespace omnipq {
@@ -24,6 +26,13 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// (lo, hi) -> one word of two bf16: ONE v_cvt_pk_bf16_f32 (two scalar conversions + shift + or are four instructions, and
+// the SLP vectoriser pairs them across words, adding two more shuffles per word)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+}
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GPITCH = 40;                 // bf16 elements per staged row (32 + 8 pad) = 80 B
@@ -87,8 +96,7 @@ constexpr int kAffMaxK = 1024;
 __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
   const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
   const float hi = __builtin_fmaxf(__builtin_fmaf(a1, __builtin_bit_cast(float, w & 0xffff0000u), b1), 0.f);
-  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 // Ball extrema (statistics variants only, s > 0): the rows of C are grouped positions, `s` consecutive rows form a
@@ -120,8 +128,7 @@ struct XyzGen {
 constexpr int kXgMaxC = 256;
 
 __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
-  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 // T: tile edge, 128 (four waves x 2 x 2 MFMA blocks) or 64 (four waves x one block).  The per-point layers outside
@@ -156,8 +163,7 @@ __device__ __forceinline__ unsigned dy_pair(unsigned dxw, unsigned yw, const f32
   const float z1 = __builtin_fmaf(c1[0], y1, c1[1]) > 0.f ? d1 : 0.f;
   const float lo = __builtin_fmaf(c0[0], z0, __builtin_fmaf(c0[2], y0, c0[3]));
   const float hi = __builtin_fmaf(c1[0], z1, __builtin_fmaf(c1[2], y1, c1[3]));
-  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 __device__ __forceinline__ uint4 dy_chunk(const uint4 &dx, const uint4 &y, const f32x4 *tab) {
@@ -194,7 +200,10 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
   static_assert(!KRES || (T == 64 && !PF2 && XG == 0 && !OUT_F32), "KRES variants");
   constexpr int NS = XG == 2 ? 5 : 2;          // column sums per statistics epilogue
   constexpr int NI = T / 64;                   // 32 x 32 MFMA blocks per wave and dimension
-  constexpr int CP = T + 8, CPF = T + 4;       // C-tile pitches (bf16 / f32 elements)
+  constexpr int CP = T, CPF = T + 4;           // C-tile pitches (bf16 / f32 elements).  bf16: NO padding -- the 16-byte reads of the
+                                               // store loop are served in the lane groups of MI355X_MICROARCH.md (LDS), which tile
+                                               // the 64 banks exactly when rows are 64 or 32 words apart; the packed 4-byte writes
+                                               // (32 banks) become 2-way conflicts, which a ds_write_b32 absorbs
   constexpr int PIECES = T / 8;                // 16-byte pieces per bf16 row of the C tile
   constexpr int RG = 256 / PIECES;             // row groups of the store loop
   // staging: [2 buffers][A | B][T rows][GPITCH]; the C tile aliases it after the main loop
@@ -542,33 +551,37 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
     // (c, c+1) of row r, the odd lane with (c-1, c) of row r+1 -> 32 ds_write_b32 instead of 64 b16.
     unsigned *ct32 = reinterpret_cast<unsigned *>(smem);
     const bool odd = lane & 1;
-    float bcol[NI];                        // per-column bias (f32, added before the single bf16 rounding)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bcol[j] = 0.f;
-    if (bias) {
+    // word index of (row, col): row * CP / 2 + col / 2 -- one base per thread, everything else is an immediate offset
+    static_assert(CP % 2 == 0, "packed C-tile pitch");
+    unsigned *const cbase = ct32 + (wm * (T / 2) + crow0 + (odd ? 1 : 0)) * (CP / 2) + ((wn * (T / 2) + (ccol & ~1)) >> 1);
+    // two copies of the loop, with and without the bias (wave-uniform): the 64 adds per thread are not paid for a NULL bias
+    auto pack_tile = [&](auto has_bias) {
+      constexpr bool HAS_BIAS = decltype(has_bias)::value;
+      float bcol[NI];                      // per-column bias (f32, added before the single bf16 rounding)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int c = n0 + wn * (T / 2) + j * 32 + ccol;
-        bcol[j] = c < g.N ? bias[c] : 0.f;
+        bcol[j] = (HAS_BIAS && c < g.N) ? bias[c] : 0.f;
       }
-    }
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float mine0 = acc[i][j][r] + bcol[j], mine1 = acc[i][j][r + 1] + bcol[j];
-          const float give = odd ? mine0 : mine1;
-          const float got = __builtin_bit_cast(
-              float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-          const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
-          const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
-                                  ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
-          const int row = wm * (T / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + crow0 + (odd ? 1 : 0);
-          const int col = wn * (T / 2) + j * 32 + (ccol & ~1);
-          ct32[(row * CP + col) >> 1] = packed;
-        }
+          for (int r = 0; r < 16; r += 2) {
+            const float mine0 = HAS_BIAS ? acc[i][j][r] + bcol[j] : acc[i][j][r];
+            const float mine1 = HAS_BIAS ? acc[i][j][r + 1] + bcol[j] : acc[i][j][r + 1];
+            const float give = odd ? mine0 : mine1;
+            const float got = __builtin_bit_cast(
+                float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+            const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
+            cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (CP / 2) + j * 16] = pack_bf16x2(lo, hi);
+          }
+    };
+    if (bias)
+      pack_tile(std::true_type{});
+    else
+      pack_tile(std::false_type{});
     const bf16_t *ct = reinterpret_cast<const bf16_t *>(smem);
     __syncthreads();
     NT_STAMP(4);
@@ -659,7 +672,77 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
       }
     }
     NT_STAMP(5);
-    if ((STATS == 1 || STATS == 2) && pool.s > 0) {
+    if ((STATS == 1 || STATS == 2) && T == 128 && !bias && (pool.s == 16 || pool.s == 32 || pool.s == 64)) {
+      // Ball extrema from the accumulators (no LDS read, no serial walk over the ball).  A lane holds 32 rows of each of
+      // its two columns.  Two rows of one column are rounded together (the pair word equals what the C tile holds), the
+      // two bf16 are mapped to order-preserving unsigned 16-bit values (negative: all bits flipped, else the sign bit
+      // set) and each becomes a 32-bit key with the row in the low bits: value << 16 | row for the minimum,
+      // value << 16 | 63 - row for the maximum, so that max / min over keys also applies the tie rule (first row).
+      // Folded per group of 16 rows first (the smallest ball), groups merged for s = 32 / 64, lane halves last.
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      const unsigned hbit = (unsigned)crow0;                      // 4 for the upper lane half: bit 2 of the row
+      unsigned kmx[NI][4], kmn[NI][4];                            // [column block j][group = 2 i + (r >> 3)]
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            unsigned mx = 0u, mn = 0xffffffffu;
+#pragma unroll
+            for (int r = 8 * gq; r < 8 * gq + 8; r += 2) {
+              const unsigned pw = pack_bf16x2(acc[i][j][r], acc[i][j][r + 1]);
+              const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, pw) >> 15);
+              const unsigned o = pw ^ (sg | 0x80008000u);
+              const unsigned row = i * 32 + (r & 3) + 8 * (r >> 2);              // + hbit below; row + 1 for the high half
+              const unsigned olo = o << 16, ohi = o & 0xffff0000u;
+              mx = max(max(mx, olo | (63u - row)), ohi | (62u - row));
+              mn = min(min(mn, olo | row), ohi | (row + 1u));
+            }
+            kmx[j][2 * i + gq] = mx ^ hbit;                       // 63 - (row + 4 h): bit 2 of 63 - row is set
+            kmn[j][2 * i + gq] = mn | hbit;
+          }
+      const int s_ = pool.s;
+      if (s_ >= 32) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            kmx[j][2 * i] = max(kmx[j][2 * i], kmx[j][2 * i + 1]);
+            kmn[j][2 * i] = min(kmn[j][2 * i], kmn[j][2 * i + 1]);
+          }
+      }
+      if (s_ == 64) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          kmx[j][0] = max(kmx[j][0], kmx[j][2]);
+          kmn[j][0] = min(kmn[j][0], kmn[j][2]);
+        }
+      }
+      const int gstep = s_ >> 4;                                  // groups per ball: 1, 2, 4
+      const bool upper = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          if (gi % gstep) continue;                               // wave-uniform
+          unsigned a = kmx[j][gi], b = kmn[j][gi];
+          a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
+          b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
+          // the lower half stores the maximum, the upper half the minimum
+          const unsigned key = upper ? b : a;
+          const unsigned o = key >> 16;
+          const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
+          const unsigned low = key & (unsigned)(s_ - 1);
+          const unsigned char row = (unsigned char)(upper ? low : (unsigned)(s_ - 1) - low);
+          const int r0 = wm * (T / 2) + gi * 16, gc = n0 + wn * (T / 2) + j * 32 + ccol;
+          if (m0 + r0 < g.M && gc < g.N) {
+            const size_t oidx = (size_t)((m0 + r0) / s_) * g.N + gc;
+            (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(bf16_t, bits);
+            (upper ? pool.amin : pool.amax)[oidx] = row;
+          }
+        }
+    } else if ((STATS == 1 || STATS == 2) && pool.s > 0) {
       const int col = tid % T, gc = n0 + col;
       const int balls = T / pool.s;
       if (gc < g.N) {
@@ -769,10 +852,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(long long n4, i
     s[0] += bias[c], s[1] += bias[c + 1], s[2] += bias[c + 2], s[3] += bias[c + 3];
   }
   uint2 w;
-  w.x = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[0]) |
-        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[1]) << 16);
-  w.y = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[2]) |
-        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)s[3]) << 16);
+  w.x = pack_bf16x2(s[0], s[1]);
+  w.y = pack_bf16x2(s[2], s[3]);
   *reinterpret_cast<uint2 *>(out + i * 4) = w;
 }
 

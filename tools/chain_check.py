@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--extra", type=int, default=0)
     ap.add_argument("--flag", default="CHAIN", help="sa_fused switch to A/B: CHAIN or ALGEBRA")
+    ap.add_argument("--per-stage", action="store_true", help="after the A/B, split the default path's time by stage")
     args = ap.parse_args()
     import pointnet2_utils
     import sa_fused
@@ -116,6 +117,53 @@ def main():
         print(f"{args.flag}={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
         for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]:
             print(f"    {k:50s} {v / args.steps * 1e3:9.1f} us/step")
+
+    if args.per_stage:
+        per_stage(sa_fused, ext, step, args.steps)
+
+
+def per_stage(sa_fused, ext, step, steps):
+    """Kernel time of every SA stage on its own: the stage's forward remembers its ordinal in ctx, so that its backward
+    launches carry the same label."""
+    F = sa_fused.FusedSAStage
+    fwd, bwd = F._forward, F._backward
+    names = ["sa1", "sa2", "sa3", "sa4", "vote"]
+    count = [0]
+
+    def _forward(ctx, *a):
+        ctx.stage_label = "@" + names[count[0] % len(names)]
+        count[0] += 1
+        ext.timing_tag = ctx.stage_label
+        return fwd(ctx, *a)
+
+    def _backward(ctx, g):
+        ext.timing_tag = ctx.stage_label
+        return bwd(ctx, g)
+
+    F._forward, F._backward = staticmethod(_forward), staticmethod(_backward)
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        count[0] = 0
+        sink = []
+        ext.set_timing_sink(sink)
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ext.set_timing_sink(None)
+    finally:
+        F._forward, F._backward = staticmethod(fwd), staticmethod(bwd)
+    tot, calls = {}, {}
+    for name, _, e0, e1 in sink:
+        tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+        calls[name] = calls.get(name, 0) + 1
+    for st in names:
+        mine = {k: v for k, v in tot.items() if k.endswith("@" + st)}
+        n = sum(calls[k] for k in mine) / steps
+        print(f"{st}: {sum(mine.values()) / steps:.3f} ms/step in {n:.0f} launches")
+        for k, v in sorted(mine.items(), key=lambda kv: -kv[1])[:12]:
+            print(f"    {k:50s} {calls[k] / steps:4.0f} x {v / calls[k] * 1e3:7.1f} us")
 
 
 if __name__ == "__main__":
