@@ -33,6 +33,19 @@ int omnipq_add_dropout_layernorm_bwd(long long R, int C, const float *x, const v
                                      const float *mean, const float *rstd, const float *g32, const void *g16,
                                      const void *g16_pe, float *dx, void *dy, float *dgamma_dbeta, void *stream);
 
+/* The same with the parameter gradients left as per-workgroup partial sums: partials [blocks][2][C] f32 with
+ * blocks = omnipq_add_dropout_layernorm_bwd_blocks(R) (every entry written, nothing needs clearing).  A training step has
+ * one such call per LayerNorm (18 in the decoder); nothing reads dgamma / dbeta before the optimizer, so ONE
+ * omnipq_layernorm_param_reduce at the end of backward sums all of them: out[i] [2][C] f32 receives ADDED sums (zero
+ * or a previous gradient on entry), n <= 32.  The host arrays are read during the call (by-value kernel arguments). */
+long long omnipq_add_dropout_layernorm_bwd_blocks(long long R);
+int omnipq_add_dropout_layernorm_bwd_partials(long long R, int C, const float *x, const void *y, const float *gamma,
+                                              float dropout_p, const unsigned long long *seed_ptr, unsigned salt,
+                                              const float *mean, const float *rstd, const float *g32, const void *g16,
+                                              const void *g16_pe, float *dx, void *dy, float *partials, void *stream);
+int omnipq_layernorm_param_reduce(int n, const float *const *partials, const int *blocks, const int *channels,
+                                  float *const *out, void *stream);
+
 /* h = dropout(relu(h)) in place on bf16 [n]; backward: out = (h > 0) ? d / (1-p) : 0 (out may be d; h = the
  * forward's OUTPUT: positive exactly where the unit was active and kept). */
 int omnipq_relu_dropout(long long n, void *h, float dropout_p, const unsigned long long *seed_ptr, unsigned salt,

@@ -49,16 +49,18 @@ __device__ __forceinline__ unsigned drop_seed(const AttnArgs &g) {
   return (unsigned)(s >> 32) ^ (unsigned)s;
 }
 
-// lowbias32-style finaliser: two 32-bit multiplies (quarter rate on the VALU) instead of murmur3's three
-__device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) {
-  unsigned x = idx ^ seed;
-  x ^= x >> 16;
-  x *= 0x7FEB352Du;
-  x ^= x >> 15;
-  x *= 0x846CA68Bu;
-  x ^= x >> 16;
-  return x;
+// Decision hash of one (batch*head, query, key) element.  Two rounds of multiply + fold like lowbias32, but with the
+// 24 x 24 -> 32 bit multiply (v_mul_u32_u24, full rate) instead of v_mul_lo_u32 (quarter rate: the two of them were half of
+// the hash's issue cycles, and the hash is most of what these kernels issue).  The rotate feeds the top byte, which the
+// first multiply does not see, into the low bits; the final xor keeps the unmultiplied bits alive.  Checked against the
+// 32-bit version on 2 M-element grids (keep rate, correlation along keys / queries / heads / seeds, chi-square of the
+// top byte): indistinguishable.  The callers add the seed into `x` (x = index + seed) so that the per-element part is one add.
+__device__ __forceinline__ unsigned drop_hash_mix(unsigned x) {
+  unsigned y = __umul24(x, 0x9E3779u) ^ __builtin_amdgcn_alignbit(x, x, 24);
+  y ^= y >> 16;
+  return __umul24(y, 0x85EBCBu) ^ y;
 }
+__device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) { return drop_hash_mix(idx + seed); }
 
 // row of accumulator register r for a lane in half h of the 32x32 MFMA result
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -102,9 +104,11 @@ constexpr int ATT_NP = 6;
 struct StagePlan {
   int tok[ATT_NP];        // token within the block, or -1 if the lane has no such piece
   int off[ATT_NP];        // channel offset (elements)
+  long long rel[ATT_NP];  // tok * token stride + off: the lane's part of the address; the block's part (t0 * stride) is
+                          // wave-uniform, so a load costs one 64-bit add instead of a 64-bit multiply per piece
 };
 
-__device__ __forceinline__ StagePlan stage_plan(int D, int lane) {
+__device__ __forceinline__ StagePlan stage_plan(int D, int lane, long long s_tok) {
   StagePlan sp;
   const int ppr = D >> 2;
 #pragma unroll
@@ -113,6 +117,7 @@ __device__ __forceinline__ StagePlan stage_plan(int D, int lane) {
     const int tok = id / ppr;
     sp.tok[i] = id < 32 * ppr ? tok : -1;
     sp.off[i] = (id - tok * ppr) * 4;
+    sp.rel[i] = (long long)tok * s_tok + sp.off[i];
   }
   return sp;
 }
@@ -128,7 +133,7 @@ __device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, const bf16_
   for (int i = 0; i < ATT_NP; ++i) {
     r.v[i] = make_uint2(0u, 0u);
     if (sp.tok[i] >= 0 && t0 + sp.tok[i] < T)
-      r.v[i] = *reinterpret_cast<const uint2 *>(base + (long long)(t0 + sp.tok[i]) * s_tok + sp.off[i]);
+      r.v[i] = *reinterpret_cast<const uint2 *>(base + (long long)t0 * s_tok + sp.rel[i]);
   }
   return r;
 }
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
                                                       const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
                                                       bf16_t *__restrict__ O, float *__restrict__ lse2) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4 + 4 * 32 * 4 * 2];
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ql = lane & 31;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
   const bool qv = q < g.L;
@@ -191,7 +196,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
-  const StagePlan sp = stage_plan(g.D, lane);
+  const StagePlan sp = stage_plan(g.D, lane, g.v_sl);
+  const bf16_t *Kl = Kb + (long long)ql * g.k_sl;          // the lane's key row of block 0 (blocks add a uniform offset)
   // software pipeline: the K fragments and the V block of iteration it+1 are loaded while it computes
   bf16x8 kfn[3];
   StageRegs vn;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
     const int k0 = wave * 32, key = k0 + ql;
     const bool kv = key < g.S;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+    for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kl + (long long)k0 * g.k_sl, j, h, g.D, kv);
     vn = stage_load(sp, Vb, g.v_sl, k0, g.S);
   }
   for (int it = 0; it < iters; ++it) {
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
       const int k1 = k0 + 128, key = k1 + ql;
       const bool kv = key < g.S;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
+      for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kl + (long long)k1 * g.k_sl, j, h, g.D, kv);
       vn = stage_load(sp, Vb, g.v_sl, k1, g.S);
     }
     __syncthreads();                                        // previous block's LDS reads are done
@@ -266,10 +272,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
     }
     m = m_new;
     if (g.drop_thresh) {
-      const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
+      // element index + seed, the lane's part (query, lane half) added once: one add per element is left
+      const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0 + seed + 4u * h;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        p[r] = drop_hash(base + (unsigned)acc_row(r, h), seed) >= g.drop_thresh ? p[r] * g.keep_inv : 0.f;
+        p[r] = drop_hash_mix(base + (unsigned)acc_row(r, 0)) >= g.drop_thresh ? p[r] * g.keep_inv : 0.f;
     }
     __syncthreads();                                        // V block staged
 #pragma unroll
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
                                                          const float *__restrict__ lse2, float *__restrict__ delta,
                                                          bf16_t *__restrict__ dQ, long long dq_sl, long long dq_sn) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4];
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ql = lane & 31;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
   const bool qv = q < g.L;
@@ -346,7 +353,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
-  const StagePlan sp = stage_plan(g.D, lane);
+  const StagePlan sp = stage_plan(g.D, lane, g.k_sl);
+  const bf16_t *Kl = Kb + (long long)ql * g.k_sl, *Vl = Vb + (long long)ql * g.v_sl;
   bf16x8 kfn[3], vfn[3];
   StageRegs kn;
   {
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
     const bool kv = key < g.S;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
-      vfn[j] = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+      kfn[j] = frag_tok(Kl + (long long)k0 * g.k_sl, j, h, g.D, kv);
+      vfn[j] = frag_tok(Vl + (long long)k0 * g.v_sl, j, h, g.D, kv);
     }
     kn = stage_load(sp, Kb, g.k_sl, k0, g.S);
   }
@@ -370,8 +378,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
       const bool kv = key < g.S;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        kfn[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
-        vfn[j] = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+        kfn[j] = frag_tok(Kl + (long long)k1 * g.k_sl, j, h, g.D, kv);
+        vfn[j] = frag_tok(Vl + (long long)k1 * g.v_sl, j, h, g.D, kv);
       }
       kn = stage_load(sp, Kb, g.k_sl, k1, g.S);
     }
@@ -386,14 +394,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
       dp = MFMA(vf[j], dof[j], dp);                         // (dO V^T)^T
     }
     float ds[16];
-    const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0;
+    const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0 + seed + 4u * h;
     const bool full = q0 + 32 <= g.L && k0 + 32 <= g.S;    // wave-uniform: nothing of this tile is out of range
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float p = fast_exp2(__builtin_fmaf(st[r], g.scale_log2, -lse));
       if (!full) p = (qv && k0 + acc_row(r, h) < g.S) ? p : 0.f;
       float d = dp[r];
-      if (g.drop_thresh) d = drop_hash(base + (unsigned)acc_row(r, h), seed) >= g.drop_thresh ? d * g.keep_inv : 0.f;
+      if (g.drop_thresh) d = drop_hash_mix(base + (unsigned)acc_row(r, 0)) >= g.drop_thresh ? d * g.keep_inv : 0.f;
       ds[r] = p * (d - dl);
     }
     __syncthreads();
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
   __shared__ __attribute__((aligned(16))) bf16_t qs[32 * ATT_PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t dos[32 * ATT_PITCH];
   __shared__ float rowv[64];                                               // [0,32) lse2, [32,64) delta
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, kl = lane & 31;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, kl = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int k0 = ((int)blockIdx.x * 4 + wave) * 32, key = k0 + kl;
   const bool kv = key < g.S;
@@ -465,11 +473,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
   // cooperative staging: 256 threads, pieces id = tid + 256 i (i < 2) of the [32][D] block
   const int ppr = g.D >> 2;
   int ptok[2], poff[2];
+  long long qrel[2], drel[2];                               // the thread's part of the Q / dO addresses
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i, tok = id / ppr;
     ptok[i] = id < 32 * ppr ? tok : -1;
     poff[i] = (id - tok * ppr) * 4;
+    qrel[i] = (long long)tok * g.q_sl + poff[i];
+    drel[i] = (long long)tok * g.o_sl + poff[i];
   }
   const float *rowsrc = (tid < 32 ? lse2 : delta) + (long long)nh * g.L;
   uint2 qn[2], dn[2];
@@ -479,8 +490,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
     for (int i = 0; i < 2; ++i) {
       qn[i] = dn[i] = make_uint2(0u, 0u);
       if (ptok[i] >= 0 && q0 + ptok[i] < g.L) {
-        qn[i] = *reinterpret_cast<const uint2 *>(Qb + (long long)(q0 + ptok[i]) * g.q_sl + poff[i]);
-        dn[i] = *reinterpret_cast<const uint2 *>(dOb + (long long)(q0 + ptok[i]) * g.o_sl + poff[i]);
+        qn[i] = *reinterpret_cast<const uint2 *>(Qb + (long long)q0 * g.q_sl + qrel[i]);
+        dn[i] = *reinterpret_cast<const uint2 *>(dOb + (long long)q0 * g.o_sl + drel[i]);
       }
     }
     rown = (tid < 64 && q0 + (tid & 31) < g.L) ? rowsrc[q0 + (tid & 31)] : 0.f;
@@ -513,6 +524,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
     }
     float pt[16], ds[16];
     const bool full = q0 + 32 <= g.L && k0 + 32 <= g.S;    // wave-uniform
+    // element index + seed: the lane's part once, acc_row(r, 0) * S is wave-uniform
+    const unsigned hbase = ((unsigned)nh * (unsigned)g.L + (unsigned)(q0 + 4 * h)) * (unsigned)g.S + (unsigned)key + seed;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r, h);
@@ -521,8 +534,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
       float d = dp[r];
       float pk = p;
       if (g.drop_thresh) {
-        const unsigned idx = ((unsigned)nh * (unsigned)g.L + (unsigned)(q0 + row)) * (unsigned)g.S + (unsigned)key;
-        const bool keep = drop_hash(idx, seed) >= g.drop_thresh;
+        const bool keep = drop_hash_mix(hbase + (unsigned)acc_row(r, 0) * (unsigned)g.S) >= g.drop_thresh;
         d = keep ? d * g.keep_inv : 0.f;
         pk = keep ? p * g.keep_inv : 0.f;
       }

@@ -19,6 +19,14 @@
 
 namespace omnipq {
 
+// (lo, hi) -> one word of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Two scalar conversions + shift + or
+// are four instructions, and the SLP vectoriser pairs scalar conversions across words, adding two shuffles per word.
+typedef float omnipq_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 omnipq_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(omnipq_f32x2{lo, hi}, omnipq_bf16x2));
+}
+
 // a*a + b*b + c*c exactly as the numerics contract in omnipq_pointops.h states it:
 // the right-hand product of the first sum is rounded on its own, the other two fuse.
 // (Compile the index kernels with -ffp-contract=off so nothing else fuses.)

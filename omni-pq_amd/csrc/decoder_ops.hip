@@ -46,10 +46,8 @@ __device__ __forceinline__ void unpack4(uint2 w, float *f) {
 
 __device__ __forceinline__ uint2 pack4(const float *f) {
   uint2 w;
-  w.x = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[0]) |
-        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[1]) << 16);
-  w.y = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[2]) |
-        ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)f[3]) << 16);
+  w.x = pack_bf16x2(f[0], f[1]);
+  w.y = pack_bf16x2(f[2], f[3]);
   return w;
 }
 
@@ -150,7 +148,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs g, const float *__re
                                                     const float *__restrict__ mean, const float *__restrict__ rstd,
                                                     const float *__restrict__ g32, const bf16_t *__restrict__ g16,
                                                     const bf16_t *__restrict__ g16_pe, float *__restrict__ dx,
-                                                    bf16_t *__restrict__ dy, float *__restrict__ dgb) {
+                                                    bf16_t *__restrict__ dy, float *__restrict__ dgb,
+                                                    float *__restrict__ part) {
   extern __shared__ float dyn[];                            // [4 waves][dgamma | dbeta][C]
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
   const int nch = g.C >> 2;
@@ -248,8 +247,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs g, const float *__re
     const int which = j / g.C, c = j - which * g.C;
     const float v = dyn[(0 * 2 + which) * g.C + c] + dyn[(1 * 2 + which) * g.C + c] + dyn[(2 * 2 + which) * g.C + c] +
                     dyn[(3 * 2 + which) * g.C + c];
-    atomicAdd(dgb + j, v);
+    if (part)
+      part[(size_t)blockIdx.x * 2 * g.C + j] = v;          // summed later, for all LayerNorms of the step at once
+    else
+      atomicAdd(dgb + j, v);
   }
+}
+
+// out[item][j] += sum over the item's blocks of part[block][j], j < 2 C: grid (ceil(2C / 64), items, kLnSplit).
+// A thread owns one column of a quarter of its split's blocks (consecutive lanes = consecutive columns: 256-byte
+// rows), the four quarters meet in LDS, the splits through kLnSplit-way atomics on a zero-initialised output.
+constexpr int kLnItems = 32, kLnSplit = 8;
+struct LnReduceItem {
+  const float *part;
+  float *out;
+  int blocks, c2;
+};
+struct LnReduceArgs {
+  LnReduceItem item[kLnItems];
+};
+
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs a) {
+  __shared__ float red[4][64];
+  const LnReduceItem it = a.item[blockIdx.y];
+  const int col = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63), q = (int)threadIdx.x >> 6;
+  const int per = (it.blocks + kLnSplit - 1) / kLnSplit;
+  const int b0 = (int)blockIdx.z * per;
+  int b1 = b0 + per;
+  if (b1 > it.blocks) b1 = it.blocks;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < it.c2) {
+    int b = b0 + q;
+    for (; b + 12 < b1; b += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += it.part[(size_t)(b + 4 * u) * it.c2 + col];
+    }
+    for (; b < b1; b += 4) acc[0] += it.part[(size_t)b * it.c2 + col];
+  }
+  red[q][threadIdx.x & 63] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (q == 0 && col < it.c2 && b0 < b1)
+    atomicAdd(it.out + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 __global__ __launch_bounds__(256) void relu_dropout_kernel(long long n4, bf16_t *__restrict__ h, float keep_inv,
@@ -339,25 +377,71 @@ extern "C" int omnipq_add_dropout_layernorm(long long R, int C, const float *x, 
   return OMNIPQ_OK;
 }
 
+namespace omnipq {
+static long long ln_bwd_blocks(long long R) {
+  long long blocks = (R + 3) / 4;
+  static const long long cap = getenv("OMNIPQ_LN_BLOCKS") ? atoll(getenv("OMNIPQ_LN_BLOCKS")) : 512;
+  return blocks > cap ? cap : blocks;   // with atomics each block ends with 2C of them; 512 blocks measured best
+}
+}  // namespace omnipq
+
+extern "C" long long omnipq_add_dropout_layernorm_bwd_blocks(long long R) {
+  return R <= 0 ? 0 : omnipq::ln_bwd_blocks(R);
+}
+
+static int ln_bwd_impl(long long R, int C, const float *x, const void *y, const float *gamma, float dropout_p,
+                       const unsigned long long *seed_ptr, unsigned salt, const float *mean, const float *rstd,
+                       const float *g32, const void *g16, const void *g16_pe, float *dx, void *dy,
+                       float *dgamma_dbeta, float *partials, void *stream) {
+  using namespace omnipq;
+  if (R < 0 || C <= 0 || (C % 4) || C > 64 * 4 * LN_MAXCH) return OMNIPQ_EINVAL;
+  if (R == 0) return OMNIPQ_OK;
+  if (!x || !gamma || !mean || !rstd || !dx || (!dgamma_dbeta == !partials) || (!y != !dy)) return OMNIPQ_EINVAL;
+  if (R * C >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
+  LnArgs g{R, C, 0.f, 1.f, 0u, salt, seed_ptr};
+  const int rc = drop_params(y ? dropout_p : 0.f, seed_ptr, &g.thresh, &g.keep_inv);
+  if (rc) return rc;
+  const long long blocks = ln_bwd_blocks(R);
+  ln_bwd_kernel<<<(int)blocks, 256, sizeof(float) * 8 * C, (hipStream_t)stream>>>(
+      g, x, (const bf16_t *)y, gamma, mean, rstd, g32, (const bf16_t *)g16, (const bf16_t *)g16_pe, dx, (bf16_t *)dy,
+      dgamma_dbeta, partials);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
 extern "C" int omnipq_add_dropout_layernorm_bwd(long long R, int C, const float *x, const void *y, const float *gamma,
                                                 float dropout_p, const unsigned long long *seed_ptr, unsigned salt,
                                                 const float *mean, const float *rstd, const float *g32,
                                                 const void *g16, const void *g16_pe, float *dx, void *dy,
                                                 float *dgamma_dbeta, void *stream) {
+  return ln_bwd_impl(R, C, x, y, gamma, dropout_p, seed_ptr, salt, mean, rstd, g32, g16, g16_pe, dx, dy, dgamma_dbeta,
+                     nullptr, stream);
+}
+
+extern "C" int omnipq_add_dropout_layernorm_bwd_partials(long long R, int C, const float *x, const void *y,
+                                                         const float *gamma, float dropout_p,
+                                                         const unsigned long long *seed_ptr, unsigned salt,
+                                                         const float *mean, const float *rstd, const float *g32,
+                                                         const void *g16, const void *g16_pe, float *dx, void *dy,
+                                                         float *partials, void *stream) {
+  return ln_bwd_impl(R, C, x, y, gamma, dropout_p, seed_ptr, salt, mean, rstd, g32, g16, g16_pe, dx, dy, nullptr,
+                     partials, stream);
+}
+
+extern "C" int omnipq_layernorm_param_reduce(int n, const float *const *partials, const int *blocks, const int *channels,
+                                             float *const *out, void *stream) {
   using namespace omnipq;
-  if (R < 0 || C <= 0 || (C % 4) || C > 64 * 4 * LN_MAXCH) return OMNIPQ_EINVAL;
-  if (R == 0) return OMNIPQ_OK;
-  if (!x || !gamma || !mean || !rstd || !dx || !dgamma_dbeta || (!y != !dy)) return OMNIPQ_EINVAL;
-  if (R * C >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
-  LnArgs g{R, C, 0.f, 1.f, 0u, salt, seed_ptr};
-  const int rc = drop_params(y ? dropout_p : 0.f, seed_ptr, &g.thresh, &g.keep_inv);
-  if (rc) return rc;
-  long long blocks = (R + 3) / 4;
-  static const long long cap = getenv("OMNIPQ_LN_BLOCKS") ? atoll(getenv("OMNIPQ_LN_BLOCKS")) : 512;
-  if (blocks > cap) blocks = cap;                       // each block ends with 2C atomics; 512 blocks measured best (parallelism vs atomics)
-  ln_bwd_kernel<<<(int)blocks, 256, sizeof(float) * 8 * C, (hipStream_t)stream>>>(
-      g, x, (const bf16_t *)y, gamma, mean, rstd, g32, (const bf16_t *)g16, (const bf16_t *)g16_pe, dx, (bf16_t *)dy,
-      dgamma_dbeta);
+  if (n < 0 || n > kLnItems) return OMNIPQ_EINVAL;
+  if (n == 0) return OMNIPQ_OK;
+  if (!partials || !blocks || !channels || !out) return OMNIPQ_EINVAL;
+  LnReduceArgs a;
+  int widest = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!partials[i] || !out[i] || blocks[i] <= 0 || channels[i] <= 0) return OMNIPQ_EINVAL;
+    a.item[i] = LnReduceItem{partials[i], out[i], blocks[i], 2 * channels[i]};
+    widest = 2 * channels[i] > widest ? 2 * channels[i] : widest;
+  }
+  ln_param_reduce_kernel<<<dim3((widest + 63) / 64, n, kLnSplit), 256, 0, (hipStream_t)stream>>>(a);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -26,13 +26,6 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-// (lo, hi) -> one word of two bf16: ONE v_cvt_pk_bf16_f32 (two scalar conversions + shift + or are four instructions, and
-// the SLP vectoriser pairs them across words, adding two more shuffles per word)
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
-}
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GPITCH = 40;                 // bf16 elements per staged row (32 + 8 pad) = 80 B

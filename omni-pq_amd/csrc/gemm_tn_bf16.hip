@@ -45,8 +45,7 @@ struct TnArgs {
 __device__ __forceinline__ unsigned tn_affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
   const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
   const float hi = __builtin_fmaxf(__builtin_fmaf(a1, __builtin_bit_cast(float, w & 0xffff0000u), b1), 0.f);
-  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 // XGB (with AFFB): the layer below is the never-materialised first layer of a coordinates-only stage (gemm_bf16.hip:
@@ -58,8 +57,7 @@ struct TnXyz {
 };
 
 __device__ __forceinline__ unsigned tn_pack2(float lo, float hi) {
-  return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)lo) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 template <bool AFFB, bool XGB = false>

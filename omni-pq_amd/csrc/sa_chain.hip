@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned short c_f2bf(float x) { return __builtin_bit
 __device__ __forceinline__ float c_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float c_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ unsigned c_pack(float lo, float hi) {
-  return (unsigned)c_f2bf(lo) | ((unsigned)c_f2bf(hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 // ---- per-channel constant tables (LDS) ------------------------------------------------------------------

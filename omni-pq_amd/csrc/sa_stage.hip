@@ -39,10 +39,10 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   uint4 v;
-  v.x = f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-  v.y = f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-  v.z = f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-  v.w = f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+  v.x = pack_bf16x2(f[0], f[1]);
+  v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]);
+  v.w = pack_bf16x2(f[6], f[7]);
   return v;
 }
 

@@ -23,8 +23,11 @@ import torch
 
 import dropout_state
 import rows_mlp
+import sa_fused
 from sa_fused import _call, _lib, _p, zeros_f32
 from utils import fused_attention
+
+_lib.omnipq_add_dropout_layernorm_bwd_blocks.restype = ctypes.c_longlong
 
 
 class AddToBf16(torch.autograd.Function):
@@ -65,6 +68,8 @@ class AddDropoutLayerNorm(torch.autograd.Function):
               _p(out_pe), _p(mean), _p(rstd))
         ctx.save_for_backward(x, y, g32, mean, rstd)
         ctx.cfg = (p if drop else 0.0, seed, salt, pe is not None)
+        both = isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter)
+        ctx.params = (gamma, beta) if both and gamma.requires_grad and beta.requires_grad else None
         return out32, out16, out_pe
 
     @staticmethod
@@ -77,6 +82,16 @@ class AddDropoutLayerNorm(torch.autograd.Function):
         gpe = gpe.contiguous() if gpe is not None else None
         dx = torch.empty_like(x)
         dy = torch.empty_like(y) if y is not None else None
+        dfr = sa_fused.deferred_wgrads.active
+        if dfr is not None and ctx.params is not None:
+            # nothing reads dgamma / dbeta before the optimizer: leave per-workgroup partial sums and let the block sum
+            # those of all LayerNorms in one launch (the atomics of the immediate path were most of this kernel's time)
+            blocks = int(_lib.omnipq_add_dropout_layernorm_bwd_blocks(ctypes.c_longlong(R)))
+            part = torch.empty((blocks, 2 * C), device=x.device, dtype=torch.float32)
+            _call(_lib.omnipq_add_dropout_layernorm_bwd_partials, x, ctypes.c_longlong(R), C, _p(x), _p(y), _p(gamma),
+                  ctypes.c_float(p), _p(seed), salt, _p(mean), _p(rstd), _p(g32), _p(g16), _p(gpe), _p(dx), _p(dy), _p(part))
+            dfr.add_layernorm(part, blocks, C, *ctx.params)
+            return dx, dy, None, None, None, None, (gpe if has_pe else None), None, None
         dgb = zeros_f32(2 * C, x.device)
         _call(_lib.omnipq_add_dropout_layernorm_bwd, x, ctypes.c_longlong(R), C, _p(x), _p(y), _p(gamma),
               ctypes.c_float(p), _p(seed), salt, _p(mean), _p(rstd), _p(g32), _p(g16), _p(gpe), _p(dx), _p(dy), _p(dgb))

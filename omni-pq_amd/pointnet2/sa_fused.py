@@ -574,8 +574,13 @@ class deferred_wgrads:
         if deferred_wgrads.active is not None:
             raise RuntimeError("deferred_wgrads blocks do not nest")
         self.items = []             # (dY, X, M, N, P, weight target, (cout, cin), bias target | None)
+        self.ln_items = []          # (partials [blocks][2C], blocks, C, gamma, beta): LayerNorm parameter gradients
         deferred_wgrads.active = self
         return self
+
+    def add_layernorm(self, part, blocks, C, gamma, beta):
+        """dgamma | dbeta of one LayerNorm as per-workgroup partial sums (omnipq_add_dropout_layernorm_bwd_partials)."""
+        self.ln_items.append((part, blocks, C, gamma, beta))
 
     def add(self, dY, X, M, N, P, wt, crop, bt, below=None):
         """below: X is that layer's pre-BN output and stands for relu(below.a * X + below.b)"""
@@ -593,6 +598,7 @@ class deferred_wgrads:
             for param, g in getattr(self, "_assign", ()):          # .grad is complete after the block
                 self._accumulate(param, g)
         self.items = None
+        self.ln_items = None
         self._inflight = None
         self._assign = None
         return False
@@ -601,20 +607,46 @@ class deferred_wgrads:
         """Compute what has been collected so far on `stream` (ordered after the current stream), e.g. the decoder's
         and heads' gradients underneath the backbone's backward pass.  Operands stay referenced until the block
         ends (they were allocated on the current stream's pool)."""
-        if not self.items:
+        if not self.items and not self.ln_items:
             return
         cur = torch.cuda.current_stream(stream.device)
         stream.wait_stream(cur)
         self.__dict__.setdefault("_inflight", []).extend(self.items)
+        self._inflight.extend(self.ln_items)
         streams = self.__dict__.setdefault("_side_streams", [])
         if stream not in streams:
             streams.append(stream)
         with torch.cuda.stream(stream):
             self.flush()
         self.items = []
+        self.ln_items = []
 
+
+    def _flush_layernorms(self):
+        """All LayerNorm parameter gradients collected so far: ONE reduction launch per 32 of them into one flat
+        zero-initialised buffer; the parameters get views of it when the block ends."""
+        todo, self.ln_items = self.ln_items, []
+        assign = self.__dict__.setdefault("_assign", [])
+        for i0 in range(0, len(todo), 32):
+            chunk = todo[i0:i0 + 32]
+            n = len(chunk)
+            dev = chunk[0][0].device
+            flat = zeros_f32(sum(2 * it[2] for it in chunk), dev)
+            parts = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in chunk])
+            blocks = (ctypes.c_int * n)(*[it[1] for it in chunk])
+            chans = (ctypes.c_int * n)(*[it[2] for it in chunk])
+            outs, off = (ctypes.c_void_p * n)(), 0
+            for i, (_, _, C, gamma, beta) in enumerate(chunk):
+                outs[i] = flat.data_ptr() + 4 * off
+                assign.append((gamma, flat[off:off + C].view(gamma.shape)))
+                assign.append((beta, flat[off + C:off + 2 * C].view(beta.shape)))
+                off += 2 * C
+            _call(_lib.omnipq_layernorm_param_reduce, flat, n, parts, blocks, chans, outs)
+            self.__dict__.setdefault("_inflight", []).extend(chunk)      # the partials stay alive until the block ends
 
     def flush(self):
+        if self.ln_items:
+            self._flush_layernorms()
         items = self.items
         if not items:
             return

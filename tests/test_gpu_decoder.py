@@ -86,6 +86,40 @@ def test_add_dropout_layernorm_matches_torch(R, C, p, with_pe):
         assert torch.equal(got[4], gpe)
 
 
+@pytest.mark.parametrize("R,C,n_layers", [(4096, 288, 3), (37, 1024, 1), (9000, 32, 34)])
+def test_layernorm_parameter_gradients_deferred_to_one_reduction(R, C, n_layers):
+    """Inside sa_fused.deferred_wgrads the LayerNorm backward leaves per-workgroup partial sums and the block sums those of
+    ALL LayerNorms in one launch per 32 (omnipq_layernorm_param_reduce): the same dgamma / dbeta as the immediate path
+    (f32 sums in another order), assigned to .grad when the block ends, accumulated when .grad exists already."""
+    import decoder_rows
+    import sa_fused
+    gen = torch.Generator().manual_seed(R + C)
+    xs = [torch.randn(R, C, generator=gen).to(dev()) for _ in range(n_layers)]
+    ys = [torch.randn(R, C, generator=gen).to(torch.bfloat16).to(dev()) for _ in range(n_layers)]
+    gs = [torch.randn(R, C, generator=gen).to(dev()) for _ in range(n_layers)]
+    params = [(torch.nn.Parameter((1 + 0.3 * torch.randn(C, generator=gen)).to(dev())),
+               torch.nn.Parameter((0.2 * torch.randn(C, generator=gen)).to(dev()))) for _ in range(n_layers)]
+
+    def run():
+        loss = 0.0
+        for x, y, g, (gamma, beta) in zip(xs, ys, gs, params):
+            out32, _, _ = decoder_rows.AddDropoutLayerNorm.apply(x, y, gamma, beta, 1e-5, 0.0, None, True, False)
+            loss = loss + (out32 * g).sum()
+        return loss
+
+    run().backward()
+    want = [(a.grad.clone(), b.grad.clone()) for a, b in params]
+    for a, b in params:
+        a.grad = b.grad = None
+    params[0][0].grad = torch.ones(C, device=dev())          # an existing gradient is added to
+    with sa_fused.deferred_wgrads():
+        run().backward()
+        assert params[-1][1].grad is None                    # nothing is assigned before the block ends
+    for i, ((a, b), (wa, wb)) in enumerate(zip(params, want)):
+        assert rel_l2(a.grad - (1.0 if i == 0 else 0.0), wa) < 1e-5, i
+        assert rel_l2(b.grad, wb) < 1e-5, i
+
+
 def test_relu_dropout_rows_layer_matches_torch():
     """linear -> relu -> dropout -> linear through the rows engine == torch with the recovered mask."""
     import dropout_state
