@@ -167,13 +167,22 @@ __global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *_
                                                          const float *__restrict__ base, QuadOut o,
                                                          float *__restrict__ norm_out) {
   __shared__ float red[4];
+  // four rows per thread and trip: the scattered 2-byte loads of a trip are independent, so the sum over the whole
+  // tensor (R / 256 rows per thread) costs R / 1024 round trips instead of R / 256.  Same order in every workgroup.
   float ss = 0.f;
-  for (int r = (int)threadIdx.x; r < R; r += 256) {
-    const bf16_t *row = y + (size_t)r * ldy + 5;
-    const float a = (float)row[0], b = (float)row[1], c = (float)row[2];
-    ss = __builtin_fmaf(a, a, ss);
-    ss = __builtin_fmaf(b, b, ss);
-    ss = __builtin_fmaf(c, c, ss);
+  for (int r0 = (int)threadIdx.x; r0 < R; r0 += 1024) {
+    float v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 256 * u;
+      const bf16_t *row = y + (size_t)(r < R ? r : r0) * ldy + 5;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[u][c] = r < R ? (float)row[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ss = __builtin_fmaf(v[u][c], v[u][c], ss);
   }
   // torch.norm of a bf16 tensor returns a bf16 scalar: the division below uses that rounded value
   const float nrm = (float)(bf16_t)__builtin_sqrtf(block_sum_256(ss, red));
@@ -199,11 +208,23 @@ __global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, cons
   const float nrm = *norm_in;
   // out = x / n, n = ||x||:  dx = g / n - x * (sum g x) / n^3
   float dot = 0.f;
-  for (int r = (int)threadIdx.x; r < R; r += 256) {
-    const int b = r / K, k = r - b * K;
-    const bf16_t *row = y + (size_t)r * ldy + 5;
+  for (int r0 = (int)threadIdx.x; r0 < R; r0 += 1024) {           // four independent rows per trip, see the forward kernel
+    float gv[4][3], yv[4][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dot = __builtin_fmaf(quad_grad_at(gs.g[2], b, k, c), (float)row[c], dot);
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 256 * u, rc = r < R ? r : r0;
+      const int b = rc / K, k = rc - b * K;
+      const bf16_t *row = y + (size_t)rc * ldy + 5;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gv[u][c] = r < R ? quad_grad_at(gs.g[2], b, k, c) : 0.f;
+        yv[u][c] = (float)row[c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dot = __builtin_fmaf(gv[u][c], yv[u][c], dot);
   }
   const float s = block_sum_256(dot, red) / (nrm * nrm * nrm);
   const int c0 = (int)threadIdx.x & 15;
