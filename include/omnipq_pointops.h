@@ -78,6 +78,11 @@ int omnipq_fps_init(void);
 int omnipq_gather_points(int b, int c, int n, int npoints, const float *points,
                          const int *idx, float *out, void *stream);
 
+/* The sampled centres straight from the cloud: xyz (b,n,3), idx (b,npoints) -> out (b,npoints,3).  Same values as
+ * transpose -> gather_points -> transpose (pointnet2_modules.py:137-141) without the two layout copies; used where no
+ * gradient flows into xyz (the backbone: raw coordinates). */
+int omnipq_gather_xyz(int b, int n, int npoints, const float *xyz, const int *idx, float *out, void *stream);
+
 /* replaces gather_points_grad_kernel_wrapper (sampling.cpp:14-16).
  *   grad_out (b,c,npoints), idx (b,npoints) -> grad_points (b,c,n), which the caller
  *   zero-fills (sampling.cpp:57-59); contributions are accumulated with f32 atomics. */

@@ -58,6 +58,19 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int c, int n, int P,
     if (l < cend) atomicAdd(dst + (size_t)l * n, v[l]);
 }
 
+// out[b][p][0..2] = xyz[b][idx[b][p]][0..2]: the sampled centres straight from the (B, N, 3) cloud -- what the reference
+// reaches by transpose + gather_points + transpose (pointnet2_modules.py:137-141), without the two layout copies
+__global__ __launch_bounds__(256) void gather_xyz_kernel(int n, int P, long long total, const float *__restrict__ xyz,
+                                                        const int *__restrict__ idx, float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long scene = i / P;
+  const float *src = xyz + ((size_t)scene * n + idx[i]) * 3;
+  const float x = src[0], y = src[1], z = src[2];
+  float *dst = out + (size_t)i * 3;
+  dst[0] = x, dst[1] = y, dst[2] = z;
+}
+
 static int launch_gather(int b, int c, int n, int P, const float *points, const int *idx,
                          float *out, hipStream_t stream) {
   if (b < 0 || c < 0 || n < 0 || P < 0) return OMNIPQ_EINVAL;
@@ -83,6 +96,17 @@ static int launch_scatter(int b, int c, int n, int P, const float *grad_out, con
 }
 
 }  // namespace omnipq
+
+extern "C" int omnipq_gather_xyz(int b, int n, int npoints, const float *xyz, const int *idx, float *out, void *stream) {
+  if (b < 0 || n < 0 || npoints < 0) return OMNIPQ_EINVAL;
+  const long long total = (long long)b * npoints;
+  if (total == 0) return OMNIPQ_OK;
+  if (!xyz || !idx || !out || n == 0) return OMNIPQ_EINVAL;
+  if (total > 0x7FFFFFFFll) return OMNIPQ_ETOOLARGE;
+  omnipq::gather_xyz_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(n, npoints, total, xyz, idx, out);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
 
 extern "C" int omnipq_gather_points(int b, int c, int n, int npoints, const float *points,
                                     const int *idx, float *out, void *stream) {

@@ -113,8 +113,11 @@ class Pointnet2Backbone(nn.Module):
                 plan["inds"].append(inds)
                 plan["events"].append(ev)
                 if name != "sa4":
-                    xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
-                        .transpose(1, 2).contiguous()
+                    if hasattr(ext, "gather_xyz"):
+                        xyz = ext.gather_xyz(xyz.contiguous(), inds)
+                    else:
+                        xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds) \
+                            .transpose(1, 2).contiguous()
                 if self.plan_extra and name in self.plan_extra:
                     extra = self.__dict__.setdefault("_plan_bufs", {}).setdefault(
                         ("extra", name, pointcloud.shape[0], str(pointcloud.device)),

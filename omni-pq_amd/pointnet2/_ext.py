@@ -111,6 +111,20 @@ def gather_points(points, idx):
     return out
 
 
+def gather_xyz(xyz, idx):
+    """(B,N,3) f32, (B,M) i32 -> (B,M,3): xyz[b, idx[b, m]] (no gradient; the reference's transpose / gather / transpose)"""
+    _check(xyz, "xyz", torch.float32)
+    _check(idx, "idx", torch.int32, cuda_like=xyz)
+    _need_gpu(xyz)
+    b, n, three = xyz.shape
+    if three != 3:
+        raise ValueError("gather_xyz: xyz must be (B, N, 3)")
+    m = idx.shape[1]
+    out = torch.empty((b, m, 3), device=xyz.device, dtype=torch.float32)
+    _run(_lib.omnipq_gather_xyz, xyz, b, n, m, _ptr(xyz), _ptr(idx), _ptr(out))
+    return out
+
+
 def gather_points_grad(grad_out, idx, n):
     """(B,C,M), (B,M) -> (B,C,n) scatter-add   [sampling.cpp:48-71]"""
     _check(grad_out, "grad_out", torch.float32)

@@ -32,6 +32,9 @@ def _centres(xyz, npoint, inds=None):
         return None, inds
     if inds is None:
         inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    if xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous() and inds.is_contiguous() and \
+            not (torch.is_grad_enabled() and xyz.requires_grad) and hasattr(pointnet2_utils._ext, "gather_xyz"):
+        return pointnet2_utils._ext.gather_xyz(xyz, inds), inds        # one launch instead of copy + gather + copy
     flipped = xyz.transpose(1, 2).contiguous()
     new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
     return new_xyz, inds

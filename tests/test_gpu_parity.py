@@ -359,3 +359,16 @@ def test_fps_on_two_streams_at_once():
         torch.cuda.synchronize()
         assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
     ext.fps_check()
+
+
+def test_gather_xyz_equals_transpose_gather_transpose():
+    """omnipq_gather_xyz == the reference's sequence (pointnet2_modules.py:137-141) bit for bit, incl. repeated indices."""
+    import pointnet2_utils
+    gen = torch.Generator().manual_seed(9)
+    xyz = torch.randn(3, 5000, 3, generator=gen).cuda()
+    idx = torch.randint(0, 5000, (3, 777), generator=gen, dtype=torch.int32).cuda()
+    idx[:, :5] = idx[:, 5:10]
+    got = pointnet2_utils._ext.gather_xyz(xyz, idx)
+    want = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    assert torch.equal(got, want)
+    assert pointnet2_utils._ext.gather_xyz(xyz[:, :0], idx[:, :0]).shape == (3, 0, 3)
