@@ -1285,10 +1285,36 @@ __global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, int
     const bool dense = g.numel < 0;
     const int numel = dense ? -g.numel : g.numel;
     float acc = 0.f;
+    if (dense && base + 4096 <= numel && (reinterpret_cast<size_t>(g.ptr) & 15) == 0) {
+      // a full chunk of a dense block (the large feature maps): memory order, 16-byte loads, all of a thread's loads in
+      // flight at once -- a sum does not care about the order
+      if (bf) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.ptr) + base);
+        uint4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = src[u * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float f[8];
+          unpack8(v[u], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc += f[e];
+        }
+      } else {
+        const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(g.ptr) + base);
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[u * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      }
+      total += acc / (float)numel;
+      continue;
+    }
     for (int u = 0; u < 16; ++u) {
       const int i = base + u * 256 + (int)threadIdx.x;
       if (i < numel) {
-        if (dense) {                  // a sum does not care about the order: memory order, coalesced
+        if (dense) {                  // tail chunk or unaligned view: element by element
           acc += bf ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[i] : reinterpret_cast<const float *>(g.ptr)[i];
           continue;
         }

@@ -59,14 +59,17 @@ def test_sum_of_means_matches_torch_on_strided_views():
     dev = torch.device("cuda", 0)
     gen = torch.Generator().manual_seed(0)
     base = [torch.randn(4, 37, 50, generator=gen), torch.randn(8, 256, 3, generator=gen), torch.randn(1000, generator=gen),
-            torch.randn(2, 3, 5, 7, generator=gen), torch.randn(6, 64, 128, generator=gen)]
+            torch.randn(2, 3, 5, 7, generator=gen), torch.randn(6, 64, 128, generator=gen), torch.randn(9001, generator=gen)]
     ts = [base[0].to(dev).requires_grad_(True),
           base[1].to(dev).to(torch.bfloat16).requires_grad_(True),
           base[2].to(dev).requires_grad_(True),
           base[3].to(dev).requires_grad_(True),
-          base[4].to(dev).to(torch.bfloat16).requires_grad_(True)]
+          base[4].to(dev).to(torch.bfloat16).requires_grad_(True),
+          base[5].to(dev).requires_grad_(True)]
     views = [ts[0].transpose(1, 2), ts[0][:, 3:20, ::2], ts[1], ts[1].transpose(0, 2), ts[2][5:900:3], ts[3].permute(3, 1, 0, 2),
-             ts[4][:, :, 10:50], ts[4].transpose(1, 2)[:, 1:]]
+             ts[4][:, :, 10:50], ts[4].transpose(1, 2)[:, 1:], ts[4],
+             ts[5][1:],                      # dense, two full chunks, but not 16-byte aligned: element by element
+             ts[5][4:]]                      # dense and aligned: 16-byte loads + a tail chunk
     got = bench.SumOfMeans.apply(*views)
     want = sum(v.float().mean() for v in views)
     assert abs(float(got) - float(want)) < 1e-4 * (1 + abs(float(want)))

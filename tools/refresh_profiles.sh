@@ -10,6 +10,7 @@
 #   4./5. rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on bench.py --graph off (whole step)
 #   6./7. the same two counters on tools/sa_stage_run.py (the five SA stages only)
 #   8./9. SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE / SQ_INSTS_VALU_MFMA_MOPS_BF16 on both (MFMA-busy, tools/pmc_mfma.py)
+#   10./11. SQ wave-cycle split / instruction counts / LDS activity on both (tools/pmc_issue.sh, tools/pmc_issue.py)
 set -u
 TAG=${1:-r01}
 R=$(pwd)
@@ -30,6 +31,10 @@ if [ "${2:-}" != "--collect" ]; then
   timeout 900 rocprofv3 --kernel-trace --pmc $MF --output-format csv -d $OUT/pmc_MFMA -o pmc -- python $R/bench.py --no-cpu-baseline --no-op-timing --graph off --steps 3 --warmup 2 > $OUT/pmc_MFMA.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc $MF --output-format csv -d $OUT/sapmc_MFMA -o pmc -- python $R/tools/sa_stage_run.py --steps 3 > $OUT/sapmc_MFMA.log 2>&1
   for p in pmc sapmc; do find $OUT/${p}_MFMA -name "*kernel_trace.csv" -delete; done
+  # 10./11. wave-cycle split, instruction counts, pipe activity per kernel (tools/pmc_issue.sh: three counter passes each)
+  bash $R/tools/pmc_issue.sh refresh_sa -- python $R/tools/sa_stage_run.py --steps 3 > $OUT/issue_sa.log 2>&1
+  bash $R/tools/pmc_issue.sh refresh_bench -- python $R/bench.py --no-cpu-baseline --no-op-timing --graph off --steps 3 --warmup 2 > $OUT/issue_bench.log 2>&1
+  cd /tmp
   # keep what travels back small: per-kernel traces are reduced on the box
   for m in graph eager; do
     D=$(dirname $(find $OUT/$m -name "*_kernel_trace.csv" | head -1))
@@ -57,3 +62,5 @@ python $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE 0.4 3 $P/
 python $R/tools/pmc_traffic.py $OUT/sapmc_FETCH_SIZE $OUT/sapmc_WRITE_SIZE 0.4 3 $P/${TAG}_sa_stage_pmc_traffic.json $P/${TAG}_sa_stage_pmc_traffic.md
 python $R/tools/pmc_mfma.py $OUT/pmc_MFMA 0.4 3 $P/${TAG}_bench_pmc_mfma.json $P/${TAG}_bench_pmc_mfma.md
 python $R/tools/pmc_mfma.py $OUT/sapmc_MFMA 0.4 3 $P/${TAG}_sa_stage_pmc_mfma.json $P/${TAG}_sa_stage_pmc_mfma.md
+python $R/tools/pmc_issue.py $R/gpurun_out/issue_refresh_sa 0.4 3 $P/${TAG}_sa_stage_pmc_issue.md > /dev/null
+python $R/tools/pmc_issue.py $R/gpurun_out/issue_refresh_bench 0.4 3 $P/${TAG}_bench_pmc_issue.md > /dev/null
