@@ -25,6 +25,22 @@ def test_random_sampling_follows_the_reference_statement():
     assert np.array_equal(ip.random_sampling(pc, 20, replace=True), pc[want])
 
 
+def test_random_sampling_reproduces_the_reference_function():
+    """tests/golden/random_sampling.npz = the choices of the reference's own random_sampling (utils/pc_util.py:36-44, run
+    by tests/golden/make_golden_random_sampling.py) under a seeded numpy generator: same draws, same rows."""
+    import os
+    import input_pipeline as ip
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_sampling.npz"))
+    for name in sorted({k.split(".")[0] for k in gold.files}):
+        seed, n, k, rep = (int(v) for v in gold[f"{name}.args"])
+        pc = np.random.RandomState(1000 + seed).rand(n, 6).astype(np.float32)
+        np.random.seed(seed)
+        sub, choices = ip.random_sampling(pc, k, replace=None if rep < 0 else bool(rep), return_choices=True)
+        assert np.array_equal(choices, gold[f"{name}.choices"]), name
+        assert np.array_equal(sub, pc[gold[f"{name}.choices"]]), name
+        assert np.allclose(sub.astype(np.float64).sum(0), gold[f"{name}.checksum"], rtol=0, atol=0), name
+
+
 def test_pipeline_refuses_the_cpu():
     import input_pipeline as ip
     with pytest.raises(RuntimeError, match="CPU not supported"):
