@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) void bq_grid_kernel(int n, int m, float inv_h,
   idx += ((size_t)scene * m + q) * nsample;
   const float qx = new_xyz[q * 3 + 0], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
   const unsigned long long lower = (1ull << lane) - 1ull;
+  // The cell of a point is exact to within 1e-3 cells only while |x| / h < ~4000 (see omnipq_ball_query_grid): a centre
+  // farther out than half of that -- un-centred world coordinates, or a non-finite coordinate (the comparison is false
+  // for NaN) -- takes the reference walk below instead of trusting the grid.  Every point of ITS ball is then within
+  // the bound too, so the test on the centre is sufficient.
+  const bool far = !(fabsf(qx) * inv_h < 2000.f && fabsf(qy) * inv_h < 2000.f && fabsf(qz) * inv_h < 2000.f);
 
   // lanes 0..26: one neighbour cell each -> its bucket, dropped if an earlier lane has the same bucket
   const int cx = bq_cell(qx, inv_h), cy = bq_cell(qy, inv_h), cz = bq_cell(qz, inv_h);
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void bq_grid_kernel(int n, int m, float inv_h,
     const int y = __shfl_up(pre, d);
     if (lane >= d) pre += y;
   }
-  const int total = __builtin_amdgcn_readlane(pre, 26);
+  const int total = far ? 0 : __builtin_amdgcn_readlane(pre, 26);
   if (lane < 27) {
     cell_beg[wave][lane] = beg;
     cell_pre[wave][lane] = pre - cnt;                    // exclusive
@@ -183,8 +188,9 @@ __global__ __launch_bounds__(256) void bq_grid_kernel(int n, int m, float inv_h,
   }
   __builtin_amdgcn_wave_barrier();
 
-  if (found > kBqCap) {
-    // more hits than the list holds: the reference walk for this centre (ball_query_kernel with one query)
+  if (far || found > kBqCap) {
+    // more hits than the list holds (or a centre outside the grid's exact range): the reference walk for this centre
+    // (ball_query_kernel with one query)
     int cntq = 0, first = 0;
     for (int k0 = 0; k0 < n && cntq < nsample; k0 += 64) {
       const int k = k0 + lane;
@@ -255,7 +261,8 @@ extern "C" int omnipq_ball_query_grid(int b, int n, int m, float radius, int nsa
   const float radius2 = radius * radius;  // ball_query_gpu.cu:27 (f32 product)
   // Cell edge 0.1 % above the radius.  A point passes the f32 test d2 < r2 only if |dx| <= r (1 + ~1e-6), and
   // fl(x * inv_h) is off by <= |x / h| * 2^-23 cells on either side: with the margin of 1e-3 cells a point of the
-  // ball can never land two cells away while |x| / h < ~4000 (800 m at r = 0.2; scenes are a few metres).
+  // ball can never land two cells away while |x| / h < ~4000 (800 m at r = 0.2; scenes are a few metres).  Centres
+  // beyond half of that (or with a non-finite coordinate) take the reference walk inside bq_grid_kernel.
   const float inv_h = 1.0f / (radius * 1.001f);
   const long long total = (long long)b * n;
   bq_cell_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(total, inv_h, xyz, bucket);

@@ -158,6 +158,25 @@ def test_ball_query_grid_boundary_and_cell_edges():
     assert want[0, 3].tolist() == [0] * 8
 
 
+def test_ball_query_grid_far_from_the_origin_and_non_finite_coordinates():
+    """A scene in un-centred world coordinates (|x| / r ~ 5000: beyond the range in which a point's cell is exact) and a
+    cloud with NaN / inf rows: centres outside the exact range take the reference walk inside the grid kernel, so the
+    indices still equal the brute-force kernel's (and the oracle's)."""
+    gen = torch.Generator().manual_seed(4)
+    xyz = torch.rand(2, 9000, 3, generator=gen) * 3.0
+    xyz[0] += torch.tensor([1000.0, -1000.0, 999.5])            # r = 0.2: |x| / h = 5000
+    xyz[1, 17] = float("nan")
+    xyz[1, 18, 1] = float("inf")
+    centres = xyz[:, torch.randperm(9000, generator=gen)[:300]].contiguous()
+    centres[1, 0] = float("nan")
+    centres[1, 1] = xyz[1, 19]
+    brute = capi.ball_query(centres.to(dev()), xyz.to(dev()), 0.2, 32)
+    grid = capi.ball_query_grid(centres.to(dev()), xyz.to(dev()), 0.2, 32)
+    assert torch.equal(grid, brute)
+    assert torch.equal(grid.cpu(), oracle_ext.ball_query(centres, xyz, 0.2, 32))
+    assert int((grid[0] != grid[0, :, :1]).sum()) > 0             # the far scene does have multi-point balls
+
+
 def test_ball_query_radius_boundary_is_strict():
     """d2 == radius^2 exactly must be OUT (ball_query_gpu.cu:35 `d2 < radius2`)."""
     xyz = torch.zeros(1, 8, 3)
