@@ -324,3 +324,139 @@ extern "C" int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, co
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
+
+// ---- voting module tail (reference models/voting_module.py:55-63, models/pq_transformer.py:216-217) -----------------
+// net rows (B*K, >= 3 + C) bf16 = [offset 3 | residual C] per seed (vote_factor 1):
+//   vote_xyz      = seed_xyz + offset                                   (B, K, 3) f32
+//   v             = seed_features + residual                            (B, C, K)
+//   vote_features = v / ||v||_2 over the channels                       (B, C, K) f32, + its bf16 twin (B, K, C)
+// The two operands of v lie in opposite layouts (rows of `net`, channel-major seed features), so a workgroup takes 32
+// seeds x all channels through LDS: rows in, channel-major out, both sides coalesced.  The op-by-op form is two adds, a
+// layout copy, a norm and a division forward and a dozen elementwise launches backward.
+namespace omnipq {
+constexpr int kVotePts = 32, kVoteMaxC = 320;
+
+__global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf16_t *__restrict__ net, int ldn,
+                                                         const float *__restrict__ seed_xyz,
+                                                         const float *__restrict__ seed_feat, long long sfb,
+                                                         long long sfc, long long sfk, float *__restrict__ vote_xyz,
+                                                         float *__restrict__ out, bf16_t *__restrict__ twin,
+                                                         float *__restrict__ norm_out) {
+  __shared__ float v[kVoteMaxC][kVotePts + 1];
+  __shared__ float part[8][kVotePts];
+  __shared__ float inv[kVotePts];
+  const int b = (int)blockIdx.y, k0 = (int)blockIdx.x * kVotePts, tid = (int)threadIdx.x;
+  const int npts = K - k0 < kVotePts ? K - k0 : kVotePts;
+  // rows in: consecutive threads walk a row's channels
+  for (int i = tid; i < npts * (C + 3); i += 256) {
+    const int p = i / (C + 3), c = i - p * (C + 3);
+    const float x = (float)net[((size_t)b * K + k0 + p) * ldn + c];
+    if (c < 3)
+      vote_xyz[((size_t)b * K + k0 + p) * 3 + c] = seed_xyz[((size_t)b * K + k0 + p) * 3 + c] + x;
+    else
+      v[c - 3][p] = x;
+  }
+  __syncthreads();
+  // channel-major: consecutive threads = consecutive seeds
+  const int p = tid & (kVotePts - 1), cg = tid >> 5;            // 8 channel groups
+  float ss = 0.f;
+  if (p < npts)
+    for (int c = cg; c < C; c += 8) {
+      const float t = seed_feat[(size_t)b * sfb + (size_t)c * sfc + (size_t)(k0 + p) * sfk] + v[c][p];
+      v[c][p] = t;
+      ss = __builtin_fmaf(t, t, ss);
+    }
+  part[cg][p] = ss;
+  __syncthreads();
+  if (tid < kVotePts) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += part[g][tid];
+    const float n = __builtin_sqrtf(s);
+    inv[tid] = 1.0f / n;
+    if (tid < npts) norm_out[(size_t)b * K + k0 + tid] = n;
+  }
+  __syncthreads();
+  if (p < npts)
+    for (int c = cg; c < C; c += 8) {
+      const float t = v[c][p] * inv[p];
+      v[c][p] = t;
+      out[((size_t)b * C + c) * K + k0 + p] = t;
+    }
+  __syncthreads();
+  for (int i = tid; i < npts * C; i += 256) {
+    const int q = i / C, c = i - q * C;
+    twin[((size_t)b * K + k0 + q) * C + c] = (bf16_t)v[c][q];
+  }
+}
+
+// dv = (g - out <g, out>) / ||v||;  d_net = [g_xyz | dv | 0...];  d_seed_features = dv (channel-major)
+__global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, const float *__restrict__ out,
+                                                             const float *__restrict__ norm,
+                                                             const float *__restrict__ g_xyz,
+                                                             const float *__restrict__ g_feat, bf16_t *__restrict__ dnet,
+                                                             int ldd, float *__restrict__ dseed) {
+  __shared__ float v[kVoteMaxC][kVotePts + 1];
+  __shared__ float part[8][kVotePts];
+  const int b = (int)blockIdx.y, k0 = (int)blockIdx.x * kVotePts, tid = (int)threadIdx.x;
+  const int npts = K - k0 < kVotePts ? K - k0 : kVotePts;
+  const int p = tid & (kVotePts - 1), cg = tid >> 5;
+  float dot = 0.f;
+  if (p < npts && g_feat)
+    for (int c = cg; c < C; c += 8) {
+      const size_t o = ((size_t)b * C + c) * K + k0 + p;
+      const float g = g_feat[o];
+      v[c][p] = g;
+      dot = __builtin_fmaf(g, out[o], dot);
+    }
+  part[cg][p] = dot;
+  __syncthreads();
+  if (p < npts) {
+    float d = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) d += part[g][p];
+    const float rn = 1.0f / norm[(size_t)b * K + k0 + p];
+    for (int c = cg; c < C; c += 8) {
+      const size_t o = ((size_t)b * C + c) * K + k0 + p;
+      const float t = g_feat ? (v[c][p] - out[o] * d) * rn : 0.f;
+      v[c][p] = t;
+      if (dseed) dseed[o] = t;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < npts * ldd; i += 256) {
+    const int q = i / ldd, c = i - q * ldd;
+    float t = 0.f;
+    if (c < 3)
+      t = g_xyz ? g_xyz[((size_t)b * K + k0 + q) * 3 + c] : 0.f;
+    else if (c < 3 + C)
+      t = v[c - 3][q];
+    dnet[((size_t)b * K + k0 + q) * ldd + c] = (bf16_t)t;
+  }
+}
+}  // namespace omnipq
+
+extern "C" int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const float *seed_xyz,
+                                  const float *seed_feat, long long sfb, long long sfc, long long sfk, float *vote_xyz,
+                                  float *vote_feat, void *twin16, float *norm, void *stream) {
+  using namespace omnipq;
+  if (b < 0 || k < 0 || c <= 0 || c > kVoteMaxC || ldn < c + 3) return OMNIPQ_EINVAL;
+  if (b == 0 || k == 0) return OMNIPQ_OK;
+  if (!net || !seed_xyz || !seed_feat || !vote_xyz || !vote_feat || !twin16 || !norm || b > 65535) return OMNIPQ_EINVAL;
+  vote_decode_kernel<<<dim3((k + kVotePts - 1) / kVotePts, b), 256, 0, (hipStream_t)stream>>>(
+      k, c, (const bf16_t *)net, ldn, seed_xyz, seed_feat, sfb, sfc, sfk, vote_xyz, vote_feat, (bf16_t *)twin16, norm);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_vote_decode_bwd(int b, int k, int c, const float *vote_feat, const float *norm, const float *g_xyz,
+                                      const float *g_feat, void *dnet, int ldd, float *dseed_feat, void *stream) {
+  using namespace omnipq;
+  if (b < 0 || k < 0 || c <= 0 || c > kVoteMaxC || ldd < c + 3) return OMNIPQ_EINVAL;
+  if (b == 0 || k == 0) return OMNIPQ_OK;
+  if (!vote_feat || !norm || !dnet || b > 65535) return OMNIPQ_EINVAL;
+  vote_decode_bwd_kernel<<<dim3((k + kVotePts - 1) / kVotePts, b), 256, 0, (hipStream_t)stream>>>(
+      k, c, vote_feat, norm, g_xyz, g_feat, (bf16_t *)dnet, ldd, dseed_feat);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

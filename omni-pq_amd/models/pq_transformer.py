@@ -454,8 +454,8 @@ class PQ_Transformer(nn.Module):
         end_points['aggregated_sample_xyz'] = quad_xyz
 
         # object branch: vote, normalise, aggregate
-        vote_xyz, vote_features = self.vote(seed_xyz, seed_features)
-        vote_features = vote_features.div(torch.norm(vote_features, p=2, dim=1).unsqueeze(1))
+        # vote + the reference's L2 normalisation over the channels (:216-217), fused on the row kernels
+        vote_xyz, vote_features = self.vote(seed_xyz, seed_features, normalized=True)
         end_points['vote_xyz'] = vote_xyz
         end_points['vote_features'] = vote_features
         cluster_xyz, cluster_feature, _ = self.vote_aggregation(vote_xyz, vote_features)

@@ -19,10 +19,57 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
 import rows_mlp  # noqa: E402
 
 
+_FUSED_TAIL = os.environ.get("OMNIPQ_VOTE_DECODE", "1") != "0"      # "0": the op-by-op tail (A/B, debugging)
+
+
 def _lin(x2d, conv):
     """kernel-size-1 Conv1d applied to rows (points x channels): one GEMM with the bias in its epilogue
     (see models/pq_transformer.py:lin)."""
     return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
+
+
+class VoteDecode(torch.autograd.Function):
+    """(net rows (B*K, >= 3 + C) bf16, seed_xyz (B,K,3), seed_features (B,C,K)) -> (vote_xyz (B,K,3) f32, L2-normalised
+    vote_features (B,C,K) f32, their bf16 row-major twin (B,K,C)): the tail of `VotingModule.forward` and the
+    normalisation models/pq_transformer.py:216-217 applies to its result, one launch each way (csrc/head_ops.hip:
+    omnipq_vote_decode) instead of two adds, a layout copy, a norm and a division forward and a dozen elementwise
+    launches backward."""
+
+    @staticmethod
+    def forward(ctx, net, seed_xyz, seed_features):
+        import ctypes
+        import sa_fused
+        B, K, _ = seed_xyz.shape
+        C = seed_features.shape[1]
+        dev = net.device
+        sx = seed_xyz.detach().float().contiguous()
+        sf = seed_features.detach()
+        vote_xyz = torch.empty((B, K, 3), device=dev, dtype=torch.float32)
+        out = torch.empty((B, C, K), device=dev, dtype=torch.float32)
+        twin = torch.empty((B, K, C), device=dev, dtype=torch.bfloat16)
+        norm = torch.empty((B, K), device=dev, dtype=torch.float32)
+        sa_fused._call(sa_fused._lib.omnipq_vote_decode, net, B, K, C, sa_fused._p(net), net.stride(0), sa_fused._p(sx),
+                       sa_fused._p(sf), ctypes.c_longlong(sf.stride(0)), ctypes.c_longlong(sf.stride(1)),
+                       ctypes.c_longlong(sf.stride(2)), sa_fused._p(vote_xyz), sa_fused._p(out), sa_fused._p(twin),
+                       sa_fused._p(norm))
+        ctx.save_for_backward(out, norm)
+        ctx.geom = (B, K, C, net.shape[1])
+        ctx.mark_non_differentiable(twin)
+        ctx.set_materialize_grads(False)
+        return vote_xyz, out, twin
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_feat, _g_twin):
+        import sa_fused
+        out, norm = ctx.saved_tensors
+        B, K, C, ld = ctx.geom
+        g_xyz = None if g_xyz is None else g_xyz.float().contiguous()
+        g_feat = None if g_feat is None else g_feat.float().contiguous()
+        dnet = torch.empty((B * K, ld), device=out.device, dtype=torch.bfloat16)
+        dseed = torch.empty((B, C, K), device=out.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        sa_fused._call(sa_fused._lib.omnipq_vote_decode_bwd, out, B, K, C, sa_fused._p(out), sa_fused._p(norm),
+                       sa_fused._p(g_xyz), sa_fused._p(g_feat), sa_fused._p(dnet), ld, sa_fused._p(dseed))
+        return dnet, (g_xyz if ctx.needs_input_grad[1] else None), dseed
 
 
 class VotingModule(nn.Module):
@@ -37,8 +84,11 @@ class VotingModule(nn.Module):
         self.bn1 = nn.BatchNorm1d(self.in_dim)
         self.bn2 = nn.BatchNorm1d(self.in_dim)
 
-    def forward(self, seed_xyz, seed_features):
-        """seed_xyz (B,K,3), seed_features (B,C,K) -> vote_xyz (B,K*vf,3), vote_features (B,C,K*vf)"""
+    def forward(self, seed_xyz, seed_features, normalized=False):
+        """seed_xyz (B,K,3), seed_features (B,C,K) -> vote_xyz (B,K*vf,3), vote_features (B,C,K*vf).
+        normalized=True (not in the reference's signature; PQ_Transformer passes it): the features come back divided by
+        their L2 norm over the channels, i.e. with models/pq_transformer.py:216-217 applied -- on the row kernels that
+        is part of the same launch (VoteDecode); elsewhere the division is done here."""
         B, K = seed_xyz.shape[0], seed_xyz.shape[1]
         vf, C = self.vote_factor, self.out_dim
         seed_rows = seed_features.transpose(2, 1)               # (B, K, C): rows = seed points
@@ -46,6 +96,12 @@ class VotingModule(nn.Module):
         stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
                  rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2),
                  rows_mlp.Layer(self.conv3.weight, self.conv3.bias)]
+        if _FUSED_TAIL and normalized and vf == 1 and C <= 320 and rows_mlp.usable(x, stack, self.training) and \
+                seed_xyz.dtype == torch.float32 and seed_features.dtype == torch.float32:
+            net = rows_mlp.run(x, stack, self.training, padded=True)
+            vote_xyz, vote_features, twin = VoteDecode.apply(net, seed_xyz, seed_features)
+            vote_features.omnipq_rows16 = twin          # the vote aggregation reads bf16 rows: no cast there
+            return vote_xyz, vote_features
         if rows_mlp.usable(x, stack, self.training):
             net = rows_mlp.run(x, stack, self.training)
         else:
@@ -57,4 +113,6 @@ class VotingModule(nn.Module):
         vote_xyz = (seed_xyz.unsqueeze(2) + offset).reshape(B, K * vf, 3)
         vote_features = seed_rows.unsqueeze(2) + residual
         vote_features = vote_features.reshape(B, K * vf, C).transpose(2, 1).contiguous()
+        if normalized:
+            vote_features = vote_features.div(torch.norm(vote_features, p=2, dim=1).unsqueeze(1))
         return vote_xyz, vote_features

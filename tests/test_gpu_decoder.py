@@ -436,3 +436,38 @@ def test_quad_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
                 assert torch.equal(e1[k], e0[k]), k
         for u, v in zip(g1, g0):
             assert rel_l2(u, v) < 2e-2, rel_l2(u, v)
+
+
+@pytest.mark.parametrize("B,K,C,ld,transposed", [(2, 1024, 288, 320, True), (3, 77, 64, 67, False), (1, 33, 320, 352, True)])
+def test_vote_decode_matches_the_op_by_op_tail(B, K, C, ld, transposed):
+    """omnipq_vote_decode(_bwd) == seed_xyz + offset, (seed_features + residual) / its L2 norm over the channels
+    (voting_module.py:55-63, pq_transformer.py:216-217) and torch's autograd through that, on f32; the twin holds the
+    bf16 rounding of the same values; the padding columns of the row gradient are zero."""
+    from voting_module import VoteDecode
+    gen = torch.Generator().manual_seed(B * K + C)
+    net = torch.randn(B * K, ld, generator=gen).to(torch.bfloat16).to(dev()).requires_grad_(True)
+    seed_xyz = torch.randn(B, K, 3, generator=gen).to(dev()).requires_grad_(True)
+    if transposed:                                        # position-major storage seen as (B, C, K), like the FP output
+        store = torch.randn(B, K, C, generator=gen).to(dev()).requires_grad_(True)
+        seed_feat = store.transpose(1, 2)
+    else:
+        store = torch.randn(B, C, K, generator=gen).to(dev()).requires_grad_(True)
+        seed_feat = store
+    vote_xyz, feat, twin = VoteDecode.apply(net, seed_xyz, seed_feat)
+    n32 = net.float().view(B, K, ld)
+    want_xyz = seed_xyz + n32[..., :3]
+    v = seed_feat + n32[..., 3:3 + C].transpose(1, 2)
+    want = v / torch.norm(v, p=2, dim=1, keepdim=True)
+    assert torch.allclose(vote_xyz, want_xyz, rtol=0, atol=1e-6)
+    assert rel_l2(feat, want) < 1e-6
+    assert torch.equal(twin, feat.transpose(1, 2).to(torch.bfloat16))
+    g1 = torch.randn(B, K, 3, generator=gen).to(dev())
+    g2 = torch.randn(B, C, K, generator=gen).to(dev())
+    got = torch.autograd.grad([vote_xyz, feat], [net, seed_xyz, store], [g1, g2])
+    ref = torch.autograd.grad([want_xyz, want], [net, seed_xyz, store], [g1, g2])
+    assert rel_l2(got[0].float()[:, :3 + C], ref[0].float()[:, :3 + C]) < 4e-3          # bf16 row gradient
+    assert float(got[0][:, 3 + C:].abs().max()) == 0.0 if ld > 3 + C else True
+    assert torch.equal(got[1], g1)
+    assert rel_l2(got[2], ref[2]) < 1e-5
+    only = torch.autograd.grad(VoteDecode.apply(net, seed_xyz, seed_feat)[0].sum(), [net, seed_xyz])     # no feature gradient
+    assert float(only[0][:, 3:].abs().max()) == 0.0 and float((only[0][:, :3].float() - 1).abs().max()) == 0.0
