@@ -85,17 +85,18 @@ int omnipq_quad_decode_bwd(int R, int K, const void *y, int ldy, const float *no
 
 /* The tail of the voting module and the normalisation that follows it (models/voting_module.py:55-63,
  * models/pq_transformer.py:216-217; vote_factor 1) in one launch, their gradient in another.
- *   net bf16 rows [b*k][ldn >= 3 + c] = [offset 3 | residual c]; seed_xyz f32 (b,k,3); seed_feat f32 (b,c,k) with element
- *   strides sfb / sfc / sfk  ->  vote_xyz f32 (b,k,3) = seed_xyz + offset;  vote_feat f32 (b,c,k) = v / ||v||_2 over the
- *   channels, v = seed_feat + residual;  twin16 bf16 (b,k,c): the same values row-major;  norm f32 (b,k) for backward.
- * Backward: g_xyz (b,k,3) / g_feat (b,c,k) f32 contiguous, either may be NULL -> dnet bf16 [b*k][ldd] = [g_xyz | dv | 0..],
- *   dseed_feat f32 (b,c,k) = dv (may be NULL), dv = (g_feat - vote_feat <g_feat, vote_feat>) / norm; the gradient with
- *   respect to seed_xyz is g_xyz itself.  c <= 320. */
-int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const float *seed_xyz, const float *seed_feat,
-                       long long sfb, long long sfc, long long sfk, float *vote_xyz, float *vote_feat, void *twin16,
-                       float *norm, void *stream);
-int omnipq_vote_decode_bwd(int b, int k, int c, const float *vote_feat, const float *norm, const float *g_xyz,
-                           const float *g_feat, void *dnet, int ldd, float *dseed_feat, void *stream);
+ *   net bf16 rows [b*k][ldn >= 3 + c] = [offset 3 | residual c]; seed_xyz f32 (b,k,3); seed_feat (b,c,k) with element
+ *   strides sfb / sfc / sfk, f32 or bf16 (feat_is_bf16)  ->  vote_xyz f32 (b,k,3) = seed_xyz + offset;  vote_feat (b,c,k)
+ *   in seed_feat's type = v / ||v||_2 over the channels, v = seed_feat + residual (f32 arithmetic);  twin16 bf16 (b,k,c):
+ *   the same values row-major;  norm f32 (b,k) for backward.
+ * Backward: g_xyz f32 (b,k,3) / g_feat (b,c,k) contiguous in vote_feat's type, either may be NULL -> dnet bf16 [b*k][ldd]
+ *   = [g_xyz | dv | 0..], dseed_feat (b,c,k) in the same type = dv (may be NULL), dv = (g_feat - vote_feat <g_feat,
+ *   vote_feat>) / norm; the gradient with respect to seed_xyz is g_xyz itself.  c <= 320. */
+int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const float *seed_xyz, const void *seed_feat,
+                       int feat_is_bf16, long long sfb, long long sfc, long long sfk, float *vote_xyz, void *vote_feat,
+                       void *twin16, float *norm, void *stream);
+int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_bf16, const float *norm,
+                           const float *g_xyz, const void *g_feat, void *dnet, int ldd, void *dseed_feat, void *stream);
 
 #ifdef __cplusplus
 }

@@ -336,11 +336,23 @@ extern "C" int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, co
 namespace omnipq {
 constexpr int kVotePts = 32, kVoteMaxC = 320;
 
+template <bool BF>
+__device__ __forceinline__ float vote_ld(const void *p, size_t i) {
+  return BF ? (float)reinterpret_cast<const bf16_t *>(p)[i] : reinterpret_cast<const float *>(p)[i];
+}
+template <bool BF>
+__device__ __forceinline__ void vote_st(void *p, size_t i, float v) {
+  if (BF) reinterpret_cast<bf16_t *>(p)[i] = (bf16_t)v;
+  else reinterpret_cast<float *>(p)[i] = v;
+}
+
+// BF: seed features, the normalised output and (backward) its gradients are bf16 (the backbone's bf16 rows), else f32
+template <bool BF>
 __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf16_t *__restrict__ net, int ldn,
                                                          const float *__restrict__ seed_xyz,
-                                                         const float *__restrict__ seed_feat, long long sfb,
+                                                         const void *__restrict__ seed_feat, long long sfb,
                                                          long long sfc, long long sfk, float *__restrict__ vote_xyz,
-                                                         float *__restrict__ out, bf16_t *__restrict__ twin,
+                                                         void *__restrict__ out, bf16_t *__restrict__ twin,
                                                          float *__restrict__ norm_out) {
   __shared__ float v[kVoteMaxC][kVotePts + 1];
   __shared__ float part[8][kVotePts];
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf
   float ss = 0.f;
   if (p < npts)
     for (int c = cg; c < C; c += 8) {
-      const float t = seed_feat[(size_t)b * sfb + (size_t)c * sfc + (size_t)(k0 + p) * sfk] + v[c][p];
+      const float t = vote_ld<BF>(seed_feat, (size_t)b * sfb + (size_t)c * sfc + (size_t)(k0 + p) * sfk) + v[c][p];
       v[c][p] = t;
       ss = __builtin_fmaf(t, t, ss);
     }
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf
     for (int c = cg; c < C; c += 8) {
       const float t = v[c][p] * inv[p];
       v[c][p] = t;
-      out[((size_t)b * C + c) * K + k0 + p] = t;
+      vote_st<BF>(out, ((size_t)b * C + c) * K + k0 + p, t);
     }
   __syncthreads();
   for (int i = tid; i < npts * C; i += 256) {
@@ -391,11 +403,12 @@ __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf
 }
 
 // dv = (g - out <g, out>) / ||v||;  d_net = [g_xyz | dv | 0...];  d_seed_features = dv (channel-major)
-__global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, const float *__restrict__ out,
+template <bool BF>
+__global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, const void *__restrict__ out,
                                                              const float *__restrict__ norm,
                                                              const float *__restrict__ g_xyz,
-                                                             const float *__restrict__ g_feat, bf16_t *__restrict__ dnet,
-                                                             int ldd, float *__restrict__ dseed) {
+                                                             const void *__restrict__ g_feat, bf16_t *__restrict__ dnet,
+                                                             int ldd, void *__restrict__ dseed) {
   __shared__ float v[kVoteMaxC][kVotePts + 1];
   __shared__ float part[8][kVotePts];
   const int b = (int)blockIdx.y, k0 = (int)blockIdx.x * kVotePts, tid = (int)threadIdx.x;
@@ -405,9 +418,9 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
   if (p < npts && g_feat)
     for (int c = cg; c < C; c += 8) {
       const size_t o = ((size_t)b * C + c) * K + k0 + p;
-      const float g = g_feat[o];
+      const float g = vote_ld<BF>(g_feat, o);
       v[c][p] = g;
-      dot = __builtin_fmaf(g, out[o], dot);
+      dot = __builtin_fmaf(g, vote_ld<BF>(out, o), dot);
     }
   part[cg][p] = dot;
   __syncthreads();
@@ -418,9 +431,9 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
     const float rn = 1.0f / norm[(size_t)b * K + k0 + p];
     for (int c = cg; c < C; c += 8) {
       const size_t o = ((size_t)b * C + c) * K + k0 + p;
-      const float t = g_feat ? (v[c][p] - out[o] * d) * rn : 0.f;
+      const float t = g_feat ? (v[c][p] - vote_ld<BF>(out, o) * d) * rn : 0.f;
       v[c][p] = t;
-      if (dseed) dseed[o] = t;
+      if (dseed) vote_st<BF>(dseed, o, t);
     }
   }
   __syncthreads();
@@ -437,26 +450,37 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
 }  // namespace omnipq
 
 extern "C" int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const float *seed_xyz,
-                                  const float *seed_feat, long long sfb, long long sfc, long long sfk, float *vote_xyz,
-                                  float *vote_feat, void *twin16, float *norm, void *stream) {
+                                  const void *seed_feat, int feat_is_bf16, long long sfb, long long sfc, long long sfk,
+                                  float *vote_xyz, void *vote_feat, void *twin16, float *norm, void *stream) {
   using namespace omnipq;
   if (b < 0 || k < 0 || c <= 0 || c > kVoteMaxC || ldn < c + 3) return OMNIPQ_EINVAL;
   if (b == 0 || k == 0) return OMNIPQ_OK;
   if (!net || !seed_xyz || !seed_feat || !vote_xyz || !vote_feat || !twin16 || !norm || b > 65535) return OMNIPQ_EINVAL;
-  vote_decode_kernel<<<dim3((k + kVotePts - 1) / kVotePts, b), 256, 0, (hipStream_t)stream>>>(
-      k, c, (const bf16_t *)net, ldn, seed_xyz, seed_feat, sfb, sfc, sfk, vote_xyz, vote_feat, (bf16_t *)twin16, norm);
+  const dim3 grid((k + kVotePts - 1) / kVotePts, b);
+  if (feat_is_bf16)
+    vote_decode_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, (const bf16_t *)net, ldn, seed_xyz, seed_feat, sfb,
+                                                                    sfc, sfk, vote_xyz, vote_feat, (bf16_t *)twin16, norm);
+  else
+    vote_decode_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, (const bf16_t *)net, ldn, seed_xyz, seed_feat, sfb,
+                                                                     sfc, sfk, vote_xyz, vote_feat, (bf16_t *)twin16, norm);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
 
-extern "C" int omnipq_vote_decode_bwd(int b, int k, int c, const float *vote_feat, const float *norm, const float *g_xyz,
-                                      const float *g_feat, void *dnet, int ldd, float *dseed_feat, void *stream) {
+extern "C" int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_bf16, const float *norm,
+                                      const float *g_xyz, const void *g_feat, void *dnet, int ldd, void *dseed_feat,
+                                      void *stream) {
   using namespace omnipq;
   if (b < 0 || k < 0 || c <= 0 || c > kVoteMaxC || ldd < c + 3) return OMNIPQ_EINVAL;
   if (b == 0 || k == 0) return OMNIPQ_OK;
   if (!vote_feat || !norm || !dnet || b > 65535) return OMNIPQ_EINVAL;
-  vote_decode_bwd_kernel<<<dim3((k + kVotePts - 1) / kVotePts, b), 256, 0, (hipStream_t)stream>>>(
-      k, c, vote_feat, norm, g_xyz, g_feat, (bf16_t *)dnet, ldd, dseed_feat);
+  const dim3 grid((k + kVotePts - 1) / kVotePts, b);
+  if (feat_is_bf16)
+    vote_decode_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, vote_feat, norm, g_xyz, g_feat, (bf16_t *)dnet,
+                                                                        ldd, dseed_feat);
+  else
+    vote_decode_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, vote_feat, norm, g_xyz, g_feat,
+                                                                         (bf16_t *)dnet, ldd, dseed_feat);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -45,15 +45,16 @@ class VoteDecode(torch.autograd.Function):
         sx = seed_xyz.detach().float().contiguous()
         sf = seed_features.detach()
         vote_xyz = torch.empty((B, K, 3), device=dev, dtype=torch.float32)
-        out = torch.empty((B, C, K), device=dev, dtype=torch.float32)
+        bf = sf.dtype == torch.bfloat16
+        out = torch.empty((B, C, K), device=dev, dtype=sf.dtype)
         twin = torch.empty((B, K, C), device=dev, dtype=torch.bfloat16)
         norm = torch.empty((B, K), device=dev, dtype=torch.float32)
         sa_fused._call(sa_fused._lib.omnipq_vote_decode, net, B, K, C, sa_fused._p(net), net.stride(0), sa_fused._p(sx),
-                       sa_fused._p(sf), ctypes.c_longlong(sf.stride(0)), ctypes.c_longlong(sf.stride(1)),
+                       sa_fused._p(sf), int(bf), ctypes.c_longlong(sf.stride(0)), ctypes.c_longlong(sf.stride(1)),
                        ctypes.c_longlong(sf.stride(2)), sa_fused._p(vote_xyz), sa_fused._p(out), sa_fused._p(twin),
                        sa_fused._p(norm))
         ctx.save_for_backward(out, norm)
-        ctx.geom = (B, K, C, net.shape[1])
+        ctx.geom = (B, K, C, net.shape[1], bf)
         ctx.mark_non_differentiable(twin)
         ctx.set_materialize_grads(False)
         return vote_xyz, out, twin
@@ -62,12 +63,12 @@ class VoteDecode(torch.autograd.Function):
     def backward(ctx, g_xyz, g_feat, _g_twin):
         import sa_fused
         out, norm = ctx.saved_tensors
-        B, K, C, ld = ctx.geom
+        B, K, C, ld, bf = ctx.geom
         g_xyz = None if g_xyz is None else g_xyz.float().contiguous()
-        g_feat = None if g_feat is None else g_feat.float().contiguous()
+        g_feat = None if g_feat is None else g_feat.to(out.dtype).contiguous()
         dnet = torch.empty((B * K, ld), device=out.device, dtype=torch.bfloat16)
-        dseed = torch.empty((B, C, K), device=out.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        sa_fused._call(sa_fused._lib.omnipq_vote_decode_bwd, out, B, K, C, sa_fused._p(out), sa_fused._p(norm),
+        dseed = torch.empty((B, C, K), device=out.device, dtype=out.dtype) if ctx.needs_input_grad[2] else None
+        sa_fused._call(sa_fused._lib.omnipq_vote_decode_bwd, out, B, K, C, sa_fused._p(out), int(bf), sa_fused._p(norm),
                        sa_fused._p(g_xyz), sa_fused._p(g_feat), sa_fused._p(dnet), ld, sa_fused._p(dseed))
         return dnet, (g_xyz if ctx.needs_input_grad[1] else None), dseed
 
@@ -97,7 +98,7 @@ class VotingModule(nn.Module):
                  rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2),
                  rows_mlp.Layer(self.conv3.weight, self.conv3.bias)]
         if _FUSED_TAIL and normalized and vf == 1 and C <= 320 and rows_mlp.usable(x, stack, self.training) and \
-                seed_xyz.dtype == torch.float32 and seed_features.dtype == torch.float32:
+                seed_xyz.dtype == torch.float32 and seed_features.dtype in (torch.float32, torch.bfloat16):
             net = rows_mlp.run(x, stack, self.training, padded=True)
             vote_xyz, vote_features, twin = VoteDecode.apply(net, seed_xyz, seed_features)
             vote_features.omnipq_rows16 = twin          # the vote aggregation reads bf16 rows: no cast there

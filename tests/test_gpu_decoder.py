@@ -438,6 +438,22 @@ def test_quad_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
             assert rel_l2(u, v) < 2e-2, rel_l2(u, v)
 
 
+def test_the_model_takes_the_fused_vote_tail_on_the_benchmarked_path():
+    """bf16 autocast, training mode: vote_features carries the bf16 row twin only VoteDecode attaches, keeps the dtype
+    of the seed features, and is L2-normalised over the channels."""
+    import bench
+    import synth
+    torch.manual_seed(1)
+    net = bench.build_model(0).to(dev()).train()
+    pc = synth.make_clouds(5, 2, 8192, kind="room").to(dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ep = net({"point_clouds": pc})
+    vf = ep["vote_features"]
+    assert getattr(vf, "omnipq_rows16", None) is not None and vf.dtype == ep["seed_features"].dtype
+    assert float((torch.norm(vf.float(), p=2, dim=1) - 1).abs().max()) < 2e-2
+    assert torch.equal(vf.omnipq_rows16, vf.transpose(1, 2).to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("B,K,C,ld,transposed", [(2, 1024, 288, 320, True), (3, 77, 64, 67, False), (1, 33, 320, 352, True)])
 def test_vote_decode_matches_the_op_by_op_tail(B, K, C, ld, transposed):
     """omnipq_vote_decode(_bwd) == seed_xyz + offset, (seed_features + residual) / its L2 norm over the channels
@@ -471,3 +487,26 @@ def test_vote_decode_matches_the_op_by_op_tail(B, K, C, ld, transposed):
     assert rel_l2(got[2], ref[2]) < 1e-5
     only = torch.autograd.grad(VoteDecode.apply(net, seed_xyz, seed_feat)[0].sum(), [net, seed_xyz])     # no feature gradient
     assert float(only[0][:, 3:].abs().max()) == 0.0 and float((only[0][:, :3].float() - 1).abs().max()) == 0.0
+
+
+def test_vote_decode_with_bf16_seed_features():
+    """The backbone hands over bf16 seed features: output and gradient keep that type, the arithmetic is f32."""
+    from voting_module import VoteDecode
+    B, K, C, ld = 2, 500, 288, 320
+    gen = torch.Generator().manual_seed(3)
+    net = torch.randn(B * K, ld, generator=gen).to(torch.bfloat16).to(dev()).requires_grad_(True)
+    seed_xyz = torch.randn(B, K, 3, generator=gen).to(dev())
+    store = torch.randn(B, K, C, generator=gen).to(torch.bfloat16).to(dev()).requires_grad_(True)
+    seed_feat = store.transpose(1, 2)
+    vote_xyz, feat, twin = VoteDecode.apply(net, seed_xyz, seed_feat)
+    assert feat.dtype == torch.bfloat16 and feat.is_contiguous()
+    v = seed_feat.float() + net.float().view(B, K, ld)[..., 3:3 + C].transpose(1, 2)
+    want = v / torch.norm(v, p=2, dim=1, keepdim=True)
+    assert float((feat.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-7
+    assert torch.equal(twin, feat.transpose(1, 2).contiguous())
+    g2 = torch.randn(B, C, K, generator=gen).to(torch.bfloat16).to(dev())
+    got = torch.autograd.grad(feat, [net, store], g2)
+    ref = torch.autograd.grad(want, [net, store], g2.float())
+    assert got[1].dtype == torch.bfloat16
+    assert rel_l2(got[0].float()[:, 3:3 + C], ref[0].float()[:, 3:3 + C]) < 8e-3
+    assert rel_l2(got[1].float(), ref[1].float()) < 8e-3
