@@ -98,6 +98,18 @@ int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const floa
 int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_bf16, const float *norm,
                            const float *g_xyz, const void *g_feat, void *dnet, int ldd, void *dseed_feat, void *stream);
 
+/* out[i] = sum_s src[s][i], i < n: up to 16 sources of one type (bf16: is_bf16 != 0, f32 accumulation, one rounding;
+ * else f32), n % 8 == 0, all pointers 16-byte aligned; out may be one of the sources.  The fan-in of a tensor that feeds
+ * several consumers (autograd: count - 1 accumulation launches, each re-reading the running sum). */
+int omnipq_add_n(int count, const void *const *src, long long n, int is_bf16, void *out, void *stream);
+
+/* The decoder's joint bf16 rows x16 (b, p, c) = [p0 object | p - p0 quad queries] per scene -> two contiguous row blocks
+ * obj16 (b * p0, c), quad16 (b * (p - p0), c) for the two prediction heads; and the gradient's way back:
+ * out16 (b, p, c) = [g_obj16 | g_quad16] + g_joint16 (each may be NULL = zero).  c % 8 == 0, 16-byte aligned. */
+int omnipq_split_rows(int b, int p, int p0, int c, const void *x16, void *obj16, void *quad16, void *stream);
+int omnipq_merge_rows(int b, int p, int p0, int c, const void *g_obj16, const void *g_quad16, const void *g_joint16,
+                      void *out16, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -522,3 +522,142 @@ extern "C" int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, cons
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
+
+// out = sum of up to 16 bf16 (or f32) tensors of n elements, f32 accumulation, one pass: what autograd's gradient
+// accumulation does with n - 1 launches (each re-reading the running sum) when a tensor feeds n consumers.
+namespace omnipq {
+constexpr int kAddMax = 16;
+struct AddNArgs {
+  const void *src[kAddMax];
+  int count;
+};
+
+template <bool BF>
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a, long long n8, void *__restrict__ out) {
+  // 8 elements per thread and source: 16 bytes (bf16) or two 16-byte loads (f32)
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n8; q += (long long)gridDim.x * 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < a.count; ++s) {
+      if (BF) {
+        const uint4 v = reinterpret_cast<const uint4 *>(a.src[s])[q];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+          acc[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        }
+      } else {
+        const float4 lo = reinterpret_cast<const float4 *>(a.src[s])[2 * q], hi = reinterpret_cast<const float4 *>(a.src[s])[2 * q + 1];
+        acc[0] += lo.x, acc[1] += lo.y, acc[2] += lo.z, acc[3] += lo.w;
+        acc[4] += hi.x, acc[5] += hi.y, acc[6] += hi.z, acc[7] += hi.w;
+      }
+    }
+    if (BF) {
+      uint4 o;
+      o.x = pack_bf16x2(acc[0], acc[1]), o.y = pack_bf16x2(acc[2], acc[3]);
+      o.z = pack_bf16x2(acc[4], acc[5]), o.w = pack_bf16x2(acc[6], acc[7]);
+      reinterpret_cast<uint4 *>(out)[q] = o;
+    } else {
+      reinterpret_cast<float4 *>(out)[2 * q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      reinterpret_cast<float4 *>(out)[2 * q + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  }
+}
+}  // namespace omnipq
+
+extern "C" int omnipq_add_n(int count, const void *const *src, long long n, int is_bf16, void *out, void *stream) {
+  using namespace omnipq;
+  if (count < 1 || count > kAddMax || n < 0 || (n % 8)) return OMNIPQ_EINVAL;
+  if (n == 0) return OMNIPQ_OK;
+  if (!src || !out) return OMNIPQ_EINVAL;
+  AddNArgs a;
+  a.count = count;
+  for (int i = 0; i < count; ++i) {
+    if (!src[i] || (reinterpret_cast<size_t>(src[i]) & 15)) return OMNIPQ_EINVAL;
+    a.src[i] = src[i];
+  }
+  if (reinterpret_cast<size_t>(out) & 15) return OMNIPQ_EINVAL;
+  const long long n8 = n / 8;
+  const int grid = (int)((n8 + 255) / 256 > 2048 ? 2048 : (n8 + 255) / 256);
+  if (is_bf16)
+    add_n_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, n8, out);
+  else
+    add_n_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a, n8, out);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// The decoder's joint rows (b, p, c) bf16 = [p0 object queries | p - p0 quad queries] per scene, as two contiguous row
+// blocks for the two prediction heads (forward, one launch instead of two strided copies), and the way back: the
+// gradient of the joint rows = [g_obj | g_quad] (+ g_joint, the gradient that reaches the joint rows directly from the
+// next decoder layer) in one launch instead of a concatenation and an accumulation.
+namespace omnipq {
+__global__ __launch_bounds__(256) void split_rows_kernel(long long chunks, int p, int p0, int c8, const uint4 *__restrict__ x,
+                                                        uint4 *__restrict__ obj, uint4 *__restrict__ quad) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= chunks) return;
+  const long long row = q / c8;
+  const int piece = (int)(q - row * c8);
+  const long long b = row / p;
+  const int t = (int)(row - b * p);
+  const uint4 v = x[q];
+  if (t < p0)
+    obj[(b * p0 + t) * c8 + piece] = v;
+  else
+    quad[(b * (p - p0) + (t - p0)) * c8 + piece] = v;
+}
+
+__global__ __launch_bounds__(256) void merge_rows_kernel(long long chunks, int p, int p0, int c8, const uint4 *__restrict__ g_obj,
+                                                        const uint4 *__restrict__ g_quad, const uint4 *__restrict__ g_joint,
+                                                        uint4 *__restrict__ out) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= chunks) return;
+  const long long row = q / c8;
+  const int piece = (int)(q - row * c8);
+  const long long b = row / p;
+  const int t = (int)(row - b * p);
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (t < p0) {
+    if (g_obj) v = g_obj[(b * p0 + t) * c8 + piece];
+  } else if (g_quad) {
+    v = g_quad[(b * (p - p0) + (t - p0)) * c8 + piece];
+  }
+  if (g_joint) {
+    const uint4 w = g_joint[q];
+    const unsigned a[4] = {v.x, v.y, v.z, v.w}, d[4] = {w.x, w.y, w.z, w.w};
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack_bf16x2(__builtin_bit_cast(float, a[e] << 16) + __builtin_bit_cast(float, d[e] << 16),
+                         __builtin_bit_cast(float, a[e] & 0xffff0000u) + __builtin_bit_cast(float, d[e] & 0xffff0000u));
+    v = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  out[q] = v;
+}
+}  // namespace omnipq
+
+extern "C" int omnipq_split_rows(int b, int p, int p0, int c, const void *x16, void *obj16, void *quad16, void *stream) {
+  using namespace omnipq;
+  if (b < 0 || p <= 0 || p0 < 0 || p0 > p || c <= 0 || (c % 8)) return OMNIPQ_EINVAL;
+  const long long chunks = (long long)b * p * (c / 8);
+  if (chunks == 0) return OMNIPQ_OK;
+  if (!x16 || (p0 > 0 && !obj16) || (p0 < p && !quad16)) return OMNIPQ_EINVAL;
+  split_rows_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      chunks, p, p0, c / 8, (const uint4 *)x16, (uint4 *)obj16, (uint4 *)quad16);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+extern "C" int omnipq_merge_rows(int b, int p, int p0, int c, const void *g_obj16, const void *g_quad16,
+                                 const void *g_joint16, void *out16, void *stream) {
+  using namespace omnipq;
+  if (b < 0 || p <= 0 || p0 < 0 || p0 > p || c <= 0 || (c % 8)) return OMNIPQ_EINVAL;
+  const long long chunks = (long long)b * p * (c / 8);
+  if (chunks == 0) return OMNIPQ_OK;
+  if (!out16) return OMNIPQ_EINVAL;
+  merge_rows_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      chunks, p, p0, c / 8, (const uint4 *)g_obj16, (const uint4 *)g_quad16, (const uint4 *)g_joint16, (uint4 *)out16);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

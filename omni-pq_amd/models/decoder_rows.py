@@ -46,6 +46,69 @@ class AddToBf16(torch.autograd.Function):
         return (g.to(ctx.a_dtype) if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None)
 
 
+class FanOut(torch.autograd.Function):
+    """x -> n aliases of x for n consumers; backward adds the n incoming gradients in ONE launch (omnipq_add_n) where
+    autograd's accumulation takes n - 1, each re-reading the running sum."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.meta = (tuple(x.shape), x.dtype)
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        shape, dtype = ctx.meta
+        numel = gs[0].numel()
+        if dtype in (torch.bfloat16, torch.float32) and numel % 8 == 0 and len(gs) <= 16 and \
+                all(g.is_cuda and g.dtype == dtype and g.is_contiguous() and g.data_ptr() % 16 == 0 and
+                    tuple(g.shape) == shape for g in gs):
+            out = torch.empty(shape, device=gs[0].device, dtype=dtype)
+            ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+            _call(_lib.omnipq_add_n, out, len(gs), ptrs, ctypes.c_longlong(numel), int(dtype == torch.bfloat16), _p(out))
+            return out, None
+        total = gs[0]
+        for g in gs[1:]:
+            total = total + g
+        return total, None
+
+
+class SplitRows(torch.autograd.Function):
+    """joint bf16 rows (B, P, C) -> (object rows (B*P0, C), quad rows (B*(P-P0), C), an alias of the joint rows for the
+    next decoder layer): one launch where two strided copies were; backward merges the two heads' gradients and the next
+    layer's into the joint gradient in one launch (a concatenation and an accumulation before)."""
+
+    @staticmethod
+    def forward(ctx, x16, p0):
+        B, P, C = x16.shape
+        obj = torch.empty((B * p0, C), device=x16.device, dtype=torch.bfloat16)
+        quad = torch.empty((B * (P - p0), C), device=x16.device, dtype=torch.bfloat16)
+        _call(_lib.omnipq_split_rows, x16, B, P, p0, C, _p(x16), _p(obj), _p(quad))
+        ctx.geom = (B, P, p0, C)
+        ctx.set_materialize_grads(False)
+        return obj, quad, x16.view_as(x16)
+
+    @staticmethod
+    def backward(ctx, g_obj, g_quad, g_joint):
+        B, P, p0, C = ctx.geom
+        gs = [None if g is None else g.to(torch.bfloat16).contiguous() for g in (g_obj, g_quad, g_joint)]
+        if all(g is None for g in gs):
+            return None, None
+        out = torch.empty((B, P, C), device=next(g for g in gs if g is not None).device, dtype=torch.bfloat16)
+        _call(_lib.omnipq_merge_rows, out, B, P, p0, C, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(out))
+        return out, None
+
+
+def split_usable(x16):
+    return x16 is not None and x16.is_cuda and x16.dtype == torch.bfloat16 and x16.is_contiguous() and \
+        x16.dim() == 3 and x16.shape[2] % 8 == 0 and x16.data_ptr() % 16 == 0
+
+
 class AddDropoutLayerNorm(torch.autograd.Function):
     """(x f32, y bf16 | None, gamma, beta, eps, p, pe bf16 | None, want32, want16)
     -> (LayerNorm(x + dropout(y)) as f32 | None, as bf16 | None, bf16(that + pe) | None)"""
@@ -131,12 +194,14 @@ def _side_stream(device):
     return s
 
 
-def key_side(layer, key, key_pos):
+def key_side(layer, key, key_pos, mem16=None):
     """The key / value side of a layer's cross attention: kv = in_proj[C:](mem + cross_posembed(key_pos)),
-    rows (B*Pk, 2C) bf16.  It depends on the memory only, not on the queries.  -> (kv, (W_q, b_q))"""
+    rows (B*Pk, 2C) bf16.  It depends on the memory only, not on the queries.  -> (kv, (W_q, b_q)).
+    mem16: the memory as bf16 rows, if the caller has it (one cast and one gradient fan-in for all layers)."""
     C = key.shape[1]
     ca = layer.multihead_attn
-    mem16 = _rows(key).to(torch.bfloat16)
+    if mem16 is None:
+        mem16 = _rows(key).to(torch.bfloat16)
     k_pe = _rows(layer.cross_posembed(key_pos)).to(torch.bfloat16)
     mem_pe = AddToBf16.apply(mem16, k_pe)
     # ONE split of the packed projection (its backward is one cat; two slices would each zero-fill and copy a
@@ -157,7 +222,9 @@ def precompute_key_sides(layers, key, key_pos):
     side = _side_stream(key.device)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        kvs = [key_side(layer, key, key_pos) for layer in layers]
+        # all layers read the same memory rows: one cast, and in backward one n-ary add for their n gradients
+        mem = FanOut.apply(_rows(key).to(torch.bfloat16).contiguous(), len(layers))
+        kvs = [key_side(layer, key, key_pos, mem[i]) for i, layer in enumerate(layers)]
     for kv, _ in kvs:
         kv.record_stream(cur)
     return kvs

@@ -491,7 +491,13 @@ class PQ_Transformer(nn.Module):
             query, query_q = torch.split(query_joint, [n_obj, n_quad], dim=2)     # one cat in backward
             rows16 = getattr(query_joint, 'omnipq_rows16', None)          # (B, P, C) bf16 twin from the row-major decoder
             rows_obj = rows_quad = None
-            if rows16 is not None:
+            if decoder_rows.split_usable(rows16):
+                # the two heads' inputs as contiguous row blocks, and the joint rows' three gradients (two heads, next
+                # layer) merged by one launch in backward
+                rows_obj, rows_quad, alias = decoder_rows.SplitRows.apply(rows16, n_obj)
+                rows_obj, rows_quad = rows_obj.view(-1, n_obj, rows16.shape[2]), rows_quad.view(-1, n_quad, rows16.shape[2])
+                query_joint.omnipq_rows16 = alias
+            elif rows16 is not None:
                 rows_obj, rows_quad = torch.split(rows16, [n_obj, n_quad], dim=1)
             head_overlap = query.is_cuda and (_OVERLAP_HEADS == "always" or (
                 _OVERLAP_HEADS == "capture" and torch.cuda.is_current_stream_capturing()))

@@ -510,3 +510,59 @@ def test_vote_decode_with_bf16_seed_features():
     assert got[1].dtype == torch.bfloat16
     assert rel_l2(got[0].float()[:, 3:3 + C], ref[0].float()[:, 3:3 + C]) < 8e-3
     assert rel_l2(got[1].float(), ref[1].float()) < 8e-3
+
+
+@pytest.mark.parametrize("dtype,n,numel", [(torch.bfloat16, 6, 8192 * 288), (torch.float32, 3, 4096), (torch.bfloat16, 2, 40)])
+def test_fan_out_sums_its_gradients_in_one_launch(dtype, n, numel):
+    """FanOut: n aliases forward; backward = the sum of the n gradients (f32 accumulation, one rounding for bf16), also
+    with missing gradients and with a gradient that is not contiguous (composed fallback)."""
+    import decoder_rows
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(numel // 8, 8, generator=gen).to(dtype).to(dev()).requires_grad_(True)
+    outs = decoder_rows.FanOut.apply(x, n)
+    assert all(o.data_ptr() == x.data_ptr() for o in outs)
+    ws = [torch.randn(numel // 8, 8, generator=gen).to(dtype).to(dev()) for _ in range(n)]
+    if n > 2:
+        used = list(zip(outs[:-1], ws[:-1]))                                      # the last alias gets no gradient
+        loss = sum((o.float() * w.float()).sum() for o, w in used)
+    else:
+        used = list(zip(outs, ws))                                                # one gradient arrives transposed
+        loss = (outs[0].float() * ws[0].float()).sum() + (outs[1].t().float() * ws[1].t().float()).sum()
+    (g,) = torch.autograd.grad(loss, x)
+    want = sum(w.float() for _, w in used)
+    tol = 2.0 ** -8 * float(want.abs().max()) + 1e-6 if dtype == torch.bfloat16 else 1e-6
+    assert float((g.float() - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("B,P,p0,C", [(8, 512, 256, 288), (3, 10, 3, 32), (2, 7, 7, 8), (2, 5, 0, 16)])
+def test_split_rows_and_its_merged_gradient(B, P, p0, C):
+    """SplitRows == the two strided slices made contiguous, plus an alias; its backward == cat of the two row gradients
+    plus the alias's gradient (bf16, one rounding), with any of the three missing."""
+    import decoder_rows
+    gen = torch.Generator().manual_seed(P + C)
+    x = torch.randn(B, P, C, generator=gen).to(torch.bfloat16).to(dev()).requires_grad_(True)
+    obj, quad, alias = decoder_rows.SplitRows.apply(x, p0)
+    assert torch.equal(obj.view(B, p0, C), x[:, :p0]) and torch.equal(quad.view(B, P - p0, C), x[:, p0:])
+    assert alias.data_ptr() == x.data_ptr()
+    go = torch.randn(B * p0, C, generator=gen).to(torch.bfloat16).to(dev())
+    gq = torch.randn(B * (P - p0), C, generator=gen).to(torch.bfloat16).to(dev())
+    ga = torch.randn(B, P, C, generator=gen).to(torch.bfloat16).to(dev())
+    cat = torch.cat([go.view(B, p0, C), gq.view(B, P - p0, C)], 1).float()
+    for use in ((1, 1, 1), (1, 1, 0), (0, 1, 1), (0, 0, 1), (1, 0, 0)):
+        outs, grads = [], []
+        for u, o, g in zip(use, (obj, quad, alias), (go, gq, ga)):
+            if u and o.numel():
+                outs.append(o)
+                grads.append(g)
+        if not outs:
+            continue
+        (got,) = torch.autograd.grad(outs, x, grads, retain_graph=True)
+        want = torch.zeros(B, P, C, device=dev())
+        if use[0]:
+            want[:, :p0] += go.view(B, p0, C).float()
+        if use[1]:
+            want[:, p0:] += gq.view(B, P - p0, C).float()
+        if use[2]:
+            want += ga.float()
+        assert float((got.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6, use
+    assert cat.shape == (B, P, C)
