@@ -130,6 +130,7 @@ class AddDropoutLayerNorm(torch.autograd.Function):
               ctypes.c_float(eps), ctypes.c_float(p if drop else 0.0), _p(seed), salt, _p(out32), _p(out16), _p(pe),
               _p(out_pe), _p(mean), _p(rstd))
         ctx.save_for_backward(x, y, g32, mean, rstd)
+        ctx.set_materialize_grads(False)        # unused outputs (f32 / bf16 / bf16 + pe) arrive as None, not as zero tensors
         ctx.cfg = (p if drop else 0.0, seed, salt, pe is not None)
         both = isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter)
         ctx.params = (gamma, beta) if both and gamma.requires_grad and beta.requires_grad else None

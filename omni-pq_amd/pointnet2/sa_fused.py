@@ -1005,6 +1005,7 @@ class FusedSAStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training, bn_cfg, *params):
+        ctx.n_inputs = 9 + len(params)
         with _tagged("@sa"):
             return FusedSAStage._forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training,
                                          bn_cfg, *params)
@@ -1170,6 +1171,7 @@ class FusedSAStage(torch.autograd.Function):
         ctx.training = training
         twin = out_pm.view(B, M, last.C)
         ctx.mark_non_differentiable(twin)
+        ctx.set_materialize_grads(False)        # no zero tensor of the twin's size per backward (its gradient is never used)
         return out, twin
 
     @staticmethod
@@ -1258,6 +1260,7 @@ class FusedSAStage(torch.autograd.Function):
         ctx.training = True
         twin = out_pm.view(B, M, last.C)
         ctx.mark_non_differentiable(twin)
+        ctx.set_materialize_grads(False)        # no zero tensor of the twin's size per backward (its gradient is never used)
         return out, twin
 
     @staticmethod
@@ -1351,6 +1354,8 @@ class FusedSAStage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_twin=None):
+        if g_out is None:                       # the stage's output took no part in the loss
+            return (None,) * ctx.n_inputs
         with _tagged("@sa"):
             if getattr(ctx, "chain", None) is not None:
                 return FusedSAStage._backward_chain(ctx, g_out)
