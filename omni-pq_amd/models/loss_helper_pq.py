@@ -168,6 +168,34 @@ def _quad_assignment(end_points, prefixes):
 
 
 # --------------------------------------------------------------------------------------------------------- row losses
+def _cast_all(tensors, dtype):
+    """[t.to(dtype).contiguous() for t in tensors] with ONE multi-tensor copy for all that need converting (the head
+    outputs arrive as ~70 small bf16 tensors: a cast launch each was a third of a millisecond per step, each way)."""
+    out = [None] * len(tensors)
+    todo = []
+    for i, t in enumerate(tensors):
+        if t is None:
+            continue
+        if t.dtype == dtype and t.is_contiguous():
+            out[i] = t
+        else:
+            todo.append(i)
+    if todo:
+        flat = torch.empty(sum(tensors[i].numel() for i in todo), device=tensors[todo[0]].device, dtype=dtype)
+        off = 0
+        for i in todo:
+            n = tensors[i].numel()
+            out[i] = flat[off:off + n].view(tensors[i].shape)
+            off += n
+        srcs = [tensors[i] for i in todo]
+        if all(t.is_contiguous() for t in srcs):
+            torch._foreach_copy_([out[i] for i in todo], srcs)
+        else:
+            for i in todo:
+                out[i].copy_(tensors[i])
+    return out
+
+
 class _Rows(torch.autograd.Function):
     """terms (heads, 8) = row kernel(head outputs); `kind` selects the box or the quad descriptor.  The non-differentiable
     operands travel in `aux` (a dict of contiguous device tensors that also keeps them alive)."""
@@ -182,7 +210,7 @@ class _Rows(torch.autograd.Function):
     def forward(ctx, kind, aux, dims, *heads):
         keys = _Rows._keys(kind, dims)
         P = len(heads) // len(keys)
-        xs = [h.detach().float().contiguous() for h in heads]
+        xs = _cast_all([h.detach() for h in heads], torch.float32)
         desc = _Rows._desc(kind, aux, dims, P, xs)
         dev = xs[0].device
         sums = torch.empty((P, 8), device=dev, dtype=torch.float64)
@@ -231,7 +259,10 @@ class _Rows(torch.autograd.Function):
                     arr[p] = outs[i].data_ptr()
         fn = _lib.omnipq_loss_box_rows_grad if kind == "box" else _lib.omnipq_loss_quad_rows_grad
         _ext._run(fn, xs[0], ctypes.byref(desc), _ext._ptr(g_terms), ctypes.byref(grads))
-        outs = [None if o is None else o.to(dt) for o, dt in zip(outs, ctx.dtypes)]
+        for dt in set(ctx.dtypes):
+            idx = [i for i, o in enumerate(outs) if o is not None and ctx.dtypes[i] == dt]
+            for i, o in zip(idx, _cast_all([outs[i] for i in idx], dt)):
+                outs[i] = o
         return (None, None, None, *outs)
 
 
