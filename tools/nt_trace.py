@@ -2,7 +2,7 @@
 """Where does a 128 x 128 tile of the SA-stage GEMMs spend its time?  Runs the benchmark's sa1 / sa2 shapes through a DEBUG
 build of the library (csrc/gemm_bf16.hip compiled with -DOMNIPQ_NT_TRACE: thread 0 of each of the first 4096 workgroups
 stamps the cycle counter at eight points) and prints the phase durations.  Build the trace library first:
-    for f in omni-pq_amd/csrc/*.hip: hipcc ... [-DOMNIPQ_NT_TRACE for gemm_bf16.hip] ; link to tools/probe/libomnipq_trace.so
+    bash tools/build_trace_lib.sh        (-> tools/probe/libomnipq_trace.so, git-ignored; travels with gpurun)
 """
 import ctypes, os, sys
 import numpy as np
