@@ -177,6 +177,15 @@ def test_fused_sa_stage_config4_50k_points_six_extra_channels(monkeypatch):
     _fused_vs_f32(spec, 50000, 6, 4, monkeypatch)
 
 
+def test_fused_sa_stage_config5_80k_points(monkeypatch):
+    """BASELINE configs[4]: dense clouds of 80 000 points (batch 16 per GPU in the benchmark; 2 scenes here so that the f32
+    op-by-op yardstick fits the test's time): sa1 of the backbone with the hash-grid ball query at 80 000 points and the
+    multi-workgroup furthest-point sampling, in bf16 (the type this configuration is measured in: DESIGN.md §6), against
+    the f32 composition."""
+    spec = dict(npoint=2048, radius=0.2, nsample=64, mlp=[0, 64, 64, 128], use_xyz=True, normalize_xyz=True)
+    _fused_vs_f32(spec, 80000, 0, 2, monkeypatch)
+
+
 def test_first_layer_generated_from_coordinates_matches_f32_composition(monkeypatch):
     """sa1 as the backbone runs it: no input features and no gradient into the coordinates, so the first layer (conv 3 -> C)
     is never materialised (sa_fused.XYZGEN: activations rebuilt from the grouped coordinates inside the consumer GEMMs,
