@@ -791,6 +791,80 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, cons
   }
 }
 
+// The same with G workgroups per scene: workgroup g owns the keys [g per, (g + 1) per), per = ceil(n / G).  Every workgroup
+// scans ALL of the scene's entries (ms ints: nothing), counts the ones below its range on the way -- that is the base of
+// its offsets, so no second launch and no exchange is needed -- and does LDS atomics only for its own keys: the one-
+// workgroup version is bound by the CU's LDS-atomic rate (2 x ms contended atomics on ONE CU per scene: 18 us for the
+// 8 x 32768 entries of sa2, 55 us for the 8 x 40000 points of the ball-query grid).
+template <int G>
+__global__ __launch_bounds__(1024) void csr_build_split_kernel(int n, int ms, const int *__restrict__ idx,
+                                                              int *__restrict__ offsets, int *__restrict__ order) {
+  constexpr int R = kCsrLdsMax / G;
+  __shared__ int cnt[R];
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int b = (int)blockIdx.x / G, part = (int)blockIdx.x % G;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + G - 1) / G;
+  const int lo = part * per;
+  if (lo >= n) return;
+  const int hi = lo + per < n ? lo + per : n;
+  const int keys = hi - lo;
+  idx += (size_t)b * ms;
+  for (int k = tid; k < keys; k += 1024) cnt[k] = 0;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  constexpr int U = 16;
+  int below = 0;
+  for (int p = tid; p < ms; p += U * 1024) {
+    int k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      below += (k[u] >= 0 && k[u] < lo) ? 1 : 0;
+      if (k[u] >= lo && k[u] < hi) atomicAdd(&cnt[k[u] - lo], 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o, 64);
+  if (lane == 0 && below) atomicAdd(&carry, below);
+  __syncthreads();
+  for (int base = 0; base < keys; base += 1024) {
+    const int k = base + tid;
+    const int v = k < keys ? cnt[k] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int wo = 0;
+    for (int w = 0; w < wave; ++w) wo += wsum[w];
+    const int excl = carry + wo + x - v;
+    if (k < keys) {
+      offsets[(size_t)b * (n + 1) + lo + k] = excl;
+      cnt[k] = excl;                       // becomes the fill cursor
+    }
+    __syncthreads();
+    if (tid == 1023) carry = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0 && hi == n) offsets[(size_t)b * (n + 1) + n] = carry;
+  for (int p = tid; p < ms; p += U * 1024) {
+    int k[U], slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) slot[u] = (k[u] >= lo && k[u] < hi) ? atomicAdd(&cnt[k[u] - lo], 1) : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (slot[u] >= 0) order[(size_t)b * ms + slot[u]] = p + u * 1024;
+  }
+}
+
 // dfeat[b][k][c0..c0+8) = sum over the bucket of dX[p][c0..c0+8)   (one lane per (b, k, 8 channels));
 // the lane of the coordinate piece accumulates dxyz[b][k] = inv_r * sum dX[p][cin..cin+3).
 __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, int n, int ms, int cin, int kpad,
@@ -1103,8 +1177,12 @@ extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, i
   if (!idx || !offsets || !order || !scratch) return OMNIPQ_EINVAL;
   const long long P = (long long)b * m * s;
   const int ms = m * s;
-  if (n <= omnipq::kCsrLdsMax && b <= 65535) {
-    omnipq::csr_build_lds_kernel<<<b, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
+  if (n <= omnipq::kCsrLdsMax && b <= 8191) {
+    static const int split = getenv("OMNIPQ_CSR_SPLIT") ? atoi(getenv("OMNIPQ_CSR_SPLIT")) : 8;
+    if (split == 8 && n >= 1024 && ms >= 8192)
+      omnipq::csr_build_split_kernel<8><<<b * 8, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
+    else
+      omnipq::csr_build_lds_kernel<<<b, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }

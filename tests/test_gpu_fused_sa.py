@@ -729,3 +729,31 @@ def test_data_gradient_gemm_with_generated_batchnorm_backward(M, N, K, below):
     if below:
         scale = want_sums[:2].abs().max(1, keepdim=True)[0]
         assert float(((got_sums[:2] - want_sums[:2]).abs() / scale).max()) < 3e-3
+
+
+@pytest.mark.parametrize("B,n,m,s", [(8, 2048, 1024, 32), (3, 1024, 2750, 3), (2, 8192, 40000, 1), (2, 1000, 9000, 1),
+                                     (2, 5000, 100, 16), (1, 40000, 2048, 64)])
+def test_build_csr_groups_every_position_under_its_source_point(B, n, m, s):
+    """omnipq_sa_build_csr on all three of its paths (one workgroup per scene with LDS counters; eight workgroups per scene,
+    each owning a key range and counting what lies below it; global counters for more than 8192 source points): offsets =
+    exclusive prefix of the per-key counts, and `order` lists exactly the positions of every key inside its range (in any
+    order), incl. keys nobody references and a key everybody references."""
+    gen = torch.Generator().manual_seed(n + m)
+    idx = torch.randint(0, n, (B, m, s), generator=gen, dtype=torch.int32)
+    idx[0, : m // 2] = 7                                           # a hot key
+    idx[-1][idx[-1] == 11] = 12                                    # an unused key
+    idx = idx.to(dev())
+    offsets = torch.full((B, n + 1), -1, device=dev(), dtype=torch.int32)
+    order = torch.full((B, m * s), -1, device=dev(), dtype=torch.int32)
+    scratch = torch.empty(B, n, device=dev(), dtype=torch.int32)
+    capi.ok("omnipq_sa_build_csr", B, n, m, s, capi.P(idx), capi.P(offsets), capi.P(order), capi.P(scratch))
+    flat = idx.view(B, -1).long()
+    counts = torch.zeros(B, n, device=dev(), dtype=torch.long).scatter_add_(1, flat, torch.ones_like(flat))
+    want = torch.cat([torch.zeros(B, 1, device=dev(), dtype=torch.long), counts.cumsum(1)], 1)
+    assert torch.equal(offsets.long(), want)
+    # every slot of `order` holds a position whose key owns that slot's range, and every position appears once
+    for b in range(B):
+        o = order[b].long()
+        assert torch.equal(torch.sort(o).values, torch.arange(m * s, device=dev()))
+        key_of_slot = torch.searchsorted(want[b, 1:].contiguous(), torch.arange(m * s, device=dev()), right=True)
+        assert torch.equal(flat[b][o], key_of_slot)
