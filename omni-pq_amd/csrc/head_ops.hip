@@ -359,25 +359,65 @@ __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf
   __shared__ float inv[kVotePts];
   const int b = (int)blockIdx.y, k0 = (int)blockIdx.x * kVotePts, tid = (int)threadIdx.x;
   const int npts = K - k0 < kVotePts ? K - k0 : kVotePts;
-  // rows in: consecutive threads walk a row's channels
-  for (int i = tid; i < npts * (C + 3); i += 256) {
-    const int p = i / (C + 3), c = i - p * (C + 3);
-    const float x = (float)net[((size_t)b * K + k0 + p) * ldn + c];
-    if (c < 3)
-      vote_xyz[((size_t)b * K + k0 + p) * 3 + c] = seed_xyz[((size_t)b * K + k0 + p) * 3 + c] + x;
-    else
-      v[c - 3][p] = x;
+  // rows in: 16-byte pieces of the rows (the GEMM's padded rows: ldn % 8 == 0), all of a thread's pieces requested before
+  // any is used; element by element otherwise
+  if ((ldn & 7) == 0) {
+    const int ppr = (C + 3 + 7) >> 3;                          // pieces per row that hold offset / residual columns
+    constexpr int kMaxPieces = (kVotePts * ((kVoteMaxC + 3 + 7) / 8) + 255) / 256;      // 6
+    uint4 w[kMaxPieces];
+#pragma unroll
+    for (int u = 0; u < kMaxPieces; ++u) {
+      const int i = tid + u * 256, p = i / ppr, piece = i - p * ppr;
+      w[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < npts) w[u] = *reinterpret_cast<const uint4 *>(net + ((size_t)b * K + k0 + p) * ldn + piece * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxPieces; ++u) {
+      const int i = tid + u * 256, p = i / ppr, piece = i - p * ppr;
+      if (p >= npts) continue;
+      const unsigned ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = piece * 8 + e;
+        const float x = __builtin_bit_cast(float, (e & 1) ? (ww[e >> 1] & 0xffff0000u) : (ww[e >> 1] << 16));
+        if (c < 3)
+          vote_xyz[((size_t)b * K + k0 + p) * 3 + c] = seed_xyz[((size_t)b * K + k0 + p) * 3 + c] + x;
+        else if (c < C + 3)
+          v[c - 3][p] = x;
+      }
+    }
+  } else {
+    for (int i = tid; i < npts * (C + 3); i += 256) {
+      const int p = i / (C + 3), c = i - p * (C + 3);
+      const float x = (float)net[((size_t)b * K + k0 + p) * ldn + c];
+      if (c < 3)
+        vote_xyz[((size_t)b * K + k0 + p) * 3 + c] = seed_xyz[((size_t)b * K + k0 + p) * 3 + c] + x;
+      else
+        v[c - 3][p] = x;
+    }
   }
   __syncthreads();
   // channel-major: consecutive threads = consecutive seeds
   const int p = tid & (kVotePts - 1), cg = tid >> 5;            // 8 channel groups
   float ss = 0.f;
-  if (p < npts)
-    for (int c = cg; c < C; c += 8) {
-      const float t = vote_ld<BF>(seed_feat, (size_t)b * sfb + (size_t)c * sfc + (size_t)(k0 + p) * sfk) + v[c][p];
-      v[c][p] = t;
-      ss = __builtin_fmaf(t, t, ss);
+  constexpr int kCh = kVoteMaxC / 8;                            // channels per thread: all of their loads in flight at once
+  if (p < npts) {
+    float sf[kCh];
+#pragma unroll
+    for (int u = 0; u < kCh; ++u) {
+      const int c = cg + 8 * u;
+      sf[u] = c < C ? vote_ld<BF>(seed_feat, (size_t)b * sfb + (size_t)c * sfc + (size_t)(k0 + p) * sfk) : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < kCh; ++u) {
+      const int c = cg + 8 * u;
+      if (c < C) {
+        const float t = sf[u] + v[c][p];
+        v[c][p] = t;
+        ss = __builtin_fmaf(t, t, ss);
+      }
+    }
+  }
   part[cg][p] = ss;
   __syncthreads();
   if (tid < kVotePts) {
@@ -414,14 +454,19 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
   const int b = (int)blockIdx.y, k0 = (int)blockIdx.x * kVotePts, tid = (int)threadIdx.x;
   const int npts = K - k0 < kVotePts ? K - k0 : kVotePts;
   const int p = tid & (kVotePts - 1), cg = tid >> 5;
+  constexpr int kCh = kVoteMaxC / 8;                            // channels per thread, held in registers across the reduction
+  float gg[kCh], oo[kCh];
   float dot = 0.f;
-  if (p < npts && g_feat)
-    for (int c = cg; c < C; c += 8) {
-      const size_t o = ((size_t)b * C + c) * K + k0 + p;
-      const float g = vote_ld<BF>(g_feat, o);
-      v[c][p] = g;
-      dot = __builtin_fmaf(g, vote_ld<BF>(out, o), dot);
-    }
+#pragma unroll
+  for (int u = 0; u < kCh; ++u) {
+    const int c = cg + 8 * u;
+    const bool ok = p < npts && g_feat && c < C;
+    const size_t o = ((size_t)b * C + (c < C ? c : 0)) * K + k0 + (p < npts ? p : 0);
+    gg[u] = ok ? vote_ld<BF>(g_feat, o) : 0.f;
+    oo[u] = ok ? vote_ld<BF>(out, o) : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < kCh; ++u) dot = __builtin_fmaf(gg[u], oo[u], dot);
   part[cg][p] = dot;
   __syncthreads();
   if (p < npts) {
@@ -429,14 +474,37 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
 #pragma unroll
     for (int g = 0; g < 8; ++g) d += part[g][p];
     const float rn = 1.0f / norm[(size_t)b * K + k0 + p];
-    for (int c = cg; c < C; c += 8) {
-      const size_t o = ((size_t)b * C + c) * K + k0 + p;
-      const float t = g_feat ? (v[c][p] - vote_ld<BF>(out, o) * d) * rn : 0.f;
-      v[c][p] = t;
-      if (dseed) vote_st<BF>(dseed, o, t);
+#pragma unroll
+    for (int u = 0; u < kCh; ++u) {
+      const int c = cg + 8 * u;
+      if (c < C) {
+        const float t = (gg[u] - oo[u] * d) * rn;              // zero without a feature gradient (gg = oo = 0)
+        v[c][p] = t;
+        if (dseed) vote_st<BF>(dseed, ((size_t)b * C + c) * K + k0 + p, t);
+      }
     }
   }
   __syncthreads();
+  if ((ldd & 7) == 0) {
+    const int ppr = ldd >> 3;
+    for (int i = tid; i < npts * ppr; i += 256) {
+      const int q = i / ppr, piece = i - q * ppr;
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = piece * 8 + e;
+        t[e] = 0.f;
+        if (c < 3)
+          t[e] = g_xyz ? g_xyz[((size_t)b * K + k0 + q) * 3 + c] : 0.f;
+        else if (c < 3 + C)
+          t[e] = v[c - 3][q];
+      }
+      uint4 o;
+      o.x = pack_bf16x2(t[0], t[1]), o.y = pack_bf16x2(t[2], t[3]), o.z = pack_bf16x2(t[4], t[5]), o.w = pack_bf16x2(t[6], t[7]);
+      *reinterpret_cast<uint4 *>(dnet + ((size_t)b * K + k0 + q) * ldd + piece * 8) = o;
+    }
+    return;
+  }
   for (int i = tid; i < npts * ldd; i += 256) {
     const int q = i / ldd, c = i - q * ldd;
     float t = 0.f;
