@@ -114,6 +114,15 @@ int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int ld
 int omnipq_sa_pool_select(long long BM, int C, const void *ymax, const void *ymin, const unsigned char *amax,
                           const unsigned char *amin, const float *a, const float *bshift, float *out_f32, void *out_pm,
                           unsigned char *arg, void *ysel, void *stream);
+/* omnipq_sa_pool_select with the layer's BatchNorm finalize (omnipq_bn_finalize without a conv bias) in the same launch:
+ * a / b / mean / invstd are derived from `sums` (double[2][C]: sum y, sum y^2 over `count` positions) by every workgroup,
+ * published (and the running statistics updated, if given) by the first.  C <= 1024. */
+int omnipq_sa_pool_select_finalize(long long BM, int C, const void *ymax, const void *ymin, const unsigned char *amax,
+                                   const unsigned char *amin, const double *sums, double count, const float *gamma,
+                                   const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                   float *a_out, float *b_out, float *mean_out, float *invstd_out, float *out_f32,
+                                   void *out_pm, unsigned char *arg, void *ysel, void *stream);
+
 int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
                                  const float *g_out, const void *out_pm, double *sums, void *stream);
 int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
@@ -244,6 +253,12 @@ int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *Y, const fl
 int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
                              const float *mean, const float *invstd, const double *sums, const float *g_out,
                              const void *out_pm, const unsigned char *arg, void *dY, void *stream);
+/* The same; additionally gb_out float[2][C] = (dbeta | dgamma), the totals as f32 -- the layer's affine gradients when
+ * `sums` are this rank's own totals (no process group); saves the omnipq_sums_to_f32 launch. */
+int omnipq_sa_pool_bwd_apply_gb(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
+                                const float *mean, const float *invstd, const double *sums, const float *g_out,
+                                const void *out_pm, const unsigned char *arg, void *dY, float *gb_out, void *stream);
+
 
 /* backward of ReLU + BatchNorm for the inner layers (dX -> dY, may be in place) */
 int omnipq_bn_bwd_stats(long long P, int C, const void *dX, const void *Y, const float *a, const float *b,

@@ -313,6 +313,69 @@ __global__ __launch_bounds__(256) void pool_select_kernel(long long items, int C
   }
 }
 
+// pool_select_kernel with the layer's BatchNorm finalize (bn_finalize_kernel) in its prologue: every workgroup derives
+// a, b of all C <= kFinMaxC channels from the f64 totals into LDS (two channels per thread), workgroup 0 publishes them
+// with mean / invstd and updates the running statistics.  One launch less per SA stage and forward.
+constexpr int kFinMaxC = 1024;
+__global__ __launch_bounds__(256) void pool_select_finalize_kernel(
+    long long items, int C, const bf16_t *__restrict__ ymax, const bf16_t *__restrict__ ymin,
+    const unsigned char *__restrict__ amax, const unsigned char *__restrict__ amin, const double *__restrict__ sums, double cnt,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ a_out, float *__restrict__ b_out,
+    float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ out_f32, bf16_t *__restrict__ out_pm,
+    unsigned char *__restrict__ arg, bf16_t *__restrict__ ysel) {
+  __shared__ __attribute__((aligned(16))) float s_a[kFinMaxC], s_b[kFinMaxC];
+  for (int c = (int)threadIdx.x; c < C; c += 256) {
+    const double mu = sums[c] / cnt;
+    double var = sums[C + c] / cnt - mu * mu;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float av = gamma[c] * is, bv = beta[c] - (float)mu * av;
+    s_a[c] = av;
+    s_b[c] = bv;
+    if (blockIdx.x == 0) {
+      a_out[c] = av;
+      b_out[c] = bv;
+      mean_out[c] = (float)mu;
+      invstd_out[c] = is;
+      if (running_mean) {
+        const double unbiased = cnt > 1 ? var * cnt / (cnt - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bm = q / cpr;
+    const int c0 = (int)(q - bm * cpr) * 8;
+    const size_t o = (size_t)bm * C + c0;
+    float av[8], bv[8], hi[8], lo[8], best[8], sel[8];
+    load8f(s_a + c0, av);
+    load8f(s_b + c0, bv);
+    unpack8(*reinterpret_cast<const uint4 *>(ymax + o), hi);
+    unpack8(*reinterpret_cast<const uint4 *>(ymin + o), lo);
+    const unsigned long long ph = *reinterpret_cast<const unsigned long long *>(amax + o);
+    const unsigned long long pl = *reinterpret_cast<const unsigned long long *>(amin + o);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool up = av[e] >= 0.f;
+      sel[e] = up ? hi[e] : lo[e];
+      best[e] = fmaxf(__builtin_fmaf(av[e], sel[e], bv[e]), 0.f);
+      const unsigned long long t = ((up ? ph : pl) >> (8 * e)) & 0xFF;
+      packed |= (best[e] > 0.f ? t : 0ull) << (8 * e);
+    }
+    *reinterpret_cast<uint4 *>(out_pm + o) = pack8(best);
+    *reinterpret_cast<uint4 *>(ysel + o) = pack8(sel);
+    *reinterpret_cast<unsigned long long *>(arg + o) = packed;
+    float *of = out_f32 + o;
+    *reinterpret_cast<float4 *>(of) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<float4 *>(of + 4) = make_float4(best[4], best[5], best[6], best[7]);
+  }
+}
+
 // pool_bwd_stats_kernel with y at the arg-max position taken from `ysel` instead of a gather out of Y
 __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, int C, const bf16_t *__restrict__ ysel,
                                                                 const float *__restrict__ mean,
@@ -538,18 +601,29 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
                                                             const float *__restrict__ a,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
-                                                            const float *__restrict__ st,
+                                                            const double *__restrict__ sums, double inv_total,
+                                                            float *__restrict__ gb_out,
                                                             const float *__restrict__ g_out,
                                                             const bf16_t *__restrict__ out_pm,
                                                             const unsigned char *__restrict__ arg,
                                                             bf16_t *__restrict__ dY) {
+  // the means S / P, T / P straight from the f64 totals (16 loads per ball and channel piece, amortised over the ball's
+  // s rows: the separate f64 -> f32 means launch is gone); the items of ball 0 also publish dbeta | dgamma when asked to
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
     const long long bm = q / cpr;
     const int c0 = (int)(q - bm * cpr) * 8;
     float o[8], av[8], mu[8], is[8], gg[8], Sv[8], Tv[8];
-    load8f(st + c0, Sv);
-    load8f(st + C + c0, Tv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double s0 = sums[c0 + e], s1 = sums[C + c0 + e];
+      Sv[e] = (float)(s0 * inv_total);
+      Tv[e] = (float)(s1 * inv_total);
+      if (gb_out && bm == 0) {
+        gb_out[c0 + e] = (float)s0;
+        gb_out[C + c0 + e] = (float)s1;
+      }
+    }
     load8f(g_out + (size_t)bm * C + c0, gg);
     unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + c0), o);
     load8f(a + c0, av);
@@ -1061,6 +1135,26 @@ extern "C" int omnipq_sa_pool_select(long long BM, int C, const void *ymax, cons
   return OMNIPQ_OK;
 }
 
+extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *ymax, const void *ymin,
+                                              const unsigned char *amax, const unsigned char *amin, const double *sums,
+                                              double count, const float *gamma, const float *beta, float eps,
+                                              float momentum, float *running_mean, float *running_var, float *a_out,
+                                              float *b_out, float *mean_out, float *invstd_out, float *out_f32, void *out_pm,
+                                              unsigned char *arg, void *ysel, void *stream) {
+  if (BM < 0 || C <= 0 || (C % 8) || C > kFinMaxC || !(count > 0)) return OMNIPQ_EINVAL;
+  const long long items = BM * (C / 8);
+  if (!ymax || !ymin || !amax || !amin || !sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out ||
+      !out_f32 || !out_pm || !arg || !ysel)
+    return OMNIPQ_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
+  const int grid = items == 0 ? 1 : grid_for(items);           // an empty batch still finalises the layer
+  pool_select_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      items, C, (const bf16_t *)ymax, (const bf16_t *)ymin, amax, amin, sums, count, gamma, beta, eps, momentum, running_mean,
+      running_var, a_out, b_out, mean_out, invstd_out, out_f32, (bf16_t *)out_pm, arg, (bf16_t *)ysel);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
 extern "C" int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
                                             const float *g_out, const void *out_pm, double *sums, void *stream) {
   if (BM < 0 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
@@ -1093,19 +1187,38 @@ extern "C" int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *
   return OMNIPQ_OK;
 }
 
+static int pool_bwd_apply_impl(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
+                               const float *mean, const float *invstd, const double *sums, const float *g_out,
+                               const void *out_pm, const unsigned char *arg, void *dY, float *gb_out, void *stream);
+
 extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions, const void *Y,
                                         const float *a, const float *mean, const float *invstd,
                                         const double *sums, const float *g_out, const void *out_pm,
                                         const unsigned char *arg, void *dY, void *stream) {
+  return pool_bwd_apply_impl(b, m, s, C, total_positions, Y, a, mean, invstd, sums, g_out, out_pm, arg, dY, nullptr, stream);
+}
+
+// The same; additionally gb_out float[2][C] = (dbeta | dgamma) = the totals as f32 (what omnipq_sums_to_f32 would give:
+// valid as the layer's affine gradients when `sums` are this rank's own totals, i.e. without a process group).
+extern "C" int omnipq_sa_pool_bwd_apply_gb(int b, int m, int s, int C, double total_positions, const void *Y,
+                                           const float *a, const float *mean, const float *invstd, const double *sums,
+                                           const float *g_out, const void *out_pm, const unsigned char *arg, void *dY,
+                                           float *gb_out, void *stream) {
+  if (!gb_out) return OMNIPQ_EINVAL;
+  return pool_bwd_apply_impl(b, m, s, C, total_positions, Y, a, mean, invstd, sums, g_out, out_pm, arg, dY, gb_out, stream);
+}
+
+static int pool_bwd_apply_impl(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
+                               const float *mean, const float *invstd, const double *sums, const float *g_out,
+                               const void *out_pm, const unsigned char *arg, void *dY, float *gb_out, void *stream) {
   if (b < 0 || m < 0 || s <= 0 || s > 255 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
   const long long chunks = (long long)b * m * s * (C / 8);
   if (chunks == 0) return OMNIPQ_OK;
   if (!Y || !a || !mean || !invstd || !sums || !g_out || !out_pm || !arg || !dY) return OMNIPQ_EINVAL;
-  float *st = means_scratch(sums, C);
-  bwd_means_kernel<<<(2 * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(2 * C, 1.0 / total_positions, sums, st);
   const long long items = chunks / s;                   // (ball, 8-channel piece)
   pool_bwd_apply_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
-      items, m, s, C, (const bf16_t *)Y, a, mean, invstd, st, g_out, (const bf16_t *)out_pm, arg, (bf16_t *)dY);
+      items, m, s, C, (const bf16_t *)Y, a, mean, invstd, sums, 1.0 / total_positions, gb_out, g_out,
+      (const bf16_t *)out_pm, arg, (bf16_t *)dY);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

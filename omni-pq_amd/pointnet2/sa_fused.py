@@ -164,6 +164,9 @@ def affine_pays(P, N):
 
 
 POOL_EPILOGUE = os.environ.get("OMNIPQ_POOL_EPILOGUE", "1") != "0"
+# the last layer's BatchNorm finalize inside the pool-select launch, its backward means / affine gradients inside the pool
+# backward apply ("0": the separate launches, for A/B)
+_FOLD_SMALL = os.environ.get("OMNIPQ_SA_FOLD", "1") != "0"
 
 
 def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None):
@@ -1117,6 +1120,9 @@ class FusedSAStage(torch.autograd.Function):
                           _p(sums), _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
                           _p(rm), _p(rv), _p(None), _p(lay.Y), _p(lay.X), _p(lay.a), _p(lay.b), _p(lay.mean),
                           _p(lay.invstd))
+                elif _FOLD_SMALL and l == L - 1 and pool is not None and cout <= 1024:
+                    # the last layer: finalised inside omnipq_sa_pool_select_finalize below
+                    lay.fin = (sums, float(P) * world, gamma.detach(), beta.detach(), eps, momentum, rm, rv, None)
                 else:
                     _call(_lib.omnipq_bn_finalize, sums, cout, ctypes.c_double(float(P) * world), _p(sums),
                           _p(gamma.detach()), _p(beta.detach()), ctypes.c_float(eps), ctypes.c_float(momentum),
@@ -1148,8 +1154,16 @@ class FusedSAStage(torch.autograd.Function):
         ysel = None
         if training and pool is not None:
             ysel = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
-            _call(_lib.omnipq_sa_pool_select, out_pm, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
-                  _p(pool[3]), _p(pool[4]), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
+            if last.fin is not None:
+                fsums, count, pg, pb, peps, pmom, prm, prv, _ = last.fin
+                last.fin = None
+                _call(_lib.omnipq_sa_pool_select_finalize, out_pm, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
+                      _p(pool[3]), _p(pool[4]), _p(fsums), ctypes.c_double(count), _p(pg), _p(pb), ctypes.c_float(peps),
+                      ctypes.c_float(pmom), _p(prm), _p(prv), _p(last.a), _p(last.b), _p(last.mean), _p(last.invstd),
+                      _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
+            else:
+                _call(_lib.omnipq_sa_pool_select, out_pm, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
+                      _p(pool[3]), _p(pool[4]), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
         else:
             _call(_lib.omnipq_sa_pool, last.Y, B, M, S, last.C, _p(last.Y), _p(last.a), _p(last.b), _p(out_f32),
                   _p(out_pm), _p(arg))
@@ -1416,11 +1430,17 @@ class FusedSAStage(torch.autograd.Function):
                   _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
         if last.Y is not None:
             # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
-            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
-            _allreduce_(sums[:2], world)
             dY = torch.empty_like(last.Y)
-            _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
-                  _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
+            if world > 1 or _FORCE_COLLECTIVES or not _FOLD_SMALL:
+                grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
+                _allreduce_(sums[:2], world)
+                _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
+                      _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
+            else:
+                gb3 = torch.empty((2, last.C), device=dev, dtype=torch.float32)      # dbeta | dgamma, written by the apply
+                grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = gb3[1], gb3[0]
+                _call(_lib.omnipq_sa_pool_bwd_apply_gb, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
+                      _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY), _p(gb3))
 
         d_feat = d_xyz = d_cen = None
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (ctx.has_features and ctx.needs_input_grad[2])
