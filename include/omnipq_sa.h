@@ -51,6 +51,13 @@ long long omnipq_gemm_nt_workspace_floats(int M, int N, int K);
 int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                            const float *bias, float *workspace, void *stream);
 
+/* C = dropout(relu(A B^T + bias)) in one launch (the decoder feed-forward's first layer, transformer.py:222-224): the
+ * same decisions as omnipq_relu_dropout (omnipq_decoder.h) applied to the stored matrix -- hash of the seed word, the
+ * salt and the element index row * ldc + col -- so both routes give the same bits.  dropout_p = 0: ReLU only. */
+int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+                                     int ldc, const float *bias, float dropout_p, const unsigned long long *seed_ptr,
+                                     unsigned salt, void *stream);
+
 /* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
 long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,

@@ -21,6 +21,24 @@ namespace omnipq {
 
 // (lo, hi) -> one word of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Two scalar conversions + shift + or
 // are four instructions, and the SLP vectoriser pairs scalar conversions across words, adding two shuffles per word.
+// dropout decisions of the decoder's row kernels and of the GEMM epilogue that applies ReLU + dropout: counter hash of
+// (seed word in device memory, per-call salt, element index)
+__device__ __forceinline__ unsigned dec_seed(const unsigned long long *seed_ptr, unsigned salt) {
+  const unsigned long long s = *seed_ptr * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (salt + 1u);
+  return (unsigned)(s >> 32) ^ (unsigned)s;
+}
+
+__device__ __forceinline__ unsigned dec_hash(unsigned idx, unsigned seed) {
+  unsigned x = idx ^ seed;
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+
 typedef float omnipq_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 omnipq_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {

@@ -15,21 +15,6 @@ namespace omnipq {
 typedef __bf16 bf16_t;
 constexpr int LN_MAXCH = 4;          // float4 chunks per lane: C <= 64 * 4 * 4 = 1024
 
-__device__ __forceinline__ unsigned dec_seed(const unsigned long long *seed_ptr, unsigned salt) {
-  const unsigned long long s = *seed_ptr * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (salt + 1u);
-  return (unsigned)(s >> 32) ^ (unsigned)s;
-}
-
-__device__ __forceinline__ unsigned dec_hash(unsigned idx, unsigned seed) {
-  unsigned x = idx ^ seed;
-  x *= 0x9E3779B1u;
-  x ^= x >> 15;
-  x *= 0x85EBCA77u;
-  x ^= x >> 13;
-  x *= 0xC2B2AE3Du;
-  x ^= x >> 16;
-  return x;
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -35,6 +35,13 @@ struct GemmArgs {
   int lda, ldb, ldc;    // leading dimensions in elements
   int k_chunk;          // K range per blockIdx.z slice (== K when not split); multiple of GBK
   int m_tiles, n_tiles;
+  // STATS = 0, bf16 output only: relu != 0 applies max(., 0) after the bias and, with drop_thresh != 0, dropout with the
+  // decisions of omnipq_relu_dropout (same hash of the element index row * ldc + col): the feed-forward's activation pass
+  // inside its first GEMM
+  int relu = 0;
+  unsigned drop_thresh = 0, drop_salt = 0;
+  float drop_keep_inv = 1.f;
+  const unsigned long long *drop_seed = nullptr;
 };
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -548,6 +555,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
     static_assert(CP % 2 == 0, "packed C-tile pitch");
     unsigned *const cbase = ct32 + (wm * (T / 2) + crow0 + (odd ? 1 : 0)) * (CP / 2) + ((wn * (T / 2) + (ccol & ~1)) >> 1);
     // two copies of the loop, with and without the bias (wave-uniform): the 64 adds per thread are not paid for a NULL bias
+    const unsigned rd_seed = (STATS == 0 && g.relu && g.drop_thresh) ? dec_seed(g.drop_seed, g.drop_salt) : 0u;
     auto pack_tile = [&](auto has_bias) {
       constexpr bool HAS_BIAS = decltype(has_bias)::value;
       float bcol[NI];                      // per-column bias (f32, added before the single bf16 rounding)
@@ -562,8 +570,18 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            const float mine0 = HAS_BIAS ? acc[i][j][r] + bcol[j] : acc[i][j][r];
-            const float mine1 = HAS_BIAS ? acc[i][j][r + 1] + bcol[j] : acc[i][j][r + 1];
+            float mine0 = HAS_BIAS ? acc[i][j][r] + bcol[j] : acc[i][j][r];
+            float mine1 = HAS_BIAS ? acc[i][j][r + 1] + bcol[j] : acc[i][j][r + 1];
+            if (STATS == 0 && g.relu) {                        // wave-uniform
+              mine0 = __builtin_fmaxf(mine0, 0.f);
+              mine1 = __builtin_fmaxf(mine1, 0.f);
+              if (g.drop_thresh) {
+                const unsigned e0 = (unsigned)(m0 + wm * (T / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + crow0) * (unsigned)g.ldc +
+                                    (unsigned)(n0 + wn * (T / 2) + j * 32 + ccol);
+                mine0 = dec_hash(e0, rd_seed) >= g.drop_thresh ? mine0 * g.drop_keep_inv : 0.f;
+                mine1 = dec_hash(e0 + (unsigned)g.ldc, rd_seed) >= g.drop_thresh ? mine1 * g.drop_keep_inv : 0.f;
+              }
+            }
             const float give = odd ? mine0 : mine1;
             const float got = __builtin_bit_cast(
                 float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
@@ -1381,6 +1399,36 @@ extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int 
     gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
                                                                           bias);
   }
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// C = dropout(relu(A B^T + bias)): the decoder feed-forward's first linear layer with its activation pass in the epilogue.
+// The decisions are those of omnipq_relu_dropout on the stored matrix (hash of seed word, salt and the element index
+// row * ldc + col), so the two routes give the same bits; dropout_p = 0: ReLU only (seed_ptr may be NULL).
+extern "C" int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+                                                void *C, int ldc, const float *bias, float dropout_p,
+                                                const unsigned long long *seed_ptr, unsigned salt, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !seed_ptr)) return OMNIPQ_EINVAL;
+  if ((long long)M * ldc >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
+  const bool small = gemm_nt_small_tiles(M, N);
+  GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, small ? 64 : 128);
+  g.relu = 1;
+  if (dropout_p > 0.f) {
+    const double th = (double)dropout_p * 4294967296.0;                     // as decoder_ops.hip: drop_params
+    g.drop_thresh = (unsigned)(th < 1.0 ? 1.0 : (th > 4294967295.0 ? 4294967295.0 : th));
+    g.drop_keep_inv = 1.0f / (1.0f - dropout_p);
+    g.drop_seed = seed_ptr;
+    g.drop_salt = salt;
+  }
+  if (small)
+    launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
+  else
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -23,6 +23,9 @@ import torch
 
 import dropout_state
 import sa_fused
+
+# ReLU + dropout of a `relu_dropout` layer inside its GEMM's epilogue ("0": the separate in-place pass, for A/B)
+_FUSE_ACT = os.environ.get("OMNIPQ_FUSE_ACT", "1") != "0"
 from sa_fused import (_allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
                       unprep_wgrad, zeros_f32, zeros_f64)
 
@@ -133,6 +136,7 @@ class RowsMLP(torch.autograd.Function):
             lay.has_bn, lay.has_bias, lay.wk = _is_bn(spec[l]), bias is not None, wk
             lay.act = spec[l] if (spec[l] is not None and not lay.has_bn) else None
             lay.fin = None
+            act_fused = False
             lay.Wp, lay.Wt = prep_weight(W2, lay.Cp, K, transpose=training, persistent=sa_fused.is_persistent(W))
             if lay.has_bn and lay.Cp != cout:
                 raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
@@ -151,8 +155,15 @@ class RowsMLP(torch.autograd.Function):
                     bp = bias.detach().float()                 # may come zero-padded already (cat_params(pad_to=))
                     if bp.shape[0] < lay.Cp:
                         bp = torch.nn.functional.pad(bp, (0, lay.Cp - bp.shape[0]))
+                act_fused = False
                 if below is not None:
                     sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, bias=bp, out=Y)
+                elif lay.act is not None and _FUSE_ACT and K < 1024 and N * lay.Cp < (1 << 32):
+                    # ReLU + dropout in the GEMM's epilogue (same decisions as omnipq_relu_dropout on the stored matrix)
+                    _, p_act, seed_act, salt_act = lay.act
+                    _call(_lib.omnipq_gemm_nt_bf16_relu_dropout, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp,
+                          _p(bp), ctypes.c_float(p_act), _p(seed_act), salt_act)
+                    act_fused = True
                 else:
                     sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K, bias=bp)
             lay.Y = Y
@@ -186,7 +197,7 @@ class RowsMLP(torch.autograd.Function):
                     _call(_lib.omnipq_bnrelu, Y, ctypes.c_longlong(N), cout, _p(Y), _p(lay.a), _p(lay.b), _p(lay.X))
                 X = lay.X
             else:
-                if lay.act is not None:
+                if lay.act is not None and not act_fused:
                     _, p, seed, salt = lay.act
                     _call(_lib.omnipq_relu_dropout, Y, ctypes.c_longlong(N * lay.Cp), _p(Y), ctypes.c_float(p),
                           _p(seed), salt)
