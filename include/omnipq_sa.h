@@ -58,6 +58,11 @@ int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void *A, int lda
                                      int ldc, const float *bias, float dropout_p, const unsigned long long *seed_ptr,
                                      unsigned salt, void *stream);
 
+/* C = (H > 0) ? (A B^T) / (1 - p) : 0 with H [M][ldc] bf16 the stored output of dropout(relu(.)): the data-gradient GEMM
+ * into such a layer with omnipq_relu_dropout_bwd (omnipq_decoder.h) in its epilogue; same bits as the two launches. */
+int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+                             const void *H, float dropout_p, void *stream);
+
 /* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
 long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,

@@ -63,6 +63,7 @@ __device__ __forceinline__ long long nt_now() {
 #define NT_STAMP(slot)
 #endif
 
+// STATS = 5: no statistics -- the stored tile is masked by the sign of bn.Y and scaled (omnipq_gemm_nt_bf16_mask).
 // STATS (bf16 output only): per-column sum and sum of squares of the ROUNDED tile values, folded into the
 // store loop -- the BatchNorm statistics of the layer without a second pass over the tensor.
 //   1: atomically added to stats_out = double[2][N]          (few M-tiles: little contention)
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
     float av[8], bv[8], mu[8], is[8];
     float cx[XG == 2 ? 3 : 1][8];          // XG = 2: sums of dz * x0_c
     f32x4 wcol[XG == 2 ? 8 : 1];           // XG = 2: W0 of this thread's 8 columns
-    if (STATS >= 3) {
+    if (STATS == 3 || STATS == 4) {
       int c0 = n0 + (tid % PIECES) * 8;
       c0 = c0 < g.N ? c0 : 0;              // columns past N are never accumulated
 #pragma unroll
@@ -640,6 +641,21 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
       const int gr = m0 + row, gc = n0 + piece * 8;
       if (gr < g.M && gc < g.N) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * CP + piece * 8);
+        if (STATS == 5) {
+          // C = (H > 0) ? C / (1 - p) : 0 with H (bn.Y, same shape and pitch as C) the stored output of dropout(relu(.)):
+          // the backward of the feed-forward's activation pass inside the GEMM that produces its input gradient
+          const uint4 hv = ypre[it];
+          const unsigned w[4] = {v.x, v.y, v.z, v.w}, hw[4] = {hv.x, hv.y, hv.z, hv.w};
+          unsigned o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d0 = __builtin_bit_cast(float, w[e] << 16), d1 = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            const float h0 = __builtin_bit_cast(float, hw[e] << 16), h1 = __builtin_bit_cast(float, hw[e] & 0xffff0000u);
+            o[e] = pack_bf16x2(h0 > 0.f ? d0 * g.drop_keep_inv : 0.f, h1 > 0.f ? d1 * g.drop_keep_inv : 0.f);
+          }
+          *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = make_uint4(o[0], o[1], o[2], o[3]);
+          continue;
+        }
         if (XG != 2) *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
         if (XG == 2) {
           const uint2 xv = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)gr * xg.ldx);
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
             cx[1][e] = __builtin_fmaf(dz, x1, cx[1][e]);
             cx[2][e] = __builtin_fmaf(dz, x2, cx[2][e]);
           }
-        } else if (STATS >= 3) {
+        } else if (STATS == 3 || STATS == 4) {
           const uint4 yv = ypre[it];
           const unsigned w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
@@ -669,7 +685,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
             cs[e] += dz;
             cs2[e] = __builtin_fmaf(dz, (y - mu[e]) * is[e], cs2[e]);
           }
-        } else if (STATS) {
+        } else if (STATS >= 1 && STATS <= 2) {
           const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -776,7 +792,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
       }
     }
     NT_STAMP(6);
-    if (STATS) {
+    if (STATS >= 1 && STATS <= 4) {
       __syncthreads();                     // the C tile is dead: reuse it as [RG row groups][NS][T] floats
       static_assert(RG * NS * T * 4 <= LDS_BYTES, "statistics fold must fit under the staging buffers");
       float *red = reinterpret_cast<float *>(smem);
@@ -1429,6 +1445,29 @@ extern "C" int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void 
     launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   else
     gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// C = (H > 0) ? (A B^T) / (1 - p) : 0: a data-gradient GEMM whose result passes backwards through dropout(relu(.)), H
+// [M][ldc] being that layer's stored output (positive exactly where the unit was active and kept) -- what
+// omnipq_relu_dropout_bwd does to the stored product, in the epilogue (same bits: the product is rounded to bf16 first).
+extern "C" int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+                                        int ldc, const void *H, float dropout_p, void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || !H || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return OMNIPQ_EINVAL;
+  const bool small = gemm_nt_small_tiles(M, N);
+  GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, small ? 64 : 128);
+  g.drop_keep_inv = 1.0f / (1.0f - dropout_p);
+  const BnBwdEpilogue bn{(const bf16_t *)H, nullptr, nullptr, nullptr, nullptr};
+  if (small)
+    launch_small<5, false>(g, A, B, C, nullptr, nullptr, bn, AffineIn(), stream);
+  else
+    gemm_nt_kernel<false, 5><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                            nullptr, nullptr, bn);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

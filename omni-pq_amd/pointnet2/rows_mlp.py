@@ -239,6 +239,7 @@ class RowsMLP(torch.autograd.Function):
         dx = None
         sums = None               # BN-backward sums of the current layer if the GEMM above already produced them
         dfr = sa_fused.deferred_wgrads.active
+        act_masked = -1                  # the dropout(relu(.)) layer whose backward mask the GEMM above it has applied already
         for l in range(L - 1, -1, -1):
             lay = layers[l]
             Xin = layers[l - 1].X if l > 0 else ctx.X0
@@ -269,7 +270,7 @@ class RowsMLP(torch.autograd.Function):
                     dcur, owned = dst, True
                 if lay.has_bias:
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
-            elif lay.act is not None:
+            elif lay.act is not None and act_masked != l:
                 # lay.Y holds dropout(relu(.)): positive exactly where the unit was active and kept
                 dst = dcur if owned else torch.empty_like(dcur)
                 _call(_lib.omnipq_relu_dropout_bwd, dcur, ctypes.c_longlong(N * lay.Cp), _p(lay.Y), _p(dcur), _p(dst),
@@ -301,7 +302,13 @@ class RowsMLP(torch.autograd.Function):
                 dcur, owned = dprev, True
             elif l > 0 or ctx.needs_input_grad[0]:
                 dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
-                sa_fused.gemm_nt_into(dcur, lay.Wt, dprev, N, lay.K, lay.Cp)
+                if l > 0 and layers[l - 1].act is not None and _FUSE_ACT and lay.Cp < 1024:
+                    # the layer below is dropout(relu(.)): its backward mask in this GEMM's epilogue
+                    _call(_lib.omnipq_gemm_nt_bf16_mask, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
+                          _p(dprev), lay.K, _p(layers[l - 1].Y), ctypes.c_float(layers[l - 1].act[1]))
+                    act_masked = l - 1
+                else:
+                    sa_fused.gemm_nt_into(dcur, lay.Wt, dprev, N, lay.K, lay.Cp)
                 if l > 0:
                     dcur, owned = dprev, True
                 else:

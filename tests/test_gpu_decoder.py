@@ -593,3 +593,22 @@ def test_gemm_with_relu_dropout_epilogue_equals_gemm_then_relu_dropout(M, N, K, 
         assert torch.equal(got, want)
     else:
         assert abs(float((got == 0).float().mean()) - (0.5 + 0.5 * p)) < 0.03      # half are negative, p of the rest dropped
+
+
+@pytest.mark.parametrize("M,N,K,p", [(4096, 2048, 288, 0.1), (300, 96, 64, 0.5), (2048, 320, 288, 0.0)])
+def test_masked_data_gradient_gemm_equals_gemm_then_relu_dropout_bwd(M, N, K, p):
+    """omnipq_gemm_nt_bf16_mask == omnipq_gemm_nt_bf16 followed by omnipq_relu_dropout_bwd, bit for bit."""
+    import ctypes
+    import capi
+    gen = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=gen).to(torch.bfloat16).to(dev())
+    B = (torch.randn(N, K, generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev())
+    H = torch.randn(M, N, generator=gen).clamp_min(0).to(torch.bfloat16).to(dev())         # about half of it zero
+    prod = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(prod), N)
+    want = torch.empty_like(prod)
+    capi.ok("omnipq_relu_dropout_bwd", ctypes.c_longlong(M * N), capi.P(H), capi.P(prod), capi.P(want), ctypes.c_float(p))
+    got = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+    capi.ok("omnipq_gemm_nt_bf16_mask", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(got), N, capi.P(H), ctypes.c_float(p))
+    assert torch.equal(got, want)
+    assert 0.3 < float((got == 0).float().mean()) < 0.7
