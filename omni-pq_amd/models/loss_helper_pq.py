@@ -188,7 +188,7 @@ def _cast_all(tensors, dtype):
             out[i] = flat[off:off + n].view(tensors[i].shape)
             off += n
         srcs = [tensors[i] for i in todo]
-        if all(t.is_contiguous() for t in srcs):
+        if hasattr(torch, "_foreach_copy_") and all(t.is_contiguous() for t in srcs):
             torch._foreach_copy_([out[i] for i in todo], srcs)
         else:
             for i in todo:
