@@ -39,18 +39,19 @@ __device__ __forceinline__ int head_argmax(const bf16_t *scores, int ns) {
   return best;
 }
 
-__global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns, int ncls, const bf16_t *__restrict__ y,
-                                                         int ldy, const float *__restrict__ base,
-                                                         const float *__restrict__ means, float hr_scale, HeadOut o) {
-  const int r = (int)blockIdx.x;
+// one row per 128 threads: r = the row (clamped by the caller; `live` false for a half-block past the end), t = 0..127,
+// s_pick = this row's slot in shared memory.  Contains a workgroup barrier: every thread of the block calls it.
+__device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s_pick, int nh, int ns, int ncls,
+                                                 const bf16_t *__restrict__ y, int ldy, const float *__restrict__ base,
+                                                 const float *__restrict__ means, float hr_scale, const HeadOut &o) {
   const bf16_t *row = y + (size_t)r * ldy;
   const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
   const int ctot = c_sem + ncls;
-  __shared__ int s_pick;
-  if (threadIdx.x == 0) s_pick = head_argmax(row + c_ss, ns);
+  if (t == 0 && live) *s_pick = head_argmax(row + c_ss, ns);
   __syncthreads();
-  const int pick = s_pick;
-  for (int c = (int)threadIdx.x; c < ctot; c += (int)blockDim.x) {
+  if (!live) return;
+  const int pick = *s_pick;
+  for (int c = t; c < ctot; c += 128) {
     const bf16_t v = row[c];
     if (c < c_ctr) {
       o.obj[(size_t)r * 2 + c] = v;
@@ -77,6 +78,13 @@ __global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns,
   }
 }
 
+__global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns, int ncls, const bf16_t *__restrict__ y,
+                                                         int ldy, const float *__restrict__ base,
+                                                         const float *__restrict__ means, float hr_scale, HeadOut o) {
+  __shared__ int s_pick;
+  head_decode_body((int)blockIdx.x, (int)threadIdx.x, true, &s_pick, nh, ns, ncls, y, ldy, base, means, hr_scale, o);
+}
+
 // One incoming gradient: logical shape [B][K][n1][n2] (n1 * n2 = the output's width), strides in elements
 // (0 for broadcast dimensions), bf16 or f32; ptr == NULL: no gradient.
 struct HeadGrad {
@@ -96,20 +104,19 @@ __device__ __forceinline__ float head_grad_at(const HeadGrad &g, int b, int k, i
   return g.is_bf16 ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
 }
 
-__global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int nh, int ns, int ncls,
-                                                             const bf16_t *__restrict__ y, int ldy,
-                                                             const float *__restrict__ means, float hr_scale,
-                                                             HeadGrads gs, bf16_t *__restrict__ dy, int lddy,
-                                                             float *__restrict__ dbase) {
-  const int r = (int)blockIdx.x;
+__device__ __forceinline__ void head_decode_bwd_body(int r, int t, bool live, int *s_pick, int K, int nh, int ns, int ncls,
+                                                     const bf16_t *__restrict__ y, int ldy,
+                                                     const float *__restrict__ means, float hr_scale,
+                                                     const HeadGrads &gs, bf16_t *__restrict__ dy, int lddy,
+                                                     float *__restrict__ dbase) {
   const int b = r / K, k = r - b * K;
   const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
   const int ctot = c_sem + ncls;
-  __shared__ int s_pick;
-  if (threadIdx.x == 0) s_pick = head_argmax(y + (size_t)r * ldy + c_ss, ns);
+  if (t == 0 && live) *s_pick = head_argmax(y + (size_t)r * ldy + c_ss, ns);
   __syncthreads();
-  const int pick = s_pick;
-  for (int c = (int)threadIdx.x; c < ctot; c += (int)blockDim.x) {
+  if (!live) return;
+  const int pick = *s_pick;
+  for (int c = t; c < ctot; c += 128) {
     float d;
     if (c < c_ctr) {
       d = head_grad_at(gs.g[0], b, k, c);
@@ -132,7 +139,17 @@ __global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int 
     }
     dy[(size_t)r * lddy + c] = (bf16_t)d;
   }
-  for (int c = ctot + (int)threadIdx.x; c < lddy; c += (int)blockDim.x) dy[(size_t)r * lddy + c] = (bf16_t)0.f;
+  for (int c = ctot + t; c < lddy; c += 128) dy[(size_t)r * lddy + c] = (bf16_t)0.f;
+}
+
+__global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int nh, int ns, int ncls,
+                                                             const bf16_t *__restrict__ y, int ldy,
+                                                             const float *__restrict__ means, float hr_scale,
+                                                             HeadGrads gs, bf16_t *__restrict__ dy, int lddy,
+                                                             float *__restrict__ dbase) {
+  __shared__ int s_pick;
+  head_decode_bwd_body((int)blockIdx.x, (int)threadIdx.x, true, &s_pick, K, nh, ns, ncls, y, ldy, means, hr_scale, gs, dy, lddy,
+                       dbase);
 }
 
 // ---- layout-quad head (reference :94-121): y[r] = [scores 2 | centre 3 | normal 3 | size 2] ----------------------
@@ -163,10 +180,10 @@ __device__ __forceinline__ float quad_grad_at(const HeadGrad &g, int b, int k, i
   return g.is_bf16 ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
 }
 
-__global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *__restrict__ y, int ldy,
-                                                         const float *__restrict__ base, QuadOut o,
-                                                         float *__restrict__ norm_out) {
-  __shared__ float red[4];
+// bid = this workgroup's block of kQuadRows rows; 256 threads; red = four floats of shared memory
+__device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, const bf16_t *__restrict__ y, int ldy,
+                                                 const float *__restrict__ base, const QuadOut &o,
+                                                 float *__restrict__ norm_out) {
   // four rows per thread and trip: the scattered 2-byte loads of a trip are independent, so the sum over the whole
   // tensor (R / 256 rows per thread) costs R / 1024 round trips instead of R / 256.  Same order in every workgroup.
   float ss = 0.f;
@@ -186,11 +203,11 @@ __global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *_
   }
   // torch.norm of a bf16 tensor returns a bf16 scalar: the division below uses that rounded value
   const float nrm = (float)(bf16_t)__builtin_sqrtf(block_sum_256(ss, red));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *norm_out = nrm;
+  if (bid == 0 && threadIdx.x == 0) *norm_out = nrm;
   const int c = (int)threadIdx.x & 15;
   if (c >= 10) return;
   for (int rr = (int)threadIdx.x >> 4; rr < kQuadRows; rr += 16) {
-    const int r = (int)blockIdx.x * kQuadRows + rr;
+    const int r = bid * kQuadRows + rr;
     if (r >= R) break;
     const bf16_t v = y[(size_t)r * ldy + c];
     if (c < 2) o.scores[r * 2 + c] = v;
@@ -200,11 +217,16 @@ __global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *_
   }
 }
 
-__global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, const bf16_t *__restrict__ y, int ldy,
-                                                             const float *__restrict__ norm_in, HeadGrads gs,
-                                                             bf16_t *__restrict__ dy, int lddy,
-                                                             float *__restrict__ dbase) {
+__global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *__restrict__ y, int ldy,
+                                                         const float *__restrict__ base, QuadOut o,
+                                                         float *__restrict__ norm_out) {
   __shared__ float red[4];
+  quad_decode_body((int)blockIdx.x, red, R, y, ldy, base, o, norm_out);
+}
+
+__device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R, int K, const bf16_t *__restrict__ y, int ldy,
+                                                     const float *__restrict__ norm_in, const HeadGrads &gs,
+                                                     bf16_t *__restrict__ dy, int lddy, float *__restrict__ dbase) {
   const float nrm = *norm_in;
   // out = x / n, n = ||x||:  dx = g / n - x * (sum g x) / n^3
   float dot = 0.f;
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, cons
   const float s = block_sum_256(dot, red) / (nrm * nrm * nrm);
   const int c0 = (int)threadIdx.x & 15;
   for (int rr = (int)threadIdx.x >> 4; rr < kQuadRows; rr += 16) {
-    const int r = (int)blockIdx.x * kQuadRows + rr;
+    const int r = bid * kQuadRows + rr;
     if (r >= R) break;
     const int b = r / K, k = r - b * K;
     for (int c = c0; c < lddy; c += 16) {
@@ -242,6 +264,59 @@ __global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, cons
       else if (c < 10) d = quad_grad_at(gs.g[3], b, k, c - 8);
       dy[(size_t)r * lddy + c] = (bf16_t)d;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, const bf16_t *__restrict__ y, int ldy,
+                                                             const float *__restrict__ norm_in, HeadGrads gs,
+                                                             bf16_t *__restrict__ dy, int lddy,
+                                                             float *__restrict__ dbase) {
+  __shared__ float red[4];
+  quad_decode_bwd_body((int)blockIdx.x, red, R, K, y, ldy, norm_in, gs, dy, lddy, dbase);
+}
+
+// Object head and quad head of one decoder stage in ONE launch each way (they are independent; two launches of 7-13 us
+// each, 28 per step): workgroups [0, ceil(Rh / 2)) take two object rows each, the rest take kQuadRows quad rows.
+struct PairHead {
+  int R, K, nh, ns, ncls, ldy, lddy;
+  const bf16_t *y;
+  const float *base, *means;
+  float hr_scale;
+  bf16_t *dy;
+  float *dbase;
+};
+struct PairQuad {
+  int R, K, ldy, lddy;
+  const bf16_t *y;
+  const float *base;
+  float *norm;
+  bf16_t *dy;
+  float *dbase;
+};
+
+__global__ __launch_bounds__(256) void decode_pair_kernel(PairHead h, HeadOut ho, PairQuad q, QuadOut qo) {
+  __shared__ int s_pick[2];
+  __shared__ float red[4];
+  const int hb = (h.R + 1) >> 1, bid = (int)blockIdx.x;
+  if (bid < hb) {
+    const int half = (int)threadIdx.x >> 7, r = 2 * bid + half;
+    head_decode_body(r < h.R ? r : h.R - 1, (int)threadIdx.x & 127, r < h.R, s_pick + half, h.nh, h.ns, h.ncls, h.y, h.ldy,
+                     h.base, h.means, h.hr_scale, ho);
+  } else {
+    quad_decode_body(bid - hb, red, q.R, q.y, q.ldy, q.base, qo, q.norm);
+  }
+}
+
+__global__ __launch_bounds__(256) void decode_pair_bwd_kernel(PairHead h, HeadGrads hg, PairQuad q, HeadGrads qg) {
+  __shared__ int s_pick[2];
+  __shared__ float red[4];
+  const int hb = (h.R + 1) >> 1, bid = (int)blockIdx.x;
+  if (bid < hb) {
+    const int half = (int)threadIdx.x >> 7, r = 2 * bid + half;
+    head_decode_bwd_body(r < h.R ? r : h.R - 1, (int)threadIdx.x & 127, r < h.R, s_pick + half, h.K, h.nh, h.ns, h.ncls, h.y,
+                         h.ldy, h.means, h.hr_scale, hg, h.dy, h.lddy, h.dbase);
+  } else {
+    quad_decode_bwd_body(bid - hb, red, q.R, q.K, q.y, q.ldy, q.norm, qg, q.dy, q.lddy, q.dbase);
   }
 }
 
@@ -321,6 +396,58 @@ extern "C" int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, co
   }
   head_decode_bwd_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, K, nh, ns, ncls, (const bf16_t *)y, ldy, means, hr_scale,
                                                              gs, (bf16_t *)dy, lddy, dbase);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// omnipq_head_decode + omnipq_quad_decode in one launch (arguments as there; head: Rh rows, quad: Rq rows).
+extern "C" int omnipq_decode_pair(int Rh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *baseh,
+                                  const float *means, float hr_scale, void *const *outs_h, int Rq, const void *yq,
+                                  int ldyq, const float *baseq, void *const *outs_q, float *norm, void *stream) {
+  using namespace omnipq;
+  if (Rh <= 0 || Rq <= 0 || nh < 1 || ns < 1 || ncls < 1) return OMNIPQ_EINVAL;
+  if (!yh || !baseh || !means || !outs_h || ldyh < 5 + 2 * nh + 4 * ns + ncls) return OMNIPQ_EINVAL;
+  if (!yq || !baseq || !outs_q || !norm || ldyq < 10 || Rq > (1 << 24)) return OMNIPQ_EINVAL;
+  for (int i = 0; i < 10; ++i)
+    if (!outs_h[i]) return OMNIPQ_EINVAL;
+  for (int i = 0; i < 4; ++i)
+    if (!outs_q[i]) return OMNIPQ_EINVAL;
+  HeadOut ho{(bf16_t *)outs_h[0], (float *)outs_h[1], (bf16_t *)outs_h[2], (bf16_t *)outs_h[3], (bf16_t *)outs_h[4],
+             (bf16_t *)outs_h[5], (bf16_t *)outs_h[6], (float *)outs_h[7], (float *)outs_h[8], (bf16_t *)outs_h[9]};
+  QuadOut qo{(bf16_t *)outs_q[0], (float *)outs_q[1], (bf16_t *)outs_q[2], (bf16_t *)outs_q[3]};
+  PairHead h{Rh, 1, nh, ns, ncls, ldyh, 0, (const bf16_t *)yh, baseh, means, hr_scale, nullptr, nullptr};
+  PairQuad q{Rq, 1, ldyq, 0, (const bf16_t *)yq, baseq, norm, nullptr, nullptr};
+  const int blocks = (Rh + 1) / 2 + (Rq + kQuadRows - 1) / kQuadRows;
+  decode_pair_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(h, ho, q, qo);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// omnipq_head_decode_bwd + omnipq_quad_decode_bwd in one launch (arguments as there).
+extern "C" int omnipq_decode_pair_bwd(int Rh, int Kh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *means,
+                                      float hr_scale, const void *const *gptr_h, const int *gstrides_h, const int *gn2_h,
+                                      const int *gbf_h, void *dyh, int lddyh, float *dbaseh, int Rq, int Kq, const void *yq,
+                                      int ldyq, const float *norm, const void *const *gptr_q, const int *gstrides_q,
+                                      const int *gbf_q, void *dyq, int lddyq, float *dbaseq, void *stream) {
+  using namespace omnipq;
+  if (Rh <= 0 || Rq <= 0 || Kh < 1 || Kq < 1 || nh < 1 || ns < 1 || ncls < 1 || (Rh % Kh) || (Rq % Kq)) return OMNIPQ_EINVAL;
+  const int width = 5 + 2 * nh + 4 * ns + ncls;
+  if (!yh || !means || !gptr_h || !gstrides_h || !gn2_h || !gbf_h || !dyh || ldyh < width || lddyh < width) return OMNIPQ_EINVAL;
+  if (!yq || !norm || !gptr_q || !gstrides_q || !gbf_q || !dyq || ldyq < 10 || lddyq < 10 || Rq > (1 << 24)) return OMNIPQ_EINVAL;
+  HeadGrads hg, qg;
+  for (int i = 0; i < 10; ++i) {
+    if (gn2_h[i] < 1) return OMNIPQ_EINVAL;
+    hg.g[i] = HeadGrad{gptr_h[i], gstrides_h[4 * i], gstrides_h[4 * i + 1], gstrides_h[4 * i + 2], gstrides_h[4 * i + 3],
+                       gn2_h[i], gbf_h[i]};
+    qg.g[i] = HeadGrad{nullptr, 0, 0, 0, 0, 1, 0};
+  }
+  for (int i = 0; i < 4; ++i)
+    qg.g[i] = HeadGrad{gptr_q[i], gstrides_q[4 * i], gstrides_q[4 * i + 1], gstrides_q[4 * i + 2], gstrides_q[4 * i + 3], 1,
+                       gbf_q[i]};
+  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, lddyh, (const bf16_t *)yh, nullptr, means, hr_scale, (bf16_t *)dyh, dbaseh};
+  PairQuad q{Rq, Kq, ldyq, lddyq, (const bf16_t *)yq, nullptr, const_cast<float *>(norm), (bf16_t *)dyq, dbaseq};
+  const int blocks = (Rh + 1) / 2 + (Rq + kQuadRows - 1) / kQuadRows;
+  decode_pair_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(h, hg, q, qg);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -235,6 +235,90 @@ class QuadDecode(torch.autograd.Function):
         return dy, dbase
 
 
+class DecodePair(torch.autograd.Function):
+    """`HeadDecode` and `QuadDecode` of one decoder stage in ONE launch each way (csrc/head_ops.hip, decode_pair): the two
+    heads are independent and each decode is a few microseconds of work, so the pair costs one launch instead of two.
+    Outputs: the ten of `HeadDecode`, then the four of `QuadDecode`, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, yh, base_h, means, nh, ns, ncls, yq, base_q):
+        import ctypes
+        B, K, _ = base_h.shape
+        Bq, Kq, _ = base_q.shape
+        dev = yh.device
+        assert yh.dtype == torch.bfloat16 and yh.stride(1) == 1 and yh.shape[0] == B * K
+        assert yh.shape[1] >= 5 + 2 * nh + 4 * ns + ncls
+        assert yq.dtype == torch.bfloat16 and yq.stride(1) == 1 and yq.shape[0] == Bq * Kq and yq.shape[1] >= 10
+        bh = base_h.detach().float().contiguous()
+        bq = base_q.detach().float().contiguous()
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        outs_h = [torch.empty((B, K, 2), **bf), torch.empty((B, K, 3), **f32), torch.empty((B, K, nh), **bf),
+                  torch.empty((B, K, nh), **bf), torch.empty((B, K, nh), **bf), torch.empty((B, K, ns), **bf),
+                  torch.empty((B, K, ns, 3), **bf), torch.empty((B, K, ns, 3), **f32), torch.empty((B, K, 3), **f32),
+                  torch.empty((B, K, ncls), **bf)]
+        outs_q = [torch.empty((Bq, Kq, 2), **bf), torch.empty((Bq, Kq, 3), **f32), torch.empty((Bq, Kq, 3), **bf),
+                  torch.empty((Bq, Kq, 2), **bf)]
+        norm = torch.empty(1, **f32)
+        scale = float(np.float32(np.pi / nh))
+        sa_fused._call(sa_fused._lib.omnipq_decode_pair, yh, B * K, nh, ns, ncls, sa_fused._p(yh), yh.stride(0),
+                       sa_fused._p(bh), sa_fused._p(means), ctypes.c_float(scale),
+                       (ctypes.c_void_p * 10)(*[o.data_ptr() for o in outs_h]), Bq * Kq, sa_fused._p(yq), yq.stride(0),
+                       sa_fused._p(bq), (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs_q]), sa_fused._p(norm))
+        ctx.save_for_backward(yh, means, yq, norm)
+        ctx.geom = (B, K, nh, ns, ncls, scale, Bq, Kq)
+        return tuple(outs_h) + tuple(outs_q)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        yh, means, yq, norm = ctx.saved_tensors
+        B, K, nh, ns, ncls, scale, Bq, Kq = ctx.geom
+        dev = yh.device
+        n2 = [1, 1, 1, 1, 1, 1, 3, 3, 1, 1]
+        ph, sh, fh, _keep_h = _grad_descriptors(gs[:10], n2)
+        pq, sq, fq, _keep_q = _grad_descriptors(gs[10:], [1, 1, 1, 1])
+        dyh = torch.empty((B * K, yh.shape[1]), device=dev, dtype=torch.bfloat16)
+        dyq = torch.empty((Bq * Kq, yq.shape[1]), device=dev, dtype=torch.bfloat16)
+        dbh = torch.empty((B, K, 3), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dbq = torch.empty((Bq, Kq, 3), device=dev, dtype=torch.float32) if ctx.needs_input_grad[7] else None
+        sa_fused._call(sa_fused._lib.omnipq_decode_pair_bwd, yh, B * K, K, nh, ns, ncls, sa_fused._p(yh), yh.stride(0),
+                       sa_fused._p(means), ctypes.c_float(scale), (ctypes.c_void_p * 10)(*ph), (ctypes.c_int * 40)(*sh),
+                       (ctypes.c_int * 10)(*n2), (ctypes.c_int * 10)(*fh), sa_fused._p(dyh), dyh.stride(0),
+                       sa_fused._p(dbh), Bq * Kq, Kq, sa_fused._p(yq), yq.stride(0), sa_fused._p(norm),
+                       (ctypes.c_void_p * 4)(*pq), (ctypes.c_int * 16)(*sq), (ctypes.c_int * 4)(*fq), sa_fused._p(dyq),
+                       dyq.stride(0), sa_fused._p(dbq))
+        return dyh, dbh, None, None, None, None, dyq, dbq
+
+
+_HEAD_KEYS = ("objectness_scores", "center", "heading_scores", "heading_residuals_normalized", "heading_residuals",
+              "size_scores", "size_residuals_normalized", "size_residuals", "pred_size", "sem_cls_scores")
+_QUAD_KEYS = ("quad_scores", "quad_center", "normal_vector", "quad_size")
+_PAIR_DECODE = os.environ.get("OMNIPQ_DECODE_PAIR", "1") != "0"
+
+
+def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, prefix, rows=None, rows_q=None):
+    """`head(net, ...)` then `quad_head(net_q, ...)` of one decoder stage (reference models/pq_transformer.py:230-233,
+    :262-267); with the fused decode both heads' tails share one launch each way.  Returns the two centres."""
+    if not (_PAIR_DECODE and _FUSED_DECODE and net.is_cuda):
+        center, _, end_points = head(net, base_xyz=base_xyz, end_points=end_points, prefix=prefix, net_rows=rows)
+        center_q, _, end_points = quad_head(net_q, base_xyz=base_xyz_q, end_points=end_points, prefix=prefix,
+                                            net_rows=rows_q)
+        return center, center_q, end_points
+    yh = head_stack(head, net, head.heads(), rows, raw=True)
+    yq = head_stack(quad_head, net_q, quad_head.heads(), rows_q, raw=True)
+    ok = all(y.dtype == torch.bfloat16 and y.stride(1) == 1 for y in (yh, yq))
+    if not ok:
+        center, _, end_points = head.finish(yh, net, base_xyz, end_points, prefix)
+        center_q, _, end_points = quad_head.finish(yq, net_q, base_xyz_q, end_points, prefix)
+        return center, center_q, end_points
+    outs = DecodePair.apply(yh, base_xyz, head._mean_sizes(net.device), head.num_heading_bin, head.num_size_cluster,
+                            head.num_class, yq, base_xyz_q)
+    for key, val in zip(_HEAD_KEYS + _QUAD_KEYS, outs):
+        end_points[f'{prefix}{key}'] = val
+    return outs[1], outs[11], end_points
+
+
 class PositionEmbeddingLearned(nn.Module):
     """xyz (B,P,C_in) -> learned embedding (B,288,P): Conv1d, BN, ReLU, Conv1d (reference :17-33)."""
 
@@ -316,22 +400,25 @@ class PredictHead(nn.Module):
             self._means = torch.from_numpy(np.asarray(self.mean_size_arr).astype(np.float32)).to(device)
         return self._means
 
+    def heads(self):
+        return (self.objectness_scores_head, self.center_head, self.heading_class_head,
+                self.heading_residual_head, self.size_class_head, self.size_residual_head,
+                self.sem_cls_scores_head)
+
     def forward(self, net, base_xyz, end_points, prefix, net_rows=None):
-        heads = (self.objectness_scores_head, self.center_head, self.heading_class_head,
-                 self.heading_residual_head, self.size_class_head, self.size_residual_head,
-                 self.sem_cls_scores_head)
-        y = head_stack(self, net, heads, net_rows, raw=True)
+        y = head_stack(self, net, self.heads(), net_rows, raw=True)
+        return self.finish(y, net, base_xyz, end_points, prefix)
+
+    def finish(self, y, net, base_xyz, end_points, prefix):
+        """From the joint output rows `y` of the seven heads to the `end_points` entries."""
+        heads = self.heads()
         B, K = net.shape[0], net.shape[2]
         if _FUSED_DECODE and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1:
             means = self._mean_sizes(net.device)
-            (obj, center, hcls, hres, hres_scaled, scls, sres, sres_scaled, pred_size, sem) = HeadDecode.apply(
-                y, base_xyz, means, self.num_heading_bin, self.num_size_cluster, self.num_class)
-            for key, val in (("objectness_scores", obj), ("center", center), ("heading_scores", hcls),
-                             ("heading_residuals_normalized", hres), ("heading_residuals", hres_scaled),
-                             ("size_scores", scls), ("size_residuals_normalized", sres),
-                             ("size_residuals", sres_scaled), ("pred_size", pred_size), ("sem_cls_scores", sem)):
+            outs = HeadDecode.apply(y, base_xyz, means, self.num_heading_bin, self.num_size_cluster, self.num_class)
+            for key, val in zip(_HEAD_KEYS, outs):
                 end_points[f'{prefix}{key}'] = val
-            return center, pred_size, end_points
+            return outs[1], outs[8], end_points
         widths = [h.out_channels for h in heads]
         obj, ctr, hcls, hres, scls, sres, sem = torch.split(y[:, :sum(widths)].reshape(B, K, -1), widths, dim=2)
         center = ctr + base_xyz
@@ -356,9 +443,15 @@ class QuadPredictHead(nn.Module):
         self.bn1 = nn.BatchNorm1d(hidden_dim)
         self.bn2 = nn.BatchNorm1d(hidden_dim)
 
+    def heads(self):
+        return (self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head)
+
     def forward(self, net, base_xyz, end_points, prefix, net_rows=None):
-        heads = (self.quad_scores_head, self.center_head, self.normal_vector_head, self.size_head)
-        y = head_stack(self, net, heads, net_rows, raw=True)
+        y = head_stack(self, net, self.heads(), net_rows, raw=True)
+        return self.finish(y, net, base_xyz, end_points, prefix)
+
+    def finish(self, y, net, base_xyz, end_points, prefix):
+        heads = self.heads()
         B, K = net.shape[0], net.shape[2]
         if _FUSED_DECODE and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1:
             scores, center, normal, size = QuadDecode.apply(y, base_xyz)
@@ -462,10 +555,8 @@ class PQ_Transformer(nn.Module):
         end_points['aggregated_vote_xyz'] = cluster_xyz
         end_points['cluster_feature'] = cluster_feature
 
-        center, _, end_points = self.proposal(cluster_feature, base_xyz=cluster_xyz,
-                                              end_points=end_points, prefix='proposal_')
-        center_q, _, end_points = self.quad_proposal(quad_feature, base_xyz=quad_xyz,
-                                                     end_points=end_points, prefix='proposal_')
+        center, center_q, end_points = predict_pair(self.proposal, self.quad_proposal, cluster_feature, quad_feature,
+                                                    cluster_xyz, quad_xyz, end_points, 'proposal_')
         # the reference clones here (:236-237); nothing writes into these tensors afterwards, a detached alias suffices
         base_xyz = center.detach()
         base_xyz_q = center_q.detach()
@@ -523,12 +614,9 @@ class PQ_Transformer(nn.Module):
                     if k not in known and torch.is_tensor(v):
                         v.record_stream(cur)
             else:
-                base_xyz, _, end_points = self.prediction_heads[i](
-                    query, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
-                    net_rows=rows_obj)
-                base_xyz_q, _, end_points = self.prediction_quad_heads[i](
-                    query_q, base_xyz=quad_xyz, end_points=end_points, prefix=prefix,
-                    net_rows=rows_quad)
+                base_xyz, base_xyz_q, end_points = predict_pair(
+                    self.prediction_heads[i], self.prediction_quad_heads[i], query, query_q, cluster_xyz, quad_xyz,
+                    end_points, prefix, rows_obj, rows_quad)
             base_xyz = base_xyz.detach()
             base_xyz_q = base_xyz_q.detach()
         return end_points

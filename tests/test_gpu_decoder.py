@@ -438,6 +438,58 @@ def test_quad_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
             assert rel_l2(u, v) < 2e-2, rel_l2(u, v)
 
 
+def test_decode_pair_is_the_two_decodes_bit_for_bit(monkeypatch):
+    """`predict_pair` with the joint launch (omnipq_decode_pair / _bwd) against the two heads called one after the other
+    (omnipq_head_decode, omnipq_quad_decode and their backward twins): same device functions, so every end_points
+    entry and every gradient is the same bits; odd row counts on both sides (the head half of the grid takes two rows
+    per block, the quad half 32)."""
+    import pq_transformer as pq
+    torch.manual_seed(5)
+    C = 288
+    means = (torch.rand(18, 3) + 0.2).numpy()
+    head = pq.PredictHead(C, 1, 18, 18, means).to(dev())
+    quad = pq.QuadPredictHead(C).to(dev())
+    head.train(), quad.train()
+    params = list(head.parameters()) + list(quad.parameters())
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in (head, quad)]
+    for B, K, Kq in ((4, 256, 256), (3, 85, 37), (1, 1, 1)):
+        net = torch.randn(B, C, K, device=dev()).requires_grad_(True)
+        net_q = torch.randn(B, C, Kq, device=dev()).requires_grad_(True)
+        base = torch.randn(B, K, 3, device=dev()).requires_grad_(True)
+        base_q = torch.randn(B, Kq, 3, device=dev()).requires_grad_(True)
+
+        def run(pair, broadcast):
+            monkeypatch.setattr(pq, "_PAIR_DECODE", pair)
+            head.load_state_dict(state[0]), quad.load_state_dict(state[1])
+            leaves = [net, net_q, base, base_q] + params
+            for t in leaves:
+                t.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                c, cq, ep = pq.predict_pair(head, quad, net, net_q, base, base_q, {}, "x_")
+            assert c is ep["x_center"] and cq is ep["x_quad_center"]
+            keys = sorted(ep)
+            gen = torch.Generator().manual_seed(9)
+            loss = 0.0
+            for k in keys:
+                v = ep[k]
+                if broadcast:
+                    loss = loss + v.float().mean() * (1 + len(k) % 3)
+                elif k != "x_size_residuals":            # one output without a gradient: the null-pointer branch
+                    loss = loss + (v.float() * torch.randn(v.shape, generator=gen).to(dev())).sum()
+            loss.backward()
+            return {k: ep[k].detach().clone() for k in keys}, [t.grad.clone() for t in leaves]
+
+        for broadcast in (False, True):
+            e1, g1 = run(True, broadcast)
+            e0, g0 = run(False, broadcast)
+            assert list(e1) == list(e0) and len(e1) == 14
+            for k in e0:
+                assert e1[k].dtype == e0[k].dtype and e1[k].shape == e0[k].shape, k
+                assert torch.equal(e1[k], e0[k]), k
+            for i, (u, v) in enumerate(zip(g1, g0)):
+                assert torch.equal(u, v), i
+
+
 def test_the_model_takes_the_fused_vote_tail_on_the_benchmarked_path():
     """bf16 autocast, training mode: vote_features carries the bf16 row twin only VoteDecode attaches, keeps the dtype
     of the seed features, and is L2-normalised over the channels."""
