@@ -84,15 +84,19 @@ int omnipq_quad_decode_bwd(int R, int K, const void *y, int ldy, const float *no
                            const int *gstrides, const int *g_is_bf16, void *dy, int lddy, float *dbase, void *stream);
 
 /* omnipq_head_decode + omnipq_quad_decode (and their backward twins) of one decoder stage in ONE launch each way: the two
- * heads are independent.  Arguments as in the single functions (h: object head, q: quad head). */
-int omnipq_decode_pair(int Rh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *baseh, const float *means,
-                       float hr_scale, void *const *outs_h, int Rq, const void *yq, int ldyq, const float *baseq,
-                       void *const *outs_q, float *norm, void *stream);
+ * heads are independent.  Arguments as in the single functions (h: object head, q: quad head; Kh / Kq proposals per scene).
+ * pos (optional): f32 [B][Kh + Kq][3], additionally receives both heads' centres side by side per scene -- the next decoder
+ * layer's query positions (reference models/pq_transformer.py:245 concatenates them).
+ * accumulate (backward): bit 0 -> dbaseh +=, bit 1 -> dbaseq += instead of = (every stage decodes against the same base
+ * positions, reference :230-233 / :262-267: their gradient is summed in place). */
+int omnipq_decode_pair(int Rh, int Kh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *baseh,
+                       const float *means, float hr_scale, void *const *outs_h, int Rq, int Kq, const void *yq, int ldyq,
+                       const float *baseq, void *const *outs_q, float *norm, float *pos, void *stream);
 int omnipq_decode_pair_bwd(int Rh, int Kh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *means,
                            float hr_scale, const void *const *gptr_h, const int *gstrides_h, const int *gn2_h,
                            const int *gbf_h, void *dyh, int lddyh, float *dbaseh, int Rq, int Kq, const void *yq, int ldyq,
                            const float *norm, const void *const *gptr_q, const int *gstrides_q, const int *gbf_q, void *dyq,
-                           int lddyq, float *dbaseq, void *stream);
+                           int lddyq, float *dbaseq, int accumulate, void *stream);
 
 /* The tail of the voting module and the normalisation that follows it (models/voting_module.py:55-63,
  * models/pq_transformer.py:216-217; vote_factor 1) in one launch, their gradient in another.

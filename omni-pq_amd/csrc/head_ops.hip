@@ -39,11 +39,24 @@ __device__ __forceinline__ int head_argmax(const bf16_t *scores, int ns) {
   return best;
 }
 
+// optional second copy of a head's centres inside the joint query positions of the next decoder layer:
+// pos[b][off + k][0..2], b = r / K, k = r % K, P positions per scene (reference models/pq_transformer.py:245 concatenates)
+struct PosOut {
+  float *pos;
+  int K, P, off;
+};
+__device__ __forceinline__ void pos_store(const PosOut &po, int r, int c, float v) {
+  if (!po.pos) return;
+  const int b = r / po.K, k = r - b * po.K;
+  po.pos[((size_t)b * po.P + po.off + k) * 3 + c] = v;
+}
+
 // one row per 128 threads: r = the row (clamped by the caller; `live` false for a half-block past the end), t = 0..127,
 // s_pick = this row's slot in shared memory.  Contains a workgroup barrier: every thread of the block calls it.
 __device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s_pick, int nh, int ns, int ncls,
                                                  const bf16_t *__restrict__ y, int ldy, const float *__restrict__ base,
-                                                 const float *__restrict__ means, float hr_scale, const HeadOut &o) {
+                                                 const float *__restrict__ means, float hr_scale, const HeadOut &o,
+                                                 const PosOut &po) {
   const bf16_t *row = y + (size_t)r * ldy;
   const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
   const int ctot = c_sem + ncls;
@@ -57,7 +70,9 @@ __device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s
       o.obj[(size_t)r * 2 + c] = v;
     } else if (c < c_hs) {
       const int k = c - c_ctr;
-      o.center[(size_t)r * 3 + k] = (float)v + base[(size_t)r * 3 + k];
+      const float ctr = (float)v + base[(size_t)r * 3 + k];
+      o.center[(size_t)r * 3 + k] = ctr;
+      pos_store(po, r, k, ctr);
     } else if (c < c_hr) {
       o.hs[(size_t)r * nh + (c - c_hs)] = v;
     } else if (c < c_ss) {
@@ -82,7 +97,8 @@ __global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns,
                                                          int ldy, const float *__restrict__ base,
                                                          const float *__restrict__ means, float hr_scale, HeadOut o) {
   __shared__ int s_pick;
-  head_decode_body((int)blockIdx.x, (int)threadIdx.x, true, &s_pick, nh, ns, ncls, y, ldy, base, means, hr_scale, o);
+  head_decode_body((int)blockIdx.x, (int)threadIdx.x, true, &s_pick, nh, ns, ncls, y, ldy, base, means, hr_scale, o,
+                   PosOut{nullptr, 1, 1, 0});
 }
 
 // One incoming gradient: logical shape [B][K][n1][n2] (n1 * n2 = the output's width), strides in elements
@@ -108,7 +124,7 @@ __device__ __forceinline__ void head_decode_bwd_body(int r, int t, bool live, in
                                                      const bf16_t *__restrict__ y, int ldy,
                                                      const float *__restrict__ means, float hr_scale,
                                                      const HeadGrads &gs, bf16_t *__restrict__ dy, int lddy,
-                                                     float *__restrict__ dbase) {
+                                                     float *__restrict__ dbase, bool acc) {
   const int b = r / K, k = r - b * K;
   const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
   const int ctot = c_sem + ncls;
@@ -122,7 +138,7 @@ __device__ __forceinline__ void head_decode_bwd_body(int r, int t, bool live, in
       d = head_grad_at(gs.g[0], b, k, c);
     } else if (c < c_hs) {
       d = head_grad_at(gs.g[1], b, k, c - c_ctr);
-      if (dbase) dbase[(size_t)r * 3 + (c - c_ctr)] = d;
+      if (dbase) dbase[(size_t)r * 3 + (c - c_ctr)] = acc ? dbase[(size_t)r * 3 + (c - c_ctr)] + d : d;
     } else if (c < c_hr) {
       d = head_grad_at(gs.g[2], b, k, c - c_hs);
     } else if (c < c_ss) {
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int 
                                                              float *__restrict__ dbase) {
   __shared__ int s_pick;
   head_decode_bwd_body((int)blockIdx.x, (int)threadIdx.x, true, &s_pick, K, nh, ns, ncls, y, ldy, means, hr_scale, gs, dy, lddy,
-                       dbase);
+                       dbase, false);
 }
 
 // ---- layout-quad head (reference :94-121): y[r] = [scores 2 | centre 3 | normal 3 | size 2] ----------------------
@@ -183,7 +199,7 @@ __device__ __forceinline__ float quad_grad_at(const HeadGrad &g, int b, int k, i
 // bid = this workgroup's block of kQuadRows rows; 256 threads; red = four floats of shared memory
 __device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, const bf16_t *__restrict__ y, int ldy,
                                                  const float *__restrict__ base, const QuadOut &o,
-                                                 float *__restrict__ norm_out) {
+                                                 float *__restrict__ norm_out, const PosOut &po) {
   // four rows per thread and trip: the scattered 2-byte loads of a trip are independent, so the sum over the whole
   // tensor (R / 256 rows per thread) costs R / 1024 round trips instead of R / 256.  Same order in every workgroup.
   float ss = 0.f;
@@ -211,7 +227,11 @@ __device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, con
     if (r >= R) break;
     const bf16_t v = y[(size_t)r * ldy + c];
     if (c < 2) o.scores[r * 2 + c] = v;
-    else if (c < 5) o.center[r * 3 + (c - 2)] = (float)v + base[r * 3 + (c - 2)];
+    else if (c < 5) {
+      const float ctr = (float)v + base[r * 3 + (c - 2)];
+      o.center[r * 3 + (c - 2)] = ctr;
+      pos_store(po, r, c - 2, ctr);
+    }
     else if (c < 8) o.normal[r * 3 + (c - 5)] = (bf16_t)((float)v / nrm);
     else o.size[r * 2 + (c - 8)] = v;
   }
@@ -221,12 +241,13 @@ __global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *_
                                                          const float *__restrict__ base, QuadOut o,
                                                          float *__restrict__ norm_out) {
   __shared__ float red[4];
-  quad_decode_body((int)blockIdx.x, red, R, y, ldy, base, o, norm_out);
+  quad_decode_body((int)blockIdx.x, red, R, y, ldy, base, o, norm_out, PosOut{nullptr, 1, 1, 0});
 }
 
 __device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R, int K, const bf16_t *__restrict__ y, int ldy,
                                                      const float *__restrict__ norm_in, const HeadGrads &gs,
-                                                     bf16_t *__restrict__ dy, int lddy, float *__restrict__ dbase) {
+                                                     bf16_t *__restrict__ dy, int lddy, float *__restrict__ dbase,
+                                                     bool acc) {
   const float nrm = *norm_in;
   // out = x / n, n = ||x||:  dx = g / n - x * (sum g x) / n^3
   float dot = 0.f;
@@ -259,7 +280,7 @@ __device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R,
       if (c < 2) d = quad_grad_at(gs.g[0], b, k, c);
       else if (c < 5) {
         d = quad_grad_at(gs.g[1], b, k, c - 2);
-        if (dbase) dbase[r * 3 + (c - 2)] = d;
+        if (dbase) dbase[r * 3 + (c - 2)] = acc ? dbase[r * 3 + (c - 2)] + d : d;
       } else if (c < 8) d = quad_grad_at(gs.g[2], b, k, c - 5) / nrm - (float)y[(size_t)r * ldy + c] * s;
       else if (c < 10) d = quad_grad_at(gs.g[3], b, k, c - 8);
       dy[(size_t)r * lddy + c] = (bf16_t)d;
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, cons
                                                              bf16_t *__restrict__ dy, int lddy,
                                                              float *__restrict__ dbase) {
   __shared__ float red[4];
-  quad_decode_bwd_body((int)blockIdx.x, red, R, K, y, ldy, norm_in, gs, dy, lddy, dbase);
+  quad_decode_bwd_body((int)blockIdx.x, red, R, K, y, ldy, norm_in, gs, dy, lddy, dbase, false);
 }
 
 // Object head and quad head of one decoder stage in ONE launch each way (they are independent; two launches of 7-13 us
@@ -284,6 +305,8 @@ struct PairHead {
   float hr_scale;
   bf16_t *dy;
   float *dbase;
+  int acc;          // backward: dbase += instead of =
+  PosOut po;        // forward
 };
 struct PairQuad {
   int R, K, ldy, lddy;
@@ -292,6 +315,8 @@ struct PairQuad {
   float *norm;
   bf16_t *dy;
   float *dbase;
+  int acc;
+  PosOut po;
 };
 
 __global__ __launch_bounds__(256) void decode_pair_kernel(PairHead h, HeadOut ho, PairQuad q, QuadOut qo) {
@@ -301,9 +326,9 @@ __global__ __launch_bounds__(256) void decode_pair_kernel(PairHead h, HeadOut ho
   if (bid < hb) {
     const int half = (int)threadIdx.x >> 7, r = 2 * bid + half;
     head_decode_body(r < h.R ? r : h.R - 1, (int)threadIdx.x & 127, r < h.R, s_pick + half, h.nh, h.ns, h.ncls, h.y, h.ldy,
-                     h.base, h.means, h.hr_scale, ho);
+                     h.base, h.means, h.hr_scale, ho, h.po);
   } else {
-    quad_decode_body(bid - hb, red, q.R, q.y, q.ldy, q.base, qo, q.norm);
+    quad_decode_body(bid - hb, red, q.R, q.y, q.ldy, q.base, qo, q.norm, q.po);
   }
 }
 
@@ -314,9 +339,9 @@ __global__ __launch_bounds__(256) void decode_pair_bwd_kernel(PairHead h, HeadGr
   if (bid < hb) {
     const int half = (int)threadIdx.x >> 7, r = 2 * bid + half;
     head_decode_bwd_body(r < h.R ? r : h.R - 1, (int)threadIdx.x & 127, r < h.R, s_pick + half, h.K, h.nh, h.ns, h.ncls, h.y,
-                         h.ldy, h.means, h.hr_scale, hg, h.dy, h.lddy, h.dbase);
+                         h.ldy, h.means, h.hr_scale, hg, h.dy, h.lddy, h.dbase, h.acc != 0);
   } else {
-    quad_decode_bwd_body(bid - hb, red, q.R, q.K, q.y, q.ldy, q.norm, qg, q.dy, q.lddy, q.dbase);
+    quad_decode_bwd_body(bid - hb, red, q.R, q.K, q.y, q.ldy, q.norm, qg, q.dy, q.lddy, q.dbase, q.acc != 0);
   }
 }
 
@@ -401,11 +426,15 @@ extern "C" int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, co
 }
 
 // omnipq_head_decode + omnipq_quad_decode in one launch (arguments as there; head: Rh rows, quad: Rq rows).
-extern "C" int omnipq_decode_pair(int Rh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *baseh,
-                                  const float *means, float hr_scale, void *const *outs_h, int Rq, const void *yq,
-                                  int ldyq, const float *baseq, void *const *outs_q, float *norm, void *stream) {
+// pos (optional): f32 [B][Kh + Kq][3], receives the two heads' centres side by side per scene (the next decoder layer's
+// query positions, reference models/pq_transformer.py:245); Kh / Kq = proposals per scene, Rh / Kh == Rq / Kq scenes.
+extern "C" int omnipq_decode_pair(int Rh, int Kh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *baseh,
+                                  const float *means, float hr_scale, void *const *outs_h, int Rq, int Kq, const void *yq,
+                                  int ldyq, const float *baseq, void *const *outs_q, float *norm, float *pos,
+                                  void *stream) {
   using namespace omnipq;
-  if (Rh <= 0 || Rq <= 0 || nh < 1 || ns < 1 || ncls < 1) return OMNIPQ_EINVAL;
+  if (Rh <= 0 || Rq <= 0 || nh < 1 || ns < 1 || ncls < 1 || Kh < 1 || Kq < 1 || (Rh % Kh) || (Rq % Kq)) return OMNIPQ_EINVAL;
+  if (pos && Rh / Kh != Rq / Kq) return OMNIPQ_EINVAL;
   if (!yh || !baseh || !means || !outs_h || ldyh < 5 + 2 * nh + 4 * ns + ncls) return OMNIPQ_EINVAL;
   if (!yq || !baseq || !outs_q || !norm || ldyq < 10 || Rq > (1 << 24)) return OMNIPQ_EINVAL;
   for (int i = 0; i < 10; ++i)
@@ -415,20 +444,23 @@ extern "C" int omnipq_decode_pair(int Rh, int nh, int ns, int ncls, const void *
   HeadOut ho{(bf16_t *)outs_h[0], (float *)outs_h[1], (bf16_t *)outs_h[2], (bf16_t *)outs_h[3], (bf16_t *)outs_h[4],
              (bf16_t *)outs_h[5], (bf16_t *)outs_h[6], (float *)outs_h[7], (float *)outs_h[8], (bf16_t *)outs_h[9]};
   QuadOut qo{(bf16_t *)outs_q[0], (float *)outs_q[1], (bf16_t *)outs_q[2], (bf16_t *)outs_q[3]};
-  PairHead h{Rh, 1, nh, ns, ncls, ldyh, 0, (const bf16_t *)yh, baseh, means, hr_scale, nullptr, nullptr};
-  PairQuad q{Rq, 1, ldyq, 0, (const bf16_t *)yq, baseq, norm, nullptr, nullptr};
+  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, 0, (const bf16_t *)yh, baseh, means, hr_scale, nullptr, nullptr, 0,
+             PosOut{pos, Kh, Kh + Kq, 0}};
+  PairQuad q{Rq, Kq, ldyq, 0, (const bf16_t *)yq, baseq, norm, nullptr, nullptr, 0, PosOut{pos, Kq, Kh + Kq, Kh}};
   const int blocks = (Rh + 1) / 2 + (Rq + kQuadRows - 1) / kQuadRows;
   decode_pair_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(h, ho, q, qo);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
 
-// omnipq_head_decode_bwd + omnipq_quad_decode_bwd in one launch (arguments as there).
+// omnipq_head_decode_bwd + omnipq_quad_decode_bwd in one launch (arguments as there).  accumulate: bit 0 -> dbaseh +=,
+// bit 1 -> dbaseq += (the base positions of all decoder stages are the same tensor: its gradient is summed in place).
 extern "C" int omnipq_decode_pair_bwd(int Rh, int Kh, int nh, int ns, int ncls, const void *yh, int ldyh, const float *means,
                                       float hr_scale, const void *const *gptr_h, const int *gstrides_h, const int *gn2_h,
                                       const int *gbf_h, void *dyh, int lddyh, float *dbaseh, int Rq, int Kq, const void *yq,
                                       int ldyq, const float *norm, const void *const *gptr_q, const int *gstrides_q,
-                                      const int *gbf_q, void *dyq, int lddyq, float *dbaseq, void *stream) {
+                                      const int *gbf_q, void *dyq, int lddyq, float *dbaseq, int accumulate,
+                                      void *stream) {
   using namespace omnipq;
   if (Rh <= 0 || Rq <= 0 || Kh < 1 || Kq < 1 || nh < 1 || ns < 1 || ncls < 1 || (Rh % Kh) || (Rq % Kq)) return OMNIPQ_EINVAL;
   const int width = 5 + 2 * nh + 4 * ns + ncls;
@@ -444,8 +476,10 @@ extern "C" int omnipq_decode_pair_bwd(int Rh, int Kh, int nh, int ns, int ncls, 
   for (int i = 0; i < 4; ++i)
     qg.g[i] = HeadGrad{gptr_q[i], gstrides_q[4 * i], gstrides_q[4 * i + 1], gstrides_q[4 * i + 2], gstrides_q[4 * i + 3], 1,
                        gbf_q[i]};
-  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, lddyh, (const bf16_t *)yh, nullptr, means, hr_scale, (bf16_t *)dyh, dbaseh};
-  PairQuad q{Rq, Kq, ldyq, lddyq, (const bf16_t *)yq, nullptr, const_cast<float *>(norm), (bf16_t *)dyq, dbaseq};
+  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, lddyh, (const bf16_t *)yh, nullptr, means, hr_scale, (bf16_t *)dyh, dbaseh,
+             accumulate & 1, PosOut{nullptr, 1, 1, 0}};
+  PairQuad q{Rq, Kq, ldyq, lddyq, (const bf16_t *)yq, nullptr, const_cast<float *>(norm), (bf16_t *)dyq, dbaseq,
+             (accumulate >> 1) & 1, PosOut{nullptr, 1, 1, 0}};
   const int blocks = (Rh + 1) / 2 + (Rq + kQuadRows - 1) / kQuadRows;
   decode_pair_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(h, hg, q, qg);
   OMNIPQ_LAUNCH_CHECK();

@@ -235,13 +235,39 @@ class QuadDecode(torch.autograd.Function):
         return dy, dbase
 
 
+class XyzGradSink:
+    """Where the decodes of all stages leave the gradient of their common base positions (`cluster_xyz`: every stage of
+    the reference decodes against it, models/pq_transformer.py:230, :262): the kernels add into one buffer instead of
+    autograd adding seven tensors one launch at a time.  `SinkFlush` hands the sum to `cluster_xyz`."""
+
+    def __init__(self):
+        self.buf = None
+
+
+class SinkFlush(torch.autograd.Function):
+    """feat -> an alias of feat.  Everything that decodes against `xyz` through `sink` must be computed from the alias:
+    then this node's backward runs after all of theirs, and returns the sink's sum as the gradient of `xyz`."""
+
+    @staticmethod
+    def forward(ctx, feat, xyz, sink):
+        ctx.sink = sink
+        return feat.view_as(feat)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.sink.buf = ctx.sink.buf, None
+        return g, buf, None
+
+
 class DecodePair(torch.autograd.Function):
     """`HeadDecode` and `QuadDecode` of one decoder stage in ONE launch each way (csrc/head_ops.hip, decode_pair): the two
     heads are independent and each decode is a few microseconds of work, so the pair costs one launch instead of two.
-    Outputs: the ten of `HeadDecode`, then the four of `QuadDecode`, bit for bit."""
+    Outputs: the ten of `HeadDecode`, then the four of `QuadDecode`, bit for bit; with `want_pos` a fifteenth: both
+    centres side by side per scene, (B, K + Kq, 3) f32 without gradient -- the next layer's query positions.
+    sink (XyzGradSink | None): the gradient of `base_h` is added into the sink instead of being returned."""
 
     @staticmethod
-    def forward(ctx, yh, base_h, means, nh, ns, ncls, yq, base_q):
+    def forward(ctx, yh, base_h, means, nh, ns, ncls, yq, base_q, sink=None, want_pos=False):
         import ctypes
         B, K, _ = base_h.shape
         Bq, Kq, _ = base_q.shape
@@ -260,14 +286,20 @@ class DecodePair(torch.autograd.Function):
         outs_q = [torch.empty((Bq, Kq, 2), **bf), torch.empty((Bq, Kq, 3), **f32), torch.empty((Bq, Kq, 3), **bf),
                   torch.empty((Bq, Kq, 2), **bf)]
         norm = torch.empty(1, **f32)
+        pos = torch.empty((B, K + Kq, 3), **f32) if (want_pos and B == Bq) else None
         scale = float(np.float32(np.pi / nh))
-        sa_fused._call(sa_fused._lib.omnipq_decode_pair, yh, B * K, nh, ns, ncls, sa_fused._p(yh), yh.stride(0),
+        sa_fused._call(sa_fused._lib.omnipq_decode_pair, yh, B * K, K, nh, ns, ncls, sa_fused._p(yh), yh.stride(0),
                        sa_fused._p(bh), sa_fused._p(means), ctypes.c_float(scale),
-                       (ctypes.c_void_p * 10)(*[o.data_ptr() for o in outs_h]), Bq * Kq, sa_fused._p(yq), yq.stride(0),
-                       sa_fused._p(bq), (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs_q]), sa_fused._p(norm))
+                       (ctypes.c_void_p * 10)(*[o.data_ptr() for o in outs_h]), Bq * Kq, Kq, sa_fused._p(yq), yq.stride(0),
+                       sa_fused._p(bq), (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs_q]), sa_fused._p(norm),
+                       sa_fused._p(pos))
         ctx.save_for_backward(yh, means, yq, norm)
         ctx.geom = (B, K, nh, ns, ncls, scale, Bq, Kq)
-        return tuple(outs_h) + tuple(outs_q)
+        ctx.sink = sink
+        if pos is None:
+            return tuple(outs_h) + tuple(outs_q)
+        ctx.mark_non_differentiable(pos)
+        return tuple(outs_h) + tuple(outs_q) + (pos,)
 
     @staticmethod
     def backward(ctx, *gs):
@@ -277,46 +309,58 @@ class DecodePair(torch.autograd.Function):
         dev = yh.device
         n2 = [1, 1, 1, 1, 1, 1, 3, 3, 1, 1]
         ph, sh, fh, _keep_h = _grad_descriptors(gs[:10], n2)
-        pq, sq, fq, _keep_q = _grad_descriptors(gs[10:], [1, 1, 1, 1])
+        pq, sq, fq, _keep_q = _grad_descriptors(gs[10:14], [1, 1, 1, 1])
         dyh = torch.empty((B * K, yh.shape[1]), device=dev, dtype=torch.bfloat16)
         dyq = torch.empty((Bq * Kq, yq.shape[1]), device=dev, dtype=torch.bfloat16)
-        dbh = torch.empty((B, K, 3), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        sink, acc = ctx.sink, 0
+        if sink is not None and ctx.needs_input_grad[1]:
+            if sink.buf is None:
+                sink.buf = torch.empty((B, K, 3), device=dev, dtype=torch.float32)
+            else:
+                acc = 1
+            dbh = sink.buf
+        else:
+            sink = None
+            dbh = torch.empty((B, K, 3), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         dbq = torch.empty((Bq, Kq, 3), device=dev, dtype=torch.float32) if ctx.needs_input_grad[7] else None
         sa_fused._call(sa_fused._lib.omnipq_decode_pair_bwd, yh, B * K, K, nh, ns, ncls, sa_fused._p(yh), yh.stride(0),
                        sa_fused._p(means), ctypes.c_float(scale), (ctypes.c_void_p * 10)(*ph), (ctypes.c_int * 40)(*sh),
                        (ctypes.c_int * 10)(*n2), (ctypes.c_int * 10)(*fh), sa_fused._p(dyh), dyh.stride(0),
                        sa_fused._p(dbh), Bq * Kq, Kq, sa_fused._p(yq), yq.stride(0), sa_fused._p(norm),
                        (ctypes.c_void_p * 4)(*pq), (ctypes.c_int * 16)(*sq), (ctypes.c_int * 4)(*fq), sa_fused._p(dyq),
-                       dyq.stride(0), sa_fused._p(dbq))
-        return dyh, dbh, None, None, None, None, dyq, dbq
+                       dyq.stride(0), sa_fused._p(dbq), acc)
+        return dyh, (None if sink is not None else dbh), None, None, None, None, dyq, dbq, None, None
 
 
 _HEAD_KEYS = ("objectness_scores", "center", "heading_scores", "heading_residuals_normalized", "heading_residuals",
               "size_scores", "size_residuals_normalized", "size_residuals", "pred_size", "sem_cls_scores")
 _QUAD_KEYS = ("quad_scores", "quad_center", "normal_vector", "quad_size")
 _PAIR_DECODE = os.environ.get("OMNIPQ_DECODE_PAIR", "1") != "0"
+_XYZ_SINK = os.environ.get("OMNIPQ_XYZ_SINK", "1") != "0"
 
 
-def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, prefix, rows=None, rows_q=None):
+def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, prefix, rows=None, rows_q=None,
+                 sink=None, want_pos=False):
     """`head(net, ...)` then `quad_head(net_q, ...)` of one decoder stage (reference models/pq_transformer.py:230-233,
-    :262-267); with the fused decode both heads' tails share one launch each way.  Returns the two centres."""
+    :262-267); with the fused decode both heads' tails share one launch each way.
+    -> (object centres, quad centres, end_points, both centres as one (B, K + Kq, 3) tensor | None)."""
     if not (_PAIR_DECODE and _FUSED_DECODE and net.is_cuda):
         center, _, end_points = head(net, base_xyz=base_xyz, end_points=end_points, prefix=prefix, net_rows=rows)
         center_q, _, end_points = quad_head(net_q, base_xyz=base_xyz_q, end_points=end_points, prefix=prefix,
                                             net_rows=rows_q)
-        return center, center_q, end_points
+        return center, center_q, end_points, None
     yh = head_stack(head, net, head.heads(), rows, raw=True)
     yq = head_stack(quad_head, net_q, quad_head.heads(), rows_q, raw=True)
     ok = all(y.dtype == torch.bfloat16 and y.stride(1) == 1 for y in (yh, yq))
     if not ok:
         center, _, end_points = head.finish(yh, net, base_xyz, end_points, prefix)
         center_q, _, end_points = quad_head.finish(yq, net_q, base_xyz_q, end_points, prefix)
-        return center, center_q, end_points
+        return center, center_q, end_points, None
     outs = DecodePair.apply(yh, base_xyz, head._mean_sizes(net.device), head.num_heading_bin, head.num_size_cluster,
-                            head.num_class, yq, base_xyz_q)
+                            head.num_class, yq, base_xyz_q, sink, want_pos)
     for key, val in zip(_HEAD_KEYS + _QUAD_KEYS, outs):
         end_points[f'{prefix}{key}'] = val
-    return outs[1], outs[11], end_points
+    return outs[1], outs[11], end_points, (outs[14] if len(outs) > 14 else None)
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -555,8 +599,15 @@ class PQ_Transformer(nn.Module):
         end_points['aggregated_vote_xyz'] = cluster_xyz
         end_points['cluster_feature'] = cluster_feature
 
-        center, center_q, end_points = predict_pair(self.proposal, self.quad_proposal, cluster_feature, quad_feature,
-                                                    cluster_xyz, quad_xyz, end_points, 'proposal_')
+        sink = None
+        if _PAIR_DECODE and _FUSED_DECODE and _XYZ_SINK and cluster_xyz.is_cuda and torch.is_grad_enabled() and \
+                cluster_xyz.requires_grad and cluster_feature.requires_grad:
+            # every stage decodes against cluster_xyz: its seven gradients are summed by the decode kernels themselves
+            sink = XyzGradSink()
+            cluster_feature = SinkFlush.apply(cluster_feature, cluster_xyz, sink)
+        center, center_q, end_points, pos_joint = predict_pair(
+            self.proposal, self.quad_proposal, cluster_feature, quad_feature, cluster_xyz, quad_xyz, end_points,
+            'proposal_', sink=sink, want_pos=True)
         # the reference clones here (:236-237); nothing writes into these tensors afterwards, a detached alias suffices
         base_xyz = center.detach()
         base_xyz_q = center_q.detach()
@@ -576,7 +627,9 @@ class PQ_Transformer(nn.Module):
 
         for i in range(self.num_layer):
             prefix = 'last_' if (i == self.num_layer - 1) else f'{i}head_'
-            query_pos_joint = torch.cat([base_xyz, base_xyz_q], 1)
+            # (the pair decode of the stage before leaves both centres side by side already)
+            query_pos_joint = pos_joint if pos_joint is not None else torch.cat([base_xyz, base_xyz_q], 1)
+            pos_joint = None
             query_joint = self.decoder[i](query_joint, key, query_pos_joint, key_pos, key_sides[i])
             n_obj, n_quad = self.num_proposal, query_joint.shape[2] - self.num_proposal
             query, query_q = torch.split(query_joint, [n_obj, n_quad], dim=2)     # one cat in backward
@@ -614,9 +667,9 @@ class PQ_Transformer(nn.Module):
                     if k not in known and torch.is_tensor(v):
                         v.record_stream(cur)
             else:
-                base_xyz, base_xyz_q, end_points = predict_pair(
+                base_xyz, base_xyz_q, end_points, pos_joint = predict_pair(
                     self.prediction_heads[i], self.prediction_quad_heads[i], query, query_q, cluster_xyz, quad_xyz,
-                    end_points, prefix, rows_obj, rows_quad)
+                    end_points, prefix, rows_obj, rows_quad, sink=sink, want_pos=i + 1 < self.num_layer)
             base_xyz = base_xyz.detach()
             base_xyz_q = base_xyz_q.detach()
         return end_points

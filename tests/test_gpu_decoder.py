@@ -441,7 +441,8 @@ def test_quad_decode_kernel_equals_the_op_by_op_composition(monkeypatch):
 def test_decode_pair_is_the_two_decodes_bit_for_bit(monkeypatch):
     """`predict_pair` with the joint launch (omnipq_decode_pair / _bwd) against the two heads called one after the other
     (omnipq_head_decode, omnipq_quad_decode and their backward twins): same device functions, so every end_points
-    entry and every gradient is the same bits; odd row counts on both sides (the head half of the grid takes two rows
+    entry and every gradient the kernels produce is the same bits (the parameter gradients behind them agree to the order
+    of the stacks' f32 atomics); odd row counts on both sides (the head half of the grid takes two rows
     per block, the quad half 32)."""
     import pq_transformer as pq
     torch.manual_seed(5)
@@ -459,14 +460,27 @@ def test_decode_pair_is_the_two_decodes_bit_for_bit(monkeypatch):
         base_q = torch.randn(B, Kq, 3, device=dev()).requires_grad_(True)
 
         def run(pair, broadcast):
+            # two stages against the same base positions, as the model's stages all decode against cluster_xyz: with the
+            # pair kernels their gradients meet in the sink (summed by the second launch), without them in autograd
             monkeypatch.setattr(pq, "_PAIR_DECODE", pair)
             head.load_state_dict(state[0]), quad.load_state_dict(state[1])
             leaves = [net, net_q, base, base_q] + params
             for t in leaves:
                 t.grad = None
+            sink, feat = None, net
+            if pair:
+                sink = pq.XyzGradSink()
+                feat = pq.SinkFlush.apply(net, base, sink)
+            ep = {}
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                c, cq, ep = pq.predict_pair(head, quad, net, net_q, base, base_q, {}, "x_")
-            assert c is ep["x_center"] and cq is ep["x_quad_center"]
+                c, cq, ep, pos = pq.predict_pair(head, quad, feat, net_q, base, base_q, ep, "x_", sink=sink, want_pos=True)
+                assert c is ep["x_center"] and cq is ep["x_quad_center"]
+                if pair:
+                    assert pos is not None and not pos.requires_grad and torch.equal(pos, torch.cat([c, cq], 1))
+                else:
+                    assert pos is None
+                _, _, ep, pos = pq.predict_pair(head, quad, feat, net_q, base, base_q, ep, "y_", sink=sink)
+                assert pos is None
             keys = sorted(ep)
             gen = torch.Generator().manual_seed(9)
             loss = 0.0
@@ -477,17 +491,21 @@ def test_decode_pair_is_the_two_decodes_bit_for_bit(monkeypatch):
                 elif k != "x_size_residuals":            # one output without a gradient: the null-pointer branch
                     loss = loss + (v.float() * torch.randn(v.shape, generator=gen).to(dev())).sum()
             loss.backward()
+            assert sink is None or sink.buf is None      # handed over and released
             return {k: ep[k].detach().clone() for k in keys}, [t.grad.clone() for t in leaves]
 
         for broadcast in (False, True):
             e1, g1 = run(True, broadcast)
             e0, g0 = run(False, broadcast)
-            assert list(e1) == list(e0) and len(e1) == 14
+            assert list(e1) == list(e0) and len(e1) == 28
             for k in e0:
                 assert e1[k].dtype == e0[k].dtype and e1[k].shape == e0[k].shape, k
                 assert torch.equal(e1[k], e0[k]), k
             for i, (u, v) in enumerate(zip(g1, g0)):
-                assert torch.equal(u, v), i
+                if i < 4:
+                    assert torch.equal(u, v), i          # net, net_q, base, base_q: the decode kernels' own results
+                else:
+                    assert rel_l2(u, v) < 1e-5, (i, rel_l2(u, v))    # parameters: the stacks' column sums are f32 atomics
 
 
 def test_the_model_takes_the_fused_vote_tail_on_the_benchmarked_path():

@@ -31,7 +31,11 @@ class M(TorchDispatchMode):
             if torch.is_tensor(out): n=out.numel()*out.element_size()
             agg[(base,fr)][0]+=1; agg[(base,fr)][1]+=n
             if fr=="?" and os.environ.get("TRACE_SHAPES"):
-                shapes[(base,tuple(out.shape),str(out.dtype).replace("torch.",""))]+=1
+                node=None
+                try: node=torch._C._current_autograd_node()
+                except Exception: pass
+                # gradient accumulation runs between nodes: the node named is the one whose backward produced the addend
+                shapes[(base,tuple(out.shape),str(out.dtype).replace("torch.","")+" after "+(node.name() if node is not None else "-"))]+=1
         return out
 with M():
     step(0)
@@ -46,4 +50,4 @@ for (b,fr),(c,n) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:70]:
 if shapes:
     print("ops issued from autograd's backward (no repo frame), by shape:")
     for (b,sh,dt),c in shapes.most_common(40):
-        print(f"{c:5d}x  {b:10s} {dt:9s} {sh}")
+        print(f"{c:5d}x  {b:10s} {dt} {sh}")
