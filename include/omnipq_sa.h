@@ -37,6 +37,17 @@ int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float i
                           const int *order, const void *dX, float *dfeat_pm, float *dxyz, float *dnew_xyz,
                           void *stream);
 
+/* Pair launches.  omnipq_pair_hold(): the NEXT GEMM of the calling thread that takes the small-tile path (any
+ * omnipq_gemm_nt_bf16* entry point on a few thousand rows) is held back instead of launched; the GEMM after it -- if it is
+ * the same kernel variant on the same stream -- goes out together with it as ONE grid.  Anything else sends the held one out
+ * on its own first, and omnipq_pair_flush() does so explicitly (call it after the second GEMM in any case; it returns the
+ * number of pair launches made so far).  The two problems must be independent and nothing else may be enqueued on the
+ * stream between hold and flush.  Used for the object / quad head stacks of a decoder stage (reference
+ * models/pq_transformer.py:62-121: same shapes, different weights), each of whose GEMMs alone covers less than one
+ * workgroup per CU. */
+void omnipq_pair_hold(void);
+long long omnipq_pair_flush(void);
+
 /* C[M][N] (bf16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */
 int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                         void *stream);

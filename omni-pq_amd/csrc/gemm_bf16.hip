@@ -183,18 +183,13 @@ __device__ __forceinline__ uint4 dy_chunk(const uint4 &dx, const uint4 &y, const
 // behind ONE barrier.
 constexpr int kResMaxSteps = 10;
 
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0, bool KRES = false,
-          bool DYG = false>
-__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
-                                                        const bf16_t *__restrict__ B,
-                                                        void *__restrict__ Cout,
-                                                        const float *__restrict__ bias,
-                                                        void *__restrict__ stats_out = nullptr,
-                                                        BnBwdEpilogue bn = BnBwdEpilogue(),
-                                                        AffineIn aff = AffineIn(),
-                                                        PoolOut pool = PoolOut(),
-                                                        XyzGen xg = XyzGen(),
-                                                        DyGen dyg = DyGen()) {
+// The workgroup program of every NT GEMM variant; `bid` = this workgroup's index within ITS problem (blockIdx.x of a
+// plain launch; the pair launch below runs two problems in one grid).
+template <bool OUT_F32, int STATS, bool AFF, int T, bool PF2, int XG, bool KRES, bool DYG>
+__device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
+                                             void *__restrict__ Cout, const float *__restrict__ bias,
+                                             void *__restrict__ stats_out, const BnBwdEpilogue &bn, const AffineIn &aff,
+                                             const PoolOut &pool, const XyzGen &xg, const DyGen &dyg, const int bid) {
   static_assert(T == 128 || T == 64, "tile edge");
   static_assert(!DYG || (!AFF && !PF2 && XG == 0 && !OUT_F32), "DYG variants");
   static_assert(XG == 0 || (XG == 1 && AFF && T == 128 && !PF2) || (XG == 2 && STATS == 4 && T == 128), "XG variants");
@@ -237,7 +232,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
   __shared__ __attribute__((aligned(16))) f32x4 s_dy[DYG ? kDyMaxK : 1];              // (a, b, beta', gamma') per A channel
 
   // XCD-aware tile order: id % 8 picks the XCD, the N-tiles of one M-tile stay on it
-  const int id = (int)blockIdx.x;
+  const int id = bid;
   const int xcd = id & 7, local = id >> 3;
   const int mt = xcd + 8 * (local / g.n_tiles);
   const int nt = local % g.n_tiles;
@@ -303,7 +298,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
   if (DYG) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) gy[i] = dyg.Y + (ga[i] - A);
-    const bool first = blockIdx.x == 0 && blockIdx.z == 0;
+    const bool first = bid == 0 && blockIdx.z == 0;
     for (int c = tid; c < g.K; c += 256) {
       const double s0 = dyg.sums[c], s1 = dyg.sums[g.K + c];
       const float m1 = (float)(s0 * dyg.inv_count), m2 = (float)(s1 * dyg.inv_count);
@@ -317,7 +312,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
     __syncthreads();
   }
   if (AFF) {
-    const bool first = blockIdx.x == 0 && blockIdx.z == 0;
+    const bool first = bid == 0 && blockIdx.z == 0;
     for (int c = tid; c < g.K; c += 256) {
       float av, bv;
       if (aff.sums) {
@@ -825,6 +820,45 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
   NT_STAMP(7);
 }
 
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0, bool KRES = false,
+          bool DYG = false>
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
+                                                        const bf16_t *__restrict__ B,
+                                                        void *__restrict__ Cout,
+                                                        const float *__restrict__ bias,
+                                                        void *__restrict__ stats_out = nullptr,
+                                                        BnBwdEpilogue bn = BnBwdEpilogue(),
+                                                        AffineIn aff = AffineIn(),
+                                                        PoolOut pool = PoolOut(),
+                                                        XyzGen xg = XyzGen(),
+                                                        DyGen dyg = DyGen()) {
+  gemm_nt_body<OUT_F32, STATS, AFF, T, PF2, XG, KRES, DYG>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, dyg,
+                                                          (int)blockIdx.x);
+}
+
+// Two INDEPENDENT small problems of the same variant in one grid (64 x 64 tiles, K-resident): the per-point stacks of
+// the object and the quad head of a decoder stage have the same shapes and different weights, and each of their GEMMs
+// alone covers less than one workgroup per CU -- launched as a pair they cost one launch latency instead of two.
+struct SmallProblem {
+  GemmArgs g;
+  const bf16_t *A, *B;
+  void *C;
+  const float *bias;
+  void *stats;
+  BnBwdEpilogue bn;
+  AffineIn aff;
+};
+template <int STATS, bool AFF>
+__global__ __launch_bounds__(256, 2) void gemm_nt_pair_kernel(SmallProblem p0, SmallProblem p1, int n0) {
+  const int id = (int)blockIdx.x;
+  if (id < n0)
+    gemm_nt_body<false, STATS, AFF, 64, false, 0, true, false>(p0.g, p0.A, p0.B, p0.C, p0.bias, p0.stats, p0.bn, p0.aff,
+                                                               PoolOut(), XyzGen(), DyGen(), id);
+  else
+    gemm_nt_body<false, STATS, AFF, 64, false, 0, true, false>(p1.g, p1.A, p1.B, p1.C, p1.bias, p1.stats, p1.bn, p1.aff,
+                                                               PoolOut(), XyzGen(), DyGen(), id - n0);
+}
+
 #ifdef OMNIPQ_NT_TRACE
 }  // namespace omnipq
 extern "C" int omnipq_debug_read_nt_trace(long long *host_out) {
@@ -951,23 +985,89 @@ static bool gemm_nt_kres(int K) {
   return on && K <= omnipq::kResMaxSteps * omnipq::GBK;
 }
 
+// ---- pair launches ------------------------------------------------------------------------------------------------------
+// omnipq_pair_hold(): the NEXT small-tile GEMM this thread issues is held back instead of launched; the one after it, if it
+// is the same variant on the same stream, goes out with it as one grid (gemm_nt_pair_kernel); anything else (another
+// variant, omnipq_pair_flush()) sends the held one out on its own first.  The caller guarantees the two are independent
+// and issues nothing else in between.
+struct HeldSmall {
+  bool armed = false, full = false;
+  int key = 0, lds = 0;
+  omnipq::SmallProblem p;
+  hipStream_t stream = nullptr;
+  void (*single)(const HeldSmall &) = nullptr;
+};
+static thread_local HeldSmall t_held;
+static long long t_pairs_launched = 0;
+
+template <int STATS, bool AFF>
+static void launch_small_single(const omnipq::SmallProblem &p, int lds, hipStream_t stream) {
+  using namespace omnipq;
+  auto kern = gemm_nt_kernel<false, STATS, AFF, 64, false, 0, true>;
+  static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)prepared;
+  kern<<<gemm_nt_grid(p.g), 256, lds, stream>>>(p.g, p.A, p.B, p.C, p.bias, p.stats, p.bn, p.aff, PoolOut(), XyzGen(),
+                                                DyGen());
+}
+
+template <int STATS, bool AFF>
+static void held_single(const HeldSmall &h) { launch_small_single<STATS, AFF>(h.p, h.lds, h.stream); }
+
 template <int STATS, bool AFF>
 static void launch_small(const omnipq::GemmArgs &g, const void *A, const void *B, void *C, const float *bias, void *stats,
                          const omnipq::BnBwdEpilogue &bn, const omnipq::AffineIn &aff, void *stream) {
   using namespace omnipq;
+  HeldSmall &h = t_held;
   if (gemm_nt_kres(g.K)) {
-    auto kern = gemm_nt_kernel<false, STATS, AFF, 64, false, 0, true>;
-    static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)prepared;
     int lds = 2 * 64 * (g.K + 8) * 2;
     if (lds < 20480) lds = 20480;                // the C tile / statistics fold alias the operand tiles
-    kern<<<gemm_nt_grid(g), 256, lds, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn,
-                                                             aff, PoolOut(), XyzGen(), DyGen());
+    const SmallProblem p{g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff};
+    const int key = STATS * 2 + (AFF ? 1 : 0);
+    if (h.armed && !h.full) {
+      h.full = true;
+      h.key = key;
+      h.lds = lds;
+      h.p = p;
+      h.stream = (hipStream_t)stream;
+      h.single = &held_single<STATS, AFF>;
+      return;
+    }
+    if (h.full) {
+      h.full = h.armed = false;
+      if (h.key == key && h.stream == (hipStream_t)stream) {
+        auto kern = gemm_nt_pair_kernel<STATS, AFF>;
+        static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)prepared;
+        const int n0 = (int)gemm_nt_grid(h.p.g).x, n1 = (int)gemm_nt_grid(g).x;
+        kern<<<dim3(n0 + n1), 256, lds > h.lds ? lds : h.lds, (hipStream_t)stream>>>(h.p, p, n0);
+        ++t_pairs_launched;
+        return;
+      }
+      h.single(h);
+    }
+    launch_small_single<STATS, AFF>(p, lds, (hipStream_t)stream);
   } else {
+    if (h.full) {
+      h.full = h.armed = false;
+      h.single(h);
+    }
     gemm_nt_kernel<false, STATS, AFF, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
         g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff, PoolOut(), XyzGen());
   }
+}
+
+extern "C" void omnipq_pair_hold(void) {
+  if (!t_held.full) t_held.armed = true;
+}
+
+// Sends out a held launch that found no partner and disarms; returns the number of pair launches made so far (diagnostic).
+extern "C" long long omnipq_pair_flush(void) {
+  HeldSmall &h = t_held;
+  if (h.full) h.single(h);
+  h.full = h.armed = false;
+  return t_pairs_launched;
 }
 
 // C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.

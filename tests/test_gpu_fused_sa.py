@@ -94,6 +94,58 @@ def test_gemm_nt_stats_epilogue(M, N, K, bias):
     assert float(((sums - want).abs() / (want.abs() + 1.0)).max()) < 1e-5
 
 
+@pytest.mark.parametrize("M0,M1,N0,N1,K", [(2048, 2048, 288, 288, 288), (2048, 2048, 128, 32, 288), (300, 77, 96, 96, 64)])
+def test_pair_launch_equals_two_launches(M0, M1, N0, N1, K):
+    """omnipq_pair_hold / omnipq_pair_flush: two independent small GEMMs (plain, and with the statistics epilogue) go out
+    as one grid and give the same bits as one after the other; a held GEMM without a partner goes out on flush, and a
+    partner of another variant does not pair."""
+    lib = capi.lib()
+    lib.omnipq_pair_flush.restype = ctypes.c_longlong
+    lib.omnipq_pair_hold.restype = None
+    gen = torch.Generator().manual_seed(M0 + N1 + K)
+
+    def problem(M, N):
+        A = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
+        B = torch.randn((N, K), generator=gen).to(torch.bfloat16).to(dev())
+        bias = torch.randn(N, generator=gen).to(dev())
+        return A, B, bias, M, N
+
+    def run(pr, stats):
+        A, B, bias, M, N = pr
+        C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+        sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
+        if stats:
+            capi.ok("omnipq_gemm_nt_bf16_stats", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N, capi.P(bias),
+                    capi.P(sums), ctypes.c_void_p(0))
+        else:
+            capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N, capi.P(bias))
+        return C, sums
+
+    p0, p1 = problem(M0, N0), problem(M1, N1)
+    for stats in (False, True):
+        want0, want1 = run(p0, stats), run(p1, stats)
+        before = int(lib.omnipq_pair_flush())
+        lib.omnipq_pair_hold()
+        got0 = run(p0, stats)
+        got1 = run(p1, stats)
+        after = int(lib.omnipq_pair_flush())
+        assert after == before + 1                           # they did go out together
+        for (c, s_), (c_want, s_want) in ((got0, want0), (got1, want1)):
+            assert torch.equal(c, c_want)
+            assert float(((s_ - s_want).abs() / (s_want.abs() + 1.0)).max()) < 1e-12 if stats else True
+    # no partner: flush launches it alone
+    lib.omnipq_pair_hold()
+    alone = run(p0, False)
+    n = int(lib.omnipq_pair_flush())
+    assert torch.equal(alone[0], run(p0, False)[0])
+    # different variants do not pair, both still run
+    lib.omnipq_pair_hold()
+    a = run(p0, False)
+    b = run(p1, True)
+    assert int(lib.omnipq_pair_flush()) == n
+    assert torch.equal(a[0], run(p0, False)[0]) and torch.equal(b[0], run(p1, True)[0])
+
+
 @pytest.mark.parametrize("M,N,K", [(100, 128, 32), (2048, 288, 288), (8320, 128, 256), (40000, 64, 128)])
 def test_gemm_nt_bn_backward_epilogue(M, N, K):
     """Data-gradient GEMM with the BatchNorm-backward sums folded in == GEMM followed by omnipq_bn_bwd_stats."""
