@@ -46,6 +46,7 @@ int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float i
  * models/pq_transformer.py:62-121: same shapes, different weights), each of whose GEMMs alone covers less than one
  * workgroup per CU. */
 void omnipq_pair_hold(void);
+int omnipq_pair_held(void);       /* 1 while a launch is being held back */
 long long omnipq_pair_flush(void);
 
 /* C[M][N] (bf16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */

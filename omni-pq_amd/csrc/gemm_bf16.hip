@@ -1062,6 +1062,8 @@ extern "C" void omnipq_pair_hold(void) {
   if (!t_held.full) t_held.armed = true;
 }
 
+extern "C" int omnipq_pair_held(void) { return t_held.full ? 1 : 0; }
+
 // Sends out a held launch that found no partner and disarms; returns the number of pair launches made so far (diagnostic).
 extern "C" long long omnipq_pair_flush(void) {
   HeldSmall &h = t_held;

@@ -98,6 +98,47 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
     already in the layout the reference reaches with `.transpose(2, 1)`.
     net_rows: the same features as (B, K, C) data in another dtype (the decoder's bf16 rows), used instead of
     `net` when given -- the kernels want bf16 rows anyway, this saves the cast forth and back."""
+    x, stack, w = _head_problem(self, net, heads, net_rows)
+    B, K = net.shape[0], net.shape[2]
+    if rows_mlp.usable(x, stack, self.training):
+        # hand-written MFMA / BN kernels; with `raw` the consumer takes the kernels' zero-padded rows as they are
+        _head_bias(self, stack, heads, w, raw, net.is_cuda)
+        y = rows_mlp.run(x, stack, self.training, padded=raw)
+    else:
+        x = F.relu(self.bn1(lin(x, self.conv1)))
+        x = F.relu(self.bn2(lin(x, self.conv2)))
+        y = F.linear(x, w, torch.cat([h.bias for h in heads], 0))
+    if raw:
+        return y                                         # (B*K, >= sum of head widths) rows
+    return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
+
+
+def _head_bias(self, stack, heads, w, raw, on_gpu):
+    """The output layer's joint bias (zero-padded to the kernels' width with `raw`)."""
+    width = w.shape[0]
+    pad_to = (width + 31) // 32 * 32 if raw else None
+    if _JOINT_HEADS and on_gpu:
+        stack[2].bias = sa_fused.joint_params(self, "b_raw" if raw else "b", [h.bias for h in heads], pad_to=pad_to)
+    else:
+        stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=pad_to)
+
+
+def head_stack_pair(head, quad_head, net, net_q, rows_a=None, rows_b=None):
+    """`head_stack(..., raw=True)` of the object and the quad head of one decoder stage; on the row kernels the two stacks
+    run as one node whose GEMMs go out pairwise (rows_mlp.run_pair: each alone covers less than a workgroup per CU)."""
+    pa = _head_problem(head, net, head.heads(), rows_a)
+    pb = _head_problem(quad_head, net_q, quad_head.heads(), rows_b)
+    if _PAIR_STACKS and head.training == quad_head.training and \
+            rows_mlp.usable(pa[0], pa[1], head.training) and rows_mlp.usable(pb[0], pb[1], quad_head.training):
+        _head_bias(head, pa[1], head.heads(), pa[2], True, net.is_cuda)
+        _head_bias(quad_head, pb[1], quad_head.heads(), pb[2], True, net_q.is_cuda)
+        return rows_mlp.run_pair(pa[0], pa[1], pb[0], pb[1], head.training, padded=True)
+    return (head_stack(head, net, head.heads(), rows_a, raw=True),
+            head_stack(quad_head, net_q, quad_head.heads(), rows_b, raw=True))
+
+
+def _head_problem(self, net, heads, net_rows=None):
+    """-> (input rows, the stack's three layers (the output layer without its bias yet), the joint output weight)"""
     B, K = net.shape[0], net.shape[2]
     x = rows(net) if net_rows is None else net_rows.reshape(B * K, -1)
     # the output heads' weights / biases live as row ranges of one joint matrix / vector (re-seated once, then only pointer
@@ -110,22 +151,7 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
         w = sa_fused.cat_params([h.weight.squeeze(-1) for h in heads])
     stack = [rows_mlp.Layer(self.conv1.weight, self.conv1.bias, self.bn1),
              rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2), rows_mlp.Layer(w, None)]
-    if rows_mlp.usable(x, stack, self.training):
-        # hand-written MFMA / BN kernels; with `raw` the consumer takes the kernels' zero-padded rows as they are
-        width = w.shape[0]
-        pad_to = (width + 31) // 32 * 32 if raw else None
-        if _JOINT_HEADS and net.is_cuda:
-            stack[2].bias = sa_fused.joint_params(self, "b_raw" if raw else "b", [h.bias for h in heads], pad_to=pad_to)
-        else:
-            stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=pad_to)
-        y = rows_mlp.run(x, stack, self.training, padded=raw)
-    else:
-        x = F.relu(self.bn1(lin(x, self.conv1)))
-        x = F.relu(self.bn2(lin(x, self.conv2)))
-        y = F.linear(x, w, torch.cat([h.bias for h in heads], 0))
-    if raw:
-        return y                                         # (B*K, >= sum of head widths) rows
-    return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
+    return x, stack, w
 
 
 def _grad_descriptors(gs, n2):
@@ -337,6 +363,7 @@ _HEAD_KEYS = ("objectness_scores", "center", "heading_scores", "heading_residual
 _QUAD_KEYS = ("quad_scores", "quad_center", "normal_vector", "quad_size")
 _PAIR_DECODE = os.environ.get("OMNIPQ_DECODE_PAIR", "1") != "0"
 _XYZ_SINK = os.environ.get("OMNIPQ_XYZ_SINK", "1") != "0"
+_PAIR_STACKS = os.environ.get("OMNIPQ_PAIR_STACKS", "1") != "0"
 
 
 def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, prefix, rows=None, rows_q=None,
@@ -349,8 +376,7 @@ def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, 
         center_q, _, end_points = quad_head(net_q, base_xyz=base_xyz_q, end_points=end_points, prefix=prefix,
                                             net_rows=rows_q)
         return center, center_q, end_points, None
-    yh = head_stack(head, net, head.heads(), rows, raw=True)
-    yq = head_stack(quad_head, net_q, quad_head.heads(), rows_q, raw=True)
+    yh, yq = head_stack_pair(head, quad_head, net, net_q, rows, rows_q)
     ok = all(y.dtype == torch.bfloat16 and y.stride(1) == 1 for y in (yh, yq))
     if not ok:
         center, _, end_points = head.finish(yh, net, base_xyz, end_points, prefix)

@@ -70,22 +70,8 @@ def run(x_rows, layers, training, padded=False):
     """x_rows (N, C_in) -> (N, C_out of the last layer), bf16.  padded: return the kernels' own (N, C_out rounded
     up to 32) buffer instead of the slice -- the extra columns are exact zeros (zero weight rows and bias), and a
     consumer that hands back a gradient of that shape saves the stack a zero-fill and a copy."""
-    spec, params = [], []
-    for lay in layers:
-        bn = lay.bn
-        if bn is None and lay.relu_dropout is not None:
-            p = float(lay.relu_dropout) if training else 0.0
-            spec.append(("relu_dropout", p, dropout_state.seed(x_rows.device) if p > 0 else None,
-                         dropout_state.next_salt() if p > 0 else 0))
-        else:
-            spec.append(None if bn is None else
-                        (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
-        params += [lay.weight, lay.bias, None if bn is None else bn.weight, None if bn is None else bn.bias]
-    # SyncBatchNorm semantics (statistics over all ranks) only where the layers ARE SyncBatchNorm; a stack of plain
-    # BatchNorm layers keeps per-rank statistics under DDP, as torch's does
-    bns = [lay.bn for lay in layers if lay.bn is not None]
-    sync = bool(bns) and all(bool(sa_fused.bn_syncs(bn)) for bn in bns)
-    return RowsMLP.apply(x_rows, (spec, bool(padded), sync), bool(training), *params)
+    spec, params = _spec_of(x_rows, layers, training, padded)
+    return RowsMLP.apply(x_rows, spec, bool(training), *params)
 
 
 def _is_bn(entry):
@@ -96,9 +82,52 @@ class _L:
     __slots__ = ("act", "K", "C", "Cp", "Wp", "Wt", "wk", "a", "b", "mean", "invstd", "Y", "X", "has_bn", "has_bias", "fin")
 
 
-class RowsMLP(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, spec, training, *params):
+_lib.omnipq_pair_hold.restype = None
+_lib.omnipq_pair_flush.restype = ctypes.c_longlong
+_lib.omnipq_pair_held.restype = ctypes.c_int
+
+
+def _hold(lead):
+    """Before a GEMM of the LEADING stack of a pair: the launch is held back for its partner's (csrc: omnipq_pair_hold)."""
+    if lead:
+        _lib.omnipq_pair_hold()
+
+
+def _drain(gen):
+    """Run one stack's program on its own."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as done:
+        return done.value
+
+
+def _lockstep(lead, follow):
+    """Run two independent stacks' programs GEMM by GEMM: each program stops right after issuing a GEMM; the leading one's
+    is held back and goes out in one grid with the follower's next GEMM of the same kind (a held launch that finds no
+    partner is sent out before anything else can be enqueued behind it)."""
+    out = [None, None]
+    alive = [True, True]
+    gens = (lead, follow)
+    while alive[0] or alive[1]:
+        for i in (0, 1):
+            if alive[i]:
+                try:
+                    next(gens[i])
+                except StopIteration as done:
+                    out[i], alive[i] = done.value, False
+            if i == 0 and not _lib.omnipq_pair_held():
+                _lib.omnipq_pair_flush()              # nothing was held: disarm before the follower runs
+        _lib.omnipq_pair_flush()
+    return out
+
+
+class _Ctx:
+    """What a stack's program keeps between forward and backward (one per stack of a pair; a lone stack uses the autograd
+    context itself)."""
+
+
+def _forward_program(ctx, lead, x, spec, training, params):
         spec, padded, sync = spec
         dev = x.device
         N, cin = x.shape
@@ -144,10 +173,12 @@ class RowsMLP(torch.autograd.Function):
             below = layers[-1] if (X is None) else None      # the layer below kept only (Y, a, b): see sa_fused
             if lay.has_bn and training:
                 sums = zeros_f64(2, cout, dev)
+                _hold(lead)
                 if below is not None:
                     Y = sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, sums=sums)
                 else:
                     Y = _gemm_nt_stats(X, lay.Wp, N, lay.Cp, K, sums)
+                yield
             else:
                 Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
                 bp = None
@@ -156,6 +187,7 @@ class RowsMLP(torch.autograd.Function):
                     if bp.shape[0] < lay.Cp:
                         bp = torch.nn.functional.pad(bp, (0, lay.Cp - bp.shape[0]))
                 act_fused = False
+                _hold(lead)
                 if below is not None:
                     sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, bias=bp, out=Y)
                 elif lay.act is not None and _FUSE_ACT and K < 1024 and N * lay.Cp < (1 << 32):
@@ -166,6 +198,7 @@ class RowsMLP(torch.autograd.Function):
                     act_fused = True
                 else:
                     sa_fused.gemm_nt_into(X, lay.Wp, Y, N, lay.Cp, K, bias=bp)
+                yield
             lay.Y = Y
             if lay.has_bn:
                 rm, rv, nbt, momentum, eps = spec[l]
@@ -218,8 +251,8 @@ class RowsMLP(torch.autograd.Function):
         ctx.padded = padded
         return X if (padded or last.Cp == last.C) else X[:, :last.C]
 
-    @staticmethod
-    def backward(ctx, g):
+
+def _backward_program(ctx, lead, g, needs_input_grad):
         if not ctx.training and any(l.has_bn for l in ctx.layers):
             raise RuntimeError("RowsMLP: backward through eval-mode BatchNorm is not supported")
         N, cin, world = ctx.geom
@@ -253,7 +286,7 @@ class RowsMLP(torch.autograd.Function):
                     sums = zeros_f64(3, lay.C, dev)
                     _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
                           _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
-                follows = l > 0 or ctx.needs_input_grad[0]
+                follows = l > 0 or needs_input_grad[0]
                 if sa_fused.DYGEN and follows and lay.Cp == lay.C and lay.C <= sa_fused.DYGEN_MAX_K and lay.Y is not None:
                     # BatchNorm backward generated inside the data-gradient GEMM (no apply pass): dY comes back for the
                     # weight gradient below
@@ -278,8 +311,8 @@ class RowsMLP(torch.autograd.Function):
                 dcur, owned = dst, True
             want_bias = not lay.has_bn and lay.has_bias
             wt, bt = ctx.targets[l] if (dfr is not None and ctx.targets is not None) else (None, None)
-            if wt is not None and ctx.needs_input_grad[3 + 4 * l] and (
-                    not want_bias or (sa_fused.bias_target_ok(bt, lay.C, lay.Cp) and ctx.needs_input_grad[4 + 4 * l])):
+            if wt is not None and needs_input_grad[3 + 4 * l] and (
+                    not want_bias or (sa_fused.bias_target_ok(bt, lay.C, lay.Cp) and needs_input_grad[4 + 4 * l])):
                 # collected; computed with all the others when the deferred_wgrads block ends
                 dfr.add(dcur, Xin, lay.Cp, lay.K, N, wt, (lay.C, lay.wk), bt if want_bias else None, below)
             else:
@@ -298,10 +331,13 @@ class RowsMLP(torch.autograd.Function):
                     dx = dprev[:, :cin].to(ctx.in_dtype)
             elif l > 0 and layers[l - 1].has_bn:
                 sums = zeros_f64(3, lay.K, dev)
+                _hold(lead)
                 dprev = _gemm_nt_bnbwd(dcur, lay.Wt, N, lay.K, lay.Cp, layers[l - 1], sums)
+                yield
                 dcur, owned = dprev, True
-            elif l > 0 or ctx.needs_input_grad[0]:
+            elif l > 0 or needs_input_grad[0]:
                 dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
+                _hold(lead)
                 if l > 0 and layers[l - 1].act is not None and _FUSE_ACT and lay.Cp < 1024:
                     # the layer below is dropout(relu(.)): its backward mask in this GEMM's epilogue
                     _call(_lib.omnipq_gemm_nt_bf16_mask, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
@@ -309,6 +345,7 @@ class RowsMLP(torch.autograd.Function):
                     act_masked = l - 1
                 else:
                     sa_fused.gemm_nt_into(dcur, lay.Wt, dprev, N, lay.K, lay.Cp)
+                yield
                 if l > 0:
                     dcur, owned = dprev, True
                 else:
@@ -320,3 +357,69 @@ class RowsMLP(torch.autograd.Function):
                 out.append(grads[4 * l + j])
         ctx.layers = None
         return tuple(out)
+
+
+class RowsMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec, training, *params):
+        return _drain(_forward_program(ctx, False, x, spec, training, params))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _drain(_backward_program(ctx, False, g, ctx.needs_input_grad))
+
+
+class RowsMLPPair(torch.autograd.Function):
+    """Two independent stacks as one node: (xa, spec_a, xb, spec_b, training, n_a, *params_a, *params_b) -> (ya, yb).  Same
+    programs as `RowsMLP`, run in lockstep so that the stacks' GEMMs of the same kind share a launch (`_lockstep`)."""
+
+    @staticmethod
+    def forward(ctx, xa, spec_a, xb, spec_b, training, n_a, *params):
+        ctx.a, ctx.b, ctx.n_a = _Ctx(), _Ctx(), n_a
+        ctx.set_materialize_grads(False)            # a stack unused downstream gets None, not a zero gradient to push through
+        ya, yb = _lockstep(_forward_program(ctx.a, True, xa, spec_a, training, params[:n_a]),
+                           _forward_program(ctx.b, False, xb, spec_b, training, params[n_a:]))
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        nig, n_a = ctx.needs_input_grad, ctx.n_a
+        nig_a = (nig[0], False, False) + tuple(nig[6:6 + n_a])
+        nig_b = (nig[2], False, False) + tuple(nig[6 + n_a:])
+        if ga is None and gb is None:
+            return (None,) * len(nig)
+        if ga is None or gb is None:                 # one stack unused downstream: nothing to pair
+            outs = []
+            for c, g, n in ((ctx.a, ga, nig_a), (ctx.b, gb, nig_b)):
+                outs.append(_drain(_backward_program(c, False, g, n)) if g is not None else (None,) * len(n))
+            oa, ob = outs
+        else:
+            oa, ob = _lockstep(_backward_program(ctx.a, True, ga, nig_a), _backward_program(ctx.b, False, gb, nig_b))
+        return (oa[0], None, ob[0], None, None, None) + tuple(oa[3:]) + tuple(ob[3:])
+
+
+def _spec_of(x_rows, layers, training, padded):
+    spec, params = [], []
+    for lay in layers:
+        bn = lay.bn
+        if bn is None and lay.relu_dropout is not None:
+            p = float(lay.relu_dropout) if training else 0.0
+            spec.append(("relu_dropout", p, dropout_state.seed(x_rows.device) if p > 0 else None,
+                         dropout_state.next_salt() if p > 0 else 0))
+        else:
+            spec.append(None if bn is None else
+                        (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps)))
+        params += [lay.weight, lay.bias, None if bn is None else bn.weight, None if bn is None else bn.bias]
+    # SyncBatchNorm semantics (statistics over all ranks) only where the layers ARE SyncBatchNorm; a stack of plain
+    # BatchNorm layers keeps per-rank statistics under DDP, as torch's does
+    bns = [lay.bn for lay in layers if lay.bn is not None]
+    sync = bool(bns) and all(bool(sa_fused.bn_syncs(bn)) for bn in bns)
+    return (spec, bool(padded), sync), params
+
+
+def run_pair(xa, layers_a, xb, layers_b, training, padded=False):
+    """`run` on two independent stacks (e.g. the object and the quad head of a decoder stage: same shapes, different
+    weights) whose GEMMs go out pairwise in one launch each.  -> (ya, yb)"""
+    spec_a, params_a = _spec_of(xa, layers_a, training, padded)
+    spec_b, params_b = _spec_of(xb, layers_b, training, padded)
+    return RowsMLPPair.apply(xa, spec_a, xb, spec_b, bool(training), len(params_a), *params_a, *params_b)

@@ -371,6 +371,74 @@ def test_graph_replay_reproduces_the_eager_step():
     assert rel_l2(g1, g0) < 5e-2
 
 
+@pytest.mark.parametrize("na,nb,wa,wb", [(2048, 2048, (288, 288, 128), (288, 288, 32)), (2048, 1000, (288, 288, 128), (288, 32)),
+                                         (300, 300, (96, 64), (96, 64))])
+def test_rows_mlp_pair_equals_the_two_stacks(na, nb, wa, wb):
+    """rows_mlp.run_pair (two independent stacks in lockstep, their GEMMs launched pairwise) against rows_mlp.run on
+    each: same outputs, input gradients, parameter gradients and running statistics; the GEMMs did pair (launch counter);
+    stacks of different depth still work (the longer one's tail goes out alone); one output unused downstream."""
+    import rows_mlp
+    import capi
+    d = dev()
+    cin = 288 if wa[0] == 288 else 96
+    lib = capi.lib()
+    lib.omnipq_pair_flush.restype = ctypes.c_longlong
+
+    def build(seed, widths):
+        torch.manual_seed(seed)
+        lins, bns = [], []
+        c = cin
+        for i, w in enumerate(widths):
+            lins.append(torch.nn.Conv1d(c, w, 1).to(d))
+            bns.append(torch.nn.BatchNorm1d(w).to(d) if i < len(widths) - 1 else None)
+            if bns[-1] is not None:
+                with torch.no_grad():
+                    bns[-1].weight.uniform_(0.5, 1.5)
+                    bns[-1].bias.uniform_(-0.3, 0.3)
+            c = w
+        return lins, bns
+
+    xa0, xb0 = torch.randn(na, cin, device=d), torch.randn(nb, cin, device=d)
+    ga, gb = torch.randn(na, wa[-1], device=d), torch.randn(nb, wb[-1], device=d)
+
+    def run(pair, use_b=True):
+        (la, ba), (lb, bb) = build(21, wa), build(22, wb)
+        xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+        sa = [rows_mlp.Layer(l.weight, l.bias, b) for l, b in zip(la, ba)]
+        sb = [rows_mlp.Layer(l.weight, l.bias, b) for l, b in zip(lb, bb)]
+        before = int(lib.omnipq_pair_flush())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if pair:
+                ya, yb = rows_mlp.run_pair(xa, sa, xb, sb, True)
+            else:
+                ya, yb = rows_mlp.run(xa, sa, True), rows_mlp.run(xb, sb, True)
+        loss = (ya.float() * ga).sum()
+        if use_b:
+            loss = loss + (yb.float() * gb).sum()
+        loss.backward()
+        pairs = int(lib.omnipq_pair_flush()) - before
+        mods = [m for m in la + ba + lb + bb if m is not None]
+        grads = [xa.grad] + ([xb.grad] if use_b else []) + \
+            [p.grad for m in mods for p in m.parameters() if p.grad is not None]
+        stats = [t.clone() for m in ba + bb if m is not None for t in (m.running_mean, m.running_var)]
+        return ya.detach(), yb.detach(), grads, stats, pairs
+
+    for use_b in (True, False):
+        y1a, y1b, g1, s1, pairs = run(True, use_b)
+        y0a, y0b, g0, s0, none = run(False, use_b)
+        assert none == 0
+        if len(wa) == len(wb):          # same structure: every forward GEMM paired, and every backward one if both are used
+            assert pairs == len(wa) * (2 if use_b else 1), pairs
+        else:                           # otherwise the first layers at least (same kind of GEMM)
+            assert pairs >= 1
+        assert torch.equal(y1a, y0a) and torch.equal(y1b, y0b)
+        assert len(g1) == len(g0)
+        for u, v in zip(g1, g0):
+            assert rel_l2(u, v) < 1e-5, rel_l2(u, v)
+        for u, v in zip(s1, s0):
+            assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("cin,widths,n", [(288, (288, 288, 97), 2048), (3, (288, 288), 8192), (288, (288, 288, 291), 8192),
                                           (1024, (512, 288), 4096)])
 def test_rows_mlp_matches_f32_layers(cin, widths, n):
