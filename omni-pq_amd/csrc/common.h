@@ -127,4 +127,45 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Pair launches (include/omnipq_sa.h: omnipq_pair_hold): one launch of the calling thread held back for a partner of the
+// same kind.  `blob` holds the kernel-specific problem record, `single` sends it out on its own.
+struct HeldLaunch {
+  bool armed = false, full = false;
+  int key = 0;                                  // kind of launch: only equal keys pair
+  hipStream_t stream = nullptr;
+  void (*single)(const HeldLaunch &) = nullptr;
+  alignas(16) unsigned char blob[768];
+};
+HeldLaunch &held_launch();                      // gemm_bf16.hip; thread-local
+void count_pair_launch();
+constexpr int kHeldApplyKey = 1000;             // bn_bwd_apply_fused (the GEMM variants use small keys)
+
+// The protocol every pairable launcher follows.  Returns true when the launch was consumed (held, or sent out as a pair by
+// `pair(first, second)`); false: the caller launches `prob` on its own (after a held stranger was sent out).
+template <typename P, typename PairFn>
+static inline bool hold_or_pair(const P &prob, int key, hipStream_t stream, void (*single)(const HeldLaunch &), PairFn pair) {
+  static_assert(sizeof(P) <= sizeof(HeldLaunch::blob), "problem record too large");
+  HeldLaunch &h = held_launch();
+  if (h.armed && !h.full) {
+    h.full = true;
+    h.key = key;
+    h.stream = stream;
+    h.single = single;
+    __builtin_memcpy(h.blob, &prob, sizeof(P));
+    return true;
+  }
+  if (h.full) {
+    h.full = h.armed = false;
+    if (h.key == key && h.stream == stream) {
+      P first;
+      __builtin_memcpy(&first, h.blob, sizeof(P));
+      pair(first, prob);
+      count_pair_launch();
+      return true;
+    }
+    h.single(h);
+  }
+  return false;
+}
+
 }  // namespace omnipq

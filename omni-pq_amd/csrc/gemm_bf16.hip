@@ -990,15 +990,16 @@ static bool gemm_nt_kres(int K) {
 // is the same variant on the same stream, goes out with it as one grid (gemm_nt_pair_kernel); anything else (another
 // variant, omnipq_pair_flush()) sends the held one out on its own first.  The caller guarantees the two are independent
 // and issues nothing else in between.
-struct HeldSmall {
-  bool armed = false, full = false;
-  int key = 0, lds = 0;
-  omnipq::SmallProblem p;
-  hipStream_t stream = nullptr;
-  void (*single)(const HeldSmall &) = nullptr;
-};
-static thread_local HeldSmall t_held;
+static thread_local omnipq::HeldLaunch t_held;
 static long long t_pairs_launched = 0;
+namespace omnipq {
+HeldLaunch &held_launch() { return t_held; }
+void count_pair_launch() { ++t_pairs_launched; }
+}  // namespace omnipq
+struct HeldSmallBlob {
+  omnipq::SmallProblem p;
+  int lds;
+};
 
 template <int STATS, bool AFF>
 static void launch_small_single(const omnipq::SmallProblem &p, int lds, hipStream_t stream) {
@@ -1012,43 +1013,34 @@ static void launch_small_single(const omnipq::SmallProblem &p, int lds, hipStrea
 }
 
 template <int STATS, bool AFF>
-static void held_single(const HeldSmall &h) { launch_small_single<STATS, AFF>(h.p, h.lds, h.stream); }
+static void held_single(const omnipq::HeldLaunch &h) {
+  HeldSmallBlob q;
+  __builtin_memcpy(&q, h.blob, sizeof(q));
+  launch_small_single<STATS, AFF>(q.p, q.lds, h.stream);
+}
 
 template <int STATS, bool AFF>
 static void launch_small(const omnipq::GemmArgs &g, const void *A, const void *B, void *C, const float *bias, void *stats,
                          const omnipq::BnBwdEpilogue &bn, const omnipq::AffineIn &aff, void *stream) {
   using namespace omnipq;
-  HeldSmall &h = t_held;
   if (gemm_nt_kres(g.K)) {
     int lds = 2 * 64 * (g.K + 8) * 2;
     if (lds < 20480) lds = 20480;                // the C tile / statistics fold alias the operand tiles
-    const SmallProblem p{g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff};
-    const int key = STATS * 2 + (AFF ? 1 : 0);
-    if (h.armed && !h.full) {
-      h.full = true;
-      h.key = key;
-      h.lds = lds;
-      h.p = p;
-      h.stream = (hipStream_t)stream;
-      h.single = &held_single<STATS, AFF>;
-      return;
-    }
-    if (h.full) {
-      h.full = h.armed = false;
-      if (h.key == key && h.stream == (hipStream_t)stream) {
-        auto kern = gemm_nt_pair_kernel<STATS, AFF>;
-        static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)prepared;
-        const int n0 = (int)gemm_nt_grid(h.p.g).x, n1 = (int)gemm_nt_grid(g).x;
-        kern<<<dim3(n0 + n1), 256, lds > h.lds ? lds : h.lds, (hipStream_t)stream>>>(h.p, p, n0);
-        ++t_pairs_launched;
-        return;
-      }
-      h.single(h);
-    }
-    launch_small_single<STATS, AFF>(p, lds, (hipStream_t)stream);
+    const HeldSmallBlob q{SmallProblem{g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff}, lds};
+    const bool consumed = hold_or_pair(
+        q, STATS * 2 + (AFF ? 1 : 0), (hipStream_t)stream, &held_single<STATS, AFF>,
+        [&](const HeldSmallBlob &first, const HeldSmallBlob &second) {
+          auto kern = gemm_nt_pair_kernel<STATS, AFF>;
+          static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+          (void)prepared;
+          const int n0 = (int)gemm_nt_grid(first.p.g).x, n1 = (int)gemm_nt_grid(second.p.g).x;
+          kern<<<dim3(n0 + n1), 256, first.lds > second.lds ? first.lds : second.lds, (hipStream_t)stream>>>(first.p,
+                                                                                                           second.p, n0);
+        });
+    if (!consumed) launch_small_single<STATS, AFF>(q.p, lds, (hipStream_t)stream);
   } else {
+    HeldLaunch &h = held_launch();
     if (h.full) {
       h.full = h.armed = false;
       h.single(h);
@@ -1066,7 +1058,7 @@ extern "C" int omnipq_pair_held(void) { return t_held.full ? 1 : 0; }
 
 // Sends out a held launch that found no partner and disarms; returns the number of pair launches made so far (diagnostic).
 extern "C" long long omnipq_pair_flush(void) {
-  HeldSmall &h = t_held;
+  omnipq::HeldLaunch &h = t_held;
   if (h.full) h.single(h);
   h.full = h.armed = false;
   return t_pairs_launched;

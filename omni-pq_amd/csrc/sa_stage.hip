@@ -445,32 +445,39 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m
 // dY[p][c] = a[c] * (dz - S/P - yhat * T/P),  dz = (s == arg ? g_out : 0) masked by out > 0
 // bn_bwd_apply with the two small kernels around it folded in: every block turns the f64 totals into the
 // per-channel means (LDS, 2C floats); block 0 writes dbeta / dgamma (= the totals, as f32) when asked to.
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(long long chunks, int C, double invP,
-                                                                const bf16_t *__restrict__ dX,
-                                                                const bf16_t *__restrict__ Y,
-                                                                const float *__restrict__ a,
-                                                                const float *__restrict__ b,
-                                                                const float *__restrict__ mean,
-                                                                const float *__restrict__ invstd,
-                                                                const double *__restrict__ sums,
-                                                                bf16_t *__restrict__ dY, float *__restrict__ dbeta_dgamma) {
+struct ApplyProblem {
+  long long chunks;
+  int C;
+  double invP;
+  const bf16_t *dX, *Y;
+  const float *a, *b, *mean, *invstd;
+  const double *sums;
+  bf16_t *dY;
+  float *dbeta_dgamma;
+};
+// bid / nblocks: this workgroup's index and the number of workgroups of ITS problem (a pair launch runs two in one grid)
+__device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, int bid, int nblocks) {
   extern __shared__ float st[];                              // [S/P | T/P]
+  const int C = p.C;
   for (int j = (int)threadIdx.x; j < 2 * C; j += 256) {
-    const double t = sums[j];
-    st[j] = (float)(t * invP);
-    if (dbeta_dgamma && blockIdx.x == 0) dbeta_dgamma[j] = (float)t;
+    const double t = p.sums[j];
+    st[j] = (float)(t * p.invP);
+    if (p.dbeta_dgamma && bid == 0) p.dbeta_dgamma[j] = (float)t;
   }
   __syncthreads();
   const int cpr = C >> 3;
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+  const bf16_t *__restrict__ Y = p.Y;
+  const bf16_t *__restrict__ dX = p.dX;
+  bf16_t *__restrict__ dY = p.dY;
+  for (long long q = (long long)bid * 256 + threadIdx.x; q < p.chunks; q += (long long)nblocks * 256) {
     const int c0 = (int)(q % cpr) * 8;
     float y[8], d[8], av[8], bv[8], mu[8], is[8];
     unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
     unpack8(*reinterpret_cast<const uint4 *>(dX + q * 8), d);
-    load8f(a + c0, av);
-    load8f(b + c0, bv);
-    load8f(mean + c0, mu);
-    load8f(invstd + c0, is);
+    load8f(p.a + c0, av);
+    load8f(p.b + c0, bv);
+    load8f(p.mean + c0, mu);
+    load8f(p.invstd + c0, is);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float dz = __builtin_fmaf(av[e], y[e], bv[e]) > 0.f ? d[e] : 0.f;
@@ -479,6 +486,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(long long chunk
     }
     *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
   }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(ApplyProblem p) {
+  bn_bwd_apply_fused_body(p, (int)blockIdx.x, (int)gridDim.x);
+}
+// two independent problems in one grid (see gemm_bf16.hip: gemm_nt_pair_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(ApplyProblem p0, ApplyProblem p1, int n0) {
+  const int id = (int)blockIdx.x;
+  if (id < n0) bn_bwd_apply_fused_body(p0, id, n0);
+  else bn_bwd_apply_fused_body(p1, id - n0, (int)gridDim.x - n0);
 }
 
 // sums (f64 totals) -> per-channel means as f32:  st[c] = sum dz / P,  st[C + c] = sum dz*yhat / P
@@ -1418,9 +1434,34 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
   const long long chunks = P * (C / 8);
   int grid = grid_for(chunks);
   if (grid < 1) grid = 1;
-  bn_bwd_apply_fused_kernel<<<grid, 256, sizeof(float) * 2 * C, (hipStream_t)stream>>>(
-      chunks, C, 1.0 / total_positions, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums, (bf16_t *)dY,
-      dbeta_dgamma);
+  struct Held {
+    omnipq::ApplyProblem p;
+    int grid;
+  };
+  const Held q{omnipq::ApplyProblem{chunks, C, 1.0 / total_positions, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean,
+                                    invstd, sums, (bf16_t *)dY, dbeta_dgamma},
+               grid};
+  auto single = +[](const omnipq::HeldLaunch &h) {
+    Held f;
+    __builtin_memcpy(&f, h.blob, sizeof(f));
+    bn_bwd_apply_fused_kernel<<<f.grid, 256, sizeof(float) * 2 * f.p.C, h.stream>>>(f.p);
+  };
+  // small problems only: a launch that fills the chip on its own gains nothing from a partner
+  const bool pairable = grid <= 1024;
+  if (!pairable) {
+    omnipq::HeldLaunch &h = omnipq::held_launch();
+    if (h.full) {
+      h.full = h.armed = false;
+      h.single(h);
+    }
+  }
+  if (!pairable || !omnipq::hold_or_pair(q, omnipq::kHeldApplyKey, (hipStream_t)stream, single,
+                                         [&](const Held &first, const Held &second) {
+                                           const int cmax = first.p.C > second.p.C ? first.p.C : second.p.C;
+                                           bn_bwd_apply_pair_kernel<<<first.grid + second.grid, 256, sizeof(float) * 2 * cmax,
+                                                                      (hipStream_t)stream>>>(first.p, second.p, first.grid);
+                                         }))
+    bn_bwd_apply_fused_kernel<<<grid, 256, sizeof(float) * 2 * C, (hipStream_t)stream>>>(q.p);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -298,8 +298,10 @@ def _backward_program(ctx, lead, g, needs_input_grad):
                     fused = (dprev, nsums)
                 else:
                     dst = dcur if owned else torch.empty_like(dcur)
+                    _hold(lead)
                     grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums,
                                                                                     world, out=dst)
+                    yield
                     dcur, owned = dst, True
                 if lay.has_bias:
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
