@@ -18,6 +18,7 @@ Every node is a custom autograd Function whose backward runs the mirrored kernel
 decoder_ops.hip, gemm_*.hip through `rows_mlp`).
 """
 import ctypes
+import os
 
 import torch
 
@@ -225,14 +226,28 @@ def precompute_key_sides(layers, key, key_pos):
     with torch.cuda.stream(side):
         # all layers read the same memory rows: one cast, and in backward one n-ary add for their n gradients
         mem = FanOut.apply(_rows(key).to(torch.bfloat16).contiguous(), len(layers))
-        kvs = [key_side(layer, key, key_pos, mem[i]) for i, layer in enumerate(layers)]
-    for kv, _ in kvs:
-        kv.record_stream(cur)
+        kvs = []
+        for i, layer in enumerate(layers):
+            kv = key_side(layer, key, key_pos, mem[i])
+            if _JOIN_PER_LAYER:
+                # layer i waits for ITS key side only, not for the six of them
+                done = torch.cuda.Event()
+                done.record(side)
+                kv = kv + (done,)
+            kvs.append(kv)
+    for kv in kvs:
+        kv[0].record_stream(cur)
     return kvs
 
 
-def join_key_sides(device):
-    torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+_JOIN_PER_LAYER = os.environ.get("OMNIPQ_KEY_JOIN", "event") != "stream"
+
+
+def join_key_sides(device, done=None):
+    if done is not None:
+        torch.cuda.current_stream(device).wait_event(done)
+    else:
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
 def run(layer, query, key, query_pos, key_pos, kv=None):
@@ -273,8 +288,8 @@ def run(layer, query, key, query_pos, key_pos, kv=None):
     if kv is None:
         kv = key_side(layer, key, key_pos)
     else:
-        join_key_sides(query.device)
-    kv, (wq, bq) = kv
+        join_key_sides(query.device, kv[2] if len(kv) > 2 else None)
+    kv, (wq, bq) = kv[0], kv[1]
     q = linear(xq, wq, bq)
     att = fused_attention.PackedAttention.apply(q, kv, Pq, Pk, B, H, float(ca.dropout) if training else 0.0)
     y = linear(att, ca.out_proj.weight, ca.out_proj.bias)
