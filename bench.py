@@ -303,9 +303,10 @@ def stage_breakdown(table, steps):
             k = "feature_propagation"
         elif base.startswith("omnipq_attn"):
             k = "attention"
-        elif base.startswith(("omnipq_add_dropout_layernorm", "omnipq_relu_dropout", "omnipq_add_to_bf16")):
+        elif base.startswith(("omnipq_add_dropout_layernorm", "omnipq_relu_dropout", "omnipq_add_to_bf16", "omnipq_layernorm",
+                              "omnipq_split_rows", "omnipq_merge_rows", "omnipq_add_n")):
             k = "decoder row kernels (LayerNorm, dropout)"
-        elif base.startswith(("omnipq_head_decode", "omnipq_quad_decode")):
+        elif base.startswith(("omnipq_head_decode", "omnipq_quad_decode", "omnipq_decode_pair", "omnipq_vote_decode")):
             k = "head decode"
         elif base.startswith(("omnipq_gemm", "omnipq_bn", "omnipq_colsum", "omnipq_prep", "omnipq_unprep", "omnipq_sums")):
             k = "rows engine (heads, decoder projections / FFN, voting, embeddings)"
