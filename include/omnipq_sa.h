@@ -77,6 +77,9 @@ int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int lda, const 
 
 /* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
 long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
+/* The slab policy behind it: how many partial tiles the position axis of a weight gradient is cut into (tiles = 128 x 128
+ * output tiles, k_step = positions per K-step of the kernel). */
+int omnipq_gemm_tn_slabs(int tiles, long long P, int k_step);
 int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                         float *workspace, void *stream);
 /* the same, and colsum[m] += sum_p A[p][m] (f32): weight AND bias gradient of a linear layer from one pass */

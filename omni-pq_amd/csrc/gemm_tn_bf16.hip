@@ -401,20 +401,22 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int
 
 // C[M][N] (f32) = A[P][M]^T * B[P][N]; M, N multiples of 8; lda, ldb multiples of 8.
 // `workspace` must hold omnipq_gemm_tn_workspace_floats(M, N, P) floats.
-// How many slabs to cut the position axis into: enough workgroups to fill the chip (~1024, four per CU: the
+// How many slabs to cut the position axis into: enough workgroups to fill the chip (~512, two per CU -- 1024 measured the
+// same step time and twice the slab traffic, 0.8 GB per step written and read back by the reduction; the
 // kernel is bound by the latency of its global loads, measured 232 -> 156 us on 512 x 256 x 262144 when the C
 // tile left LDS and occupancy doubled), but every workgroup keeps at least kMinSteps K-steps of work -- a slab
 // costs a 64 KB f32 tile store plus its share of the reduction, which dwarfs a one- or two-step main loop on
 // the small per-point layers (P ~ 4096).
-static int tn_slabs(int tiles, int P) {
+extern "C" int omnipq_gemm_tn_slabs(int tiles, long long P, int k_step) {
   static const int kMinSteps = getenv("OMNIPQ_TN_MINSTEPS") ? atoi(getenv("OMNIPQ_TN_MINSTEPS")) : 6;
-  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 1024;
-  int slabs = (kTarget + tiles - 1) / tiles;
-  const int max_slabs = (P + omnipq::TBK * kMinSteps - 1) / (omnipq::TBK * kMinSteps);
+  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 512;
+  long long slabs = (kTarget + tiles - 1) / tiles;
+  const long long max_slabs = (P + (long long)k_step * kMinSteps - 1) / ((long long)k_step * kMinSteps);
   if (slabs > max_slabs) slabs = max_slabs;
   if (slabs < 1) slabs = 1;
-  return slabs;
+  return (int)slabs;
 }
+static int tn_slabs(int tiles, int P) { return omnipq_gemm_tn_slabs(tiles, P, omnipq::TBK); }
 
 extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P) {
   using namespace omnipq;

@@ -1336,15 +1336,8 @@ extern "C" int omnipq_sa_rowgemm(const omnipq_rowgemm_desc *q, void *stream) {
 
 extern "C" long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 
-static int tn_gen_slabs(int tiles, long long P) {
-  static const int kMinSteps = getenv("OMNIPQ_TN_MINSTEPS") ? atoi(getenv("OMNIPQ_TN_MINSTEPS")) : 6;
-  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 1024;
-  long long slabs = (kTarget + tiles - 1) / tiles;
-  const long long max_slabs = (P + omnipq::GTK * kMinSteps - 1) / (omnipq::GTK * kMinSteps);
-  if (slabs > max_slabs) slabs = max_slabs;
-  if (slabs < 1) slabs = 1;
-  return (int)slabs;
-}
+extern "C" int omnipq_gemm_tn_slabs(int tiles, long long P, int k_step);      // gemm_tn_bf16.hip: the one slab policy
+static int tn_gen_slabs(int tiles, long long P) { return omnipq_gemm_tn_slabs(tiles, P, omnipq::GTK); }
 
 template <int AK>
 static int tn_gen_launch(const omnipq::TnGenDev &g, int b_kind, dim3 grid, hipStream_t st) {
