@@ -126,6 +126,12 @@ int omnipq_group_points_grad(int b, int c, int n, int npoints, int nsample,
 int omnipq_three_nn(int b, int n, int m, const float *unknown,
                     const float *known, float *dist2, int *idx, void *stream);
 
+/* omnipq_three_nn plus the interpolation weights the reference derives from its distances in Python
+ * (pointnet2/pointnet2_modules.py:395-397: dist_recip = 1 / (dist + 1e-8), weight = dist_recip / sum): weight f32
+ * [b][n][3], from the same launch. */
+int omnipq_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                            float *weight, void *stream);
+
 /* replaces three_interpolate_kernel_wrapper (interpolate.cpp:14-16).
  *   points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n) */
 int omnipq_three_interpolate(int b, int c, int m, int n, const float *points,

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kNNBlock) void three_nn_kernel(int n, int m,
                                                             const float *__restrict__ unknown,
                                                             const float *__restrict__ known,
                                                             float *__restrict__ dist2,
-                                                            int *__restrict__ idx) {
+                                                            int *__restrict__ idx,
+                                                            float *__restrict__ weight) {
   __shared__ float tile[kNNTile * 3];
   const int scene = (int)blockIdx.y;
   unknown += (size_t)scene * n * 3;
@@ -76,6 +77,15 @@ __global__ __launch_bounds__(kNNBlock) void three_nn_kernel(int n, int m,
     dd[0] = b1; dd[1] = b2; dd[2] = b3;
     // fewer than three known points: the reference leaves index 0 in the unused slots
     ii[0] = i1 == kBig ? 0 : i1; ii[1] = i2 == kBig ? 0 : i2; ii[2] = i3 == kBig ? 0 : i3;
+    if (weight) {
+      // the interpolation weights of reference pointnet2_modules.py:395-397 from the same registers:
+      // r = 1 / (sqrt(d2) + 1e-8), w = r / (r0 + r1 + r2) -- f32, correctly rounded sqrt and divisions as torch's
+      const float r1 = 1.0f / (__builtin_sqrtf(b1) + 1e-8f), r2 = 1.0f / (__builtin_sqrtf(b2) + 1e-8f),
+                  r3 = 1.0f / (__builtin_sqrtf(b3) + 1e-8f);
+      const float norm = (r1 + r2) + r3;
+      float *ww = weight + ((size_t)scene * n + j) * 3;
+      ww[0] = r1 / norm; ww[1] = r2 / norm; ww[2] = r3 / norm;
+    }
   }
 }
 
@@ -142,7 +152,23 @@ extern "C" int omnipq_three_nn(int b, int n, int m, const float *unknown, const 
   if (!unknown || !dist2 || !idx || (m > 0 && !known)) return OMNIPQ_EINVAL;
   if (b > 65535) return OMNIPQ_ETOOLARGE;
   dim3 grid((n + kNNBlock / kNNSplit - 1) / (kNNBlock / kNNSplit), b);
-  three_nn_kernel<<<grid, kNNBlock, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+  three_nn_kernel<<<grid, kNNBlock, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// omnipq_three_nn, and the normalised inverse-distance weights (reference pointnet2/pointnet2_modules.py:395-397: six
+// elementwise launches on the (B, n, 3) distances) out of the same launch: weight[b][j][t] = r_t / sum_t r_t,
+// r_t = 1 / (sqrt(dist2_t) + 1e-8).
+extern "C" int omnipq_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                                       float *weight, void *stream) {
+  using namespace omnipq;
+  if (b < 0 || n < 0 || m < 0) return OMNIPQ_EINVAL;
+  if (b == 0 || n == 0) return OMNIPQ_OK;
+  if (!unknown || !dist2 || !idx || !weight || (m > 0 && !known)) return OMNIPQ_EINVAL;
+  if (b > 65535) return OMNIPQ_ETOOLARGE;
+  dim3 grid((n + kNNBlock / kNNSplit - 1) / (kNNBlock / kNNSplit), b);
+  three_nn_kernel<<<grid, kNNBlock, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, weight);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -188,6 +188,21 @@ def three_nn(unknowns, knows):
     return [dist2, idx]
 
 
+def three_nn_weights(unknowns, knows):
+    """(B,n,3), (B,m,3) -> (weight (B,n,3) f32, idx (B,n,3) i32): three_nn and the normalised inverse-distance weights of
+    pointnet2_modules.py:395-397 in one launch."""
+    _check(unknowns, "unknowns", torch.float32)
+    _check(knows, "knows", torch.float32, cuda_like=unknowns)
+    _need_gpu(unknowns)
+    b, n = unknowns.shape[0], unknowns.shape[1]
+    m = knows.shape[1]
+    idx = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.int32)
+    dist2 = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
+    weight = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
+    _run(_lib.omnipq_three_nn_weights, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), _ptr(weight))
+    return weight, idx
+
+
 def three_interpolate(points, idx, weight):
     """(B,C,m), (B,n,3) i32, (B,n,3) f32 -> (B,C,n)   [interpolate.cpp:50-78]"""
     _check(points, "points", torch.float32)

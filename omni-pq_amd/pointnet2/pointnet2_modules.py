@@ -281,8 +281,11 @@ def _fp_forward_rows(self, unknown, known, unknow_feats, known_feats):
             return None
     if known_pm is None or C2 % 8:
         return None
-    dist, idx = pointnet2_utils.three_nn(unknown, known)
-    weight = inverse_distance_weights(dist).contiguous()
+    if unknown.dtype == torch.float32 and known.dtype == torch.float32 and not (unknown.requires_grad or known.requires_grad):
+        weight, idx = pointnet2_utils._ext.three_nn_weights(unknown.contiguous(), known.contiguous())   # one launch
+    else:
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        weight = inverse_distance_weights(dist).contiguous()
     rows_in = sa_fused.FPGatherRows.apply(known_feats, known_pm, unknow_feats, skip_pm, idx, weight)
     y = _rows_mlp(self.mlp, rows_in)
     if y is None:

@@ -229,6 +229,17 @@ def test_three_nn_exact_and_interpolate(kind, b, n, m):
     dist = torch.sqrt(w_d2)
     recip = 1.0 / (dist + 1e-8)
     weight = (recip / recip.sum(2, keepdim=True)).contiguous()
+    # omnipq_three_nn_weights: the same indices / squared distances and the reference's weight formula
+    # (pointnet2_modules.py:395-397, evaluated above by torch on the CPU) out of one launch -- f32, within 1e-6 relative
+    import ctypes
+    d2w = torch.empty((b, n, 3), device=d)
+    idxw = torch.empty((b, n, 3), device=d, dtype=torch.int32)
+    ww = torch.empty((b, n, 3), device=d)
+    capi.ok("omnipq_three_nn_weights", b, n, m, capi.P(unknown.to(d)), capi.P(known.to(d)), capi.P(d2w), capi.P(idxw),
+            capi.P(ww))
+    assert torch.equal(idxw.cpu(), w_idx) and torch.equal(d2w.cpu(), w_d2)
+    assert float(((ww.cpu() - weight).abs() / weight.abs().clamp_min(1e-30)).max()) < 1e-6
+    assert float((ww.sum(2) - 1).abs().max()) < 1e-6
     got = capi.three_interpolate(feats.to(d), w_idx.to(d), weight.to(d))
     assert torch.equal(got.cpu(), oracle_ext.three_interpolate(feats, w_idx, weight))
     go = torch.randn((b, c, n), generator=gen)
