@@ -75,6 +75,20 @@ def lin(x2d, conv):
     return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
 
 
+def conv1x1_pair(xa, conv_a, xb, conv_b):
+    """`conv1x1` of two independent inputs through two independent layers; on the row kernels their GEMMs share a launch
+    each way (rows_mlp.run_pair)."""
+    ra, rb = rows(xa), rows(xb)
+    sa, sb = [rows_mlp.Layer(conv_a.weight, conv_a.bias)], [rows_mlp.Layer(conv_b.weight, conv_b.bias)]
+    if _PAIR_STACKS and conv_a.training == conv_b.training and rows_mlp.usable(ra, sa, conv_a.training) and \
+            rows_mlp.usable(rb, sb, conv_b.training):
+        ya, yb = rows_mlp.run_pair(ra, sa, rb, sb, conv_a.training)
+    else:
+        ya, yb = lin(ra, conv_a), lin(rb, conv_b)
+    (Ba, _, Ka), (Bb, _, Kb) = xa.shape, xb.shape
+    return ya.view(Ba, Ka, -1).transpose(1, 2), yb.view(Bb, Kb, -1).transpose(1, 2)
+
+
 def conv1x1(x, conv):
     """(B, C_in, K) -> (B, C_out, K), as a transposed view of the row-major result."""
     B, _, K = x.shape
@@ -638,8 +652,8 @@ class PQ_Transformer(nn.Module):
         base_xyz = center.detach()
         base_xyz_q = center_q.detach()
 
-        query_joint = torch.cat([conv1x1(cluster_feature, self.decoder_query_proj),
-                                 conv1x1(quad_feature, self.quad_decoder_query_proj)], -1)
+        query_joint = torch.cat(conv1x1_pair(cluster_feature, self.decoder_query_proj,
+                                             quad_feature, self.quad_decoder_query_proj), -1)
         key = conv1x1(seed_features, self.decoder_key_proj)
         key_pos = seed_xyz
 
