@@ -109,16 +109,19 @@ def _lockstep(lead, follow):
     out = [None, None]
     alive = [True, True]
     gens = (lead, follow)
-    while alive[0] or alive[1]:
-        for i in (0, 1):
-            if alive[i]:
-                try:
-                    next(gens[i])
-                except StopIteration as done:
-                    out[i], alive[i] = done.value, False
-            if i == 0 and not _lib.omnipq_pair_held():
-                _lib.omnipq_pair_flush()              # nothing was held: disarm before the follower runs
-        _lib.omnipq_pair_flush()
+    try:
+        while alive[0] or alive[1]:
+            for i in (0, 1):
+                if alive[i]:
+                    try:
+                        next(gens[i])
+                    except StopIteration as done:
+                        out[i], alive[i] = done.value, False
+                if i == 0 and not _lib.omnipq_pair_held():
+                    _lib.omnipq_pair_flush()              # nothing was held: disarm before the follower runs
+            _lib.omnipq_pair_flush()
+    finally:
+        _lib.omnipq_pair_flush()      # an exception in either program must not leave a launch held or the hold armed
     return out
 
 
