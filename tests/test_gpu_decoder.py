@@ -524,6 +524,36 @@ def test_the_model_takes_the_fused_vote_tail_on_the_benchmarked_path():
     assert torch.equal(vf.omnipq_rows16, vf.transpose(1, 2).to(torch.bfloat16))
 
 
+def test_model_forward_with_pair_launches_equals_the_separate_launches(monkeypatch):
+    """The whole model in eval mode (running statistics: no atomics, so bit-reproducible) under bf16 autocast: with the
+    pair machinery (head stacks in lockstep, decode pair with joint query positions, paired query projections) every
+    end_points entry is the same bits as with one launch per head."""
+    import bench
+    import synth
+    import pq_transformer as pq
+    import capi
+    torch.manual_seed(1)
+    net = bench.build_model(0).to(dev()).eval()
+    pc = synth.make_clouds(6, 2, 8192, kind="room").to(dev())
+    lib = capi.lib()
+    lib.omnipq_pair_flush.restype = ctypes.c_longlong
+
+    def run(on):
+        for flag in ("_PAIR_STACKS", "_PAIR_DECODE", "_XYZ_SINK"):
+            monkeypatch.setattr(pq, flag, on)
+        before = int(lib.omnipq_pair_flush())
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            ep = net({"point_clouds": pc})
+        return {k: v.clone() for k, v in ep.items() if torch.is_tensor(v)}, int(lib.omnipq_pair_flush()) - before
+
+    e1, pairs = run(True)
+    e0, none = run(False)
+    assert none == 0 and pairs >= 7 * 3 + 1            # seven stages x three GEMMs, and the query projections
+    assert sorted(e1) == sorted(e0)
+    for k in e0:
+        assert e1[k].dtype == e0[k].dtype and torch.equal(e1[k], e0[k]), k
+
+
 @pytest.mark.parametrize("B,K,C,ld,transposed", [(2, 1024, 288, 320, True), (3, 77, 64, 67, False), (1, 33, 320, 352, True)])
 def test_vote_decode_matches_the_op_by_op_tail(B, K, C, ld, transposed):
     """omnipq_vote_decode(_bwd) == seed_xyz + offset, (seed_features + residual) / its L2 norm over the channels
