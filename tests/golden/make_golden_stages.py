@@ -1,0 +1,139 @@
+"""Generate tests/golden/model_stages_8192.pt: the REFERENCE model cut at its stage boundaries.
+
+    python tests/golden/make_golden_stages.py
+
+Why: the whole-model bf16 comparison (tests/test_gpu_bf16_fixtures.py) compounds 2^-8 roundings through ~40 layers of a
+network that, at procedural weights, doubles a perturbation per stage -- it cannot fail for a wrong kernel.  Here the
+reference's `PQ_Transformer` (imported in place from /root/reference, the C oracle standing in for its CUDA extension,
+exactly as make_golden.py does) runs ONE forward + backward in train mode (dropout 0) in which every stage boundary is
+*teacher-forced*:
+
+  * the output a stage hands to the next one is replaced by its bf16-rounded value (a value both sides can hold
+    exactly), detached -- so every stage of the reference is evaluated on an input the test can feed bit for bit to the
+    stage under test, and errors cannot compound;
+  * the loss is sum_k <stage output k, G_k> + sum_e <end_point e, G_e> with PROCEDURAL upstream gradients G
+    (tests/procedural.py, regenerated on both sides, never stored), so every parameter's gradient is produced inside
+    one segment, by that segment's kernels only.
+
+Stored: the forced boundary tensors in full (bf16), the reference's own pre-forcing stage outputs and all float
+end_points as strided samples + norms, integer end_points in full, and a strided sample + norm of every parameter
+gradient.  Boundaries (reference models/pq_transformer.py:196-267, backbone_module.py:86-139):
+    backbone.sa1..sa4 -> features;  backbone.fp1, fp2 -> features;  vote -> (xyz, L2-normalised features) as handed to
+    vote_aggregation;  vote_aggregation -> features;  decoder[0..5] -> joint query features.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import make_golden as mg  # noqa: E402  (sets up the in-place import of the reference + oracle backend)
+import torch  # noqa: E402
+
+from procedural import load_procedural, procedural_tensor, summarize  # noqa: E402
+import synth  # noqa: E402
+
+BOUNDARY_SA = ("sa1", "sa2", "sa3", "sa4")
+BOUNDARY_FP = ("fp1", "fp2")
+GRAD_SAMPLES = 1024
+
+
+def round16(t):
+    return t.detach().to(torch.bfloat16).float()
+
+
+def upstream(name, t):
+    """Procedural upstream gradient of a stage output / end_point (same call on the test side)."""
+    return procedural_tensor("stages.g." + name, tuple(t.shape), torch.float32)
+
+
+def stage_case(name, xyz):
+    import pq_transformer as ref_model
+    assert ref_model.__file__.startswith(mg.REF)
+    net = ref_model.PQ_Transformer(input_feature_dim=xyz.shape[-1] - 3, num_class=18, num_proposal=256,
+                                   num_quad_proposal=256, num_heading_bin=1, num_size_cluster=18,
+                                   mean_size_arr=mg.mean_size_arr())
+    load_procedural(net)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+            m.dropout = 0.0
+
+    own = {}        # the reference's own stage outputs (before forcing), still attached to the graph
+    forced = {}     # what the next stage was given
+    handles = []
+
+    def force(key, t):
+        own[key] = t
+        f = round16(t).requires_grad_(True)
+        forced[key] = f
+        return f
+
+    for sa in BOUNDARY_SA:
+        def hook(_m, _i, out, sa=sa):
+            new_xyz, feats, inds = out
+            return new_xyz, force(sa + "_features", feats), inds
+        handles.append(getattr(net.backbone, sa).register_forward_hook(hook))
+    for fp in BOUNDARY_FP:
+        handles.append(getattr(net.backbone, fp).register_forward_hook(
+            lambda _m, _i, out, fp=fp: force(fp + "_features", out)))
+
+    # the votes: the reference normalises the features OUTSIDE the module (pq_transformer.py:216-217), so the forcing
+    # point is the input of vote_aggregation
+    def agg_pre(_m, args):
+        vxyz, vfeat = args[0], args[1]
+        own["vote_xyz"], own["vote_features"] = vxyz, vfeat
+        fx = vxyz.detach().clone().requires_grad_(True)       # f32 coordinates: forced exactly
+        forced["vote_xyz"] = fx
+        ff = round16(vfeat).requires_grad_(True)
+        forced["vote_features"] = ff
+        return (fx, ff) + tuple(args[2:])
+    handles.append(net.vote_aggregation.register_forward_pre_hook(agg_pre))
+
+    def agg_post(_m, _i, out):
+        new_xyz, feats, inds = out
+        return new_xyz, force("cluster_feature", feats), inds
+    handles.append(net.vote_aggregation.register_forward_hook(agg_post))
+    for i in range(6):
+        handles.append(net.decoder[i].register_forward_hook(
+            lambda _m, _i, out, i=i: force(f"decoder{i}_query", out)))
+
+    end_points = net({"point_clouds": xyz})
+    for h in handles:
+        h.remove()
+
+    loss = 0.0
+    for k in sorted(own):
+        loss = loss + (own[k] * upstream(k, own[k])).sum()
+    boundary_ids = {id(v) for v in forced.values()} | {id(v) for v in own.values()}
+    for k in sorted(end_points):
+        v = end_points[k]
+        if v.is_floating_point() and v.requires_grad and id(v) not in boundary_ids:
+            loss = loss + (v.float() * upstream("ep." + k, v)).sum()
+    loss.backward()
+
+    out = {"keys": sorted(end_points.keys()), "loss": float(loss)}
+    for k, v in end_points.items():
+        out["ep." + k] = summarize(v)
+    for k, v in own.items():
+        out["own." + k] = summarize(v)
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            out["grad." + k] = None
+        else:
+            out["grad." + k] = summarize(p.grad, max_full=GRAD_SAMPLES)
+            out["gradnorm." + k] = float(p.grad.double().norm())
+    inputs = {"point_clouds": xyz}
+    for k, v in forced.items():
+        inputs["forced." + k] = v.detach().clone() if k == "vote_xyz" else v.detach().to(torch.bfloat16)
+    path = os.path.join(HERE, name + ".pt")
+    torch.save({"inputs": inputs, "outputs": out}, path)
+    print(f"{name}: {os.path.getsize(path) / 2**20:.1f} MiB, loss {float(loss):.6e}, "
+          f"{sum(1 for k in out if k.startswith('grad.') and out[k] is not None)} parameter gradients")
+
+
+if __name__ == "__main__":
+    stage_case("model_stages_8192", synth.make_clouds(21, 2, 8192, kind="room"))

@@ -244,3 +244,43 @@ def test_bf16_model_matches_reference_fixture_and_f32_gradient_direction():
         print(f"  tensors below 0.98: mean cosine fused {mean16:.4f} | autocast {meanac:.4f}; {worse:.1%} worse by > 0.15")
         assert mean16 >= meanac - 0.06, (mean16, meanac)
         assert worse <= 0.25, worse
+
+
+def test_whole_model_with_six_extra_input_channels_bf16_forward_and_backward():
+    """BASELINE configs[3] end to end: `PQ_Transformer(input_feature_dim=6)` (rgb + normals: a 9-channel first layer in
+    sa1, reference models/backbone_module.py:38-46) forward + backward on the benchmarked bf16 path, against this repo's
+    f32 mode on the same input.  Sampling is coordinate-only, so the index end_points must be equal; sa1's features are
+    one stage deep and are held to the single-stage bound; every parameter gets a finite gradient of its own shape."""
+    import synth
+    import sa_fused
+    from test_oracle_golden import build_model
+    pc = synth.make_clouds(77, 2, 20000, extra_channels=6, kind="room").to(DEV)
+    res = {}
+    for mode in ("f32", "bf16"):
+        net = build_model(6)
+        load_procedural(net)
+        net.to(DEV).train()
+        assert net.backbone.sa1.mlp_module.layer0.conv.weight.shape == (128, 9, 1, 1)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "bf16"):
+            ep = net({"point_clouds": pc})
+        loss = sum(v.float().mean() for k, v in sorted(ep.items()) if v.is_floating_point() and v.requires_grad)
+        if mode == "bf16":
+            with sa_fused.deferred_wgrads():
+                loss.backward()
+            assert hasattr(ep["sa1_features"], "omnipq_rows16"), "the fused stage did not run"
+        else:
+            loss.backward()
+        res[mode] = (ep, {k: p.grad for k, p in net.named_parameters()}, float(loss))
+    ep32, g32, l32 = res["f32"]
+    ep16, g16, l16 = res["bf16"]
+    assert sorted(ep32) == sorted(ep16) and len(ep16) == 119
+    for k in ("sa1_inds", "sa2_inds", "fp2_inds", "seed_inds"):
+        assert ep16[k].dtype == torch.int32 and torch.equal(ep16[k], ep32[k]), k
+    for k in ("sa1_xyz", "sa2_xyz", "sa3_xyz", "sa4_xyz", "aggregated_sample_xyz"):
+        assert torch.equal(ep16[k], ep32[k]), k
+    e = float((ep16["sa1_features"].float() - ep32["sa1_features"]).norm() / ep32["sa1_features"].norm())
+    print(f"\n  input_feature_dim=6: sa1_features rel-L2 bf16 vs f32 {e:.2e}; loss {l16:.4f} vs {l32:.4f}")
+    assert e <= 1e-2, e
+    assert abs(l16 - l32) <= 0.05 * abs(l32) + 0.05
+    for k, g in g16.items():
+        assert g is not None and g.shape == g32[k].shape and torch.isfinite(g).all(), k

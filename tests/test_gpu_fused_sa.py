@@ -238,6 +238,24 @@ def test_fused_sa_stage_config5_80k_points(monkeypatch):
     _fused_vs_f32(spec, 80000, 0, 2, monkeypatch)
 
 
+def test_fused_sa_stage_config4_at_the_backbones_real_widths(monkeypatch):
+    """BASELINE configs[3] as the backbone runs it (reference models/backbone_module.py:38-46 with input_feature_dim=6):
+    sa1 = 2048 centres, r 0.2, 64 samples, mlp [6, 128, 128, 256] on 4 scenes x 50 000 points."""
+    spec = dict(npoint=2048, radius=0.2, nsample=64, mlp=[6, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+    _fused_vs_f32(spec, 50000, 6, 4, monkeypatch)
+
+
+def test_fused_sa_stage_config5_at_the_backbones_real_widths(monkeypatch):
+    """BASELINE configs[4] at sa1's real widths [0, 128, 128, 256] on 80 000-point clouds (4 scenes: the f32 op-by-op
+    yardstick materialises (B, 256, 2048, 64) tensors); no gradient into the coordinates, as in the backbone, so the
+    coordinate-generated first layer is the path that runs."""
+    import sa_fused
+    spec = dict(npoint=2048, radius=0.2, nsample=64, mlp=[0, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+    before = sa_fused.xyzgen_uses
+    _fused_vs_f32(spec, 80000, 0, 4, monkeypatch, xyz_grad=False)
+    assert sa_fused.xyzgen_uses == before + 1
+
+
 def test_first_layer_generated_from_coordinates_matches_f32_composition(monkeypatch):
     """sa1 as the backbone runs it: no input features and no gradient into the coordinates, so the first layer (conv 3 -> C)
     is never materialised (sa_fused.XYZGEN: activations rebuilt from the grouped coordinates inside the consumer GEMMs,
