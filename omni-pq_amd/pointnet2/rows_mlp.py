@@ -24,8 +24,9 @@ import torch
 import dropout_state
 import sa_fused
 
-# ReLU + dropout of a `relu_dropout` layer inside its GEMM's epilogue ("0": the separate in-place pass, for A/B)
-_FUSE_ACT = os.environ.get("OMNIPQ_FUSE_ACT", "1") != "0"
+# ReLU + dropout of a `relu_dropout` layer inside its GEMM's epilogue (False: the separate in-place pass; the tests
+# compare the two)
+_FUSE_ACT = True
 from sa_fused import (_allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
                       unprep_wgrad, zeros_f32, zeros_f64)
 
@@ -95,6 +96,7 @@ def _hold(lead):
 
 def _drain(gen):
     """Run one stack's program on its own."""
+    assert not _lib.omnipq_pair_held(), "rows_mlp: a held pair launch leaked into a lone stack"
     try:
         while True:
             next(gen)
@@ -109,6 +111,7 @@ def _lockstep(lead, follow):
     out = [None, None]
     alive = [True, True]
     gens = (lead, follow)
+    assert not _lib.omnipq_pair_held(), "rows_mlp: a pair launch was still held when a lockstep run started"
     try:
         while alive[0] or alive[1]:
             for i in (0, 1):
@@ -122,6 +125,7 @@ def _lockstep(lead, follow):
             _lib.omnipq_pair_flush()
     finally:
         _lib.omnipq_pair_flush()      # an exception in either program must not leave a launch held or the hold armed
+    assert not _lib.omnipq_pair_held()
     return out
 
 
@@ -283,29 +287,17 @@ def _backward_program(ctx, lead, g, needs_input_grad):
             if Xin is None:                    # rebuilt from the layer's pre-BN output inside the GEMM
                 below = layers[l - 1]
                 Xin = below.Y
-            fused = None                       # (dprev, next sums): the data-gradient GEMM already ran, with dY generated
             if lay.has_bn:
                 if sums is None:
                     sums = zeros_f64(3, lay.C, dev)
                     _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
                           _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
-                follows = l > 0 or needs_input_grad[0]
-                if sa_fused.DYGEN and follows and lay.Cp == lay.C and lay.C <= sa_fused.DYGEN_MAX_K and lay.Y is not None:
-                    # BatchNorm backward generated inside the data-gradient GEMM (no apply pass): dY comes back for the
-                    # weight gradient below
-                    below_bn = layers[l - 1] if (l > 0 and layers[l - 1].has_bn) else None
-                    nsums = zeros_f64(3, lay.K, dev) if below_bn is not None else None
-                    dprev, dcur, grads[4 * l + 2], grads[4 * l + 3] = sa_fused.gemm_nt_dygen(
-                        dcur, lay, N, sums, world, lay.Wt, lay.K, below=below_bn, below_sums=nsums)
-                    owned = True
-                    fused = (dprev, nsums)
-                else:
-                    dst = dcur if owned else torch.empty_like(dcur)
-                    _hold(lead)
-                    grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums,
-                                                                                    world, out=dst)
-                    yield
-                    dcur, owned = dst, True
+                dst = dcur if owned else torch.empty_like(dcur)
+                _hold(lead)
+                grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums,
+                                                                                world, out=dst)
+                yield
+                dcur, owned = dst, True
                 if lay.has_bias:
                     grads[4 * l + 1] = zeros_f32(lay.C, dev)                # removed by the batch mean
             elif lay.act is not None and act_masked != l:
@@ -328,13 +320,7 @@ def _backward_program(ctx, lead, g, needs_input_grad):
                 dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum, below=below)
                 grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
             sums = None
-            if fused is not None:
-                dprev, sums = fused
-                if l > 0:
-                    dcur, owned = dprev, True
-                else:
-                    dx = dprev[:, :cin].to(ctx.in_dtype)
-            elif l > 0 and layers[l - 1].has_bn:
+            if l > 0 and layers[l - 1].has_bn:
                 sums = zeros_f64(3, lay.K, dev)
                 _hold(lead)
                 dprev = _gemm_nt_bnbwd(dcur, lay.Wt, N, lay.K, lay.Cp, layers[l - 1], sums)

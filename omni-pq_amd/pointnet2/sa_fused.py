@@ -142,9 +142,9 @@ def _gemm_nt_stats(A, B, M, N, K, sums, bias=None, pool=None):
 
 
 # Conv+BN+ReLU stacks without stored activations: the consumer GEMMs rebuild X = relu(a y + b) from the layer's
-# pre-BN output while staging their operand (csrc: AffineIn / AFFB).  OMNIPQ_AFFINE=0 restores the separate
-# normalise+ReLU pass (kept for the parity tests and A/B timing).
-AFFINE_OPERANDS = os.environ.get("OMNIPQ_AFFINE", "1") != "0"
+# pre-BN output while staging their operand (csrc: AffineIn / AFFB).  AFFINE_OPERANDS = False restores the separate
+# normalise+ReLU pass (kept for the parity tests).
+AFFINE_OPERANDS = True
 
 
 def affine_pays(P, N):
@@ -154,19 +154,14 @@ def affine_pays(P, N):
     transform vs without | the pass it replaces): P = 1 M, K = 128, N = 128: +53 us | 106 us; N = 256: +46 | 106;
     P = 262 k, K = 256, N = 256: +18 | 40; N = 512: +34 | 40; P = 65 k, N = 512: +9 | 11; 4096 x 288 x 288: +2 | 6.
     So it pays everywhere on this model (with the scale / shift vectors in LDS; when they were fetched per K-step it
-    lost on the wide layers).  OMNIPQ_AFFINE=selective restores the narrower policy of that time, =0 the stored
-    dataflow."""
-    if not AFFINE_OPERANDS:
-        return False
-    if os.environ.get("OMNIPQ_AFFINE", "1") == "selective":
-        return P <= 16384 or (P >= (1 << 19) and N <= 256)
-    return True
+    lost on the wide layers).  AFFINE_OPERANDS = False restores the stored dataflow (parity tests)."""
+    return AFFINE_OPERANDS
 
 
-POOL_EPILOGUE = os.environ.get("OMNIPQ_POOL_EPILOGUE", "1") != "0"
+POOL_EPILOGUE = True
 # the last layer's BatchNorm finalize inside the pool-select launch, its backward means / affine gradients inside the pool
-# backward apply ("0": the separate launches, for A/B)
-_FOLD_SMALL = os.environ.get("OMNIPQ_SA_FOLD", "1") != "0"
+# backward apply
+_FOLD_SMALL = True
 
 
 def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None):
@@ -204,8 +199,8 @@ def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=N
 # consumers recompute y = W0 . x0 from the grouped coordinates (three FMAs per element), its BatchNorm statistics and its
 # weight gradient follow from the moments of x0 (csrc/xyz_layer.hip, gemm_bf16.hip: XyzGen).  Per step on sa1 this removes
 # one write and four reads of Y1, the write and read of dz1, of dY1, and two GEMM launches: 2.4 GB of 7.8 GB.
-# OMNIPQ_SA_XYZGEN=0 restores the stored first layer.
-XYZGEN = os.environ.get("OMNIPQ_SA_XYZGEN", "1") != "0"
+# XYZGEN = False restores the stored first layer (tests compare the two).
+XYZGEN = True
 xyzgen_uses = 0            # forwards that took the path (tests check that it is the one that ran)
 _lib.omnipq_gemm_nt_xyz_workspace_floats.restype = ctypes.c_longlong
 
@@ -239,47 +234,6 @@ def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     return C
 
 
-# BatchNorm backward without its own pass: the data-gradient GEMM of a conv+BN+ReLU layer generates dY = a (dz - mean(dz) -
-# yhat mean(dz yhat)) from (dX, Y) while it stages its operand and stores it for the weight gradient (csrc/gemm_bf16.hip:
-# DyGen).  OPT-IN (OMNIPQ_DYGEN=rows: the per-point stacks outside the SA stages, =all: the SA stages too), because measured
-# on MI355X, config 2, it does not pay: 28 apply launches of 9 us go, but the data-gradient GEMMs of the small stacks grow
-# from 10 to 15 us (prologue with the f64 totals, a second operand stream, every N-tile workgroup regenerating its rows: 5 x
-# at N = 288), and inside the SA stages the generator sits in the latency-critical K loop of the 128 x 128 tiles
-# (262144 x 256 x 256: 182 us against 112 + 42 for GEMM + apply).  Whole step as a hipGraph replay: 13.25 ms (rows),
-# 13.20 (all) against 13.12-13.16 with the separate apply pass.
-_DYGEN_MODE = os.environ.get("OMNIPQ_DYGEN", "0")
-DYGEN = _DYGEN_MODE in ("rows", "all", "1")
-DYGEN_SA = _DYGEN_MODE == "all"
-DYGEN_MAX_K = 512
-
-
-def gemm_nt_dygen(dX, lay, P, sums, world, Wt, N, below=None, below_sums=None):
-    """-> (dX_below bf16 [P][N], dY bf16 [P][C], dgamma, dbeta): the BatchNorm backward of `lay` (constants, pre-BN output
-    lay.Y, totals `sums` of THIS rank) fused into its data-gradient GEMM against Wt [N][C]; with `below`, the BN-backward
-    sums of that layer come out of the epilogue into below_sums (zero on entry)."""
-    C = lay.C
-    dev = dX.device
-    if world > 1 or _FORCE_COLLECTIVES:
-        dgamma, dbeta = affine_grads(sums, C)
-        _allreduce_(sums[:2], world)
-        gb = None
-    else:
-        gb = torch.empty((2, C), device=dev, dtype=torch.float32)
-        dgamma, dbeta = gb[1], gb[0]
-    dY = torch.empty((P, C), device=dev, dtype=torch.bfloat16)
-    out = torch.empty((P, N), device=dev, dtype=torch.bfloat16)
-    ws = None
-    if below is not None:
-        n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(P, N))
-        ws = torch.empty((n_ws,), device=dev, dtype=torch.float32) if n_ws else None
-    _call(_lib.omnipq_gemm_nt_bf16_dygen, dX, P, N, C, _p(dX), _p(lay.Y), C, _p(lay.a), _p(lay.b), _p(lay.mean),
-          _p(lay.invstd), _p(sums), ctypes.c_double(1.0 / (float(P) * world)), _p(dY), _p(gb), _p(Wt), C, _p(out), N,
-          _p(None if below is None else below.Y), _p(None if below is None else below.a),
-          _p(None if below is None else below.b), _p(None if below is None else below.mean),
-          _p(None if below is None else below.invstd), _p(below_sums), _p(ws))
-    return out, dY, dgamma, dbeta
-
-
 def _gemm_tn(A, B, M, N, P, colsum=None, below=None):
     """f32 C[M][N] = A[P][M]^T B[P][N]; colsum (f32 [M], zero on entry): also += column sums of A;
     below: B is that layer's pre-BN output and stands for relu(below.a * B + below.b)"""
@@ -304,140 +258,6 @@ class _TnProblem(ctypes.Structure):
 
 
 _lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
-
-
-class _RowGemmDesc(ctypes.Structure):
-    """include/omnipq_chain.h: omnipq_rowgemm_desc"""
-    _fields_ = [("P", ctypes.c_longlong), ("N", ctypes.c_int), ("K", ctypes.c_int), ("a_kind", ctypes.c_int),
-                ("epi_kind", ctypes.c_int),
-                ("A0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("arg", ctypes.c_void_p), ("lda", ctypes.c_int),
-                ("n", ctypes.c_int), ("m", ctypes.c_int), ("s", ctypes.c_int), ("cin", ctypes.c_int),
-                ("xyz", ctypes.c_void_p), ("new_xyz", ctypes.c_void_p), ("idx", ctypes.c_void_p),
-                ("inv_r", ctypes.c_float), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
-                ("a_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("fin_sums", ctypes.c_void_p),
-                ("fin_count", ctypes.c_double), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
-                ("conv_bias", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
-                ("a_out", ctypes.c_void_p), ("b_out", ctypes.c_void_p), ("mean_out", ctypes.c_void_p),
-                ("invstd_out", ctypes.c_void_p),
-                ("bwd_sums", ctypes.c_void_p), ("inv_count", ctypes.c_double), ("bn_a", ctypes.c_void_p),
-                ("bn_mean", ctypes.c_void_p), ("bn_invstd", ctypes.c_void_p), ("gb_out", ctypes.c_void_p),
-                ("split", ctypes.c_int), ("lda1", ctypes.c_int), ("crow", ctypes.c_void_p),
-                ("B", ctypes.c_void_p), ("ldb", ctypes.c_int),
-                ("C", ctypes.c_void_p), ("ldc", ctypes.c_int),
-                ("pool_s", ctypes.c_int), ("sums", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-                ("ymax", ctypes.c_void_p), ("ymin", ctypes.c_void_p), ("amax", ctypes.c_void_p), ("amin", ctypes.c_void_p),
-                ("below_Y", ctypes.c_void_p), ("below_a", ctypes.c_void_p), ("below_b", ctypes.c_void_p),
-                ("below_mean", ctypes.c_void_p), ("below_invstd", ctypes.c_void_p)]
-
-
-class _TnGenDesc(ctypes.Structure):
-    """include/omnipq_chain.h: omnipq_tn_gen_desc"""
-    _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_longlong), ("a_kind", ctypes.c_int),
-                ("b_kind", ctypes.c_int), ("A0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("arg", ctypes.c_void_p),
-                ("lda", ctypes.c_int), ("s", ctypes.c_int), ("bwd_sums", ctypes.c_void_p), ("inv_count", ctypes.c_double),
-                ("bn_a", ctypes.c_void_p), ("bn_mean", ctypes.c_void_p), ("bn_invstd", ctypes.c_void_p),
-                ("B0", ctypes.c_void_p), ("ldb", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p),
-                ("C", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("split", ctypes.c_int),
-                ("bcolsum", ctypes.c_void_p)]
-
-
-A_PLAIN, A_AFFINE, A_GATHER, A_DY, A_DY3, A_POOLX = 0, 1, 2, 3, 4, 5
-E_STORE, E_STORE_STATS, E_STORE_BNBWD = 0, 1, 2
-_lib.omnipq_sa_rowgemm_workspace_floats.restype = ctypes.c_longlong
-_lib.omnipq_sa_rowgemm_workspace_floats.argtypes = [ctypes.c_longlong, ctypes.c_int]
-
-# Row-tile GEMMs with operand generators (csrc/sa_chain.hip), OMNIPQ_SA_CHAIN=1.  Measured on the benchmark configuration
-# (tools/chain_check.py, round 2): 6.1 ms for the five SA stages against 5.7 ms for the per-layer kernels above -- the passes
-# it removes (gather, pool / BatchNorm backward apply) are paid back by two operand streams per generated gradient and by
-# load / compute / store phases that do not overlap inside a persistent workgroup (DESIGN.md section 4) -- so it is opt-in.
-CHAIN = os.environ.get("OMNIPQ_SA_CHAIN", "0") == "1"
-
-
-# Last layer of a large, narrow stage (sa1: 1 M positions, 128 -> 256 channels -- HBM bound) without its output: the forward
-# GEMM records statistics and ball extrema and stores nothing; the backward pass runs on the algebraic form of
-# include/omnipq_chain.h (omnipq_sa_pool_alg_*): neither Y_L nor dY_L ever exists (2.7 GB less HBM traffic per step on sa1).
-# Opt-in (OMNIPQ_SA_ALGEBRA=1): numerically equivalent (tests/test_gpu_chain.py; gradients within 7e-3 of the stored
-# dataflow on the benchmark stage) but not faster yet -- measured round 2 on sa1: forward 288 us (was 310), weight
-# gradient 335 (185), data gradient 358 (216 + 203 for the pool backward it absorbs), 125 us of small kernels: the
-# per-element epilogue work (statistics, ball extrema) and the generated operands are VALU bound where the stored
-# dataflow was HBM bound (DESIGN.md section 4).
-ALGEBRA = os.environ.get("OMNIPQ_SA_ALGEBRA", "0") == "1"
-ALGEBRA_MIN_ROWS = int(os.environ.get("OMNIPQ_SA_ALGEBRA_MIN_ROWS", str(1 << 19)))
-
-
-def _rowgemm_ks(K):
-    steps = K // 32
-    for ks in (10, 9, 8, 4, 1):
-        if steps % ks == 0:
-            return ks
-    return 1
-
-
-def algebra_ok(P, S, c_last, c_below):
-    """May the last layer (c_below -> c_last channels over P grouped positions, balls of S rows) take the algebraic path?
-    Worth it where the layer is bandwidth bound (many rows, few channels); the extended products need split = c_last to be
-    a multiple of the row-tile GEMM's K chunk and of the weight-gradient GEMM's 128-wide tiles."""
-    if not ALGEBRA or P < ALGEBRA_MIN_ROWS or 64 % S or c_last > 512 or c_below > 256 or c_last % 128 or c_below % 8:
-        return False
-    return c_last % (32 * _rowgemm_ks(c_last + c_below)) == 0 and c_last + c_below <= 1024
-
-
-def _chain_kpad(cin):
-    """Padded width of the grouped rows [features(cin), xyz(3), 0...] for the row-tile GEMM: a multiple of 32 whose
-    K-step count the kernel covers in at most two chunks of 8 / 9 / 10 steps (csrc/sa_chain.hip: rowgemm_ks)."""
-    steps = (cin + 3 + 31) // 32
-    while True:
-        if steps in (1, 4, 8, 9, 10) or any(steps % k == 0 and steps // k <= 2 for k in (10, 9, 8)):
-            return steps * 32
-        steps += 1
-
-
-_lib.omnipq_pack_b_elems.restype = ctypes.c_longlong
-
-
-def pack_b(W, N, K):
-    """bf16 [N][K] weights -> the fragment order omnipq_sa_rowgemm reads (csrc/sa_chain.hip: pack_b_kernel)"""
-    out = torch.empty((int(_lib.omnipq_pack_b_elems(N, K)),), device=W.device, dtype=torch.bfloat16)
-    _call(_lib.omnipq_pack_b, W, N, K, _p(W), W.stride(0), _p(out))
-    return out
-
-
-def _rowgemm(anchor, **kw):
-    """One omnipq_sa_rowgemm launch; keyword arguments are descriptor fields (tensors are passed as such).  `B` is
-    the row-major bf16 weight [N][K] (packed here) unless `B_packed` is given."""
-    d = _RowGemmDesc()
-    keep = []
-    if "B_packed" in kw:
-        kw["B"] = kw.pop("B_packed")
-    elif isinstance(kw.get("B"), torch.Tensor):
-        kw["B"] = pack_b(kw["B"], kw["N"], kw["K"])
-    for k, v in kw.items():
-        if isinstance(v, torch.Tensor):
-            keep.append(v)
-            v = v.data_ptr()
-        setattr(d, k, v)
-    if d.epi_kind != E_STORE and not d.workspace:
-        n_ws = int(_lib.omnipq_sa_rowgemm_workspace_floats(d.P, d.N))
-        if n_ws:
-            ws = torch.empty((n_ws,), device=anchor.device, dtype=torch.float32)
-            keep.append(ws)
-            d.workspace = ws.data_ptr()
-    _call(_lib.omnipq_sa_rowgemm, anchor, ctypes.byref(d))
-
-
-def _tn_gen(anchor, M, N, P, **kw):
-    """f32 C[M][N] = genA^T genB (csrc/sa_chain.hip: omnipq_gemm_tn_gen)"""
-    C = torch.empty((M, N), device=anchor.device, dtype=torch.float32)
-    ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=anchor.device, dtype=torch.float32)
-    d = _TnGenDesc()
-    d.M, d.N, d.P = M, N, P
-    for k, v in kw.items():
-        if isinstance(v, torch.Tensor):
-            v = v.data_ptr()
-        setattr(d, k, v)
-    d.C, d.workspace = C.data_ptr(), ws.data_ptr()
-    _call(_lib.omnipq_gemm_tn_gen, anchor, ctypes.byref(d))
-    return C
 
 
 _ZERO_TAILS = {}
@@ -1026,11 +846,6 @@ class FusedSAStage(torch.autograd.Function):
         kpad = _round_up(cin + 3, 32)
         inv_r = (1.0 / radius) if normalize_xyz else 1.0
         world = _world() if (training and _SYNC) else 1
-        if CHAIN and training and 64 % S == 0 and kpad <= 640 and L >= 1 and cin == cin_raw and \
-                all(params[3 * l].shape[0] <= 512 for l in range(L)):
-            return FusedSAStage._forward_chain(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz,
-                                               bn_cfg, *params)
-
         if features is None:
             feat_pm = None
         elif feat_pm is None or cin != cin_raw:
@@ -1077,8 +892,6 @@ class FusedSAStage(torch.autograd.Function):
                     ext16 = torch.empty((2, B * M, cout), device=dev, dtype=torch.bfloat16)
                     ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
                     pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
-                alg = l == L - 1 and l > 0 and X is None and pool is not None and layers[l - 1].fin is not None and \
-                    algebra_ok(P, S, cout, K)
                 if xgen and l == 0:
                     # never materialised (see XYZGEN): statistics from the moments of the grouped coordinates
                     lay.mom = torch.empty((12,), device=dev, dtype=torch.float64)
@@ -1087,18 +900,6 @@ class FusedSAStage(torch.autograd.Function):
                     lay.Y = None
                 elif xgen and l == 1:
                     lay.Y = gemm_nt_xyz(X0, layers[0], lay.Wp, P, cout, K, sums)
-                elif alg:
-                    # statistics and ball extrema only: the layer's output is never stored (see ALGEBRA above)
-                    prev = layers[l - 1]
-                    fsums, count, pg, pb, peps, pmom, prm, prv, _ = prev.fin
-                    prev.fin = None
-                    _rowgemm(prev.Y, P=P, N=cout, K=K, a_kind=A_AFFINE, epi_kind=E_STORE_STATS, A0=prev.Y, lda=prev.C,
-                             fin_sums=fsums, fin_count=count, gamma=pg, beta=pb, eps=peps, momentum=pmom,
-                             running_mean=prm, running_var=prv, a_out=prev.a, b_out=prev.b, mean_out=prev.mean,
-                             invstd_out=prev.invstd, B=lay.Wp, ldb=K, ldc=cout, sums=sums, pool_s=S, ymax=pool[1],
-                             ymin=pool[2], amax=pool[3], amin=pool[4])
-                    lay.Y = None
-                    ctx.alg_w = W2 if W2.dtype == torch.float32 and W2.is_contiguous() else W2.float().contiguous()
                 elif l > 0 and X is None:
                     # the layer below never stored relu(bn(Y)): this GEMM rebuilds it while staging its operand
                     lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums, pool=pool)
@@ -1175,7 +976,6 @@ class FusedSAStage(torch.autograd.Function):
         ctx.layers = layers
         ctx.X0 = X0
         ctx.xgen = xgen
-        ctx.chain = None
         ctx.cin_raw = cin_raw
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
         ctx.idx = idx
@@ -1189,190 +989,10 @@ class FusedSAStage(torch.autograd.Function):
         return out, twin
 
     @staticmethod
-    def _forward_chain(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, bn_cfg, *params):
-        """Training-mode forward on the row-tile GEMMs with operand generators (csrc/sa_chain.hip): the grouped
-        tensor X0 and the activations relu(bn(Y_l)) are generated while the consumer GEMM stages its operand; what
-        is stored per layer is the pre-BN output Y_l (the backward pass needs it)."""
-        dev = xyz.device
-        B, N, _ = xyz.shape
-        M, S = idx.shape[1], idx.shape[2]
-        P = B * M * S
-        L = len(params) // 3
-        cin = 0 if features is None else features.shape[1]
-        kpad = _chain_kpad(cin)
-        inv_r = (1.0 / radius) if normalize_xyz else 1.0
-        world = _world() if _SYNC else 1
-        if features is None:
-            feat_pm = None
-        elif feat_pm is None:
-            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16).contiguous()
-        xyz_c = xyz.detach().contiguous()
-        cen_c = new_xyz.detach().contiguous()
-
-        layers = []
-        pool = None
-        for l in range(L):
-            W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
-            rm, rv, nbt, momentum, eps = bn_cfg[l]
-            lay = _Layer()
-            W2 = W.detach().reshape(W.shape[0], -1)
-            cout = W2.shape[0]
-            K = kpad if l == 0 else W2.shape[1]
-            lay.K, lay.C = K, cout
-            lay.Wp, lay.Wt = prep_weight(W2, cout, K, rot=3 if l == 0 else 0, transpose=True,
-                                         persistent=is_persistent(W))
-            sums = zeros_f64(2, cout, dev)
-            lay.Y = torch.empty((P, cout), device=dev, dtype=torch.bfloat16)
-            stats = torch.empty((4, cout), device=dev)                # a | b | mean | invstd
-            lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
-            kw = dict(P=P, N=cout, K=K, epi_kind=E_STORE_STATS, B=lay.Wp, ldb=K, C=lay.Y, ldc=cout, sums=sums)
-            if l == L - 1:
-                ext16 = torch.empty((2, B * M, cout), device=dev, dtype=torch.bfloat16)
-                ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
-                pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
-                kw.update(pool_s=S, ymax=ext16[0], ymin=ext16[1], amax=ext8[0], amin=ext8[1])
-            if l == 0:
-                kw.update(a_kind=A_GATHER, A0=feat_pm, n=N, m=M, s=S, cin=cin, xyz=xyz_c, new_xyz=cen_c, idx=idx,
-                          inv_r=inv_r)
-            else:
-                prev = layers[l - 1]
-                fsums, count, pg, pb, peps, pmom, prm, prv, _ = prev.fin
-                prev.fin = None
-                kw.update(a_kind=A_AFFINE, A0=prev.Y, lda=prev.C, fin_sums=fsums, fin_count=count, gamma=pg, beta=pb,
-                          eps=peps, momentum=pmom, running_mean=prm, running_var=prv, a_out=prev.a, b_out=prev.b,
-                          mean_out=prev.mean, invstd_out=prev.invstd)
-            _rowgemm(xyz_c, **kw)
-            _allreduce_(sums, world)
-            lay.X = None
-            lay.fin = (sums, float(P) * world, gamma.detach(), beta.detach(), eps, momentum, rm, rv, None)
-            bump(nbt)
-            layers.append(lay)
-
-        last = layers[-1]
-        fsums, count, pg, pb, peps, pmom, prm, prv, _ = last.fin
-        last.fin = None
-        _call(_lib.omnipq_bn_finalize, last.Y, last.C, ctypes.c_double(count), _p(fsums), _p(pg), _p(pb),
-              ctypes.c_float(peps), ctypes.c_float(pmom), _p(prm), _p(prv), _p(last.a), _p(last.b), _p(last.mean),
-              _p(last.invstd), _p(None))
-        out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
-        out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
-        arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
-        ysel = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
-        _call(_lib.omnipq_sa_pool_select, last.Y, ctypes.c_longlong(B * M), last.C, _p(pool[1]), _p(pool[2]),
-              _p(pool[3]), _p(pool[4]), _p(last.a), _p(last.b), _p(out_f32), _p(out_pm), _p(arg), _p(ysel))
-        out = out_f32.transpose(1, 2)
-
-        ctx.layers = layers
-        ctx.X0 = None
-        ctx.chain = (xyz_c, cen_c, feat_pm)
-        ctx.cin_raw = cin
-        ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
-        ctx.idx = idx
-        ctx.out_pm, ctx.arg, ctx.ysel = out_pm, arg, ysel
-        ctx.has_features = features is not None
-        ctx.feat_dtype = features.dtype if features is not None else None
-        ctx.training = True
-        twin = out_pm.view(B, M, last.C)
-        ctx.mark_non_differentiable(twin)
-        ctx.set_materialize_grads(False)        # no zero tensor of the twin's size per backward (its gradient is never used)
-        return out, twin
-
-    @staticmethod
-    def _backward_chain(ctx, g_out):
-        """Backward of _forward_chain: neither the max-pool gradient nor any BatchNorm-backward result dY_l is
-        written -- the weight- and data-gradient GEMMs of layer l generate dY_l = alpha dz_l + beta Y_l + gamma while
-        staging it (dz_L from the per-ball gradient and arg-max, dz_l<L = the masked ReLU gradient the layer above
-        stored), and the data-gradient GEMM's epilogue stores dz_{l-1} and its BatchNorm-backward totals."""
-        B, N, M, S, P, cin, kpad, inv_r, world = ctx.geom
-        layers = ctx.layers
-        L = len(layers)
-        dev = g_out.device
-        g_out = g_out.float().transpose(1, 2).contiguous()      # position-major [B*M][C] (no-op for a view)
-        inv_count = 1.0 / (float(P) * world)
-        grads = [None] * (3 * L)
-        sync = world > 1 or _FORCE_COLLECTIVES
-        xyz_c, cen_c, feat_pm = ctx.chain
-
-        last = layers[-1]
-        sums = torch.empty((2, last.C), device=dev, dtype=torch.float64)
-        gz = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
-        _call(_lib.omnipq_sa_pool_bwd_stats_gz, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
-              _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), _p(gz))
-        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or \
-            (ctx.has_features and ctx.needs_input_grad[2])
-        X0 = None
-        d_feat = d_xyz = d_cen = None
-        dz = None
-        for l in range(L - 1, -1, -1):
-            lay = layers[l]
-            # dgamma / dbeta of layer l are this rank's totals (DDP averages them): taken before the all-reduce
-            gb = None
-            if sync or (l == 0 and not need_in):
-                grads[3 * l + 1], grads[3 * l + 2] = affine_grads(sums, lay.C)
-                _allreduce_(sums, world)
-            else:
-                gb = torch.empty((2, lay.C), device=dev, dtype=torch.float32)
-                grads[3 * l + 1], grads[3 * l + 2] = gb[1], gb[0]
-            if l == L - 1:
-                akw = dict(a_kind=A_DY3, A0=gz, A1=lay.Y, arg=ctx.arg, lda=lay.C, s=S)
-            else:
-                akw = dict(a_kind=A_DY, A0=dz, A1=lay.Y, lda=lay.C)
-            akw.update(bwd_sums=sums, inv_count=inv_count, bn_a=lay.a, bn_mean=lay.mean, bn_invstd=lay.invstd)
-            # weight gradient dW_l = dY_l^T X_{l-1}
-            if l > 0:
-                prev = layers[l - 1]
-                dWp = _tn_gen(lay.Y, lay.C, lay.K, P, b_kind=A_AFFINE, B0=prev.Y, ldb=prev.C, ba=prev.a, bb=prev.b, **akw)
-            else:
-                X0 = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
-                _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
-                      _p(ctx.idx), _p(feat_pm), _p(X0))
-                dWp = _tn_gen(lay.Y, lay.C, lay.K, P, b_kind=A_PLAIN, B0=X0, ldb=kpad, **akw)
-            wk = cin + 3 if l == 0 else lay.K
-            grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
-            if l == 0 and not need_in:
-                break
-            if l > 0:
-                prev = layers[l - 1]
-                nsums = zeros_f64(2, prev.C, dev)
-                dzn = torch.empty((P, prev.C), device=dev, dtype=torch.bfloat16)
-                _rowgemm(lay.Y, P=P, N=prev.C, K=lay.C, epi_kind=E_STORE_BNBWD, B=lay.Wt, ldb=lay.C, C=dzn, ldc=prev.C,
-                         sums=nsums, below_Y=prev.Y, below_a=prev.a, below_b=prev.b, below_mean=prev.mean,
-                         below_invstd=prev.invstd, gb_out=gb, **akw)
-                dz, sums = dzn, nsums
-            else:
-                dX = torch.empty((P, kpad), device=dev, dtype=torch.bfloat16)
-                # at most 512 columns per launch (sa3 / sa4: 544 = 256 + 288)
-                c0 = 0
-                while c0 < kpad:
-                    nc = kpad - c0 if kpad - c0 <= 512 else _round_up((kpad - c0) // 2, 32)
-                    _rowgemm(lay.Y, P=P, N=nc, K=lay.C, epi_kind=E_STORE, B=lay.Wt[c0:c0 + nc],
-                             ldb=lay.C, C=dX.data_ptr() + 2 * c0, ldc=kpad, gb_out=gb if c0 == 0 else None, **akw)
-                    c0 += nc
-                want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-                dfeat_pm = torch.empty((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
-                    else None
-                if want_xyz:
-                    d_xyz = torch.empty((B, N, 3), device=dev)
-                    d_cen = torch.empty((B, M, 3), device=dev)
-                offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
-                order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
-                scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
-                _call(_lib.omnipq_sa_build_csr, dX, B, N, M, S, _p(ctx.idx), _p(offsets), _p(order), _p(scratch))
-                _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
-                      _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
-                if dfeat_pm is not None:
-                    d_feat = dfeat_pm.transpose(1, 2).to(ctx.feat_dtype)
-        ctx.layers = None
-        ctx.chain = None
-        return (d_xyz, d_cen, d_feat, None, None, None, None, None, None, *grads)
-
-    @staticmethod
     def backward(ctx, g_out, _g_twin=None):
         if g_out is None:                       # the stage's output took no part in the loss
             return (None,) * ctx.n_inputs
         with _tagged("@sa"):
-            if getattr(ctx, "chain", None) is not None:
-                return FusedSAStage._backward_chain(ctx, g_out)
             return FusedSAStage._backward(ctx, g_out)
 
     @staticmethod
@@ -1388,84 +1008,35 @@ class FusedSAStage(torch.autograd.Function):
         grads = [None] * (3 * L)
 
         last = layers[-1]
-        top = L - 1                  # first layer the generic loop below handles
-        if last.Y is None:
-            # ---- algebraic last layer (see ALGEBRA): dW_L and dz_{L-1} from (per-ball gradient, arg-max, X_{L-1}) --------
-            prev = layers[L - 2]
-            C, Cin = last.C, prev.C
-            sums = torch.empty((2, C), device=dev, dtype=torch.float64)
-            gz = torch.empty((B * M, C), device=dev, dtype=torch.bfloat16)
-            _call(_lib.omnipq_sa_pool_bwd_stats_gz, g_out, ctypes.c_longlong(B * M), C, _p(ctx.ysel), _p(last.mean),
-                  _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), _p(gz))
-            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, C)      # local totals, before the all-reduce
-            _allreduce_(sums, world)
-            inv_count = ctypes.c_double(1.0 / (float(P) * world))
-            bext = torch.empty((Cin, C + Cin), device=dev, dtype=torch.bfloat16)
-            crow = torch.empty((Cin,), device=dev, dtype=torch.float32)
-            _call(_lib.omnipq_sa_pool_alg_consts, bext, C, Cin, _p(ctx.alg_w), _p(last.a), _p(last.mean), _p(last.invstd),
-                  _p(sums), inv_count, _p(bext), _p(crow))
-            cs = zeros_f32(Cin, dev)
-            ext = _tn_gen(prev.Y, C + Cin, Cin, P, a_kind=A_POOLX, b_kind=A_AFFINE, A0=gz, arg=ctx.arg, lda=C, s=S, split=C,
-                          B0=prev.Y, ldb=Cin, ba=prev.a, bb=prev.b, bcolsum=cs)
-            dW = torch.empty((C, Cin, 1, 1), device=dev, dtype=torch.float32)
-            _call(_lib.omnipq_sa_pool_alg_dw, dW, C, Cin, _p(ctx.alg_w), _p(last.a), _p(last.mean), _p(last.invstd), _p(sums),
-                  inv_count, _p(ext), _p(cs), _p(dW))
-            grads[3 * (L - 1)] = dW
-            nsums = zeros_f64(3, Cin, dev)
-            dY = torch.empty((P, Cin), device=dev, dtype=torch.bfloat16)
-            _rowgemm(prev.Y, P=P, N=Cin, K=C + Cin, a_kind=A_POOLX, epi_kind=E_STORE_BNBWD, A0=gz, A1=prev.Y, arg=ctx.arg,
-                     lda=C, lda1=Cin, s=S, split=C, a_in=prev.a, b_in=prev.b, crow=crow, B=bext, ldb=C + Cin, C=dY, ldc=Cin,
-                     sums=nsums, below_Y=prev.Y, below_a=prev.a, below_b=prev.b, below_mean=prev.mean,
-                     below_invstd=prev.invstd)
-            grads[3 * (L - 2) + 1], grads[3 * (L - 2) + 2] = bn_backward_apply(dY, prev, P, Cin, total, nsums, world)
-            ctx.alg_w = None
-            top = L - 2
-        elif ctx.ysel is not None:
-            sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
+        sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
+        if ctx.ysel is not None:
             _call(_lib.omnipq_sa_pool_bwd_stats_sel, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
                   _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums))
         else:
-            sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
             _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
                   _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
-        if last.Y is not None:
-            # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
-            dY = torch.empty_like(last.Y)
-            if world > 1 or _FORCE_COLLECTIVES or not _FOLD_SMALL:
-                grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
-                _allreduce_(sums[:2], world)
-                _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
-                      _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
-            else:
-                gb3 = torch.empty((2, last.C), device=dev, dtype=torch.float32)      # dbeta | dgamma, written by the apply
-                grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = gb3[1], gb3[0]
-                _call(_lib.omnipq_sa_pool_bwd_apply_gb, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
-                      _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY), _p(gb3))
+        # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
+        dY = torch.empty_like(last.Y)
+        if world > 1 or _FORCE_COLLECTIVES or not _FOLD_SMALL:
+            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
+            _allreduce_(sums[:2], world)
+            _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
+                  _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY))
+        else:
+            gb3 = torch.empty((2, last.C), device=dev, dtype=torch.float32)      # dbeta | dgamma, written by the apply
+            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = gb3[1], gb3[0]
+            _call(_lib.omnipq_sa_pool_bwd_apply_gb, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
+                  _p(last.invstd), _p(sums), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(dY), _p(gb3))
 
         d_feat = d_xyz = d_cen = None
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (ctx.has_features and ctx.needs_input_grad[2])
         xgen = getattr(ctx, "xgen", False)
         pend = None                  # BatchNorm-backward totals of layer l when `dY` still holds dX (gradient w.r.t. its ReLU output)
-        for l in range(top, -1, -1):
+        for l in range(L - 1, -1, -1):
             lay = layers[l]
-            dX_in = None             # the data gradient of this layer, if the fused GEMM below already produced it
             if pend is not None:
-                follows = l > 0 or need_in
-                if DYGEN_SA and follows and lay.C <= DYGEN_MAX_K and not (xgen and l == 1):
-                    # BatchNorm backward generated inside this layer's data-gradient GEMM (DyGen): no apply pass
-                    prev = layers[l - 1] if l > 0 else None
-                    nsums = zeros_f64(3, prev.C, dev) if (prev is not None and not (xgen and l - 1 == 0)) else None
-                    if l > 0 and nsums is None:
-                        prev = None                      # cannot happen: l == 1 under xgen is excluded above
-                    dX_in, dY, grads[3 * l + 1], grads[3 * l + 2] = gemm_nt_dygen(
-                        dY, lay, P, pend, world, lay.Wt, lay.K, below=prev, below_sums=nsums)
-                    pend = nsums
-                else:
-                    grads[3 * l + 1], grads[3 * l + 2] = bn_backward_apply(dY, lay, P, lay.C, total, pend, world)
-                    pend = None
-                fused_here = dX_in is not None
-            else:
-                fused_here = False
+                grads[3 * l + 1], grads[3 * l + 2] = bn_backward_apply(dY, lay, P, lay.C, total, pend, world)
+                pend = None
             if l == 1 and xgen:
                 # the layer below is the never-materialised first layer (see XYZGEN): this layer's weight gradient
                 # contracts against activations rebuilt from the grouped coordinates, and the data-gradient GEMM is
@@ -1502,15 +1073,12 @@ class FusedSAStage(torch.autograd.Function):
             if l == 0 and not need_in:
                 break
             if l > 0:
-                if fused_here:
-                    dY = dX_in                                   # dX of layer l - 1; its totals are `pend`
-                else:
-                    prev = layers[l - 1]
-                    pend = zeros_f64(3, prev.C, dev)
-                    # Wt = [K][Cout]; the BN-backward sums of the layer below come out of the same pass
-                    dY = _gemm_nt_bnbwd(dY, lay.Wt, P, lay.K, lay.C, prev, pend)
+                prev = layers[l - 1]
+                pend = zeros_f64(3, prev.C, dev)
+                # Wt = [K][Cout]; the BN-backward sums of the layer below come out of the same pass
+                dY = _gemm_nt_bnbwd(dY, lay.Wt, P, lay.K, lay.C, prev, pend)
             else:
-                dX = dX_in if fused_here else _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)
+                dX = _gemm_nt(dY, lay.Wt, P, lay.K, lay.C)
                 want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
                 dfeat_pm = torch.empty((B, N, cin), device=dev) if (ctx.has_features and ctx.needs_input_grad[2]) \
                     else None

@@ -8,9 +8,10 @@ packed projections, deferred grouped weight gradients: the composition bench.py 
 the same boundaries.  Every stage therefore sees the reference's input bit for bit, errors cannot compound, and the
 bounds below are SINGLE-STAGE bf16 bounds (8-bit mantissa through <= 3 conv+BN+ReLU layers or one decoder layer):
 
-    stage outputs and float end_points   rel-L2 <= OUT_TOL
+    stage outputs and float end_points   rel-L2 <= OUT_TOL, and <= 1.3 x torch's bf16 autocast on the same tensor + 2e-3
     integer end_points                   exact
-    every parameter gradient             cosine >= GRAD_COS against the reference's f32 gradient
+    every parameter gradient             cosine >= GRAD_COS against the reference's f32 gradient, and
+                                         1 - cos <= 2 x (1 - cos of torch's bf16 autocast, worst tensor of the segment) + 5e-3
 
 A kernel that is 30 % wrong, a transposed layout, a mis-paired launch or a dropped weight-gradient fails these; the
 un-forced whole-model test (test_gpu_bf16_fixtures.py) could not.
@@ -25,8 +26,10 @@ from test_gpu_bf16_fixtures import composed, cosine, rel_l2
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-OUT_TOL = 1.0e-2          # one stage in bf16: measured 2e-3 .. 6e-3 (printed by the test)
-GRAD_COS = 0.99           # measured >= 0.995 on every tensor with a non-vanishing gradient
+OUT_TOL = 1.5e-2          # one segment in bf16.  Measured (MI355X, round 3): SA / FP / voting stages 4.2e-3 .. 7.4e-3, decoder
+                          # layers (projections + self/cross attention + FFN + 3 LayerNorms) 8.2e-3 .. 1.05e-2, head outputs
+                          # 5e-3 .. 9.4e-3 -- torch's own bf16 autocast over the composition: the same figures within 10 %
+GRAD_COS = 0.975          # measured: worst tensor per segment 0.983 (sa4 / sa3 BatchNorm biases) .. 0.998; torch autocast 0.985
 GRAD_FLOOR = 1e-5         # relative to the largest gradient norm: below it a gradient is analytically zero (conv / linear
                           # biases in front of a BatchNorm) and its direction is rounding noise on both sides
 
@@ -176,7 +179,7 @@ def test_every_bf16_stage_matches_the_reference_at_single_stage_tolerance():
     ac_rows = dict(ac["rows"])
     print()
     for k, e in got["rows"]:
-        if not k.startswith("ep.") or e > 0.5 * OUT_TOL:
+        if not k.startswith("ep.") or e > 0.6 * OUT_TOL:
             print(f"  {k:40s} rel-L2 vs reference: fused bf16 {e:.2e} | torch autocast {ac_rows[k]:.2e}")
     print(f"  outputs: worst {got['worst_out']:.2e} (autocast {ac['worst_out']:.2e}) over {len(got['rows'])} tensors; "
           f"{got['n_int']} integer end_points exact")
@@ -188,7 +191,10 @@ def test_every_bf16_stage_matches_the_reference_at_single_stage_tolerance():
     assert got["n_int"] >= 4 and got["n_float"] >= 90 and got["n_grad"] >= 300
     for k, e in got["rows"]:
         assert e <= OUT_TOL, (k, e)
+        assert e <= 1.3 * ac_rows[k] + 2e-3, (k, e, ac_rows[k])
     assert got["worst_cos"] >= GRAD_COS, (got["worst_name"], got["worst_cos"])
+    for seg, c in got["per_seg"].items():
+        assert (1 - c) <= 2 * (1 - ac["per_seg"][seg]) + 5e-3, (seg, c, ac["per_seg"][seg])
 
 
 def test_f32_mode_matches_the_forced_reference_at_1e_4():
