@@ -103,16 +103,9 @@ def build_model(extra_channels):
 def loss_of(end_points):
     """sum over the float end_points that require grad of mean(v)  (SURVEY.md 8d), evaluated as ONE dot
     product  <cat(v), cat(1/numel(v))>  instead of ~110 separate mean + add kernels."""
-    if os.environ.get("OMNIPQ_BENCH_LOSS") == "separate":      # the literal form, one mean per tensor
-        total = 0.0
-        for k in sorted(end_points.keys()):
-            v = end_points[k]
-            if v.is_floating_point() and v.requires_grad:
-                total = total + v.float().mean()
-        return total
     parts = [end_points[k] for k in sorted(end_points.keys())
              if end_points[k].is_floating_point() and end_points[k].requires_grad]
-    if parts and parts[0].is_cuda and os.environ.get("OMNIPQ_BENCH_LOSS") != "dot" and \
+    if parts and parts[0].is_cuda and \
             all(p.dim() <= 4 and p.dtype in (torch.float32, torch.bfloat16) for p in parts):
         total = 0.0
         for i in range(0, len(parts), 72):
@@ -442,7 +435,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             return teacher({"point_clouds": batch})            # train mode, no grad (train.py:462,490-491)
 
     # DistributedDataParallel (--eager-dp ddp) needs the per-parameter hooks: no deferral there
-    defer = os.environ.get("OMNIPQ_DEFER_WGRADS", "1") != "0" and not ddp
+    defer = not ddp
     # eager multi-rank steps without DDP: the same single flat all-reduce as in the captured step
     flat_eager = FlatGradients(net, world) if (distributed and not ddp) else None
 

@@ -171,21 +171,6 @@ int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const
                               int ldc, const void *Y, const float *a, const float *b, const float *mean,
                               const float *invstd, double *sums, float *workspace, void *stream);
 
-/* Data-gradient GEMM whose operand is the BatchNorm-backward result of its layer, generated while the tile is staged:
- *   dY = a (dz - mean(dz) - yhat mean(dz yhat)),  dz = dX * [a y + b > 0],  yhat = (y - mean) invstd
- *   C[M][N] = dY[M][K] B[N][K]^T  (bf16)
- * from dX (gradient w.r.t. the layer's ReLU output) and Y (its pre-BN output), both [M][K] with pitch lda, the layer's
- * constants and totals (sums = double[2][K]: sum dz, sum dz yhat; inv_count = 1 / rows, global under SyncBatchNorm).
- * Replaces omnipq_bn_bwd_apply_fused + omnipq_gemm_nt_bf16(_bnbwd): dY_out (may be NULL) receives the generated rows for the
- * layer's weight gradient, gb_out (may be NULL) = float[2][K] the totals as f32 (dbeta | dgamma).  below_Y != NULL: the
- * epilogue forms the sums of the layer below as omnipq_gemm_nt_bf16_bnbwd does (below_sums double[2][N], zero on entry;
- * workspace omnipq_gemm_nt_stats_workspace_floats(M, N)).  K <= 512. */
-int omnipq_gemm_nt_bf16_dygen(int M, int N, int K, const void *dX, const void *Y, int lda, const float *a, const float *b,
-                              const float *mean, const float *invstd, const double *sums, double inv_count, void *dY_out,
-                              float *gb_out, const void *B, int ldb, void *C, int ldc, const void *below_Y,
-                              const float *below_a, const float *below_b, const float *below_mean,
-                              const float *below_invstd, double *below_sums, float *workspace, void *stream);
-
 /* ---- The first layer of a coordinates-only stage WITHOUT its output (sa1: Conv2d 3 -> C0 + BatchNorm + ReLU over all
  * grouped positions; reference pointnet2_modules.py:243-257, pytorch_utils.py:11-36).  y[p][c] = W0[c] . x0[p] is three
  * FMAs: its consumers recompute it from the grouped coordinates X0 (bf16 [P][ldx], columns 0..2, ldx % 4 == 0: the

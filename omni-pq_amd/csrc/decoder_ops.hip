@@ -365,7 +365,7 @@ extern "C" int omnipq_add_dropout_layernorm(long long R, int C, const float *x, 
 namespace omnipq {
 static long long ln_bwd_blocks(long long R) {
   long long blocks = (R + 3) / 4;
-  static const long long cap = getenv("OMNIPQ_LN_BLOCKS") ? atoll(getenv("OMNIPQ_LN_BLOCKS")) : 512;
+  constexpr long long cap = 512;      // measured: 128 / 256 / 1024 blocks are slower
   return blocks > cap ? cap : blocks;   // with atomics each block ends with 2C of them; 512 blocks measured best
 }
 }  // namespace omnipq

@@ -552,7 +552,7 @@ extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *
   const int G4 = (n + per4 - 1) / per4, G8 = (n + per8 - 1) / per8;
   // 8 points per thread by default: a round costs the same (the cross-workgroup exchange dominates it) while
   // the scene occupies half as many CUs -- CUs the overlapped backward pass of the previous batch can use
-  static const bool prefer8 = !(getenv("OMNIPQ_FPS_PPT") && atoi(getenv("OMNIPQ_FPS_PPT")) == 4);
+  constexpr bool prefer8 = true;
   if (prefer8 && G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);
   if (G4 <= 12) return launch_multi<4>(b, n, m, bs_mask, G4, dataset, temp, idxs, stream);
   if (G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);

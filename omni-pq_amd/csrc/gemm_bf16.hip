@@ -137,45 +137,6 @@ __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
 // its 8 MFMAs per K-step back to back (0.21 of the 0.36 us a K-step takes) -- they are bound by the MFMA issue of ONE
 // wave, not by loads (three K-steps of register prefetch changed nothing).  64 x 64 tiles put four times as many
 // waves to work, 2 MFMAs per step each.
-// PF2: operand tiles are fetched TWO K-steps ahead (two named register sets, the loop unrolled by two): with one step of
-// prefetch and two or three workgroups per CU a K-step lasts as long as a global load takes to come back (the SA layers'
-// 8-step contractions ran at 13 % MFMA utilisation: 16 us per 128 x 128 tile against 0.85 us of matrix work).
-// DYG: the A operand of a data-gradient GEMM is the BatchNorm-backward result of its layer,
-//   dY = a (dz - mean(dz) - yhat mean(dz yhat)),  dz = dX * [a y + b > 0],  yhat = (y - mu) invstd,
-// GENERATED while the tile is staged from the two tensors it is a function of -- dX (the gradient w.r.t. the layer's ReLU
-// output, the `A` argument) and Y (its pre-BN output) -- and the layer's totals: per channel (a, b, beta', gamma') with
-// dY = a dz + beta' y + gamma'.  The separate apply pass (read dX, read Y, write dY: one launch per BatchNorm layer, 55 per
-// step) disappears; the workgroups of the first N-tile also store the generated rows, because the layer's weight gradient
-// (deferred, grouped launch) contracts against dY too.  Workgroup 0 publishes the totals as f32 (dbeta | dgamma).
-struct DyGen {
-  const bf16_t *Y;                       // [M][lda]
-  const float *a, *b, *mean, *invstd;    // [K]
-  const double *sums;                    // [2][K]: sum dz, sum dz yhat over 1 / inv_count rows
-  double inv_count;
-  bf16_t *dY_out;                        // [M][lda] or NULL
-  float *gb_out;                         // [2][K] or NULL
-};
-constexpr int kDyMaxK = 512;
-
-__device__ __forceinline__ unsigned dy_pair(unsigned dxw, unsigned yw, const f32x4 &c0, const f32x4 &c1) {
-  const float d0 = __builtin_bit_cast(float, dxw << 16), d1 = __builtin_bit_cast(float, dxw & 0xffff0000u);
-  const float y0 = __builtin_bit_cast(float, yw << 16), y1 = __builtin_bit_cast(float, yw & 0xffff0000u);
-  const float z0 = __builtin_fmaf(c0[0], y0, c0[1]) > 0.f ? d0 : 0.f;
-  const float z1 = __builtin_fmaf(c1[0], y1, c1[1]) > 0.f ? d1 : 0.f;
-  const float lo = __builtin_fmaf(c0[0], z0, __builtin_fmaf(c0[2], y0, c0[3]));
-  const float hi = __builtin_fmaf(c1[0], z1, __builtin_fmaf(c1[2], y1, c1[3]));
-  return pack_bf16x2(lo, hi);
-}
-
-__device__ __forceinline__ uint4 dy_chunk(const uint4 &dx, const uint4 &y, const f32x4 *tab) {
-  uint4 o;
-  o.x = dy_pair(dx.x, y.x, tab[0], tab[1]);
-  o.y = dy_pair(dx.y, y.y, tab[2], tab[3]);
-  o.z = dy_pair(dx.z, y.z, tab[4], tab[5]);
-  o.w = dy_pair(dx.w, y.w, tab[6], tab[7]);
-  return o;
-}
-
 // KRES (T = 64, K <= 320, no split): the per-point layers outside the SA stages are 64..320 workgroups of nine K-steps, and
 // with one step of prefetch every K-step lasts as long as a load from L2 takes to come back (~0.5 us): the main loop is nine
 // round trips.  Here ALL K-steps of both operand tiles are requested at once (18 loads of 16 bytes per lane in flight), put
@@ -185,15 +146,14 @@ constexpr int kResMaxSteps = 10;
 
 // The workgroup program of every NT GEMM variant; `bid` = this workgroup's index within ITS problem (blockIdx.x of a
 // plain launch; the pair launch below runs two problems in one grid).
-template <bool OUT_F32, int STATS, bool AFF, int T, bool PF2, int XG, bool KRES, bool DYG>
+template <bool OUT_F32, int STATS, bool AFF, int T, int XG, bool KRES>
 __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
                                              void *__restrict__ Cout, const float *__restrict__ bias,
                                              void *__restrict__ stats_out, const BnBwdEpilogue &bn, const AffineIn &aff,
-                                             const PoolOut &pool, const XyzGen &xg, const DyGen &dyg, const int bid) {
+                                             const PoolOut &pool, const XyzGen &xg, const int bid) {
   static_assert(T == 128 || T == 64, "tile edge");
-  static_assert(!DYG || (!AFF && !PF2 && XG == 0 && !OUT_F32), "DYG variants");
-  static_assert(XG == 0 || (XG == 1 && AFF && T == 128 && !PF2) || (XG == 2 && STATS == 4 && T == 128), "XG variants");
-  static_assert(!KRES || (T == 64 && !PF2 && XG == 0 && !OUT_F32), "KRES variants");
+  static_assert(XG == 0 || (XG == 1 && AFF && T == 128) || (XG == 2 && STATS == 4 && T == 128), "XG variants");
+  static_assert(!KRES || (T == 64 && XG == 0 && !OUT_F32), "KRES variants");
   constexpr int NS = XG == 2 ? 5 : 2;          // column sums per statistics epilogue
   constexpr int NI = T / 64;                   // 32 x 32 MFMA blocks per wave and dimension
   constexpr int CP = T, CPF = T + 4;           // C-tile pitches (bf16 / f32 elements).  bf16: NO padding -- the 16-byte reads of the
@@ -229,7 +189,6 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   auto w0_at = [&](int c) -> f32x4 * {
     return PADW0 ? reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + c * (GPITCH / 2) + 16) : s_w0_mem + c;
   };
-  __shared__ __attribute__((aligned(16))) f32x4 s_dy[DYG ? kDyMaxK : 1];              // (a, b, beta', gamma') per A channel
 
   // XCD-aware tile order: id % 8 picks the XCD, the N-tiles of one M-tile stay on it
   const int id = bid;
@@ -294,23 +253,6 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
       x0r[i][2] = __builtin_bit_cast(float, v.y << 16);
     }
   }
-  const bf16_t *gy[NI];                        // DYG: the Y rows that go with the dX rows ga[]
-  if (DYG) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) gy[i] = dyg.Y + (ga[i] - A);
-    const bool first = bid == 0 && blockIdx.z == 0;
-    for (int c = tid; c < g.K; c += 256) {
-      const double s0 = dyg.sums[c], s1 = dyg.sums[g.K + c];
-      const float m1 = (float)(s0 * dyg.inv_count), m2 = (float)(s1 * dyg.inv_count);
-      const float av = dyg.a[c], is = dyg.invstd[c];
-      s_dy[c] = f32x4{av, dyg.b[c], -av * m2 * is, av * (m2 * is * dyg.mean[c] - m1)};
-      if (first && dyg.gb_out) {
-        dyg.gb_out[c] = (float)s0;
-        dyg.gb_out[g.K + c] = (float)s1;
-      }
-    }
-    __syncthreads();
-  }
   if (AFF) {
     const bool first = bid == 0 && blockIdx.z == 0;
     for (int c = tid; c < g.K; c += 256) {
@@ -354,15 +296,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
 
   NT_STAMP(1);
   uint4 ra[NI], rb[NI];
-  uint4 ra2[NI], rb2[NI];            // second register set (PF2)
-  uint4 ry[DYG ? NI : 1];            // DYG: the Y tile that goes with ra
-  const bool dy_store = DYG && nt == 0 && dyg.dY_out != nullptr;
 #define OMNIPQ_LOAD_TILES(RA, RB, KT)                                 \
   {                                                                   \
     const int koff_ = (KT) * GBK;                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {               \
       if (XG != 1) RA[i_] = ldg16(ga[i_] + koff_);                    \
-      if (DYG) ry[i_] = ldg16(gy[i_] + koff_);                        \
       RB[i_] = ldg16(gb[i_] + koff_);                                 \
     }                                                                 \
   }
@@ -370,14 +308,6 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   {                                                                                                     \
     bf16_t *sa_ = stage + (BUF) * (2 * T * GPITCH);                                                     \
     bf16_t *sb_ = sa_ + T * GPITCH;                                                                     \
-    if (DYG) {                                                                                          \
-      const int k0_ = kbeg + (KT) * GBK + skc[0] * 8;                                                   \
-      _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                               \
-        RA[i_] = dy_chunk(RA[i_], ry[i_], s_dy + k0_);                                                  \
-        if (dy_store && m0 + srow[i_] < g.M)                                                            \
-          *reinterpret_cast<uint4 *>(dyg.dY_out + (ga[i_] - A) + (KT) * GBK) = RA[i_];                  \
-      }                                                                                                 \
-    }                                                                                                   \
     if (AFF) {                                                                                          \
       /* a, b of this thread's 8 channels of K-step KT (both chunks share them): four LDS reads */      \
       const int k0_ = kbeg + (KT) * GBK + skc[0] * 8;                                                   \
@@ -439,12 +369,10 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
     const int KP = nk * GBK + 8;               // row pitch: same residue mod 128 bytes as GPITCH, conflict-free b128 reads
     bf16_t *sa = stage, *sb = stage + T * KP;
     uint4 qa[kResMaxSteps], qb[kResMaxSteps];
-    uint4 qy[DYG ? kResMaxSteps : 1];
 #pragma unroll
     for (int kt = 0; kt < kResMaxSteps; ++kt)
       if (kt < nk) {
         qa[kt] = ldg16(ga[0] + kt * GBK);
-        if (DYG) qy[kt] = ldg16(gy[0] + kt * GBK);
         qb[kt] = ldg16(gb[0] + kt * GBK);
       }
 #pragma unroll
@@ -459,11 +387,6 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
           qa[kt].y = affine_relu_pair(qa[kt].y, fa0[2], fb0[2], fa0[3], fb0[3]);
           qa[kt].z = affine_relu_pair(qa[kt].z, fa1[0], fb1[0], fa1[1], fb1[1]);
           qa[kt].w = affine_relu_pair(qa[kt].w, fa1[2], fb1[2], fa1[3], fb1[3]);
-        }
-        if (DYG) {
-          qa[kt] = dy_chunk(qa[kt], qy[kt], s_dy + kbeg + kt * GBK + skc[0] * 8);
-          if (dy_store && m0 + srow[0] < g.M)
-            *reinterpret_cast<uint4 *>(dyg.dY_out + (ga[0] - A) + kt * GBK) = qa[kt];
         }
         *reinterpret_cast<uint4 *>(sa + srow[0] * KP + kt * GBK + skc[0] * 8) = qa[kt];
         *reinterpret_cast<uint4 *>(sb + srow[0] * KP + kt * GBK + skc[0] * 8) = qb[kt];
@@ -485,31 +408,15 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
     OMNIPQ_LOAD_TILES(ra, rb, 0)
     OMNIPQ_STORE_TILES(ra, rb, 0, 0)
   }
-  if (PF2 && nk > 1) OMNIPQ_LOAD_TILES(ra2, rb2, 1)
   __syncthreads();
   NT_STAMP(2);
 
-  if (!PF2) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) OMNIPQ_LOAD_TILES(ra, rb, kt + 1)
-      mma_step(buf);
-      if (kt + 1 < nk) OMNIPQ_STORE_TILES(ra, rb, buf ^ 1, kt + 1)
-      __syncthreads();
-    }
-  } else {
-    // even step kt (buffer 0): set 1 holds step kt + 1, set 0 takes the loads of step kt + 2; odd step the other way
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) OMNIPQ_LOAD_TILES(ra, rb, kt + 2)
-      mma_step(0);
-      if (kt + 1 < nk) OMNIPQ_STORE_TILES(ra2, rb2, 1, kt + 1)
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) OMNIPQ_LOAD_TILES(ra2, rb2, kt + 3)
-      mma_step(1);
-      if (kt + 2 < nk) OMNIPQ_STORE_TILES(ra, rb, 0, kt + 2)
-      __syncthreads();
-    }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) OMNIPQ_LOAD_TILES(ra, rb, kt + 1)
+    mma_step(buf);
+    if (kt + 1 < nk) OMNIPQ_STORE_TILES(ra, rb, buf ^ 1, kt + 1)
+    __syncthreads();
   }
   }
 #undef OMNIPQ_LOAD_TILES
@@ -820,9 +727,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   NT_STAMP(7);
 }
 
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, bool PF2 = false, int XG = 0, bool KRES = false,
-          bool DYG = false>
-__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false>
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
                                                         const bf16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
@@ -830,10 +736,8 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && !DYG && !PF2 && XG !=
                                                         BnBwdEpilogue bn = BnBwdEpilogue(),
                                                         AffineIn aff = AffineIn(),
                                                         PoolOut pool = PoolOut(),
-                                                        XyzGen xg = XyzGen(),
-                                                        DyGen dyg = DyGen()) {
-  gemm_nt_body<OUT_F32, STATS, AFF, T, PF2, XG, KRES, DYG>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, dyg,
-                                                          (int)blockIdx.x);
+                                                        XyzGen xg = XyzGen()) {
+  gemm_nt_body<OUT_F32, STATS, AFF, T, XG, KRES>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, (int)blockIdx.x);
 }
 
 // Two INDEPENDENT small problems of the same variant in one grid (64 x 64 tiles, K-resident): the per-point stacks of
@@ -852,11 +756,11 @@ template <int STATS, bool AFF>
 __global__ __launch_bounds__(256, 2) void gemm_nt_pair_kernel(SmallProblem p0, SmallProblem p1, int n0) {
   const int id = (int)blockIdx.x;
   if (id < n0)
-    gemm_nt_body<false, STATS, AFF, 64, false, 0, true, false>(p0.g, p0.A, p0.B, p0.C, p0.bias, p0.stats, p0.bn, p0.aff,
-                                                               PoolOut(), XyzGen(), DyGen(), id);
+    gemm_nt_body<false, STATS, AFF, 64, 0, true>(p0.g, p0.A, p0.B, p0.C, p0.bias, p0.stats, p0.bn, p0.aff, PoolOut(),
+                                                 XyzGen(), id);
   else
-    gemm_nt_body<false, STATS, AFF, 64, false, 0, true, false>(p1.g, p1.A, p1.B, p1.C, p1.bias, p1.stats, p1.bn, p1.aff,
-                                                               PoolOut(), XyzGen(), DyGen(), id - n0);
+    gemm_nt_body<false, STATS, AFF, 64, 0, true>(p1.g, p1.A, p1.B, p1.C, p1.bias, p1.stats, p1.bn, p1.aff, PoolOut(),
+                                                 XyzGen(), id - n0);
 }
 
 #ifdef OMNIPQ_NT_TRACE
@@ -956,21 +860,10 @@ static int gemm_nt_splitk_bf16(int M, int N, int K, const void *A, int lda, cons
   return OMNIPQ_OK;
 }
 
-// Few 128 x 128 tiles (the per-point layers outside the SA stages): 64 x 64 tiles, see the kernel's comment on T.
-// OMNIPQ_GEMM_SMALL: 0 never, 1 (default) when at most 256 big tiles would be launched, 2 always.
+// Few 128 x 128 tiles (the per-point layers outside the SA stages): 64 x 64 tiles when at most 256 big tiles would be
+// launched, see the kernel's comment on T.
 static bool gemm_nt_small_tiles(int M, int N) {
-  static const int mode = getenv("OMNIPQ_GEMM_SMALL") ? atoi(getenv("OMNIPQ_GEMM_SMALL")) : 1;
-  if (mode != 1) return mode == 2;
-  static const int limit = getenv("OMNIPQ_GEMM_SMALL_TILES") ? atoi(getenv("OMNIPQ_GEMM_SMALL_TILES")) : 256;
-  return (long long)((M + 127) / 128) * ((N + 127) / 128) <= limit;
-}
-
-// OMNIPQ_GEMM_PF2=1: two-step operand prefetch in the plain 128 x 128-tile kernel.  Measured (round 2): SLOWER on the
-// large SA shapes (262144 x 512 x 256: 177 vs 144 us; 1 M x 256 x 128: 239 vs 193) -- the extra register set costs the
-// third workgroup per CU, which hides more latency than the deeper prefetch does -- slightly faster on 4096-row shapes.
-static bool gemm_nt_pf2() {
-  static const bool on = getenv("OMNIPQ_GEMM_PF2") ? atoi(getenv("OMNIPQ_GEMM_PF2")) != 0 : false;
-  return on;
+  return (long long)((M + 127) / 128) * ((N + 127) / 128) <= 256;
 }
 
 static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int ldc, int T) {
@@ -979,11 +872,8 @@ static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int 
 
 static dim3 gemm_nt_grid(const omnipq::GemmArgs &g) { return dim3(((g.m_tiles + 7) / 8) * 8 * g.n_tiles, 1, 1); }
 
-// 64 x 64-tile launches: the K-resident variant (see KRES) whenever the contraction fits, OMNIPQ_GEMM_KRES=0 to compare
-static bool gemm_nt_kres(int K) {
-  static const bool on = !(getenv("OMNIPQ_GEMM_KRES") && atoi(getenv("OMNIPQ_GEMM_KRES")) == 0);
-  return on && K <= omnipq::kResMaxSteps * omnipq::GBK;
-}
+// 64 x 64-tile launches: the K-resident variant (see KRES) whenever the contraction fits
+static bool gemm_nt_kres(int K) { return K <= omnipq::kResMaxSteps * omnipq::GBK; }
 
 // ---- pair launches ------------------------------------------------------------------------------------------------------
 // omnipq_pair_hold(): the NEXT small-tile GEMM this thread issues is held back instead of launched; the one after it, if it
@@ -1004,12 +894,11 @@ struct HeldSmallBlob {
 template <int STATS, bool AFF>
 static void launch_small_single(const omnipq::SmallProblem &p, int lds, hipStream_t stream) {
   using namespace omnipq;
-  auto kern = gemm_nt_kernel<false, STATS, AFF, 64, false, 0, true>;
+  auto kern = gemm_nt_kernel<false, STATS, AFF, 64, 0, true>;
   static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)prepared;
-  kern<<<gemm_nt_grid(p.g), 256, lds, stream>>>(p.g, p.A, p.B, p.C, p.bias, p.stats, p.bn, p.aff, PoolOut(), XyzGen(),
-                                                DyGen());
+  kern<<<gemm_nt_grid(p.g), 256, lds, stream>>>(p.g, p.A, p.B, p.C, p.bias, p.stats, p.bn, p.aff, PoolOut(), XyzGen());
 }
 
 template <int STATS, bool AFF>
@@ -1076,12 +965,8 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
     launch_small<0, false>(g, A, B, C, nullptr, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-    if (gemm_nt_pf2())
-      gemm_nt_kernel<false, 0, false, 128, true><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
-          g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr);
-    else
-      gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
-                                                                            nullptr);
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+                                                                          nullptr);
   }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1343,74 +1228,6 @@ extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int
 }
 
 
-// ---- data-gradient GEMM with the BatchNorm-backward result generated as its operand (see DyGen) ----------------------
-template <int STATS, int T, bool KRES>
-static void launch_dygen(const omnipq::GemmArgs &g, const void *A, const void *B, void *C, void *stats,
-                         const omnipq::BnBwdEpilogue &bn, const omnipq::DyGen &dy, void *stream) {
-  using namespace omnipq;
-  auto kern = gemm_nt_kernel<false, STATS, false, T, false, 0, KRES, true>;
-  int lds = 0;
-  if (KRES) {
-    static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)prepared;
-    lds = 2 * 64 * (g.K + 8) * 2;
-    if (lds < 20480) lds = 20480;
-  }
-  kern<<<gemm_nt_grid(g), 256, lds, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr, stats, bn,
-                                                           AffineIn(), PoolOut(), XyzGen(), dy);
-}
-
-// C[M][N] = dY[M][K] B[N][K]^T (bf16) where dY = a (dz - mean(dz) - yhat mean(dz yhat)) is generated from dX, Y [M][K] (pitch
-// lda) and the layer's constants / totals (sums = double[2][K]: sum dz, sum dz yhat; inv_count = 1 / rows, global under
-// SyncBatchNorm); dY_out (may be NULL) receives the generated rows, gb_out (may be NULL) = float[2][K] the totals (dbeta |
-// dgamma).  With below_Y != NULL the epilogue also forms the BatchNorm-backward sums of the layer below into below_sums
-// (double[2][N], zero on entry) exactly as omnipq_gemm_nt_bf16_bnbwd; workspace as there.  K <= 512.
-extern "C" int omnipq_gemm_nt_bf16_dygen(int M, int N, int K, const void *dX, const void *Y, int lda, const float *a,
-                                         const float *b, const float *mean, const float *invstd, const double *sums,
-                                         double inv_count, void *dY_out, float *gb_out, const void *B, int ldb, void *C,
-                                         int ldc, const void *below_Y, const float *below_a, const float *below_b,
-                                         const float *below_mean, const float *below_invstd, double *below_sums,
-                                         float *workspace, void *stream) {
-  using namespace omnipq;
-  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
-  if (M == 0 || N == 0) return OMNIPQ_OK;
-  if (!dX || !Y || !a || !b || !mean || !invstd || !sums || !B || !C || !(inv_count > 0)) return OMNIPQ_EINVAL;
-  if ((K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8) || K > kDyMaxK) return OMNIPQ_EINVAL;
-  const bool below = below_Y != nullptr;
-  if (below && (!below_a || !below_b || !below_mean || !below_invstd || !below_sums)) return OMNIPQ_EINVAL;
-  const DyGen dy{(const bf16_t *)Y, a, b, mean, invstd, sums, inv_count, (bf16_t *)dY_out, gb_out};
-  const BnBwdEpilogue bn{(const bf16_t *)below_Y, below_a, below_b, below_mean, below_invstd};
-  const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-  const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
-  const bool small = gemm_nt_small_tiles(M, N);
-  const bool kres = small && gemm_nt_kres(K);
-  if (!below) {
-    if (kres) launch_dygen<0, 64, true>(gs, dX, B, C, nullptr, bn, dy, stream);
-    else if (small) launch_dygen<0, 64, false>(gs, dX, B, C, nullptr, bn, dy, stream);
-    else launch_dygen<0, 128, false>(g, dX, B, C, nullptr, bn, dy, stream);
-    OMNIPQ_LAUNCH_CHECK();
-    return OMNIPQ_OK;
-  }
-  if (g.m_tiles <= kStatsDirectTiles) {
-    if (kres) launch_dygen<3, 64, true>(gs, dX, B, C, below_sums, bn, dy, stream);
-    else if (small) launch_dygen<3, 64, false>(gs, dX, B, C, below_sums, bn, dy, stream);
-    else launch_dygen<3, 128, false>(g, dX, B, C, below_sums, bn, dy, stream);
-    OMNIPQ_LAUNCH_CHECK();
-    return OMNIPQ_OK;
-  }
-  if (!workspace) return OMNIPQ_EINVAL;
-  launch_dygen<4, 128, false>(g, dX, B, C, workspace, bn, dy, stream);
-  OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  if (slabs < 1) slabs = 1;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    below_sums);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
-}
-
 // ---- first layer of a coordinates-only stage, never materialised (see XyzGen) -------------------------------------
 extern "C" long long omnipq_gemm_nt_xyz_workspace_floats(int M, int N) {
   const long long m_tiles = (M + omnipq::GBM - 1) / omnipq::GBM;
@@ -1452,7 +1269,7 @@ extern "C" int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void 
   const XyzGen xg{(const bf16_t *)X0, ldx, (const bf16_t *)W0, ldw0};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false, 2, true, 128, false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
+  gemm_nt_kernel<false, 2, true, 128, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
       g, (const bf16_t *)B, (const bf16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
@@ -1483,7 +1300,7 @@ extern "C" int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A,
   const BnBwdEpilogue bn{nullptr, a, b, mean, invstd};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false, 4, false, 128, false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
+  gemm_nt_kernel<false, 4, false, 128, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
       g, (const bf16_t *)A, (const bf16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;

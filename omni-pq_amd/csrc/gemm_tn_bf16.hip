@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int
 // costs a 64 KB f32 tile store plus its share of the reduction, which dwarfs a one- or two-step main loop on
 // the small per-point layers (P ~ 4096).
 extern "C" int omnipq_gemm_tn_slabs(int tiles, long long P, int k_step) {
-  static const int kMinSteps = getenv("OMNIPQ_TN_MINSTEPS") ? atoi(getenv("OMNIPQ_TN_MINSTEPS")) : 6;
-  static const int kTarget = getenv("OMNIPQ_TN_TARGET") ? atoi(getenv("OMNIPQ_TN_TARGET")) : 512;
+  constexpr int kMinSteps = 6;
+  constexpr int kTarget = 512;
   long long slabs = (kTarget + tiles - 1) / tiles;
   const long long max_slabs = (P + (long long)k_step * kMinSteps - 1) / ((long long)k_step * kMinSteps);
   if (slabs > max_slabs) slabs = max_slabs;
@@ -515,7 +515,7 @@ struct omnipq_tn_problem_ {
 static int tng_chunk() {
   // positions per workgroup in the grouped launch: the grid is full anyway, so workgroups are cut for balance
   // (a few thousand of them), not to create parallelism
-  static const int steps = getenv("OMNIPQ_TNG_STEPS") ? atoi(getenv("OMNIPQ_TNG_STEPS")) : 16;
+  constexpr int steps = 16;
   return omnipq::TBK * (steps < 1 ? 1 : steps);
 }
 

@@ -1307,7 +1307,7 @@ extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, i
   const long long P = (long long)b * m * s;
   const int ms = m * s;
   if (n <= omnipq::kCsrLdsMax && b <= 8191) {
-    static const int split = getenv("OMNIPQ_CSR_SPLIT") ? atoi(getenv("OMNIPQ_CSR_SPLIT")) : 8;
+    constexpr int split = 8;
     if (split == 8 && n >= 1024 && ms >= 8192)
       omnipq::csr_build_split_kernel<8><<<b * 8, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
     else

@@ -240,7 +240,7 @@ def precompute_key_sides(layers, key, key_pos):
     return kvs
 
 
-_JOIN_PER_LAYER = os.environ.get("OMNIPQ_KEY_JOIN", "event") != "stream"
+_JOIN_PER_LAYER = True
 
 
 def join_key_sides(device, done=None):

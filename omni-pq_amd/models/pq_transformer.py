@@ -35,28 +35,9 @@ from voting_module import VotingModule  # noqa: E402
 import rows_mlp  # noqa: E402
 import sa_fused  # noqa: E402
 
-# "capture" (default): overlap the decoder's key sides on a side stream while a hipGraph is being captured (in
-# eager mode the extra stream switches cost more host time than the overlap returns); "always" / "inline"
-_OVERLAP_KEY_SIDE = os.environ.get("OMNIPQ_KEY_SIDE", "capture")
-# The object head and the quad head of a decoder layer are independent of each other, and in BACKWARD independent of the
-# decoder chain too (the centres they hand to the next layer are detached, :236-237 of the reference): each runs on its own
-# side stream, so in a captured step the backward passes of the 14 heads (a few kernels of 64-128 workgroups each) lie
-# underneath the decoder's backward instead of in front of it.  MEASURED (MI355X, config 2, hipGraph replay): 19.7 ms per
-# step with the head streams against 13.8 ms without -- every cross-stream edge of a captured graph costs tens of
-# microseconds at replay on this runtime, and the 12 forks / joins of the forward plus the ones autograd mirrors in backward
-# outweigh the ~1 ms of head kernels they hide.  Hence "off" by default; "capture": only while a hipGraph is being captured;
-# "always".
-_OVERLAP_HEADS = os.environ.get("OMNIPQ_HEAD_STREAMS", "off")
-_HEAD_STREAMS = {}
-
-
-def _head_streams(device):
-    st = _HEAD_STREAMS.get(device)
-    if st is None:
-        st = _HEAD_STREAMS[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-    return st
-
-
+# "capture": overlap the decoder's key sides on a side stream while a hipGraph is being captured (in eager mode the
+# extra stream switches cost more host time than the overlap returns); tests set "always" / "inline"
+_OVERLAP_KEY_SIDE = "capture"
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
 # here on row-major activations (points x channels) through F.linear -- one GEMM with the bias in its
 # epilogue -- instead of Conv1d on (B, C, K): same arithmetic, no layout-shuffling copies around every call,
@@ -95,7 +76,7 @@ def conv1x1(x, conv):
     return lin(rows(x), conv).view(B, K, -1).transpose(1, 2)
 
 
-_JOINT_HEADS = os.environ.get("OMNIPQ_JOINT_HEADS", "1") != "0"
+_JOINT_HEADS = True
 
 
 def _rows_of(heads):
@@ -188,8 +169,8 @@ def _grad_descriptors(gs, n2):
     return ptrs, strides, flags, keep
 
 
-_FUSED_DECODE = os.environ.get("OMNIPQ_HEAD_DECODE", "fused") != "torch"
-_WGRAD_SIDE = os.environ.get("OMNIPQ_WGRAD_SIDE", "1") != "0"
+_FUSED_DECODE = True       # False: the op-by-op decode of the reference (tests compare the two)
+_WGRAD_SIDE = True
 
 
 class HeadDecode(torch.autograd.Function):
@@ -375,9 +356,9 @@ class DecodePair(torch.autograd.Function):
 _HEAD_KEYS = ("objectness_scores", "center", "heading_scores", "heading_residuals_normalized", "heading_residuals",
               "size_scores", "size_residuals_normalized", "size_residuals", "pred_size", "sem_cls_scores")
 _QUAD_KEYS = ("quad_scores", "quad_center", "normal_vector", "quad_size")
-_PAIR_DECODE = os.environ.get("OMNIPQ_DECODE_PAIR", "1") != "0"
-_XYZ_SINK = os.environ.get("OMNIPQ_XYZ_SINK", "1") != "0"
-_PAIR_STACKS = os.environ.get("OMNIPQ_PAIR_STACKS", "1") != "0"
+_PAIR_DECODE = True        # module switches, toggled by tests/test_gpu_decoder.py to compare with the separate launches
+_XYZ_SINK = True
+_PAIR_STACKS = True
 
 
 def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, prefix, rows=None, rows_q=None,
@@ -683,33 +664,9 @@ class PQ_Transformer(nn.Module):
                 query_joint.omnipq_rows16 = alias
             elif rows16 is not None:
                 rows_obj, rows_quad = torch.split(rows16, [n_obj, n_quad], dim=1)
-            head_overlap = query.is_cuda and (_OVERLAP_HEADS == "always" or (
-                _OVERLAP_HEADS == "capture" and torch.cuda.is_current_stream_capturing()))
-            if head_overlap:
-                cur = torch.cuda.current_stream(query.device)
-                known = set(end_points.keys())
-                for st, head, q, xyz, rows in zip(_head_streams(query.device),
-                                                  (self.prediction_heads[i], self.prediction_quad_heads[i]),
-                                                  (query, query_q), (cluster_xyz, quad_xyz), (rows_obj, rows_quad)):
-                    st.wait_stream(cur)
-                    for t in (q, rows, query_joint, rows16):
-                        if t is not None:
-                            t.record_stream(st)
-                    with torch.cuda.stream(st):
-                        centre, _, end_points = head(q, base_xyz=xyz, end_points=end_points, prefix=prefix, net_rows=rows)
-                    if head is self.prediction_heads[i]:
-                        base_xyz = centre
-                    else:
-                        base_xyz_q = centre
-                for st in _head_streams(query.device):
-                    cur.wait_stream(st)                 # the next layer's query positions are these heads' centres
-                for k, v in end_points.items():
-                    if k not in known and torch.is_tensor(v):
-                        v.record_stream(cur)
-            else:
-                base_xyz, base_xyz_q, end_points, pos_joint = predict_pair(
-                    self.prediction_heads[i], self.prediction_quad_heads[i], query, query_q, cluster_xyz, quad_xyz,
-                    end_points, prefix, rows_obj, rows_quad, sink=sink, want_pos=i + 1 < self.num_layer)
+            base_xyz, base_xyz_q, end_points, pos_joint = predict_pair(
+                self.prediction_heads[i], self.prediction_quad_heads[i], query, query_q, cluster_xyz, quad_xyz,
+                end_points, prefix, rows_obj, rows_quad, sink=sink, want_pos=i + 1 < self.num_layer)
             base_xyz = base_xyz.detach()
             base_xyz_q = base_xyz_q.detach()
         return end_points

@@ -19,7 +19,7 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
 import rows_mlp  # noqa: E402
 
 
-_FUSED_TAIL = os.environ.get("OMNIPQ_VOTE_DECODE", "1") != "0"      # "0": the op-by-op tail (A/B, debugging)
+_FUSED_TAIL = True      # False: the op-by-op tail (tests compare the two)
 
 
 def _lin(x2d, conv):

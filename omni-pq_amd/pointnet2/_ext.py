@@ -229,7 +229,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
-_BQ_GRID_MIN = int(os.environ.get("OMNIPQ_BQ_GRID_MIN", "8192"))      # points per scene from which the grid pays
+_BQ_GRID_MIN = 8192      # points per scene from which the grid pays
 _lib.omnipq_ball_query_grid_workspace_bytes.restype = ctypes.c_longlong
 
 

@@ -817,59 +817,6 @@ def test_ball_extrema_epilogue_and_pool_select_equal_the_pooling_pass(M, N, K, S
     assert float(((s1[:2] - s0[:2]).abs() / scale).max()) < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K,below", [(2048, 288, 288, True), (4096 + 40, 288, 288, False), (128 * 70, 256, 256, True),
-                                         (8192, 512, 288, False)])
-def test_data_gradient_gemm_with_generated_batchnorm_backward(M, N, K, below):
-    """omnipq_gemm_nt_bf16_dygen (opt-in, OMNIPQ_DYGEN) = omnipq_bn_bwd_apply_fused followed by the data-gradient GEMM:
-    the same dY rows (stored for the weight gradient), the same product, the same sums of the layer below."""
-    import ctypes
-    import sa_fused
-    from sa_fused import _lib, _p, _call
-    g = torch.Generator(device="cuda").manual_seed(M + N)
-    dX = (torch.randn(M, K, device="cuda", generator=g) * 0.2).bfloat16()
-    Y = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    Wt = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
-
-    class L:
-        pass
-    lay = L()
-    lay.C, lay.Y = K, Y
-    lay.a = torch.rand(K, device="cuda", generator=g) + 0.5
-    lay.b = torch.randn(K, device="cuda", generator=g) * 0.3
-    lay.mean = torch.randn(K, device="cuda", generator=g) * 0.2
-    lay.invstd = torch.rand(K, device="cuda", generator=g) + 0.7
-    sums = torch.zeros(3, K, device="cuda", dtype=torch.float64)
-    _call(_lib.omnipq_bn_bwd_stats_z, dX, ctypes.c_longlong(M), K, _p(dX), _p(Y), _p(lay.a), _p(lay.b), _p(lay.mean),
-          _p(lay.invstd), _p(sums))
-    low = None
-    if below:
-        low = L()
-        low.C = N
-        low.Y = torch.randn(M, N, device="cuda", generator=g).bfloat16()
-        low.a, low.b = torch.rand(N, device="cuda", generator=g) + 0.5, torch.randn(N, device="cuda", generator=g) * 0.3
-        low.mean, low.invstd = torch.randn(N, device="cuda", generator=g) * 0.2, torch.rand(N, device="cuda", generator=g) + 0.7
-    # the two-pass dataflow
-    want_dY = torch.empty_like(dX)
-    dgam, dbet = sa_fused.bn_backward_apply(dX, lay, M, K, ctypes.c_double(float(M)), sums.clone(), 1, out=want_dY)
-    if below:
-        want_sums = torch.zeros(3, N, device="cuda", dtype=torch.float64)
-        want = sa_fused._gemm_nt_bnbwd(want_dY, Wt, M, N, K, low, want_sums)
-    else:
-        want = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        sa_fused.gemm_nt_into(want_dY, Wt, want, M, N, K)
-    # generated
-    got_sums = torch.zeros(3, N, device="cuda", dtype=torch.float64) if below else None
-    got, got_dY, g_gam, g_bet = sa_fused.gemm_nt_dygen(dX, lay, M, sums.clone(), 1, Wt, N, below=low, below_sums=got_sums)
-    assert torch.allclose(g_gam, dgam) and torch.allclose(g_bet, dbet)
-    d = (got_dY.float() - want_dY.float()).abs()
-    assert float(d.max()) <= 2 ** -7 * float(want_dY.float().abs().max())            # one bf16 step: the affine form regroups the sum
-    assert float(d.mean()) <= 1e-3 * float(want_dY.float().abs().mean())
-    assert rel_l2(got.float(), want.float()) < 3e-3
-    if below:
-        scale = want_sums[:2].abs().max(1, keepdim=True)[0]
-        assert float(((got_sums[:2] - want_sums[:2]).abs() / scale).max()) < 3e-3
-
-
 @pytest.mark.parametrize("B,n,m,s", [(8, 2048, 1024, 32), (3, 1024, 2750, 3), (2, 8192, 40000, 1), (2, 1000, 9000, 1),
                                      (2, 5000, 100, 16), (1, 40000, 2048, 64)])
 def test_build_csr_groups_every_position_under_its_source_point(B, n, m, s):

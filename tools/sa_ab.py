@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""A/B of the set-abstraction stage: row-tile GEMMs with operand generators (sa_fused.CHAIN = True) against the
-per-layer kernels (False) on the benchmark configuration -- outputs, gradients, and event-timed stage time.
+"""A/B of the set-abstraction stages with one sa_fused module switch on / off (default: XYZGEN) on the benchmark
+configuration -- outputs, gradients, and event-timed stage time; --per-stage splits the default path's time by stage.
 
-    python tools/chain_check.py [--batch 8] [--points 40000] [--steps 5]
+    python tools/sa_ab.py [--batch 8] [--points 40000] [--steps 5] [--flag XYZGEN] [--per-stage]
 """
 import argparse
 import os
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--extra", type=int, default=0)
-    ap.add_argument("--flag", default="CHAIN", help="sa_fused switch to A/B: CHAIN or ALGEBRA")
+    ap.add_argument("--flag", default="XYZGEN", help="sa_fused module switch to A/B (XYZGEN, AFFINE_OPERANDS, POOL_EPILOGUE, ...)")
     ap.add_argument("--per-stage", action="store_true", help="after the A/B, split the default path's time by stage")
     args = ap.parse_args()
     import pointnet2_utils
