@@ -53,7 +53,11 @@ def parse():
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--extra-channels", type=int, default=0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32)")
+                    help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32); bf16 and fp16 run the hand-written "
+                         "kernels (libomnipq_pointops.so / _f16.so), fp32 the op-by-op composition")
+    ap.add_argument("--loss-scale", type=float, default=0.0,
+                    help="the loss is multiplied by this before backward (what torch.amp.GradScaler does for fp16: a mean "
+                         "over 1e5 elements hands every element a gradient below fp16's normal range); 0 = 16384 for fp16, 1 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scenes", type=int, default=0, help="scenes per CPU-baseline step (0: the batch size)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up)")
@@ -106,7 +110,7 @@ def loss_of(end_points):
     parts = [end_points[k] for k in sorted(end_points.keys())
              if end_points[k].is_floating_point() and end_points[k].requires_grad]
     if parts and parts[0].is_cuda and \
-            all(p.dim() <= 4 and p.dtype in (torch.float32, torch.bfloat16) for p in parts):
+            all(p.dim() <= 4 and p.dtype in (torch.float32, _e16()) for p in parts):
         total = 0.0
         for i in range(0, len(parts), 72):
             total = total + SumOfMeans.apply(*parts[i:i + 72])
@@ -115,6 +119,12 @@ def loss_of(end_points):
     sizes = tuple(p.numel() for p in parts)
     w = _loss_weights(sizes, parts[0].device)
     return torch.dot(torch.cat(parts), w)
+
+
+def _e16():
+    """the 16-bit element type the hand-written kernels currently run in (bfloat16 / float16: sa_fused.E16)"""
+    import sa_fused
+    return sa_fused.E16.dtype
 
 
 class SumOfMeans(torch.autograd.Function):
@@ -133,7 +143,7 @@ class SumOfMeans(torch.autograd.Function):
             pad = 4 - t.dim()
             sizes += [1] * pad + list(t.shape)
             strides += [0] * pad + list(t.stride())
-        flags = (ctypes.c_int * n)(*[int(t.dtype == torch.bfloat16) for t in ts])
+        flags = (ctypes.c_int * n)(*[int(t.dtype == sa_fused.E16.dtype) for t in ts])
         out = sa_fused.zeros_f32(1, ts[0].device)
         sa_fused._call(sa_fused._lib.omnipq_sum_of_means, ts[0], n, ptrs, (ctypes.c_int * (4 * n))(*sizes),
                        (ctypes.c_int * (4 * n))(*strides), flags, sa_fused._p(out))
@@ -148,8 +158,9 @@ class SumOfMeans(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g32 = g * ctx.inv
-        g16 = g32.to(torch.bfloat16) if any(dt == torch.bfloat16 for _, dt in ctx.meta) else None
-        return tuple((g16 if dt == torch.bfloat16 else g32)[i].expand(shape) for i, (shape, dt) in enumerate(ctx.meta))
+        e16 = _e16()
+        g16 = g32.to(e16) if any(dt == e16 for _, dt in ctx.meta) else None
+        return tuple((g16 if dt == e16 else g32)[i].expand(shape) for i, (shape, dt) in enumerate(ctx.meta))
 
 
 _INV_NUMEL = {}
@@ -192,7 +203,7 @@ def algorithmic_bytes(name, a):
     return 0
 
 
-SA_STAGE_CALLS = ("omnipq_ball_query", "omnipq_sa_gather", "omnipq_gemm_nt_bf16", "omnipq_gemm_tn_bf16",
+SA_STAGE_CALLS = ("omnipq_ball_query", "omnipq_sa_gather", "omnipq_gemm_nt_e16", "omnipq_gemm_tn_e16",
                   "omnipq_colstats", "omnipq_bn_finalize", "omnipq_bnrelu", "omnipq_sa_pool",
                   "omnipq_sa_pool_bwd_stats", "omnipq_sa_pool_bwd_apply", "omnipq_bn_bwd_stats",
                   "omnipq_bn_bwd_apply", "omnipq_sa_build_csr", "omnipq_sa_scatter_csr",
@@ -301,7 +312,7 @@ def stage_breakdown(table, steps):
             k = "feature_propagation"
         elif base.startswith("omnipq_attn"):
             k = "attention"
-        elif base.startswith(("omnipq_add_dropout_layernorm", "omnipq_relu_dropout", "omnipq_add_to_bf16", "omnipq_layernorm",
+        elif base.startswith(("omnipq_add_dropout_layernorm", "omnipq_relu_dropout", "omnipq_add_to_e16", "omnipq_layernorm",
                               "omnipq_split_rows", "omnipq_merge_rows", "omnipq_add_n")):
             k = "decoder row kernels (LayerNorm, dropout)"
         elif base.startswith(("omnipq_head_decode", "omnipq_quad_decode", "omnipq_decode_pair", "omnipq_vote_decode")):
@@ -447,7 +458,11 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         gt.update(labels)
         return loss_helper_pq.get_loss(gt, LossConfig, pc_loss=True)[0]
 
+    scale = float(getattr(args, "loss_scale", 0.0) or (16384.0 if args.dtype == "fp16" else 1.0))
+
     def backward(loss):
+        if scale != 1.0:
+            loss = loss * scale                      # static loss scaling (fp16): see --loss-scale
         if defer:
             import sa_fused
             with sa_fused.deferred_wgrads():         # ~115 small weight gradients as one grouped launch

@@ -2,7 +2,7 @@
  *
  * Replaces, inside models/utils/multi_head_attention.py:375-391 of the reference,
  *     q = q * head_dim**-0.5;  w = softmax(bmm(q, k^T), -1);  w = dropout(w, p);  out = bmm(w, v)
- * and its autograd backward.  Tensors stay in the reference's (tokens, batch, embed) layout, bf16:
+ * and its autograd backward.  Tensors stay in the reference's (tokens, batch, embed) layout, e16:
  * element (token t, batch n, head h, channel d) of q sits at  q[t * strides[0] + n * strides[1] + h * D + d].
  *   strides[8]      = {q_tok, q_batch, k_tok, k_batch, v_tok, v_batch, o_tok, o_batch}  (elements, % 4 == 0;
  *                     dO uses o's strides)
@@ -14,6 +14,7 @@
  * 64-bit seed is READ FROM DEVICE MEMORY at kernel time (so a captured graph sees a new seed per replay),
  * `salt` distinguishes the calls that share a seed.  dropout_p == 0: seed_ptr may be NULL.
  * All pointers are device pointers; `stream` is a hipStream_t.  Returns 0 or an OMNIPQ_E* / hipError_t code.
+  * `e16`: the element type of the loaded library (bfloat16 / IEEE half), see omnipq_sa.h.
  */
 #ifndef OMNIPQ_ATTN_H
 #define OMNIPQ_ATTN_H

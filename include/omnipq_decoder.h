@@ -3,9 +3,10 @@
  *     x = norm(x + dropout(branch))            three times per layer
  *     ffn = linear2(dropout(relu(linear1(x))))
  * Activations are rows [R][C] (one token per row, channels contiguous); the residual stream is f32, branch
- * outputs and GEMM operands bf16.  Dropout masks are a counter hash of (seed read from device memory,
+ * outputs and GEMM operands e16.  Dropout masks are a counter hash of (seed read from device memory,
  * salt, row * C + channel): keep iff hash >= p * 2^32, kept values scaled by 1/(1-p); backward recomputes
  * them.  All pointers are device pointers, `stream` a hipStream_t; returns 0 or an OMNIPQ_E* / hip code.
+  * `e16`: the element type of the loaded library (bfloat16 / IEEE half), see omnipq_sa.h.
  */
 #ifndef OMNIPQ_DECODER_H
 #define OMNIPQ_DECODER_H
@@ -16,17 +17,17 @@ extern "C" {
 #endif
 
 /* r = x + dropout(y);  out = LayerNorm(r) * gamma + beta   (eps inside the sqrt, biased variance)
- *   x [R][C] f32, y [R][C] bf16 (NULL: r = x), gamma/beta [C] f32
- *   out32 [R][C] f32 (may be NULL), out16 [R][C] bf16 (may be NULL),
- *   out16_pe [R][C] bf16 = bf16(out + pe) with pe [R][C] bf16 (both NULL to skip)
+ *   x [R][C] f32, y [R][C] e16 (NULL: r = x), gamma/beta [C] f32
+ *   out32 [R][C] f32 (may be NULL), out16 [R][C] e16 (may be NULL),
+ *   out16_pe [R][C] e16 = e16(out + pe) with pe [R][C] e16 (both NULL to skip)
  *   mean/rstd [R] f32 saved for backward.   C % 4 == 0, C <= 1024. */
 int omnipq_add_dropout_layernorm(long long R, int C, const float *x, const void *y, const float *gamma,
                                  const float *beta, float eps, float dropout_p,
                                  const unsigned long long *seed_ptr, unsigned salt, float *out32, void *out16,
                                  const void *pe, void *out16_pe, float *mean, float *rstd, void *stream);
 
-/* Backward of the above.  g32 (f32), g16, g16_pe (bf16): gradients w.r.t. the three outputs, any may be NULL.
- *   dx [R][C] f32 = dr;  dy [R][C] bf16 = dropout-masked dr (NULL if y was NULL);
+/* Backward of the above.  g32 (f32), g16, g16_pe (e16): gradients w.r.t. the three outputs, any may be NULL.
+ *   dx [R][C] f32 = dr;  dy [R][C] e16 = dropout-masked dr (NULL if y was NULL);
  *   dgamma_dbeta [2][C] f32, zero on entry, receives ADDED sums (dgamma first). */
 int omnipq_add_dropout_layernorm_bwd(long long R, int C, const float *x, const void *y, const float *gamma,
                                      float dropout_p, const unsigned long long *seed_ptr, unsigned salt,
@@ -46,42 +47,42 @@ int omnipq_add_dropout_layernorm_bwd_partials(long long R, int C, const float *x
 int omnipq_layernorm_param_reduce(int n, const float *const *partials, const int *blocks, const int *channels,
                                   float *const *out, void *stream);
 
-/* h = dropout(relu(h)) in place on bf16 [n]; backward: out = (h > 0) ? d / (1-p) : 0 (out may be d; h = the
+/* h = dropout(relu(h)) in place on e16 [n]; backward: out = (h > 0) ? d / (1-p) : 0 (out may be d; h = the
  * forward's OUTPUT: positive exactly where the unit was active and kept). */
 int omnipq_relu_dropout(long long n, void *h, float dropout_p, const unsigned long long *seed_ptr, unsigned salt,
                         void *stream);
 int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d, void *out, float dropout_p, void *stream);
 
-/* out16 [n] bf16 = bf16(a + b):  a f32 or bf16 (a_is_f32), b bf16. */
-int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16, void *stream);
-/* x f32 / bf16 [n][cin] with row pitch ldx -> out16 bf16 [n][k], columns cin .. k-1 zero (a narrow input widened to the row
- * GEMMs' operand width: torch's .to(bf16) + F.pad is three launches) */
-int omnipq_pad_rows_bf16(long long n, int cin, int k, long long ldx, const void *x, int x_is_f32, void *out16, void *stream);
+/* out16 [n] e16 = e16(a + b):  a f32 or e16 (a_is_f32), b e16. */
+int omnipq_add_to_e16(long long n, const void *a, int a_is_f32, const void *b, void *out16, void *stream);
+/* x f32 / e16 [n][cin] with row pitch ldx -> out16 e16 [n][k], columns cin .. k-1 zero (a narrow input widened to the row
+ * GEMMs' operand width: torch's .to(e16) + F.pad is three launches) */
+int omnipq_pad_rows_e16(long long n, int cin, int k, long long ldx, const void *x, int x_is_f32, void *out16, void *stream);
 
 /* Object prediction head after its output GEMM (models/pq_transformer.py:35-59 `decode_scores`, :86-89): row
  * r = (batch, proposal), y[r] = [objectness 2 | centre 3 | heading scores nh | heading residuals nh | size scores ns |
- * size residuals 3 ns | semantic scores ncls] in bf16 (pitch ldy).  One launch writes the ten `end_points` tensors:
- * outs[10] = { objectness bf16 [R][2], center f32 [R][3] (= y + base), heading_scores bf16 [R][nh],
- * heading_residuals_normalized bf16 [R][nh], heading_residuals bf16 [R][nh] (x hr_scale = pi / nh), size_scores bf16
- * [R][ns], size_residuals_normalized bf16 [R][ns][3], size_residuals f32 [R][ns][3] (x means), pred_size f32 [R][3]
- * (= (residual + mean)[argmax size_scores], first maximum as torch.argmax), sem_cls_scores bf16 [R][ncls] }.
+ * size residuals 3 ns | semantic scores ncls] in e16 (pitch ldy).  One launch writes the ten `end_points` tensors:
+ * outs[10] = { objectness e16 [R][2], center f32 [R][3] (= y + base), heading_scores e16 [R][nh],
+ * heading_residuals_normalized e16 [R][nh], heading_residuals e16 [R][nh] (x hr_scale = pi / nh), size_scores e16
+ * [R][ns], size_residuals_normalized e16 [R][ns][3], size_residuals f32 [R][ns][3] (x means), pred_size f32 [R][3]
+ * (= (residual + mean)[argmax size_scores], first maximum as torch.argmax), sem_cls_scores e16 [R][ncls] }.
  * `outs` is a HOST array of device pointers. */
 int omnipq_head_decode(int R, int nh, int ns, int ncls, const void *y, int ldy, const float *base, const float *means,
                        float hr_scale, void *const *outs, void *stream);
-/* Its gradient: dy (bf16 [R][lddy]) from the ten output gradients (HOST arrays in the order above: device pointer or
+/* Its gradient: dy (e16 [R][lddy]) from the ten output gradients (HOST arrays in the order above: device pointer or
  * NULL, strides [10][4] in elements for the logical shape [B][K][n1][n2] with 0 for broadcast dimensions, n2, dtype
  * flag), dbase (f32 [R][3] or NULL) = the centre gradient.  R = B * K. */
 int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, const void *y, int ldy, const float *means,
                            float hr_scale, const void *const *gptr, const int *gstrides, const int *gn2,
-                           const int *g_is_bf16, void *dy, int lddy, float *dbase, void *stream);
+                           const int *g_is_e16, void *dy, int lddy, float *dbase, void *stream);
 
 /* Layout-quad head after its output GEMM (models/pq_transformer.py:94-121): y[r] = [scores 2 | centre 3 | normal 3 |
- * size 2] bf16; outs[4] = { quad_scores bf16 [R][2], quad_center f32 [R][3] (= y + base), normal_vector bf16 [R][3]
- * (= y / ||all normals||_2: the reference divides by the norm of the WHOLE tensor, :112-113), quad_size bf16 [R][2] };
- * norm: one float, the (bf16-rounded) norm, kept for the backward call. */
+ * size 2] e16; outs[4] = { quad_scores e16 [R][2], quad_center f32 [R][3] (= y + base), normal_vector e16 [R][3]
+ * (= y / ||all normals||_2: the reference divides by the norm of the WHOLE tensor, :112-113), quad_size e16 [R][2] };
+ * norm: one float, the (e16-rounded) norm, kept for the backward call. */
 int omnipq_quad_decode(int R, const void *y, int ldy, const float *base, void *const *outs, float *norm, void *stream);
 int omnipq_quad_decode_bwd(int R, int K, const void *y, int ldy, const float *norm, const void *const *gptr,
-                           const int *gstrides, const int *g_is_bf16, void *dy, int lddy, float *dbase, void *stream);
+                           const int *gstrides, const int *g_is_e16, void *dy, int lddy, float *dbase, void *stream);
 
 /* omnipq_head_decode + omnipq_quad_decode (and their backward twins) of one decoder stage in ONE launch each way: the two
  * heads are independent.  Arguments as in the single functions (h: object head, q: quad head; Kh / Kq proposals per scene).
@@ -100,25 +101,25 @@ int omnipq_decode_pair_bwd(int Rh, int Kh, int nh, int ns, int ncls, const void 
 
 /* The tail of the voting module and the normalisation that follows it (models/voting_module.py:55-63,
  * models/pq_transformer.py:216-217; vote_factor 1) in one launch, their gradient in another.
- *   net bf16 rows [b*k][ldn >= 3 + c] = [offset 3 | residual c]; seed_xyz f32 (b,k,3); seed_feat (b,c,k) with element
- *   strides sfb / sfc / sfk, f32 or bf16 (feat_is_bf16)  ->  vote_xyz f32 (b,k,3) = seed_xyz + offset;  vote_feat (b,c,k)
- *   in seed_feat's type = v / ||v||_2 over the channels, v = seed_feat + residual (f32 arithmetic);  twin16 bf16 (b,k,c):
+ *   net e16 rows [b*k][ldn >= 3 + c] = [offset 3 | residual c]; seed_xyz f32 (b,k,3); seed_feat (b,c,k) with element
+ *   strides sfb / sfc / sfk, f32 or e16 (feat_is_e16)  ->  vote_xyz f32 (b,k,3) = seed_xyz + offset;  vote_feat (b,c,k)
+ *   in seed_feat's type = v / ||v||_2 over the channels, v = seed_feat + residual (f32 arithmetic);  twin16 e16 (b,k,c):
  *   the same values row-major;  norm f32 (b,k) for backward.
- * Backward: g_xyz f32 (b,k,3) / g_feat (b,c,k) contiguous in vote_feat's type, either may be NULL -> dnet bf16 [b*k][ldd]
+ * Backward: g_xyz f32 (b,k,3) / g_feat (b,c,k) contiguous in vote_feat's type, either may be NULL -> dnet e16 [b*k][ldd]
  *   = [g_xyz | dv | 0..], dseed_feat (b,c,k) in the same type = dv (may be NULL), dv = (g_feat - vote_feat <g_feat,
  *   vote_feat>) / norm; the gradient with respect to seed_xyz is g_xyz itself.  c <= 320. */
 int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const float *seed_xyz, const void *seed_feat,
-                       int feat_is_bf16, long long sfb, long long sfc, long long sfk, float *vote_xyz, void *vote_feat,
+                       int feat_is_e16, long long sfb, long long sfc, long long sfk, float *vote_xyz, void *vote_feat,
                        void *twin16, float *norm, void *stream);
-int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_bf16, const float *norm,
+int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_e16, const float *norm,
                            const float *g_xyz, const void *g_feat, void *dnet, int ldd, void *dseed_feat, void *stream);
 
-/* out[i] = sum_s src[s][i], i < n: up to 16 sources of one type (bf16: is_bf16 != 0, f32 accumulation, one rounding;
+/* out[i] = sum_s src[s][i], i < n: up to 16 sources of one type (e16: is_e16 != 0, f32 accumulation, one rounding;
  * else f32), n % 8 == 0, all pointers 16-byte aligned; out may be one of the sources.  The fan-in of a tensor that feeds
  * several consumers (autograd: count - 1 accumulation launches, each re-reading the running sum). */
-int omnipq_add_n(int count, const void *const *src, long long n, int is_bf16, void *out, void *stream);
+int omnipq_add_n(int count, const void *const *src, long long n, int is_e16, void *out, void *stream);
 
-/* The decoder's joint bf16 rows x16 (b, p, c) = [p0 object | p - p0 quad queries] per scene -> two contiguous row blocks
+/* The decoder's joint e16 rows x16 (b, p, c) = [p0 object | p - p0 quad queries] per scene -> two contiguous row blocks
  * obj16 (b * p0, c), quad16 (b * (p - p0), c) for the two prediction heads; and the gradient's way back:
  * out16 (b, p, c) = [g_obj16 | g_quad16] + g_joint16 (each may be NULL = zero).  c % 8 == 0, 16-byte aligned. */
 int omnipq_split_rows(int b, int p, int p0, int c, const void *x16, void *obj16, void *quad16, void *stream);

@@ -8,8 +8,12 @@
  *   F.max_pool2d over nsample       pointnet2/pointnet2_modules.py:251-257
  * and their autograd.  A maintainer binds them from PointnetSAModuleVotes.forward.
  *
- * Layout: activations are position-major bf16, X[p][c] with p = (b * npoint + j) * nsample + s and
- * the channel axis contiguous; weights are [C_out][C_in] bf16; statistics f32/f64.  All pointers
+ * `e16` = the 16-bit floating-point element type of the library that is loaded: bfloat16 in libomnipq_pointops.so,
+ * IEEE half in libomnipq_pointops_f16.so (same sources compiled with -DOMNIPQ_ELEM_F16, same entry points, MFMA opcode
+ * v_mfma_f32_32x32x16_bf16 / _f16; all arithmetic f32 either way).  A binding loads the one that matches its tensors.
+ *
+ * Layout: activations are position-major e16, X[p][c] with p = (b * npoint + j) * nsample + s and
+ * the channel axis contiguous; weights are [C_out][C_in] e16; statistics f32/f64.  All pointers
  * are device pointers, all launches asynchronous on `stream`, return value 0 or an error code
  * (omnipq_pointops.h).  Channel counts must be multiples of 8, GEMM contraction lengths of 32.
  */
@@ -20,7 +24,7 @@ extern "C" {
 #endif
 
 /* X[p][0..cin) = feat_pm[b][idx[p]][:]; X[p][cin..cin+3) = (xyz[b][idx[p]] - new_xyz[b][j]) * inv_radius;
- * columns up to kpad zero.  feat_pm is [b][n][cin] bf16 (NULL when cin == 0); idx is (b,m,s) i32. */
+ * columns up to kpad zero.  feat_pm is [b][n][cin] e16 (NULL when cin == 0); idx is (b,m,s) i32. */
 int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const float *xyz,
                      const float *new_xyz, const int *idx, const void *feat_pm, void *X, void *stream);
 
@@ -38,7 +42,7 @@ int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float i
                           void *stream);
 
 /* Pair launches.  omnipq_pair_hold(): the NEXT GEMM of the calling thread that takes the small-tile path (any
- * omnipq_gemm_nt_bf16* entry point on a few thousand rows) is held back instead of launched; the GEMM after it -- if it is
+ * omnipq_gemm_nt_e16* entry point on a few thousand rows) is held back instead of launched; the GEMM after it -- if it is
  * the same kernel variant on the same stream -- goes out together with it as ONE grid.  Anything else sends the held one out
  * on its own first, and omnipq_pair_flush() does so explicitly (call it after the second GEMM in any case; it returns the
  * number of pair launches made so far).  The two problems must be independent and nothing else may be enqueued on the
@@ -49,30 +53,30 @@ void omnipq_pair_hold(void);
 int omnipq_pair_held(void);       /* 1 while a launch is being held back */
 long long omnipq_pair_flush(void);
 
-/* C[M][N] (bf16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */
-int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+/* C[M][N] (e16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */
+int omnipq_gemm_nt_e16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                         void *stream);
 
-/* C = A B^T + bias[n] (f32 bias added before the bf16 rounding) */
-int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+/* C = A B^T + bias[n] (f32 bias added before the e16 rounding) */
+int omnipq_gemm_nt_e16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                              int ldc, const float *bias, void *stream);
 /* C = A B^T + bias (bias may be NULL) with a workspace of omnipq_gemm_nt_workspace_floats(M, N, K) floats (0 for
  * most shapes): long contractions over few tiles (K >= 1024, <= 128 tiles) are split over several workgroups per
- * tile and combined in f32 before the single rounding to bf16.  Requires ldc == N when it splits. */
+ * tile and combined in f32 before the single rounding to e16.  Requires ldc == N when it splits. */
 long long omnipq_gemm_nt_workspace_floats(int M, int N, int K);
-int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+int omnipq_gemm_nt_e16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                            const float *bias, float *workspace, void *stream);
 
 /* C = dropout(relu(A B^T + bias)) in one launch (the decoder feed-forward's first layer, transformer.py:222-224): the
  * same decisions as omnipq_relu_dropout (omnipq_decoder.h) applied to the stored matrix -- hash of the seed word, the
  * salt and the element index row * ldc + col -- so both routes give the same bits.  dropout_p = 0: ReLU only. */
-int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+int omnipq_gemm_nt_e16_relu_dropout(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                                      int ldc, const float *bias, float dropout_p, const unsigned long long *seed_ptr,
                                      unsigned salt, void *stream);
 
-/* C = (H > 0) ? (A B^T) / (1 - p) : 0 with H [M][ldc] bf16 the stored output of dropout(relu(.)): the data-gradient GEMM
+/* C = (H > 0) ? (A B^T) / (1 - p) : 0 with H [M][ldc] e16 the stored output of dropout(relu(.)): the data-gradient GEMM
  * into such a layer with omnipq_relu_dropout_bwd (omnipq_decoder.h) in its epilogue; same bits as the two launches. */
-int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+int omnipq_gemm_nt_e16_mask(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                              const void *H, float dropout_p, void *stream);
 
 /* C[M][N] (f32) = A[P][M]^T * B[P][N]: the weight gradient.  workspace: omnipq_gemm_tn_workspace_floats(). */
@@ -80,10 +84,10 @@ long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
 /* The slab policy behind it: how many partial tiles the position axis of a weight gradient is cut into (tiles = 128 x 128
  * output tiles, k_step = positions per K-step of the kernel). */
 int omnipq_gemm_tn_slabs(int tiles, long long P, int k_step);
-int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
+int omnipq_gemm_tn_e16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                         float *workspace, void *stream);
 /* the same, and colsum[m] += sum_p A[p][m] (f32): weight AND bias gradient of a linear layer from one pass */
-int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
+int omnipq_gemm_tn_e16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
                                float *workspace, float *colsum, void *stream);
 
 /* Many independent weight gradients in ONE grid plus ONE reduction (the ~115 small dW = dY^T X of the per-point
@@ -105,34 +109,34 @@ typedef struct {
 long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);
 
 /* Conv + BatchNorm + ReLU stacks without the activation tensors: the GEMM that consumes X = relu(bn(Y)) reads the
- * pre-BatchNorm output Y of the layer below and applies relu(a[k] * y + b[k]) (rounded to bf16 -- the values
+ * pre-BatchNorm output Y of the layer below and applies relu(a[k] * y + b[k]) (rounded to e16 -- the values
  * omnipq_bnrelu would have stored) between its global load and its LDS store.  Replaces the separate
  * normalise+ReLU pass of pytorch_utils.py:39-64 (BatchNorm2d, ReLU after every Conv2d) and the write + read of X.
  *   ..._nt_..._affine:  C = relu(a_in .* A + b_in) B^T (+ bias); sums != NULL: also the BatchNorm statistics of C
- *                       (sums / workspace as omnipq_gemm_nt_bf16_stats)
- *   ..._tn_..._affine:  C = A^T relu(ba .* B + bb) (+ colsum as omnipq_gemm_tn_bf16_colsum, may be NULL) */
-int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in, const float *b_in,
+ *                       (sums / workspace as omnipq_gemm_nt_e16_stats)
+ *   ..._tn_..._affine:  C = A^T relu(ba .* B + bb) (+ colsum as omnipq_gemm_tn_e16_colsum, may be NULL) */
+int omnipq_gemm_nt_e16_affine(int M, int N, int K, const void *A, int lda, const float *a_in, const float *b_in,
                                const void *B, int ldb, void *C, int ldc, const float *bias, double *sums,
                                float *workspace, void *stream);
 /* ..._bnaffine: as ..._nt_..._affine, with the BatchNorm finalize of the layer that produced A folded into the
  * prologue (replaces one omnipq_bn_finalize launch per BatchNorm layer): a / b are derived from that layer's totals
  * fin_sums (double[2][K] over `count` rows, all-reduced by the caller under SyncBatchNorm) and stored with mean /
  * invstd for the backward pass; running statistics and conv_bias as in omnipq_bn_finalize (may be NULL). */
-int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
+int omnipq_gemm_nt_e16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
                                  const float *gamma, const float *beta, float eps, float momentum,
                                  float *running_mean, float *running_var, const float *conv_bias, float *a_out,
                                  float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
                                  int ldc, const float *bias, double *sums, float *workspace, void *stream);
 /* Max-pool without re-reading the layer: the ..._pool variants of the statistics GEMMs also record, per ball of `s`
  * consecutive rows (s divides 128 and M) and column, the maximum and minimum of the stored outputs and the first row
- * attaining each (ymax / ymin bf16 [M/s][N], amax / amin uint8 [M/s][N]); once the BatchNorm constants exist,
+ * attaining each (ymax / ymin e16 [M/s][N], amax / amin uint8 [M/s][N]); once the BatchNorm constants exist,
  * omnipq_sa_pool_select takes relu(a y* + b) with y* = max where a >= 0, min where a < 0 -- the max-pool of
  * pointnet2_modules.py:259-262 over relu(bn(.)) -- and writes what omnipq_sa_pool writes (out_f32 / out_pm / arg) plus
  * ysel = y*; omnipq_sa_pool_bwd_stats_sel is omnipq_sa_pool_bwd_stats reading ysel instead of gathering from Y. */
-int omnipq_gemm_nt_bf16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
+int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                                    const float *bias, double *sums, float *workspace, int s, void *ymax, void *ymin,
                                    unsigned char *amax, unsigned char *amin, void *stream);
-int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
+int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
                                       const float *gamma, const float *beta, float eps, float momentum,
                                       float *running_mean, float *running_var, const float *conv_bias, float *a_out,
                                       float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
@@ -152,53 +156,53 @@ int omnipq_sa_pool_select_finalize(long long BM, int C, const void *ymax, const 
 
 int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
                                  const float *g_out, const void *out_pm, double *sums, void *stream);
-int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
+int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
 
 /* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares
- * of the bf16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of
+ * of the e16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of
  * omnipq_gemm_nt_stats_workspace_floats(M, N) elements (0 for few rows: then it may be NULL). */
 long long omnipq_gemm_nt_stats_workspace_floats(int M, int N);
-int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                               int ldc, const float *bias, double *sums, float *workspace, void *stream);
 
 /* Data-gradient GEMM + BatchNorm-backward sums of the layer below in one pass:
- *   dX = dY Wt^T (bf16, [M][N]),  dz = dX * [a y + b > 0],
+ *   dX = dY Wt^T (e16, [M][N]),  dz = dX * [a y + b > 0],
  *   sums[0][n] += sum_m dz,  sums[1][n] += sum_m dz * (y - mean) * invstd
  * Y: that layer's pre-BN activations, [M][N] with pitch ldc.  sums / workspace as above. */
-int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                               int ldc, const void *Y, const float *a, const float *b, const float *mean,
                               const float *invstd, double *sums, float *workspace, void *stream);
 
 /* ---- The first layer of a coordinates-only stage WITHOUT its output (sa1: Conv2d 3 -> C0 + BatchNorm + ReLU over all
  * grouped positions; reference pointnet2_modules.py:243-257, pytorch_utils.py:11-36).  y[p][c] = W0[c] . x0[p] is three
- * FMAs: its consumers recompute it from the grouped coordinates X0 (bf16 [P][ldx], columns 0..2, ldx % 4 == 0: the
- * omnipq_sa_gather output with kpad = 8) and the layer's prepared weights W0 (bf16 [C0][ldw0], columns 0..2), and the
+ * FMAs: its consumers recompute it from the grouped coordinates X0 (e16 [P][ldx], columns 0..2, ldx % 4 == 0: the
+ * omnipq_sa_gather output with kpad = 8) and the layer's prepared weights W0 (e16 [C0][ldw0], columns 0..2), and the
  * layer's BatchNorm statistics / weight gradient follow from the first two moments of x0.  Nothing of shape [P][C0] is
  * written or read for this layer in either direction.
  *   omnipq_sa_xyz_moments    mom = double[12]: S1 = sum_p x0 (3), M2 = sum_p x0 x0^T (3 x 3 row major)
  *   omnipq_sa_xyz_stats      sums = double[2][C0]: sum_p y_c = W0[c] . S1, sum_p y_c^2 = W0[c]^T M2 W0[c]
- *   omnipq_gemm_nt_bf16_xyz_bnaffine   the SECOND layer's GEMM: C = relu(a .* (X0 W0^T) + b) B^T + its statistics, a / b
- *                            from fin_sums exactly as omnipq_gemm_nt_bf16_bnaffine (K = C0 <= 256, M > 8192 rows)
- *   omnipq_gemm_nt_bf16_xyz_bnbwd      the data-gradient GEMM INTO the first layer reduced to five column sums
+ *   omnipq_gemm_nt_e16_xyz_bnaffine   the SECOND layer's GEMM: C = relu(a .* (X0 W0^T) + b) B^T + its statistics, a / b
+ *                            from fin_sums exactly as omnipq_gemm_nt_e16_bnaffine (K = C0 <= 256, M > 8192 rows)
+ *   omnipq_gemm_nt_e16_xyz_bnbwd      the data-gradient GEMM INTO the first layer reduced to five column sums
  *                            sums5 = double[5][N = C0] (zero on entry): sum dz, sum dz yhat, sum dz x0_0..2 with
  *                            dz = (A B^T) * [a y + b > 0]; workspace omnipq_gemm_nt_xyz_workspace_floats(M, N)
- *   omnipq_gemm_tn_bf16_xyz_affine     the second layer's weight gradient C = A^T relu(ba .* (X0 W0^T) + bb)
+ *   omnipq_gemm_tn_e16_xyz_affine     the second layer's weight gradient C = A^T relu(ba .* (X0 W0^T) + bb)
  *   omnipq_sa_xyz_bwd        dW0 f32 [C0][3] from sums5 (rows 0, 1 global under SyncBatchNorm, inv_count = 1 / global
  *                            positions), the moments and the layer's a / mean / invstd */
 int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, double *mom, void *stream);
 int omnipq_sa_xyz_stats(int C, const void *W0, int ldw0, const double *mom, double *sums, void *stream);
-int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
+int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
                                      const double *fin_sums, double count, const float *gamma, const float *beta,
                                      float eps, float momentum, float *running_mean, float *running_var, float *a_out,
                                      float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
                                      int ldc, double *sums, float *workspace, void *stream);
 long long omnipq_gemm_nt_xyz_workspace_floats(int M, int N);
-int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, const void *X0,
+int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, const void *X0,
                                   int ldx, const void *W0, int ldw0, const float *a, const float *b, const float *mean,
                                   const float *invstd, double *sums5, float *workspace, void *stream);
-int omnipq_gemm_tn_bf16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx, const void *W0,
+int omnipq_gemm_tn_e16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx, const void *W0,
                                    int ldw0, const float *ba, const float *bb, float *C, float *workspace, void *stream);
 int omnipq_sa_xyz_bwd(int C, const void *W0, int ldw0, const double *mom, const double *sums5, const float *a,
                       const float *mean, const float *invstd, double inv_count, float *dW, void *stream);
@@ -208,7 +212,7 @@ int omnipq_sa_xyz_bwd(int C, const void *W0, int ldw0, const double *mom, const 
 int omnipq_colstats(long long P, int C, const void *Y, double *sums, void *stream);
 int omnipq_colstats_z(long long P, int C, const void *Y, double *sums, void *stream);
 
-/* sums[c] += sum_p Y[p][c] for bf16 Y [P][C], any C % 8 == 0 (bias gradients). */
+/* sums[c] += sum_p Y[p][c] for e16 Y [P][C], any C % 8 == 0 (bias gradients). */
 int omnipq_colsum(long long P, int C, const void *Y, double *sums, void *stream);
 int omnipq_colsum_f32(long long P, int C, const void *Y, float *sums, void *stream);    /* f32 accumulator */
 
@@ -225,14 +229,14 @@ int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positions, const 
                               const float *a, const float *b, const float *mean, const float *invstd,
                               const double *sums, void *dY, float *dbeta_dgamma, void *stream);
 
-/* Weight preparation in one pass: W f32 [cout][cin] (row pitch ldw) -> Wp bf16 [cp][k] zero-padded with its
- * columns rotated left by `rot` (SA layer 0: [xyz, feat] -> [feat, xyz]) and, if Wt != NULL, Wt bf16 [k][cp]
+/* Weight preparation in one pass: W f32 [cout][cin] (row pitch ldw) -> Wp e16 [cp][k] zero-padded with its
+ * columns rotated left by `rot` (SA layer 0: [xyz, feat] -> [feat, xyz]) and, if Wt != NULL, Wt e16 [k][cp]
  * = Wp^T.  omnipq_unprep_wgrad undoes padding and rotation for the f32 weight gradient. */
 int omnipq_prep_weight(int cout, int cin, int ldw, int cp, int k, int rot, const float *W, void *Wp, void *Wt,
                        void *stream);
 /* The same for a table of matrices in one launch.  segs: device array of nseg packed 56-byte records
  *   { const float *W; int64_t wp_off, wt_off, reserved; int32_t cout, cin, ldw, cp, k, rot; }
- * wp_off / wt_off: element offsets of the record's outputs in the two bf16 arenas.  tiles: device array of
+ * wp_off / wt_off: element offsets of the record's outputs in the two e16 arenas.  tiles: device array of
  * ntiles x int32[4] = {record, first row, first column, 0}, one per 64 x 64 tile of every padded matrix. */
 int omnipq_prep_weights_all(int nseg, int ntiles, const void *segs, const int *tiles, void *Wp_arena,
                             void *Wt_arena, void *stream);
@@ -251,7 +255,7 @@ int omnipq_bn_finalize(int C, double count, const double *sums, const float *gam
 /* X = relu(a * Y + b) */
 int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, const float *b, void *X, void *stream);
 
-/* out[(b,j)][c] = max_s relu(a Y[(b,j,s)][c] + b) -> out_f32 [b*m][C] f32 and out_pm [b*m][C] bf16
+/* out[(b,j)][c] = max_s relu(a Y[(b,j,s)][c] + b) -> out_f32 [b*m][C] f32 and out_pm [b*m][C] e16
  * (both position-major), arg [b*m][C] u8 = first s attaining the maximum */
 int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const float *a, const float *bshift,
                    float *out_f32, void *out_pm, unsigned char *arg, void *stream);
@@ -282,9 +286,9 @@ int omnipq_bn_bwd_apply(long long P, int C, double total_positions, const void *
                         const double *sums, void *dY, void *stream);
 
 /* Feature propagation on position-major rows (pointnet2_modules.py:371-416): three_interpolate with channels
- * contiguous.  feat bf16 [b][m][C]; idx int32 / weight f32 [b][n][3] as from omnipq_three_nn + the reference's
- * inverse-distance weights; result bf16 into columns [col0, col0 + C) of rows [b*n][ldo].  The gradient is
- * ADDED to dfeat f32 [b][m][C] (zero it first).  omnipq_place_rows copies a [rows][C] bf16 block into a column
+ * contiguous.  feat e16 [b][m][C]; idx int32 / weight f32 [b][n][3] as from omnipq_three_nn + the reference's
+ * inverse-distance weights; result e16 into columns [col0, col0 + C) of rows [b*n][ldo].  The gradient is
+ * ADDED to dfeat f32 [b][m][C] (zero it first).  omnipq_place_rows copies a [rows][C] e16 block into a column
  * range of wider rows (the skip features next to the interpolated ones).  C, ldo, col0 multiples of 8. */
 int omnipq_interp_rows(int b, int n, int m, int C, const void *feat, const int *idx, const float *weight, void *out,
                        int ldo, int col0, void *stream);
@@ -297,10 +301,10 @@ int omnipq_interp_rows_grad_csr(int b, int n, int m, int C, const void *g, int l
 int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd, int col0, void *stream);
 
 /* out[0] += sum_i mean(tensor_i), i < nseg <= 72: the benchmark's stand-in loss in one launch over strided
- * views (<= 4 dims, f32 or bf16; no casts, no concatenation).  HOST arrays: ptrs[nseg] device pointers,
- * sizes / strides [nseg][4] in elements (unused leading dims: size 1), is_bf16[nseg].  The descriptors are
+ * views (<= 4 dims, f32 or e16; no casts, no concatenation).  HOST arrays: ptrs[nseg] device pointers,
+ * sizes / strides [nseg][4] in elements (unused leading dims: size 1), is_e16[nseg].  The descriptors are
  * passed by value in the kernel arguments, so the call can be captured into a graph. */
-int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int *sizes, const int *strides, const int *is_bf16,
+int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int *sizes, const int *strides, const int *is_e16,
                         float *out, void *stream);
 
 /* Mean-teacher weight averaging (reference train.py:435-439): ema = alpha * ema + beta * param over a whole model

@@ -1,8 +1,11 @@
-"""Builds libomnipq_pointops.so (hand-written HIP for gfx950) in-tree with hipcc.
+"""Builds the hand-written HIP library for gfx950 in-tree with hipcc -- twice, once per 16-bit element type:
+
+    lib/libomnipq_pointops.so        e16 = bfloat16   (torch.autocast(bfloat16); also every index / f32 operator)
+    lib/libomnipq_pointops_f16.so    e16 = IEEE half  (torch.autocast(float16); -DOMNIPQ_ELEM_F16, same sources, same entry points)
 
     python omni-pq_amd/build.py [--force]
 
-No torch, no hipify, no cmake: one hipcc invocation per translation unit, one link.
+No torch, no hipify, no cmake: one hipcc invocation per translation unit and element type, one link each.
 hipcc cross-compiles gfx950 code objects on a machine without a GPU.
 """
 import os
@@ -14,7 +17,10 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomnipq_pointops.so")
+LIB_F16 = os.path.join(LIBDIR, "libomnipq_pointops_f16.so")
 OBJDIR = os.path.join(HERE, "build")
+# (library, object sub-directory, extra defines)
+VARIANTS = [(LIB, "bf16", []), (LIB_F16, "f16", ["-DOMNIPQ_ELEM_F16=1"])]
 
 # -ffp-contract=off: the index-producing kernels spell out every fma themselves (numerics
 # contract in include/omnipq_pointops.h); nothing else may fuse.
@@ -47,29 +53,36 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    """-> path of the bf16 library (the f16 twin is built next to it: LIB_F16)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     inc = os.path.join(REPO, "include")
     headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
-    objs = []
-    procs = []
-    for src in sources():
-        obj = os.path.join(OBJDIR, src[:-4] + ".o")
-        objs.append(obj)
-        if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
-            cmd = [hipcc()] + COMMON + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd)))
+    procs, links = [], []
+    for lib, sub, defines in VARIANTS:
+        objdir = os.path.join(OBJDIR, sub)
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        compiled = False
+        for src in sources():
+            obj = os.path.join(objdir, src[:-4] + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
+                cmd = [hipcc()] + COMMON + defines + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((src, subprocess.Popen(cmd)))
+                compiled = True
+        links.append((lib, objs, compiled))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    for lib, objs, compiled in links:
+        if force or compiled or _stale(lib, objs):
+            cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     return LIB
 
 

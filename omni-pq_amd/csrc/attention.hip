@@ -26,8 +26,6 @@
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ATT_DMAX = 48;        // padded head dim of the q.k contraction
@@ -67,19 +65,19 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 
 // Fragment with lane = token, k = channels [16 j + 8 h, +8): two 8-byte loads, zero where channel >= D
 // (D % 4 == 0) or the token is out of range.
-__device__ __forceinline__ bf16x8 frag_tok(const bf16_t *row, int j, int h, int D, bool valid) {
+__device__ __forceinline__ e16x8 frag_tok(const e16_t *row, int j, int h, int D, bool valid) {
   const int d0 = 16 * j + 8 * h;
   uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
   if (valid && d0 < D) lo = *reinterpret_cast<const uint2 *>(row + d0);
   if (valid && d0 + 4 < D) hi = *reinterpret_cast<const uint2 *>(row + d0 + 4);
   uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(e16x8, v);
 }
 
-__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return e16_lo(w); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return e16_hi(w); }
 
-__device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
+__device__ __forceinline__ float frag_dot(e16x8 a, e16x8 b) {
   const uint4 x = __builtin_bit_cast(uint4, a), y = __builtin_bit_cast(uint4, b);
   float s = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x);
   s += bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y);
@@ -88,11 +86,11 @@ __device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
   return s;
 }
 
-// 8 accumulator registers [8 j2, +8) -> bf16x8 operand (contraction index = accumulator row order)
-__device__ __forceinline__ bf16x8 pack_regs(const float *p, int j2) {
-  bf16x8 f;
+// 8 accumulator registers [8 j2, +8) -> e16x8 operand (contraction index = accumulator row order)
+__device__ __forceinline__ e16x8 pack_regs(const float *p, int j2) {
+  e16x8 f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) f[e] = (bf16_t)p[8 * j2 + e];
+  for (int e = 0; e < 8; ++e) f[e] = (e16_t)p[8 * j2 + e];
   return f;
 }
 
@@ -126,7 +124,7 @@ struct StageRegs {
   uint2 v[ATT_NP];
 };
 
-__device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, const bf16_t *base, long long s_tok, int t0,
+__device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, const e16_t *base, long long s_tok, int t0,
                                                 int T) {
   StageRegs r;
 #pragma unroll
@@ -138,7 +136,7 @@ __device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, const bf16_
   return r;
 }
 
-__device__ __forceinline__ void stage_store(const StagePlan &sp, const StageRegs &r, bf16_t *lds) {
+__device__ __forceinline__ void stage_store(const StagePlan &sp, const StageRegs &r, e16_t *lds) {
 #pragma unroll
   for (int i = 0; i < ATT_NP; ++i)
     if (sp.tok[i] >= 0) *reinterpret_cast<uint2 *>(lds + sp.tok[i] * ATT_PITCH + sp.off[i]) = r.v[i];
@@ -154,36 +152,36 @@ __device__ __forceinline__ void stage_store(const StagePlan &sp, const StageRegs
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
-__device__ __forceinline__ bf16x8 frag_chan(const bf16_t *lds, int t, int j2, int h, int lane) {
+__device__ __forceinline__ e16x8 frag_chan(const e16_t *lds, int t, int j2, int h, int lane) {
   const int grp = lane >> 4, l16 = lane & 15;
   int c0 = 32 * t + 16 * (grp & 1);
   c0 = c0 + 16 <= ATT_DMAX ? c0 : ATT_DMAX - 16;
-  const bf16_t *p = lds + (16 * j2 + 4 * h + (l16 >> 2)) * ATT_PITCH + c0 + (l16 & 3) * 4;
+  const e16_t *p = lds + (16 * j2 + 4 * h + (l16 >> 2)) * ATT_PITCH + c0 + (l16 & 3) * 4;
   const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)p);
   const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(p + 8 * ATT_PITCH));
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  return __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA(a, b, c) mfma_e16_32x32x16(a, b, c)
 
 // ---- forward ------------------------------------------------------------------------------------------
 // grid (ceil(L/32), N*H), 256 threads.  out: O (bf16, strides o_*), lse2[N*H][L] = log2 sum exp2(s) (f32).
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
-                                                      const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
-                                                      bf16_t *__restrict__ O, float *__restrict__ lse2) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const e16_t *__restrict__ Q,
+                                                      const e16_t *__restrict__ K, const e16_t *__restrict__ V,
+                                                      e16_t *__restrict__ O, float *__restrict__ lse2) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4 + 4 * 32 * 4 * 2];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
   const bool qv = q < g.L;
-  const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
-  bf16_t *vs = reinterpret_cast<bf16_t *>(smem) + wave * 32 * ATT_PITCH;
+  const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
+  e16_t *vs = reinterpret_cast<e16_t *>(smem) + wave * 32 * ATT_PITCH;
 
-  bf16x8 qf[3];
+  e16x8 qf[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) qf[j] = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
 
@@ -197,9 +195,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
   const StagePlan sp = stage_plan(g.D, lane, g.v_sl);
-  const bf16_t *Kl = Kb + (long long)ql * g.k_sl;          // the lane's key row of block 0 (blocks add a uniform offset)
+  const e16_t *Kl = Kb + (long long)ql * g.k_sl;          // the lane's key row of block 0 (blocks add a uniform offset)
   // software pipeline: the K fragments and the V block of iteration it+1 are loaded while it computes
-  bf16x8 kfn[3];
+  e16x8 kfn[3];
   StageRegs vn;
   {
     const int k0 = wave * 32, key = k0 + ql;
@@ -210,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
   }
   for (int it = 0; it < iters; ++it) {
     const int k0 = (it * 4 + wave) * 32;
-    bf16x8 kf[3];
+    e16x8 kf[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) kf[j] = kfn[j];
     const StageRegs vc = vn;
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
     __syncthreads();                                        // V block staged
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
-      const bf16x8 pf = pack_regs(p, j2);
+      const e16x8 pf = pack_regs(p, j2);
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[t] = MFMA(frag_chan(vs, t, j2, h, lane), pf, acc[t]);   // O^T: rows = channels
     }
@@ -307,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
       const float l = ms[128 + qq] + ms[160 + qq] + ms[192 + qq] + ms[224 + qq];
       const float o = comb[(0 * 64 + d) * 33 + qq] + comb[(1 * 64 + d) * 33 + qq] + comb[(2 * 64 + d) * 33 + qq] +
                       comb[(3 * 64 + d) * 33 + qq];
-      O[(long long)(q0 + qq) * g.o_sl + n * g.o_sn + hd * g.D + d] = (bf16_t)(o / l);
+      O[(long long)(q0 + qq) * g.o_sl + n * g.o_sn + hd * g.D + d] = (e16_t)(o / l);
     }
   }
   if (tid < 32 && q0 + tid < g.L) {
@@ -319,21 +317,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const bf16_t 
 
 // ---- backward, dQ ---------------------------------------------------------------------------------------
 // grid (ceil(L/32), N*H).  Also writes delta[N*H][L] = sum_d dO*O for the dK/dV kernel.
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
-                                                         const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
-                                                         const bf16_t *__restrict__ O, const bf16_t *__restrict__ dO,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_t *__restrict__ Q,
+                                                         const e16_t *__restrict__ K, const e16_t *__restrict__ V,
+                                                         const e16_t *__restrict__ O, const e16_t *__restrict__ dO,
                                                          const float *__restrict__ lse2, float *__restrict__ delta,
-                                                         bf16_t *__restrict__ dQ, long long dq_sl, long long dq_sn) {
+                                                         e16_t *__restrict__ dQ, long long dq_sl, long long dq_sn) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
   const bool qv = q < g.L;
-  const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
-  const bf16_t *Ob = O + n * g.o_sn + hd * g.D, *dOb = dO + n * g.o_sn + hd * g.D;
-  bf16_t *ks = reinterpret_cast<bf16_t *>(smem) + wave * 32 * ATT_PITCH;
+  const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
+  const e16_t *Ob = O + n * g.o_sn + hd * g.D, *dOb = dO + n * g.o_sn + hd * g.D;
+  e16_t *ks = reinterpret_cast<e16_t *>(smem) + wave * 32 * ATT_PITCH;
 
-  bf16x8 qf[3], dof[3];
+  e16x8 qf[3], dof[3];
   float dl = 0.f;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -354,8 +352,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
   const StagePlan sp = stage_plan(g.D, lane, g.k_sl);
-  const bf16_t *Kl = Kb + (long long)ql * g.k_sl, *Vl = Vb + (long long)ql * g.v_sl;
-  bf16x8 kfn[3], vfn[3];
+  const e16_t *Kl = Kb + (long long)ql * g.k_sl, *Vl = Vb + (long long)ql * g.v_sl;
+  e16x8 kfn[3], vfn[3];
   StageRegs kn;
   {
     const int k0 = wave * 32, key = k0 + ql;
@@ -369,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
   }
   for (int it = 0; it < iters; ++it) {
     const int k0 = (it * 4 + wave) * 32;
-    bf16x8 kf[3], vf[3];
+    e16x8 kf[3], vf[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) kf[j] = kfn[j], vf[j] = vfn[j];
     const StageRegs kc = kn;
@@ -407,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
     __syncthreads();
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
-      const bf16x8 df = pack_regs(ds, j2);
+      const e16x8 df = pack_regs(ds, j2);
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[t] = MFMA(frag_chan(ks, t, j2, h, lane), df, acc[t]);   // dQ^T: rows = channels
     }
@@ -424,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
     if (q0 + qq < g.L) {
       const float v = comb[(0 * 64 + d) * 33 + qq] + comb[(1 * 64 + d) * 33 + qq] + comb[(2 * 64 + d) * 33 + qq] +
                       comb[(3 * 64 + d) * 33 + qq];
-      dQ[(long long)(q0 + qq) * dq_sl + n * dq_sn + hd * g.D + d] = (bf16_t)(v * g.scale);
+      dQ[(long long)(q0 + qq) * dq_sl + n * dq_sn + hd * g.D + d] = (e16_t)(v * g.scale);
     }
   }
 }
@@ -432,32 +430,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const bf16
 // ---- backward, dK and dV --------------------------------------------------------------------------------
 // grid (ceil(S/128), N*H).  Each WAVE owns 32 keys and walks over all query blocks, so there is nothing to
 // merge; the four waves of a workgroup share the staged Q / dO block and the per-query lse / delta.
-__device__ __forceinline__ bf16x8 frag_lds_tok(const bf16_t *lds, int row, int j, int h, int D) {
+__device__ __forceinline__ e16x8 frag_lds_tok(const e16_t *lds, int row, int j, int h, int D) {
   const int d0 = 16 * j + 8 * h;
   uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
   if (d0 < D) lo = *reinterpret_cast<const uint2 *>(lds + row * ATT_PITCH + d0);
   if (d0 + 4 < D) hi = *reinterpret_cast<const uint2 *>(lds + row * ATT_PITCH + d0 + 4);
   uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(e16x8, v);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf16_t *__restrict__ Q,
-                                                           const bf16_t *__restrict__ K, const bf16_t *__restrict__ V,
-                                                           const bf16_t *__restrict__ dO, const float *__restrict__ lse2,
-                                                           const float *__restrict__ delta, bf16_t *__restrict__ dK,
-                                                           long long dk_sl, long long dk_sn, bf16_t *__restrict__ dV,
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const e16_t *__restrict__ Q,
+                                                           const e16_t *__restrict__ K, const e16_t *__restrict__ V,
+                                                           const e16_t *__restrict__ dO, const float *__restrict__ lse2,
+                                                           const float *__restrict__ delta, e16_t *__restrict__ dK,
+                                                           long long dk_sl, long long dk_sn, e16_t *__restrict__ dV,
                                                            long long dv_sl, long long dv_sn) {
-  __shared__ __attribute__((aligned(16))) bf16_t qs[32 * ATT_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t dos[32 * ATT_PITCH];
+  __shared__ __attribute__((aligned(16))) e16_t qs[32 * ATT_PITCH];
+  __shared__ __attribute__((aligned(16))) e16_t dos[32 * ATT_PITCH];
   __shared__ float rowv[64];                                               // [0,32) lse2, [32,64) delta
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, kl = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int k0 = ((int)blockIdx.x * 4 + wave) * 32, key = k0 + kl;
   const bool kv = key < g.S;
-  const bf16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
-  const bf16_t *dOb = dO + n * g.o_sn + hd * g.D;
+  const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
+  const e16_t *dOb = dO + n * g.o_sn + hd * g.D;
 
-  bf16x8 kf[3], vf[3];
+  e16x8 kf[3], vf[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     kf[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
@@ -543,7 +541,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
     }
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
-      const bf16x8 pf = pack_regs(pt, j2), df = pack_regs(ds, j2);
+      const e16x8 pf = pack_regs(pt, j2), df = pack_regs(ds, j2);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         accv[t] = MFMA(pf, frag_chan(dos, t, j2, h, lane), accv[t]);      // dV: rows = keys, cols = channels
@@ -560,8 +558,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const bf
       for (int r = 0; r < 16; ++r) {
         const int kk = k0 + acc_row(r, h);
         if (kk < g.S) {
-          dV[(long long)kk * dv_sl + n * dv_sn + hd * g.D + d] = (bf16_t)accv[t][r];
-          dK[(long long)kk * dk_sl + n * dk_sn + hd * g.D + d] = (bf16_t)(acck[t][r] * g.scale);
+          dV[(long long)kk * dv_sl + n * dv_sn + hd * g.D + d] = (e16_t)accv[t][r];
+          dK[(long long)kk * dk_sl + n * dk_sn + hd * g.D + d] = (e16_t)(acck[t][r] * g.scale);
         }
       }
     }
@@ -607,7 +605,7 @@ extern "C" int omnipq_attn_fwd(int N, int H, int L, int S, int D, const void *q,
   const int rc = fill_args(g, N, H, L, S, D, strides, dropout_p, seed_ptr, salt);
   if (rc) return rc;
   attn_fwd_kernel<<<dim3((L + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
-      g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (bf16_t *)o, lse2);
+      g, (const e16_t *)q, (const e16_t *)k, (const e16_t *)v, (e16_t *)o, lse2);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -625,12 +623,12 @@ extern "C" int omnipq_attn_bwd(int N, int H, int L, int S, int D, const void *q,
   for (int i = 0; i < 6; ++i)
     if (grad_strides[i] % 4) return OMNIPQ_EINVAL;
   attn_bwd_dq_kernel<<<dim3((L + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
-      g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)o, (const bf16_t *)d_o, lse2, delta,
-      (bf16_t *)dq, grad_strides[0], grad_strides[1]);
+      g, (const e16_t *)q, (const e16_t *)k, (const e16_t *)v, (const e16_t *)o, (const e16_t *)d_o, lse2, delta,
+      (e16_t *)dq, grad_strides[0], grad_strides[1]);
   OMNIPQ_LAUNCH_CHECK();
   attn_bwd_dkdv_kernel<<<dim3((S + 127) / 128, N * H), 256, 0, (hipStream_t)stream>>>(
-      g, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)d_o, lse2, delta, (bf16_t *)dk,
-      grad_strides[2], grad_strides[3], (bf16_t *)dv, grad_strides[4], grad_strides[5]);
+      g, (const e16_t *)q, (const e16_t *)k, (const e16_t *)v, (const e16_t *)d_o, lse2, delta, (e16_t *)dk,
+      grad_strides[2], grad_strides[3], (e16_t *)dv, grad_strides[4], grad_strides[5]);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -19,8 +19,6 @@
 
 namespace omnipq {
 
-// (lo, hi) -> one word of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Two scalar conversions + shift + or
-// are four instructions, and the SLP vectoriser pairs scalar conversions across words, adding two shuffles per word.
 // dropout decisions of the decoder's row kernels and of the GEMM epilogue that applies ReLU + dropout: counter hash of
 // (seed word in device memory, per-call salt, element index)
 __device__ __forceinline__ unsigned dec_seed(const unsigned long long *seed_ptr, unsigned salt) {
@@ -39,10 +37,52 @@ __device__ __forceinline__ unsigned dec_hash(unsigned idx, unsigned seed) {
   return x;
 }
 
+// ---- the library's 16-bit element type ------------------------------------------------------------------------------
+// Every activation / gradient tensor of the hand-written MLP, attention and decoder kernels is stored in ONE 16-bit
+// floating-point type, `e16_t`, fixed when the library is compiled (omni-pq_amd/build.py builds the sources twice):
+//   libomnipq_pointops.so       e16 = bfloat16  (v_mfma_f32_32x32x16_bf16)   torch.autocast(bfloat16): BASELINE configs[1..3]
+//   libomnipq_pointops_f16.so   e16 = IEEE half (v_mfma_f32_32x32x16_f16)    torch.autocast(float16):  BASELINE configs[4]
+// Arithmetic is f32 (f64 across workgroups) either way; only the storage conversions and the MFMA opcode differ, and they
+// are all here.  Entry points carry `e16` in their names and mean "the element type of this library".
+#ifdef OMNIPQ_ELEM_F16
+typedef _Float16 e16_t;
+#define OMNIPQ_ELEM_IS_F16 1
+#else
+typedef __bf16 e16_t;
+#define OMNIPQ_ELEM_IS_F16 0
+#endif
+typedef e16_t e16x8 __attribute__((ext_vector_type(8)));
+typedef e16_t omnipq_e16x2 __attribute__((ext_vector_type(2)));
 typedef float omnipq_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 omnipq_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(omnipq_f32x2{lo, hi}, omnipq_bf16x2));
+typedef float omnipq_f32x16 __attribute__((ext_vector_type(16)));
+
+// low / high half of a 32-bit word of two e16 -> f32.  bf16 is the upper half of an f32: a shift / a mask.
+__device__ __forceinline__ float e16_lo(unsigned w) {
+#if OMNIPQ_ELEM_IS_F16
+  return (float)__builtin_bit_cast(omnipq_e16x2, w)[0];
+#else
+  return __builtin_bit_cast(float, w << 16);
+#endif
+}
+__device__ __forceinline__ float e16_hi(unsigned w) {
+#if OMNIPQ_ELEM_IS_F16
+  return (float)__builtin_bit_cast(omnipq_e16x2, w)[1];
+#else
+  return __builtin_bit_cast(float, w & 0xffff0000u);
+#endif
+}
+// (lo, hi) -> one word of two e16 (round to nearest even).  bf16: ONE v_cvt_pk_bf16_f32 -- two scalar conversions + shift
+// + or are four instructions, and the SLP vectoriser pairs scalar conversions across words, adding two shuffles per word.
+__device__ __forceinline__ unsigned pack_e16x2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(omnipq_f32x2{lo, hi}, omnipq_e16x2));
+}
+// D = A (32 x 16) B (16 x 32) + C on the matrix cores, f32 accumulation
+__device__ __forceinline__ omnipq_f32x16 mfma_e16_32x32x16(const e16x8 &a, const e16x8 &b, const omnipq_f32x16 &c) {
+#if OMNIPQ_ELEM_IS_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // a*a + b*b + c*c exactly as the numerics contract in omnipq_pointops.h states it:

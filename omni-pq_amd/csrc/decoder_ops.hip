@@ -12,7 +12,6 @@
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
 constexpr int LN_MAXCH = 4;          // float4 chunks per lane: C <= 64 * 4 * 4 = 1024
 
 
@@ -23,16 +22,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ void unpack4(uint2 w, float *f) {
-  f[0] = __builtin_bit_cast(float, w.x << 16);
-  f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
-  f[2] = __builtin_bit_cast(float, w.y << 16);
-  f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+  f[0] = e16_lo(w.x);
+  f[1] = e16_hi(w.x);
+  f[2] = e16_lo(w.y);
+  f[3] = e16_hi(w.y);
 }
 
 __device__ __forceinline__ uint2 pack4(const float *f) {
   uint2 w;
-  w.x = pack_bf16x2(f[0], f[1]);
-  w.y = pack_bf16x2(f[2], f[3]);
+  w.x = pack_e16x2(f[0], f[1]);
+  w.y = pack_e16x2(f[2], f[3]);
   return w;
 }
 
@@ -46,7 +45,7 @@ struct LnArgs {
 
 // r = x + dropout(y) for this lane's chunks of one row
 __device__ __forceinline__ void load_residual(const LnArgs &g, long long row, int lane, unsigned seed,
-                                              const float *__restrict__ x, const bf16_t *__restrict__ y,
+                                              const float *__restrict__ x, const e16_t *__restrict__ y,
                                               float (*r)[4]) {
   const int nch = g.C >> 2;
 #pragma unroll
@@ -72,10 +71,10 @@ __device__ __forceinline__ void load_residual(const LnArgs &g, long long row, in
 }
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs g, const float *__restrict__ x,
-                                                    const bf16_t *__restrict__ y, const float *__restrict__ gamma,
+                                                    const e16_t *__restrict__ y, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, float *__restrict__ out32,
-                                                    bf16_t *__restrict__ out16, const bf16_t *__restrict__ pe,
-                                                    bf16_t *__restrict__ out16_pe, float *__restrict__ mean,
+                                                    e16_t *__restrict__ out16, const e16_t *__restrict__ pe,
+                                                    e16_t *__restrict__ out16_pe, float *__restrict__ mean,
                                                     float *__restrict__ rstd) {
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
   const int nch = g.C >> 2;
@@ -129,11 +128,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs g, const float *__re
 }
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs g, const float *__restrict__ x,
-                                                    const bf16_t *__restrict__ y, const float *__restrict__ gamma,
+                                                    const e16_t *__restrict__ y, const float *__restrict__ gamma,
                                                     const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                    const float *__restrict__ g32, const bf16_t *__restrict__ g16,
-                                                    const bf16_t *__restrict__ g16_pe, float *__restrict__ dx,
-                                                    bf16_t *__restrict__ dy, float *__restrict__ dgb,
+                                                    const float *__restrict__ g32, const e16_t *__restrict__ g16,
+                                                    const e16_t *__restrict__ g16_pe, float *__restrict__ dx,
+                                                    e16_t *__restrict__ dy, float *__restrict__ dgb,
                                                     float *__restrict__ part) {
   extern __shared__ float dyn[];                            // [4 waves][dgamma | dbeta][C]
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs a) {
     atomicAdd(it.out + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-__global__ __launch_bounds__(256) void relu_dropout_kernel(long long n4, bf16_t *__restrict__ h, float keep_inv,
+__global__ __launch_bounds__(256) void relu_dropout_kernel(long long n4, e16_t *__restrict__ h, float keep_inv,
                                                           unsigned thresh, unsigned salt,
                                                           const unsigned long long *__restrict__ seed_ptr) {
   const unsigned seed = thresh ? dec_seed(seed_ptr, salt) : 0u;
@@ -292,8 +291,8 @@ __global__ __launch_bounds__(256) void relu_dropout_kernel(long long n4, bf16_t 
   }
 }
 
-__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(long long n4, const bf16_t *__restrict__ h,
-                                                              const bf16_t *d, bf16_t *out, float keep_inv) {
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(long long n4, const e16_t *__restrict__ h,
+                                                              const e16_t *d, e16_t *out, float keep_inv) {
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
     float hv[4], dv[4];
     unpack4(*reinterpret_cast<const uint2 *>(h + q * 4), hv);
@@ -306,14 +305,14 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(long long n4, con
 
 template <bool A_F32>
 __global__ __launch_bounds__(256) void add_to_bf16_kernel(long long n4, const void *__restrict__ a,
-                                                         const bf16_t *__restrict__ b, bf16_t *__restrict__ out) {
+                                                         const e16_t *__restrict__ b, e16_t *__restrict__ out) {
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
     float av[4], bv[4];
     if (A_F32) {
       const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a) + q * 4);
       av[0] = v.x, av[1] = v.y, av[2] = v.z, av[3] = v.w;
     } else {
-      unpack4(*reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(a) + q * 4), av);
+      unpack4(*reinterpret_cast<const uint2 *>(reinterpret_cast<const e16_t *>(a) + q * 4), av);
     }
     unpack4(*reinterpret_cast<const uint2 *>(b + q * 4), bv);
 #pragma unroll
@@ -355,8 +354,8 @@ extern "C" int omnipq_add_dropout_layernorm(long long R, int C, const float *x, 
   LnArgs g{R, C, eps, 1.f, 0u, salt, seed_ptr};
   const int rc = drop_params(y ? dropout_p : 0.f, seed_ptr, &g.thresh, &g.keep_inv);
   if (rc) return rc;
-  ln_fwd_kernel<<<rows_grid(R), 256, 0, (hipStream_t)stream>>>(g, x, (const bf16_t *)y, gamma, beta, out32,
-                                                              (bf16_t *)out16, (const bf16_t *)pe, (bf16_t *)out16_pe,
+  ln_fwd_kernel<<<rows_grid(R), 256, 0, (hipStream_t)stream>>>(g, x, (const e16_t *)y, gamma, beta, out32,
+                                                              (e16_t *)out16, (const e16_t *)pe, (e16_t *)out16_pe,
                                                               mean, rstd);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -388,7 +387,7 @@ static int ln_bwd_impl(long long R, int C, const float *x, const void *y, const 
   if (rc) return rc;
   const long long blocks = ln_bwd_blocks(R);
   ln_bwd_kernel<<<(int)blocks, 256, sizeof(float) * 8 * C, (hipStream_t)stream>>>(
-      g, x, (const bf16_t *)y, gamma, mean, rstd, g32, (const bf16_t *)g16, (const bf16_t *)g16_pe, dx, (bf16_t *)dy,
+      g, x, (const e16_t *)y, gamma, mean, rstd, g32, (const e16_t *)g16, (const e16_t *)g16_pe, dx, (e16_t *)dy,
       dgamma_dbeta, partials);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -442,7 +441,7 @@ extern "C" int omnipq_relu_dropout(long long n, void *h, float dropout_p, const 
   float keep_inv;
   const int rc = drop_params(dropout_p, seed_ptr, &thresh, &keep_inv);
   if (rc) return rc;
-  relu_dropout_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, (bf16_t *)h, keep_inv, thresh, salt,
+  relu_dropout_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, (e16_t *)h, keep_inv, thresh, salt,
                                                                         seed_ptr);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -455,7 +454,7 @@ extern "C" int omnipq_relu_dropout_bwd(long long n, const void *h, const void *d
   if (n == 0) return OMNIPQ_OK;
   if (!h || !d || !out) return OMNIPQ_EINVAL;
   relu_dropout_bwd_kernel<<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(
-      n / 4, (const bf16_t *)h, (const bf16_t *)d, (bf16_t *)out, 1.0f / (1.0f - dropout_p));
+      n / 4, (const e16_t *)h, (const e16_t *)d, (e16_t *)out, 1.0f / (1.0f - dropout_p));
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -465,18 +464,18 @@ namespace omnipq {
 // from a narrow input (3 coordinates -> 32 columns), in one launch instead of cast + zero fill + strided copy
 template <bool F32>
 __global__ __launch_bounds__(256) void pad_rows_bf16_kernel(long long total, int cin, int k, long long ldx,
-                                                            const void *__restrict__ x, bf16_t *__restrict__ out) {
+                                                            const void *__restrict__ x, e16_t *__restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const long long r = i / k;
   const int c = (int)(i - r * k);
   float v = 0.f;
-  if (c < cin) v = F32 ? reinterpret_cast<const float *>(x)[r * ldx + c] : (float)reinterpret_cast<const bf16_t *>(x)[r * ldx + c];
-  out[i] = (bf16_t)v;
+  if (c < cin) v = F32 ? reinterpret_cast<const float *>(x)[r * ldx + c] : (float)reinterpret_cast<const e16_t *>(x)[r * ldx + c];
+  out[i] = (e16_t)v;
 }
 }  // namespace omnipq
 
-extern "C" int omnipq_pad_rows_bf16(long long n, int cin, int k, long long ldx, const void *x, int x_is_f32, void *out16,
+extern "C" int omnipq_pad_rows_e16(long long n, int cin, int k, long long ldx, const void *x, int x_is_f32, void *out16,
                                     void *stream) {
   using namespace omnipq;
   if (n < 0 || cin < 0 || k < cin || k <= 0 || ldx < cin) return OMNIPQ_EINVAL;
@@ -485,25 +484,25 @@ extern "C" int omnipq_pad_rows_bf16(long long n, int cin, int k, long long ldx, 
   const long long total = n * k;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (x_is_f32)
-    pad_rows_bf16_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(total, cin, k, ldx, x, (bf16_t *)out16);
+    pad_rows_bf16_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(total, cin, k, ldx, x, (e16_t *)out16);
   else
-    pad_rows_bf16_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(total, cin, k, ldx, x, (bf16_t *)out16);
+    pad_rows_bf16_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(total, cin, k, ldx, x, (e16_t *)out16);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
 
-extern "C" int omnipq_add_to_bf16(long long n, const void *a, int a_is_f32, const void *b, void *out16,
+extern "C" int omnipq_add_to_e16(long long n, const void *a, int a_is_f32, const void *b, void *out16,
                                   void *stream) {
   using namespace omnipq;
   if (n < 0 || (n % 4)) return OMNIPQ_EINVAL;
   if (n == 0) return OMNIPQ_OK;
   if (!a || !b || !out16) return OMNIPQ_EINVAL;
   if (a_is_f32)
-    add_to_bf16_kernel<true><<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, a, (const bf16_t *)b,
-                                                                               (bf16_t *)out16);
+    add_to_bf16_kernel<true><<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, a, (const e16_t *)b,
+                                                                               (e16_t *)out16);
   else
-    add_to_bf16_kernel<false><<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, a, (const bf16_t *)b,
-                                                                                (bf16_t *)out16);
+    add_to_bf16_kernel<false><<<flat_grid(n / 4), 256, 0, (hipStream_t)stream>>>(n / 4, a, (const e16_t *)b,
+                                                                                (e16_t *)out16);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -529,8 +528,8 @@ __global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a, long long n8, vo
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[2 * e] += __builtin_bit_cast(float, w[e] << 16);
-          acc[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+          acc[2 * e] += e16_lo(w[e]);
+          acc[2 * e + 1] += e16_hi(w[e]);
         }
       } else {
         const float4 lo = reinterpret_cast<const float4 *>(a.src[s])[2 * q], hi = reinterpret_cast<const float4 *>(a.src[s])[2 * q + 1];
@@ -540,8 +539,8 @@ __global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a, long long n8, vo
     }
     if (BF) {
       uint4 o;
-      o.x = pack_bf16x2(acc[0], acc[1]), o.y = pack_bf16x2(acc[2], acc[3]);
-      o.z = pack_bf16x2(acc[4], acc[5]), o.w = pack_bf16x2(acc[6], acc[7]);
+      o.x = pack_e16x2(acc[0], acc[1]), o.y = pack_e16x2(acc[2], acc[3]);
+      o.z = pack_e16x2(acc[4], acc[5]), o.w = pack_e16x2(acc[6], acc[7]);
       reinterpret_cast<uint4 *>(out)[q] = o;
     } else {
       reinterpret_cast<float4 *>(out)[2 * q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -614,8 +613,8 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(long long chunks, int p
     unsigned o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      o[e] = pack_bf16x2(__builtin_bit_cast(float, a[e] << 16) + __builtin_bit_cast(float, d[e] << 16),
-                         __builtin_bit_cast(float, a[e] & 0xffff0000u) + __builtin_bit_cast(float, d[e] & 0xffff0000u));
+      o[e] = pack_e16x2(e16_lo(a[e]) + e16_lo(d[e]),
+                         e16_hi(a[e]) + e16_hi(d[e]));
     v = make_uint4(o[0], o[1], o[2], o[3]);
   }
   out[q] = v;

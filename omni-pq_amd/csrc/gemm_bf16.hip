@@ -22,8 +22,6 @@
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -44,7 +42,7 @@ struct GemmArgs {
   const unsigned long long *drop_seed = nullptr;
 };
 
-__device__ __forceinline__ uint4 ldg16(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ uint4 ldg16(const e16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
 #ifdef OMNIPQ_NT_TRACE
 // Debug build only (tools/nt_trace.py): cycle stamps of a workgroup's phases, thread 0 of the first 4096 workgroups.
@@ -63,7 +61,7 @@ __device__ __forceinline__ long long nt_now() {
 #define NT_STAMP(slot)
 #endif
 
-// STATS = 5: no statistics -- the stored tile is masked by the sign of bn.Y and scaled (omnipq_gemm_nt_bf16_mask).
+// STATS = 5: no statistics -- the stored tile is masked by the sign of bn.Y and scaled (omnipq_gemm_nt_e16_mask).
 // STATS (bf16 output only): per-column sum and sum of squares of the ROUNDED tile values, folded into the
 // store loop -- the BatchNorm statistics of the layer without a second pass over the tensor.
 //   1: atomically added to stats_out = double[2][N]          (few M-tiles: little contention)
@@ -72,7 +70,7 @@ __device__ __forceinline__ long long nt_now() {
 //   gradient w.r.t. the ReLU output, Y the pre-BN activations of that layer (same shape and pitch as C),
 //   dz = dX * [a y + b > 0],   column sums of dz and of dz * (y - mean) * invstd.
 struct BnBwdEpilogue {
-  const bf16_t *Y;
+  const e16_t *Y;
   const float *a, *b, *mean, *invstd;
 };
 
@@ -95,9 +93,9 @@ struct AffineIn {
 constexpr int kAffMaxK = 1024;
 
 __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
-  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
-  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, __builtin_bit_cast(float, w & 0xffff0000u), b1), 0.f);
-  return pack_bf16x2(lo, hi);
+  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, e16_lo(w), b0), 0.f);
+  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, e16_hi(w), b1), 0.f);
+  return pack_e16x2(lo, hi);
 }
 
 // Ball extrema (statistics variants only, s > 0): the rows of C are grouped positions, `s` consecutive rows form a
@@ -108,7 +106,7 @@ __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float
 // omnipq_sa_pool_select then picks per column.  The pooling pass never reads Y again.
 struct PoolOut {
   int s;
-  bf16_t *ymax, *ymin;            // [M / s][N]
+  e16_t *ymax, *ymin;            // [M / s][N]
   unsigned char *amax, *amin;     // [M / s][N] row within the ball
 };
 
@@ -121,15 +119,15 @@ struct PoolOut {
 //          layer has no input gradient, and its weight gradient follows from these sums and the moments of x0
 //          (omnipq_sa_xyz_bwd), so neither dz nor the BatchNorm-backward result of the layer ever exists.
 struct XyzGen {
-  const bf16_t *X0;
+  const e16_t *X0;
   int ldx;
-  const bf16_t *W0;
+  const e16_t *W0;
   int ldw;
 };
 constexpr int kXgMaxC = 256;
 
 __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
-  return pack_bf16x2(lo, hi);
+  return pack_e16x2(lo, hi);
 }
 
 // T: tile edge, 128 (four waves x 2 x 2 MFMA blocks) or 64 (four waves x one block).  The per-point layers outside
@@ -147,7 +145,7 @@ constexpr int kResMaxSteps = 10;
 // The workgroup program of every NT GEMM variant; `bid` = this workgroup's index within ITS problem (blockIdx.x of a
 // plain launch; the pair launch below runs two problems in one grid).
 template <bool OUT_F32, int STATS, bool AFF, int T, int XG, bool KRES>
-__device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
+__device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__restrict__ A, const e16_t *__restrict__ B,
                                              void *__restrict__ Cout, const float *__restrict__ bias,
                                              void *__restrict__ stats_out, const BnBwdEpilogue &bn, const AffineIn &aff,
                                              const PoolOut &pool, const XyzGen &xg, const int bid) {
@@ -169,7 +167,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   __shared__ __attribute__((aligned(16))) unsigned char static_smem[KRES ? 16 : LDS_BYTES];
   unsigned char *const smem = KRES ? dyn_smem : static_smem;
-  bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
+  e16_t *stage = reinterpret_cast<e16_t *>(smem);
   // a | b of the A operand's channels.  T = 128 (PADTAB): the table lives in the 16 padding bytes of the staging rows
   // (512 rows x 4 floats = the 2 x 1024 entries exactly; a in rows 0..255, b in rows 256..511), which nothing else
   // writes before the C tile takes the buffer over -- 8 KB less LDS, so four workgroups fit a CU instead of three.
@@ -212,7 +210,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   // contribute lands in C rows / columns that are never stored, and the loads stay unconditional
   // 16-byte loads (a select against zero makes hipcc split them into predicated dword loads).
   int srow[NI], skc[NI];
-  const bf16_t *ga[NI], *gb[NI];
+  const e16_t *ga[NI], *gb[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int q = tid + i * 256;
@@ -237,8 +235,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   if (XG == 2) {
     for (int c = tid; c < g.N; c += 256) {
       const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
-      *w0_at(c) = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
-                      __builtin_bit_cast(float, w.y << 16), 0.f};
+      *w0_at(c) = f32x4{e16_lo(w.x), e16_hi(w.x),
+                      e16_lo(w.y), 0.f};
     }
     __syncthreads();
   }
@@ -248,9 +246,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
       int ar = m0 + srow[i];
       ar = ar < g.M ? ar : g.M - 1;
       const uint2 v = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)ar * xg.ldx);
-      x0r[i][0] = __builtin_bit_cast(float, v.x << 16);
-      x0r[i][1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
-      x0r[i][2] = __builtin_bit_cast(float, v.y << 16);
+      x0r[i][0] = e16_lo(v.x);
+      x0r[i][1] = e16_hi(v.x);
+      x0r[i][2] = e16_lo(v.y);
     }
   }
   if (AFF) {
@@ -287,8 +285,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
       if (XG == 1) {
         // relu(a (W0 . x0) + b) = relu((a W0) . x0 + b): one table entry (a w0, a w1, a w2, b) per channel
         const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
-        *w0_at(c) = f32x4{av * __builtin_bit_cast(float, w.x << 16), av * __builtin_bit_cast(float, w.x & 0xffff0000u),
-                        av * __builtin_bit_cast(float, w.y << 16), bv};
+        *w0_at(c) = f32x4{av * e16_lo(w.x), av * e16_hi(w.x),
+                        av * e16_lo(w.y), bv};
       }
     }
     __syncthreads();
@@ -306,8 +304,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
   }
 #define OMNIPQ_STORE_TILES(RA, RB, BUF, KT)                                                             \
   {                                                                                                     \
-    bf16_t *sa_ = stage + (BUF) * (2 * T * GPITCH);                                                     \
-    bf16_t *sb_ = sa_ + T * GPITCH;                                                                     \
+    e16_t *sa_ = stage + (BUF) * (2 * T * GPITCH);                                                     \
+    e16_t *sb_ = sa_ + T * GPITCH;                                                                     \
     if (AFF) {                                                                                          \
       /* a, b of this thread's 8 channels of K-step KT (both chunks share them): four LDS reads */      \
       const int k0_ = kbeg + (KT) * GBK + skc[0] * 8;                                                   \
@@ -347,27 +345,27 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
 
   const int frow = lane & 31, fk = (lane >> 5) * 8;
   auto mma_step = [&](int buf) {
-    const bf16_t *sa = stage + buf * (2 * T * GPITCH);
-    const bf16_t *sb = sa + T * GPITCH;
+    const e16_t *sa = stage + buf * (2 * T * GPITCH);
+    const e16_t *sb = sa + T * GPITCH;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[NI], fb[NI];
+      e16x8 fa[NI], fb[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8 *>(sa + (wm * (T / 2) + i * 32 + frow) * GPITCH + kk * 16 + fk);
-        fb[i] = *reinterpret_cast<const bf16x8 *>(sb + (wn * (T / 2) + i * 32 + frow) * GPITCH + kk * 16 + fk);
+        fa[i] = *reinterpret_cast<const e16x8 *>(sa + (wm * (T / 2) + i * 32 + frow) * GPITCH + kk * 16 + fk);
+        fb[i] = *reinterpret_cast<const e16x8 *>(sb + (wn * (T / 2) + i * 32 + frow) * GPITCH + kk * 16 + fk);
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_e16_32x32x16(fa[i], fb[j], acc[i][j]);
     }
   };
 
   if (KRES) {
     const int KP = nk * GBK + 8;               // row pitch: same residue mod 128 bytes as GPITCH, conflict-free b128 reads
-    bf16_t *sa = stage, *sb = stage + T * KP;
+    e16_t *sa = stage, *sb = stage + T * KP;
     uint4 qa[kResMaxSteps], qb[kResMaxSteps];
 #pragma unroll
     for (int kt = 0; kt < kResMaxSteps; ++kt)
@@ -392,14 +390,14 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
         *reinterpret_cast<uint4 *>(sb + srow[0] * KP + kt * GBK + skc[0] * 8) = qb[kt];
       }
     __syncthreads();
-    const bf16_t *pa = sa + (wm * (T / 2) + frow) * KP + fk;
-    const bf16_t *pb = sb + (wn * (T / 2) + frow) * KP + fk;
+    const e16_t *pa = sa + (wm * (T / 2) + frow) * KP + fk;
+    const e16_t *pb = sb + (wn * (T / 2) + frow) * KP + fk;
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(pa + kt * GBK + kk * 16);
-        const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(pb + kt * GBK + kk * 16);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][0], 0, 0, 0);
+        const e16x8 fa = *reinterpret_cast<const e16x8 *>(pa + kt * GBK + kk * 16);
+        const e16x8 fb = *reinterpret_cast<const e16x8 *>(pb + kt * GBK + kk * 16);
+        acc[0][0] = mfma_e16_32x32x16(fa, fb, acc[0][0]);
       }
     }
     __syncthreads();                             // the C tile aliases the operand tiles
@@ -489,17 +487,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
             const float got = __builtin_bit_cast(
                 float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
             const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
-            cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (CP / 2) + j * 16] = pack_bf16x2(lo, hi);
+            cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (CP / 2) + j * 16] = pack_e16x2(lo, hi);
           }
     };
     if (bias)
       pack_tile(std::true_type{});
     else
       pack_tile(std::false_type{});
-    const bf16_t *ct = reinterpret_cast<const bf16_t *>(smem);
+    const e16_t *ct = reinterpret_cast<const e16_t *>(smem);
     __syncthreads();
     NT_STAMP(4);
-    bf16_t *C = reinterpret_cast<bf16_t *>(Cout);
+    e16_t *C = reinterpret_cast<e16_t *>(Cout);
     float cs[8], cs2[8];                   // this thread's 8 columns (piece = tid % PIECES), rows tid / PIECES + RG * it
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cs2[e] = 0.f;
@@ -551,9 +549,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
           unsigned o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float d0 = __builtin_bit_cast(float, w[e] << 16), d1 = __builtin_bit_cast(float, w[e] & 0xffff0000u);
-            const float h0 = __builtin_bit_cast(float, hw[e] << 16), h1 = __builtin_bit_cast(float, hw[e] & 0xffff0000u);
-            o[e] = pack_bf16x2(h0 > 0.f ? d0 * g.drop_keep_inv : 0.f, h1 > 0.f ? d1 * g.drop_keep_inv : 0.f);
+            const float d0 = e16_lo(w[e]), d1 = e16_hi(w[e]);
+            const float h0 = e16_lo(hw[e]), h1 = e16_hi(hw[e]);
+            o[e] = pack_e16x2(h0 > 0.f ? d0 * g.drop_keep_inv : 0.f, h1 > 0.f ? d1 * g.drop_keep_inv : 0.f);
           }
           *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = make_uint4(o[0], o[1], o[2], o[3]);
           continue;
@@ -561,12 +559,12 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
         if (XG != 2) *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
         if (XG == 2) {
           const uint2 xv = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)gr * xg.ldx);
-          const float x0 = __builtin_bit_cast(float, xv.x << 16), x1 = __builtin_bit_cast(float, xv.x & 0xffff0000u);
-          const float x2 = __builtin_bit_cast(float, xv.y << 16);
+          const float x0 = e16_lo(xv.x), x1 = e16_hi(xv.x);
+          const float x2 = e16_lo(xv.y);
           const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float d = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+            const float d = (e & 1) ? e16_hi(w[e >> 1]) : e16_lo(w[e >> 1]);
             const float y = __builtin_fmaf(wcol[e][2], x2, __builtin_fmaf(wcol[e][1], x1, wcol[e][0] * x0));
             const float dz = __builtin_fmaf(av[e], y, bv[e]) > 0.f ? d : 0.f;
             cs[e] += dz;
@@ -580,9 +578,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
           const unsigned w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const unsigned sh = (e & 1) ? 0u : 16u;
-            const float d = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << sh));
-            const float y = __builtin_bit_cast(float, (e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << sh));
+            const float d = (e & 1) ? e16_hi(w[e >> 1]) : e16_lo(w[e >> 1]);
+            const float y = (e & 1) ? e16_hi(yw[e >> 1]) : e16_lo(yw[e >> 1]);
             const float dz = __builtin_fmaf(av[e], y, bv[e]) > 0.f ? d : 0.f;
             cs[e] += dz;
             cs2[e] = __builtin_fmaf(dz, (y - mu[e]) * is[e], cs2[e]);
@@ -591,7 +588,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
           const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float lo = __builtin_bit_cast(float, w[e] << 16), hi = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            const float lo = e16_lo(w[e]), hi = e16_hi(w[e]);
             cs[2 * e] += lo;
             cs2[2 * e] += lo * lo;
             cs[2 * e + 1] += hi;
@@ -620,7 +617,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
             unsigned mx = 0u, mn = 0xffffffffu;
 #pragma unroll
             for (int r = 8 * gq; r < 8 * gq + 8; r += 2) {
-              const unsigned pw = pack_bf16x2(acc[i][j][r], acc[i][j][r + 1]);
+              const unsigned pw = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
               const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, pw) >> 15);
               const unsigned o = pw ^ (sg | 0x80008000u);
               const unsigned row = i * 32 + (r & 3) + 8 * (r >> 2);              // + hbit below; row + 1 for the high half
@@ -667,7 +664,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
           const int r0 = wm * (T / 2) + gi * 16, gc = n0 + wn * (T / 2) + j * 32 + ccol;
           if (m0 + r0 < g.M && gc < g.N) {
             const size_t oidx = (size_t)((m0 + r0) / s_) * g.N + gc;
-            (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(bf16_t, bits);
+            (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
             (upper ? pool.amin : pool.amax)[oidx] = row;
           }
         }
@@ -686,8 +683,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
             if (v < lo) { lo = v; ilo = r; }
           }
           const size_t o = (size_t)((m0 + r0) / pool.s) * g.N + gc;
-          pool.ymax[o] = (bf16_t)hi;
-          pool.ymin[o] = (bf16_t)lo;
+          pool.ymax[o] = (e16_t)hi;
+          pool.ymin[o] = (e16_t)lo;
           pool.amax[o] = (unsigned char)ihi;
           pool.amin[o] = (unsigned char)ilo;
         }
@@ -728,8 +725,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const bf16_t *__
 }
 
 template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false>
-__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const bf16_t *__restrict__ A,
-                                                        const bf16_t *__restrict__ B,
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
+                                                        const e16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
                                                         void *__restrict__ stats_out = nullptr,
@@ -745,7 +742,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? 4 : 2) voi
 // alone covers less than one workgroup per CU -- launched as a pair they cost one launch latency instead of two.
 struct SmallProblem {
   GemmArgs g;
-  const bf16_t *A, *B;
+  const e16_t *A, *B;
   void *C;
   const float *bias;
   void *stats;
@@ -807,7 +804,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int n, int slabs, co
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(long long n4, int N, int slabs,
                                                                 const f32x4 *__restrict__ part,
                                                                 const float *__restrict__ bias,
-                                                                bf16_t *__restrict__ out) {
+                                                                e16_t *__restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   f32x4 s = part[i];
@@ -817,8 +814,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(long long n4, i
     s[0] += bias[c], s[1] += bias[c + 1], s[2] += bias[c + 2], s[3] += bias[c + 3];
   }
   uint2 w;
-  w.x = pack_bf16x2(s[0], s[1]);
-  w.y = pack_bf16x2(s[2], s[3]);
+  w.x = pack_e16x2(s[0], s[1]);
+  w.y = pack_e16x2(s[2], s[3]);
   *reinterpret_cast<uint2 *>(out + i * 4) = w;
 }
 
@@ -850,12 +847,12 @@ static int gemm_nt_splitk_bf16(int M, int N, int K, const void *A, int lda, cons
   GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, used);
-  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
+  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace,
                                                            nullptr);
   OMNIPQ_LAUNCH_CHECK();
   const long long n4 = (long long)M * N / 4;
   splitk_reduce_bf16_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      n4, N, used, reinterpret_cast<const f32x4 *>(workspace), bias, (bf16_t *)C);
+      n4, N, used, reinterpret_cast<const f32x4 *>(workspace), bias, (e16_t *)C);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -915,7 +912,7 @@ static void launch_small(const omnipq::GemmArgs &g, const void *A, const void *B
   if (gemm_nt_kres(g.K)) {
     int lds = 2 * 64 * (g.K + 8) * 2;
     if (lds < 20480) lds = 20480;                // the C tile / statistics fold alias the operand tiles
-    const HeldSmallBlob q{SmallProblem{g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff}, lds};
+    const HeldSmallBlob q{SmallProblem{g, (const e16_t *)A, (const e16_t *)B, C, bias, stats, bn, aff}, lds};
     const bool consumed = hold_or_pair(
         q, STATS * 2 + (AFF ? 1 : 0), (hipStream_t)stream, &held_single<STATS, AFF>,
         [&](const HeldSmallBlob &first, const HeldSmallBlob &second) {
@@ -935,7 +932,7 @@ static void launch_small(const omnipq::GemmArgs &g, const void *A, const void *B
       h.single(h);
     }
     gemm_nt_kernel<false, STATS, AFF, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
-        g, (const bf16_t *)A, (const bf16_t *)B, C, bias, stats, bn, aff, PoolOut(), XyzGen());
+        g, (const e16_t *)A, (const e16_t *)B, C, bias, stats, bn, aff, PoolOut(), XyzGen());
   }
 }
 
@@ -954,7 +951,7 @@ extern "C" long long omnipq_pair_flush(void) {
 }
 
 // C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.
-extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_nt_e16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                    void *C, int ldc, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
@@ -965,7 +962,7 @@ extern "C" int omnipq_gemm_nt_bf16(int M, int N, int K, const void *A, int lda, 
     launch_small<0, false>(g, A, B, C, nullptr, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                           nullptr);
   }
   OMNIPQ_LAUNCH_CHECK();
@@ -983,7 +980,7 @@ extern "C" long long omnipq_gemm_nt_stats_workspace_floats(int M, int N) {
 // C = A B^T (+ bias) as above, and sums[0][n] += sum_m C[m][n], sums[1][n] += sum_m C[m][n]^2 over the bf16
 // values actually stored.  `sums` (double[2][N]) must be zero on entry; `workspace` holds
 // omnipq_gemm_nt_stats_workspace_floats(M, N) floats (may be NULL when that is 0).
-extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                          void *C, int ldc, const float *bias, double *sums, float *workspace,
                                          void *stream) {
   using namespace omnipq;
@@ -998,14 +995,14 @@ extern "C" int omnipq_gemm_nt_bf16_stats(int M, int N, int K, const void *A, int
       const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
       launch_small<1, false>(gs, A, B, C, bias, sums, BnBwdEpilogue(), AffineIn(), stream);
     } else {
-      gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+      gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                                   sums);
     }
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                               workspace);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
@@ -1033,7 +1030,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
     if (small)
       launch_small<0, true>(gs, A, B, C, bias, nullptr, BnBwdEpilogue(), aff, stream);
     else
-      gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+      gemm_nt_kernel<false, 0, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                         bias, nullptr, BnBwdEpilogue(), aff);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
@@ -1044,13 +1041,13 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
     return OMNIPQ_OK;
   }
   if (g.m_tiles <= kStatsDirectTiles) {
-    gemm_nt_kernel<false, 1, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+    gemm_nt_kernel<false, 1, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                       bias, sums, BnBwdEpilogue(), aff, pool);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+  gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                                     workspace, BnBwdEpilogue(), aff, pool);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
@@ -1063,8 +1060,8 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
 }
 
 // C = relu(a_in .* A + b_in) B^T (+ bias), the A operand transformed on the fly (see AffineIn); with `sums`
-// (double[2][N], zero on entry) also the BatchNorm statistics of C as in omnipq_gemm_nt_bf16_stats.
-extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, int lda, const float *a_in,
+// (double[2][N], zero on entry) also the BatchNorm statistics of C as in omnipq_gemm_nt_e16_stats.
+extern "C" int omnipq_gemm_nt_e16_affine(int M, int N, int K, const void *A, int lda, const float *a_in,
                                           const float *b_in, const void *B, int ldb, void *C, int ldc,
                                           const float *bias, double *sums, float *workspace, void *stream) {
   if (!a_in || !b_in) return OMNIPQ_EINVAL;
@@ -1081,12 +1078,12 @@ extern "C" int omnipq_gemm_nt_bf16_affine(int M, int N, int K, const void *A, in
 static int pool_out_check(int M, int N, int s, void *ymax, void *ymin, unsigned char *amax, unsigned char *amin,
                           omnipq::PoolOut *out) {
   if (s <= 0 || (128 % s) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
-  *out = omnipq::PoolOut{s, (omnipq::bf16_t *)ymax, (omnipq::bf16_t *)ymin, amax, amin};
+  *out = omnipq::PoolOut{s, (omnipq::e16_t *)ymax, (omnipq::e16_t *)ymin, amax, amin};
   (void)N;
   return OMNIPQ_OK;
 }
 
-extern "C" int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums,
+extern "C" int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums,
                                                  double count, const float *gamma, const float *beta, float eps,
                                                  float momentum, float *running_mean, float *running_var,
                                                  const float *conv_bias, float *a_out, float *b_out, float *mean_out,
@@ -1094,7 +1091,7 @@ extern "C" int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void
                                                  const float *bias, double *sums, float *workspace, int s, void *ymax,
                                                  void *ymin, unsigned char *amax, unsigned char *amin, void *stream);
 
-extern "C" int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums,
+extern "C" int omnipq_gemm_nt_e16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums,
                                             double count, const float *gamma, const float *beta, float eps,
                                             float momentum, float *running_mean, float *running_var,
                                             const float *conv_bias, float *a_out, float *b_out, float *mean_out,
@@ -1121,7 +1118,7 @@ extern "C" int omnipq_gemm_nt_bf16_bnaffine(int M, int N, int K, const void *A, 
 
 // ..._bnaffine plus the ball extrema of C (see PoolOut): s rows per ball (s divides 128 and M); ymax / ymin bf16
 // [M / s][N], amax / amin uint8 [M / s][N].  `sums` is required (the statistics variants carry the extra pass).
-extern "C" int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums,
+extern "C" int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums,
                                                  double count, const float *gamma, const float *beta, float eps,
                                                  float momentum, float *running_mean, float *running_var,
                                                  const float *conv_bias, float *a_out, float *b_out, float *mean_out,
@@ -1151,8 +1148,8 @@ extern "C" int omnipq_gemm_nt_bf16_bnaffine_pool(int M, int N, int K, const void
   return gemm_nt_affine_impl(M, N, K, A, lda, aff, B, ldb, C, ldc, bias, sums, workspace, stream, pool);
 }
 
-// omnipq_gemm_nt_bf16_stats plus the ball extrema of C (see PoolOut).
-extern "C" int omnipq_gemm_nt_bf16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+// omnipq_gemm_nt_e16_stats plus the ball extrema of C (see PoolOut).
+extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                               void *C, int ldc, const float *bias, double *sums, float *workspace,
                                               int s, void *ymax, void *ymin, unsigned char *amax, unsigned char *amin,
                                               void *stream) {
@@ -1167,13 +1164,13 @@ extern "C" int omnipq_gemm_nt_bf16_stats_pool(int M, int N, int K, const void *A
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   if (g.m_tiles <= kStatsDirectTiles) {
-    gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+    gemm_nt_kernel<false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                                 sums, BnBwdEpilogue(), AffineIn(), pool);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias,
+  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                               workspace, BnBwdEpilogue(), AffineIn(), pool);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
@@ -1189,8 +1186,8 @@ extern "C" int omnipq_gemm_nt_bf16_stats_pool(int M, int N, int K, const void *A
 //   dX[M][N] = dY[M][K] Wt[N][K]^T  (stored bf16),   dz = dX * [a y + b > 0],
 //   sums[0][n] += sum_m dz,   sums[1][n] += sum_m dz * (y - mean) * invstd
 // Y = that layer's pre-BN activations [M][N] (pitch ldc, like dX); sums double[2][N] zero on entry;
-// workspace as for omnipq_gemm_nt_bf16_stats.
-extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+// workspace as for omnipq_gemm_nt_e16_stats.
+extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                          void *C, int ldc, const void *Y, const float *a, const float *b,
                                          const float *mean, const float *invstd, double *sums, float *workspace,
                                          void *stream) {
@@ -1202,20 +1199,20 @@ extern "C" int omnipq_gemm_nt_bf16_bnbwd(int M, int N, int K, const void *A, int
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  BnBwdEpilogue bn{(const bf16_t *)Y, a, b, mean, invstd};
+  BnBwdEpilogue bn{(const e16_t *)Y, a, b, mean, invstd};
   if (g.m_tiles <= kStatsDirectTiles) {
     if (gemm_nt_small_tiles(M, N)) {
       const GemmArgs gs = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
       launch_small<3, false>(gs, A, B, C, nullptr, sums, bn, AffineIn(), stream);
     } else {
-      gemm_nt_kernel<false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+      gemm_nt_kernel<false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                   nullptr, sums, bn);
     }
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, nullptr,
+  gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, nullptr,
                                                               workspace, bn);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
@@ -1234,10 +1231,10 @@ extern "C" long long omnipq_gemm_nt_xyz_workspace_floats(int M, int N) {
   return m_tiles * 5 * (long long)N;
 }
 
-// C[M][N] = relu(a .* (X0 W0^T) + b) B^T with the statistics of C (as omnipq_gemm_nt_bf16_bnaffine: a / b derived from
+// C[M][N] = relu(a .* (X0 W0^T) + b) B^T with the statistics of C (as omnipq_gemm_nt_e16_bnaffine: a / b derived from
 // fin_sums = the first layer's totals, which come from omnipq_sa_xyz_stats).  X0 bf16 [M][ldx] (columns 0..2), W0 bf16
 // [K][ldw0] (columns 0..2), K <= 256, M > 64 * 128 (the partial-sum path), workspace omnipq_gemm_nt_stats_workspace_floats.
-extern "C" int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
+extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
                                                 const double *fin_sums, double count, const float *gamma,
                                                 const float *beta, float eps, float momentum, float *running_mean,
                                                 float *running_var, float *a_out, float *b_out, float *mean_out,
@@ -1266,11 +1263,11 @@ extern "C" int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void 
   aff.count = count;
   aff.eps = eps;
   aff.momentum = momentum;
-  const XyzGen xg{(const bf16_t *)X0, ldx, (const bf16_t *)W0, ldw0};
+  const XyzGen xg{(const e16_t *)X0, ldx, (const e16_t *)W0, ldw0};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   gemm_nt_kernel<false, 2, true, 128, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
-      g, (const bf16_t *)B, (const bf16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
+      g, (const e16_t *)B, (const e16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1284,7 +1281,7 @@ extern "C" int omnipq_gemm_nt_bf16_xyz_bnaffine(int M, int N, int K, const void 
 // above [M][K], B = its transposed weights [N][K]), y = X0 W0^T, dz = dX * [a y + b > 0]:
 //   sums5[0][n] = sum dz, [1] = sum dz (y - mean) invstd, [2 + c] = sum dz x0_c   (double[5][N], zero on entry)
 // Nothing of size M x N is written.  N <= 256, M > 64 * 128, workspace omnipq_gemm_nt_xyz_workspace_floats(M, N).
-extern "C" int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                              const void *X0, int ldx, const void *W0, int ldw0, const float *a,
                                              const float *b, const float *mean, const float *invstd, double *sums5,
                                              float *workspace, void *stream) {
@@ -1296,12 +1293,12 @@ extern "C" int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A,
     return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, N, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
-  const XyzGen xg{(const bf16_t *)X0, ldx, (const bf16_t *)W0, ldw0};
+  const XyzGen xg{(const e16_t *)X0, ldx, (const e16_t *)W0, ldw0};
   const BnBwdEpilogue bn{nullptr, a, b, mean, invstd};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   gemm_nt_kernel<false, 4, false, 128, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
-      g, (const bf16_t *)A, (const bf16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
+      g, (const e16_t *)A, (const e16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1312,7 +1309,7 @@ extern "C" int omnipq_gemm_nt_bf16_xyz_bnbwd(int M, int N, int K, const void *A,
 }
 
 // Same with a per-column f32 bias added to the accumulators before rounding:  C = A B^T + bias[n].
-extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_nt_e16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                         void *C, int ldc, const float *bias, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
@@ -1323,7 +1320,7 @@ extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int 
     launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                           bias);
   }
   OMNIPQ_LAUNCH_CHECK();
@@ -1333,7 +1330,7 @@ extern "C" int omnipq_gemm_nt_bf16_bias(int M, int N, int K, const void *A, int 
 // C = dropout(relu(A B^T + bias)): the decoder feed-forward's first linear layer with its activation pass in the epilogue.
 // The decisions are those of omnipq_relu_dropout on the stored matrix (hash of seed word, salt and the element index
 // row * ldc + col), so the two routes give the same bits; dropout_p = 0: ReLU only (seed_ptr may be NULL).
-extern "C" int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_nt_e16_relu_dropout(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                                 void *C, int ldc, const float *bias, float dropout_p,
                                                 const unsigned long long *seed_ptr, unsigned salt, void *stream) {
   using namespace omnipq;
@@ -1355,7 +1352,7 @@ extern "C" int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void 
   if (small)
     launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   else
-    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C, bias);
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1363,7 +1360,7 @@ extern "C" int omnipq_gemm_nt_bf16_relu_dropout(int M, int N, int K, const void 
 // C = (H > 0) ? (A B^T) / (1 - p) : 0: a data-gradient GEMM whose result passes backwards through dropout(relu(.)), H
 // [M][ldc] being that layer's stored output (positive exactly where the unit was active and kept) -- what
 // omnipq_relu_dropout_bwd does to the stored product, in the epilogue (same bits: the product is rounded to bf16 first).
-extern "C" int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+extern "C" int omnipq_gemm_nt_e16_mask(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                                         int ldc, const void *H, float dropout_p, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
@@ -1373,11 +1370,11 @@ extern "C" int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int 
   const bool small = gemm_nt_small_tiles(M, N);
   GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, small ? 64 : 128);
   g.drop_keep_inv = 1.0f / (1.0f - dropout_p);
-  const BnBwdEpilogue bn{(const bf16_t *)H, nullptr, nullptr, nullptr, nullptr};
+  const BnBwdEpilogue bn{(const e16_t *)H, nullptr, nullptr, nullptr, nullptr};
   if (small)
     launch_small<5, false>(g, A, B, C, nullptr, nullptr, bn, AffineIn(), stream);
   else
-    gemm_nt_kernel<false, 5><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+    gemm_nt_kernel<false, 5><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                             nullptr, nullptr, bn);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1386,7 +1383,7 @@ extern "C" int omnipq_gemm_nt_bf16_mask(int M, int N, int K, const void *A, int 
 // C = A B^T + bias (bias may be NULL) with an optional workspace of omnipq_gemm_nt_workspace_floats(M, N, K)
 // floats: when that is non-zero and the workspace is given, the contraction is split over several workgroups
 // per tile (same result up to f32 summation order, one rounding to bf16 at the end).
-extern "C" int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
+extern "C" int omnipq_gemm_nt_e16_ws(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                                       int ldc, const float *bias, float *workspace, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
@@ -1400,7 +1397,7 @@ extern "C" int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int ld
     launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, C,
+    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
                                                                           bias);
   }
   OMNIPQ_LAUNCH_CHECK();
@@ -1409,7 +1406,7 @@ extern "C" int omnipq_gemm_nt_bf16_ws(int M, int N, int K, const void *A, int ld
 
 // C[M][N] (f32) = A[M][K] * B[N][K]^T with K split into `slabs` slices; `workspace` holds
 // slabs*M*N floats.  Used for the weight gradient, where K = number of grouped positions.
-extern "C" int omnipq_gemm_nt_bf16_splitk(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_nt_e16_splitk(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                           float *C, int slabs, float *workspace, void *stream) {
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0 || slabs < 1) return OMNIPQ_EINVAL;
@@ -1421,7 +1418,7 @@ extern "C" int omnipq_gemm_nt_bf16_splitk(int M, int N, int K, const void *A, in
   GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, used);
-  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
+  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace,
                                                            nullptr);
   OMNIPQ_LAUNCH_CHECK();
   const int n = M * N;

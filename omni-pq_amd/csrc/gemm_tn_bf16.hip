@@ -18,8 +18,6 @@
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -43,25 +41,25 @@ struct TnArgs {
 // relu(ba[n] * Y[p][n] + bb[n]) rounded to bf16 -- the activations that layer's normalise+ReLU pass would have
 // stored, rebuilt between the global load and the LDS store (see gemm_bf16.hip: AffineIn).
 __device__ __forceinline__ unsigned tn_affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
-  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, __builtin_bit_cast(float, w << 16), b0), 0.f);
-  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, __builtin_bit_cast(float, w & 0xffff0000u), b1), 0.f);
-  return pack_bf16x2(lo, hi);
+  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, e16_lo(w), b0), 0.f);
+  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, e16_hi(w), b1), 0.f);
+  return pack_e16x2(lo, hi);
 }
 
 // XGB (with AFFB): the layer below is the never-materialised first layer of a coordinates-only stage (gemm_bf16.hip:
 // XyzGen): B points at the grouped coordinates x0 (bf16 [P][ldb], columns 0..2) and its pre-BN output is recomputed as
 // y[p][n] = W0[n] . x0[p] from the layer's prepared weights W0 (bf16 [N][ldw0], columns 0..2) before the affine + ReLU.
 struct TnXyz {
-  const bf16_t *W0;
+  const e16_t *W0;
   int ldw;
 };
 
 __device__ __forceinline__ unsigned tn_pack2(float lo, float hi) {
-  return pack_bf16x2(lo, hi);
+  return pack_e16x2(lo, hi);
 }
 
 template <bool AFFB, bool XGB = false>
-__device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restrict__ A, const bf16_t *__restrict__ B,
+__device__ __forceinline__ void tn_tile(const TnArgs &g, const e16_t *__restrict__ A, const e16_t *__restrict__ B,
                                         float *__restrict__ part, float *__restrict__ colsum, const int id,
                                         const float *__restrict__ ba = nullptr, const float *__restrict__ bb = nullptr,
                                         const TnXyz xg = TnXyz()) {
@@ -69,7 +67,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
   constexpr int STAGE_ELEMS = 2 * 2 * TBK * TPITCH;            // 18432 bf16 = 36 KB: four workgroups per CU
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_ELEMS * 2];
   static_assert(16 * 128 * 4 <= STAGE_ELEMS * 2, "the column-sum fold aliases the staging buffers");
-  bf16_t *stage = reinterpret_cast<bf16_t *>(smem);
+  e16_t *stage = reinterpret_cast<e16_t *>(smem);
 
   // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8 picks the XCD and
   // all tiles of one slab are placed on it -- the slab's rows are then fetched into ONE L2 and shared by the
@@ -137,8 +135,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
         // relu(a (W0 . x0) + b) = relu((a W0) . x0 + b): one table entry (a w0, a w1, a w2, b) per channel
         const uint2 w = *reinterpret_cast<const uint2 *>(xg.W0 + (size_t)c * xg.ldw);
         const float av = ba[c];
-        s_w0[tid] = f32x4{av * __builtin_bit_cast(float, w.x << 16), av * __builtin_bit_cast(float, w.x & 0xffff0000u),
-                          av * __builtin_bit_cast(float, w.y << 16), bb[c]};
+        s_w0[tid] = f32x4{av * e16_lo(w.x), av * e16_hi(w.x),
+                          av * e16_lo(w.y), bb[c]};
       }
     }
     __syncthreads();
@@ -163,8 +161,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
     }
   };
   auto store_tiles = [&](int buf) {
-    bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
-    bf16_t *sb = sa + TBK * TPITCH;
+    e16_t *sa = stage + buf * (2 * TBK * TPITCH);
+    e16_t *sb = sa + TBK * TPITCH;
     f32x4 wx[XGB ? 8 : 1];               // both chunks of a thread cover the same eight channels
     if (XGB) {
 #pragma unroll
@@ -173,8 +171,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (XGB) {
-        const float x0 = __builtin_bit_cast(float, rb[i].x << 16), x1 = __builtin_bit_cast(float, rb[i].x & 0xffff0000u);
-        const float x2 = __builtin_bit_cast(float, rb[i].y << 16);
+        const float x0 = e16_lo(rb[i].x), x1 = e16_hi(rb[i].x);
+        const float x2 = e16_lo(rb[i].y);
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -199,8 +197,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
         const unsigned w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          csum[2 * e] += __builtin_bit_cast(float, w[e] << 16);
-          csum[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+          csum[2 * e] += e16_lo(w[e]);
+          csum[2 * e + 1] += e16_hi(w[e]);
         }
       }
       *reinterpret_cast<uint4 *>(sa + spos[i] * TPITCH + sc8[i] * 8) = ra[i];
@@ -225,27 +223,27 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
-    const bf16_t *sa = stage + buf * (2 * TBK * TPITCH);
-    const bf16_t *sb = sa + TBK * TPITCH;
+    const e16_t *sa = stage + buf * (2 * TBK * TPITCH);
+    const e16_t *sb = sa + TBK * TPITCH;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[2], fb[2];
+      e16x8 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const bf16_t *pa = sa + (kk * 16 + tr_row) * TPITCH + wm * 64 + i * 32 + tr_col;
-        const bf16_t *pb = sb + (kk * 16 + tr_row) * TPITCH + wn * 64 + i * 32 + tr_col;
+        const e16_t *pa = sa + (kk * 16 + tr_row) * TPITCH + wm * 64 + i * 32 + tr_col;
+        const e16_t *pb = sb + (kk * 16 + tr_row) * TPITCH + wn * 64 + i * 32 + tr_col;
         const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pa);
         const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pa + 4 * TPITCH));
         const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pb);
         const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pb + 4 * TPITCH));
-        fa[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-        fb[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        fa[i] = __builtin_bit_cast(e16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        fb[i] = __builtin_bit_cast(e16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_e16_32x32x16(fa[i], fb[j], acc[i][j]);
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
@@ -286,22 +284,22 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const bf16_t *__restric
     }
 }
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const bf16_t *__restrict__ A,
-                                                        const bf16_t *__restrict__ B,
+__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const e16_t *__restrict__ A,
+                                                        const e16_t *__restrict__ B,
                                                         float *__restrict__ part, float *__restrict__ colsum) {
   tn_tile<false>(g, A, B, part, colsum, (int)blockIdx.x);
 }
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_affine_kernel(TnArgs g, const bf16_t *__restrict__ A,
-                                                               const bf16_t *__restrict__ B,
+__global__ __launch_bounds__(256, 4) void gemm_tn_affine_kernel(TnArgs g, const e16_t *__restrict__ A,
+                                                               const e16_t *__restrict__ B,
                                                                float *__restrict__ part, float *__restrict__ colsum,
                                                                const float *__restrict__ ba,
                                                                const float *__restrict__ bb) {
   tn_tile<true>(g, A, B, part, colsum, (int)blockIdx.x, ba, bb);
 }
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_xyz_kernel(TnArgs g, const bf16_t *__restrict__ A,
-                                                            const bf16_t *__restrict__ X0,
+__global__ __launch_bounds__(256, 4) void gemm_tn_xyz_kernel(TnArgs g, const e16_t *__restrict__ A,
+                                                            const e16_t *__restrict__ X0,
                                                             float *__restrict__ part, const float *__restrict__ ba,
                                                             const float *__restrict__ bb, TnXyz xg) {
   tn_tile<true, true>(g, A, X0, part, nullptr, (int)blockIdx.x, ba, bb, xg);
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_xyz_kernel(TnArgs g, const bf1
 // also crops the padded rows / columns and writes the gradient in the parameter's own shape.
 constexpr int kGroupMax = 32;
 struct TnGroupItem {
-  const bf16_t *A, *B;
+  const e16_t *A, *B;
   float *part, *colsum, *out;
   const float *ba, *bb;         // AFFB launches only
   int M, N, P, lda, ldb, p_chunk, m_tiles, n_tiles;
@@ -429,14 +427,14 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
                         float *workspace, float *colsum, const float *ba, const float *bb, void *stream,
                         const void *W0 = nullptr, int ldw0 = 0);
 
-extern "C" int omnipq_gemm_tn_bf16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_tn_e16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                    float *C, float *workspace, void *stream) {
   return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, nullptr, nullptr, nullptr, stream);
 }
 
 // The same, and colsum[m] += sum_p A[p][m] (f32, zero or a running total on entry): weight and bias gradient
 // of a linear layer from one pass over dY.
-extern "C" int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_tn_e16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                           float *C, float *workspace, float *colsum, void *stream) {
   if (!colsum) return OMNIPQ_EINVAL;
   return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, nullptr, nullptr, stream);
@@ -444,7 +442,7 @@ extern "C" int omnipq_gemm_tn_bf16_colsum(int M, int N, int P, const void *A, in
 
 // C = A^T relu(ba .* B + bb): the B operand (activations of a conv+BN+ReLU layer) rebuilt from that layer's
 // pre-BatchNorm output on the fly; colsum may be NULL.
-extern "C" int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
+extern "C" int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                           const float *ba, const float *bb, float *C, float *workspace,
                                           float *colsum, void *stream) {
   if (!ba || !bb) return OMNIPQ_EINVAL;
@@ -453,7 +451,7 @@ extern "C" int omnipq_gemm_tn_bf16_affine(int M, int N, int P, const void *A, in
 
 // C = A^T relu(ba .* (X0 W0^T) + bb): the weight gradient of the layer ABOVE a never-materialised first layer (see TnXyz).
 // X0 bf16 [P][ldx] (columns 0..2), W0 bf16 [N][ldw0] (columns 0..2).
-extern "C" int omnipq_gemm_tn_bf16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx,
+extern "C" int omnipq_gemm_tn_e16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx,
                                               const void *W0, int ldw0, const float *ba, const float *bb, float *C,
                                               float *workspace, void *stream) {
   if (!ba || !bb || !W0 || (ldx % 4) || (ldw0 % 4) || ldx < 3 || ldw0 < 3) return OMNIPQ_EINVAL;
@@ -474,13 +472,13 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
   const int used = P > 0 ? (P + g.p_chunk - 1) / g.p_chunk : 1;
   dim3 grid(tiles * ((used + 7) / 8) * 8);
   if (W0)
-    gemm_tn_xyz_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace, ba, bb,
-                                                            TnXyz{(const bf16_t *)W0, ldw0});
+    gemm_tn_xyz_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace, ba, bb,
+                                                            TnXyz{(const e16_t *)W0, ldw0});
   else if (ba)
-    gemm_tn_affine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace,
+    gemm_tn_affine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace,
                                                                colsum, ba, bb);
   else
-    gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)A, (const bf16_t *)B, workspace, colsum);
+    gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace, colsum);
   OMNIPQ_LAUNCH_CHECK();
   const int n4 = M * N / 4;        // M, N multiples of 8
   const f32x4 *part = reinterpret_cast<const f32x4 *>(workspace);
@@ -562,8 +560,8 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
         const omnipq_tn_problem_ &q = pr[next];
         if ((q.ba != nullptr) == (pass == 1)) {
           TnGroupItem &it = a.item[a.n++];
-          it.A = (const bf16_t *)q.A;
-          it.B = (const bf16_t *)q.B;
+          it.A = (const e16_t *)q.A;
+          it.B = (const e16_t *)q.B;
           it.part = workspace + ws_off[next];
           it.colsum = q.colsum;
           it.out = q.out;

@@ -10,22 +10,21 @@
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
 
 struct HeadOut {
-  bf16_t *obj;      // [R][2]
+  e16_t *obj;      // [R][2]
   float *center;    // [R][3]   = y_centre + base_xyz
-  bf16_t *hs;       // [R][nh]
-  bf16_t *hrn;      // [R][nh]
-  bf16_t *hr;       // [R][nh]  = hrn * (pi / nh)
-  bf16_t *ss;       // [R][ns]
-  bf16_t *srn;      // [R][ns][3]
+  e16_t *hs;       // [R][nh]
+  e16_t *hrn;      // [R][nh]
+  e16_t *hr;       // [R][nh]  = hrn * (pi / nh)
+  e16_t *ss;       // [R][ns]
+  e16_t *srn;      // [R][ns][3]
   float *sr;        // [R][ns][3] = srn * mean_size
   float *pred;      // [R][3]     = (sr + mean_size)[argmax ss]
-  bf16_t *sem;      // [R][ncls]
+  e16_t *sem;      // [R][ncls]
 };
 
-__device__ __forceinline__ int head_argmax(const bf16_t *scores, int ns) {
+__device__ __forceinline__ int head_argmax(const e16_t *scores, int ns) {
   // torch.argmax: the first maximum
   int best = 0;
   float bv = (float)scores[0];
@@ -54,10 +53,10 @@ __device__ __forceinline__ void pos_store(const PosOut &po, int r, int c, float 
 // one row per 128 threads: r = the row (clamped by the caller; `live` false for a half-block past the end), t = 0..127,
 // s_pick = this row's slot in shared memory.  Contains a workgroup barrier: every thread of the block calls it.
 __device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s_pick, int nh, int ns, int ncls,
-                                                 const bf16_t *__restrict__ y, int ldy, const float *__restrict__ base,
+                                                 const e16_t *__restrict__ y, int ldy, const float *__restrict__ base,
                                                  const float *__restrict__ means, float hr_scale, const HeadOut &o,
                                                  const PosOut &po) {
-  const bf16_t *row = y + (size_t)r * ldy;
+  const e16_t *row = y + (size_t)r * ldy;
   const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
   const int ctot = c_sem + ncls;
   if (t == 0 && live) *s_pick = head_argmax(row + c_ss, ns);
@@ -65,7 +64,7 @@ __device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s
   if (!live) return;
   const int pick = *s_pick;
   for (int c = t; c < ctot; c += 128) {
-    const bf16_t v = row[c];
+    const e16_t v = row[c];
     if (c < c_ctr) {
       o.obj[(size_t)r * 2 + c] = v;
     } else if (c < c_hs) {
@@ -78,7 +77,7 @@ __device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s
     } else if (c < c_ss) {
       const int k = c - c_hr;
       o.hrn[(size_t)r * nh + k] = v;
-      o.hr[(size_t)r * nh + k] = (bf16_t)((float)v * hr_scale);
+      o.hr[(size_t)r * nh + k] = (e16_t)((float)v * hr_scale);
     } else if (c < c_sr) {
       o.ss[(size_t)r * ns + (c - c_ss)] = v;
     } else if (c < c_sem) {
@@ -93,7 +92,7 @@ __device__ __forceinline__ void head_decode_body(int r, int t, bool live, int *s
   }
 }
 
-__global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns, int ncls, const bf16_t *__restrict__ y,
+__global__ __launch_bounds__(128) void head_decode_kernel(int R, int nh, int ns, int ncls, const e16_t *__restrict__ y,
                                                          int ldy, const float *__restrict__ base,
                                                          const float *__restrict__ means, float hr_scale, HeadOut o) {
   __shared__ int s_pick;
@@ -117,13 +116,13 @@ __device__ __forceinline__ float head_grad_at(const HeadGrad &g, int b, int k, i
   if (!g.ptr) return 0.f;
   const int j1 = j / g.n2, j2 = j - j1 * g.n2;
   const long long off = (long long)b * g.sb + (long long)k * g.sk + (long long)j1 * g.s1 + (long long)j2 * g.s2;
-  return g.is_bf16 ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
+  return g.is_bf16 ? (float)reinterpret_cast<const e16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
 }
 
 __device__ __forceinline__ void head_decode_bwd_body(int r, int t, bool live, int *s_pick, int K, int nh, int ns, int ncls,
-                                                     const bf16_t *__restrict__ y, int ldy,
+                                                     const e16_t *__restrict__ y, int ldy,
                                                      const float *__restrict__ means, float hr_scale,
-                                                     const HeadGrads &gs, bf16_t *__restrict__ dy, int lddy,
+                                                     const HeadGrads &gs, e16_t *__restrict__ dy, int lddy,
                                                      float *__restrict__ dbase, bool acc) {
   const int b = r / K, k = r - b * K;
   const int c_ctr = 2, c_hs = 5, c_hr = 5 + nh, c_ss = 5 + 2 * nh, c_sr = c_ss + ns, c_sem = c_sr + 3 * ns;
@@ -153,15 +152,15 @@ __device__ __forceinline__ void head_decode_bwd_body(int r, int t, bool live, in
     } else {
       d = head_grad_at(gs.g[9], b, k, c - c_sem);
     }
-    dy[(size_t)r * lddy + c] = (bf16_t)d;
+    dy[(size_t)r * lddy + c] = (e16_t)d;
   }
-  for (int c = ctot + t; c < lddy; c += 128) dy[(size_t)r * lddy + c] = (bf16_t)0.f;
+  for (int c = ctot + t; c < lddy; c += 128) dy[(size_t)r * lddy + c] = (e16_t)0.f;
 }
 
 __global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int nh, int ns, int ncls,
-                                                             const bf16_t *__restrict__ y, int ldy,
+                                                             const e16_t *__restrict__ y, int ldy,
                                                              const float *__restrict__ means, float hr_scale,
-                                                             HeadGrads gs, bf16_t *__restrict__ dy, int lddy,
+                                                             HeadGrads gs, e16_t *__restrict__ dy, int lddy,
                                                              float *__restrict__ dbase) {
   __shared__ int s_pick;
   head_decode_bwd_body((int)blockIdx.x, (int)threadIdx.x, true, &s_pick, K, nh, ns, ncls, y, ldy, means, hr_scale, gs, dy, lddy,
@@ -171,10 +170,10 @@ __global__ __launch_bounds__(128) void head_decode_bwd_kernel(int R, int K, int 
 // ---- layout-quad head (reference :94-121): y[r] = [scores 2 | centre 3 | normal 3 | size 2] ----------------------
 // The normal is divided by the 2-norm of the WHOLE (B, K, 3) tensor (reference :112-113, batch-coupled).
 struct QuadOut {
-  bf16_t *scores;   // [R][2]
+  e16_t *scores;   // [R][2]
   float *center;    // [R][3]
-  bf16_t *normal;   // [R][3]
-  bf16_t *size;     // [R][2]
+  e16_t *normal;   // [R][3]
+  e16_t *size;     // [R][2]
 };
 
 // Every workgroup takes kQuadRows rows and first derives the tensor-wide sum ITSELF (R x 3 values out of L2, the
@@ -193,11 +192,11 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
 __device__ __forceinline__ float quad_grad_at(const HeadGrad &g, int b, int k, int c) {      // n2 == 1: no division
   if (!g.ptr) return 0.f;
   const long long off = (long long)b * g.sb + (long long)k * g.sk + (long long)c * g.s1;
-  return g.is_bf16 ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
+  return g.is_bf16 ? (float)reinterpret_cast<const e16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
 }
 
 // bid = this workgroup's block of kQuadRows rows; 256 threads; red = four floats of shared memory
-__device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, const bf16_t *__restrict__ y, int ldy,
+__device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, const e16_t *__restrict__ y, int ldy,
                                                  const float *__restrict__ base, const QuadOut &o,
                                                  float *__restrict__ norm_out, const PosOut &po) {
   // four rows per thread and trip: the scattered 2-byte loads of a trip are independent, so the sum over the whole
@@ -208,7 +207,7 @@ __device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, con
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = r0 + 256 * u;
-      const bf16_t *row = y + (size_t)(r < R ? r : r0) * ldy + 5;
+      const e16_t *row = y + (size_t)(r < R ? r : r0) * ldy + 5;
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[u][c] = r < R ? (float)row[c] : 0.f;
     }
@@ -218,35 +217,35 @@ __device__ __forceinline__ void quad_decode_body(int bid, float *red, int R, con
       for (int c = 0; c < 3; ++c) ss = __builtin_fmaf(v[u][c], v[u][c], ss);
   }
   // torch.norm of a bf16 tensor returns a bf16 scalar: the division below uses that rounded value
-  const float nrm = (float)(bf16_t)__builtin_sqrtf(block_sum_256(ss, red));
+  const float nrm = (float)(e16_t)__builtin_sqrtf(block_sum_256(ss, red));
   if (bid == 0 && threadIdx.x == 0) *norm_out = nrm;
   const int c = (int)threadIdx.x & 15;
   if (c >= 10) return;
   for (int rr = (int)threadIdx.x >> 4; rr < kQuadRows; rr += 16) {
     const int r = bid * kQuadRows + rr;
     if (r >= R) break;
-    const bf16_t v = y[(size_t)r * ldy + c];
+    const e16_t v = y[(size_t)r * ldy + c];
     if (c < 2) o.scores[r * 2 + c] = v;
     else if (c < 5) {
       const float ctr = (float)v + base[r * 3 + (c - 2)];
       o.center[r * 3 + (c - 2)] = ctr;
       pos_store(po, r, c - 2, ctr);
     }
-    else if (c < 8) o.normal[r * 3 + (c - 5)] = (bf16_t)((float)v / nrm);
+    else if (c < 8) o.normal[r * 3 + (c - 5)] = (e16_t)((float)v / nrm);
     else o.size[r * 2 + (c - 8)] = v;
   }
 }
 
-__global__ __launch_bounds__(256) void quad_decode_kernel(int R, const bf16_t *__restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void quad_decode_kernel(int R, const e16_t *__restrict__ y, int ldy,
                                                          const float *__restrict__ base, QuadOut o,
                                                          float *__restrict__ norm_out) {
   __shared__ float red[4];
   quad_decode_body((int)blockIdx.x, red, R, y, ldy, base, o, norm_out, PosOut{nullptr, 1, 1, 0});
 }
 
-__device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R, int K, const bf16_t *__restrict__ y, int ldy,
+__device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R, int K, const e16_t *__restrict__ y, int ldy,
                                                      const float *__restrict__ norm_in, const HeadGrads &gs,
-                                                     bf16_t *__restrict__ dy, int lddy, float *__restrict__ dbase,
+                                                     e16_t *__restrict__ dy, int lddy, float *__restrict__ dbase,
                                                      bool acc) {
   const float nrm = *norm_in;
   // out = x / n, n = ||x||:  dx = g / n - x * (sum g x) / n^3
@@ -257,7 +256,7 @@ __device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R,
     for (int u = 0; u < 4; ++u) {
       const int r = r0 + 256 * u, rc = r < R ? r : r0;
       const int b = rc / K, k = rc - b * K;
-      const bf16_t *row = y + (size_t)rc * ldy + 5;
+      const e16_t *row = y + (size_t)rc * ldy + 5;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gv[u][c] = r < R ? quad_grad_at(gs.g[2], b, k, c) : 0.f;
@@ -283,14 +282,14 @@ __device__ __forceinline__ void quad_decode_bwd_body(int bid, float *red, int R,
         if (dbase) dbase[r * 3 + (c - 2)] = acc ? dbase[r * 3 + (c - 2)] + d : d;
       } else if (c < 8) d = quad_grad_at(gs.g[2], b, k, c - 5) / nrm - (float)y[(size_t)r * ldy + c] * s;
       else if (c < 10) d = quad_grad_at(gs.g[3], b, k, c - 8);
-      dy[(size_t)r * lddy + c] = (bf16_t)d;
+      dy[(size_t)r * lddy + c] = (e16_t)d;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, const bf16_t *__restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, const e16_t *__restrict__ y, int ldy,
                                                              const float *__restrict__ norm_in, HeadGrads gs,
-                                                             bf16_t *__restrict__ dy, int lddy,
+                                                             e16_t *__restrict__ dy, int lddy,
                                                              float *__restrict__ dbase) {
   __shared__ float red[4];
   quad_decode_bwd_body((int)blockIdx.x, red, R, K, y, ldy, norm_in, gs, dy, lddy, dbase, false);
@@ -300,20 +299,20 @@ __global__ __launch_bounds__(256) void quad_decode_bwd_kernel(int R, int K, cons
 // each, 28 per step): workgroups [0, ceil(Rh / 2)) take two object rows each, the rest take kQuadRows quad rows.
 struct PairHead {
   int R, K, nh, ns, ncls, ldy, lddy;
-  const bf16_t *y;
+  const e16_t *y;
   const float *base, *means;
   float hr_scale;
-  bf16_t *dy;
+  e16_t *dy;
   float *dbase;
   int acc;          // backward: dbase += instead of =
   PosOut po;        // forward
 };
 struct PairQuad {
   int R, K, ldy, lddy;
-  const bf16_t *y;
+  const e16_t *y;
   const float *base;
   float *norm;
-  bf16_t *dy;
+  e16_t *dy;
   float *dbase;
   int acc;
   PosOut po;
@@ -357,8 +356,8 @@ extern "C" int omnipq_quad_decode(int R, const void *y, int ldy, const float *ba
   if (!y || !base || !outs || !norm || ldy < 10 || R > (1 << 24)) return OMNIPQ_EINVAL;
   for (int i = 0; i < 4; ++i)
     if (!outs[i]) return OMNIPQ_EINVAL;
-  QuadOut o{(bf16_t *)outs[0], (float *)outs[1], (bf16_t *)outs[2], (bf16_t *)outs[3]};
-  quad_decode_kernel<<<(R + kQuadRows - 1) / kQuadRows, 256, 0, (hipStream_t)stream>>>(R, (const bf16_t *)y, ldy, base, o, norm);
+  QuadOut o{(e16_t *)outs[0], (float *)outs[1], (e16_t *)outs[2], (e16_t *)outs[3]};
+  quad_decode_kernel<<<(R + kQuadRows - 1) / kQuadRows, 256, 0, (hipStream_t)stream>>>(R, (const e16_t *)y, ldy, base, o, norm);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -377,7 +376,7 @@ extern "C" int omnipq_quad_decode_bwd(int R, int K, const void *y, int ldy, cons
   for (int i = 0; i < 4; ++i)
     gs.g[i] = HeadGrad{gptr[i], gstrides[4 * i], gstrides[4 * i + 1], gstrides[4 * i + 2], gstrides[4 * i + 3], 1,
                        g_is_bf16[i]};
-  quad_decode_bwd_kernel<<<(R + kQuadRows - 1) / kQuadRows, 256, 0, (hipStream_t)stream>>>(R, K, (const bf16_t *)y, ldy, norm, gs, (bf16_t *)dy, lddy,
+  quad_decode_bwd_kernel<<<(R + kQuadRows - 1) / kQuadRows, 256, 0, (hipStream_t)stream>>>(R, K, (const e16_t *)y, ldy, norm, gs, (e16_t *)dy, lddy,
                                                               dbase);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -392,9 +391,9 @@ extern "C" int omnipq_head_decode(int R, int nh, int ns, int ncls, const void *y
   if (!y || !base || !means || !outs || ldy < 5 + 2 * nh + 4 * ns + ncls) return OMNIPQ_EINVAL;
   for (int i = 0; i < 10; ++i)
     if (!outs[i]) return OMNIPQ_EINVAL;
-  HeadOut o{(bf16_t *)outs[0], (float *)outs[1], (bf16_t *)outs[2], (bf16_t *)outs[3], (bf16_t *)outs[4],
-            (bf16_t *)outs[5], (bf16_t *)outs[6], (float *)outs[7], (float *)outs[8], (bf16_t *)outs[9]};
-  head_decode_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, nh, ns, ncls, (const bf16_t *)y, ldy, base, means, hr_scale,
+  HeadOut o{(e16_t *)outs[0], (float *)outs[1], (e16_t *)outs[2], (e16_t *)outs[3], (e16_t *)outs[4],
+            (e16_t *)outs[5], (e16_t *)outs[6], (float *)outs[7], (float *)outs[8], (e16_t *)outs[9]};
+  head_decode_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, nh, ns, ncls, (const e16_t *)y, ldy, base, means, hr_scale,
                                                          o);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -419,8 +418,8 @@ extern "C" int omnipq_head_decode_bwd(int R, int K, int nh, int ns, int ncls, co
     gs.g[i] = HeadGrad{gptr[i], gstrides[4 * i], gstrides[4 * i + 1], gstrides[4 * i + 2], gstrides[4 * i + 3], gn2[i],
                        g_is_bf16[i]};
   }
-  head_decode_bwd_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, K, nh, ns, ncls, (const bf16_t *)y, ldy, means, hr_scale,
-                                                             gs, (bf16_t *)dy, lddy, dbase);
+  head_decode_bwd_kernel<<<R, 128, 0, (hipStream_t)stream>>>(R, K, nh, ns, ncls, (const e16_t *)y, ldy, means, hr_scale,
+                                                             gs, (e16_t *)dy, lddy, dbase);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -441,12 +440,12 @@ extern "C" int omnipq_decode_pair(int Rh, int Kh, int nh, int ns, int ncls, cons
     if (!outs_h[i]) return OMNIPQ_EINVAL;
   for (int i = 0; i < 4; ++i)
     if (!outs_q[i]) return OMNIPQ_EINVAL;
-  HeadOut ho{(bf16_t *)outs_h[0], (float *)outs_h[1], (bf16_t *)outs_h[2], (bf16_t *)outs_h[3], (bf16_t *)outs_h[4],
-             (bf16_t *)outs_h[5], (bf16_t *)outs_h[6], (float *)outs_h[7], (float *)outs_h[8], (bf16_t *)outs_h[9]};
-  QuadOut qo{(bf16_t *)outs_q[0], (float *)outs_q[1], (bf16_t *)outs_q[2], (bf16_t *)outs_q[3]};
-  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, 0, (const bf16_t *)yh, baseh, means, hr_scale, nullptr, nullptr, 0,
+  HeadOut ho{(e16_t *)outs_h[0], (float *)outs_h[1], (e16_t *)outs_h[2], (e16_t *)outs_h[3], (e16_t *)outs_h[4],
+             (e16_t *)outs_h[5], (e16_t *)outs_h[6], (float *)outs_h[7], (float *)outs_h[8], (e16_t *)outs_h[9]};
+  QuadOut qo{(e16_t *)outs_q[0], (float *)outs_q[1], (e16_t *)outs_q[2], (e16_t *)outs_q[3]};
+  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, 0, (const e16_t *)yh, baseh, means, hr_scale, nullptr, nullptr, 0,
              PosOut{pos, Kh, Kh + Kq, 0}};
-  PairQuad q{Rq, Kq, ldyq, 0, (const bf16_t *)yq, baseq, norm, nullptr, nullptr, 0, PosOut{pos, Kq, Kh + Kq, Kh}};
+  PairQuad q{Rq, Kq, ldyq, 0, (const e16_t *)yq, baseq, norm, nullptr, nullptr, 0, PosOut{pos, Kq, Kh + Kq, Kh}};
   const int blocks = (Rh + 1) / 2 + (Rq + kQuadRows - 1) / kQuadRows;
   decode_pair_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(h, ho, q, qo);
   OMNIPQ_LAUNCH_CHECK();
@@ -476,9 +475,9 @@ extern "C" int omnipq_decode_pair_bwd(int Rh, int Kh, int nh, int ns, int ncls, 
   for (int i = 0; i < 4; ++i)
     qg.g[i] = HeadGrad{gptr_q[i], gstrides_q[4 * i], gstrides_q[4 * i + 1], gstrides_q[4 * i + 2], gstrides_q[4 * i + 3], 1,
                        gbf_q[i]};
-  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, lddyh, (const bf16_t *)yh, nullptr, means, hr_scale, (bf16_t *)dyh, dbaseh,
+  PairHead h{Rh, Kh, nh, ns, ncls, ldyh, lddyh, (const e16_t *)yh, nullptr, means, hr_scale, (e16_t *)dyh, dbaseh,
              accumulate & 1, PosOut{nullptr, 1, 1, 0}};
-  PairQuad q{Rq, Kq, ldyq, lddyq, (const bf16_t *)yq, nullptr, const_cast<float *>(norm), (bf16_t *)dyq, dbaseq,
+  PairQuad q{Rq, Kq, ldyq, lddyq, (const e16_t *)yq, nullptr, const_cast<float *>(norm), (e16_t *)dyq, dbaseq,
              (accumulate >> 1) & 1, PosOut{nullptr, 1, 1, 0}};
   const int blocks = (Rh + 1) / 2 + (Rq + kQuadRows - 1) / kQuadRows;
   decode_pair_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(h, hg, q, qg);
@@ -499,21 +498,21 @@ constexpr int kVotePts = 32, kVoteMaxC = 320;
 
 template <bool BF>
 __device__ __forceinline__ float vote_ld(const void *p, size_t i) {
-  return BF ? (float)reinterpret_cast<const bf16_t *>(p)[i] : reinterpret_cast<const float *>(p)[i];
+  return BF ? (float)reinterpret_cast<const e16_t *>(p)[i] : reinterpret_cast<const float *>(p)[i];
 }
 template <bool BF>
 __device__ __forceinline__ void vote_st(void *p, size_t i, float v) {
-  if (BF) reinterpret_cast<bf16_t *>(p)[i] = (bf16_t)v;
+  if (BF) reinterpret_cast<e16_t *>(p)[i] = (e16_t)v;
   else reinterpret_cast<float *>(p)[i] = v;
 }
 
 // BF: seed features, the normalised output and (backward) its gradients are bf16 (the backbone's bf16 rows), else f32
 template <bool BF>
-__global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf16_t *__restrict__ net, int ldn,
+__global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const e16_t *__restrict__ net, int ldn,
                                                          const float *__restrict__ seed_xyz,
                                                          const void *__restrict__ seed_feat, long long sfb,
                                                          long long sfc, long long sfk, float *__restrict__ vote_xyz,
-                                                         void *__restrict__ out, bf16_t *__restrict__ twin,
+                                                         void *__restrict__ out, e16_t *__restrict__ twin,
                                                          float *__restrict__ norm_out) {
   __shared__ float v[kVoteMaxC][kVotePts + 1];
   __shared__ float part[8][kVotePts];
@@ -540,7 +539,7 @@ __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = piece * 8 + e;
-        const float x = __builtin_bit_cast(float, (e & 1) ? (ww[e >> 1] & 0xffff0000u) : (ww[e >> 1] << 16));
+        const float x = (e & 1) ? e16_hi(ww[e >> 1]) : e16_lo(ww[e >> 1]);
         if (c < 3)
           vote_xyz[((size_t)b * K + k0 + p) * 3 + c] = seed_xyz[((size_t)b * K + k0 + p) * 3 + c] + x;
         else if (c < C + 3)
@@ -599,7 +598,7 @@ __global__ __launch_bounds__(256) void vote_decode_kernel(int K, int C, const bf
   __syncthreads();
   for (int i = tid; i < npts * C; i += 256) {
     const int q = i / C, c = i - q * C;
-    twin[((size_t)b * K + k0 + q) * C + c] = (bf16_t)v[c][q];
+    twin[((size_t)b * K + k0 + q) * C + c] = (e16_t)v[c][q];
   }
 }
 
@@ -608,7 +607,7 @@ template <bool BF>
 __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, const void *__restrict__ out,
                                                              const float *__restrict__ norm,
                                                              const float *__restrict__ g_xyz,
-                                                             const void *__restrict__ g_feat, bf16_t *__restrict__ dnet,
+                                                             const void *__restrict__ g_feat, e16_t *__restrict__ dnet,
                                                              int ldd, void *__restrict__ dseed) {
   __shared__ float v[kVoteMaxC][kVotePts + 1];
   __shared__ float part[8][kVotePts];
@@ -661,7 +660,7 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
           t[e] = v[c - 3][q];
       }
       uint4 o;
-      o.x = pack_bf16x2(t[0], t[1]), o.y = pack_bf16x2(t[2], t[3]), o.z = pack_bf16x2(t[4], t[5]), o.w = pack_bf16x2(t[6], t[7]);
+      o.x = pack_e16x2(t[0], t[1]), o.y = pack_e16x2(t[2], t[3]), o.z = pack_e16x2(t[4], t[5]), o.w = pack_e16x2(t[6], t[7]);
       *reinterpret_cast<uint4 *>(dnet + ((size_t)b * K + k0 + q) * ldd + piece * 8) = o;
     }
     return;
@@ -673,7 +672,7 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
       t = g_xyz ? g_xyz[((size_t)b * K + k0 + q) * 3 + c] : 0.f;
     else if (c < 3 + C)
       t = v[c - 3][q];
-    dnet[((size_t)b * K + k0 + q) * ldd + c] = (bf16_t)t;
+    dnet[((size_t)b * K + k0 + q) * ldd + c] = (e16_t)t;
   }
 }
 }  // namespace omnipq
@@ -687,11 +686,11 @@ extern "C" int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn,
   if (!net || !seed_xyz || !seed_feat || !vote_xyz || !vote_feat || !twin16 || !norm || b > 65535) return OMNIPQ_EINVAL;
   const dim3 grid((k + kVotePts - 1) / kVotePts, b);
   if (feat_is_bf16)
-    vote_decode_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, (const bf16_t *)net, ldn, seed_xyz, seed_feat, sfb,
-                                                                    sfc, sfk, vote_xyz, vote_feat, (bf16_t *)twin16, norm);
+    vote_decode_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, (const e16_t *)net, ldn, seed_xyz, seed_feat, sfb,
+                                                                    sfc, sfk, vote_xyz, vote_feat, (e16_t *)twin16, norm);
   else
-    vote_decode_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, (const bf16_t *)net, ldn, seed_xyz, seed_feat, sfb,
-                                                                     sfc, sfk, vote_xyz, vote_feat, (bf16_t *)twin16, norm);
+    vote_decode_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, (const e16_t *)net, ldn, seed_xyz, seed_feat, sfb,
+                                                                     sfc, sfk, vote_xyz, vote_feat, (e16_t *)twin16, norm);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -705,11 +704,11 @@ extern "C" int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat
   if (!vote_feat || !norm || !dnet || b > 65535) return OMNIPQ_EINVAL;
   const dim3 grid((k + kVotePts - 1) / kVotePts, b);
   if (feat_is_bf16)
-    vote_decode_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, vote_feat, norm, g_xyz, g_feat, (bf16_t *)dnet,
+    vote_decode_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, vote_feat, norm, g_xyz, g_feat, (e16_t *)dnet,
                                                                         ldd, dseed_feat);
   else
     vote_decode_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, vote_feat, norm, g_xyz, g_feat,
-                                                                         (bf16_t *)dnet, ldd, dseed_feat);
+                                                                         (e16_t *)dnet, ldd, dseed_feat);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

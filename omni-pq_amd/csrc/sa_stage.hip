@@ -21,28 +21,26 @@
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void unpack8(const uint4 &v, float (&f)[8]) {
   const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
-    f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xFFFF0000u);
+    f[2 * i] = e16_lo(w[i]);
+    f[2 * i + 1] = e16_hi(w[i]);
   }
 }
 
 __device__ __forceinline__ unsigned short f2bf(float x) {
-  return __builtin_bit_cast(unsigned short, (bf16_t)x);
+  return __builtin_bit_cast(unsigned short, (e16_t)x);
 }
 
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   uint4 v;
-  v.x = pack_bf16x2(f[0], f[1]);
-  v.y = pack_bf16x2(f[2], f[3]);
-  v.z = pack_bf16x2(f[4], f[5]);
-  v.w = pack_bf16x2(f[6], f[7]);
+  v.x = pack_e16x2(f[0], f[1]);
+  v.y = pack_e16x2(f[2], f[3]);
+  v.z = pack_e16x2(f[4], f[5]);
+  v.w = pack_e16x2(f[6], f[7]);
   return v;
 }
 
@@ -61,8 +59,8 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(long long chunks, int n,
                                                        const float *__restrict__ xyz,
                                                        const float *__restrict__ new_xyz,
                                                        const int *__restrict__ idx,
-                                                       const bf16_t *__restrict__ feat,
-                                                       bf16_t *__restrict__ X) {
+                                                       const e16_t *__restrict__ feat,
+                                                       e16_t *__restrict__ X) {
   const int cpr = kpad >> 3;   // 16-byte pieces per row
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
     const long long p = q / cpr;
@@ -118,7 +116,7 @@ __device__ __forceinline__ void row_partition(int C, int &cgs, int &rpb, int &cg
 }
 
 // sums[0][c] = sum_p Y[p][c],  sums[1][c] = sum_p Y[p][c]^2
-__global__ __launch_bounds__(256) void colstats_kernel(long long P, int C, const bf16_t *__restrict__ Y,
+__global__ __launch_bounds__(256) void colstats_kernel(long long P, int C, const e16_t *__restrict__ Y,
                                                       double *__restrict__ sums) {
   int cgs, rpb, cg, rsub;
   row_partition(C, cgs, rpb, cg, rsub);
@@ -170,9 +168,9 @@ __global__ void bn_finalize_kernel(int C, double cnt, const double *__restrict__
 }
 
 // X = relu(a * Y + b)
-__global__ __launch_bounds__(256) void bnrelu_kernel(long long chunks, int C, const bf16_t *__restrict__ Y,
+__global__ __launch_bounds__(256) void bnrelu_kernel(long long chunks, int C, const e16_t *__restrict__ Y,
                                                     const float *__restrict__ a, const float *__restrict__ b,
-                                                    bf16_t *__restrict__ X) {
+                                                    e16_t *__restrict__ X) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
     const int c0 = (int)(q % cpr) * 8;
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(256) void bn_finalize_relu_kernel(long long chunks,
                                                               float *__restrict__ running_mean,
                                                               float *__restrict__ running_var,
                                                               const float *__restrict__ conv_bias,
-                                                              const bf16_t *__restrict__ Y, bf16_t *__restrict__ X,
+                                                              const e16_t *__restrict__ Y, e16_t *__restrict__ X,
                                                               float *__restrict__ a, float *__restrict__ b,
                                                               float *__restrict__ mean, float *__restrict__ invstd) {
   extern __shared__ float ab[];                              // [a | b]
@@ -238,9 +236,9 @@ __global__ __launch_bounds__(256) void bn_finalize_relu_kernel(long long chunks,
 // out[bm][c] = max_s relu(a Y[(bm,s)][c] + b); arg = first s reaching it.  One lane per (bm, 8 ch).
 // Outputs are position-major ([b*m][C]); g_out of the backward kernels likewise.
 __global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s, int C,
-                                                  const bf16_t *__restrict__ Y, const float *__restrict__ a,
+                                                  const e16_t *__restrict__ Y, const float *__restrict__ a,
                                                   const float *__restrict__ b, float *__restrict__ out_f32,
-                                                  bf16_t *__restrict__ out_pm, unsigned char *__restrict__ arg) {
+                                                  e16_t *__restrict__ out_pm, unsigned char *__restrict__ arg) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
     const long long bm = q / cpr;
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s
     load8f(b + c0, bv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { best[e] = -1.f; bi[e] = 0; }
-    const bf16_t *row = Y + ((size_t)bm * s) * C + c0;
+    const e16_t *row = Y + ((size_t)bm * s) * C + c0;
     for (int t = 0; t < s; ++t) {
       float y[8];
       unpack8(*reinterpret_cast<const uint4 *>(row + (size_t)t * C), y);
@@ -276,13 +274,13 @@ __global__ __launch_bounds__(256) void pool_kernel(long long items, int m, int s
 // value is relu(a y* + b) with y* = the ball's maximum of y where a >= 0, its minimum where a < 0; `arg` = the first
 // row attaining it (row 0 when the result is clamped to 0, as pool_kernel's strict '>' leaves it), ysel = y* (what
 // the backward statistics need of Y).  8 channels per lane.
-__global__ __launch_bounds__(256) void pool_select_kernel(long long items, int C, const bf16_t *__restrict__ ymax,
-                                                         const bf16_t *__restrict__ ymin,
+__global__ __launch_bounds__(256) void pool_select_kernel(long long items, int C, const e16_t *__restrict__ ymax,
+                                                         const e16_t *__restrict__ ymin,
                                                          const unsigned char *__restrict__ amax,
                                                          const unsigned char *__restrict__ amin,
                                                          const float *__restrict__ a, const float *__restrict__ b,
-                                                         float *__restrict__ out_f32, bf16_t *__restrict__ out_pm,
-                                                         unsigned char *__restrict__ arg, bf16_t *__restrict__ ysel) {
+                                                         float *__restrict__ out_f32, e16_t *__restrict__ out_pm,
+                                                         unsigned char *__restrict__ arg, e16_t *__restrict__ ysel) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
     const long long bm = q / cpr;
@@ -318,12 +316,12 @@ __global__ __launch_bounds__(256) void pool_select_kernel(long long items, int C
 // with mean / invstd and updates the running statistics.  One launch less per SA stage and forward.
 constexpr int kFinMaxC = 1024;
 __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
-    long long items, int C, const bf16_t *__restrict__ ymax, const bf16_t *__restrict__ ymin,
+    long long items, int C, const e16_t *__restrict__ ymax, const e16_t *__restrict__ ymin,
     const unsigned char *__restrict__ amax, const unsigned char *__restrict__ amin, const double *__restrict__ sums, double cnt,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ a_out, float *__restrict__ b_out,
-    float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ out_f32, bf16_t *__restrict__ out_pm,
-    unsigned char *__restrict__ arg, bf16_t *__restrict__ ysel) {
+    float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ out_f32, e16_t *__restrict__ out_pm,
+    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel) {
   __shared__ __attribute__((aligned(16))) float s_a[kFinMaxC], s_b[kFinMaxC];
   for (int c = (int)threadIdx.x; c < C; c += 256) {
     const double mu = sums[c] / cnt;
@@ -377,11 +375,11 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
 }
 
 // pool_bwd_stats_kernel with y at the arg-max position taken from `ysel` instead of a gather out of Y
-__global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, int C, const bf16_t *__restrict__ ysel,
+__global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, int C, const e16_t *__restrict__ ysel,
                                                                 const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd,
                                                                 const float *__restrict__ g_out,
-                                                                const bf16_t *__restrict__ out_pm,
+                                                                const e16_t *__restrict__ out_pm,
                                                                 double *__restrict__ sums) {
   int cgs, rpb, cg, rsub;
   row_partition(C, cgs, rpb, cg, rsub);
@@ -409,11 +407,11 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, i
 // dz lives only at the argmax position of every (bm, c):  dz = g_out[b][c][m] if out > 0.
 // sums[0][c] = sum dz, sums[1][c] = sum dz * yhat  with yhat = (y - mean) * invstd at that position.
 __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long BM, int m, int s, int C,
-                                                            const bf16_t *__restrict__ Y,
+                                                            const e16_t *__restrict__ Y,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ g_out,
-                                                            const bf16_t *__restrict__ out_pm,
+                                                            const e16_t *__restrict__ out_pm,
                                                             const unsigned char *__restrict__ arg,
                                                             double *__restrict__ sums) {
   int cgs, rpb, cg, rsub;
@@ -449,10 +447,10 @@ struct ApplyProblem {
   long long chunks;
   int C;
   double invP;
-  const bf16_t *dX, *Y;
+  const e16_t *dX, *Y;
   const float *a, *b, *mean, *invstd;
   const double *sums;
-  bf16_t *dY;
+  e16_t *dY;
   float *dbeta_dgamma;
 };
 // bid / nblocks: this workgroup's index and the number of workgroups of ITS problem (a pair launch runs two in one grid)
@@ -466,9 +464,9 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
   }
   __syncthreads();
   const int cpr = C >> 3;
-  const bf16_t *__restrict__ Y = p.Y;
-  const bf16_t *__restrict__ dX = p.dX;
-  bf16_t *__restrict__ dY = p.dY;
+  const e16_t *__restrict__ Y = p.Y;
+  const e16_t *__restrict__ dX = p.dX;
+  e16_t *__restrict__ dY = p.dY;
   for (long long q = (long long)bid * 256 + threadIdx.x; q < p.chunks; q += (long long)nblocks * 256) {
     const int c0 = (int)(q % cpr) * 8;
     float y[8], d[8], av[8], bv[8], mu[8], is[8];
@@ -506,7 +504,7 @@ __global__ void bwd_means_kernel(int n2, double invP, const double *__restrict__
 // column sums of a bf16 [P][C] matrix for any C % 8 == 0 (bias gradients of wide layers):
 // block = 32 column pieces (256 columns) x 8 row lanes; grid (ceil(C/256), row slabs); sums += (f64 atomics)
 template <typename ACC>
-__global__ __launch_bounds__(256) void colsum_kernel(long long P, int C, const bf16_t *__restrict__ Y,
+__global__ __launch_bounds__(256) void colsum_kernel(long long P, int C, const e16_t *__restrict__ Y,
                                                     ACC *__restrict__ sums) {
   __shared__ float red[8][256];
   const int tid = (int)threadIdx.x, piece = (int)blockIdx.x * 32 + (tid & 31), rsub = tid >> 5;
@@ -535,8 +533,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(long long P, int C, const b
 //   Wp bf16 [cp][k]   zero-padded, columns rotated left by `rot` (SA layer 0: [xyz(3), feat] -> [feat, xyz])
 //   Wt bf16 [k][cp]   its transpose (operand of the data-gradient GEMM)
 __global__ __launch_bounds__(256) void prep_weight_kernel(int cout, int cin, int ldw, int cp, int k, int rot,
-                                                         const float *__restrict__ W, bf16_t *__restrict__ Wp,
-                                                         bf16_t *__restrict__ Wt) {
+                                                         const float *__restrict__ W, e16_t *__restrict__ Wp,
+                                                         e16_t *__restrict__ Wt) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= cp * k) return;
   const int r = i / k, c = i - r * k;
@@ -545,7 +543,7 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(int cout, int cin, int
     const int src = c < cin - rot ? c + rot : c - (cin - rot);
     v = W[(size_t)r * ldw + src];
   }
-  const bf16_t h = (bf16_t)v;
+  const e16_t h = (e16_t)v;
   Wp[i] = h;
   if (Wt) Wt[(size_t)c * cp + r] = h;
 }
@@ -563,8 +561,8 @@ struct PrepSeg {
 // column): coalesced reads along the source rows, coalesced writes of both the matrix and -- through an LDS
 // transpose -- its transpose.
 __global__ __launch_bounds__(256) void prep_all_kernel(const PrepSeg *__restrict__ segs, const int *__restrict__ tiles,
-                                                      bf16_t *__restrict__ Wp_arena, bf16_t *__restrict__ Wt_arena) {
-  __shared__ bf16_t t[64][66];
+                                                      e16_t *__restrict__ Wp_arena, e16_t *__restrict__ Wt_arena) {
+  __shared__ e16_t t[64][66];
   const int *tl = tiles + 4 * (size_t)blockIdx.x;
   const PrepSeg g = segs[tl[0]];
   const int r0 = tl[1], c0 = tl[2];
@@ -576,7 +574,7 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const PrepSeg *__restrict
       const int src = c < g.cin - g.rot ? c + g.rot : c - (g.cin - g.rot);
       v = g.W[(size_t)r * g.ldw + src];
     }
-    const bf16_t h = (bf16_t)v;
+    const e16_t h = (e16_t)v;
     t[e >> 6][e & 63] = h;
     if (r < g.cp && c < g.k) Wp_arena[g.wp_off + (size_t)r * g.k + c] = h;
   }
@@ -613,16 +611,16 @@ __global__ void sums_to_f32_kernel(int C, const double *__restrict__ sums, float
 // per-position form re-read those per-ball vectors s times from L2 and ran at 2.5 TB/s; this one is bound by
 // the Y read + dY write alone.
 __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, int m, int s, int C,
-                                                            const bf16_t *__restrict__ Y,
+                                                            const e16_t *__restrict__ Y,
                                                             const float *__restrict__ a,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const double *__restrict__ sums, double inv_total,
                                                             float *__restrict__ gb_out,
                                                             const float *__restrict__ g_out,
-                                                            const bf16_t *__restrict__ out_pm,
+                                                            const e16_t *__restrict__ out_pm,
                                                             const unsigned char *__restrict__ arg,
-                                                            bf16_t *__restrict__ dY) {
+                                                            e16_t *__restrict__ dY) {
   // the means S / P, T / P straight from the f64 totals (16 loads per ball and channel piece, amortised over the ball's
   // s rows: the separate f64 -> f32 means launch is gone); the items of ball 0 also publish dbeta | dgamma when asked to
   const int cpr = C >> 3;
@@ -654,8 +652,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
       Tv[e] *= av[e] * is[e];                                                // a * invstd * T/P
       gg[e] *= av[e];
     }
-    const bf16_t *src = Y + ((size_t)bm * s) * C + c0;
-    bf16_t *dst = dY + ((size_t)bm * s) * C + c0;
+    const e16_t *src = Y + ((size_t)bm * s) * C + c0;
+    e16_t *dst = dY + ((size_t)bm * s) * C + c0;
     for (int t = 0; t < s; ++t) {
       float y[8];
       unpack8(*reinterpret_cast<const uint4 *>(src + (size_t)t * C), y);
@@ -671,8 +669,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
 }
 
 // dense layers:  dz = dX * [a y + b > 0]
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(long long P, int C, const bf16_t *__restrict__ dX,
-                                                          const bf16_t *__restrict__ Y,
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(long long P, int C, const e16_t *__restrict__ dX,
+                                                          const e16_t *__restrict__ Y,
                                                           const float *__restrict__ a,
                                                           const float *__restrict__ b,
                                                           const float *__restrict__ mean,
@@ -703,14 +701,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(long long P, int C, c
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long long chunks, int C,
-                                                          const bf16_t *__restrict__ dX,
-                                                          const bf16_t *__restrict__ Y,
+                                                          const e16_t *__restrict__ dX,
+                                                          const e16_t *__restrict__ Y,
                                                           const float *__restrict__ a,
                                                           const float *__restrict__ b,
                                                           const float *__restrict__ mean,
                                                           const float *__restrict__ invstd,
                                                           const float *__restrict__ st,
-                                                          bf16_t *__restrict__ dY) {
+                                                          e16_t *__restrict__ dY) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
     const int c0 = (int)(q % cpr) * 8;
@@ -738,7 +736,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long long chunks, int
 // d = dX0[p][cin..cin+3) * inv_r:  dxyz[b][idx[p]] += d,  dcentre[b][m] -= d.
 __global__ __launch_bounds__(256) void sa_scatter_kernel(long long chunks, int n, int m, int s, int cin,
                                                         int kpad, float inv_r, const int *__restrict__ idx,
-                                                        const bf16_t *__restrict__ dX,
+                                                        const e16_t *__restrict__ dX,
                                                         float *__restrict__ dfeat, float *__restrict__ dxyz,
                                                         float *__restrict__ dcentre) {
   const int cpr = (cin >> 3) + 1;      // feature pieces + the coordinate piece
@@ -960,7 +958,7 @@ __global__ __launch_bounds__(1024) void csr_build_split_kernel(int n, int ms, co
 __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, int n, int ms, int cin, int kpad,
                                                             float inv_r, const int *__restrict__ offsets,
                                                             const int *__restrict__ order,
-                                                            const bf16_t *__restrict__ dX,
+                                                            const e16_t *__restrict__ dX,
                                                             float *__restrict__ dfeat, float *__restrict__ dxyz) {
   const int cpr = (cin >> 3) + 1;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
@@ -1010,7 +1008,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
 
 // dcentre[b][j] = -inv_r * sum_s dX[(b,j,s)][cin..cin+3)
 __global__ __launch_bounds__(256) void sa_centre_grad_kernel(long long BM, int s, int cin, int kpad, float inv_r,
-                                                            const bf16_t *__restrict__ dX,
+                                                            const e16_t *__restrict__ dX,
                                                             float *__restrict__ dcentre) {
   const long long bm = (long long)blockIdx.x * 256 + threadIdx.x;
   if (bm >= BM) return;
@@ -1073,7 +1071,7 @@ extern "C" int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, f
   if (!xyz || !new_xyz || !idx || !X || (cin > 0 && !feat_pm)) return OMNIPQ_EINVAL;
   const long long chunks = P * (kpad / 8);
   sa_gather_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const bf16_t *)feat_pm, (bf16_t *)X);
+      chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, (e16_t *)X);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1096,7 +1094,7 @@ static int colstats_impl(long long P, int C, const void *Y, double *sums, int ze
   if (P == 0) return OMNIPQ_OK;
   const int rpb = rows_per_block(C);
   (void)rpb;
-  colstats_kernel<<<stats_grid(P, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+  colstats_kernel<<<stats_grid(P, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(P, C, (const e16_t *)Y,
                                                                                            sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1120,7 +1118,7 @@ extern "C" int omnipq_bnrelu(long long P, int C, const void *Y, const float *a, 
   if (P == 0) return OMNIPQ_OK;
   if (!Y || !a || !b || !X) return OMNIPQ_EINVAL;
   const long long chunks = P * (C / 8);
-  bnrelu_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, C, (const bf16_t *)Y, a, b, (bf16_t *)X);
+  bnrelu_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, C, (const e16_t *)Y, a, b, (e16_t *)X);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1131,8 +1129,8 @@ extern "C" int omnipq_sa_pool(int b, int m, int s, int C, const void *Y, const f
   const long long items = (long long)b * m * (C / 8);
   if (items == 0) return OMNIPQ_OK;
   if (!Y || !a || !bshift || !out_f32 || !out_pm || !arg) return OMNIPQ_EINVAL;
-  pool_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, m, s, C, (const bf16_t *)Y, a, bshift, out_f32,
-                                                              (bf16_t *)out_pm, arg);
+  pool_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, m, s, C, (const e16_t *)Y, a, bshift, out_f32,
+                                                              (e16_t *)out_pm, arg);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1144,9 +1142,9 @@ extern "C" int omnipq_sa_pool_select(long long BM, int C, const void *ymax, cons
   const long long items = BM * (C / 8);
   if (items == 0) return OMNIPQ_OK;
   if (!ymax || !ymin || !amax || !amin || !a || !bshift || !out_f32 || !out_pm || !arg || !ysel) return OMNIPQ_EINVAL;
-  pool_select_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, C, (const bf16_t *)ymax, (const bf16_t *)ymin,
-                                                                     amax, amin, a, bshift, out_f32, (bf16_t *)out_pm, arg,
-                                                                     (bf16_t *)ysel);
+  pool_select_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, C, (const e16_t *)ymax, (const e16_t *)ymin,
+                                                                     amax, amin, a, bshift, out_f32, (e16_t *)out_pm, arg,
+                                                                     (e16_t *)ysel);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1165,8 +1163,8 @@ extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *y
   if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
   const int grid = items == 0 ? 1 : grid_for(items);           // an empty batch still finalises the layer
   pool_select_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
-      items, C, (const bf16_t *)ymax, (const bf16_t *)ymin, amax, amin, sums, count, gamma, beta, eps, momentum, running_mean,
-      running_var, a_out, b_out, mean_out, invstd_out, out_f32, (bf16_t *)out_pm, arg, (bf16_t *)ysel);
+      items, C, (const e16_t *)ymax, (const e16_t *)ymin, amax, amin, sums, count, gamma, beta, eps, momentum, running_mean,
+      running_var, a_out, b_out, mean_out, invstd_out, out_f32, (e16_t *)out_pm, arg, (e16_t *)ysel);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1182,7 +1180,7 @@ extern "C" int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *yse
   int blocks = stats_grid(BM, C);
   if (blocks > 128) blocks = 128;
   pool_bwd_stats_sel_kernel<<<blocks, 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
-      BM, C, (const bf16_t *)ysel, mean, invstd, g_out, (const bf16_t *)out_pm, sums);
+      BM, C, (const e16_t *)ysel, mean, invstd, g_out, (const e16_t *)out_pm, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1198,7 +1196,7 @@ extern "C" int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *
   const int rpb = rows_per_block(C);
   (void)rpb;
   pool_bwd_stats_kernel<<<stats_grid(BM, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
-      BM, m, s, C, (const bf16_t *)Y, mean, invstd, g_out, (const bf16_t *)out_pm, arg, sums);
+      BM, m, s, C, (const e16_t *)Y, mean, invstd, g_out, (const e16_t *)out_pm, arg, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1233,8 +1231,8 @@ static int pool_bwd_apply_impl(int b, int m, int s, int C, double total_position
   if (!Y || !a || !mean || !invstd || !sums || !g_out || !out_pm || !arg || !dY) return OMNIPQ_EINVAL;
   const long long items = chunks / s;                   // (ball, 8-channel piece)
   pool_bwd_apply_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
-      items, m, s, C, (const bf16_t *)Y, a, mean, invstd, sums, 1.0 / total_positions, gb_out, g_out,
-      (const bf16_t *)out_pm, arg, (bf16_t *)dY);
+      items, m, s, C, (const e16_t *)Y, a, mean, invstd, sums, 1.0 / total_positions, gb_out, g_out,
+      (const e16_t *)out_pm, arg, (e16_t *)dY);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1262,7 +1260,7 @@ static int bn_bwd_stats_impl(long long P, int C, const void *dX, const void *Y, 
   const int rpb = rows_per_block(C);
   (void)rpb;
   bn_bwd_stats_kernel<<<stats_grid(P, C), 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
-      P, C, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, sums);
+      P, C, (const e16_t *)dX, (const e16_t *)Y, a, b, mean, invstd, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1277,7 +1275,7 @@ extern "C" int omnipq_bn_bwd_apply(long long P, int C, double total_positions, c
   float *st = means_scratch(sums, C);
   bwd_means_kernel<<<(2 * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(2 * C, 1.0 / total_positions, sums, st);
   bn_bwd_apply_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, C, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean, invstd, st, (bf16_t *)dY);
+      chunks, C, (const e16_t *)dX, (const e16_t *)Y, a, b, mean, invstd, st, (e16_t *)dY);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1292,7 +1290,7 @@ extern "C" int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, 
   if (!idx || !dX || (dxyz && !dnew_xyz)) return OMNIPQ_EINVAL;
   const long long chunks = P * (cin / 8 + 1);
   sa_scatter_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, n, m, s, cin, kpad, inv_radius, idx, (const bf16_t *)dX, dfeat_pm, dxyz, dnew_xyz);
+      chunks, n, m, s, cin, kpad, inv_radius, idx, (const e16_t *)dX, dfeat_pm, dxyz, dnew_xyz);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1340,13 +1338,13 @@ extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kp
   if (!offsets || !order || !dX || (dxyz && !dnew_xyz)) return OMNIPQ_EINVAL;
   const long long items = (long long)b * n * (cin / 8 + 1);
   sa_scatter_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
-      items, n, m * s, cin, kpad, inv_radius, offsets, order, (const bf16_t *)dX, dfeat_pm, dxyz);
+      items, n, m * s, cin, kpad, inv_radius, offsets, order, (const e16_t *)dX, dfeat_pm, dxyz);
   OMNIPQ_LAUNCH_CHECK();
   if (dnew_xyz) {
     const long long BM = (long long)b * m;
     if (BM > 0) {
       sa_centre_grad_kernel<<<(int)((BM + 255) / 256), 256, 0, (hipStream_t)stream>>>(BM, s, cin, kpad, inv_radius,
-                                                                                  (const bf16_t *)dX, dnew_xyz);
+                                                                                  (const e16_t *)dX, dnew_xyz);
       OMNIPQ_LAUNCH_CHECK();
     }
   }
@@ -1357,8 +1355,8 @@ extern "C" int omnipq_prep_weight(int cout, int cin, int ldw, int cp, int k, int
                                   void *Wt, void *stream) {
   if (cout <= 0 || cin <= 0 || cp < cout || k < cin || rot < 0 || rot > cin || !W || !Wp) return OMNIPQ_EINVAL;
   const int n = cp * k;
-  prep_weight_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, ldw, cp, k, rot, W, (bf16_t *)Wp,
-                                                                   (bf16_t *)Wt);
+  prep_weight_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, ldw, cp, k, rot, W, (e16_t *)Wp,
+                                                                   (e16_t *)Wt);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1386,7 +1384,7 @@ extern "C" int omnipq_colsum(long long P, int C, const void *Y, double *sums, vo
   long long slabs = P / 128;
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
-  colsum_kernel<double><<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+  colsum_kernel<double><<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const e16_t *)Y,
                                                                                           sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1400,7 +1398,7 @@ extern "C" int omnipq_colsum_f32(long long P, int C, const void *Y, float *sums,
   long long slabs = P / 128;
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
-  colsum_kernel<float><<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const bf16_t *)Y,
+  colsum_kernel<float><<<dim3((C + 255) / 256, (int)slabs), 256, 0, (hipStream_t)stream>>>(P, C, (const e16_t *)Y,
                                                                                          sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1417,8 +1415,8 @@ extern "C" int omnipq_bn_finalize_relu(long long P, int C, double count, const d
   int grid = grid_for(chunks);
   if (grid < 1) grid = 1;                        // block 0 must run even for P == 0: it publishes a, b, ...
   bn_finalize_relu_kernel<<<grid, 256, sizeof(float) * 2 * C, (hipStream_t)stream>>>(
-      chunks, C, count, sums, gamma, beta, eps, momentum, running_mean, running_var, conv_bias, (const bf16_t *)Y,
-      (bf16_t *)X, a, b, mean, invstd);
+      chunks, C, count, sums, gamma, beta, eps, momentum, running_mean, running_var, conv_bias, (const e16_t *)Y,
+      (e16_t *)X, a, b, mean, invstd);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1438,8 +1436,8 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
     omnipq::ApplyProblem p;
     int grid;
   };
-  const Held q{omnipq::ApplyProblem{chunks, C, 1.0 / total_positions, (const bf16_t *)dX, (const bf16_t *)Y, a, b, mean,
-                                    invstd, sums, (bf16_t *)dY, dbeta_dgamma},
+  const Held q{omnipq::ApplyProblem{chunks, C, 1.0 / total_positions, (const e16_t *)dX, (const e16_t *)Y, a, b, mean,
+                                    invstd, sums, (e16_t *)dY, dbeta_dgamma},
                grid};
   auto single = +[](const omnipq::HeldLaunch &h) {
     Held f;
@@ -1476,8 +1474,8 @@ extern "C" int omnipq_prep_weights_all(int nseg, int ntiles, const void *segs, c
   if (nseg < 0 || ntiles < 0) return OMNIPQ_EINVAL;
   if (nseg == 0 || ntiles == 0) return OMNIPQ_OK;
   if (!segs || !tiles || !Wp_arena || !Wt_arena) return OMNIPQ_EINVAL;
-  prep_all_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const PrepSeg *)segs, tiles, (bf16_t *)Wp_arena,
-                                                           (bf16_t *)Wt_arena);
+  prep_all_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const PrepSeg *)segs, tiles, (e16_t *)Wp_arena,
+                                                           (e16_t *)Wt_arena);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1521,7 +1519,7 @@ __global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, int
       // a full chunk of a dense block (the large feature maps): memory order, 16-byte loads, all of a thread's loads in
       // flight at once -- a sum does not care about the order
       if (bf) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.ptr) + base);
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const e16_t *>(g.ptr) + base);
         uint4 v[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) v[u] = src[u * 256 + threadIdx.x];
@@ -1547,7 +1545,7 @@ __global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, int
       const int i = base + u * 256 + (int)threadIdx.x;
       if (i < numel) {
         if (dense) {                  // tail chunk or unaligned view: element by element
-          acc += bf ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[i] : reinterpret_cast<const float *>(g.ptr)[i];
+          acc += bf ? (float)reinterpret_cast<const e16_t *>(g.ptr)[i] : reinterpret_cast<const float *>(g.ptr)[i];
           continue;
         }
         int r = i;
@@ -1556,7 +1554,7 @@ __global__ __launch_bounds__(256) void sum_of_means_kernel(const MeanArgs a, int
         const int i1 = r % g.size[1]; r /= g.size[1];
         const long long off = (long long)r * g.stride[0] + (long long)i1 * g.stride[1] + (long long)i2 * g.stride[2] +
                               (long long)i3 * g.stride[3];
-        acc += bf ? (float)reinterpret_cast<const bf16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
+        acc += bf ? (float)reinterpret_cast<const e16_t *>(g.ptr)[off] : reinterpret_cast<const float *>(g.ptr)[off];
       }
     }
     total += acc / (float)numel;
@@ -1625,9 +1623,9 @@ extern "C" int omnipq_sum_of_means(int nseg, const void *const *ptrs, const int 
 // Same arithmetic as three_interpolate (f32 weights, f32 accumulation), but with channels contiguous a
 // neighbour is ONE 16-byte read per 8 channels instead of 8 strided ones, and the result lands directly in
 // the columns of the MLP's input rows (no transpose, no concatenation pass).
-__global__ __launch_bounds__(256) void interp_rows_kernel(long long chunks, int n, int m, int C, const bf16_t *__restrict__ feat,
+__global__ __launch_bounds__(256) void interp_rows_kernel(long long chunks, int n, int m, int C, const e16_t *__restrict__ feat,
                                                          const int *__restrict__ idx, const float *__restrict__ w,
-                                                         bf16_t *__restrict__ out, int ldo, int col0) {
+                                                         e16_t *__restrict__ out, int ldo, int col0) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
     const long long row = q / cpr;                         // (b, i)
@@ -1649,7 +1647,7 @@ __global__ __launch_bounds__(256) void interp_rows_kernel(long long chunks, int 
 
 // dfeat[b][idx][c] += w * g[(b,i)][col0 + c]      (f32 atomics, 8 consecutive channels per lane; dfeat zeroed)
 __global__ __launch_bounds__(256) void interp_rows_grad_kernel(long long chunks, int n, int m, int C,
-                                                              const bf16_t *__restrict__ g, int ldg, int col0,
+                                                              const e16_t *__restrict__ g, int ldg, int col0,
                                                               const int *__restrict__ idx, const float *__restrict__ w,
                                                               float *__restrict__ dfeat) {
   const int cpr = C >> 3;
@@ -1676,7 +1674,7 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(long long chunks,
 __global__ __launch_bounds__(256) void interp_rows_grad_csr_kernel(long long items, int n3, int m, int C,
                                                                   const int *__restrict__ offsets,
                                                                   const int *__restrict__ order,
-                                                                  const bf16_t *__restrict__ g, int ldg, int col0,
+                                                                  const e16_t *__restrict__ g, int ldg, int col0,
                                                                   const float *__restrict__ w, float *__restrict__ dfeat) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
@@ -1701,8 +1699,8 @@ __global__ __launch_bounds__(256) void interp_rows_grad_csr_kernel(long long ite
 }
 
 // copy of a bf16 row block into a column range of wider rows: dst[r][col0 + c] = src[r][c]
-__global__ __launch_bounds__(256) void place_rows_kernel(long long chunks, int C, const bf16_t *__restrict__ src,
-                                                        bf16_t *__restrict__ dst, int ldd, int col0) {
+__global__ __launch_bounds__(256) void place_rows_kernel(long long chunks, int C, const e16_t *__restrict__ src,
+                                                        e16_t *__restrict__ dst, int ldd, int col0) {
   const int cpr = C >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
     const long long row = q / cpr;
@@ -1719,8 +1717,8 @@ extern "C" int omnipq_interp_rows(int b, int n, int m, int C, const void *feat, 
   const long long chunks = (long long)b * n * (C / 8);
   if (chunks == 0) return OMNIPQ_OK;
   if (!feat || !idx || !weight || !out) return OMNIPQ_EINVAL;
-  interp_rows_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const bf16_t *)feat, idx, weight,
-                                                                      (bf16_t *)out, ldo, col0);
+  interp_rows_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const e16_t *)feat, idx, weight,
+                                                                      (e16_t *)out, ldo, col0);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1732,7 +1730,7 @@ extern "C" int omnipq_interp_rows_grad(int b, int n, int m, int C, const void *g
   const long long chunks = (long long)b * n * (C / 8);
   if (chunks == 0) return OMNIPQ_OK;
   if (!g || !idx || !weight || !dfeat) return OMNIPQ_EINVAL;
-  interp_rows_grad_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const bf16_t *)g, ldg, col0,
+  interp_rows_grad_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, n, m, C, (const e16_t *)g, ldg, col0,
                                                                            idx, weight, dfeat);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1748,7 +1746,7 @@ extern "C" int omnipq_interp_rows_grad_csr(int b, int n, int m, int C, const voi
   if (items == 0) return OMNIPQ_OK;
   if (!g || !offsets || !order || !weight || !dfeat) return OMNIPQ_EINVAL;
   interp_rows_grad_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(items, 3 * n, m, C, offsets, order,
-                                                                              (const bf16_t *)g, ldg, col0, weight, dfeat);
+                                                                              (const e16_t *)g, ldg, col0, weight, dfeat);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1758,7 +1756,7 @@ extern "C" int omnipq_place_rows(long long rows, int C, const void *src, void *d
   const long long chunks = rows * (C / 8);
   if (chunks == 0) return OMNIPQ_OK;
   if (!src || !dst) return OMNIPQ_EINVAL;
-  place_rows_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, C, (const bf16_t *)src, (bf16_t *)dst, ldd,
+  place_rows_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(chunks, C, (const e16_t *)src, (e16_t *)dst, ldd,
                                                                      col0);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;

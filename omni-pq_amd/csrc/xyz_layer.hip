@@ -7,24 +7,23 @@
 //             sum_p y_c^2 = W0[c]^T M2 W0[c]              M2 = sum_p x0[p] x0[p]^T         (3 x 3)
 //   backward  dW0[c][j] = a_c ( sum_p dz x0_j  -  m1_c S1_j  -  m2_c is_c ( (W0 M2)[c][j] - mu_c S1_j ) )
 //             with dz the masked gradient the layer above hands down, m1 = mean(dz), m2 = mean(dz yhat); the three sums over p
-//             come out of the data-gradient GEMM's epilogue (omnipq_gemm_nt_bf16_xyz_bnbwd), so neither y, nor dz, nor the
+//             come out of the data-gradient GEMM's epilogue (omnipq_gemm_nt_e16_xyz_bnbwd), so neither y, nor dz, nor the
 //             BatchNorm-backward result of this layer is ever written: 2.4 GB less HBM traffic per step on sa1.
 #include "common.h"
 
 namespace omnipq {
 
-typedef __bf16 bf16_t;
 
 // mom[0..2] = S1, mom[3..11] = M2 (row major), f64, added to (zero on entry)
-__global__ __launch_bounds__(256) void xyz_moments_kernel(long long P, int ldx, const bf16_t *__restrict__ X0,
+__global__ __launch_bounds__(256) void xyz_moments_kernel(long long P, int ldx, const e16_t *__restrict__ X0,
                                                           double *__restrict__ mom) {
   __shared__ float red[4][9];
   float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // x y z xx xy xz yy yz zz
 #pragma unroll 4
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
     const uint2 v = *reinterpret_cast<const uint2 *>(X0 + (size_t)p * ldx);
-    const float x = __builtin_bit_cast(float, v.x << 16), y = __builtin_bit_cast(float, v.x & 0xffff0000u);
-    const float z = __builtin_bit_cast(float, v.y << 16);
+    const float x = e16_lo(v.x), y = e16_hi(v.x);
+    const float z = e16_lo(v.y);
     s[0] += x;
     s[1] += y;
     s[2] += z;
@@ -52,15 +51,15 @@ __global__ __launch_bounds__(256) void xyz_moments_kernel(long long P, int ldx, 
   }
 }
 
-__device__ __forceinline__ void load_w0(const bf16_t *W0, int ldw, int c, double w[3]) {
+__device__ __forceinline__ void load_w0(const e16_t *W0, int ldw, int c, double w[3]) {
   const uint2 v = *reinterpret_cast<const uint2 *>(W0 + (size_t)c * ldw);
-  w[0] = (double)__builtin_bit_cast(float, v.x << 16);
-  w[1] = (double)__builtin_bit_cast(float, v.x & 0xffff0000u);
-  w[2] = (double)__builtin_bit_cast(float, v.y << 16);
+  w[0] = (double)e16_lo(v.x);
+  w[1] = (double)e16_hi(v.x);
+  w[2] = (double)e16_lo(v.y);
 }
 
 // sums[0][c] = W0[c] . S1,  sums[1][c] = W0[c]^T M2 W0[c]   (what a statistics pass over y would have produced)
-__global__ void xyz_stats_kernel(int C, const bf16_t *__restrict__ W0, int ldw, const double *__restrict__ mom,
+__global__ void xyz_stats_kernel(int C, const e16_t *__restrict__ W0, int ldw, const double *__restrict__ mom,
                                  double *__restrict__ sums) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (c >= C) return;
@@ -79,7 +78,7 @@ __global__ void xyz_stats_kernel(int C, const bf16_t *__restrict__ W0, int ldw, 
 
 // dW0 f32 [C][3] from the five column sums of the data-gradient GEMM (sums5[0], sums5[1] are the GLOBAL totals under
 // SyncBatchNorm, inv_count = 1 / global positions; rows 2..4 and the moments are this rank's)
-__global__ void xyz_bwd_kernel(int C, const bf16_t *__restrict__ W0, int ldw, const double *__restrict__ mom,
+__global__ void xyz_bwd_kernel(int C, const e16_t *__restrict__ W0, int ldw, const double *__restrict__ mom,
                                const double *__restrict__ sums5, const float *__restrict__ a,
                                const float *__restrict__ mean, const float *__restrict__ invstd, double inv_count,
                                float *__restrict__ dW) {
@@ -111,7 +110,7 @@ extern "C" int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, doubl
   // (1 M positions); 256 blocks of 16 positions per thread stream the 16 MB in ~10
   long long blocks = (P + 255) / 256;
   if (blocks > 256) blocks = 256;
-  xyz_moments_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(P, ldx, (const bf16_t *)X0, mom);
+  xyz_moments_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(P, ldx, (const e16_t *)X0, mom);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -119,7 +118,7 @@ extern "C" int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, doubl
 // W0 bf16 [C][ldw] (columns 0..2: the layer's prepared weights) -> sums double[2][C] (overwritten)
 extern "C" int omnipq_sa_xyz_stats(int C, const void *W0, int ldw, const double *mom, double *sums, void *stream) {
   if (C <= 0 || !W0 || !mom || !sums || (ldw % 4) || ldw < 3) return OMNIPQ_EINVAL;
-  xyz_stats_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, (const bf16_t *)W0, ldw, mom, sums);
+  xyz_stats_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, (const e16_t *)W0, ldw, mom, sums);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -127,7 +126,7 @@ extern "C" int omnipq_sa_xyz_stats(int C, const void *W0, int ldw, const double 
 extern "C" int omnipq_sa_xyz_bwd(int C, const void *W0, int ldw, const double *mom, const double *sums5, const float *a,
                                  const float *mean, const float *invstd, double inv_count, float *dW, void *stream) {
   if (C <= 0 || !W0 || !mom || !sums5 || !a || !mean || !invstd || !dW || (ldw % 4) || ldw < 3) return OMNIPQ_EINVAL;
-  xyz_bwd_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, (const bf16_t *)W0, ldw, mom, sums5, a, mean, invstd,
+  xyz_bwd_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(C, (const e16_t *)W0, ldw, mom, sums5, a, mean, invstd,
                                                                   inv_count, dW);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;

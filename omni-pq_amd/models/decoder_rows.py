@@ -25,7 +25,7 @@ import torch
 import dropout_state
 import rows_mlp
 import sa_fused
-from sa_fused import _call, _lib, _p, zeros_f32
+from sa_fused import E16, _call, _lib, _p, zeros_f32
 from utils import fused_attention
 
 _lib.omnipq_add_dropout_layernorm_bwd_blocks.restype = ctypes.c_longlong
@@ -36,14 +36,16 @@ class AddToBf16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
-        _call(_lib.omnipq_add_to_bf16, a, ctypes.c_longlong(a.numel()), _p(a), int(a.dtype == torch.float32), _p(b),
+        ctx.e16 = E16.dtype
+        out = torch.empty(a.shape, device=a.device, dtype=E16.dtype)
+        _call(_lib.omnipq_add_to_e16, a, ctypes.c_longlong(a.numel()), _p(a), int(a.dtype == torch.float32), _p(b),
               _p(out))
         ctx.a_dtype = a.dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
+        E16.select(ctx.e16)
         return (g.to(ctx.a_dtype) if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None)
 
 
@@ -53,12 +55,14 @@ class FanOut(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.e16 = E16.dtype
         ctx.meta = (tuple(x.shape), x.dtype)
         ctx.set_materialize_grads(False)
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
+        E16.select(ctx.e16)
         gs = [g for g in gs if g is not None]
         if not gs:
             return None, None
@@ -66,12 +70,12 @@ class FanOut(torch.autograd.Function):
             return gs[0], None
         shape, dtype = ctx.meta
         numel = gs[0].numel()
-        if dtype in (torch.bfloat16, torch.float32) and numel % 8 == 0 and len(gs) <= 16 and \
+        if dtype in (E16.dtype, torch.float32) and numel % 8 == 0 and len(gs) <= 16 and \
                 all(g.is_cuda and g.dtype == dtype and g.is_contiguous() and g.data_ptr() % 16 == 0 and
                     tuple(g.shape) == shape for g in gs):
             out = torch.empty(shape, device=gs[0].device, dtype=dtype)
             ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
-            _call(_lib.omnipq_add_n, out, len(gs), ptrs, ctypes.c_longlong(numel), int(dtype == torch.bfloat16), _p(out))
+            _call(_lib.omnipq_add_n, out, len(gs), ptrs, ctypes.c_longlong(numel), int(dtype == E16.dtype), _p(out))
             return out, None
         total = gs[0]
         for g in gs[1:]:
@@ -86,9 +90,10 @@ class SplitRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x16, p0):
+        ctx.e16 = E16.dtype
         B, P, C = x16.shape
-        obj = torch.empty((B * p0, C), device=x16.device, dtype=torch.bfloat16)
-        quad = torch.empty((B * (P - p0), C), device=x16.device, dtype=torch.bfloat16)
+        obj = torch.empty((B * p0, C), device=x16.device, dtype=E16.dtype)
+        quad = torch.empty((B * (P - p0), C), device=x16.device, dtype=E16.dtype)
         _call(_lib.omnipq_split_rows, x16, B, P, p0, C, _p(x16), _p(obj), _p(quad))
         ctx.geom = (B, P, p0, C)
         ctx.set_materialize_grads(False)
@@ -96,17 +101,18 @@ class SplitRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_obj, g_quad, g_joint):
+        E16.select(ctx.e16)
         B, P, p0, C = ctx.geom
-        gs = [None if g is None else g.to(torch.bfloat16).contiguous() for g in (g_obj, g_quad, g_joint)]
+        gs = [None if g is None else g.to(E16.dtype).contiguous() for g in (g_obj, g_quad, g_joint)]
         if all(g is None for g in gs):
             return None, None
-        out = torch.empty((B, P, C), device=next(g for g in gs if g is not None).device, dtype=torch.bfloat16)
+        out = torch.empty((B, P, C), device=next(g for g in gs if g is not None).device, dtype=E16.dtype)
         _call(_lib.omnipq_merge_rows, out, B, P, p0, C, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(out))
         return out, None
 
 
 def split_usable(x16):
-    return x16 is not None and x16.is_cuda and x16.dtype == torch.bfloat16 and x16.is_contiguous() and \
+    return x16 is not None and x16.is_cuda and x16.dtype == E16.dtype and x16.is_contiguous() and \
         x16.dim() == 3 and x16.shape[2] % 8 == 0 and x16.data_ptr() % 16 == 0
 
 
@@ -116,11 +122,12 @@ class AddDropoutLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, gamma, beta, eps, p, pe, want32, want16):
+        ctx.e16 = E16.dtype
         R, C = x.shape
         dev = x.device
         out32 = torch.empty((R, C), device=dev, dtype=torch.float32) if want32 else None
-        out16 = torch.empty((R, C), device=dev, dtype=torch.bfloat16) if want16 else None
-        out_pe = torch.empty((R, C), device=dev, dtype=torch.bfloat16) if pe is not None else None
+        out16 = torch.empty((R, C), device=dev, dtype=E16.dtype) if want16 else None
+        out_pe = torch.empty((R, C), device=dev, dtype=E16.dtype) if pe is not None else None
         mean = torch.empty(R, device=dev, dtype=torch.float32)
         rstd = torch.empty(R, device=dev, dtype=torch.float32)
         drop = p > 0 and y is not None
@@ -139,6 +146,7 @@ class AddDropoutLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g32, g16, gpe):
+        E16.select(ctx.e16)
         x, y, gamma, mean, rstd = ctx.saved_tensors
         p, seed, salt, has_pe = ctx.cfg
         R, C = x.shape
@@ -165,8 +173,7 @@ class AddDropoutLayerNorm(torch.autograd.Function):
 
 def usable(layer, query, key):
     """bf16 autocast on the GPU, learned position embeddings present, shapes the kernels accept."""
-    if not query.is_cuda or not torch.is_autocast_enabled("cuda") or \
-            torch.get_autocast_dtype("cuda") != torch.bfloat16:
+    if not query.is_cuda or not E16.autocast():
         return False
     if layer.self_posembed is None or layer.cross_posembed is None or layer.activation is not torch.nn.functional.relu:
         return False
@@ -203,8 +210,8 @@ def key_side(layer, key, key_pos, mem16=None):
     C = key.shape[1]
     ca = layer.multihead_attn
     if mem16 is None:
-        mem16 = _rows(key).to(torch.bfloat16)
-    k_pe = _rows(layer.cross_posembed(key_pos)).to(torch.bfloat16)
+        mem16 = _rows(key).to(E16.dtype)
+    k_pe = _rows(layer.cross_posembed(key_pos)).to(E16.dtype)
     mem_pe = AddToBf16.apply(mem16, k_pe)
     # ONE split of the packed projection (its backward is one cat; two slices would each zero-fill and copy a
     # full-size gradient and add them up); the query part travels with the result to run()
@@ -225,7 +232,7 @@ def precompute_key_sides(layers, key, key_pos):
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         # all layers read the same memory rows: one cast, and in backward one n-ary add for their n gradients
-        mem = FanOut.apply(_rows(key).to(torch.bfloat16).contiguous(), len(layers))
+        mem = FanOut.apply(_rows(key).to(E16.dtype).contiguous(), len(layers))
         kvs = []
         for i, layer in enumerate(layers):
             kv = key_side(layer, key, key_pos, mem[i])
@@ -267,7 +274,7 @@ def run(layer, query, key, query_pos, key_pos, kv=None):
         return rows_mlp.run(x, [rows_mlp.Layer(w, b, **kw)], training)
 
     x32 = _rows(query).float()
-    q_pe = _rows(layer.self_posembed(query_pos)).to(torch.bfloat16)
+    q_pe = _rows(layer.self_posembed(query_pos)).to(E16.dtype)
 
     # self attention: q = k = v = x + q_pe (transformer.py:203-205).  When the previous layer left its bf16 twin the sum is
     # formed from that: the gradient of this branch then reaches the twin as the bf16 tensor it is (added to the twin's other

@@ -34,6 +34,7 @@ from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
 import rows_mlp  # noqa: E402
 import sa_fused  # noqa: E402
+from sa_fused import E16  # noqa: E402
 
 # "capture": overlap the decoder's key sides on a side stream while a hipGraph is being captured (in eager mode the
 # extra stream switches cost more host time than the overlap returns); tests set "always" / "inline"
@@ -159,13 +160,13 @@ def _grad_descriptors(gs, n2):
             strides += [0, 0, 0, 0]
             flags.append(0)
             continue
-        if g.dtype not in (torch.float32, torch.bfloat16):
+        if g.dtype not in (torch.float32, E16.dtype):
             g = g.float()
         keep.append(g)
         st = list(g.stride())
         ptrs.append(g.data_ptr())
         strides += st if len(st) == 4 else st + [0]
-        flags.append(int(g.dtype == torch.bfloat16))
+        flags.append(int(g.dtype == E16.dtype))
     return ptrs, strides, flags, keep
 
 
@@ -182,13 +183,14 @@ class HeadDecode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, base_xyz, means, nh, ns, ncls):
+        ctx.e16 = E16.dtype
         import ctypes
         B, K, _ = base_xyz.shape
         R = B * K
         dev = y.device
-        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape[0] == R and y.shape[1] >= 5 + 2 * nh + 4 * ns + ncls
+        assert y.dtype == E16.dtype and y.stride(1) == 1 and y.shape[0] == R and y.shape[1] >= 5 + 2 * nh + 4 * ns + ncls
         base = base_xyz.detach().float().contiguous()
-        bf = dict(device=dev, dtype=torch.bfloat16)
+        bf = dict(device=dev, dtype=E16.dtype)
         f32 = dict(device=dev, dtype=torch.float32)
         outs = [torch.empty((B, K, 2), **bf), torch.empty((B, K, 3), **f32), torch.empty((B, K, nh), **bf),
                 torch.empty((B, K, nh), **bf), torch.empty((B, K, nh), **bf), torch.empty((B, K, ns), **bf),
@@ -204,13 +206,14 @@ class HeadDecode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        E16.select(ctx.e16)
         import ctypes
         y, means = ctx.saved_tensors
         B, K, nh, ns, ncls, scale = ctx.geom
         R = B * K
         n2 = [1, 1, 1, 1, 1, 1, 3, 3, 1, 1]
         ptrs, strides, flags, _keep = _grad_descriptors(gs, n2)
-        dy = torch.empty((R, y.shape[1]), device=y.device, dtype=torch.bfloat16)
+        dy = torch.empty((R, y.shape[1]), device=y.device, dtype=E16.dtype)
         dbase = torch.empty((B, K, 3), device=y.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         sa_fused._call(sa_fused._lib.omnipq_head_decode_bwd, y, R, K, nh, ns, ncls, sa_fused._p(y), y.stride(0),
                        sa_fused._p(means), ctypes.c_float(scale), (ctypes.c_void_p * 10)(*ptrs),
@@ -226,15 +229,16 @@ class QuadDecode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, base_xyz):
+        ctx.e16 = E16.dtype
         import ctypes
         B, K, _ = base_xyz.shape
         R = B * K
         dev = y.device
-        assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape[0] == R and y.shape[1] >= 10
+        assert y.dtype == E16.dtype and y.stride(1) == 1 and y.shape[0] == R and y.shape[1] >= 10
         base = base_xyz.detach().float().contiguous()
-        outs = [torch.empty((B, K, 2), device=dev, dtype=torch.bfloat16), torch.empty((B, K, 3), device=dev),
-                torch.empty((B, K, 3), device=dev, dtype=torch.bfloat16),
-                torch.empty((B, K, 2), device=dev, dtype=torch.bfloat16)]
+        outs = [torch.empty((B, K, 2), device=dev, dtype=E16.dtype), torch.empty((B, K, 3), device=dev),
+                torch.empty((B, K, 3), device=dev, dtype=E16.dtype),
+                torch.empty((B, K, 2), device=dev, dtype=E16.dtype)]
         norm = torch.empty(1, device=dev)
         sa_fused._call(sa_fused._lib.omnipq_quad_decode, y, R, sa_fused._p(y), y.stride(0), sa_fused._p(base),
                        (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs]), sa_fused._p(norm))
@@ -244,11 +248,12 @@ class QuadDecode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        E16.select(ctx.e16)
         import ctypes
         y, norm = ctx.saved_tensors
         B, K = ctx.geom
         ptrs, strides, flags, _keep = _grad_descriptors(gs, [1, 1, 1, 1])
-        dy = torch.empty((B * K, y.shape[1]), device=y.device, dtype=torch.bfloat16)
+        dy = torch.empty((B * K, y.shape[1]), device=y.device, dtype=E16.dtype)
         dbase = torch.empty((B, K, 3), device=y.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         sa_fused._call(sa_fused._lib.omnipq_quad_decode_bwd, y, B * K, K, sa_fused._p(y), y.stride(0), sa_fused._p(norm),
                        (ctypes.c_void_p * 4)(*ptrs), (ctypes.c_int * 16)(*strides), (ctypes.c_int * 4)(*flags),
@@ -271,11 +276,13 @@ class SinkFlush(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat, xyz, sink):
+        ctx.e16 = E16.dtype
         ctx.sink = sink
         return feat.view_as(feat)
 
     @staticmethod
     def backward(ctx, g):
+        E16.select(ctx.e16)
         buf, ctx.sink.buf = ctx.sink.buf, None
         return g, buf, None
 
@@ -289,16 +296,17 @@ class DecodePair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, yh, base_h, means, nh, ns, ncls, yq, base_q, sink=None, want_pos=False):
+        ctx.e16 = E16.dtype
         import ctypes
         B, K, _ = base_h.shape
         Bq, Kq, _ = base_q.shape
         dev = yh.device
-        assert yh.dtype == torch.bfloat16 and yh.stride(1) == 1 and yh.shape[0] == B * K
+        assert yh.dtype == E16.dtype and yh.stride(1) == 1 and yh.shape[0] == B * K
         assert yh.shape[1] >= 5 + 2 * nh + 4 * ns + ncls
-        assert yq.dtype == torch.bfloat16 and yq.stride(1) == 1 and yq.shape[0] == Bq * Kq and yq.shape[1] >= 10
+        assert yq.dtype == E16.dtype and yq.stride(1) == 1 and yq.shape[0] == Bq * Kq and yq.shape[1] >= 10
         bh = base_h.detach().float().contiguous()
         bq = base_q.detach().float().contiguous()
-        bf = dict(device=dev, dtype=torch.bfloat16)
+        bf = dict(device=dev, dtype=E16.dtype)
         f32 = dict(device=dev, dtype=torch.float32)
         outs_h = [torch.empty((B, K, 2), **bf), torch.empty((B, K, 3), **f32), torch.empty((B, K, nh), **bf),
                   torch.empty((B, K, nh), **bf), torch.empty((B, K, nh), **bf), torch.empty((B, K, ns), **bf),
@@ -324,6 +332,7 @@ class DecodePair(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        E16.select(ctx.e16)
         import ctypes
         yh, means, yq, norm = ctx.saved_tensors
         B, K, nh, ns, ncls, scale, Bq, Kq = ctx.geom
@@ -331,8 +340,8 @@ class DecodePair(torch.autograd.Function):
         n2 = [1, 1, 1, 1, 1, 1, 3, 3, 1, 1]
         ph, sh, fh, _keep_h = _grad_descriptors(gs[:10], n2)
         pq, sq, fq, _keep_q = _grad_descriptors(gs[10:14], [1, 1, 1, 1])
-        dyh = torch.empty((B * K, yh.shape[1]), device=dev, dtype=torch.bfloat16)
-        dyq = torch.empty((Bq * Kq, yq.shape[1]), device=dev, dtype=torch.bfloat16)
+        dyh = torch.empty((B * K, yh.shape[1]), device=dev, dtype=E16.dtype)
+        dyq = torch.empty((Bq * Kq, yq.shape[1]), device=dev, dtype=E16.dtype)
         sink, acc = ctx.sink, 0
         if sink is not None and ctx.needs_input_grad[1]:
             if sink.buf is None:
@@ -372,7 +381,7 @@ def predict_pair(head, quad_head, net, net_q, base_xyz, base_xyz_q, end_points, 
                                             net_rows=rows_q)
         return center, center_q, end_points, None
     yh, yq = head_stack_pair(head, quad_head, net, net_q, rows, rows_q)
-    ok = all(y.dtype == torch.bfloat16 and y.stride(1) == 1 for y in (yh, yq))
+    ok = all(y.dtype == E16.dtype and y.stride(1) == 1 for y in (yh, yq))
     if not ok:
         center, _, end_points = head.finish(yh, net, base_xyz, end_points, prefix)
         center_q, _, end_points = quad_head.finish(yq, net_q, base_xyz_q, end_points, prefix)
@@ -478,7 +487,7 @@ class PredictHead(nn.Module):
         """From the joint output rows `y` of the seven heads to the `end_points` entries."""
         heads = self.heads()
         B, K = net.shape[0], net.shape[2]
-        if _FUSED_DECODE and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1:
+        if _FUSED_DECODE and y.is_cuda and y.dtype == E16.dtype and y.stride(1) == 1:
             means = self._mean_sizes(net.device)
             outs = HeadDecode.apply(y, base_xyz, means, self.num_heading_bin, self.num_size_cluster, self.num_class)
             for key, val in zip(_HEAD_KEYS, outs):
@@ -518,7 +527,7 @@ class QuadPredictHead(nn.Module):
     def finish(self, y, net, base_xyz, end_points, prefix):
         heads = self.heads()
         B, K = net.shape[0], net.shape[2]
-        if _FUSED_DECODE and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1:
+        if _FUSED_DECODE and y.is_cuda and y.dtype == E16.dtype and y.stride(1) == 1:
             scores, center, normal, size = QuadDecode.apply(y, base_xyz)
             end_points[f'{prefix}quad_scores'] = scores
             end_points[f'{prefix}quad_center'] = center
@@ -590,6 +599,7 @@ class PQ_Transformer(nn.Module):
         nn.SyncBatchNorm.convert_sync_batchnorm(self)      # in place for every child BN (:194)
 
     def forward(self, inputs):
+        E16.autocast()                 # bf16 / fp16 autocast: the hand-written kernels' element type for this step
         arena = sa_fused.arena_of(self)
         with sa_fused.deferred_counters(), arena.step(inputs['point_clouds'].device):
             return self._forward(inputs)

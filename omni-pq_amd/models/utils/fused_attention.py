@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 import sa_fused
-from sa_fused import _call, _lib, _p
+from sa_fused import E16, _call, _lib, _p
 
 MAX_HEAD_DIM = 48
 
@@ -20,7 +20,7 @@ from dropout_state import STATE  # noqa: E402  (shared with the other dropout si
 
 def usable(q, k, v, num_heads):
     E = q.shape[-1]
-    if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16):
+    if not (q.is_cuda and q.dtype == k.dtype == v.dtype == E16.dtype):
         return False
     D = E // num_heads
     if D * num_heads != E or D % 4 or D > MAX_HEAD_DIM:
@@ -43,10 +43,11 @@ class FusedAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, num_heads, dropout_p):
+        ctx.e16 = E16.dtype
         L, N, E = q.shape
         S = k.shape[0]
         D = E // num_heads
-        o = torch.empty((L, N, E), device=q.device, dtype=torch.bfloat16)
+        o = torch.empty((L, N, E), device=q.device, dtype=E16.dtype)
         lse = torch.empty((N * num_heads, L), device=q.device, dtype=torch.float32)
         seed = STATE.seed(q.device) if dropout_p > 0 else None
         salt = STATE.next_salt() if dropout_p > 0 else 0
@@ -58,17 +59,18 @@ class FusedAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_o):
+        E16.select(ctx.e16)
         q, k, v, o, lse = ctx.saved_tensors
         num_heads, dropout_p, seed, salt = ctx.cfg
         L, N, E = q.shape
         S = k.shape[0]
         D = E // num_heads
-        d_o = d_o.to(torch.bfloat16)
+        d_o = d_o.to(E16.dtype)
         if d_o.stride() != o.stride():
             d_o = d_o.contiguous()
-        dq = torch.empty((L, N, E), device=q.device, dtype=torch.bfloat16)
-        dk = torch.empty((S, N, E), device=q.device, dtype=torch.bfloat16)
-        dv = torch.empty((S, N, E), device=q.device, dtype=torch.bfloat16)
+        dq = torch.empty((L, N, E), device=q.device, dtype=E16.dtype)
+        dk = torch.empty((S, N, E), device=q.device, dtype=E16.dtype)
+        dv = torch.empty((S, N, E), device=q.device, dtype=E16.dtype)
         delta = torch.empty_like(lse)
         _call(_lib.omnipq_attn_bwd, q, N, num_heads, L, S, D, _p(q), _p(k), _p(v), _p(o), _p(d_o),
               _strides(q, k, v, o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _strides(dq, dk, dv),
@@ -104,10 +106,11 @@ class PackedAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, L, S, N, H, dropout_p):
+        ctx.e16 = E16.dtype
         E = a.shape[1] // 3 if b is None else a.shape[1]
         D = E // H
         (qp, kp, vp), st = PackedAttention._pointers(a, b, E, L, S)
-        o = torch.empty((N * L, E), device=a.device, dtype=torch.bfloat16)
+        o = torch.empty((N * L, E), device=a.device, dtype=E16.dtype)
         lse = torch.empty((N * H, L), device=a.device, dtype=torch.float32)
         seed = STATE.seed(a.device) if dropout_p > 0 else None
         salt = STATE.next_salt() if dropout_p > 0 else 0
@@ -120,11 +123,12 @@ class PackedAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_o):
+        E16.select(ctx.e16)
         a, b, o, lse = ctx.saved_tensors
         L, S, N, H, dropout_p, seed, salt = ctx.cfg
         E = o.shape[1]
         D = E // H
-        d_o = d_o.to(torch.bfloat16).contiguous()
+        d_o = d_o.to(E16.dtype).contiguous()
         (qp, kp, vp), st = PackedAttention._pointers(a, b, E, L, S)
         da = torch.empty_like(a)
         db = torch.empty_like(b) if b is not None else None
@@ -141,7 +145,7 @@ class PackedAttention(torch.autograd.Function):
 def packed_usable(a, b, H):
     E = a.shape[1] // 3 if b is None else a.shape[1]
     D = E // H
-    ok = a.is_cuda and a.dtype == torch.bfloat16 and a.is_contiguous() and D * H == E and D % 4 == 0 and D <= MAX_HEAD_DIM
+    ok = a.is_cuda and a.dtype == E16.dtype and a.is_contiguous() and D * H == E and D % 4 == 0 and D <= MAX_HEAD_DIM
     if b is not None:
-        ok = ok and b.dtype == torch.bfloat16 and b.is_contiguous() and b.shape[1] == 2 * E
+        ok = ok and b.dtype == E16.dtype and b.is_contiguous() and b.shape[1] == 2 * E
     return ok

@@ -17,6 +17,7 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
         sys.path.append(_p)
 
 import rows_mlp  # noqa: E402
+from sa_fused import E16  # noqa: E402
 
 
 _FUSED_TAIL = True      # False: the op-by-op tail (tests compare the two)
@@ -37,6 +38,7 @@ class VoteDecode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, seed_xyz, seed_features):
+        ctx.e16 = E16.dtype
         import ctypes
         import sa_fused
         B, K, _ = seed_xyz.shape
@@ -45,9 +47,9 @@ class VoteDecode(torch.autograd.Function):
         sx = seed_xyz.detach().float().contiguous()
         sf = seed_features.detach()
         vote_xyz = torch.empty((B, K, 3), device=dev, dtype=torch.float32)
-        bf = sf.dtype == torch.bfloat16
+        bf = sf.dtype == E16.dtype
         out = torch.empty((B, C, K), device=dev, dtype=sf.dtype)
-        twin = torch.empty((B, K, C), device=dev, dtype=torch.bfloat16)
+        twin = torch.empty((B, K, C), device=dev, dtype=E16.dtype)
         norm = torch.empty((B, K), device=dev, dtype=torch.float32)
         sa_fused._call(sa_fused._lib.omnipq_vote_decode, net, B, K, C, sa_fused._p(net), net.stride(0), sa_fused._p(sx),
                        sa_fused._p(sf), int(bf), ctypes.c_longlong(sf.stride(0)), ctypes.c_longlong(sf.stride(1)),
@@ -61,12 +63,13 @@ class VoteDecode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_xyz, g_feat, _g_twin):
+        E16.select(ctx.e16)
         import sa_fused
         out, norm = ctx.saved_tensors
         B, K, C, ld, bf = ctx.geom
         g_xyz = None if g_xyz is None else g_xyz.float().contiguous()
         g_feat = None if g_feat is None else g_feat.to(out.dtype).contiguous()
-        dnet = torch.empty((B * K, ld), device=out.device, dtype=torch.bfloat16)
+        dnet = torch.empty((B * K, ld), device=out.device, dtype=E16.dtype)
         dseed = torch.empty((B, C, K), device=out.device, dtype=out.dtype) if ctx.needs_input_grad[2] else None
         sa_fused._call(sa_fused._lib.omnipq_vote_decode_bwd, out, B, K, C, sa_fused._p(out), int(bf), sa_fused._p(norm),
                        sa_fused._p(g_xyz), sa_fused._p(g_feat), sa_fused._p(dnet), ld, sa_fused._p(dseed))
@@ -98,7 +101,7 @@ class VotingModule(nn.Module):
                  rows_mlp.Layer(self.conv2.weight, self.conv2.bias, self.bn2),
                  rows_mlp.Layer(self.conv3.weight, self.conv3.bias)]
         if _FUSED_TAIL and normalized and vf == 1 and C <= 320 and rows_mlp.usable(x, stack, self.training) and \
-                seed_xyz.dtype == torch.float32 and seed_features.dtype in (torch.float32, torch.bfloat16):
+                seed_xyz.dtype == torch.float32 and seed_features.dtype in (torch.float32, E16.dtype):
             net = rows_mlp.run(x, stack, self.training, padded=True)
             vote_xyz, vote_features, twin = VoteDecode.apply(net, seed_xyz, seed_features)
             vote_features.omnipq_rows16 = twin          # the vote aggregation reads bf16 rows: no cast there

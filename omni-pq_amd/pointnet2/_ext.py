@@ -26,13 +26,102 @@ if not os.path.exists(_LIB_PATH):
         f"pointnet2._ext: {_LIB_PATH} not found -- build it with `python omni-pq_amd/build.py` "
         "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for these operators.")
 
-_lib = ctypes.CDLL(_LIB_PATH)
-_lib.omnipq_error_string.restype = ctypes.c_char_p
-_lib.omnipq_abi_version.restype = ctypes.c_int
-if _lib.omnipq_abi_version() != 1:
-    raise ImportError("pointnet2._ext: libomnipq_pointops.so has an unexpected ABI version")
+def _load(path):
+    lib = ctypes.CDLL(path)
+    lib.omnipq_error_string.restype = ctypes.c_char_p
+    lib.omnipq_abi_version.restype = ctypes.c_int
+    if lib.omnipq_abi_version() != 1:
+        raise ImportError(f"pointnet2._ext: {path} has an unexpected ABI version")
+    return lib
+
+
+# The library is built once per 16-bit element type (omni-pq_amd/build.py, csrc/common.h: e16_t): bfloat16 in
+# libomnipq_pointops.so -- which also serves every index / f32 operator below -- and IEEE half in its `_f16` twin.
+_LIB_F16_PATH = _LIB_PATH[:-3] + "_f16.so"
+_LIBS = {torch.bfloat16: _load(_LIB_PATH)}
+if os.path.exists(_LIB_F16_PATH):
+    _LIBS[torch.float16] = _load(_LIB_F16_PATH)
+
+
+class _Elem16:
+    """The element type the hand-written 16-bit kernels are running in: `E16.dtype`.  It follows torch.autocast:
+    every entry into the hand-written path asks `E16.autocast()` -- True when CUDA autocast is on with a dtype a library
+    exists for, which also makes that dtype current -- and the autograd nodes re-select the type their saved tensors
+    have before they launch anything in backward.  Two element types interleaved on ONE thread between a forward and its
+    backward are therefore fine; two threads running different types at once are not supported (module state)."""
+
+    def __init__(self):
+        self.dtype = torch.bfloat16
+
+    def available(self, dtype):
+        return dtype in _LIBS
+
+    def select(self, dtype):
+        if dtype is not self.dtype:
+            if dtype not in _LIBS:
+                raise RuntimeError(f"pointnet2._ext: no library for element type {dtype} ({_LIB_F16_PATH} missing?)")
+            self.dtype = dtype
+        return dtype
+
+    def autocast(self):
+        if not torch.is_autocast_enabled("cuda"):
+            return False
+        dt = torch.get_autocast_dtype("cuda")
+        if dt not in _LIBS:
+            return False
+        self.dtype = dt
+        return True
+
+    def is16(self, dtype):
+        """Is `dtype` the current element type?"""
+        return dtype is self.dtype
+
+
+E16 = _Elem16()
+
+
+class _Entry:
+    """One C-ABI entry point, resolved at call time in the library of the current element type."""
+    __slots__ = ("__name__", "_fns")
+
+    def __init__(self, name):
+        self.__name__ = name
+        self._fns = {dt: getattr(lib, name) for dt, lib in _LIBS.items()}
+
+    def __call__(self, *args):
+        return self._fns[E16.dtype](*args)
+
+    @property
+    def restype(self):
+        return self._fns[torch.bfloat16].restype
+
+    @restype.setter
+    def restype(self, value):
+        for fn in self._fns.values():
+            fn.restype = value
+
+    @property
+    def argtypes(self):
+        return self._fns[torch.bfloat16].argtypes
+
+    @argtypes.setter
+    def argtypes(self, value):
+        for fn in self._fns.values():
+            fn.argtypes = value
+
+
+class _Libs:
+    def __getattr__(self, name):
+        entry = _Entry(name)
+        object.__setattr__(self, name, entry)
+        return entry
+
+
+_lib = _Libs()
+_lib0 = _LIBS[torch.bfloat16]        # element-type independent entry points (index ops, FPS state) always live here
 
 LIB_PATH = _LIB_PATH
+LIB_F16_PATH = _LIB_F16_PATH if torch.float16 in _LIBS else None
 
 
 def _check(x, name, dtype=None, cuda_like=None):
@@ -96,7 +185,7 @@ def _run(fn, anchor, *args):
     else:
         rc = fn(*args, _stream(dev))
     if rc != 0:
-        raise RuntimeError(f"{fn.__name__} failed: {_lib.omnipq_error_string(rc).decode()} ({rc})")
+        raise RuntimeError(f"{fn.__name__} failed: {_lib0.omnipq_error_string(rc).decode()} ({rc})")
 
 
 def gather_points(points, idx):
@@ -107,7 +196,7 @@ def gather_points(points, idx):
     b, c, n = points.shape
     m = idx.shape[1]
     out = torch.empty((b, c, m), device=points.device, dtype=torch.float32)
-    _run(_lib.omnipq_gather_points, points, b, c, n, m, _ptr(points), _ptr(idx), _ptr(out))
+    _run(_lib0.omnipq_gather_points, points, b, c, n, m, _ptr(points), _ptr(idx), _ptr(out))
     return out
 
 
@@ -121,7 +210,7 @@ def gather_xyz(xyz, idx):
         raise ValueError("gather_xyz: xyz must be (B, N, 3)")
     m = idx.shape[1]
     out = torch.empty((b, m, 3), device=xyz.device, dtype=torch.float32)
-    _run(_lib.omnipq_gather_xyz, xyz, b, n, m, _ptr(xyz), _ptr(idx), _ptr(out))
+    _run(_lib0.omnipq_gather_xyz, xyz, b, n, m, _ptr(xyz), _ptr(idx), _ptr(out))
     return out
 
 
@@ -132,7 +221,7 @@ def gather_points_grad(grad_out, idx, n):
     _need_gpu(grad_out)
     b, c, m = grad_out.shape
     out = torch.zeros((b, c, int(n)), device=grad_out.device, dtype=torch.float32)
-    _run(_lib.omnipq_gather_points_grad, grad_out, b, c, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out))
+    _run(_lib0.omnipq_gather_points_grad, grad_out, b, c, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out))
     return out
 
 
@@ -142,18 +231,18 @@ _fps_ready = set()
 def fps_poll():
     """Raise if a multi-workgroup FPS launch on the current device has reported a hand-off timeout since the last
     poll (non-blocking: the flag is pinned host memory the kernel writes through)."""
-    rc = _lib.omnipq_fps_poll()
+    rc = _lib0.omnipq_fps_poll()
     if rc != 0:
-        raise RuntimeError(f"furthest point sampling: {_lib.omnipq_error_string(rc).decode()} ({rc}) -- a "
+        raise RuntimeError(f"furthest point sampling: {_lib0.omnipq_error_string(rc).decode()} ({rc}) -- a "
                            "multi-workgroup launch gave up waiting for its sibling workgroups; its indices are invalid")
 
 
 def _fps_prepare(device):
     if device.index not in _fps_ready:
         with torch.cuda.device(device):
-            rc = _lib.omnipq_fps_init()            # allocations happen here, outside any stream capture
+            rc = _lib0.omnipq_fps_init()            # allocations happen here, outside any stream capture
         if rc != 0:
-            raise RuntimeError(f"omnipq_fps_init failed: {_lib.omnipq_error_string(rc).decode()} ({rc})")
+            raise RuntimeError(f"omnipq_fps_init failed: {_lib0.omnipq_error_string(rc).decode()} ({rc})")
         _fps_ready.add(device.index)
     fps_poll()
 
@@ -171,7 +260,7 @@ def furthest_point_sampling(points, nsamples, out=None):
         _check(out, "out", torch.int32, cuda_like=points)
         assert tuple(out.shape) == (b, int(nsamples))
     tmp = torch.full((b, n), 1e10, device=points.device, dtype=torch.float32)
-    _run(_lib.omnipq_furthest_point_sampling, points, b, n, int(nsamples), _ptr(points), _ptr(tmp), _ptr(out))
+    _run(_lib0.omnipq_furthest_point_sampling, points, b, n, int(nsamples), _ptr(points), _ptr(tmp), _ptr(out))
     return out
 
 
@@ -184,7 +273,7 @@ def three_nn(unknowns, knows):
     m = knows.shape[1]
     idx = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.int32)
     dist2 = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
-    _run(_lib.omnipq_three_nn, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx))
+    _run(_lib0.omnipq_three_nn, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx))
     return [dist2, idx]
 
 
@@ -199,7 +288,7 @@ def three_nn_weights(unknowns, knows):
     idx = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.int32)
     dist2 = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
     weight = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
-    _run(_lib.omnipq_three_nn_weights, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), _ptr(weight))
+    _run(_lib0.omnipq_three_nn_weights, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), _ptr(weight))
     return weight, idx
 
 
@@ -212,7 +301,7 @@ def three_interpolate(points, idx, weight):
     b, c, m = points.shape
     n = idx.shape[1]
     out = torch.empty((b, c, n), device=points.device, dtype=torch.float32)
-    _run(_lib.omnipq_three_interpolate, points, b, c, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out))
+    _run(_lib0.omnipq_three_interpolate, points, b, c, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out))
     return out
 
 
@@ -224,13 +313,13 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     _need_gpu(grad_out)
     b, c, n = grad_out.shape
     out = torch.zeros((b, c, int(m)), device=grad_out.device, dtype=torch.float32)
-    _run(_lib.omnipq_three_interpolate_grad, grad_out, b, c, n, int(m), _ptr(grad_out), _ptr(idx),
+    _run(_lib0.omnipq_three_interpolate_grad, grad_out, b, c, n, int(m), _ptr(grad_out), _ptr(idx),
          _ptr(weight), _ptr(out))
     return out
 
 
 _BQ_GRID_MIN = 8192      # points per scene from which the grid pays
-_lib.omnipq_ball_query_grid_workspace_bytes.restype = ctypes.c_longlong
+_lib0.omnipq_ball_query_grid_workspace_bytes.restype = ctypes.c_longlong
 
 
 def ball_query(new_xyz, xyz, radius, nsample):
@@ -243,12 +332,12 @@ def ball_query(new_xyz, xyz, radius, nsample):
     idx = torch.empty((b, m, int(nsample)), device=new_xyz.device, dtype=torch.int32)
     if n >= _BQ_GRID_MIN and radius > 0 and b <= 65535:
         # large clouds: the same indices through a hash grid (csrc/ball_query.hip) instead of n tests per centre
-        ws = torch.empty((int(_lib.omnipq_ball_query_grid_workspace_bytes(b, n)),), device=new_xyz.device,
+        ws = torch.empty((int(_lib0.omnipq_ball_query_grid_workspace_bytes(b, n)),), device=new_xyz.device,
                          dtype=torch.uint8)
-        _run(_lib.omnipq_ball_query_grid, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
+        _run(_lib0.omnipq_ball_query_grid, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
              _ptr(xyz), _ptr(idx), _ptr(ws))
         return idx
-    _run(_lib.omnipq_ball_query, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
+    _run(_lib0.omnipq_ball_query, new_xyz, b, n, m, ctypes.c_float(radius), int(nsample), _ptr(new_xyz),
          _ptr(xyz), _ptr(idx))
     return idx
 
@@ -261,7 +350,7 @@ def group_points(points, idx):
     b, c, n = points.shape
     npoints, nsample = idx.shape[1], idx.shape[2]
     out = torch.empty((b, c, npoints, nsample), device=points.device, dtype=torch.float32)
-    _run(_lib.omnipq_group_points, points, b, c, n, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out))
+    _run(_lib0.omnipq_group_points, points, b, c, n, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out))
     return out
 
 
@@ -272,13 +361,13 @@ def group_points_grad(grad_out, idx, n):
     _need_gpu(grad_out)
     b, c, npoints, nsample = grad_out.shape
     out = torch.zeros((b, c, int(n)), device=grad_out.device, dtype=torch.float32)
-    _run(_lib.omnipq_group_points_grad, grad_out, b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx),
+    _run(_lib0.omnipq_group_points_grad, grad_out, b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx),
          _ptr(out))
     return out
 
 
 def fps_check():
     """Raise if a multi-workgroup FPS launch on this device reported a hand-off timeout."""
-    rc = _lib.omnipq_fps_check(_stream())
+    rc = _lib0.omnipq_fps_check(_stream())
     if rc != 0:
-        raise RuntimeError(f"omnipq_fps_check: {_lib.omnipq_error_string(rc).decode()} ({rc})")
+        raise RuntimeError(f"omnipq_fps_check: {_lib0.omnipq_error_string(rc).decode()} ({rc})")

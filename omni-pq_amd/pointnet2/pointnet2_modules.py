@@ -23,6 +23,8 @@ if _HERE not in sys.path:
     sys.path.append(_HERE)
 
 import pointnet2_utils  # noqa: E402
+
+E16 = pointnet2_utils._load_ext().E16      # element type selector of the hand-written 16-bit kernels
 import pytorch_utils as pt_utils  # noqa: E402
 
 
@@ -147,7 +149,7 @@ class PointnetSAModuleVotes(nn.Module):
 
     def _fused(self, xyz, features):
         """Run group + MLP + max-pool on the fused HIP kernels (sa_fused.py)?  OMNIPQ_SA=fused|composed
-        forces the choice; by default the fused bf16 stage is used under torch.autocast(bfloat16) and the
+        forces the choice; by default the fused 16-bit stage is used under torch.autocast(bfloat16 | float16) and the
         reference's f32 op-by-op composition otherwise."""
         mode = os.environ.get("OMNIPQ_SA", "auto")
         if mode == "composed" or self.ret_unique_cnt:
@@ -155,9 +157,8 @@ class PointnetSAModuleVotes(nn.Module):
         import sa_fused
         if not sa_fused.eligible(self, xyz, features):
             return False
-        if mode == "fused":
-            return True
-        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        auto = E16.autocast()          # bf16 / fp16 autocast: also makes that the kernels' element type
+        return True if mode == "fused" else auto
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         if inds is not None:
@@ -244,8 +245,7 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
-        if known is not None and known_feats.is_cuda and torch.is_autocast_enabled("cuda") and \
-                torch.get_autocast_dtype("cuda") == torch.bfloat16 and _rows_enabled():
+        if known is not None and known_feats.is_cuda and E16.autocast() and _rows_enabled():
             out = self._forward_rows(unknown, known, unknow_feats, known_feats)
             if out is not None:
                 return out

@@ -7,14 +7,14 @@ BatchNorm and ReLU on (B, C, K) tensors:
     voting       Conv1d+BN+ReLU x2, Conv1d(288->291)               models/voting_module.py:32-53
     FP layers    SharedMLP: Conv2d(1x1, no bias)+BN+ReLU x2        pointnet2/pointnet2_modules.py:356-416
 Here each stack is ONE autograd node over rows (points x channels, bf16): per layer a MFMA GEMM
-(`omnipq_gemm_nt_bf16[_bias]`), for BatchNorm layers the statistic / finalize / normalise+ReLU kernels of
+(`omnipq_gemm_nt_e16[_bias]`), for BatchNorm layers the statistic / finalize / normalise+ReLU kernels of
 csrc/sa_stage.hip, and in backward the matching `bn_bwd_*` kernels, the data-gradient GEMM and the
 split-K weight-gradient GEMM.  Training-mode BatchNorm semantics are the reference's (batch statistics,
 momentum update of the running estimates, SyncBatchNorm all-reduce of the sums under a process group).  A
 linear bias that feeds a BatchNorm is never added: the batch mean removes it again; only the running
 mean accounts for it (and its gradient is exactly zero).
 
-Used under `torch.autocast("cuda", dtype=torch.bfloat16)`; otherwise callers keep PyTorch's f32 layers.
+Used under `torch.autocast("cuda", dtype=torch.bfloat16)` (or float16: sa_fused.E16); otherwise callers keep PyTorch's f32 layers.
 """
 import ctypes
 import os
@@ -27,7 +27,7 @@ import sa_fused
 # ReLU + dropout of a `relu_dropout` layer inside its GEMM's epilogue (False: the separate in-place pass; the tests
 # compare the two)
 _FUSE_ACT = True
-from sa_fused import (_allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
+from sa_fused import (E16, _allreduce_, _call, _gemm_nt_bnbwd, _gemm_nt_stats, _gemm_tn, _lib, _p, _round_up, _world, affine_grads, prep_weight,
                       unprep_wgrad, zeros_f32, zeros_f64)
 
 
@@ -51,7 +51,7 @@ def usable(x, layers, training):
     """bf16 autocast on a GPU, training-mode BN (or no grad in eval), widths the kernels accept."""
     if not enabled():
         return False
-    if not x.is_cuda or not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.bfloat16:
+    if not x.is_cuda or not E16.autocast():
         return False
     for lay in layers:
         if lay.bn is not None:
@@ -149,13 +149,13 @@ def _forward_program(ctx, lead, x, spec, training, params):
             X = cached[1]
         else:
             if K == cin:
-                X = x.detach().to(torch.bfloat16).contiguous()
-            elif x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1:
-                X = torch.empty((N, K), device=x.device, dtype=torch.bfloat16)          # cast + zero padding in one launch
-                _call(_lib.omnipq_pad_rows_bf16, x, ctypes.c_longlong(N), cin, K, ctypes.c_longlong(x.stride(0)), _p(x),
+                X = x.detach().to(E16.dtype).contiguous()
+            elif x.dtype in (torch.float32, E16.dtype) and x.stride(1) == 1:
+                X = torch.empty((N, K), device=x.device, dtype=E16.dtype)          # cast + zero padding in one launch
+                _call(_lib.omnipq_pad_rows_e16, x, ctypes.c_longlong(N), cin, K, ctypes.c_longlong(x.stride(0)), _p(x),
                       int(x.dtype == torch.float32), _p(X))
             else:
-                X = torch.nn.functional.pad(x.detach().to(torch.bfloat16), (0, K - cin))
+                X = torch.nn.functional.pad(x.detach().to(E16.dtype), (0, K - cin))
             if X.data_ptr() != x.data_ptr() and not x.requires_grad:
                 try:
                     x.omnipq_rows_in = (x._version, X)    # inputs without gradient only: constants of the forward pass
@@ -187,7 +187,7 @@ def _forward_program(ctx, lead, x, spec, training, params):
                     Y = _gemm_nt_stats(X, lay.Wp, N, lay.Cp, K, sums)
                 yield
             else:
-                Y = torch.empty((N, lay.Cp), device=dev, dtype=torch.bfloat16)
+                Y = torch.empty((N, lay.Cp), device=dev, dtype=E16.dtype)
                 bp = None
                 if lay.has_bias and not lay.has_bn:
                     bp = bias.detach().float()                 # may come zero-padded already (cat_params(pad_to=))
@@ -200,7 +200,7 @@ def _forward_program(ctx, lead, x, spec, training, params):
                 elif lay.act is not None and _FUSE_ACT and K < 1024 and N * lay.Cp < (1 << 32):
                     # ReLU + dropout in the GEMM's epilogue (same decisions as omnipq_relu_dropout on the stored matrix)
                     _, p_act, seed_act, salt_act = lay.act
-                    _call(_lib.omnipq_gemm_nt_bf16_relu_dropout, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp,
+                    _call(_lib.omnipq_gemm_nt_e16_relu_dropout, X, N, lay.Cp, K, _p(X), K, _p(lay.Wp), K, _p(Y), lay.Cp,
                           _p(bp), ctypes.c_float(p_act), _p(seed_act), salt_act)
                     act_fused = True
                 else:
@@ -270,10 +270,10 @@ def _backward_program(ctx, lead, g, needs_input_grad):
         grads = [None] * (4 * L)
         last = layers[-1]
         if last.Cp == last.C or ctx.padded:
-            dcur = g.to(torch.bfloat16).contiguous()
+            dcur = g.to(E16.dtype).contiguous()
             owned = dcur.data_ptr() != g.data_ptr()        # autograd's buffer must not be modified in place
         else:
-            dcur = torch.zeros((N, last.Cp), device=dev, dtype=torch.bfloat16)
+            dcur = torch.zeros((N, last.Cp), device=dev, dtype=E16.dtype)
             dcur[:, :last.C] = g
             owned = True
         dx = None
@@ -327,11 +327,11 @@ def _backward_program(ctx, lead, g, needs_input_grad):
                 yield
                 dcur, owned = dprev, True
             elif l > 0 or needs_input_grad[0]:
-                dprev = torch.empty((N, lay.K), device=dev, dtype=torch.bfloat16)
+                dprev = torch.empty((N, lay.K), device=dev, dtype=E16.dtype)
                 _hold(lead)
                 if l > 0 and layers[l - 1].act is not None and _FUSE_ACT and lay.Cp < 1024:
                     # the layer below is dropout(relu(.)): its backward mask in this GEMM's epilogue
-                    _call(_lib.omnipq_gemm_nt_bf16_mask, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
+                    _call(_lib.omnipq_gemm_nt_e16_mask, dcur, N, lay.K, lay.Cp, _p(dcur), lay.Cp, _p(lay.Wt), lay.Cp,
                           _p(dprev), lay.K, _p(layers[l - 1].Y), ctypes.c_float(layers[l - 1].act[1]))
                     act_masked = l - 1
                 else:
@@ -353,10 +353,12 @@ def _backward_program(ctx, lead, g, needs_input_grad):
 class RowsMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, spec, training, *params):
+        ctx.e16 = E16.dtype
         return _drain(_forward_program(ctx, False, x, spec, training, params))
 
     @staticmethod
     def backward(ctx, g):
+        E16.select(ctx.e16)
         return _drain(_backward_program(ctx, False, g, ctx.needs_input_grad))
 
 
@@ -366,6 +368,7 @@ class RowsMLPPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, spec_a, xb, spec_b, training, n_a, *params):
+        ctx.e16 = E16.dtype
         ctx.a, ctx.b, ctx.n_a = _Ctx(), _Ctx(), n_a
         ctx.set_materialize_grads(False)            # a stack unused downstream gets None, not a zero gradient to push through
         ya, yb = _lockstep(_forward_program(ctx.a, True, xa, spec_a, training, params[:n_a]),
@@ -374,6 +377,7 @@ class RowsMLPPair(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ga, gb):
+        E16.select(ctx.e16)
         nig, n_a = ctx.needs_input_grad, ctx.n_a
         nig_a = (nig[0], False, False) + tuple(nig[6:6 + n_a])
         nig_b = (nig[2], False, False) + tuple(nig[6 + n_a:])

@@ -27,6 +27,7 @@ import pointnet2_utils
 
 _ext = pointnet2_utils._load_ext()      # always the product binding, whatever pointnet2_utils._ext is
 _lib = _ext._lib
+E16 = _ext.E16                         # the 16-bit element type the hand-written kernels run in (bfloat16 / float16)
 _lib.omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
 _lib.omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
 _lib.omnipq_gemm_nt_workspace_floats.restype = ctypes.c_longlong
@@ -113,8 +114,8 @@ def _round_up(x, q):
 
 def _gemm_nt(A, B, M, N, K):
     """bf16 C[M][N] = A[M][K] B[N][K]^T"""
-    C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
-    _call(_lib.omnipq_gemm_nt_bf16, A, M, N, K, _p(A), K, _p(B), K, _p(C), N)
+    C = torch.empty((M, N), device=A.device, dtype=E16.dtype)
+    _call(_lib.omnipq_gemm_nt_e16, A, M, N, K, _p(A), K, _p(B), K, _p(C), N)
     return C
 
 
@@ -123,21 +124,21 @@ def gemm_nt_into(A, B, C, M, N, K, bias=None):
     split-K workspace."""
     n_ws = int(_lib.omnipq_gemm_nt_workspace_floats(M, N, K))
     ws = torch.empty((n_ws,), device=A.device, dtype=torch.float32) if n_ws else None
-    _call(_lib.omnipq_gemm_nt_bf16_ws, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(ws))
+    _call(_lib.omnipq_gemm_nt_e16_ws, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(ws))
 
 
 def _gemm_nt_stats(A, B, M, N, K, sums, bias=None, pool=None):
     """bf16 C = A B^T and, in the same pass, sums (f64 [2][N], zero on entry) += column sum / sum of squares;
     pool = (S, ymax, ymin, amax, amin): also the extrema of every ball of S rows (csrc/gemm_bf16.hip: PoolOut)."""
-    C = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
+    C = torch.empty((M, N), device=A.device, dtype=E16.dtype)
     n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
     ws = torch.empty((n_ws,), device=A.device, dtype=torch.float32) if n_ws else None
     if pool is not None:
         S, ymax, ymin, amax, amin = pool
-        _call(_lib.omnipq_gemm_nt_bf16_stats_pool, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws),
+        _call(_lib.omnipq_gemm_nt_e16_stats_pool, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws),
               S, _p(ymax), _p(ymin), _p(amax), _p(amin))
         return C
-    _call(_lib.omnipq_gemm_nt_bf16_stats, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws))
+    _call(_lib.omnipq_gemm_nt_e16_stats, A, M, N, K, _p(A), K, _p(B), K, _p(C), N, _p(bias), _p(sums), _p(ws))
     return C
 
 
@@ -166,7 +167,7 @@ _FOLD_SMALL = True
 
 def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None):
     """bf16 C = relu(below.a * Y + below.b) Bw^T (+ bias); sums (f64 [2][N], zero on entry): also C's statistics."""
-    C = torch.empty((M, N), device=Y.device, dtype=torch.bfloat16) if out is None else out
+    C = torch.empty((M, N), device=Y.device, dtype=E16.dtype) if out is None else out
     ws = None
     if sums is not None:
         n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
@@ -179,18 +180,18 @@ def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=N
         below.fin = None
         if pool is not None:
             S, ymax, ymin, amax, amin = pool
-            _call(_lib.omnipq_gemm_nt_bf16_bnaffine_pool, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count),
+            _call(_lib.omnipq_gemm_nt_e16_bnaffine_pool, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count),
                   _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm), _p(rv), _p(cb), _p(below.a),
                   _p(below.b), _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(bias), _p(sums), _p(ws), S,
                   _p(ymax), _p(ymin), _p(amax), _p(amin))
             return C
-        _call(_lib.omnipq_gemm_nt_bf16_bnaffine, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count), _p(gamma),
+        _call(_lib.omnipq_gemm_nt_e16_bnaffine, Y, M, N, K, _p(Y), K, _p(fsums), ctypes.c_double(count), _p(gamma),
               _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm), _p(rv), _p(cb), _p(below.a), _p(below.b),
               _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(bias), _p(sums), _p(ws))
         return C
     if pool is not None:
         raise RuntimeError("gemm_nt_affine: ball extrema need the layer below to be finalised in the prologue")
-    _call(_lib.omnipq_gemm_nt_bf16_affine, Y, M, N, K, _p(Y), K, _p(below.a), _p(below.b), _p(Bw), K, _p(C), N,
+    _call(_lib.omnipq_gemm_nt_e16_affine, Y, M, N, K, _p(Y), K, _p(below.a), _p(below.b), _p(Bw), K, _p(C), N,
           _p(bias), _p(sums), _p(ws))
     return C
 
@@ -213,11 +214,11 @@ def xyzgen_ok(P, L, c0, needs_input_grad):
 
 def gemm_nt_xyz(X0c, below, Bw, M, N, K, sums):
     """bf16 C = relu(bn(X0c W0^T)) Bw^T + its statistics: `below` is the never-materialised first layer (Wp, fin)."""
-    C = torch.empty((M, N), device=X0c.device, dtype=torch.bfloat16)
+    C = torch.empty((M, N), device=X0c.device, dtype=E16.dtype)
     ws = torch.empty((int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N)),), device=X0c.device, dtype=torch.float32)
     fsums, count, gamma, beta, eps, momentum, rm, rv, _ = below.fin
     below.fin = None
-    _call(_lib.omnipq_gemm_nt_bf16_xyz_bnaffine, X0c, M, N, K, _p(X0c), X0c.shape[1], _p(below.Wp), below.Wp.shape[1],
+    _call(_lib.omnipq_gemm_nt_e16_xyz_bnaffine, X0c, M, N, K, _p(X0c), X0c.shape[1], _p(below.Wp), below.Wp.shape[1],
           _p(fsums), ctypes.c_double(count), _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm),
           _p(rv), _p(below.a), _p(below.b), _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(sums), _p(ws))
     return C
@@ -226,10 +227,10 @@ def gemm_nt_xyz(X0c, below, Bw, M, N, K, sums):
 def _gemm_nt_bnbwd(dY, Wt, M, N, K, below, sums):
     """dX = dY Wt^T (bf16 [M][N]) and, in the same pass, the BatchNorm-backward sums of the layer `below`
     (its pre-BN output Y and constants a, b, mean, invstd) into sums (f64 [>=2][N], zero on entry)."""
-    C = torch.empty((M, N), device=dY.device, dtype=torch.bfloat16)
+    C = torch.empty((M, N), device=dY.device, dtype=E16.dtype)
     n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
     ws = torch.empty((n_ws,), device=dY.device, dtype=torch.float32) if n_ws else None
-    _call(_lib.omnipq_gemm_nt_bf16_bnbwd, dY, M, N, K, _p(dY), K, _p(Wt), K, _p(C), N, _p(below.Y), _p(below.a),
+    _call(_lib.omnipq_gemm_nt_e16_bnbwd, dY, M, N, K, _p(dY), K, _p(Wt), K, _p(C), N, _p(below.Y), _p(below.a),
           _p(below.b), _p(below.mean), _p(below.invstd), _p(sums), _p(ws))
     return C
 
@@ -240,12 +241,12 @@ def _gemm_tn(A, B, M, N, P, colsum=None, below=None):
     C = torch.empty((M, N), device=A.device, dtype=torch.float32)
     ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(M, N, P)),), device=A.device, dtype=torch.float32)
     if below is not None:
-        _call(_lib.omnipq_gemm_tn_bf16_affine, A, M, N, P, _p(A), M, _p(B), N, _p(below.a), _p(below.b), _p(C), _p(ws),
+        _call(_lib.omnipq_gemm_tn_e16_affine, A, M, N, P, _p(A), M, _p(B), N, _p(below.a), _p(below.b), _p(C), _p(ws),
               _p(colsum))
     elif colsum is None:
-        _call(_lib.omnipq_gemm_tn_bf16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
+        _call(_lib.omnipq_gemm_tn_e16, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws))
     else:
-        _call(_lib.omnipq_gemm_tn_bf16_colsum, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws), _p(colsum))
+        _call(_lib.omnipq_gemm_tn_e16_colsum, A, M, N, P, _p(A), M, _p(B), N, _p(C), _p(ws), _p(colsum))
     return C
 
 
@@ -291,6 +292,7 @@ class _JointRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, joint, *parts):
+        ctx.e16 = E16.dtype
         ctx.meta = [(p.shape, p.shape[0]) for p in parts]
         # inside deferred_wgrads the consumer returns no gradient for the joint matrix: an undefined gradient must stay
         # undefined (the default would hand this node a zero tensor, and every parameter a zero .grad to be added to later)
@@ -299,6 +301,7 @@ class _JointRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        E16.select(ctx.e16)
         if g is None:
             return (None,) * (1 + len(ctx.meta))
         out, r = [], 0
@@ -582,11 +585,13 @@ class WgradFlushPoint(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, stream_of):
+        ctx.e16 = E16.dtype
         ctx.stream_of = stream_of
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
+        E16.select(ctx.e16)
         dfr = deferred_wgrads.active
         if dfr is not None and g.is_cuda:
             st = ctx.stream_of()
@@ -681,8 +686,8 @@ class WeightArena:
                  for r0 in range(0, cp, 64) for c0 in range(0, k, 64)]
         self.tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4).to(device)
         self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
-        self.wp = torch.empty(off, device=device, dtype=torch.bfloat16)
-        self.wt = torch.empty(off, device=device, dtype=torch.bfloat16)
+        self.wp = torch.empty(off, device=device, dtype=E16.dtype)
+        self.wt = torch.empty(off, device=device, dtype=E16.dtype)
         self.views = []
         off = 0
         for (_, _, _, _, cp, k, _) in self.entries:
@@ -716,6 +721,8 @@ class _ArenaStep:
         self.outer = _ARENA
         if torch.device(self.device).type != "cuda":
             return self
+        if a.built and a.wp.dtype != E16.dtype:
+            a.built = 0                        # the element type changed since the arenas were laid out
         if len(a.entries) != a.built and not torch.cuda.is_current_stream_capturing():
             a._build(self.device)              # table upload: never inside a capture
         if a.built:
@@ -764,8 +771,8 @@ def prep_weight(W2, cp, k, rot=0, transpose=True, persistent=False):
             return got
         _ARENA.record(W2, cp, k, rot)
     cout, cin = W2.shape
-    Wp = torch.empty((cp, k), device=W2.device, dtype=torch.bfloat16)
-    Wt = torch.empty((k, cp), device=W2.device, dtype=torch.bfloat16) if transpose else None
+    Wp = torch.empty((cp, k), device=W2.device, dtype=E16.dtype)
+    Wt = torch.empty((k, cp), device=W2.device, dtype=E16.dtype) if transpose else None
     _call(_lib.omnipq_prep_weight, W2, cout, cin, W2.stride(0), cp, k, rot, _p(W2), _p(Wp), _p(Wt))
     return Wp, Wt
 
@@ -809,7 +816,7 @@ def rows16_of(t, shape):
     """The position-major bf16 twin a producer attached to `t` (attribute `omnipq_rows16`: the same values as
     (B, n, C) bf16 data), if it is there and matches."""
     twin = getattr(t, "omnipq_rows16", None) if t is not None else None
-    if twin is None or tuple(twin.shape) != tuple(shape) or twin.dtype != torch.bfloat16 or not twin.is_contiguous():
+    if twin is None or tuple(twin.shape) != tuple(shape) or twin.dtype != E16.dtype or not twin.is_contiguous():
         return None
     return twin
 
@@ -828,6 +835,7 @@ class FusedSAStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training, bn_cfg, *params):
+        ctx.e16 = E16.dtype
         ctx.n_inputs = 9 + len(params)
         with _tagged("@sa"):
             return FusedSAStage._forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training,
@@ -850,7 +858,7 @@ class FusedSAStage(torch.autograd.Function):
             feat_pm = None
         elif feat_pm is None or cin != cin_raw:
             # position-major bf16 copy [B][N][cin] (a producer that has one passes it in: see run())
-            feat_pm = features.detach().transpose(1, 2).to(torch.bfloat16)
+            feat_pm = features.detach().transpose(1, 2).to(E16.dtype)
             feat_pm = torch.nn.functional.pad(feat_pm, (0, cin - cin_raw)) if cin != cin_raw else feat_pm.contiguous()
         xyz_c = xyz.detach().contiguous()
         cen_c = new_xyz.detach().contiguous()
@@ -861,7 +869,7 @@ class FusedSAStage(torch.autograd.Function):
         if xgen:
             global xyzgen_uses
             xyzgen_uses += 1
-        X = torch.empty((P, xpad), device=dev, dtype=torch.bfloat16)
+        X = torch.empty((P, xpad), device=dev, dtype=E16.dtype)
         _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, xpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
               _p(idx), _p(feat_pm), _p(X))
 
@@ -889,7 +897,7 @@ class FusedSAStage(torch.autograd.Function):
                 pool = None
                 if l == L - 1 and POOL_EPILOGUE and 128 % S == 0 and (X is not None or layers[l - 1].fin is not None):
                     # the last layer's GEMM also records every ball's extrema: the pooling pass below needs no Y
-                    ext16 = torch.empty((2, B * M, cout), device=dev, dtype=torch.bfloat16)
+                    ext16 = torch.empty((2, B * M, cout), device=dev, dtype=E16.dtype)
                     ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
                     pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
                 if xgen and l == 0:
@@ -950,11 +958,11 @@ class FusedSAStage(torch.autograd.Function):
 
         last = layers[-1]
         out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
-        out_pm = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+        out_pm = torch.empty((B * M, last.C), device=dev, dtype=E16.dtype)
         arg = torch.empty((B * M, last.C), device=dev, dtype=torch.uint8)
         ysel = None
         if training and pool is not None:
-            ysel = torch.empty((B * M, last.C), device=dev, dtype=torch.bfloat16)
+            ysel = torch.empty((B * M, last.C), device=dev, dtype=E16.dtype)
             if last.fin is not None:
                 fsums, count, pg, pb, peps, pmom, prm, prv, _ = last.fin
                 last.fin = None
@@ -990,6 +998,7 @@ class FusedSAStage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_twin=None):
+        E16.select(ctx.e16)
         if g_out is None:                       # the stage's output took no part in the loss
             return (None,) * ctx.n_inputs
         with _tagged("@sa"):
@@ -1046,13 +1055,13 @@ class FusedSAStage(torch.autograd.Function):
                 dWp = torch.empty((lay.C, lay.K), device=dev, dtype=torch.float32)
                 ws = torch.empty((int(_lib.omnipq_gemm_tn_workspace_floats(lay.C, lay.K, P)),), device=dev,
                                  dtype=torch.float32)
-                _call(_lib.omnipq_gemm_tn_bf16_xyz_affine, dY, lay.C, lay.K, P, _p(dY), lay.C, _p(X0c), X0c.shape[1],
+                _call(_lib.omnipq_gemm_tn_e16_xyz_affine, dY, lay.C, lay.K, P, _p(dY), lay.C, _p(X0c), X0c.shape[1],
                       _p(prev.Wp), prev.Wp.shape[1], _p(prev.a), _p(prev.b), _p(dWp), _p(ws))
                 grads[3] = unprep_wgrad(dWp, lay.C, lay.K, 0, (lay.C, lay.K, 1, 1))
                 sums5 = zeros_f64(5, prev.C, dev)
                 ws5 = torch.empty((int(_lib.omnipq_gemm_nt_xyz_workspace_floats(P, prev.C)),), device=dev,
                                   dtype=torch.float32)
-                _call(_lib.omnipq_gemm_nt_bf16_xyz_bnbwd, dY, P, prev.C, lay.C, _p(dY), lay.C, _p(lay.Wt), lay.C, _p(X0c),
+                _call(_lib.omnipq_gemm_nt_e16_xyz_bnbwd, dY, P, prev.C, lay.C, _p(dY), lay.C, _p(lay.Wt), lay.C, _p(X0c),
                       X0c.shape[1], _p(prev.Wp), prev.Wp.shape[1], _p(prev.a), _p(prev.b), _p(prev.mean), _p(prev.invstd),
                       _p(sums5), _p(ws5))
                 grads[1], grads[2] = affine_grads(sums5, prev.C)            # this rank's dgamma / dbeta
@@ -1179,10 +1188,11 @@ class FPGatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, known_feats, known_pm, skip_feats, skip_pm, idx, weight):
+        ctx.e16 = E16.dtype
         B, n = idx.shape[0], idx.shape[1]
         m, C2 = known_pm.shape[1], known_pm.shape[2]
         C1 = 0 if skip_pm is None else skip_pm.shape[2]
-        rows = torch.empty((B * n, C2 + C1), device=idx.device, dtype=torch.bfloat16)
+        rows = torch.empty((B * n, C2 + C1), device=idx.device, dtype=E16.dtype)
         _call(_lib.omnipq_interp_rows, rows, B, n, m, C2, _p(known_pm), _p(idx), _p(weight), _p(rows), C2 + C1, 0)
         if C1:
             _call(_lib.omnipq_place_rows, rows, ctypes.c_longlong(B * n), C1, _p(skip_pm), _p(rows), C2 + C1, C2)
@@ -1192,9 +1202,10 @@ class FPGatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        E16.select(ctx.e16)
         idx, weight = ctx.saved_tensors
         B, n, m, C2, C1, kdt, sdt = ctx.geom
-        g = g.to(torch.bfloat16).contiguous()
+        g = g.to(E16.dtype).contiguous()
         d_known = d_skip = None
         if ctx.needs_input_grad[0]:
             # bucket the (unknown point, slot) pairs by the known point they read, then sum bucket-wise: no atomics

@@ -30,6 +30,17 @@ def pytest_configure(config):
         pass
 
 
+@pytest.fixture(autouse=True)
+def _default_element_type():
+    """Every test starts with the hand-written kernels' element type at its default (bfloat16): the selector is module
+    state that follows the last torch.autocast dtype seen (pointnet2/_ext.py: E16)."""
+    ext = sys.modules.get("pointnet2._ext")
+    if ext is not None:
+        import torch
+        ext.E16.dtype = torch.bfloat16
+    yield
+
+
 @pytest.fixture(scope="session")
 def built_lib():
     """libomnipq_pointops.so, (re)built with hipcc if stale (cross-compiles without a GPU)."""

@@ -4,17 +4,44 @@ import ctypes
 import capi
 
 
-def test_library_exports_every_declared_symbol(built_lib):
+def both(built_lib):
+    """the bfloat16 library and its IEEE-half twin (same sources, -DOMNIPQ_ELEM_F16: omni-pq_amd/build.py)"""
+    return [built_lib, built_lib[:-3] + "_f16.so"]
+
+
+def test_libraries_export_every_declared_symbol(built_lib):
     syms = capi.declared_symbols()
     assert len(syms) >= 25 and "omnipq_furthest_point_sampling" in syms and "omnipq_sa_gather" in syms
-    lib = ctypes.CDLL(built_lib)
-    missing = [s for s in syms if not hasattr(lib, s)]
-    assert not missing, missing
+    assert "omnipq_gemm_nt_e16_stats" in syms
+    for path in both(built_lib):
+        lib = ctypes.CDLL(path)
+        missing = [s for s in syms if not hasattr(lib, s)]
+        assert not missing, (path, missing)
 
 
-def test_library_has_gfx950_code_object(built_lib):
-    blob = open(built_lib, "rb").read()
-    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+def test_libraries_have_gfx950_code_objects_with_their_mfma_opcode(built_lib, tmp_path):
+    """Both libraries carry gfx950 code objects, and each one's matrix instructions are those of ITS element type only
+    (disassembly of the bundled code objects: llvm-objdump --offloading extracts them next to its input)."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    for path, opcode, other in zip(both(built_lib), ("v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16"),
+                                   ("v_mfma_f32_32x32x16_f16", "v_mfma_f32_32x32x16_bf16")):
+        blob = open(path, "rb").read()
+        assert b"amdgcn-amd-amdhsa--gfx950" in blob
+        if not os.path.exists(objdump):
+            continue
+        work = tmp_path / os.path.basename(path)
+        work.mkdir()
+        shutil.copy(path, work)
+        subprocess.run([objdump, "--offloading", os.path.basename(path)], cwd=work, capture_output=True)
+        asm = "".join(subprocess.run([objdump, "-d", f], capture_output=True, text=True).stdout
+                      for f in glob.glob(str(work / "*gfx950")))
+        if "v_mfma" not in asm:
+            continue                                  # this objdump could not open the bundles: nothing to check
+        assert asm.count(opcode) >= 100 and other not in asm, (path, asm.count(opcode), asm.count(other))
 
 
 def test_host_helpers_without_gpu(built_lib):
@@ -47,9 +74,9 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert lib.omnipq_attn_fwd(8, 8, 256, 256, 36, p, p, p, p, strides, p, f(0.1), null, 0, null) == EINVAL   # no seed
     assert lib.omnipq_attn_fwd(64, 16, 4096, 4096, 36, p, p, p, p, strides, p, f(0.0), null, 0, null) == ETOOLARGE
     # GEMMs: contraction length must be a multiple of the K step, leading dimensions of 8
-    assert lib.omnipq_gemm_nt_bf16(128, 128, 33, p, 40, p, 40, p, 128, null) == EINVAL
-    assert lib.omnipq_gemm_nt_bf16_stats(128, 128, 32, p, 32, p, 32, p, 128, null, null, null, null) == EINVAL  # no sums
-    assert lib.omnipq_gemm_tn_bf16(100, 128, 64, p, 100, p, 128, p, p, null) == EINVAL                          # M % 8
+    assert lib.omnipq_gemm_nt_e16(128, 128, 33, p, 40, p, 40, p, 128, null) == EINVAL
+    assert lib.omnipq_gemm_nt_e16_stats(128, 128, 32, p, 32, p, 32, p, 128, null, null, null, null) == EINVAL  # no sums
+    assert lib.omnipq_gemm_tn_e16(100, 128, 64, p, 100, p, 128, p, p, null) == EINVAL                          # M % 8
     lib.omnipq_gemm_nt_stats_workspace_floats.restype = ll
     assert lib.omnipq_gemm_nt_stats_workspace_floats(64 * 128, 256) == 0
     assert lib.omnipq_gemm_nt_stats_workspace_floats(64 * 128 + 1, 256) == 65 * 2 * 256
@@ -68,6 +95,6 @@ def test_argument_validation_needs_no_gpu(built_lib):
     flags = (ctypes.c_int * 73)()
     assert lib.omnipq_sum_of_means(73, ptrs, ones, ones, flags, p, null) == EINVAL
     # zero-sized problems are no-ops that succeed without a device
-    assert lib.omnipq_gemm_nt_bf16(0, 128, 32, p, 32, p, 32, p, 128, null) == 0
+    assert lib.omnipq_gemm_nt_e16(0, 128, 32, p, 32, p, 32, p, 128, null) == 0
     assert lib.omnipq_interp_rows(0, 10, 5, 64, p, p, p, p, 64, 0, null) == 0
     assert lib.omnipq_relu_dropout(ll(0), p, f(0.0), null, 0, null) == 0

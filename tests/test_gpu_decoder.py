@@ -670,7 +670,7 @@ def test_split_rows_and_its_merged_gradient(B, P, p0, C):
 
 @pytest.mark.parametrize("M,N,K,p,bias", [(4096, 2048, 288, 0.1, True), (300, 96, 64, 0.5, False), (2048, 288, 288, 0.0, True)])
 def test_gemm_with_relu_dropout_epilogue_equals_gemm_then_relu_dropout(M, N, K, p, bias):
-    """omnipq_gemm_nt_bf16_relu_dropout against omnipq_gemm_nt_bf16_bias followed by omnipq_relu_dropout with the same seed
+    """omnipq_gemm_nt_e16_relu_dropout against omnipq_gemm_nt_e16_bias followed by omnipq_relu_dropout with the same seed
     and salt: the same units survive (the decisions hash the element index, whichever kernel asks) and the values agree
     to one bf16 rounding (the epilogue scales the f32 accumulator and rounds once, the two-pass route rounds twice)."""
     import ctypes
@@ -682,10 +682,10 @@ def test_gemm_with_relu_dropout_epilogue_equals_gemm_then_relu_dropout(M, N, K, 
     seed = torch.tensor([0x1234567890ABCDEF], dtype=torch.int64, device=dev())
     null = ctypes.c_void_p(0)
     want = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(want), N, capi.P(bvec) if bias else null)
+    capi.ok("omnipq_gemm_nt_e16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(want), N, capi.P(bvec) if bias else null)
     capi.ok("omnipq_relu_dropout", ctypes.c_longlong(M * N), capi.P(want), ctypes.c_float(p), capi.P(seed) if p > 0 else null, 7)
     got = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16_relu_dropout", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(got), N,
+    capi.ok("omnipq_gemm_nt_e16_relu_dropout", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(got), N,
             capi.P(bvec) if bias else null, ctypes.c_float(p), capi.P(seed) if p > 0 else null, 7)
     assert torch.equal(got == 0, want == 0)
     assert float((got.float() - want.float()).abs().max()) <= 2.0 ** -7 * float(want.float().abs().max())
@@ -697,7 +697,7 @@ def test_gemm_with_relu_dropout_epilogue_equals_gemm_then_relu_dropout(M, N, K, 
 
 @pytest.mark.parametrize("M,N,K,p", [(4096, 2048, 288, 0.1), (300, 96, 64, 0.5), (2048, 320, 288, 0.0)])
 def test_masked_data_gradient_gemm_equals_gemm_then_relu_dropout_bwd(M, N, K, p):
-    """omnipq_gemm_nt_bf16_mask == omnipq_gemm_nt_bf16 followed by omnipq_relu_dropout_bwd, bit for bit."""
+    """omnipq_gemm_nt_e16_mask == omnipq_gemm_nt_e16 followed by omnipq_relu_dropout_bwd, bit for bit."""
     import ctypes
     import capi
     gen = torch.Generator().manual_seed(M + K)
@@ -705,10 +705,10 @@ def test_masked_data_gradient_gemm_equals_gemm_then_relu_dropout_bwd(M, N, K, p)
     B = (torch.randn(N, K, generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev())
     H = torch.randn(M, N, generator=gen).clamp_min(0).to(torch.bfloat16).to(dev())         # about half of it zero
     prod = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(prod), N)
+    capi.ok("omnipq_gemm_nt_e16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(prod), N)
     want = torch.empty_like(prod)
     capi.ok("omnipq_relu_dropout_bwd", ctypes.c_longlong(M * N), capi.P(H), capi.P(prod), capi.P(want), ctypes.c_float(p))
     got = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16_mask", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(got), N, capi.P(H), ctypes.c_float(p))
+    capi.ok("omnipq_gemm_nt_e16_mask", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(got), N, capi.P(H), ctypes.c_float(p))
     assert torch.equal(got, want)
     assert 0.3 < float((got == 0).float().mean()) < 0.7

@@ -35,7 +35,7 @@ def test_gemm_nt_matches_torch(M, N, K):
     A = torch.randn((M, K), generator=gen).to(torch.bfloat16).to(dev())
     B = torch.randn((N, K), generator=gen).to(torch.bfloat16).to(dev())     # asymmetric, random
     C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N)
+    capi.ok("omnipq_gemm_nt_e16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N)
     want = A.float() @ B.float().t()
     assert torch.isfinite(C.float()).all()
     # bf16 output rounding: half a step of 2^-8 relative to each element, plus f32 accumulation noise
@@ -57,7 +57,7 @@ def test_gemm_nt_split_k_matches_single_pass(M, N, K, bias):
     assert (n_ws > 0) == (K >= 1024)
     ws = torch.empty(max(n_ws, 1), device=dev())
     C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16_ws", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N,
+    capi.ok("omnipq_gemm_nt_e16_ws", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N,
             capi.P(bvec) if bias else ctypes.c_void_p(0), capi.P(ws))
     want = A.float() @ B.float().t() + (bvec if bias else 0.0)
     assert torch.isfinite(C.float()).all()
@@ -76,16 +76,16 @@ def test_gemm_nt_stats_epilogue(M, N, K, bias):
     bvec = torch.randn(N, generator=gen).to(dev()) if bias else None
     C0 = torch.empty((M, N), device=dev(), dtype=torch.bfloat16)
     if bias:
-        capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C0), N, capi.P(bvec))
+        capi.ok("omnipq_gemm_nt_e16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C0), N, capi.P(bvec))
     else:
-        capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C0), N)
+        capi.ok("omnipq_gemm_nt_e16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C0), N)
     C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
     sums = torch.ones((2, N), device=dev(), dtype=torch.float64)
     capi.lib().omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
     n_ws = int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N))
     assert (n_ws == 0) == (M <= 64 * 128)
     ws = torch.empty(max(n_ws, 1), device=dev())
-    capi.ok("omnipq_gemm_nt_bf16_stats", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N,
+    capi.ok("omnipq_gemm_nt_e16_stats", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N,
             capi.P(bvec) if bias else ctypes.c_void_p(0), capi.P(sums), capi.P(ws))
     assert torch.equal(C, C0)
     y = C.double()
@@ -115,10 +115,10 @@ def test_pair_launch_equals_two_launches(M0, M1, N0, N1, K):
         C = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
         sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
         if stats:
-            capi.ok("omnipq_gemm_nt_bf16_stats", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N, capi.P(bias),
+            capi.ok("omnipq_gemm_nt_e16_stats", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N, capi.P(bias),
                     capi.P(sums), ctypes.c_void_p(0))
         else:
-            capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N, capi.P(bias))
+            capi.ok("omnipq_gemm_nt_e16_bias", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N, capi.P(bias))
         return C, sums
 
     p0, p1 = problem(M0, N0), problem(M1, N1)
@@ -158,7 +158,7 @@ def test_gemm_nt_bn_backward_epilogue(M, N, K):
     mean = (0.1 * torch.randn(N, generator=gen)).to(dev())
     invstd = (0.5 + torch.rand(N, generator=gen)).to(dev())
     dX0 = torch.empty((M, N), device=dev(), dtype=torch.bfloat16)
-    capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(dY), K, capi.P(Wt), K, capi.P(dX0), N)
+    capi.ok("omnipq_gemm_nt_e16", M, N, K, capi.P(dY), K, capi.P(Wt), K, capi.P(dX0), N)
     want = torch.zeros((2, N), device=dev(), dtype=torch.float64)
     capi.ok("omnipq_bn_bwd_stats", ctypes.c_longlong(M), N, capi.P(dX0), capi.P(Y), capi.P(a), capi.P(b),
             capi.P(mean), capi.P(invstd), capi.P(want))
@@ -166,7 +166,7 @@ def test_gemm_nt_bn_backward_epilogue(M, N, K):
     sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
     capi.lib().omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
     ws = torch.empty(max(int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N)), 1), device=dev())
-    capi.ok("omnipq_gemm_nt_bf16_bnbwd", M, N, K, capi.P(dY), K, capi.P(Wt), K, capi.P(dX), N, capi.P(Y), capi.P(a),
+    capi.ok("omnipq_gemm_nt_e16_bnbwd", M, N, K, capi.P(dY), K, capi.P(Wt), K, capi.P(dX), N, capi.P(Y), capi.P(a),
             capi.P(b), capi.P(mean), capi.P(invstd), capi.P(sums), capi.P(ws))
     assert torch.equal(dX, dX0)
     scale = want.abs().max(dim=1, keepdim=True).values + 1e-3          # f32 partial sums, different order
@@ -182,13 +182,13 @@ def test_gemm_tn_matches_torch(P, M, N):
     C = torch.full((M, N), float("nan"), device=dev())
     capi.lib().omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
     ws = torch.empty(int(capi.lib().omnipq_gemm_tn_workspace_floats(M, N, P)), device=dev())
-    capi.ok("omnipq_gemm_tn_bf16", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C), capi.P(ws))
+    capi.ok("omnipq_gemm_tn_e16", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C), capi.P(ws))
     want = A.float().t() @ B.float()
     assert rel_l2(C, want) < 1e-5          # exact bf16 products, f32 accumulation: only summation order differs
     # the variant that also returns the column sums of A (bias gradient), added to what is there
     C2 = torch.full((M, N), float("nan"), device=dev())
     cs = torch.ones(M, device=dev())
-    capi.ok("omnipq_gemm_tn_bf16_colsum", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C2), capi.P(ws), capi.P(cs))
+    capi.ok("omnipq_gemm_tn_e16_colsum", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C2), capi.P(ws), capi.P(cs))
     assert rel_l2(C2, want) < 1e-5
     tot = A.double().sum(0) + 1.0
     assert float((cs.double() - tot).abs().max()) < 1e-4 * (1 + float(tot.abs().max()))
@@ -273,7 +273,7 @@ def test_first_layer_generated_from_coordinates_matches_f32_composition(monkeypa
         assert gen[k] < max(1.5 * stored[k], 2e-2), (k, gen[k], stored[k])
 
 
-def _fused_vs_f32(spec, n, cin, B, monkeypatch, xyz_grad=True):
+def _fused_vs_f32(spec, n, cin, B, monkeypatch, xyz_grad=True, dtype=torch.bfloat16, g_scale=1.0):
     xyz = synth.make_clouds(41, B, n, kind="room").to(dev())
     feats = None
     if cin:
@@ -291,15 +291,18 @@ def _fused_vs_f32(spec, n, cin, B, monkeypatch, xyz_grad=True):
 
     monkeypatch.setenv("OMNIPQ_SA", "composed")
     w_new_xyz, w_out, w_inds = ref_mod(want_xyz, want_f)               # f32 op-by-op: the yardstick
-    with torch.autocast("cuda", dtype=torch.bfloat16):                  # PyTorch's own bf16 path
+    with torch.autocast("cuda", dtype=dtype):                           # PyTorch's own 16-bit autocast path
         _, a_out, _ = amp_mod(amp_xyz, amp_f)
     monkeypatch.setenv("OMNIPQ_SA", "fused")
-    g_new_xyz, g_out, g_inds = fus_mod(got_xyz, got_f)
+    with torch.autocast("cuda", dtype=dtype):
+        g_new_xyz, g_out, g_inds = fus_mod(got_xyz, got_f)
+    import sa_fused
+    assert sa_fused.E16.dtype == dtype and g_out.omnipq_rows16.dtype == dtype
     assert torch.equal(w_inds, g_inds) and torch.equal(w_new_xyz, g_new_xyz)
     assert g_out.dtype == torch.float32 and g_out.shape == w_out.shape
     assert rel_l2(g_out, w_out) < 2e-2, rel_l2(g_out, w_out)
 
-    g_up = procedural_tensor("fused.g_up", tuple(w_out.shape), torch.float32).to(dev())
+    g_up = procedural_tensor("fused.g_up", tuple(w_out.shape), torch.float32).to(dev()) * g_scale
     w_out.backward(g_up)
     g_out.backward(g_up)
     a_out.float().backward(g_up)
@@ -344,17 +347,20 @@ def test_fused_sa_eval_mode_uses_running_statistics(monkeypatch):
     assert rel_l2(g_out, w_out) < 2e-2
 
 
-def test_fused_stage_is_selected_under_bf16_autocast_only(monkeypatch):
+def test_fused_stage_is_selected_under_16_bit_autocast_only(monkeypatch):
     import pointnet2_modules
     monkeypatch.delenv("OMNIPQ_SA", raising=False)
     spec, n, cin = SA_SPECS[0]
     mod = pointnet2_modules.PointnetSAModuleVotes(mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}).to(dev())
     xyz = synth.make_clouds(44, 1, n, kind="room").to(dev())
     assert not mod._fused(xyz, None)
+    import sa_fused
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        assert mod._fused(xyz, None)
-    with torch.autocast("cuda", dtype=torch.float16):
-        assert not mod._fused(xyz, None)
+        assert mod._fused(xyz, None) and sa_fused.E16.dtype == torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.float16):                     # the IEEE-half library (BASELINE configs[4])
+        assert mod._fused(xyz, None) and sa_fused.E16.dtype == torch.float16
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert mod._fused(xyz, None) and sa_fused.E16.dtype == torch.bfloat16
 
 
 def test_graph_replay_reproduces_the_eager_step():
@@ -634,14 +640,14 @@ def test_gemm_nt_affine_operand_equals_the_materialised_activations(M, N, K, sta
     ws = torch.empty(max(int(capi.lib().omnipq_gemm_nt_stats_workspace_floats(M, N)), 1), device=dev())
     want_sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
     if stats:
-        capi.ok("omnipq_gemm_nt_bf16_stats", M, N, K, capi.P(X), K, capi.P(W), K, capi.P(want), N,
+        capi.ok("omnipq_gemm_nt_e16_stats", M, N, K, capi.P(X), K, capi.P(W), K, capi.P(want), N,
                 capi.P(bvec) if bias else null, capi.P(want_sums), capi.P(ws))
     else:
-        capi.ok("omnipq_gemm_nt_bf16_bias", M, N, K, capi.P(X), K, capi.P(W), K, capi.P(want), N,
+        capi.ok("omnipq_gemm_nt_e16_bias", M, N, K, capi.P(X), K, capi.P(W), K, capi.P(want), N,
                 capi.P(bvec) if bias else null)
     got = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
     sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
-    capi.ok("omnipq_gemm_nt_bf16_affine", M, N, K, capi.P(Y), K, capi.P(a), capi.P(b), capi.P(W), K, capi.P(got), N,
+    capi.ok("omnipq_gemm_nt_e16_affine", M, N, K, capi.P(Y), K, capi.P(a), capi.P(b), capi.P(W), K, capi.P(got), N,
             capi.P(bvec) if bias else null, capi.P(sums) if stats else null, capi.P(ws))
     assert torch.equal(got, want)
     if stats:
@@ -665,10 +671,10 @@ def test_gemm_tn_affine_operand_equals_the_materialised_activations(P, M, N, col
     capi.lib().omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
     ws = torch.empty(int(capi.lib().omnipq_gemm_tn_workspace_floats(M, N, P)), device=dev())
     want = torch.empty((M, N), device=dev())
-    capi.ok("omnipq_gemm_tn_bf16", M, N, P, capi.P(dY), M, capi.P(X), N, capi.P(want), capi.P(ws))
+    capi.ok("omnipq_gemm_tn_e16", M, N, P, capi.P(dY), M, capi.P(X), N, capi.P(want), capi.P(ws))
     got = torch.full((M, N), float("nan"), device=dev())
     cs = torch.zeros(M, device=dev()) if colsum else None
-    capi.ok("omnipq_gemm_tn_bf16_affine", M, N, P, capi.P(dY), M, capi.P(Y), N, capi.P(a), capi.P(b), capi.P(got),
+    capi.ok("omnipq_gemm_tn_e16_affine", M, N, P, capi.P(dY), M, capi.P(Y), N, capi.P(a), capi.P(b), capi.P(got),
             capi.P(ws), capi.P(cs) if colsum else ctypes.c_void_p(0))
     assert torch.equal(got, want)
     ref = dY.double().t() @ X.double()
@@ -783,7 +789,7 @@ def test_ball_extrema_epilogue_and_pool_select_equal_the_pooling_pass(M, N, K, S
     sums = torch.zeros((2, N), device=dev(), dtype=torch.float64)
     ext16 = torch.full((2, BM, N), float("nan"), device=dev(), dtype=torch.bfloat16)
     ext8 = torch.full((2, BM, N), 255, device=dev(), dtype=torch.uint8)
-    capi.ok("omnipq_gemm_nt_bf16_stats_pool", M, N, K, capi.P(A), K, capi.P(W), K, capi.P(Y), N, null, capi.P(sums),
+    capi.ok("omnipq_gemm_nt_e16_stats_pool", M, N, K, capi.P(A), K, capi.P(W), K, capi.P(Y), N, null, capi.P(sums),
             capi.P(ws), S, capi.P(ext16[0]), capi.P(ext16[1]), capi.P(ext8[0]), capi.P(ext8[1]))
     Yb = Y.float().view(BM, S, N)
     assert torch.equal(ext16[0].float(), Yb.max(1).values) and torch.equal(ext16[1].float(), Yb.min(1).values)

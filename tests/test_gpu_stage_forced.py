@@ -44,7 +44,7 @@ def upstream(name, t):
 def run_forced(fx, mode):
     """-> (own stage outputs, end_points, parameter gradients) of this repo's model with the fixture's tensors forced at
     the reference's stage boundaries.  mode: 'bf16' (the benchmarked path), 'autocast' (torch's bf16 autocast over the
-    op-by-op composition) or 'f32'."""
+    op-by-op composition), 'fp16' (the IEEE-half library under fp16 autocast, upstream gradients x 2^10) or 'f32'."""
     import sa_fused
     from test_oracle_golden import build_model, zero_dropout
     inp = fx["inputs"]
@@ -52,13 +52,15 @@ def run_forced(fx, mode):
     load_procedural(net)
     net.to(DEV).train()
     zero_dropout(net)
-    twins = mode == "bf16"
+    twins = mode in ("bf16", "fp16")
+    e16 = torch.float16 if mode == "fp16" else torch.bfloat16
+    gscale = 1024.0 if mode == "fp16" else 1.0
     own, forced_ids, handles = {}, set(), []
 
     def forced(key):
         t16 = inp["forced." + key].to(DEV)                        # (B, C, n) bf16
         if twins:
-            pm = t16.transpose(1, 2).contiguous()                 # position-major, as the producers here leave it
+            pm = t16.transpose(1, 2).to(e16).contiguous()         # position-major, as the producers here leave it
             f = pm.float().transpose(1, 2).requires_grad_(True)
             f.omnipq_rows16 = pm
         else:
@@ -96,7 +98,7 @@ def run_forced(fx, mode):
 
     pc = inp["point_clouds"].to(DEV)
     try:
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "f32"):
+        with torch.autocast("cuda", dtype=e16, enabled=mode != "f32"):
             ep = net({"point_clouds": pc})
     finally:
         for h in handles:
@@ -109,12 +111,13 @@ def run_forced(fx, mode):
         v = ep[k]
         if v.is_floating_point() and v.requires_grad and id(v) not in skip:
             loss = loss + (v.float() * upstream("ep." + k, v)).sum()
-    if mode == "bf16":
+    if twins:
+        assert sa_fused.E16.dtype == e16
         with sa_fused.deferred_wgrads():                          # as bench.py's step does
-            loss.backward()
+            (loss * gscale).backward()
     else:
         loss.backward()
-    grads = {k: p.grad.detach().float() for k, p in net.named_parameters() if p.grad is not None}
+    grads = {k: p.grad.detach().float() / gscale for k, p in net.named_parameters() if p.grad is not None}
     return {k: v.detach() for k, v in own.items()}, {k: v.detach() for k, v in ep.items()}, grads
 
 

@@ -70,7 +70,7 @@ def test_second_layer_gemm_from_coordinates(rows, C0, N):
     ws = torch.empty(lib.omnipq_gemm_nt_stats_workspace_floats(rows, N), device=DEV)
     outs = [torch.empty(C0, device=DEV) for _ in range(4)]
     rm, rv = torch.zeros(C0, device=DEV), torch.ones(C0, device=DEV)
-    capi.ok("omnipq_gemm_nt_bf16_xyz_bnaffine", rows, N, C0, ptr(X0), 8, ptr(W0), 32, ptr(fin), ctypes.c_double(rows),
+    capi.ok("omnipq_gemm_nt_e16_xyz_bnaffine", rows, N, C0, ptr(X0), 8, ptr(W0), 32, ptr(fin), ctypes.c_double(rows),
             ptr(gamma), ptr(beta), ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(rm), ptr(rv), ptr(outs[0]), ptr(outs[1]),
             ptr(outs[2]), ptr(outs[3]), ptr(B), C0, ptr(C), N, ptr(sums), ptr(ws))
     assert torch.allclose(outs[0], a, rtol=1e-4, atol=1e-6) and torch.allclose(outs[1], b, rtol=1e-4, atol=1e-5)
@@ -95,7 +95,7 @@ def test_data_gradient_sums_weight_gradient_above_and_first_layer_weight_gradien
     lib.omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
     sums5 = torch.zeros(5, C0, device=DEV, dtype=torch.float64)
     ws = torch.empty(lib.omnipq_gemm_nt_xyz_workspace_floats(rows, C0), device=DEV)
-    capi.ok("omnipq_gemm_nt_bf16_xyz_bnbwd", rows, C0, C1, ptr(dY), C1, ptr(W1t), C1, ptr(X0), 8, ptr(W0), 32, ptr(a),
+    capi.ok("omnipq_gemm_nt_e16_xyz_bnbwd", rows, C0, C1, ptr(dY), C1, ptr(W1t), C1, ptr(X0), 8, ptr(W0), 32, ptr(a),
             ptr(b), ptr(mean), ptr(invstd), ptr(sums5), ptr(ws))
     yf = y.float()
     dX = (dY.float() @ W1t.float().t()).bfloat16().float()                 # the kernel rounds the tile like a stored dX
@@ -109,7 +109,7 @@ def test_data_gradient_sums_weight_gradient_above_and_first_layer_weight_gradien
     # the weight gradient of the layer above: dW1 = dY^T relu(bn(y))
     dW1 = torch.empty(C1, C0, device=DEV)
     ws2 = torch.empty(lib.omnipq_gemm_tn_workspace_floats(C1, C0, rows), device=DEV)
-    capi.ok("omnipq_gemm_tn_bf16_xyz_affine", C1, C0, rows, ptr(dY), C1, ptr(X0), 8, ptr(W0), 32, ptr(a), ptr(b), ptr(dW1),
+    capi.ok("omnipq_gemm_tn_e16_xyz_affine", C1, C0, rows, ptr(dY), C1, ptr(X0), 8, ptr(W0), 32, ptr(a), ptr(b), ptr(dW1),
             ptr(ws2))
     act = torch.relu(a * yf + b).bfloat16().float()
     want = dY.float().t() @ act
@@ -136,6 +136,6 @@ def test_argument_validation():
     assert lib.omnipq_sa_xyz_moments(ctypes.c_longlong(100), p, 6, p, null) == 10001                # ldx % 4
     assert lib.omnipq_sa_xyz_stats(128, p, 32, null, p, null) == 10001
     # the generated-operand GEMMs only exist on the many-tile path
-    assert lib.omnipq_gemm_nt_bf16_xyz_bnbwd(4096, 128, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null) == 10001
-    assert lib.omnipq_gemm_nt_bf16_xyz_bnbwd(128 * 70, 320, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null) == 10001
-    assert lib.omnipq_gemm_tn_bf16_xyz_affine(128, 128, 9000, p, 128, p, 8, null, 32, p, p, p, p, null) == 10001
+    assert lib.omnipq_gemm_nt_e16_xyz_bnbwd(4096, 128, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null) == 10001
+    assert lib.omnipq_gemm_nt_e16_xyz_bnbwd(128 * 70, 320, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null) == 10001
+    assert lib.omnipq_gemm_tn_e16_xyz_affine(128, 128, 9000, p, 128, p, 8, null, 32, p, p, p, p, null) == 10001

@@ -110,9 +110,9 @@ def test_bench_accounting_helpers(built_lib):
     assert abs(per_scene - 3165.7) < 3.0, per_scene
     assert bench.sa_stage_algorithmic_bytes(8, 40000, 0, 2) == 12673789952
     table = {("omnipq_furthest_point_sampling", (8, 40000, 2048)): [10.0, 2, 0],
-             ("omnipq_gemm_nt_bf16_stats@sa", (1, 2, 3)): [4.0, 4, 0],
+             ("omnipq_gemm_nt_e16_stats@sa", (1, 2, 3)): [4.0, 4, 0],
              ("omnipq_ball_query_grid@sa", (1,)): [1.0, 2, 0],
-             ("omnipq_gemm_nt_bf16", (4096, 288, 288)): [6.0, 20, 0],
+             ("omnipq_gemm_nt_e16", (4096, 288, 288)): [6.0, 20, 0],
              ("omnipq_attn_fwd", (8,)): [2.0, 2, 0],
              ("omnipq_head_decode", (2048,)): [0.5, 2, 0]}
     got = bench.stage_breakdown(table, 2)

@@ -36,7 +36,7 @@ def gemm():
         A = torch.randn((M, K), device=dev).to(torch.bfloat16)
         B = torch.randn((N, K), device=dev).to(torch.bfloat16)
         C = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
-        ms = timeit(lambda: capi.ok("omnipq_gemm_nt_bf16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N))
+        ms = timeit(lambda: capi.ok("omnipq_gemm_nt_e16", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(C), N))
         ms_t = timeit(lambda: torch.matmul(A, B.t()))
         fl = 2.0 * M * N * K
         by = 2.0 * (M * K + M * N + N * K)
@@ -48,7 +48,7 @@ def gemm():
         B = torch.randn((P, N), device=dev).to(torch.bfloat16)
         C = torch.empty((M, N), device=dev)
         ws = torch.empty(int(capi.lib().omnipq_gemm_tn_workspace_floats(M, N, P)), device=dev)
-        ms = timeit(lambda: capi.ok("omnipq_gemm_tn_bf16", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C), capi.P(ws)))
+        ms = timeit(lambda: capi.ok("omnipq_gemm_tn_e16", M, N, P, capi.P(A), M, capi.P(B), N, capi.P(C), capi.P(ws)))
         ms_t = timeit(lambda: torch.matmul(A.t(), B))
         fl = 2.0 * M * N * P
         by = 2.0 * (P * M + P * N)
