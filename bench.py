@@ -405,8 +405,11 @@ class GraphUnavailable(RuntimeError):
 def workload_name(args):
     """Which BASELINE.json configuration the arguments correspond to."""
     key = (args.batch, args.points, args.extra_channels)
-    return {(8, 40000, 0): "BASELINE configs[1]", (4, 50000, 6): "BASELINE configs[3]",
-            (16, 80000, 0): "BASELINE configs[4] (in bf16)"}.get(key, "custom configuration")
+    name = {(8, 40000, 0): "BASELINE configs[1]", (4, 50000, 6): "BASELINE configs[3]",
+            (16, 80000, 0): "BASELINE configs[4]"}.get(key, "custom configuration")
+    if key == (16, 80000, 0) and args.dtype != "fp16":
+        name += f" (in {args.dtype}; the configuration names fp16: --dtype fp16)"
+    return name
 
 
 class FlatGradients:
@@ -458,7 +461,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         gt.update(labels)
         return loss_helper_pq.get_loss(gt, LossConfig, pc_loss=True)[0]
 
-    scale = float(getattr(args, "loss_scale", 0.0) or (16384.0 if args.dtype == "fp16" else 1.0))
+    scale = float(getattr(args, "loss_scale", 0.0) or (16384.0 if getattr(args, "dtype", "bf16") == "fp16" else 1.0))
 
     def backward(loss):
         if scale != 1.0:

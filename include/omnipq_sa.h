@@ -103,7 +103,9 @@ typedef struct {
   int M, N, P, lda, ldb;
   int out_rows, out_cols, out_ld;
   int flags;                 /* bit 0: add to out */
-  int pad_;
+  int rot;                   /* 0, or rot | split << 8: out column c takes C's column (c < rot ? split + c : c - rot) -- the
+                              * first layer of an SA stage multiplies rows laid out [features(split) | xyz(rot) | 0...]
+                              * while the parameter's columns are [xyz(rot) | features] */
   const float *ba, *bb;      /* both NULL, or float[N]: B stands for relu(ba .* B + bb) (see ..._affine below) */
 } omnipq_tn_problem;
 long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);

@@ -323,7 +323,7 @@ struct TnGroupItem {
   int out_rows, out_cols, out_ld;
   int blk_begin;                // first block of this problem in the reduction grid
   int flags;                    // bit 0: add to `out` instead of overwriting it
-  int pad_;
+  int rot;                      // rot | split << 8: output column c takes C's column (c < rot ? split + c : c - rot)
 };
 struct TnGroupArgs {
   int n;
@@ -357,7 +357,11 @@ __global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(TnGroupArgs a) {
   const int e = (blk - it.blk_begin) * 256 + (int)threadIdx.x;
   if (e >= it.out_rows * it.out_cols) return;
   const int r = e / it.out_cols, c = e - r * it.out_cols;
-  const float *src = it.part + (size_t)r * it.N + c;
+  // the first layer of an SA stage multiplies rows ordered [features(split, zero-padded) | xyz(rot) | 0...] where the
+  // parameter's columns are [xyz(rot) | features] (reference pointnet2_utils.py:357-359): undo that here
+  const int rot = it.rot & 255, split = it.rot >> 8;
+  const int sc = c < rot ? split + c : c - rot;
+  const float *src = it.part + (size_t)r * it.N + sc;
   const size_t mn = (size_t)it.M * it.N;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   int z = 0;
@@ -506,27 +510,35 @@ struct omnipq_tn_problem_ {
   int M, N, P, lda, ldb;
   int out_rows, out_cols, out_ld;
   int flags;                // bit 0: out += C
-  int pad_;
+  int rot;                  // rot | split << 8 (0: none): out column c = C column (c < rot ? split + c : c - rot)
   const float *ba, *bb;     // NULL, or: B stands for relu(ba .* B + bb)
 };
 
-static int tng_chunk() {
-  // positions per workgroup in the grouped launch: the grid is full anyway, so workgroups are cut for balance
-  // (a few thousand of them), not to create parallelism
-  constexpr int steps = 16;
-  return omnipq::TBK * (steps < 1 ? 1 : steps);
+// Positions per workgroup in a grouped launch, the same for every problem of the call (balance): at least 16 K-steps
+// (the ~115 per-point layers of 4096 rows: the grid is full anyway), and for calls that carry the SA stages' layers (up to
+// 1 M rows each) as many as it takes to bring the call down to ~4096 workgroups -- a workgroup leaves a 64 KB f32 slab
+// behind, the bytes of four K-steps of operands, so slabs of 16 steps on a million-row problem would move more than the
+// operands do.
+static int tng_chunk(int nprob, const omnipq_tn_problem_ *pr) {
+  long long tile_steps = 0;
+  for (int i = 0; i < nprob; ++i)
+    tile_steps += (long long)((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128) * ((pr[i].P + omnipq::TBK - 1) / omnipq::TBK);
+  long long steps = (tile_steps + 4095) / 4096;
+  if (steps < 16) steps = 16;
+  if (steps > 1024) steps = 1024;
+  return omnipq::TBK * (int)steps;
 }
 
-static int tng_slabs(int P) {
-  const int c = tng_chunk();
-  const int s = (P + c - 1) / c;
+static int tng_slabs(int P, int chunk) {
+  const int s = (P + chunk - 1) / chunk;
   return s < 1 ? 1 : s;
 }
 
 extern "C" long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs_) {
   const omnipq_tn_problem_ *pr = (const omnipq_tn_problem_ *)probs_;
+  const int chunk = tng_chunk(nprob, pr);
   long long total = 0;
-  for (int i = 0; i < nprob; ++i) total += (long long)tng_slabs(pr[i].P) * pr[i].M * pr[i].N;
+  for (int i = 0; i < nprob; ++i) total += (long long)tng_slabs(pr[i].P, chunk) * pr[i].M * pr[i].N;
   return total;
 }
 
@@ -538,16 +550,18 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
     const omnipq_tn_problem_ &q = pr[i];
     if (q.M <= 0 || q.N <= 0 || q.P < 0 || (q.P > 0 && (!q.A || !q.B)) || !q.out || (q.M % 8) || (q.N % 8) || (q.lda % 8) || (q.ldb % 8) ||
         q.out_rows <= 0 || q.out_cols <= 0 || q.out_rows > q.M || q.out_cols > q.N || q.out_ld < q.out_cols ||
-        ((q.ba != nullptr) != (q.bb != nullptr)))
+        ((q.ba != nullptr) != (q.bb != nullptr)) || q.rot < 0 || (q.rot >> 8) + (q.rot & 255) > q.N ||
+        (q.rot & 255) > q.out_cols)
       return OMNIPQ_EINVAL;
   }
+  const int chunk = tng_chunk(nprob, pr);
   // workspace offsets follow the problem order (as omnipq_gemm_tn_grouped_workspace_floats counts them)
   size_t off = 0;
   static thread_local std::vector<size_t> ws_off;
   ws_off.resize(nprob);
   for (int i = 0; i < nprob; ++i) {
     ws_off[i] = off;
-    off += (size_t)tng_slabs(pr[i].P) * pr[i].M * pr[i].N;
+    off += (size_t)tng_slabs(pr[i].P, chunk) * pr[i].M * pr[i].N;
   }
   for (int pass = 0; pass < 2; ++pass) {              // plain problems, then the ones with a transformed B operand
     int next = 0;
@@ -570,7 +584,7 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
           it.M = q.M; it.N = q.N; it.P = q.P; it.lda = q.lda; it.ldb = q.ldb;
           it.m_tiles = (q.M + 127) / 128;
           it.n_tiles = (q.N + 127) / 128;
-          const int slabs = tng_slabs(q.P);
+          const int slabs = tng_slabs(q.P, chunk);
           it.p_chunk = (((q.P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
           it.slabs = q.P > 0 ? (q.P + it.p_chunk - 1) / it.p_chunk : 1;
           it.wg_begin = wg;
@@ -579,7 +593,7 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
           it.blk_begin = blk;
           blk += (q.out_rows * q.out_cols + 255) / 256;
           it.flags = q.flags;
-          it.pad_ = 0;
+          it.rot = q.rot;
         }
         ++next;
       }

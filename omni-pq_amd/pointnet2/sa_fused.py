@@ -255,7 +255,7 @@ class _TnProblem(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
                 ("out_rows", ctypes.c_int), ("out_cols", ctypes.c_int), ("out_ld", ctypes.c_int),
-                ("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p)]
+                ("flags", ctypes.c_int), ("rot", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p)]
 
 
 _lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
@@ -399,7 +399,8 @@ class deferred_wgrads:
     def __enter__(self):
         if deferred_wgrads.active is not None:
             raise RuntimeError("deferred_wgrads blocks do not nest")
-        self.items = []             # (dY, X, M, N, P, weight target, (cout, cin), bias target | None)
+        self.items = []             # (dY, X, M, N, P, weight target, (cout, cin[, rot]), bias target | None, affine | None)
+        self.sa_items = []          # the same for the SA stages' layers: a grouped launch of their own (see add_sa)
         self.ln_items = []          # (partials [blocks][2C], blocks, C, gamma, beta): LayerNorm parameter gradients
         deferred_wgrads.active = self
         return self
@@ -411,6 +412,13 @@ class deferred_wgrads:
     def add(self, dY, X, M, N, P, wt, crop, bt, below=None):
         """below: X is that layer's pre-BN output and stands for relu(below.a * X + below.b)"""
         self.items.append((dY, X, M, N, P, wt, crop, bt, None if below is None else (below.a, below.b)))
+
+    def add_sa(self, dY, X, M, N, P, wt, crop, below=None):
+        """A layer of a fused SA stage (up to a million positions): collected apart from the per-point layers and run
+        as ONE grouped launch for all stages when the block ends.  One by one these GEMMs are split into ~512
+        workgroups each -- two per CU, the launch's tail and its slab reduction paid 14 times per step; together
+        they fill the chip with ~4000 workgroups cut for balance.  crop = (cout, cin, rot): see omnipq_tn_problem."""
+        self.sa_items.append((dY, X, M, N, P, wt, crop, None, None if below is None else (below.a, below.b)))
 
     def __exit__(self, et, ev, tb):
         deferred_wgrads.active = None
@@ -424,6 +432,7 @@ class deferred_wgrads:
             for param, g in getattr(self, "_assign", ()):          # .grad is complete after the block
                 self._accumulate(param, g)
         self.items = None
+        self.sa_items = None
         self.ln_items = None
         self._inflight = None
         self._assign = None
@@ -473,9 +482,15 @@ class deferred_wgrads:
     def flush(self):
         if self.ln_items:
             self._flush_layernorms()
-        items = self.items
-        if not items:
-            return
+        if self.items:
+            self._flush_items(self.items)
+        if self.sa_items and deferred_wgrads.active is None:       # only when the block ends: every stage is in
+            items, self.sa_items = self.sa_items, []
+            with _tagged("@sa"):
+                self._flush_items(items)
+            self.__dict__.setdefault("_inflight", []).extend(items)
+
+    def _flush_items(self, items):
         dev = items[0][0].device
         whole = {}              # id(param) -> [param, f32 buffer of its shape, offsets written so far]
         pieces = []             # (param, f32 view of a scratch buffer) assigned / accumulated afterwards
@@ -484,7 +499,8 @@ class deferred_wgrads:
         # which packed weights are covered completely by the row ranges collected (q | k,v of a cross-attention):
         # those buffers need no clearing
         covered = {}
-        for (_, _, _, _, _, wt, (cout, cin), _, _) in items:
+        for (_, _, _, _, _, wt, crop, _, _) in items:
+            cout, cin = crop[0], crop[1]
             if wt[0] == "param":
                 covered.setdefault(id(wt[1]), {})[wt[2]] = cout * cin
         complete = {k for k, v in covered.items() if sum(v.values()) == next(
@@ -505,8 +521,10 @@ class deferred_wgrads:
             return ent
 
         probs = (_TnProblem * len(items))()
-        for i, (dY, X, M, N, P, wt, (cout, cin), bt, aff) in enumerate(items):
+        for i, (dY, X, M, N, P, wt, crop, bt, aff) in enumerate(items):
+            cout, cin = crop[0], crop[1]
             q = probs[i]
+            q.rot = crop[2] if len(crop) > 2 else 0
             q.A, q.B = dY.data_ptr(), X.data_ptr()
             q.ba, q.bb = (0, 0) if aff is None else (aff[0].data_ptr(), aff[1].data_ptr())
             q.M, q.N, q.P, q.lda, q.ldb = M, N, P, dY.stride(0), X.stride(0)
@@ -984,6 +1002,8 @@ class FusedSAStage(torch.autograd.Function):
         ctx.layers = layers
         ctx.X0 = X0
         ctx.xgen = xgen
+        # where a layer's weight gradient may be written behind autograd's back (deferred_wgrads): Parameters only
+        ctx.wtargets = [grad_target(params[3 * l]) for l in range(L)] if training else None
         ctx.cin_raw = cin_raw
         ctx.geom = (B, N, M, S, P, cin, kpad, inv_r, world)
         ctx.idx = idx
@@ -1040,6 +1060,7 @@ class FusedSAStage(torch.autograd.Function):
         d_feat = d_xyz = d_cen = None
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (ctx.has_features and ctx.needs_input_grad[2])
         xgen = getattr(ctx, "xgen", False)
+        dfr = deferred_wgrads.active
         pend = None                  # BatchNorm-backward totals of layer l when `dY` still holds dX (gradient w.r.t. its ReLU output)
         for l in range(L - 1, -1, -1):
             lay = layers[l]
@@ -1071,14 +1092,21 @@ class FusedSAStage(torch.autograd.Function):
                       _p(prev.mean), _p(prev.invstd), ctypes.c_double(1.0 / (float(P) * world)), _p(dW0))
                 grads[0] = dW0
                 break
-            if l > 0 and layers[l - 1].X is None:
-                dWp = _gemm_tn(dY, layers[l - 1].Y, lay.C, lay.K, P, below=layers[l - 1])
+            below = layers[l - 1] if (l > 0 and layers[l - 1].X is None) else None
+            Xin = below.Y if below is not None else (layers[l - 1].X if l > 0 else ctx.X0)
+            wt = ctx.wtargets[l] if dfr is not None else None
+            if wt is not None and ctx.needs_input_grad[9 + 3 * l]:
+                # collected: one grouped launch for the layers of ALL SA stages when the deferred_wgrads block ends
+                if l == 0:
+                    dfr.add_sa(dY, Xin, lay.C, lay.K, P, wt, (lay.C, ctx.cin_raw + 3, 3 | (cin << 8)))
+                else:
+                    dfr.add_sa(dY, Xin, lay.C, lay.K, P, wt, (lay.C, lay.K), below)
             else:
-                dWp = _gemm_tn(dY, layers[l - 1].X if l > 0 else ctx.X0, lay.C, lay.K, P)      # [Cout][K]
-            wk = cin + 3 if l == 0 else lay.K
-            grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
-            if l == 0 and ctx.cin_raw != cin:
-                grads[0] = grads[0][:, :ctx.cin_raw + 3].contiguous()       # drop the padded feature columns
+                dWp = _gemm_tn(dY, Xin, lay.C, lay.K, P, below=below)      # [Cout][K]
+                wk = cin + 3 if l == 0 else lay.K
+                grads[3 * l] = unprep_wgrad(dWp, lay.C, wk, 3 if l == 0 else 0, (lay.C, wk, 1, 1))
+                if l == 0 and ctx.cin_raw != cin:
+                    grads[0] = grads[0][:, :ctx.cin_raw + 3].contiguous()       # drop the padded feature columns
             if l == 0 and not need_in:
                 break
             if l > 0:

@@ -332,6 +332,43 @@ def _fused_vs_f32(spec, n, cin, B, monkeypatch, xyz_grad=True, dtype=torch.bfloa
     return errors
 
 
+@pytest.mark.parametrize("case", ["sa1_like", "sa2_like", "vote_like", "six_padded_features"])
+def test_sa_weight_gradients_deferred_into_one_grouped_launch_equal_the_immediate_ones(case, monkeypatch):
+    """Inside `sa_fused.deferred_wgrads()` the layers of a fused SA stage hand their weight gradients to the block
+    (`add_sa`): one grouped launch for all stages at its end, the first layer's columns rotated back from the kernels'
+    [features | xyz] order to the parameter's [xyz | features] (and the zero-padded feature columns dropped) by the
+    launch's reduction.  Same operands, another partition of the position axis: equal to the immediate GEMMs up to f32
+    summation order."""
+    import pointnet2_modules
+    import sa_fused
+    spec, n, cin = {"sa1_like": SA_SPECS[0], "sa2_like": SA_SPECS[1], "vote_like": SA_SPECS[2],
+                    "six_padded_features": (dict(npoint=256, radius=0.4, nsample=32, mlp=[6, 64, 64, 128], use_xyz=True,
+                                                 normalize_xyz=True), 4096, 6)}[case]
+    xyz = synth.make_clouds(47, 2, n, kind="room").to(dev())
+    feats = procedural_tensor("defer.feats", (2, cin, n), torch.float32).to(dev()) if cin else None
+    monkeypatch.setenv("OMNIPQ_SA", "fused")
+    grads = {}
+    for mode in ("immediate", "deferred"):
+        mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
+            mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}), 9).to(dev()).train()
+        f = None if feats is None else feats.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            _, out, _ = mod(xyz, f)
+        g_up = procedural_tensor("defer.g_up", tuple(out.shape), torch.float32).to(dev())
+        if mode == "deferred":
+            with sa_fused.deferred_wgrads() as dfr:
+                out.backward(g_up)
+                assert len(dfr.sa_items) >= len(spec["mlp"]) - 2, "the stage did not hand its weight gradients over"
+                assert all(p.grad is None for k, p in mod.named_parameters() if k.endswith("conv.weight")
+                           and not (case == "sa1_like" and ("layer0" in k or "layer1" in k)))
+        else:
+            out.backward(g_up)
+        grads[mode] = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    for k, g in grads["immediate"].items():
+        assert grads["deferred"][k].shape == g.shape, k
+        assert rel_l2(grads["deferred"][k], g) < 2e-5, (k, rel_l2(grads["deferred"][k], g))
+
+
 def test_fused_sa_eval_mode_uses_running_statistics(monkeypatch):
     spec, n, cin = SA_SPECS[1]
     xyz = synth.make_clouds(43, 2, n, kind="room").to(dev())
