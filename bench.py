@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32); bf16 and fp16 run the hand-written "
                          "kernels (libomnipq_pointops.so / _f16.so), fp32 the op-by-op composition")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
+                    help="A/B runs on one box: set a module-level switch before the model is built, e.g. "
+                         "--set sa_fused.SA_WGRADS_GROUPED=0 (int / float / True / False values)")
     ap.add_argument("--loss-scale", type=float, default=0.0,
                     help="the loss is multiplied by this before backward (what torch.amp.GradScaler does for fp16: a mean "
                          "over 1e5 elements hands every element a gradient below fp16's normal range); 0 = 16384 for fp16, 1 otherwise")
@@ -64,6 +67,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32, help="thread count tried next to 'all cores'")
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
+    ap.add_argument("--prefetch-at", default="forward", choices=["forward", "backward"],
+                    help="where the next batch's sampling chain (7 ms of dependent rounds, side stream) starts inside the "
+                         "step: at the beginning of forward (default) or, as in rounds 1-2, when backward begins")
     ap.add_argument("--eager-dp", default="flat", choices=["flat", "ddp"],
                     help="data parallelism of EAGER multi-rank steps (the fallback when RCCL cannot be captured): "
                          "flat = SyncBN all-reduces + one flat gradient all-reduce after backward, as in the captured "
@@ -511,15 +517,22 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         nxt_t = teacher_pool[0].clone() if teacher is not None else None
         lab_cur = {k: v.clone() for k, v in labels_pool[0].items()} if labels_pool is not None else None
 
+        early = not args.no_prefetch and getattr(args, "prefetch_at", "forward") == "forward"
+
         def graph_body():
             for p in net.parameters():
                 p.grad = None
+            if early:
+                # the next batch's sampling chain starts inside forward(), as soon as this batch's plan has been taken
+                net.prefetch({"point_clouds": nxt}, trusted=True, at_next_forward=True)
+                if teacher is not None:
+                    teacher.prefetch({"point_clouds": nxt_t}, trusted=True, at_next_forward=True)
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 ep = model({"point_clouds": cur})
                 loss = criterion(ep, lab_cur)
             if teacher is not None:
                 teacher_forward(cur_t)
-            if not args.no_prefetch:
+            if not args.no_prefetch and not early:
                 net.prefetch({"point_clouds": nxt}, trusted=True)
                 if teacher is not None:
                     teacher.prefetch({"point_clouds": nxt_t}, trusted=True)
@@ -623,6 +636,14 @@ def main():
         sa_fused._FORCE_COLLECTIVES = True
     ext = pointnet2_utils._ext
     assert ext.__name__ == "pointnet2._ext", "the product binding must be the one that runs"
+    for item in args.set:                       # --set module.ATTR=value (A/B runs)
+        import ast
+        import importlib
+        target, value = item.split("=", 1)
+        mod, attr = target.rsplit(".", 1)
+        m = importlib.import_module(mod)
+        assert hasattr(m, attr), f"--set: {mod} has no attribute {attr}"
+        setattr(m, attr, ast.literal_eval(value))
 
     torch.manual_seed(1234)
     net = build_model(args.extra_channels).to(dev)

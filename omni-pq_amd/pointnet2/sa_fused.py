@@ -159,6 +159,9 @@ def affine_pays(P, N):
     return AFFINE_OPERANDS
 
 
+# inside deferred_wgrads the SA stages' weight gradients run as ONE grouped launch when the block ends (False: one
+# GEMM + slab reduction per layer, as outside the block)
+SA_WGRADS_GROUPED = True
 POOL_EPILOGUE = True
 # the last layer's BatchNorm finalize inside the pool-select launch, its backward means / affine gradients inside the pool
 # backward apply
@@ -1094,7 +1097,7 @@ class FusedSAStage(torch.autograd.Function):
                 break
             below = layers[l - 1] if (l > 0 and layers[l - 1].X is None) else None
             Xin = below.Y if below is not None else (layers[l - 1].X if l > 0 else ctx.X0)
-            wt = ctx.wtargets[l] if dfr is not None else None
+            wt = ctx.wtargets[l] if (dfr is not None and SA_WGRADS_GROUPED) else None
             if wt is not None and ctx.needs_input_grad[9 + 3 * l]:
                 # collected: one grouped launch for the layers of ALL SA stages when the deferred_wgrads block ends
                 if l == 0:
