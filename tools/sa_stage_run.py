@@ -70,7 +70,9 @@ def main():
                     loss = loss + rows_loss(k, f)
             _, vf, _ = net.vote_aggregation(seed_xyz, seed_feat, vote_inds)
             loss = loss + rows_loss("vote", vf)
-        loss.backward()
+        import sa_fused
+        with sa_fused.deferred_wgrads():          # as bench.py's step: the stages' weight gradients as one grouped launch
+            loss.backward()
 
     for _ in range(2):
         step()
