@@ -55,6 +55,14 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32); bf16 and fp16 run the hand-written "
                          "kernels (libomnipq_pointops.so / _f16.so), fp32 the op-by-op composition")
+    ap.add_argument("--input-pipeline", action="store_true",
+                    help="feed every step from the HOST instead of a pool of HBM-resident batches (SURVEY 8f-3; reference "
+                         "train.py:465-472): raw clouds are sub-sampled with the reference's random_sampling "
+                         "(utils/pc_util.py:36-44) in --loader-workers threads, staged in pinned memory and copied to the "
+                         "device inside the timed region; the sampling plan is prefetched behind the copy.  The headline "
+                         "`value` keeps its definition (inputs resident): this mode reports the host-inclusive rate")
+    ap.add_argument("--loader-workers", type=int, default=4, help="host threads sub-sampling scenes (a DataLoader's workers)")
+    ap.add_argument("--raw-points", type=int, default=60000, help="points per raw scene before random_sampling")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
                     help="A/B runs on one box: set a module-level switch before the model is built, e.g. "
                          "--set sa_fused.SA_WGRADS_GROUPED=0 (int / float / True / False values)")
@@ -441,6 +449,73 @@ class FlatGradients:
             off += n
 
 
+class HostFeeder:
+    """The input side of the step on the host: `workers` threads turn raw scenes into batches with the
+    reference's per-scene `random_sampling` (what its Dataset.__getitem__ does inside DataLoader workers,
+    scannet_detection_dataset.py / utils/pc_util.py:36-44), the main thread stages one batch per step in pinned memory
+    and issues the host-to-device copy on the step's stream.  Three pinned buffers: a buffer is rewritten only after the
+    copy that read it has completed (event)."""
+
+    def __init__(self, args, device, rank):
+        import queue
+        import threading
+        import numpy as np
+        import input_pipeline
+        import synth
+        self.device = device
+        raw = [synth.make_clouds(500 + i, 1, args.raw_points, extra_channels=args.extra_channels, kind="room",
+                                 first_scene=rank * 16 + i)[0].numpy() for i in range(max(8, args.batch))]
+        shape = (args.batch, args.points, 3 + args.extra_channels)
+        self.pinned = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(3)]
+        self.free = [None, None, None]
+        self.n = 0
+        self.q = queue.Queue(maxsize=4)
+        self.stop = False
+        self.host_wait_s = 0.0
+
+        def work(seed):
+            rng_lock.acquire()
+            np.random.seed(seed)               # random_sampling draws from numpy's global RNG (as the reference's does)
+            rng_lock.release()
+            i = seed
+            while not self.stop:
+                scenes = []
+                for b in range(args.batch):
+                    with rng_lock:
+                        scenes.append(input_pipeline.random_sampling(raw[(i + b) % len(raw)], args.points))
+                i += args.batch
+                batch = torch.from_numpy(np.stack(scenes).astype(np.float32, copy=False))
+                while not self.stop:
+                    try:
+                        self.q.put(batch, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+
+        rng_lock = threading.Lock()
+        self.threads = [threading.Thread(target=work, args=(1000 + w,), daemon=True) for w in range(args.loader_workers)]
+        for t in self.threads:
+            t.start()
+
+    def next_into(self, dst):
+        """dst (device, static buffer) <- the next host batch, asynchronously on the current stream."""
+        t0 = time.perf_counter()
+        host = self.q.get()
+        k = self.n % 3
+        self.n += 1
+        if self.free[k] is not None:
+            self.free[k].synchronize()
+        self.pinned[k].copy_(host)
+        self.host_wait_s += time.perf_counter() - t0
+        dst.copy_(self.pinned[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.free[k] = ev
+
+    def close(self):
+        self.stop = True
+
+
 EMA_DECAY, EMA_STEP = 0.999, 100_000          # steady state of train.py:437: alpha = min(1 - 1/(step+1), 0.999) = 0.999
 
 
@@ -456,8 +531,13 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
 
     # DistributedDataParallel (--eager-dp ddp) needs the per-parameter hooks: no deferral there
     defer = not ddp
-    # eager multi-rank steps without DDP: the same single flat all-reduce as in the captured step
-    flat_eager = FlatGradients(net, world) if (distributed and not ddp) else None
+    # multi-rank steps without DDP: two gradient buckets, the first (everything but the backbone: 15.4 M of 17.9 M
+    # parameters) all-reduced on the side stream underneath the backbone's backward pass (data_parallel.GradientBuckets)
+    buckets = None
+    if distributed and not ddp:
+        import data_parallel
+        buckets = data_parallel.GradientBuckets(net, world)
+    args.buckets = buckets
 
     def criterion(ep, labels):
         if labels is None:
@@ -470,14 +550,20 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
     scale = float(getattr(args, "loss_scale", 0.0) or (16384.0 if getattr(args, "dtype", "bf16") == "fp16" else 1.0))
 
     def backward(loss):
+        if buckets is not None:
+            buckets.collectives = 0
         if scale != 1.0:
             loss = loss * scale                      # static loss scaling (fp16): see --loss-scale
         if defer:
             import sa_fused
-            with sa_fused.deferred_wgrads():         # ~115 small weight gradients as one grouped launch
+            # ~130 weight gradients as a few grouped launches; under data parallelism the first gradient bucket is
+            # all-reduced from the block's early flush
+            with sa_fused.deferred_wgrads(on_early_flush=buckets.on_early_flush if buckets is not None else None):
                 loss.backward()
         else:
             loss.backward()
+        if buckets is not None:
+            buckets.finish()
 
     def step(i):
         for p in net.parameters():
@@ -495,8 +581,6 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             if teacher is not None:
                 teacher.prefetch({"point_clouds": teacher_pool[(i + 1) % len(teacher_pool)]})
         backward(loss)
-        if flat_eager is not None:
-            flat_eager.reduce()
         if teacher is not None:
             import ema
             ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)       # train.py:576
@@ -504,7 +588,6 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
 
     use_graph = args.graph in ("on", "auto") and (not distributed or dist_graph)
     if use_graph:
-        flat = FlatGradients(net, world) if distributed else None
         # The whole step (forward, loss, next batch's sampling, backward; ~3000 launches) is captured ONCE
         # into a hipGraph and replayed: same kernels, same order, no per-launch host work.  Two static
         # input buffers: `cur` feeds forward/backward, `nxt` feeds the sampling plan of the following
@@ -542,13 +625,16 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
                 teacher.join_prefetch()
                 import ema
                 ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)
-            if flat is not None:
-                flat.reduce()
             return loss
+
+        feeder = getattr(args, "feeder", None)
 
         def feed(i):
             cur.copy_(nxt)
-            nxt.copy_(pool[(i + 1) % len(pool)])
+            if feeder is not None:
+                feeder.next_into(nxt)              # host batch -> pinned -> device, inside the timed region
+            else:
+                nxt.copy_(pool[(i + 1) % len(pool)])
             if lab_cur is not None:
                 for k, v in labels_pool[i % len(pool)].items():
                     lab_cur[k].copy_(v)
@@ -678,6 +764,11 @@ def main():
         LossConfig.mean_size_arr = mean_size_arr()
         labels_pool = [{k: v.to(dev) for k, v in synth.make_labels(pc, 300 + i, mean_size_arr=mean_size_arr()).items()}
                        for i, pc in enumerate(pool)]
+    args.feeder = None
+    if args.input_pipeline:
+        if args.graph == "off" or args.mean_teacher or args.loss == "supervised":
+            sys.exit("bench.py: --input-pipeline drives the captured default step (no --graph off / --mean-teacher / --loss)")
+        args.feeder = HostFeeder(args, dev, rank)
     try:
         step, launch_mode = make_step(net, model, pool, args, amp_dtype, world, distributed, dist_graph, teacher,
                                       teacher_pool, ddp, labels_pool)
@@ -709,6 +800,8 @@ def main():
     dt = time.perf_counter() - t0
     ext.set_timing_sink(None)
     ext.fps_check()
+    if args.feeder is not None:
+        args.feeder.close()
     timing_note = ""
     timing_steps = args.steps
     if not args.no_op_timing:
@@ -738,6 +831,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    dp_counts = ""
+    if distributed and not ddp:
+        import sa_fused
+        b = getattr(args, "buckets", None)
+        dp_counts = (f"{sa_fused.COLLECTIVES_LAST_STEP} SyncBN statistics all-reduces (<= 4 KB each) + "
+                     f"{b.collectives if b is not None else 0} gradient-bucket all-reduces per step (bucket 0 = everything but "
+                     "the backbone, issued on the side stream when backward reaches the seed features; bucket 1 = backbone)")
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
@@ -749,12 +849,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "launch": "hipGraph replay" if use_graph else "eager",
+            "input": ("resident: a pool of batches in HBM before the timed region (3.84 MB device-to-device per step inside it)"
+                      if args.feeder is None else
+                      f"host pipeline INSIDE the timed region: random_sampling {args.raw_points} -> {args.points} points per "
+                      f"scene in {args.loader_workers} host threads, pinned staging, one host-to-device copy of "
+                      f"{args.batch * args.points * (3 + args.extra_channels) * 4 / 1e6:.2f} MB per step; the main thread "
+                      f"spent {1e3 * args.feeder.host_wait_s / max(args.steps + args.warmup, 1):.3f} ms per step waiting for "
+                      "/ staging batches"),
             "data_parallel": (None if not distributed else
-                              "SyncBN + one flat gradient all-reduce, all inside the graph (RCCL graph probe passed)"
-                              if use_graph else
-                              ("DistributedDataParallel, eager" if ddp else
-                               "SyncBN + one flat gradient all-reduce after backward, eager launches") +
-                              (" (RCCL graph probe passed)" if probe_ok else " (RCCL graph probe failed or skipped)")),
+                              (f"{dp_counts}, all inside the graph (RCCL graph probe passed)"
+                               if use_graph else
+                               ("DistributedDataParallel, eager" if ddp else f"{dp_counts}, eager launches") +
+                               (" (RCCL graph probe passed)" if probe_ok else " (RCCL graph probe failed or skipped)"))),
             "config": {"workload": f"{workload_name(args)}: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
                                    f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,

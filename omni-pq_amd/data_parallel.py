@@ -1,0 +1,99 @@
+"""Data-parallel gradient reduction for the step that runs inside `sa_fused.deferred_wgrads()`.
+
+The reference wraps the model in `DistributedDataParallel(..., broadcast_buffers=False)` (train.py:382): per-parameter
+autograd hooks fill 25 MB buckets which NCCL all-reduces while backward continues.  The step here computes its ~130
+weight gradients behind autograd's back (grouped launches, `sa_fused.deferred_wgrads`), so parameter hooks never fire
+for them -- `deferred_wgrads` refuses parameters that belong to a DistributedDataParallel module (see
+`sa_fused.forbid_deferral_under_ddp`).  What DDP's buckets buy is reproduced directly, with the order in which THIS
+model's backward completes its gradients:
+
+    bucket 0   everything downstream of the seed features in forward -- voting module, vote aggregation, proposal
+               heads, query / key projections, six decoder layers, twelve prediction heads: 15.4 M of 17.9 M parameters.
+               Complete when backward reaches the seed features (`sa_fused.WgradFlushPoint`): packed and all-reduced on
+               the side stream there, underneath the backbone's backward pass (feature propagation + four SA stages).
+    bucket 1   the backbone (2.4 M parameters): packed and all-reduced when the block has ended.
+
+On eight MI355X a ring all-reduce of bucket 0 (62 MB f32) is per-link bound at ~0.7 ms (7 xGMI links x ~153 GB/s:
+SURVEY.md section 5) against ~4 ms of backbone backward left to run; only bucket 1 (10 MB) is exposed.  Gradients come
+back as views of the two flat buffers, averaged over the ranks, exactly what DDP leaves in `.grad`.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _backbone_param_ids(net):
+    bb = getattr(net, "backbone", None)
+    return {id(p) for p in bb.parameters()} if bb is not None else set()
+
+
+class GradientBuckets:
+    def __init__(self, net, world, group=None):
+        self.world, self.group = world, group
+        late = _backbone_param_ids(net)
+        params = [p for p in net.parameters() if p.requires_grad]
+        self.buckets = [[p for p in params if id(p) not in late], [p for p in params if id(p) in late]]
+        self.flat = [None, None]
+        self.early_done = False
+        self.collectives = 0          # all-reduces issued by the last step (reported by bench.py)
+
+    # ---- called by sa_fused.deferred_wgrads.flush_on, on the side stream, after the early grouped launch ----------
+    def on_early_flush(self, dfr):
+        """Bucket 0 is complete: autograd has accumulated its share into `.grad` (the side stream waited for the main
+        stream), the deferred share sits in `dfr._assign` as (parameter, f32 buffer) pairs computed on this stream."""
+        if self.early_done or self.world < 1:
+            return
+        mine = {id(p) for p in self.buckets[0]}
+        assign = getattr(dfr, "_assign", None) or []
+        take = [(p, g) for p, g in assign if id(p) in mine]
+        dfr._assign = [(p, g) for p, g in assign if id(p) not in mine]
+        self.flat[0] = self._pack(self.buckets[0], take)
+        self._reduce(self.flat[0])
+        self.early_done = True
+
+    # ---- called by the step once the deferred_wgrads block has ended ------------------------------------------------
+    def finish(self):
+        if not self.early_done:                   # no flush point was hit (eager helper paths): everything now
+            self.flat[0] = self._pack(self.buckets[0], [])
+            self._reduce(self.flat[0])
+        self.flat[1] = self._pack(self.buckets[1], [])
+        self._reduce(self.flat[1])
+        inv = 1.0 / self.world
+        for flat, params in zip(self.flat, self.buckets):
+            if flat.is_cuda and not torch.cuda.is_current_stream_capturing():
+                flat.record_stream(torch.cuda.current_stream(flat.device))     # bucket 0 was allocated on the side stream
+            flat.mul_(inv)
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+        self.early_done = False
+
+    # -------------------------------------------------------------------------------------------------------------------
+    def _pack(self, params, extra):
+        """One flat f32 buffer holding, per parameter, `.grad` (if any) plus the deferred gradients in `extra`."""
+        by_param = {}
+        for p, g in extra:
+            by_param.setdefault(id(p), []).append(g)
+        pieces, again = [], []
+        for p in params:
+            gs = ([p.grad] if p.grad is not None else []) + by_param.get(id(p), [])
+            if not gs:
+                pieces.append(torch.zeros(p.numel(), device=p.device, dtype=torch.float32))
+                continue
+            pieces.append(gs[0].reshape(-1).float())
+            again.extend((len(pieces) - 1, g) for g in gs[1:])
+        flat = torch.cat(pieces)
+        if again:
+            off, offs = 0, []
+            for t in pieces:
+                offs.append(off)
+                off += t.numel()
+            for i, g in again:
+                flat[offs[i]:offs[i] + g.numel()].add_(g.reshape(-1).float())
+        return flat
+
+    def _reduce(self, flat):
+        if self.world > 1 or dist.is_initialized():
+            dist.all_reduce(flat, group=self.group)
+            self.collectives += 1

@@ -95,6 +95,9 @@ class deferred_counters:
         return False
 
 
+COLLECTIVES = 0                  # SyncBatchNorm statistics all-reduces issued so far by the hand-written kernels' host code
+COLLECTIVES_LAST_STEP = 0        # ... during the last PQ_Transformer forward + backward (set by deferred_wgrads.__exit__)
+_COLLECTIVES_MARK = 0
 _FORCE_COLLECTIVES = False       # test hook: issue the SyncBatchNorm all-reduces even over a 1-rank group
 
 
@@ -104,6 +107,8 @@ def _allreduce_(sums, world=None):
     if world is None:
         world = _world()
     if world > 1 or (_FORCE_COLLECTIVES and dist.is_initialized()):
+        global COLLECTIVES
+        COLLECTIVES += 1
         dist.all_reduce(sums)
     return sums
 
@@ -388,6 +393,33 @@ def bias_target_ok(bt, C, Cp):
     return bt is not None and (Cp == C or bt[0] == "parts" or (bt[2] == 0 and bt[1].numel() == C))
 
 
+# Parameters of every DistributedDataParallel module that has run a forward pass in this process.  DDP reduces gradients
+# from per-parameter autograd hooks; a gradient written behind autograd's back never reaches them, so the ranks would
+# silently train on their local gradients.  A global forward pre-hook records DDP-wrapped parameters; deferred_wgrads
+# refuses them (use data_parallel.GradientBuckets on the bare module, or stay outside deferred_wgrads under DDP).
+_DDP_PARAM_IDS = set()
+
+
+def _note_ddp(module, _args):
+    if isinstance(module, torch.nn.parallel.DistributedDataParallel):
+        for p in module.parameters():
+            _DDP_PARAM_IDS.add(id(p))
+
+
+torch.nn.modules.module.register_module_forward_pre_hook(_note_ddp)
+
+
+def _refuse_ddp(wt):
+    if not _DDP_PARAM_IDS or wt is None:
+        return
+    params = [wt[1]] if wt[0] == "param" else [q[0] for q in wt[1]]
+    if any(id(p) in _DDP_PARAM_IDS for p in params):
+        raise RuntimeError(
+            "sa_fused.deferred_wgrads: this parameter belongs to a DistributedDataParallel module -- its gradient would "
+            "bypass DDP's reduction hooks.  Run backward outside deferred_wgrads under DDP, or keep the module bare and "
+            "reduce with data_parallel.GradientBuckets")
+
+
 class deferred_wgrads:
     """`with deferred_wgrads(): loss.backward()` -- inside the block the rows engine does not launch the weight
     (and bias) gradient of a linear layer whose weight is a Parameter (a row range of one, or a cat_params of
@@ -398,6 +430,11 @@ class deferred_wgrads:
     Tensor hooks on those parameters do not fire (DistributedDataParallel relies on them: do not combine the
     two)."""
     active = None
+
+    def __init__(self, on_early_flush=None):
+        """on_early_flush(dfr): called on the side stream right after an early flush (`flush_on`) has launched -- the
+        gradients collected up to that point are final; data_parallel.GradientBuckets starts their all-reduce there."""
+        self.on_early_flush = on_early_flush
 
     def __enter__(self):
         if deferred_wgrads.active is not None:
@@ -414,6 +451,7 @@ class deferred_wgrads:
 
     def add(self, dY, X, M, N, P, wt, crop, bt, below=None):
         """below: X is that layer's pre-BN output and stands for relu(below.a * X + below.b)"""
+        _refuse_ddp(wt)
         self.items.append((dY, X, M, N, P, wt, crop, bt, None if below is None else (below.a, below.b)))
 
     def add_sa(self, dY, X, M, N, P, wt, crop, below=None):
@@ -421,10 +459,13 @@ class deferred_wgrads:
         as ONE grouped launch for all stages when the block ends.  One by one these GEMMs are split into ~512
         workgroups each -- two per CU, the launch's tail and its slab reduction paid 14 times per step; together
         they fill the chip with ~4000 workgroups cut for balance.  crop = (cout, cin, rot): see omnipq_tn_problem."""
+        _refuse_ddp(wt)
         self.sa_items.append((dY, X, M, N, P, wt, crop, None, None if below is None else (below.a, below.b)))
 
     def __exit__(self, et, ev, tb):
         deferred_wgrads.active = None
+        global COLLECTIVES_LAST_STEP, _COLLECTIVES_MARK
+        COLLECTIVES_LAST_STEP, _COLLECTIVES_MARK = COLLECTIVES - _COLLECTIVES_MARK, COLLECTIVES
         if et is None:
             self.flush()
         # early flushes run on side streams: join them on BOTH paths (after an exception their launches must not
@@ -456,8 +497,10 @@ class deferred_wgrads:
             streams.append(stream)
         with torch.cuda.stream(stream):
             self.flush()
-        self.items = []
-        self.ln_items = []
+            self.items = []
+            self.ln_items = []
+            if self.on_early_flush is not None:
+                self.on_early_flush(self)
 
 
     def _flush_layernorms(self):

@@ -80,6 +80,56 @@ def _worker(rank, world, port, out_dir):
         assert torch.allclose(got_flat, want, rtol=1e-6, atol=1e-8), float((got_flat - want).abs().max())
         assert all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in solo.parameters())
 
+        # 2c) the bucketed reduction of the deferred-gradient step (omni-pq_amd/data_parallel.py): bucket 0 (everything
+        # but `backbone`) reduced from the early flush -- part of it handed over as deferred (parameter, buffer) pairs,
+        # part of it sitting in .grad -- bucket 1 when the block has ended; result == DDP's averaging
+        import data_parallel
+
+        class Two(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.backbone = torch.nn.Linear(6, 5)
+                self.head = torch.nn.Linear(5, 3)
+                self.extra = torch.nn.Linear(3, 2)
+
+        two = Two()
+        gen = torch.Generator().manual_seed(300 + rank)
+        local = {n: torch.randn(p.shape, generator=gen) for n, p in two.named_parameters()}
+        stacked = {n: [torch.empty_like(g) for _ in range(world)] for n, g in local.items()}
+        for n, g in local.items():
+            dist.all_gather(stacked[n], g)
+        buckets = data_parallel.GradientBuckets(two, world)
+        assert [len(b) for b in buckets.buckets] == [4, 2]
+
+        class FakeBlock:                       # what deferred_wgrads looks like to the early-flush callback
+            _assign = None
+        blk = FakeBlock()
+        # head.weight: half in .grad, half deferred; head.bias: deferred only; extra.*: .grad only; backbone: later
+        two.head.weight.grad = 0.5 * local["head.weight"]
+        blk._assign = [(two.head.weight, 0.5 * local["head.weight"]), (two.head.bias, local["head.bias"].clone()),
+                       (two.backbone.weight, local["backbone.weight"].clone())]
+        two.extra.weight.grad, two.extra.bias.grad = local["extra.weight"].clone(), local["extra.bias"].clone()
+        buckets.on_early_flush(blk)
+        assert buckets.early_done and buckets.collectives == 1
+        assert [p is two.backbone.weight for p, _ in blk._assign] == [True]          # bucket-1 entries stay with the block
+        two.backbone.weight.grad, two.backbone.bias.grad = blk._assign[0][1], local["backbone.bias"].clone()
+        buckets.finish()
+        assert buckets.collectives == 2
+        for n, p in two.named_parameters():
+            want_n = torch.stack(stacked[n]).mean(0)
+            assert torch.allclose(p.grad, want_n, rtol=1e-6, atol=1e-7), n
+
+        # 2d) deferred_wgrads refuses parameters of a DistributedDataParallel module (their hooks would never fire)
+        with sa_fused.deferred_wgrads() as blk2:
+            w = net.fp.mlp.layer0.conv.weight            # `net` ran a forward pass under DDP above
+            try:
+                blk2.add(None, None, 8, 8, 8, ("param", w, 0), (8, 8), None)
+                raise AssertionError("a DDP-wrapped parameter was accepted")
+            except RuntimeError as err:
+                assert "DistributedDataParallel" in str(err)
+            blk2.add(torch.zeros(8, 8), torch.zeros(8, 8), 8, 8, 8, ("param", two.head.weight, 0), (8, 8), None)
+            blk2.items.clear()                           # (nothing to launch on the CPU)
+
         # 3) the statistics all-reduce of the fused SA stage (SyncBatchNorm semantics)
         sums = torch.full((2, 5), float(rank + 1), dtype=torch.float64)
         sa_fused._allreduce_(sums)

@@ -84,6 +84,15 @@ def test_pipeline_delivers_the_batches_and_their_sampling_plans():
         assert a.keys() == b.keys() and len(a) >= 3
         for k in a:
             assert torch.equal(a[k], b[k]), k
+    # ... and both are what the ORACLE samples from the HOST copy of each batch (restatement of sampling_gpu.cu:74-178):
+    # the chain 8192 -> 2048 -> 1024, indices of each level taken among the previous level's picks
+    from oracle import oracle_ext
+    for h, a in zip(host, got):
+        i1 = oracle_ext.furthest_point_sampling(h, 2048)
+        assert torch.equal(a["sa1_inds"].cpu(), i1)
+        lvl1 = torch.gather(h, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        assert torch.equal(a["sa2_inds"].cpu(), oracle_ext.furthest_point_sampling(lvl1, 1024))
+        assert torch.equal(a["fp2_inds"].cpu(), i1[:, :1024])
     with pytest.raises(RuntimeError):
         pipe.pop()
     pipe.push(host[0])
