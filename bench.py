@@ -61,7 +61,7 @@ def parse():
                          "(utils/pc_util.py:36-44) in --loader-workers threads, staged in pinned memory and copied to the "
                          "device inside the timed region; the sampling plan is prefetched behind the copy.  The headline "
                          "`value` keeps its definition (inputs resident): this mode reports the host-inclusive rate")
-    ap.add_argument("--loader-workers", type=int, default=4, help="host threads sub-sampling scenes (a DataLoader's workers)")
+    ap.add_argument("--loader-workers", type=int, default=8, help="DataLoader worker processes sub-sampling scenes")
     ap.add_argument("--raw-points", type=int, default=60000, help="points per raw scene before random_sampling")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
                     help="A/B runs on one box: set a module-level switch before the model is built, e.g. "
@@ -449,71 +449,52 @@ class FlatGradients:
             off += n
 
 
+class _RawScenes(torch.utils.data.Dataset):
+    """What the reference's dataset does per item for the model's input (scannet_detection_dataset.py:86-312, reduced to
+    the cloud): take a raw scene and sub-sample it to `points` rows with utils/pc_util.py:36-44's random_sampling (numpy's
+    global RNG: every DataLoader worker process has its own)."""
+
+    def __init__(self, raw, points, length=1 << 30):
+        self.raw, self.points, self.length = raw, points, length
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        import input_pipeline
+        return torch.from_numpy(input_pipeline.random_sampling(self.raw[i % len(self.raw)], self.points))
+
+
 class HostFeeder:
-    """The input side of the step on the host: `workers` threads turn raw scenes into batches with the
-    reference's per-scene `random_sampling` (what its Dataset.__getitem__ does inside DataLoader workers,
-    scannet_detection_dataset.py / utils/pc_util.py:36-44), the main thread stages one batch per step in pinned memory
-    and issues the host-to-device copy on the step's stream.  Three pinned buffers: a buffer is rewritten only after the
-    copy that read it has completed (event)."""
+    """The input side of the step on the host, as the reference has it (train.py:230-275, 465-472): a
+    torch DataLoader whose `workers` processes sub-sample raw scenes (random_sampling per item) and collate batches,
+    its pin-memory thread stages them, and the step issues ONE host-to-device copy on its own stream into the static
+    buffer the captured step (and the next sampling plan) reads."""
 
     def __init__(self, args, device, rank):
-        import queue
-        import threading
-        import numpy as np
-        import input_pipeline
         import synth
         self.device = device
         raw = [synth.make_clouds(500 + i, 1, args.raw_points, extra_channels=args.extra_channels, kind="room",
                                  first_scene=rank * 16 + i)[0].numpy() for i in range(max(8, args.batch))]
-        shape = (args.batch, args.points, 3 + args.extra_channels)
-        self.pinned = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(3)]
-        self.free = [None, None, None]
-        self.n = 0
-        self.q = queue.Queue(maxsize=4)
-        self.stop = False
+        self.loader = torch.utils.data.DataLoader(_RawScenes(raw, args.points), batch_size=args.batch, shuffle=False,
+                                                  num_workers=args.loader_workers, pin_memory=True,
+                                                  persistent_workers=args.loader_workers > 0,
+                                                  prefetch_factor=4 if args.loader_workers > 0 else None)
+        self.it = iter(self.loader)
+        self.keep = collections.deque(maxlen=3)      # pinned batches whose copy may still be in flight
         self.host_wait_s = 0.0
-
-        def work(seed):
-            rng_lock.acquire()
-            np.random.seed(seed)               # random_sampling draws from numpy's global RNG (as the reference's does)
-            rng_lock.release()
-            i = seed
-            while not self.stop:
-                scenes = []
-                for b in range(args.batch):
-                    with rng_lock:
-                        scenes.append(input_pipeline.random_sampling(raw[(i + b) % len(raw)], args.points))
-                i += args.batch
-                batch = torch.from_numpy(np.stack(scenes).astype(np.float32, copy=False))
-                while not self.stop:
-                    try:
-                        self.q.put(batch, timeout=0.1)
-                        break
-                    except queue.Full:
-                        pass
-
-        rng_lock = threading.Lock()
-        self.threads = [threading.Thread(target=work, args=(1000 + w,), daemon=True) for w in range(args.loader_workers)]
-        for t in self.threads:
-            t.start()
 
     def next_into(self, dst):
         """dst (device, static buffer) <- the next host batch, asynchronously on the current stream."""
         t0 = time.perf_counter()
-        host = self.q.get()
-        k = self.n % 3
-        self.n += 1
-        if self.free[k] is not None:
-            self.free[k].synchronize()
-        self.pinned[k].copy_(host)
+        host = next(self.it)
         self.host_wait_s += time.perf_counter() - t0
-        dst.copy_(self.pinned[k], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.free[k] = ev
+        dst.copy_(host, non_blocking=True)
+        self.keep.append(host)
 
     def close(self):
-        self.stop = True
+        self.it = None
+        self.loader = None
 
 
 EMA_DECAY, EMA_STEP = 0.999, 100_000          # steady state of train.py:437: alpha = min(1 - 1/(step+1), 0.999) = 0.999
@@ -656,6 +637,11 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
+            # let the process group's watchdog thread retire the warm-up steps' collectives before the capture starts: it
+            # polls their completion events every ~100 ms, and a poll that overlaps the beginning of the capture has been
+            # seen to abort the process ("operation not permitted on an event last recorded in a capturing stream")
+            # -- measured round 3 on a 1-rank group: 2 of 4 runs aborted without the pause, 0 of 6 with it
+            time.sleep(1.5)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         import sa_fused
         sa_fused.reset_pools()
@@ -851,11 +837,11 @@ def main():
             "launch": "hipGraph replay" if use_graph else "eager",
             "input": ("resident: a pool of batches in HBM before the timed region (3.84 MB device-to-device per step inside it)"
                       if args.feeder is None else
-                      f"host pipeline INSIDE the timed region: random_sampling {args.raw_points} -> {args.points} points per "
-                      f"scene in {args.loader_workers} host threads, pinned staging, one host-to-device copy of "
-                      f"{args.batch * args.points * (3 + args.extra_channels) * 4 / 1e6:.2f} MB per step; the main thread "
-                      f"spent {1e3 * args.feeder.host_wait_s / max(args.steps + args.warmup, 1):.3f} ms per step waiting for "
-                      "/ staging batches"),
+                      f"host pipeline INSIDE the timed region: torch DataLoader, {args.loader_workers} worker processes doing "
+                      f"random_sampling {args.raw_points} -> {args.points} points per scene, pinned batches, one "
+                      f"host-to-device copy of {args.batch * args.points * (3 + args.extra_channels) * 4 / 1e6:.2f} MB per "
+                      f"step; the main thread waited {1e3 * args.feeder.host_wait_s / max(args.steps + args.warmup, 1):.3f} "
+                      "ms per step for the loader"),
             "data_parallel": (None if not distributed else
                               (f"{dp_counts}, all inside the graph (RCCL graph probe passed)"
                                if use_graph else

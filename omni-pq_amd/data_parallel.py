@@ -21,6 +21,9 @@ import torch
 import torch.distributed as dist
 
 
+EARLY_BUCKET = True        # False: both buckets are reduced when the block has ended (A/B and debugging)
+
+
 def _backbone_param_ids(net):
     bb = getattr(net, "backbone", None)
     return {id(p) for p in bb.parameters()} if bb is not None else set()
@@ -40,7 +43,7 @@ class GradientBuckets:
     def on_early_flush(self, dfr):
         """Bucket 0 is complete: autograd has accumulated its share into `.grad` (the side stream waited for the main
         stream), the deferred share sits in `dfr._assign` as (parameter, f32 buffer) pairs computed on this stream."""
-        if self.early_done or self.world < 1:
+        if self.early_done or not EARLY_BUCKET:
             return
         mine = {id(p) for p in self.buckets[0]}
         assign = getattr(dfr, "_assign", None) or []
