@@ -32,6 +32,7 @@ from utils.pointnet_util import FPSModule  # noqa: E402
 from utils import fused_attention  # noqa: E402
 from pointnet2_modules import PointnetSAModuleVotes  # noqa: E402
 from voting_module import VotingModule  # noqa: E402
+import rows_f32  # noqa: E402
 import rows_mlp  # noqa: E402
 import sa_fused  # noqa: E402
 from sa_fused import E16  # noqa: E402
@@ -54,7 +55,7 @@ def lin(x2d, conv):
     stack = [rows_mlp.Layer(conv.weight, conv.bias)]
     if rows_mlp.usable(x2d, stack, conv.training):
         return rows_mlp.run(x2d, stack, conv.training)          # bf16 MFMA GEMM, weight gradient deferrable
-    return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
+    return rows_f32.linear(x2d, conv.weight, conv.bias)         # f32 mode: hand-written split-f32 GEMM on a GPU
 
 
 def conv1x1_pair(xa, conv_a, xb, conv_b):
@@ -101,9 +102,9 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
         _head_bias(self, stack, heads, w, raw, net.is_cuda)
         y = rows_mlp.run(x, stack, self.training, padded=raw)
     else:
-        x = F.relu(self.bn1(lin(x, self.conv1)))
-        x = F.relu(self.bn2(lin(x, self.conv2)))
-        y = F.linear(x, w, torch.cat([h.bias for h in heads], 0))
+        x = rows_f32.bn_act(lin(x, self.conv1), self.bn1)
+        x = rows_f32.bn_act(lin(x, self.conv2), self.bn2)
+        y = rows_f32.linear(x, w, torch.cat([h.bias for h in heads], 0))
     if raw:
         return y                                         # (B*K, >= sum of head widths) rows
     return list(torch.split(y.view(B, K, -1), [h.out_channels for h in heads], dim=2))
@@ -416,7 +417,7 @@ class PositionEmbeddingLearned(nn.Module):
         if rows_mlp.usable(x, stack, self.training):
             x = rows_mlp.run(x, stack, self.training)
         else:
-            x = lin(head[2](head[1](lin(x, head[0]))), head[3])
+            x = lin(rows_f32.bn_act(lin(x, head[0]), head[1]), head[3])
         return x.view(B, P, -1).transpose(1, 2)
 
 

@@ -19,6 +19,7 @@ if _HERE not in sys.path:
 
 from utils.multi_head_attention import MultiheadAttention  # noqa: E402
 import decoder_rows  # noqa: E402
+import rows_f32  # noqa: E402
 
 _USE_ROWS = os.environ.get("OMNIPQ_DECODER", "rows") != "torch"
 
@@ -75,6 +76,7 @@ class TransformerDecoderLayer(nn.Module):
         att = self.multihead_attn(self.with_pos_embed(x, q_pe), mem_pe, mem_pe, need_weights=False)[0]
         x = self.norm2(x + self.dropout2(att))
 
-        ffn = self.linear2(self.dropout(self.activation(self.linear1(x))))
+        h = rows_f32.linear(x, self.linear1.weight, self.linear1.bias)      # (f32 mode on a GPU: hand-written GEMMs)
+        ffn = rows_f32.linear(self.dropout(self.activation(h)), self.linear2.weight, self.linear2.bias)
         x = self.norm3(x + self.dropout3(ffn))
         return x.permute(1, 2, 0)

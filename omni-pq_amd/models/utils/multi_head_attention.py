@@ -22,6 +22,7 @@ from torch.nn.init import constant_, xavier_normal_, xavier_uniform_
 from torch.nn.parameter import Parameter
 
 from utils import fused_attention  # noqa: E402  (hand-written attention kernels; GPU bf16 only)
+import rows_f32  # noqa: E402  (f32 mode: projections on the hand-written split-f32 GEMM; F.linear elsewhere)
 
 _USE_FUSED = os.environ.get("OMNIPQ_ATTN", "fused") != "torch"
 
@@ -60,13 +61,13 @@ class MultiheadAttention(Module):
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
         if (query is key) and (key is value):
-            return F.linear(query, w, b).chunk(3, dim=-1)
-        q = F.linear(query, w[:E], None if b is None else b[:E])
+            return rows_f32.linear(query, w, b).chunk(3, dim=-1)
+        q = rows_f32.linear(query, w[:E], None if b is None else b[:E])
         if key is value:
-            k, v = F.linear(key, w[E:], None if b is None else b[E:]).chunk(2, dim=-1)
+            k, v = rows_f32.linear(key, w[E:], None if b is None else b[E:]).chunk(2, dim=-1)
         else:
-            k = F.linear(key, w[E:2 * E], None if b is None else b[E:2 * E])
-            v = F.linear(value, w[2 * E:], None if b is None else b[2 * E:])
+            k = rows_f32.linear(key, w[E:2 * E], None if b is None else b[E:2 * E])
+            v = rows_f32.linear(value, w[2 * E:], None if b is None else b[2 * E:])
         return q, k, v
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None,
@@ -81,14 +82,14 @@ class MultiheadAttention(Module):
             # on the probabilities (reference :375-391).
             if _USE_FUSED and fused_attention.usable(q, k, v, H):
                 out = fused_attention.attention(q, k, v, H, self.dropout if self.training else 0.0)
-                return F.linear(out, self.out_proj.weight, self.out_proj.bias), None
+                return rows_f32.linear(out, self.out_proj.weight, self.out_proj.bias), None
             S = k.shape[0]
             qh = q.reshape(L, N, H, D).permute(1, 2, 0, 3)
             kh = k.reshape(S, N, H, D).permute(1, 2, 0, 3)
             vh = v.reshape(S, N, H, D).permute(1, 2, 0, 3)
             out = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=self.dropout if self.training else 0.0)
             out = out.permute(2, 0, 1, 3).reshape(L, N, E)
-            return F.linear(out, self.out_proj.weight, self.out_proj.bias), None
+            return rows_f32.linear(out, self.out_proj.weight, self.out_proj.bias), None
         q = q * (float(D) ** -0.5)
         q = q.contiguous().view(L, N * H, D).transpose(0, 1)
         k = k.contiguous().view(-1, N * H, D).transpose(0, 1)
@@ -105,7 +106,7 @@ class MultiheadAttention(Module):
         probs = F.dropout(probs, p=self.dropout, training=self.training)
         out = torch.bmm(probs, v)                                 # (N*H, L, D)
         out = out.transpose(0, 1).contiguous().view(L, N, E)
-        out = F.linear(out, self.out_proj.weight, self.out_proj.bias)
+        out = rows_f32.linear(out, self.out_proj.weight, self.out_proj.bias)
         if need_weights:
             return out, probs.view(N, H, L, S).sum(dim=1) / H
         return out, None

@@ -16,6 +16,7 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
     if _p not in sys.path:
         sys.path.append(_p)
 
+import rows_f32  # noqa: E402
 import rows_mlp  # noqa: E402
 from sa_fused import E16  # noqa: E402
 
@@ -26,7 +27,7 @@ _FUSED_TAIL = True      # False: the op-by-op tail (tests compare the two)
 def _lin(x2d, conv):
     """kernel-size-1 Conv1d applied to rows (points x channels): one GEMM with the bias in its epilogue
     (see models/pq_transformer.py:lin)."""
-    return F.linear(x2d, conv.weight.squeeze(-1), conv.bias)
+    return rows_f32.linear(x2d, conv.weight, conv.bias)        # f32 mode: hand-written split-f32 GEMM on a GPU
 
 
 class VoteDecode(torch.autograd.Function):
@@ -109,8 +110,8 @@ class VotingModule(nn.Module):
         if rows_mlp.usable(x, stack, self.training):
             net = rows_mlp.run(x, stack, self.training)
         else:
-            net = F.relu(self.bn1(_lin(x, self.conv1)))
-            net = F.relu(self.bn2(_lin(net, self.conv2)))
+            net = rows_f32.bn_act(_lin(x, self.conv1), self.bn1)
+            net = rows_f32.bn_act(_lin(net, self.conv2), self.bn2)
             net = _lin(net, self.conv3)
         net = net.view(B, K, vf, 3 + C)                         # the reference's transpose(2,1).view
         offset, residual = torch.split(net, [3, C], dim=-1)      # (one cat in backward instead of two zero-fills)

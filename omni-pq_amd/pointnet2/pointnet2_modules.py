@@ -170,7 +170,7 @@ class PointnetSAModuleVotes(nn.Module):
         grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None
         grouped_features, grouped_xyz = grouped[0], grouped[1]
-        new_features = self._pool(self.mlp_module(grouped_features), grouped_xyz)
+        new_features = self._pool(_shared_mlp(self.mlp_module, grouped_features), grouped_xyz)
         if self.ret_unique_cnt:
             return new_xyz, new_features, inds, unique_cnt
         return new_xyz, new_features, inds
@@ -192,6 +192,19 @@ class PointnetSAModuleMSGVotes(nn.Module):
         return new_xyz, torch.cat(pooled, dim=1), inds
 
 
+def _shared_mlp(shared_mlp, x):
+    """SharedMLP on (B, C, M, S).  f32 mode on a GPU: the layers run on position-major rows through the hand-written
+    split-f32 GEMM and row BatchNorm (rows_f32) instead of Conv2d / BatchNorm2d library kernels -- same arithmetic
+    (reference pytorch_utils.py:11-36: 1x1 convolutions), the result comes back as a (B, C_out, M, S) view of the rows."""
+    import rows_f32
+    if x.dim() == 4 and rows_f32.enabled(x):
+        B, C, M, S = x.shape
+        y = _rows_mlp(shared_mlp, x.permute(0, 2, 3, 1).reshape(B * M * S, C))
+        if y is not None:
+            return y.view(B, M, S, -1).permute(0, 3, 1, 2)
+    return shared_mlp(x)
+
+
 def _rows_mlp(shared_mlp, x_rows):
     """Run a SharedMLP whose layers are plain [1x1 Conv2d (no bias), BatchNorm2d, ReLU] on row-major
     activations (points x channels): per layer one F.linear + BatchNorm over the rows + ReLU.  Same
@@ -210,13 +223,10 @@ def _rows_mlp(shared_mlp, x_rows):
     stack = [rows_mlp.Layer(conv.weight, None, bn) for conv, bn in plan]
     if rows_mlp.usable(x_rows, stack, shared_mlp.training):
         return rows_mlp.run(x_rows, stack, shared_mlp.training)        # hand-written MFMA / BN kernels
+    import rows_f32
     for conv, bn in plan:
-        y = F.linear(x_rows, conv.weight.view(conv.out_channels, -1))
-        if isinstance(bn, nn.BatchNorm2d):           # wants 4-D: (N, C) -> (N, C, 1, 1) is a free view
-            y = bn(y.view(y.shape[0], y.shape[1], 1, 1)).view(y.shape[0], y.shape[1])
-        else:                                        # SyncBatchNorm (after conversion) takes rows as is
-            y = bn(y)
-        x_rows = F.relu(y)
+        # f32 mode: on a GPU the hand-written split-f32 GEMM and row BatchNorm (rows_f32), otherwise F.linear + torch's BN
+        x_rows = rows_f32.bn_act(rows_f32.linear(x_rows, conv.weight), bn)
     return x_rows
 
 
