@@ -40,18 +40,40 @@ def _load_into(module, state):
     module.load_state_dict(fixed, strict=False)
 
 
-def load_checkpoint(args, model, optimizer, scheduler, **kwargs):
+def _read(path, trust_pickle):
+    """The reference's checkpoints hold an argparse.Namespace (`config`) next to tensors, and some an entire pickled EMA
+    module.  Try the safe loader first (tensors, containers, Namespace); only an explicit `trust_pickle=True` falls
+    back to full unpickling -- which executes code from the file."""
+    import argparse
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as safe_err:
+        if not trust_pickle:
+            raise RuntimeError(
+                f"{path}: not loadable with weights_only=True ({type(safe_err).__name__}: {safe_err}).  If the file "
+                "comes from a source you trust (e.g. it pickles a whole EMA module, train.py:181-207), pass "
+                "trust_pickle=True to load_checkpoint") from safe_err
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load_checkpoint(args, model, optimizer, scheduler, trust_pickle=False, **kwargs):
     """Restore model / optimizer / scheduler (and `ema_model=` when args.ema) from args.checkpoint_path; sets
-    args.start_epoch to the epoch after the saved one ('last' counts as 600, 'best' as 0, as in the reference)."""
-    checkpoint = torch.load(args.checkpoint_path, map_location='cpu', weights_only=False)
+    args.start_epoch to the epoch after the saved one ('last' counts as 600, 'best' as 0, as in the reference).
+    A state the file holds but no object was given for (optimizer=None / scheduler=None) is skipped with a warning."""
+    import warnings
+    checkpoint = _read(args.checkpoint_path, trust_pickle)
     epoch = checkpoint['epoch']
     epoch = {'last': 600, 'best': 0}.get(epoch, epoch)
     args.start_epoch = epoch + 1
     _load_into(model, checkpoint['model'])
-    if optimizer is not None and checkpoint.get('optimizer') is not None:
-        optimizer.load_state_dict(checkpoint['optimizer'])
-    if scheduler is not None and checkpoint.get('scheduler') is not None:
-        scheduler.load_state_dict(checkpoint['scheduler'])
+    for name, obj in (('optimizer', optimizer), ('scheduler', scheduler)):
+        if obj is not None and checkpoint.get(name) is not None:
+            obj.load_state_dict(checkpoint[name])
+        elif checkpoint.get(name) is not None:
+            warnings.warn(f"load_checkpoint: the file holds a {name} state but no {name} was given; it is NOT restored")
+        elif obj is not None:
+            warnings.warn(f"load_checkpoint: no {name} state in the file; the given {name} keeps its own")
     if getattr(args, 'ema', False) and 'ema_model' in kwargs:
         _load_into(kwargs['ema_model'], checkpoint['ema_model'] if 'ema_model' in checkpoint else checkpoint['model'])
     return epoch

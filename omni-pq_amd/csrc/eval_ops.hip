@@ -158,7 +158,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms3d_kernel(int k, const double 
   if (cls) cls += (size_t)b * k;
   if (threadIdx.x == 0) n_live = 0;
   for (int j = (int)threadIdx.x; j < k; j += kNmsThreads) {
-    sc[j] = score[j];
+    // a NaN score (a diverged checkpoint) must not break the ranking below, which needs a total order: it sorts last, like
+    // the reference's np.argsort puts it, by standing for -inf (ties among them fall back to the index rule)
+    const float sv = score[j];
+    sc[j] = (sv != sv) ? -INFINITY : sv;
     dead[j] = valid ? (valid[j] ? 0 : 1) : 0;
     keep[j] = 0;
   }

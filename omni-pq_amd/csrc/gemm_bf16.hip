@@ -16,6 +16,7 @@
 // The C tile leaves through LDS so that global stores are 16 B per lane along rows.
 // blockIdx is remapped so that the N-tiles of one M-tile run on the same XCD (A-tile re-reads hit
 // that XCD's L2 instead of going back to HBM once per N-tile).
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -878,7 +879,7 @@ static bool gemm_nt_kres(int K) { return K <= omnipq::kResMaxSteps * omnipq::GBK
 // variant, omnipq_pair_flush()) sends the held one out on its own first.  The caller guarantees the two are independent
 // and issues nothing else in between.
 static thread_local omnipq::HeldLaunch t_held;
-static long long t_pairs_launched = 0;
+static std::atomic<long long> t_pairs_launched{0};      // written by the forward thread and the autograd thread
 namespace omnipq {
 HeldLaunch &held_launch() { return t_held; }
 void count_pair_launch() { ++t_pairs_launched; }

@@ -176,7 +176,8 @@ class Oracle64:
     def group_points(points, idx):
         B, C, _ = points.shape
         flat = idx.long().reshape(B, 1, -1).expand(-1, C, -1)
-        return torch.gather(points, 2, flat).reshape(B, C, idx.shape[1], idx.shape[2])
+        # (a fresh tensor, not a view: the reference modifies the grouped coordinates in place, pointnet2_utils.py:350)
+        return torch.gather(points, 2, flat).reshape(B, C, idx.shape[1], idx.shape[2]).clone()
 
     @staticmethod
     def group_points_grad(grad_out, idx, n):

@@ -126,6 +126,72 @@ def stage_case(name, xyz):
         else:
             out["grad." + k] = summarize(p.grad, max_full=GRAD_SAMPLES)
             out["gradnorm." + k] = float(p.grad.double().norm())
+    # ---- the same forced forward + backward in float64 (index decisions from the f32 oracle, as make_golden.py's
+    # Oracle64): how far the reference's OWN f32 gradients are from exact.  Parameter gradients of small BatchNorm layers
+    # are sums of a few hundred terms that cancel to 1e-3 of their size; an implementation that accumulates statistics in
+    # f64 lands on the f64 value, not on the reference's f32 rounding of it.
+    forced_vals = {k: v.detach().double() for k, v in forced.items()}
+    for prm in net.parameters():
+        prm.grad = None
+    net64 = net.double()
+    for m in net64.modules():
+        if hasattr(m, "_means"):
+            m._means = None
+    own64, handles = {}, []
+
+    def force64(key, t):
+        own64[key] = t
+        return forced_vals[key].clone().requires_grad_(True)
+
+    for sa in BOUNDARY_SA:
+        handles.append(getattr(net64.backbone, sa).register_forward_hook(
+            lambda _m, _i, out, sa=sa: (out[0], force64(sa + "_features", out[1]), out[2])))
+    for fp in BOUNDARY_FP:
+        handles.append(getattr(net64.backbone, fp).register_forward_hook(
+            lambda _m, _i, out, fp=fp: force64(fp + "_features", out)))
+
+    def agg_pre64(_m, args):
+        own64["vote_xyz"], own64["vote_features"] = args[0], args[1]
+        return (forced_vals["vote_xyz"].clone().requires_grad_(True),
+                forced_vals["vote_features"].clone().requires_grad_(True)) + tuple(args[2:])
+    handles.append(net64.vote_aggregation.register_forward_pre_hook(agg_pre64))
+    handles.append(net64.vote_aggregation.register_forward_hook(
+        lambda _m, _i, out: (out[0], force64("cluster_feature", out[1]), out[2])))
+    for i in range(6):
+        handles.append(net64.decoder[i].register_forward_hook(
+            lambda _m, _i, out, i=i: force64(f"decoder{i}_query", out)))
+    mg.ref_utils._ext = mg.Oracle64            # (stays plugged in through backward: the grad kernels are looked up at call time)
+    ep64 = net64({"point_clouds": xyz.double()})
+    for h in handles:
+        h.remove()
+    loss64 = 0.0
+    for k in sorted(own64):
+        loss64 = loss64 + (own64[k] * upstream(k, own64[k]).double()).sum()
+    skip64 = {id(v) for v in own64.values()}
+    for k in sorted(ep64):
+        v = ep64[k]
+        if v.is_floating_point() and v.requires_grad and v.grad_fn is not None and id(v) not in skip64:
+            loss64 = loss64 + (v * upstream("ep." + k, v).double()).sum()
+    loss64.backward()
+    mg.ref_utils._ext = mg.oracle_ext
+    out["loss64"] = float(loss64)
+    worst = (0.0, "")
+    for k, prm in net64.named_parameters():
+        if prm.grad is None or out.get("grad." + k) is None:
+            continue
+        g64 = prm.grad
+        out["grad64." + k] = summarize(g64.float(), max_full=GRAD_SAMPLES)
+        ref32 = out["grad." + k]
+        flat = g64.reshape(-1)
+        have = flat if "full" in ref32 else flat[::ref32["stride"]]
+        want = (ref32["full"] if "full" in ref32 else ref32["sample"]).double()
+        noise = float((want - have).norm() / (have.norm() + 1e-300))
+        out["grad_f32_vs_f64." + k] = noise
+        if out["gradnorm." + k] > 1e-5 * max(out[q] for q in out if q.startswith("gradnorm.")) and noise > worst[0]:
+            worst = (noise, k)
+    print(f"{name}: loss f32 {float(loss):.6f} / f64 {float(loss64):.6f}; the reference's own f32 gradients are up to "
+          f"{worst[0]:.2e} (rel-L2, {worst[1]}) away from its f64 gradients")
+
     inputs = {"point_clouds": xyz}
     for k, v in forced.items():
         inputs["forced." + k] = v.detach().clone() if k == "vote_xyz" else v.detach().to(torch.bfloat16)

