@@ -83,6 +83,10 @@ class MultiheadAttention(Module):
             if _USE_FUSED and fused_attention.usable(q, k, v, H):
                 out = fused_attention.attention(q, k, v, H, self.dropout if self.training else 0.0)
                 return rows_f32.linear(out, self.out_proj.weight, self.out_proj.bias), None
+            if rows_f32.enabled(q):
+                # f32 mode: the two products per (batch, head) on the hand-written split-f32 GEMM as well
+                out = rows_f32.attention_core(q, k, v, H, self.dropout if self.training else 0.0)
+                return rows_f32.linear(out, self.out_proj.weight, self.out_proj.bias), None
             S = k.shape[0]
             qh = q.reshape(L, N, H, D).permute(1, 2, 0, 3)
             kh = k.reshape(S, N, H, D).permute(1, 2, 0, 3)

@@ -107,6 +107,45 @@ def linear(x, weight, bias=None):
     return y.reshape(*lead, y.shape[-1])
 
 
+class _MatmulNT(torch.autograd.Function):
+    """C = A B^T for two f32 matrices that both carry gradients (the attention core's two products)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm_nt(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = gemm_nt(g, b.t().contiguous()) if ctx.needs_input_grad[0] else None        # g B
+        db = gemm_tn(g, a) if ctx.needs_input_grad[1] else None                         # g^T A
+        return da, db
+
+
+def attention_core(q, k, v, num_heads, dropout_p=0.0):
+    """softmax(q k^T / sqrt(D)) v per (batch, head) for f32 q (L, N, E), k / v (S, N, E) -> (L, N, E): the attention
+    core of models/utils/multi_head_attention.py:375-391 in the f32 mode, its two products per (batch, head) on the
+    hand-written split-f32 GEMM (softmax and dropout are PyTorch elementwise kernels).  A parity path, not a fast one:
+    N * H pairs of small GEMMs per call -- the measured step runs the fused bf16 / fp16 attention kernels."""
+    L, N, E = q.shape
+    S = k.shape[0]
+    D = E // num_heads
+    scale = float(D) ** -0.5
+    qh = (q * scale).reshape(L, N * num_heads, D)
+    kh = k.reshape(S, N * num_heads, D)
+    vh = v.reshape(S, N * num_heads, D)
+    outs = []
+    for i in range(N * num_heads):
+        scores = _MatmulNT.apply(qh[:, i].contiguous(), kh[:, i].contiguous())          # (L, S)
+        probs = F.softmax(scores, dim=-1)
+        if dropout_p > 0.0:
+            probs = F.dropout(probs, p=dropout_p, training=True)
+        outs.append(_MatmulNT.apply(probs, vh[:, i].t().contiguous()))                  # (L, D)
+    return torch.stack(outs, dim=1).reshape(L, N, E)
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, rm, rv, nbt, momentum, eps, training, relu, sync, conv_bias):

@@ -91,12 +91,13 @@ def test_linear_and_row_batchnorm_match_float64_autograd(bn_cls, training):
 def test_f32_model_step_calls_no_library_linear_conv_or_batchnorm(monkeypatch):
     """One f32 forward + backward of the whole model on the GPU: every 1x1 convolution / linear layer and every
     BatchNorm goes through the hand-written f32 path -- torch's F.linear, conv1d / conv2d and batch_norm are not called
-    once (the attention core's two batched products per attention are the library calls that remain: torch.bmm / SDPA)."""
+    once, and neither are torch.bmm / scaled_dot_product_attention (the attention core's products per (batch, head) run on
+    the split-f32 GEMM too: rows_f32.attention_core)."""
     import rows_f32
     import synth
     from procedural import load_procedural
     from test_oracle_golden import build_model
-    calls = {"linear": 0, "conv": 0, "batch_norm": 0}
+    calls = {"linear": 0, "conv": 0, "batch_norm": 0, "bmm": 0}
     real_linear, real_bn = F.linear, F.batch_norm
     real_c1, real_c2 = F.conv1d, F.conv2d
 
@@ -111,14 +112,36 @@ def test_f32_model_step_calls_no_library_linear_conv_or_batchnorm(monkeypatch):
     monkeypatch.setattr(F, "conv2d", count("conv", real_c2))
     monkeypatch.setattr(torch, "conv1d", count("conv", torch.conv1d))
     monkeypatch.setattr(torch, "conv2d", count("conv", torch.conv2d))
+    monkeypatch.setattr(torch, "bmm", count("bmm", torch.bmm))
+    monkeypatch.setattr(F, "scaled_dot_product_attention", count("bmm", F.scaled_dot_product_attention))
     net = load_procedural(build_model(0)).to(DEV).train()
     pc = synth.make_clouds(5, 2, 8192, kind="room").to(DEV)
     ep = net({"point_clouds": pc})
     loss = sum(v.float().mean() for k, v in sorted(ep.items()) if v.is_floating_point() and v.requires_grad)
     loss.backward()
     assert torch.isfinite(loss).item()
-    assert calls == {"linear": 0, "conv": 0, "batch_norm": 0}, calls
+    assert calls == {"linear": 0, "conv": 0, "batch_norm": 0, "bmm": 0}, calls
     # and with the switch off the same step is PyTorch's library path
     monkeypatch.setattr(rows_f32, "HANDWRITTEN_F32", False)
     ep = net({"point_clouds": pc})
-    assert calls["linear"] > 50 and calls["batch_norm"] > 50, calls
+    assert calls["linear"] > 50 and calls["batch_norm"] > 50 and calls["bmm"] >= 12, calls
+
+
+def test_f32_attention_core_matches_float64():
+    import rows_f32
+    torch.manual_seed(0)
+    L, S, N, H, D = 96, 160, 2, 8, 36
+    q = torch.randn(L, N, H * D, device=DEV, requires_grad=True)
+    k = torch.randn(S, N, H * D, device=DEV, requires_grad=True)
+    v = torch.randn(S, N, H * D, device=DEV, requires_grad=True)
+    out = rows_f32.attention_core(q, k, v, H)
+    g = torch.randn_like(out)
+    out.backward(g)
+    q64, k64, v64 = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    qh = q64.reshape(L, N, H, D).permute(1, 2, 0, 3)
+    kh = k64.reshape(S, N, H, D).permute(1, 2, 0, 3)
+    vh = v64.reshape(S, N, H, D).permute(1, 2, 0, 3)
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / D ** 0.5, -1) @ vh).permute(2, 0, 1, 3).reshape(L, N, H * D)
+    want.backward(g.double())
+    for name, a, b in (("out", out, want), ("dq", q.grad, q64.grad), ("dk", k.grad, k64.grad), ("dv", v.grad, v64.grad)):
+        assert rel(a, b) < 5e-6, (name, rel(a, b))

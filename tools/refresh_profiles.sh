@@ -47,6 +47,26 @@ if [ "${2:-}" != "--collect" ]; then
       find $OUT/${p}_$c -name "*kernel_trace.csv" -delete
     done
   done
+  # 12. the callers of the path: mean-teacher step and supervised-loss step as kernel summaries of the replayed
+  #     step, and the bench lines of the other BASELINE configurations / input modes
+  for m in mean_teacher supervised; do
+    FLAG=$([ $m = mean_teacher ] && echo "--mean-teacher" || echo "--loss supervised")
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$m -o t -- python $R/bench.py $FLAG --steps 8 --warmup 3 --no-cpu-baseline --no-op-timing > $OUT/$m.log 2>&1
+    D=$(dirname $(find $OUT/$m -name "*_kernel_trace.csv" | head -1))
+    python $R/tools/rocprof_summary.py $D 6 $OUT/${m}_steady.csv $OUT/${m}_summary.md
+    rm -rf $OUT/$m
+  done
+  : > $OUT/other_lines.jsonl
+  for F in "--mean-teacher" "--loss supervised" "--input-pipeline" "--dtype fp16 --batch 16 --points 80000" "--dtype bf16 --batch 16 --points 80000" "--batch 4 --points 50000 --extra-channels 6" "--dtype fp16" "--prefetch-at backward"; do
+    python $R/bench.py --no-cpu-baseline $F 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    keep = {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'launch', 'input', 'config') if k in d}
+    keep['flags'] = '$F'
+    keep['sa_stage'] = {k: d['sa_stage'][k] for k in ('avg_ms', 'frac', 'algorithmic_bytes')} if 'sa_stage' in d else None
+    print(json.dumps(keep))" >> $OUT/other_lines.jsonl
+  done
   du -sh $OUT
   exit 0
 fi
@@ -64,3 +84,6 @@ python $R/tools/pmc_mfma.py $OUT/pmc_MFMA 0.4 3 $P/${TAG}_bench_pmc_mfma.json $P
 python $R/tools/pmc_mfma.py $OUT/sapmc_MFMA 0.4 3 $P/${TAG}_sa_stage_pmc_mfma.json $P/${TAG}_sa_stage_pmc_mfma.md
 python $R/tools/pmc_issue.py $R/gpurun_out/issue_refresh_sa 0.4 3 $P/${TAG}_sa_stage_pmc_issue.md > /dev/null
 python $R/tools/pmc_issue.py $R/gpurun_out/issue_refresh_bench 0.4 3 $P/${TAG}_bench_pmc_issue.md > /dev/null
+cp $OUT/mean_teacher_summary.md $P/${TAG}_mean_teacher_summary.md
+cp $OUT/supervised_summary.md $P/${TAG}_supervised_summary.md
+cp $OUT/other_lines.jsonl $P/${TAG}_bench_lines_other_configs.jsonl
