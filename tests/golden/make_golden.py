@@ -311,6 +311,24 @@ def crosscheck():
         for form in (0, 2):
             rec[f"{case}.fps_diff_form{form}_vs_1"] = int((res[form][0] != res[1][0]).sum())
             rec[f"{case}.ball_diff_form{form}_vs_1"] = int((res[form][1] != res[1][1]).sum())
+    # ... and the same count on the BENCHMARK's inputs (bench.py: synth.make_clouds(100 + i, 8, 40000, kind="room"),
+    # i = 0..2): sa1's sampling (40 000 -> 2048) and ball query (r 0.2, 64 samples) under the three contraction forms
+    for i in range(3):
+        pc = synth.make_clouds(100 + i, 8, 40000, kind="room")
+        res = {}
+        for form in (0, 1, 2):
+            oracle_ext.set_dist_form(form)
+            fi = oracle_ext.furthest_point_sampling(pc, 2048)
+            nx = torch.gather(pc, 1, fi.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            res[form] = (fi, oracle_ext.ball_query(nx, pc, 0.2, 64), nx)
+        for form in (0, 2):
+            rec[f"bench{100 + i}.fps_diff_form{form}_vs_1"] = int((res[form][0] != res[1][0]).sum())
+            # ball query compared on the SAME centres (form 1's), so that a changed pick is not counted twice
+            oracle_ext.set_dist_form(form)
+            bq = oracle_ext.ball_query(res[1][2], pc, 0.2, 64)
+            rec[f"bench{100 + i}.ball_diff_form{form}_vs_1"] = int((bq != res[1][1]).sum())
+        rec[f"bench{100 + i}.fps_picks"] = int(res[1][0].numel())
+        rec[f"bench{100 + i}.ball_slots"] = int(res[1][1].numel())
     oracle_ext.set_dist_form(1)
     torch.save(rec, os.path.join(HERE, "crosscheck.pt"))
     for k, v in rec.items():

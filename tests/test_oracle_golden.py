@@ -297,3 +297,16 @@ def test_ema_oracle_matches_the_reference_statements():
     e0 = [np.ones((4,), np.float32)]
     step_oracle.update_ema_variables(e0, [np.full((4,), 3.0, np.float32)], 0.999, 0)
     assert np.array_equal(e0[0], np.full((4,), 3.0, np.float32))
+
+
+def test_contraction_form_sensitivity_on_the_benchmark_inputs_is_recorded():
+    """the reference's `.cu` cannot be compiled here, so whether nvcc contracts dx*dx + dy*dy + dz*dz as
+    fma(dz,dz,fma(dx,dx,dy*dy)) (form 1, what oracle and kernels use), not at all (form 0) or right-to-left (form 2) is an
+    assumption of the restatement.  tests/golden/make_golden.py:crosscheck counts how many index decisions that choice
+    changes -- on the fixtures and on the BENCHMARK's own inputs (3 batches x 8 scenes x 40 000 points: 16 384 sampling
+    picks and 1 048 576 ball-query slots each).  Form 0 vs 1: none anywhere; form 2 vs 1: two picks in one batch."""
+    rec = load_golden("crosscheck")
+    for i in (100, 101, 102):
+        assert rec[f"bench{i}.fps_picks"] == 8 * 2048 and rec[f"bench{i}.ball_slots"] == 8 * 2048 * 64
+        assert rec[f"bench{i}.fps_diff_form0_vs_1"] == 0 and rec[f"bench{i}.ball_diff_form0_vs_1"] == 0
+        assert rec[f"bench{i}.fps_diff_form2_vs_1"] <= 4 and rec[f"bench{i}.ball_diff_form2_vs_1"] == 0
