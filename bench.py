@@ -392,17 +392,18 @@ def cpu_baseline(args):
         pointnet2_utils._ext = saved
 
 
-def probe_rccl_graph(timeout):
+def probe_rccl_graph(timeout, two_groups=False):
     """Run tools/rccl_graph_probe.py in a child of THIS rank (same rank / world, rendezvous on the next
     port), before this process touches the GPU.  True iff it exits 0 in time; a stuck child is killed
-    by pid."""
+    by pid.  two_groups: the variant with the gradient bucket on a second process group and a forked stream."""
     import subprocess
     env = dict(os.environ)
     env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
-    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + (31 if two_groups else 23))
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
         env.pop(k, None)
-    child = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "rccl_graph_probe.py")], env=env,
+    child = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "rccl_graph_probe.py")] +
+                             (["--two-groups"] if two_groups else []), env=env,
                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     try:
         return child.wait(timeout=timeout) == 0
@@ -517,7 +518,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
     buckets = None
     if distributed and not ddp:
         import data_parallel
-        buckets = data_parallel.GradientBuckets(net, world)
+        buckets = data_parallel.GradientBuckets(net, world, group=getattr(args, "bucket_group", None))
     args.buckets = buckets
 
     def criterion(ep, labels):
@@ -683,9 +684,12 @@ def main():
         cpu_rec = cpu_baseline(args)
 
     force_dist = os.environ.get("OMNIPQ_BENCH_FORCE_DIST") == "1"      # single-rank exercise of the N>1 path
-    probe_ok = False
+    probe_ok = probe2_ok = False
     if (world > 1 or force_dist) and args.graph != "off":
         probe_ok = probe_rccl_graph(args.probe_timeout)
+        # may the gradient buckets have a communicator of their own (so that bucket 0's all-reduce on the side stream does
+        # not queue the SyncBatchNorm exchanges of the backbone's backward pass behind it)?
+        probe2_ok = probe_ok and probe_rccl_graph(args.probe_timeout, two_groups=True)
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -697,9 +701,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         # every rank must take the same path: graph only if ALL probes passed
-        flag = torch.tensor([1 if probe_ok else 0], device=dev, dtype=torch.int32)
+        flag = torch.tensor([1 if probe_ok else 0, 1 if probe2_ok else 0], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        probe_ok = bool(flag.item())
+        probe_ok, probe2_ok = bool(flag[0].item()), bool(flag[1].item())
+    args.bucket_group = dist.new_group() if ((world > 1 or force_dist) and probe2_ok) else None
 
     import pointnet2_utils
     import synth
@@ -823,7 +828,9 @@ def main():
         b = getattr(args, "buckets", None)
         dp_counts = (f"{sa_fused.COLLECTIVES_LAST_STEP} SyncBN statistics all-reduces (<= 4 KB each) + "
                      f"{b.collectives if b is not None else 0} gradient-bucket all-reduces per step (bucket 0 = everything but "
-                     "the backbone, issued on the side stream when backward reaches the seed features; bucket 1 = backbone)")
+                     "the backbone, issued on the side stream when backward reaches the seed features; bucket 1 = backbone; "
+                     + ("buckets on a communicator of their own" if getattr(args, "bucket_group", None) is not None else
+                        "buckets on the default communicator") + ")")
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
