@@ -454,45 +454,73 @@ struct ApplyProblem {
   float *dbeta_dgamma;
 };
 // bid / nblocks: this workgroup's index and the number of workgroups of ITS problem (a pair launch runs two in one grid)
+// Streaming shape (tools/probe/copy_bw.hip on this chip: one 16-byte piece per thread over a grid that covers the tensor
+// reaches 6.2 TB/s, four pieces per thread 5.6 -- 6.1 with non-temporal accesses --, a grid-stride loop over 8-16
+// workgroups per CU 5.1): U independent pieces per thread and iteration, requested before any is used; dX is read
+// non-temporally (this kernel is its only reader).  Per channel ONE 16-byte LDS entry (a, b, beta', gamma') with
+//   dY = a dz + beta' y + gamma',  beta' = -a invstd T/P,  gamma' = -a S/P + a invstd T/P mean
+// instead of four 32-byte global loads and sixteen conflicting scalar LDS reads per piece.
+typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
 __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, int bid, int nblocks) {
-  extern __shared__ float st[];                              // [S/P | T/P]
+  extern __shared__ __attribute__((aligned(16))) float st_raw[];
+  st_f32x4 *tab = reinterpret_cast<st_f32x4 *>(st_raw);      // [C]
   const int C = p.C;
-  for (int j = (int)threadIdx.x; j < 2 * C; j += 256) {
-    const double t = p.sums[j];
-    st[j] = (float)(t * p.invP);
-    if (p.dbeta_dgamma && bid == 0) p.dbeta_dgamma[j] = (float)t;
+  for (int c = (int)threadIdx.x; c < C; c += 256) {
+    const double s0 = p.sums[c], s1 = p.sums[C + c];
+    const float m1 = (float)(s0 * p.invP), m2 = (float)(s1 * p.invP);
+    const float av = p.a[c], is = p.invstd[c];
+    tab[c] = st_f32x4{av, p.b[c], -av * is * m2, av * (is * m2 * p.mean[c] - m1)};
+    if (p.dbeta_dgamma && bid == 0) {
+      p.dbeta_dgamma[c] = (float)s0;
+      p.dbeta_dgamma[C + c] = (float)s1;
+    }
   }
   __syncthreads();
   const int cpr = C >> 3;
-  const e16_t *__restrict__ Y = p.Y;
-  const e16_t *__restrict__ dX = p.dX;
-  e16_t *__restrict__ dY = p.dY;
-  for (long long q = (long long)bid * 256 + threadIdx.x; q < p.chunks; q += (long long)nblocks * 256) {
-    const int c0 = (int)(q % cpr) * 8;
-    float y[8], d[8], av[8], bv[8], mu[8], is[8];
-    unpack8(*reinterpret_cast<const uint4 *>(Y + q * 8), y);
-    unpack8(*reinterpret_cast<const uint4 *>(dX + q * 8), d);
-    load8f(p.a + c0, av);
-    load8f(p.b + c0, bv);
-    load8f(p.mean + c0, mu);
-    load8f(p.invstd + c0, is);
+  const st_u32x4 *__restrict__ Y = reinterpret_cast<const st_u32x4 *>(p.Y);
+  const st_u32x4 *__restrict__ dX = reinterpret_cast<const st_u32x4 *>(p.dX);
+  st_u32x4 *__restrict__ dY = reinterpret_cast<st_u32x4 *>(p.dY);
+  for (long long q0 = (long long)bid * (256 * U) + threadIdx.x; q0 < p.chunks; q0 += (long long)nblocks * (256 * U)) {
+    st_u32x4 yv[U], dv[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dz = __builtin_fmaf(av[e], y[e], bv[e]) > 0.f ? d[e] : 0.f;
-      const float yhat = (y[e] - mu[e]) * is[e];
-      y[e] = av[e] * (dz - st[c0 + e] - yhat * st[C + c0 + e]);
+    for (int u = 0; u < U; ++u) {
+      const long long q = q0 + u * 256;
+      if (q < p.chunks) {
+        yv[u] = Y[q];
+        dv[u] = NT ? __builtin_nontemporal_load(dX + q) : dX[q];
+      }
     }
-    *reinterpret_cast<uint4 *>(dY + q * 8) = pack8(y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long q = q0 + u * 256;
+      if (q >= p.chunks) continue;
+      const int c0 = (int)(q % cpr) * 8;
+      st_u32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const st_f32x4 t0 = tab[c0 + 2 * w], t1 = tab[c0 + 2 * w + 1];
+        const float y0 = e16_lo(yv[u][w]), y1 = e16_hi(yv[u][w]);
+        const float d0 = e16_lo(dv[u][w]), d1 = e16_hi(dv[u][w]);
+        const float z0 = __builtin_fmaf(t0[0], y0, t0[1]) > 0.f ? d0 : 0.f;
+        const float z1 = __builtin_fmaf(t1[0], y1, t1[1]) > 0.f ? d1 : 0.f;
+        o[w] = pack_e16x2(__builtin_fmaf(t0[0], z0, __builtin_fmaf(t0[2], y0, t0[3])),
+                          __builtin_fmaf(t1[0], z1, __builtin_fmaf(t1[2], y1, t1[3])));
+      }
+      dY[q] = o;
+    }
   }
 }
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(ApplyProblem p) {
-  bn_bwd_apply_fused_body(p, (int)blockIdx.x, (int)gridDim.x);
+  bn_bwd_apply_fused_body<U, NT>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // two independent problems in one grid (see gemm_bf16.hip: gemm_nt_pair_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(ApplyProblem p0, ApplyProblem p1, int n0) {
   const int id = (int)blockIdx.x;
-  if (id < n0) bn_bwd_apply_fused_body(p0, id, n0);
-  else bn_bwd_apply_fused_body(p1, id - n0, (int)gridDim.x - n0);
+  if (id < n0) bn_bwd_apply_fused_body<1, false>(p0, id, n0);
+  else bn_bwd_apply_fused_body<1, false>(p1, id - n0, (int)gridDim.x - n0);
 }
 
 // sums (f64 totals) -> per-channel means as f32:  st[c] = sum dz / P,  st[C + c] = sum dz*yhat / P
@@ -1430,7 +1458,10 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
   if (P < 0 || C <= 0 || (C % 8) || C > 4096) return OMNIPQ_EINVAL;
   if (!dX || !Y || !a || !b || !mean || !invstd || !sums || !dY) return OMNIPQ_EINVAL;
   const long long chunks = P * (C / 8);
-  int grid = grid_for(chunks);
+  // large tensors: four pieces per thread and as many workgroups as that takes (no grid-stride loop); small ones (the
+  // per-point stacks: a few hundred KB) keep one piece per thread and stay pairable
+  const bool big = chunks >= (1LL << 20);
+  int grid = big ? grid_for(chunks, 256 * 4, 1 << 22) : grid_for(chunks);
   if (grid < 1) grid = 1;
   struct Held {
     omnipq::ApplyProblem p;
@@ -1439,10 +1470,23 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
   const Held q{omnipq::ApplyProblem{chunks, C, 1.0 / total_positions, (const e16_t *)dX, (const e16_t *)Y, a, b, mean,
                                     invstd, sums, (e16_t *)dY, dbeta_dgamma},
                grid};
+  const int lds = (int)sizeof(float) * 4 * C;
+  if (big) {
+    omnipq::HeldLaunch &h = omnipq::held_launch();
+    if (h.full) {
+      h.full = h.armed = false;
+      h.single(h);
+    }
+    // (measured round 3, 1 M x 128 / 262 144 x 256: 153 / 83 us = 5.3 / 4.8 TB/s on the three streams; a capped grid with a
+    // grid-stride loop and plain loads are within 2 % of it -- two reads per write do not reach the 6.2 TB/s of a 1 : 1 copy)
+    bn_bwd_apply_fused_kernel<4, true><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
   auto single = +[](const omnipq::HeldLaunch &h) {
     Held f;
     __builtin_memcpy(&f, h.blob, sizeof(f));
-    bn_bwd_apply_fused_kernel<<<f.grid, 256, sizeof(float) * 2 * f.p.C, h.stream>>>(f.p);
+    bn_bwd_apply_fused_kernel<1, false><<<f.grid, 256, sizeof(float) * 4 * f.p.C, h.stream>>>(f.p);
   };
   // small problems only: a launch that fills the chip on its own gains nothing from a partner
   const bool pairable = grid <= 1024;
@@ -1456,10 +1500,10 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
   if (!pairable || !omnipq::hold_or_pair(q, omnipq::kHeldApplyKey, (hipStream_t)stream, single,
                                          [&](const Held &first, const Held &second) {
                                            const int cmax = first.p.C > second.p.C ? first.p.C : second.p.C;
-                                           bn_bwd_apply_pair_kernel<<<first.grid + second.grid, 256, sizeof(float) * 2 * cmax,
+                                           bn_bwd_apply_pair_kernel<<<first.grid + second.grid, 256, sizeof(float) * 4 * cmax,
                                                                       (hipStream_t)stream>>>(first.p, second.p, first.grid);
                                          }))
-    bn_bwd_apply_fused_kernel<<<grid, 256, sizeof(float) * 2 * C, (hipStream_t)stream>>>(q.p);
+    bn_bwd_apply_fused_kernel<1, false><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

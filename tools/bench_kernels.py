@@ -1,6 +1,6 @@
 """Micro-benchmarks of the hand-written kernels through the C ABI (device time via events).
 
-    python tools/bench_kernels.py gemm | fps | bq | stream
+    python tools/bench_kernels.py gemm | fps | bq | stream | apply
 """
 import ctypes
 import os
@@ -53,6 +53,36 @@ def gemm():
         fl = 2.0 * M * N * P
         by = 2.0 * (P * M + P * N)
         print(f"TN {P:8d}: {M:4d}x{N:4d}: {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {by / ms / 1e6:7.1f} GB/s   | torch {ms_t:7.3f} ms")
+
+
+def apply():
+    """the two backward apply passes of the SA stages at their benchmark shapes, GB/s on the bytes they move"""
+    for P, C in [(1048576, 128), (262144, 256), (65536, 256), (32768, 288)]:
+        dX = torch.randn((P, C), device=dev).to(torch.bfloat16)
+        Y = torch.randn((P, C), device=dev).to(torch.bfloat16)
+        dY = torch.empty_like(Y)
+        a, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        mean, invstd = torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+        sums = torch.randn(2, C, device=dev, dtype=torch.float64)
+        gb = torch.empty(2, C, device=dev)
+        ms = timeit(lambda: capi.ok("omnipq_bn_bwd_apply_fused", ctypes.c_longlong(P), C, ctypes.c_double(float(P)), capi.P(dX),
+                                    capi.P(Y), capi.P(a), capi.P(b), capi.P(mean), capi.P(invstd), capi.P(sums), capi.P(dY),
+                                    capi.P(gb)))
+        print(f"bn_bwd_apply {P:8d} x {C:4d}: {ms * 1e3:7.1f} us  {3.0 * P * C * 2 / ms / 1e9:6.2f} TB/s")
+    for B, M, S, C in [(8, 2048, 64, 256), (8, 1024, 32, 512), (8, 512, 16, 512), (8, 256, 16, 288)]:
+        P = B * M * S
+        Y = torch.randn((P, C), device=dev).to(torch.bfloat16)
+        dY = torch.empty_like(Y)
+        a, mean, invstd = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+        sums = torch.randn(3, C, device=dev, dtype=torch.float64)
+        g_out = torch.randn((B * M, C), device=dev)
+        out_pm = torch.randn((B * M, C), device=dev).to(torch.bfloat16)
+        arg = torch.randint(0, S, (B * M, C), device=dev, dtype=torch.uint8)
+        gb = torch.empty(2, C, device=dev)
+        ms = timeit(lambda: capi.ok("omnipq_sa_pool_bwd_apply_gb", B, M, S, C, ctypes.c_double(float(P)), capi.P(Y), capi.P(a),
+                                    capi.P(mean), capi.P(invstd), capi.P(sums), capi.P(g_out), capi.P(out_pm), capi.P(arg),
+                                    capi.P(dY), capi.P(gb)))
+        print(f"pool_bwd_apply {B}x{M}x{S} x {C:4d}: {ms * 1e3:7.1f} us  {2.0 * P * C * 2 / ms / 1e9:6.2f} TB/s")
 
 
 def stream():
