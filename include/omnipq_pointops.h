@@ -44,6 +44,9 @@ extern "C" {
 
 int omnipq_abi_version(void);
 const char *omnipq_error_string(int code);
+/* Measurement helper: dst[0..bytes) = src[0..bytes) (bytes % 16 == 0) with the streaming shape that reaches this chip's
+ * highest copy rate -- the "measured copy ceiling" bench.py reports next to the 8 TB/s datasheet peak. */
+int omnipq_copy_probe(const void *src, void *dst, long long bytes, void *stream);
 
 /* cuda_utils.h:20-24 opt_n_threads(): the reference's block size for `work_size`
  * items, 2^floor(log2) clamped to [1, 512].  Exposed because the FPS tie rule is
