@@ -93,10 +93,16 @@ struct AffineIn {
 };
 constexpr int kAffMaxK = 1024;
 
+// relu(a y + b) of two packed elements.  The ReLU is applied AFTER the rounding, on the packed word: a 16-bit float is
+// sign-magnitude, so max(., 0) is the signed 16-bit integer max with 0 -- one v_pk_max_i16 for the pair instead of two
+// v_max_f32 (rounding keeps the sign, so round(max(x, 0)) == max(round(x), 0) up to the sign of zero); the two FMAs are one
+// packed-f32 FMA.  These kernels are VALU bound: 16 of the 68 VALU instructions of a K-step were these.
 __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
-  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, e16_lo(w), b0), 0.f);
-  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, e16_hi(w), b1), 0.f);
-  return pack_e16x2(lo, hi);
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const omnipq_f32x2 v = __builtin_elementwise_fma(omnipq_f32x2{a0, a1}, omnipq_f32x2{e16_lo(w), e16_hi(w)},
+                                                  omnipq_f32x2{b0, b1});
+  const unsigned o = pack_e16x2(v[0], v[1]);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o), s16x2{0, 0}));
 }
 
 // Ball extrema (statistics variants only, s > 0): the rows of C are grouped positions, `s` consecutive rows form a
@@ -458,6 +464,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
     unsigned *const cbase = ct32 + (wm * (T / 2) + crow0 + (odd ? 1 : 0)) * (CP / 2) + ((wn * (T / 2) + (ccol & ~1)) >> 1);
     // two copies of the loop, with and without the bias (wave-uniform): the 64 adds per thread are not paid for a NULL bias
     const unsigned rd_seed = (STATS == 0 && g.relu && g.drop_thresh) ? dec_seed(g.drop_seed, g.drop_salt) : 0u;
+    // v_perm_b32(other, mine): selector bytes 0..3 pick from `mine`, 4..7 from `other`.  even lane: (mine.lo16, other.lo16);
+    // odd lane: (other.hi16, mine.hi16)
+    const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;
     auto pack_tile = [&](auto has_bias) {
       constexpr bool HAS_BIAS = decltype(has_bias)::value;
       float bcol[NI];                      // per-column bias (f32, added before the single bf16 rounding)
@@ -484,11 +493,12 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
                 mine1 = dec_hash(e0 + (unsigned)g.ldc, rd_seed) >= g.drop_thresh ? mine1 * g.drop_keep_inv : 0.f;
               }
             }
-            const float give = odd ? mine0 : mine1;
-            const float got = __builtin_bit_cast(
-                float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-            const float lo = odd ? got : mine0, hi = odd ? mine1 : got;
-            cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (CP / 2) + j * 16] = pack_e16x2(lo, hi);
+            // this lane's two rows of its column as one word, the neighbour's word over the DPP network, and one byte
+            // permute that leaves the even lane with (row r: c, c + 1) and the odd lane with (row r + 1: c, c + 1) -- three
+            // VALU instructions per row pair (was five: two selects around the exchange and one after it)
+            const unsigned mine = pack_e16x2(mine0, mine1);
+            const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+            cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (CP / 2) + j * 16] = __builtin_amdgcn_perm(other, mine, pair_sel);
           }
     };
     if (bias)

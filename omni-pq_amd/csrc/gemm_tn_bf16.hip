@@ -41,9 +41,12 @@ struct TnArgs {
 // relu(ba[n] * Y[p][n] + bb[n]) rounded to bf16 -- the activations that layer's normalise+ReLU pass would have
 // stored, rebuilt between the global load and the LDS store (see gemm_bf16.hip: AffineIn).
 __device__ __forceinline__ unsigned tn_affine_relu_pair(unsigned w, float a0, float b0, float a1, float b1) {
-  const float lo = __builtin_fmaxf(__builtin_fmaf(a0, e16_lo(w), b0), 0.f);
-  const float hi = __builtin_fmaxf(__builtin_fmaf(a1, e16_hi(w), b1), 0.f);
-  return pack_e16x2(lo, hi);
+  // (packed FMA, ReLU as a signed 16-bit max on the rounded pair: see gemm_bf16.hip: affine_relu_pair)
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const omnipq_f32x2 v = __builtin_elementwise_fma(omnipq_f32x2{a0, a1}, omnipq_f32x2{e16_lo(w), e16_hi(w)},
+                                                  omnipq_f32x2{b0, b1});
+  const unsigned o = pack_e16x2(v[0], v[1]);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o), s16x2{0, 0}));
 }
 
 // XGB (with AFFB): the layer below is the never-materialised first layer of a coordinates-only stage (gemm_bf16.hip:
