@@ -126,6 +126,44 @@ def stage_case(name, xyz):
         else:
             out["grad." + k] = summarize(p.grad, max_full=GRAD_SAMPLES)
             out["gradnorm." + k] = float(p.grad.double().norm())
+    # ---- eval mode (running statistics, no gradients) on the SAME forced tensors: the inference path of every stage
+    trained_buffers = {k: v.clone() for k, v in net.state_dict().items()}
+    load_procedural(net)                 # the running statistics as a fresh load_procedural() gives them, not after the
+    net.eval()                           # momentum update of the train pass above
+    own_e, handles = {}, []
+    fvals = {k: v.detach() for k, v in forced.items()}
+
+    def force_e(key, t):
+        own_e[key] = t
+        return fvals[key]
+
+    for sa in BOUNDARY_SA:
+        handles.append(getattr(net.backbone, sa).register_forward_hook(
+            lambda _m, _i, out_, sa=sa: (out_[0], force_e(sa + "_features", out_[1]), out_[2])))
+    for fp in BOUNDARY_FP:
+        handles.append(getattr(net.backbone, fp).register_forward_hook(
+            lambda _m, _i, out_, fp=fp: force_e(fp + "_features", out_)))
+
+    def agg_pre_e(_m, args):
+        own_e["vote_xyz"], own_e["vote_features"] = args[0], args[1]
+        return (fvals["vote_xyz"], fvals["vote_features"]) + tuple(args[2:])
+    handles.append(net.vote_aggregation.register_forward_pre_hook(agg_pre_e))
+    handles.append(net.vote_aggregation.register_forward_hook(
+        lambda _m, _i, out_: (out_[0], force_e("cluster_feature", out_[1]), out_[2])))
+    for i in range(6):
+        handles.append(net.decoder[i].register_forward_hook(
+            lambda _m, _i, out_, i=i: force_e(f"decoder{i}_query", out_)))
+    with torch.no_grad():
+        ep_e = net({"point_clouds": xyz})
+    for h in handles:
+        h.remove()
+    for k, v in ep_e.items():
+        out["eval.ep." + k] = summarize(v)
+    for k, v in own_e.items():
+        out["eval.own." + k] = summarize(v)
+    net.load_state_dict(trained_buffers)
+    net.train()
+
     # ---- the same forced forward + backward in float64 (index decisions from the f32 oracle, as make_golden.py's
     # Oracle64): how far the reference's OWN f32 gradients are from exact.  Parameter gradients of small BatchNorm layers
     # are sums of a few hundred terms that cancel to 1e-3 of their size; an implementation that accumulates statistics in

@@ -257,8 +257,10 @@ def test_crosscheck_record():
     rec = load_golden("crosscheck")
     assert rec["fps_equal"] is True
     assert rec["ball_rows_equal"] == 1.0 and rec["three_nn_rows_equal"] == 1.0
-    # golden inputs are insensitive to the FMA-contraction form of the distance
-    assert all(v == 0 for k, v in rec.items() if "_diff_" in k)
+    # the golden fixtures' inputs are insensitive to the FMA-contraction form of the distance; the benchmark's
+    # own inputs (bench100..102) are counted in test_contraction_form_sensitivity_on_the_benchmark_inputs_is_recorded
+    fixture_counts = {k: v for k, v in rec.items() if "_diff_" in k and not k.startswith("bench")}
+    assert len(fixture_counts) >= 16 and all(v == 0 for v in fixture_counts.values()), fixture_counts
 
 
 def test_everything_before_the_votes_needs_no_forcing(oracle_backend):
