@@ -112,6 +112,7 @@ def _lockstep(lead, follow):
     alive = [True, True]
     gens = (lead, follow)
     assert not _lib.omnipq_pair_held(), "rows_mlp: a pair launch was still held when a lockstep run started"
+    outer, sa_fused.PairStats.active = sa_fused.PairStats.active, sa_fused.PairStats()
     try:
         while alive[0] or alive[1]:
             for i in (0, 1):
@@ -124,6 +125,7 @@ def _lockstep(lead, follow):
                     _lib.omnipq_pair_flush()              # nothing was held: disarm before the follower runs
             _lib.omnipq_pair_flush()
     finally:
+        sa_fused.PairStats.active = outer
         _lib.omnipq_pair_flush()      # an exception in either program must not leave a launch held or the hold armed
     assert not _lib.omnipq_pair_held()
     return out
@@ -178,8 +180,9 @@ def _forward_program(ctx, lead, x, spec, training, params):
                 raise RuntimeError("RowsMLP: BatchNorm widths must be multiples of 32")
             sums = None
             below = layers[-1] if (X is None) else None      # the layer below kept only (Y, a, b): see sa_fused
+            slot = None
             if lay.has_bn and training:
-                sums = zeros_f64(2, cout, dev)
+                sums, slot = sa_fused.pair_sums(lead, 2, cout, dev, world)
                 _hold(lead)
                 if below is not None:
                     Y = sa_fused.gemm_nt_affine(below.Y, below, lay.Wp, N, lay.Cp, K, sums=sums)
@@ -210,7 +213,7 @@ def _forward_program(ctx, lead, x, spec, training, params):
             if lay.has_bn:
                 rm, rv, nbt, momentum, eps = spec[l]
                 if training:
-                    _allreduce_(sums, world)
+                    sa_fused.pair_allreduce(sums, slot, lead, world)
                     stats = torch.empty((4, cout), device=dev)            # a | b | mean | invstd
                     lay.a, lay.b, lay.mean, lay.invstd = stats[0], stats[1], stats[2], stats[3]
                     cb = bias.detach().float().contiguous() if lay.has_bias else None
@@ -278,6 +281,7 @@ def _backward_program(ctx, lead, g, needs_input_grad):
             owned = True
         dx = None
         sums = None               # BN-backward sums of the current layer if the GEMM above already produced them
+        slot = None               # ... and the pair buffer they live in (sa_fused.PairStats)
         dfr = sa_fused.deferred_wgrads.active
         act_masked = -1                  # the dropout(relu(.)) layer whose backward mask the GEMM above it has applied already
         for l in range(L - 1, -1, -1):
@@ -289,13 +293,15 @@ def _backward_program(ctx, lead, g, needs_input_grad):
                 Xin = below.Y
             if lay.has_bn:
                 if sums is None:
-                    sums = zeros_f64(3, lay.C, dev)
+                    sums, slot = sa_fused.pair_sums(lead, 3, lay.C, dev, world)
                     _call(_lib.omnipq_bn_bwd_stats_z, dcur, ctypes.c_longlong(N), lay.C, _p(dcur), _p(lay.Y),
                           _p(lay.a), _p(lay.b), _p(lay.mean), _p(lay.invstd), _p(sums))
+                    if sa_fused.PairStats.active is not None and (world > 1 or sa_fused._FORCE_COLLECTIVES):
+                        yield              # the partner's statistics kernel goes out before the exchange both share
                 dst = dcur if owned else torch.empty_like(dcur)
                 _hold(lead)
                 grads[4 * l + 2], grads[4 * l + 3] = sa_fused.bn_backward_apply(dcur, lay, N, lay.C, total, sums,
-                                                                                world, out=dst)
+                                                                                world, out=dst, pair=(slot, lead))
                 yield
                 dcur, owned = dst, True
                 if lay.has_bias:
@@ -319,9 +325,9 @@ def _backward_program(ctx, lead, g, needs_input_grad):
                     grads[4 * l + 1] = bsum[:ctx.nbias[l]]
                 dWp = _gemm_tn(dcur, Xin, lay.Cp, lay.K, N, colsum=bsum, below=below)
                 grads[4 * l] = unprep_wgrad(dWp, lay.C, lay.wk, 0, ctx.wshapes[l])
-            sums = None
+            sums, slot = None, None
             if l > 0 and layers[l - 1].has_bn:
-                sums = zeros_f64(3, lay.K, dev)
+                sums, slot = sa_fused.pair_sums(lead, 3, lay.K, dev, world)
                 _hold(lead)
                 dprev = _gemm_nt_bnbwd(dcur, lay.Wt, N, lay.K, lay.Cp, layers[l - 1], sums)
                 yield

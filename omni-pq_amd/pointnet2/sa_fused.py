@@ -113,6 +113,63 @@ def _allreduce_(sums, world=None):
     return sums
 
 
+class PairStats:
+    """SyncBatchNorm statistics of the two stacks of a pair launch (rows_mlp._lockstep) in ONE buffer, exchanged by ONE
+    all-reduce: the leading stack allocates [its rows | the partner's rows], the partner -- whose GEMM of the same kind goes
+    out in the same grid -- takes the second half, and the leader, which resumes first, reduces both.  A partner that does not
+    show up (different widths, a stack that ended) leaves the leader with a collective of its own."""
+    active = None                  # the lockstep run in progress on this thread's stream, if any
+
+    def __init__(self):
+        self.slot = None
+
+    class _Slot:
+        __slots__ = ("buf", "rows", "joined", "reduced", "stash")
+
+    def take(self, lead, rows, cols, device):
+        """-> (f64 zeros [rows][cols], slot or None)"""
+        if lead:
+            s = self.slot = PairStats._Slot()
+            s.buf, s.rows, s.joined, s.reduced, s.stash = zeros_f64(2 * rows, cols, device), rows, False, False, None
+            return s.buf[:rows], s
+        s = self.slot
+        if s is not None and not s.joined and not s.reduced and tuple(s.buf.shape) == (2 * rows, cols):
+            s.joined = True
+            return s.buf[rows:], s
+        return zeros_f64(rows, cols, device), None
+
+
+def pair_sums(lead, rows, cols, device, world):
+    """Statistics buffer of a BatchNorm layer; shared with the partner stack when a pair is running under a process group."""
+    bus = PairStats.active
+    if bus is None or not (world > 1 or _FORCE_COLLECTIVES):
+        return zeros_f64(rows, cols, device), None
+    return bus.take(lead, rows, cols, device)
+
+
+def pair_allreduce(sums, slot, lead, world, before_partner=None):
+    """`_allreduce_(sums)`, once for both stacks of a pair.  before_partner(partner's half) runs on the partner's LOCAL
+    totals before they are replaced by the global ones (the BatchNorm backward takes its per-rank affine gradients from them)
+    and its result is handed to the partner.  -> what before_partner returned for this stack, if it was run on its behalf."""
+    if slot is None:
+        _allreduce_(sums, world)
+        return None
+    if lead:
+        if slot.joined:
+            if before_partner is not None:
+                slot.stash = before_partner(slot.buf[slot.rows:])
+            _allreduce_(slot.buf, world)
+            slot.reduced = True
+        else:
+            slot.reduced = True              # closes the slot: a late partner reduces on its own
+            _allreduce_(sums, world)
+        return None
+    if slot.reduced and slot.joined:
+        return slot.stash if before_partner is not None else None
+    _allreduce_(sums, world)
+    return None
+
+
 def _round_up(x, q):
     return (x + q - 1) // q * q
 
@@ -851,15 +908,22 @@ def unprep_wgrad(dWp, cout, cin, rot, shape):
     return dW
 
 
-def bn_backward_apply(d, lay, P, C, total, sums, world, out=None):
+def bn_backward_apply(d, lay, P, C, total, sums, world, out=None, pair=None):
     """d (gradient w.r.t. the ReLU output, bf16 [P][C]) -> gradient w.r.t. the layer's pre-BN output, written to
     `out` (default: in place), given the BatchNorm-backward totals `sums` of THIS rank.  Returns (dgamma, dbeta),
     this rank's share.
     Single process: one launch does the means, the f32 copies of the totals and the apply; under a process
     group the totals are all-reduced in between (SyncBatchNorm), so the local gradients are taken first."""
     if world > 1 or _FORCE_COLLECTIVES:
-        dgamma, dbeta = affine_grads(sums, C)
-        _allreduce_(sums[:2], world)
+        slot, lead = pair if pair is not None else (None, False)
+        if slot is not None and not lead and slot.joined and slot.reduced:
+            dgamma, dbeta = slot.stash           # taken by the leader before its all-reduce covered both halves
+        else:
+            dgamma, dbeta = affine_grads(sums, C)
+            if slot is None:
+                _allreduce_(sums[:2], world)
+            else:
+                pair_allreduce(sums[:2], slot, lead, world, before_partner=lambda half: affine_grads(half, C))
         gb = None
     else:
         gb = torch.empty((2, C), device=d.device, dtype=torch.float32)

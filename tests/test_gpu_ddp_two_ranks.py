@@ -69,14 +69,29 @@ def _toy(which, dev):
             self.c2, self.b2 = torch.nn.Conv1d(288, 288, 1), torch.nn.BatchNorm1d(288)
             self.c3 = torch.nn.Conv1d(288, 64, 1)
 
+        def stack(self):
+            return [rows_mlp.Layer(self.c1.weight, self.c1.bias, self.b1), rows_mlp.Layer(self.c2.weight, self.c2.bias, self.b2),
+                    rows_mlp.Layer(self.c3.weight, self.c3.bias)]
+
         def forward(self, xyz):
-            stack = [rows_mlp.Layer(self.c1.weight, self.c1.bias, self.b1), rows_mlp.Layer(self.c2.weight, self.c2.bias, self.b2),
-                     rows_mlp.Layer(self.c3.weight, self.c3.bias)]
-            return rows_mlp.run(xyz.reshape(-1, 3), stack, True).view(xyz.shape[0], xyz.shape[1], -1)
+            return rows_mlp.run(xyz.reshape(-1, 3), self.stack(), True).view(xyz.shape[0], xyz.shape[1], -1)
+
+    class Pair(torch.nn.Module):
+        """Two independent stacks as one pair node (the object / quad heads of a decoder stage): their SyncBatchNorm
+        statistics travel in ONE all-reduce per layer and direction (sa_fused.PairStats)."""
+
+        def __init__(self):
+            super().__init__()
+            self.p, self.q = Rows(), Rows()
+
+        def forward(self, xyz):
+            x = xyz.reshape(-1, 3)
+            ya, yb = rows_mlp.run_pair(x, self.p.stack(), (x * 0.5 + 0.1).contiguous(), self.q.stack(), True)
+            return torch.cat([ya, yb], 1).view(xyz.shape[0], xyz.shape[1], -1)
 
     # SyncBatchNorm as the reference converts every BatchNorm (pq_transformer.py:194): the hand-written kernels exchange
     # statistics across ranks for SyncBatchNorm layers only -- a plain BatchNorm keeps per-rank statistics, like torch's
-    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm({"chain": Chain, "rows": Rows}[which]())
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm({"chain": Chain, "rows": Rows, "pair": Pair}[which]())
     return load_procedural(net, 3).to(dev).train()
 
 
@@ -90,7 +105,7 @@ def _exact_worker(rank, world, port, out_dir):
     xyz = (torch.rand(world * per, 2048, 3, generator=torch.Generator().manual_seed(5)) * 3).to(dev)
     refs = {}
     if rank == 0:                                  # single process, all scenes, before a process group exists
-        for which in ("chain", "rows"):
+        for which in ("chain", "rows", "pair"):
             net = _toy(which, dev)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 f = net(xyz)
@@ -99,18 +114,23 @@ def _exact_worker(rank, world, port, out_dir):
             refs[which] = (f.detach().float().cpu(), _flat_grads(net).cpu())
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        worst = {}
-        for which in ("chain", "rows"):
+        import sa_fused
+        worst, exchanges = {}, {}
+        for which in ("chain", "rows", "pair"):
             net = _toy(which, dev)
+            before = sa_fused.COLLECTIVES
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 f = net(xyz[rank * per:(rank + 1) * per].contiguous())
             wfull = torch.randn((world * per,) + tuple(f.shape[1:]), generator=torch.Generator().manual_seed(9)).to(dev)
             (f.float() * wfull[rank * per:(rank + 1) * per]).mean().backward()
+            exchanges[which] = sa_fused.COLLECTIVES - before
             g = _flat_grads(net)
             dist.all_reduce(g)
             g = (g / world).cpu()
             if rank == 0:
                 worst[which] = (_rel(f.detach().float().cpu(), refs[which][0][:per]), _rel(g, refs[which][1]))
+        if rank == 0:
+            worst["exchanges"] = exchanges
         if rank == 0:
             torch.save(worst, os.path.join(out_dir, "exact.pt"))
     finally:
@@ -121,8 +141,11 @@ def _exact_worker(rank, world, port, out_dir):
 def test_syncbn_semantics_are_exact_on_matching_tile_partitions(tmp_path):
     mp.spawn(_exact_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     worst = torch.load(tmp_path / "exact.pt")
+    exchanges = worst.pop("exchanges")
     for which, (fwd, grad) in worst.items():
         assert fwd < 1e-4 and grad < 1e-4, (which, fwd, grad)
+    # two BatchNorm layers, forward + backward: 4 statistics exchanges for a stack, and the SAME 4 for a pair of stacks
+    assert exchanges["rows"] == 4 and exchanges["pair"] == 4, exchanges
 
 
 # ---------------------------------------------------------------------------------------------- model part
