@@ -203,15 +203,38 @@ def _side_stream(device):
     return s
 
 
-def key_side(layer, key, key_pos, mem16=None):
+def _posembed_stack(pe):
+    head = pe.position_embedding_head              # Conv1d, BatchNorm1d, ReLU, Conv1d (pq_transformer.PositionEmbeddingLearned)
+    return [rows_mlp.Layer(head[0].weight, head[0].bias, head[1]), rows_mlp.Layer(head[3].weight, head[3].bias)]
+
+
+def posembed_pair(pe_a, pe_b, xyz):
+    """Two layers' learned embeddings of the SAME positions as one pair node (rows_mlp.run_pair: their GEMMs share a launch
+    each way, their SyncBatchNorm statistics one all-reduce).  -> (rows_a, rows_b), each (B*P, 288) 16-bit, or None when
+    the row kernels do not apply (the caller embeds layer by layer)."""
+    B, P, _ = xyz.shape
+    x = getattr(xyz, "omnipq_rows2d", None)
+    if x is None or x.shape != (B * P, xyz.shape[2]):
+        x = xyz.reshape(B * P, -1)
+        if not xyz.requires_grad:
+            xyz.omnipq_rows2d = x
+    sa, sb = _posembed_stack(pe_a), _posembed_stack(pe_b)
+    if pe_a.training != pe_b.training or not (rows_mlp.usable(x, sa, pe_a.training) and rows_mlp.usable(x, sb, pe_b.training)):
+        return None
+    return rows_mlp.run_pair(x, sa, x, sb, pe_a.training)
+
+
+def key_side(layer, key, key_pos, mem16=None, k_pe=None):
     """The key / value side of a layer's cross attention: kv = in_proj[C:](mem + cross_posembed(key_pos)),
     rows (B*Pk, 2C) bf16.  It depends on the memory only, not on the queries.  -> (kv, (W_q, b_q)).
-    mem16: the memory as bf16 rows, if the caller has it (one cast and one gradient fan-in for all layers)."""
+    mem16: the memory as bf16 rows, if the caller has it (one cast and one gradient fan-in for all layers); k_pe: the
+    layer's position embedding as rows, if the caller computed it (posembed_pair)."""
     C = key.shape[1]
     ca = layer.multihead_attn
     if mem16 is None:
         mem16 = _rows(key).to(E16.dtype)
-    k_pe = _rows(layer.cross_posembed(key_pos)).to(E16.dtype)
+    if k_pe is None:
+        k_pe = _rows(layer.cross_posembed(key_pos)).to(E16.dtype)
     mem_pe = AddToBf16.apply(mem16, k_pe)
     # ONE split of the packed projection (its backward is one cat; two slices would each zero-fill and copy a
     # full-size gradient and add them up); the query part travels with the result to run()
@@ -234,8 +257,15 @@ def precompute_key_sides(layers, key, key_pos):
         # all layers read the same memory rows: one cast, and in backward one n-ary add for their n gradients
         mem = FanOut.apply(_rows(key).to(E16.dtype).contiguous(), len(layers))
         kvs = []
+        k_pes = [None] * len(layers)
+        if PAIR_KEY_EMBEDDINGS:
+            # the layers' embeddings of the key positions are independent stacks over one input: two layers per node
+            for i in range(0, len(layers) - 1, 2):
+                both = posembed_pair(layers[i].cross_posembed, layers[i + 1].cross_posembed, key_pos)
+                if both is not None:
+                    k_pes[i], k_pes[i + 1] = both
         for i, layer in enumerate(layers):
-            kv = key_side(layer, key, key_pos, mem[i])
+            kv = key_side(layer, key, key_pos, mem[i], k_pes[i])
             if _JOIN_PER_LAYER:
                 # layer i waits for ITS key side only, not for the six of them
                 done = torch.cuda.Event()
@@ -248,6 +278,7 @@ def precompute_key_sides(layers, key, key_pos):
 
 
 _JOIN_PER_LAYER = True
+PAIR_KEY_EMBEDDINGS = True
 
 
 def join_key_sides(device, done=None):
