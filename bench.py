@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32, help="thread count tried next to 'all cores'")
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
+    ap.add_argument("--fps-footprint", default="auto", choices=["auto", "small", "fast"],
+                    help="compute units per scene of the prefetched sampling chain (Pointnet2Backbone.prefetch): auto = small "
+                         "(3 instead of 5 per 40 000-point scene, ~40 %% longer rounds) for a chain that starts inside forward "
+                         "and has the whole step to hide under, fast otherwise")
     ap.add_argument("--prefetch-at", default="forward", choices=["forward", "backward"],
                     help="where the next batch's sampling chain (7 ms of dependent rounds, side stream) starts inside the "
                          "step: at the beginning of forward (default) or, as in rounds 1-2, when backward begins")
@@ -589,15 +593,19 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         lab_cur = {k: v.clone() for k, v in labels_pool[0].items()} if labels_pool is not None else None
 
         early = not args.no_prefetch and getattr(args, "prefetch_at", "forward") == "forward"
+        footprint = getattr(args, "fps_footprint", "auto")
+        if footprint == "auto":
+            footprint = None       # Pointnet2Backbone.prefetch: small for a chain started inside forward (measured: default step
+                                   # 11.52 -> 11.23 ms, configs[4] 19.65 -> 19.20, mean-teacher step 15.85 either way)
 
         def graph_body():
             for p in net.parameters():
                 p.grad = None
             if early:
                 # the next batch's sampling chain starts inside forward(), as soon as this batch's plan has been taken
-                net.prefetch({"point_clouds": nxt}, trusted=True, at_next_forward=True)
+                net.prefetch({"point_clouds": nxt}, trusted=True, at_next_forward=True, footprint=footprint)
                 if teacher is not None:
-                    teacher.prefetch({"point_clouds": nxt_t}, trusted=True, at_next_forward=True)
+                    teacher.prefetch({"point_clouds": nxt_t}, trusted=True, at_next_forward=True, footprint=footprint)
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 ep = model({"point_clouds": cur})
                 loss = criterion(ep, lab_cur)

@@ -75,6 +75,11 @@ int omnipq_fps_check(void *stream);
  * sizes the multi-workgroup launches (occupancy query); call it once per device outside any stream capture. */
 int omnipq_fps_poll(void);
 int omnipq_fps_init(void);
+/* Extension (the reference's FPS is one block per scene, sampling_gpu.cu:168-176; there is nothing to choose): for the
+ * CALLING THREAD, sampling launches on clouds of more than 8192 points issued after omnipq_fps_footprint(1) use 16 points
+ * per thread -- 3 workgroups per 40 000-point scene instead of 5, ~40 % longer rounds, identical indices -- until
+ * omnipq_fps_footprint(0).  For a chain that runs underneath other work and ends before it. */
+void omnipq_fps_footprint(int small);
 
 /* replaces gather_points_kernel_wrapper (sampling.cpp:11-13).
  *   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */

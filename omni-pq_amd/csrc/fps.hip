@@ -527,6 +527,12 @@ extern "C" int omnipq_fps_check(void *stream) {
   return omnipq_fps_poll();
 }
 
+static thread_local int t_small_footprint = 0;
+
+// Calling thread only: sampling launches issued after omnipq_fps_footprint(1) trade round time for compute units (see
+// omnipq_furthest_point_sampling); 0 restores the fastest rounds.  Results are the same indices either way.
+extern "C" void omnipq_fps_footprint(int small) { t_small_footprint = small ? 1 : 0; }
+
 extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset,
                                               float *temp, int *idxs, void *stream_) {
   using namespace omnipq;
@@ -553,6 +559,13 @@ extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *
   // 8 points per thread by default: a round costs the same (the cross-workgroup exchange dominates it) while
   // the scene occupies half as many CUs -- CUs the overlapped backward pass of the previous batch can use
   constexpr bool prefer8 = true;
+  if (t_small_footprint) {
+    // 16 points per thread: n = 40 000 -> 3 workgroups (CUs) per scene instead of 5.  A round gets longer (3.7 instead of
+    // 2.6 us: 16 distance updates per lane in front of the same exchange), the chain occupies 24 instead of 40 CUs -- for a
+    // chain that runs underneath a whole training step and ends well before it (omnipq_fps_footprint)
+    const int G16 = (n + 1024 * 16 - 1) / (1024 * 16);
+    if (G16 <= 12) return launch_multi<16>(b, n, m, bs_mask, G16, dataset, temp, idxs, stream);
+  }
   if (prefer8 && G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);
   if (G4 <= 12) return launch_multi<4>(b, n, m, bs_mask, G4, dataset, temp, idxs, stream);
   if (G8 <= 12) return launch_multi<8>(b, n, m, bs_mask, G8, dataset, temp, idxs, stream);

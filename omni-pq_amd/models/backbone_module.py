@@ -82,7 +82,7 @@ class Pointnet2Backbone(nn.Module):
                                      dtype=torch.int32) for n in ("sa1", "sa2", "sa3", "sa4")]
         return bufs[key]
 
-    def _launch_plan(self, pointcloud, trusted=False):
+    def _launch_plan(self, pointcloud, trusted=False, small=False):
         """FPS chain for `pointcloud` on the side stream -> {"key", "inds": [4 x (B,npoint) int32],
         "events": [4 x Event]}; the caller's stream has to wait on events[i] before using inds[i]."""
         main = torch.cuda.current_stream(pointcloud.device)
@@ -105,7 +105,7 @@ class Pointnet2Backbone(nn.Module):
             for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
                 npoint = getattr(self, name).npoint
                 if hasattr(ext, "set_timing_sink"):          # the product binding: write in place
-                    inds = ext.furthest_point_sampling(xyz, npoint, out=bufs[li])
+                    inds = ext.furthest_point_sampling(xyz, npoint, out=bufs[li], small_footprint=small)
                 else:
                     inds = ext.furthest_point_sampling(xyz, npoint)
                 ev = torch.cuda.Event()
@@ -134,7 +134,7 @@ class Pointnet2Backbone(nn.Module):
                     plan["extra"] = (name, e_inds, e_ev)
         return plan
 
-    def prefetch(self, pointcloud, trusted=False, at_next_forward=False):
+    def prefetch(self, pointcloud, trusted=False, at_next_forward=False, footprint=None):
         """Start the sampling plan of a FUTURE batch now (e.g. while the current batch is in backward).
         A later forward() on the very same tensor picks the result up; any other input recomputes.
         trusted=True: the next forward() takes the plan whatever tensor it is given (the caller vouches
@@ -142,13 +142,17 @@ class Pointnet2Backbone(nn.Module):
         at_next_forward=True: do not start now but inside the NEXT forward(), right after it has taken (and copied) the plan
         it runs on -- the earliest point at which the plan's persistent index buffers may be overwritten.  The sampling
         chain (7 ms of dependent argmax rounds for 8 x 40 000 points) then has the whole step to hide under, forward
-        included, instead of the backward pass only."""
+        included, instead of the backward pass only.
+        footprint: "small" runs the 40 000-point level on 3 instead of 5 compute units per scene with ~40 % longer rounds
+        (_ext.furthest_point_sampling(small_footprint=True): same indices) -- right when the chain ends well before the
+        step it hides under, which is the default for at_next_forward; "fast" otherwise (e.g. two chains per step)."""
         if not pointcloud.is_cuda:
             return
+        small = (footprint or ("small" if at_next_forward else "fast")) == "small"
         if at_next_forward:
-            self._pending = (pointcloud, trusted)
+            self._pending = (pointcloud, trusted, small)
         else:
-            self._plan = self._launch_plan(pointcloud, trusted)
+            self._plan = self._launch_plan(pointcloud, trusted, small)
 
     def join(self, device=None):
         """Make the current stream wait for everything queued on the sampling stream."""

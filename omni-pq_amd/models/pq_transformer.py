@@ -682,12 +682,12 @@ class PQ_Transformer(nn.Module):
             base_xyz_q = base_xyz_q.detach()
         return end_points
 
-    def prefetch(self, inputs, trusted=False, at_next_forward=False):
+    def prefetch(self, inputs, trusted=False, at_next_forward=False, footprint=None):
         """Optional: start the coordinate-only sampling (FPS chain of the backbone) of a FUTURE batch on
         a side stream; `forward` on the same `inputs['point_clouds']` tensor then skips it.  Results do
         not change (sa1's FPS depends only on the input cloud).  at_next_forward: start it inside the
         next forward() call (of the CURRENT batch) instead of now, see Pointnet2Backbone.prefetch."""
-        self.backbone.prefetch(inputs['point_clouds'], trusted, at_next_forward)
+        self.backbone.prefetch(inputs['point_clouds'], trusted, at_next_forward, footprint)
 
     def join_prefetch(self):
         """Order the current stream after the sampling stream (needed before a graph capture ends)."""

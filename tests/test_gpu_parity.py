@@ -68,6 +68,22 @@ def test_fps_index_exact(kind, b, n, m):
     assert torch.equal(tmp.cpu(), want_tmp)
 
 
+@pytest.mark.parametrize("kind,b,n,m", [c for c in FPS_CASES if c[2] > 8192])
+def test_fps_small_footprint_variant_gives_the_same_indices(kind, b, n, m):
+    """omnipq_fps_footprint(1): 16 points per thread, fewer workgroups per scene (what the prefetched sampling chain of a
+    training step runs on) -- indices and running distances equal the oracle's, and the switch is per thread and resets."""
+    xyz = cloud(kind, 5, b, n)
+    want = oracle_ext.furthest_point_sampling(xyz, m)
+    capi.lib().omnipq_fps_footprint(1)
+    try:
+        got, tmp = capi.fps(xyz.to(dev()), m)
+    finally:
+        capi.lib().omnipq_fps_footprint(0)
+    fast, tmp_fast = capi.fps(xyz.to(dev()), m)
+    assert torch.equal(got.cpu(), want), f"first mismatch at {(got.cpu() != want).nonzero()[:3].tolist()}"
+    assert torch.equal(fast, got) and torch.equal(tmp, tmp_fast)
+
+
 def test_fps_all_points_inside_skip_ball_yields_zeros():
     xyz = torch.rand(2, 500, 3) * 0.01            # |p|^2 <= 1e-3 everywhere
     got, _ = capi.fps(xyz.to(dev()), 40)
