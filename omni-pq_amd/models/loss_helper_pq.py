@@ -22,6 +22,15 @@ in a B x 256 x 256 Python loop that reads a device scalar per iteration.  Here t
 plus a dozen scalar ops to weigh the terms, with no host read anywhere (the step can be captured in a hipGraph); the
 backward is five launches that recompute their rows and write every gradient entry.  There is no CPU path: CPU tensors are
 refused (the CPU restatement used by the tests lives in oracle/get_loss_oracle.py and is never imported from here).
+
+Two deviations in behaviour, both outside what the reference's drivers exercise:
+  * `get_loss(..., num_layer=n)` hands n to every sub-loss, which then sums the proposal head and the n decoder heads.  The
+    reference's get_loss (:412-486) calls its sub-losses with their DEFAULT num_layer = 6 whatever it was given and uses n
+    only in the 1 / (n + 1) factor: for n = 6 (the only value train.py passes, and the tested one) the two are identical; for
+    n < 6 the reference sums seven heads while dividing by n + 1, for n > 6 it divides by more heads than it sums -- here sum and
+    divisor always agree.
+  * the reductions add their per-workgroup partial sums with f32 / f64 atomics: the last bits of a loss value depend on the
+    order workgroups finish in, i.e. the loss is not bit-reproducible from run to run (tests compare at 1e-5 relative).
 """
 import ctypes
 

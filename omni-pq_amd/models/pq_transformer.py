@@ -111,13 +111,33 @@ def head_stack(self, net, heads, net_rows=None, raw=False):
 
 
 def _head_bias(self, stack, heads, w, raw, on_gpu):
-    """The output layer's joint bias (zero-padded to the kernels' width with `raw`)."""
+    """The output layer's joint bias (zero-padded to the kernels' width with `raw`).  ONE seated buffer serves both modes:
+    it is always padded, the unpadded form is its leading view (two buffers would un-seat each other at every call)."""
     width = w.shape[0]
-    pad_to = (width + 31) // 32 * 32 if raw else None
+    padded = (width + 31) // 32 * 32
     if _JOINT_HEADS and on_gpu:
-        stack[2].bias = sa_fused.joint_params(self, "b_raw" if raw else "b", [h.bias for h in heads], pad_to=pad_to)
+        b = sa_fused.joint_params(self, "b", [h.bias for h in heads], pad_to=padded)
+        if not raw and padded != width:
+            parts = b.omnipq_parts
+            b = b[:width]
+            b.omnipq_parts = parts
+        stack[2].bias = b
     else:
-        stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=pad_to)
+        stack[2].bias = sa_fused.cat_params([h.bias for h in heads], pad_to=padded if raw else None)
+
+
+def seat_head_parameters(head):
+    """Move the 1x1 output heads' weights and biases of a prediction head into their joint buffers NOW (sa_fused.joint_params
+    does it lazily inside the first forward otherwise).  Anything that records parameter storage -- a captured hipGraph,
+    flattened / bucketed gradient views, an optimizer's foreach lists -- must be built after this; PQ_Transformer calls it
+    for every head whenever the module is moved (`.to()`, `.cuda()`), so only code that holds raw pointers across such a
+    move has to care."""
+    heads = head.heads()
+    if not (_JOINT_HEADS and heads[0].weight.is_cuda):
+        return
+    w = sa_fused.joint_params(head, "w", [h.weight for h in heads])
+    width = w.shape[0]
+    sa_fused.joint_params(head, "b", [h.bias for h in heads], pad_to=(width + 31) // 32 * 32)
 
 
 def head_stack_pair(head, quad_head, net, net_q, rows_a=None, rows_b=None):
@@ -448,7 +468,24 @@ def decode_scores(base_xyz, objectness_scores, center, heading_scores, heading_r
     return end_points, pred_size
 
 
-class PredictHead(nn.Module):
+class _SeatedHeads:
+    """copy.deepcopy of a prediction head (the EMA teacher is a deepcopy of the student): Parameter.__deepcopy__ clones every
+    parameter into storage of its own, so the copy's output heads are seated into fresh joint buffers right away instead of
+    inside its first forward."""
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_omnipq_joint":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        with torch.no_grad():
+            seat_head_parameters(new)
+        return new
+
+
+class PredictHead(_SeatedHeads, nn.Module):
     """Object head: 2 x (Conv1d+BN+ReLU) trunk, then seven 1x1 heads (reference :62-91)."""
 
     def __init__(self, hidden_dim, num_heading_bin, num_size_cluster, num_class, mean_size_arr):
@@ -503,7 +540,7 @@ class PredictHead(nn.Module):
         return center, pred_size, end_points
 
 
-class QuadPredictHead(nn.Module):
+class QuadPredictHead(_SeatedHeads, nn.Module):
     """Layout-quad head: scores, centre, normal, size (reference :94-121).  The normal is divided
     by the 2-norm of the WHOLE (B,K,3) tensor (:112-113) -- batch-coupled, reproduced as is."""
 
@@ -681,6 +718,14 @@ class PQ_Transformer(nn.Module):
             base_xyz = base_xyz.detach()
             base_xyz_q = base_xyz_q.detach()
         return end_points
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, (PredictHead, QuadPredictHead)):
+                    seat_head_parameters(m)
+        return out
 
     def prefetch(self, inputs, trusted=False, at_next_forward=False, footprint=None):
         """Optional: start the coordinate-only sampling (FPS chain of the backbone) of a FUTURE batch on

@@ -112,3 +112,48 @@ def test_ema_update_matches_the_oracle():
     assert len(ema._TABLES) == 1
     with pytest.raises(RuntimeError, match="CPU not supported"):
         ema.update_ema_variables(torch.nn.Linear(2, 2), torch.nn.Linear(2, 2), 0.999, 1)
+
+
+def test_output_head_parameters_are_seated_when_the_model_is_moved_and_stay_put():
+    """The 1x1 output heads of every prediction head live as row ranges of one joint weight matrix and one (padded) joint
+    bias vector.  They are seated by `.to(device)` -- before anything can record parameter storage (a captured graph,
+    gradient buckets) -- and a training step, an eval step and a deepcopy (the EMA teacher) leave every address where it is."""
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    import synth
+    import pq_transformer
+    dev = torch.device("cuda", 0)
+    net = bench.build_model(0).to(dev).train()
+    heads = [m for m in net.modules() if isinstance(m, (pq_transformer.PredictHead, pq_transformer.QuadPredictHead))]
+    assert len(heads) == 14
+
+    def addresses(model):
+        return {n: p.data_ptr() for n, p in model.named_parameters()}
+
+    for m in heads:
+        joint_w, joint_b = m._omnipq_joint["w"], m._omnipq_joint["b"]
+        off_w = off_b = 0
+        for h in m.heads():
+            assert h.weight.data_ptr() == joint_w.data_ptr() + off_w and h.bias.data_ptr() == joint_b.data_ptr() + off_b
+            off_w += h.weight.numel() * 4
+            off_b += h.bias.numel() * 4
+        assert joint_b.shape[0] % 32 == 0 and float(joint_b[off_b // 4:].abs().sum()) == 0.0
+    before = addresses(net)
+    pc = synth.make_clouds(5, 2, 8192, kind="room").to(dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ep = net({"point_clouds": pc})
+    sum(v.float().sum() for k, v in ep.items() if v.is_floating_point() and v.requires_grad).backward()
+    assert all(p.grad is not None for m in heads for h in m.heads() for p in (h.weight, h.bias))
+    net.eval()
+    with torch.no_grad():
+        net({"point_clouds": pc})                       # f32 eval: the unpadded view of the same bias buffer
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            net({"point_clouds": pc})
+    assert addresses(net) == before
+    teacher = copy.deepcopy(net)
+    t_before = addresses(teacher)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        teacher({"point_clouds": pc})
+    moved = [n for n, a in addresses(teacher).items() if a != t_before[n]] + [n for n, a in addresses(net).items() if a != before[n]]
+    assert not moved, moved
