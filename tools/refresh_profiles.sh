@@ -57,7 +57,7 @@ if [ "${2:-}" != "--collect" ]; then
     rm -rf $OUT/$m
   done
   : > $OUT/other_lines.jsonl
-  for F in "--mean-teacher" "--loss supervised" "--input-pipeline" "--dtype fp16 --batch 16 --points 80000" "--dtype bf16 --batch 16 --points 80000" "--batch 4 --points 50000 --extra-channels 6" "--dtype fp16" "--prefetch-at backward"; do
+  for F in "--mean-teacher" "--loss supervised" "--input-pipeline" "--dtype fp16 --batch 16 --points 80000" "--dtype bf16 --batch 16 --points 80000" "--batch 4 --points 50000 --extra-channels 6" "--dtype fp16" "--prefetch-at backward" "--fps-footprint fast"; do
     python $R/bench.py --no-cpu-baseline $F 2>/dev/null | grep "^{" | python -c "
 import sys, json
 for l in sys.stdin:
