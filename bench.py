@@ -302,6 +302,19 @@ def pmc_traffic(kind):
         return None, None
 
 
+def counters_stale(summary):
+    """True if a committed counter summary was taken on other kernel sources than the ones in the tree (its
+    `kernel_sources_sha1` stamp against omni-pq_amd/build.py:sources_digest), None if it carries no stamp."""
+    stamp = summary.get("kernel_sources_sha1") if isinstance(summary, dict) else None
+    if stamp is None:
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("omnipq_build", os.path.join(REPO, "omni-pq_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return stamp != mod.sources_digest()
+
+
 # C-ABI entry point -> substring of the device kernel it launches for the benchmark's shapes
 PMC_KERNEL_OF = {"omnipq_furthest_point_sampling": "fps_kernel<1024, "}
 
@@ -931,6 +944,8 @@ def main():
             if sa_pmc is not None and args.batch == 8 and args.points == 40000 and args.dtype == "bf16":
                 rec["roofline"]["traffic"] = sa_pmc["total_traffic_bytes_per_step"]
                 rec["roofline"]["traffic_source"] = sa_file
+                # a counter figure read from profiles/ says so when the kernels changed after it was taken
+                rec["roofline"]["traffic_stale"] = counters_stale(sa_pmc)
             mf, mf_file = pmc_mfma("bench")
             sa_mf, sa_mf_file = pmc_mfma("sa_stage")
             if mf is not None:
@@ -938,12 +953,12 @@ def main():
                                "bf16_mfma_gflop_per_step": mf["bf16_mfma_flops_per_step"] / 1e9,
                                "peak_tflops_dense_bf16": 2500.0, "source": mf_file,
                                "busy_frac_sa_stage": None if sa_mf is None else sa_mf["mfma_busy_frac_over_all_dispatches"],
-                               "source_sa_stage": sa_mf_file,
+                               "source_sa_stage": sa_mf_file, "stale": counters_stale(mf),
                                "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) from a separate rocprofv3 "
                                        "counter pass of this command (tools/pmc_mfma.py)"}
             rec["hbm_copy_ceiling_gbs"] = ceiling
-            rec["sa_stage"] = {k: rec["roofline"][k] for k in ("avg_ms", "achieved", "peak", "unit", "frac", "traffic",
-                                                                "traffic_source", "feature_bytes")}
+            rec["sa_stage"] = {k: rec["roofline"].get(k) for k in ("avg_ms", "achieved", "peak", "unit", "frac", "traffic",
+                                                                    "traffic_source", "traffic_stale", "feature_bytes")}
             rec["sa_stage"]["ms_per_step"] = sa_ms
             rec["sa_stage"]["algorithmic_bytes"] = sa_bytes
             if args.breakdown:

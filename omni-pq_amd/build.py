@@ -45,6 +45,22 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def sources_digest():
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): stamped into the counter summaries under profiles/
+    by tools/pmc_*.py and compared by bench.py, which labels a committed counter figure `stale` when the kernels have changed
+    since it was taken."""
+    import hashlib
+    h = hashlib.sha1()
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    files += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -168,3 +168,22 @@ def test_joint_params_reseat_once_and_stay_consistent():
     x = sa_fused.joint_params(own, "w", [h.weight for h in own.heads])
     (x.detach().sum() + own.heads[0].bias.sum()).backward()
     assert all(h.weight.grad is None for h in own.heads)
+
+
+def test_bench_labels_committed_counter_figures_taken_on_other_kernel_sources():
+    """bench.py reads HBM traffic / MFMA-busy from the counter summaries under profiles/; each carries the digest of the
+    kernel sources it was measured on, and a figure from other sources is labelled stale in the JSON line."""
+    import importlib.util
+    import os
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    import bench
+    spec = importlib.util.spec_from_file_location("omnipq_build", os.path.join(REPO, "omni-pq_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    now = mod.sources_digest()
+    assert len(now) == 40 and now == mod.sources_digest()
+    assert bench.counters_stale({"kernel_sources_sha1": now}) is False
+    assert bench.counters_stale({"kernel_sources_sha1": "0" * 40}) is True
+    assert bench.counters_stale({"total_traffic_bytes_per_step": 1.0}) is None       # summaries older than the stamp

@@ -26,6 +26,16 @@ XCDS = 8      # the CSV holds ONE value per dispatch and counter: the sum over t
               # (rocprofv3's own MfmaUtil uses reduce(GRBM_GUI_ACTIVE, max) for the same reason)
 
 
+def _digest():
+    """The kernel sources this summary was measured on (omni-pq_amd/build.py:sources_digest)."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("omnipq_build", os.path.join(here, "omni-pq_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.sources_digest()
+
+
 def main():
     d, warm_frac, steps, out_json, out_md = sys.argv[1:6]
     warm_frac, steps = float(warm_frac), int(steps)
@@ -51,7 +61,7 @@ def main():
     rows.sort(key=lambda r: -r["mfma_busy_cycles_per_step"])
     overall = tot_busy / (tot_active * SIMDS) if tot_active else 0.0
     json.dump({"mfma_busy_frac_over_all_dispatches": overall, "bf16_mfma_flops_per_step": tot_mops * 512 / steps,
-               "kernels": rows}, open(out_json, "w"), indent=1)
+               "kernel_sources_sha1": _digest(), "kernels": rows}, open(out_json, "w"), indent=1)
     with open(out_md, "w") as fh:
         fh.write(f"MFMA-busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x {SIMDS} SIMDs)) over all dispatches of a step: "
                  f"{100 * overall:.2f} %; bf16 MFMA work {tot_mops * 512 / steps / 1e9:.1f} GFLOP per step\n\n")

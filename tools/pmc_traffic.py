@@ -27,6 +27,16 @@ def load(d, name):
     return per
 
 
+def _digest():
+    """The kernel sources this summary was measured on (omni-pq_amd/build.py:sources_digest)."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("omnipq_build", os.path.join(here, "omni-pq_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.sources_digest()
+
+
 def main():
     fdir, wdir, warm_frac, steps, out_json, out_md = sys.argv[1:7]
     steps = int(steps)
@@ -45,7 +55,8 @@ def main():
                      "traffic_bytes_per_step": 2 * fb + wb})
     rows.sort(key=lambda r: -r["traffic_bytes_per_step"])
     total = sum(r["traffic_bytes_per_step"] for r in rows)
-    json.dump({"total_traffic_bytes_per_step": total, "kernels": rows}, open(out_json, "w"), indent=1)
+    json.dump({"total_traffic_bytes_per_step": total, "kernel_sources_sha1": _digest(), "kernels": rows},
+              open(out_json, "w"), indent=1)
     with open(out_md, "w") as fh:
         fh.write(f"HBM traffic per step from PMC (FETCH_SIZE x2 + WRITE_SIZE): {total / 1e9:.2f} GB\n\n")
         fh.write("| kernel | launches/step | fetch (corrected) MB | write MB | MB / launch |\n|---|---|---|---|---|\n")

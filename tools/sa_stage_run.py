@@ -61,7 +61,9 @@ def main():
     def step():
         for p in net.parameters():
             p.grad = None
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        import sa_fused
+        # as PQ_Transformer.forward: every weight matrix of the step prepared by ONE launch (the model's weight arena)
+        with torch.autocast("cuda", dtype=torch.bfloat16), sa_fused.arena_of(net).step(dev):
             x, f = xyz, None
             loss = 0.0
             for k, (sa, i) in enumerate(zip(stages, inds)):
@@ -70,7 +72,6 @@ def main():
                     loss = loss + rows_loss(k, f)
             _, vf, _ = net.vote_aggregation(seed_xyz, seed_feat, vote_inds)
             loss = loss + rows_loss("vote", vf)
-        import sa_fused
         with sa_fused.deferred_wgrads():          # as bench.py's step: the stages' weight gradients as one grouped launch
             loss.backward()
 
