@@ -31,7 +31,12 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 # per-file extra flags.  fps.hip: the SLP vectorizer packs the per-point f32 arithmetic into
 # v_pk_* pairs, which doubles the live registers of the 8-points-per-thread variants (134 spilled
 # VGPRs); scalar code needs 79 and runs the same instruction count.
-EXTRA = {"fps.hip": ["-fno-slp-vectorize"]}
+# attention.hip: -amdgpu-mfma-vgpr-form keeps the MFMA accumulators in the architectural registers.  The compiler's default
+# put the output accumulators (which the online-softmax rescale also touches with VALU instructions) into AGPRs and copied them
+# out and back around the matrix instructions of EVERY key block: 64 v_accvgpr_read / _write + 26 v_mov of the ~570 VALU
+# instructions of a forward iteration.  With the flag: no copies, 160 / 184 / 204 registers instead of 192 / 212 / 236
+# (forward: three waves per SIMD instead of two).
+EXTRA = {"fps.hip": ["-fno-slp-vectorize"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc():
