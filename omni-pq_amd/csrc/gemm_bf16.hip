@@ -835,14 +835,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(long long n4, i
 // Long contractions over few tiles (the decoder's 2048-wide feed-forward: 96 tiles, 64 K-steps each) are
 // latency bound: split K over `slabs` workgroups per tile into f32 partials (workspace: slabs * M * N floats),
 // then one pass sums them, adds the bias and rounds to bf16.
-static int gemm_nt_splitk_slabs(int M, int N, int K) {
+struct SplitPlan {
+  int slabs, T;
+};
+static SplitPlan gemm_nt_split_plan(int M, int N, int K) {
   const int tiles = ((M + omnipq::GBM - 1) / omnipq::GBM) * ((N + omnipq::GBN - 1) / omnipq::GBN);
-  if (K < 1024 || tiles > 128) return 1;
-  int slabs = 512 / tiles;
+  if (K < 1024 || tiles > 128) return SplitPlan{1, 128};
+  // 64 x 64 tiles put four times as many workgroups on a slab, so ~1000 workgroups take fewer slabs (less partial traffic,
+  // a shorter reduction) and each runs a third of the K-steps: 4096 x 288 x 2048 (the feed-forward's second layer and its
+  // data gradient) 21.7 + 5.1 us with five slabs of 128 x 128 tiles -> three slabs of 64 x 64
+  const long long tiles64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+  int slabs = (int)(1024 / tiles64);
   if (slabs > K / 256) slabs = K / 256;                      // >= 8 K-steps per slab
   if (slabs > 8) slabs = 8;
-  return slabs < 2 ? 1 : slabs;
+  if (slabs >= 2) return SplitPlan{slabs, 64};
+  slabs = 512 / tiles;
+  if (slabs > K / 256) slabs = K / 256;
+  if (slabs > 8) slabs = 8;
+  return SplitPlan{slabs < 2 ? 1 : slabs, 128};
 }
+static int gemm_nt_splitk_slabs(int M, int N, int K) { return gemm_nt_split_plan(M, N, K).slabs; }
 
 extern "C" long long omnipq_gemm_nt_workspace_floats(int M, int N, int K) {
   const int slabs = gemm_nt_splitk_slabs(M, N, K);
@@ -850,16 +862,21 @@ extern "C" long long omnipq_gemm_nt_workspace_floats(int M, int N, int K) {
 }
 
 static int gemm_nt_splitk_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
-                               const float *bias, float *workspace, int slabs, void *stream) {
+                               const float *bias, float *workspace, SplitPlan plan, void *stream) {
   using namespace omnipq;
   if (ldc != N || (N % 4)) return OMNIPQ_EINVAL;
+  const int slabs = plan.slabs, T = plan.T;
   int k_chunk = ((K / GBK + slabs - 1) / slabs) * GBK;
   const int used = (K + k_chunk - 1) / k_chunk;
-  GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  GemmArgs g{M, N, K, lda, ldb, N, k_chunk, (M + T - 1) / T, (N + T - 1) / T};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, used);
-  gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace,
-                                                           nullptr);
+  if (T == 64)
+    gemm_nt_kernel<true, 0, false, 64><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B,
+                                                                             workspace, nullptr);
+  else
+    gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace,
+                                                             nullptr);
   OMNIPQ_LAUNCH_CHECK();
   const long long n4 = (long long)M * N / 4;
   splitk_reduce_bf16_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
@@ -1400,9 +1417,9 @@ extern "C" int omnipq_gemm_nt_e16_ws(int M, int N, int K, const void *A, int lda
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
-  const int slabs = gemm_nt_splitk_slabs(M, N, K);
-  if (slabs > 1 && workspace && ldc == N)
-    return gemm_nt_splitk_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, workspace, slabs, stream);
+  const SplitPlan plan = gemm_nt_split_plan(M, N, K);
+  if (plan.slabs > 1 && workspace && ldc == N)
+    return gemm_nt_splitk_bf16(M, N, K, A, lda, B, ldb, C, ldc, bias, workspace, plan, stream);
   if (gemm_nt_small_tiles(M, N)) {
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
     launch_small<0, false>(g, A, B, C, bias, nullptr, BnBwdEpilogue(), AffineIn(), stream);
