@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Time the grouped weight-gradient launch of the SA stages in isolation: one training step records the problem table of the
+"@sa" flush (sa_fused.deferred_wgrads), then the same `omnipq_gemm_tn_grouped` call is replayed on the recorded operands.
+
+    python tools/bench_tn_grouped.py [--reps 20]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("omni-pq_amd", "omni-pq_amd/pointnet2", "omni-pq_amd/models"):
+    sys.path.insert(0, os.path.join(REPO, p))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import sa_fused
+    import synth
+    dev = torch.device("cuda", 0)
+    net = bench.build_model(0).to(dev).train()
+    pc = synth.make_clouds(100, 8, 40000, kind="room").to(dev)
+    captured = []
+    orig = sa_fused._lib.omnipq_gemm_tn_grouped
+    keep = []
+
+    # record through the python-level call: wrap _call's target by name
+    real_call = sa_fused._call
+
+    def spy_call(fn, ref, *a):
+        if fn is orig and sa_fused._ext.timing_tag == "@sa":
+            captured.append(a)
+        return real_call(fn, ref, *a)
+    sa_fused._call = spy_call
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ep = net({"point_clouds": pc})
+    loss = sum(v.float().mean() for k, v in ep.items() if v.is_floating_point() and v.requires_grad)
+    with sa_fused.deferred_wgrads() as dfr:
+        loss.backward()
+        keep.append(dfr)
+        items = list(dfr.sa_items)           # operands stay alive through `keep`
+    sa_fused._call = real_call
+    torch.cuda.synchronize()
+    if not captured:
+        print("no @sa grouped launch recorded")
+        return
+    n, probs, ws = captured[-1]
+    pr = ctypes.cast(probs, ctypes.POINTER(sa_fused._TnProblem))
+    tot = 0
+    for i in range(n):
+        q = pr[i]
+        tot += 2 * q.P * (q.M + q.N)
+        print(f"  problem {i:2d}: P {q.P:8d}  M {q.M:4d}  N {q.N:4d}  affine {bool(q.ba)}  rot {q.rot}")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        real_call(orig, items[0][0], n, probs, ws)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.reps):
+        real_call(orig, items[0][0], n, probs, ws)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    print(f"grouped SA weight gradients: {n} problems, {tot / 1e9:.2f} GB of operands (each read once), {ms * 1e3:.1f} us per "
+          f"call = {tot / ms / 1e6:.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
