@@ -75,7 +75,13 @@ def dgrad(M, N, K):
     report(f"bnbwd {M} x {N} x {K}", timed(run), (M // 128) * ((N + 127) // 128))
 
 
-forward_pool(1 << 20, 256, 128, 64)
-dgrad(1 << 20, 128, 256)
-forward_pool(1 << 18, 512, 256, 32)
-dgrad(1 << 18, 256, 512)
+if "--small" in sys.argv:                      # sa4 / vote aggregation: 32 768 grouped positions, one round of workgroups
+    forward_pool(1 << 15, 512, 256, 16)
+    dgrad(1 << 15, 256, 512)
+    forward_pool(1 << 15, 288, 288, 16)
+    dgrad(1 << 15, 288, 288)
+else:
+    forward_pool(1 << 20, 256, 128, 64)
+    dgrad(1 << 20, 128, 256)
+    forward_pool(1 << 18, 512, 256, 32)
+    dgrad(1 << 18, 256, 512)
