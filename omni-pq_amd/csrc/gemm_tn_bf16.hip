@@ -519,19 +519,20 @@ struct omnipq_tn_problem_ {
 
 // Positions per workgroup in a grouped launch, the same for every problem of the call (balance): at least 16 K-steps
 // (the ~115 per-point layers of 4096 rows: the grid is full anyway), and for calls that carry the SA stages' layers (up to
-// 1 M rows each) as many as it takes to bring the call down to ~2048 workgroups (~4096 without such layers) -- a workgroup leaves a 64 KB f32 slab
+// 1 M rows each) as many as it takes to bring the call down to ~2048 workgroups (~8192 without such layers) -- a workgroup leaves a 64 KB f32 slab
 // behind, the bytes of four K-steps of operands, so slabs of 16 steps on a million-row problem would move more than the
 // operands do.
 static int tng_chunk(int nprob, const omnipq_tn_problem_ *pr) {
   long long tile_steps = 0;
   for (int i = 0; i < nprob; ++i)
     tile_steps += (long long)((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128) * ((pr[i].P + omnipq::TBK - 1) / omnipq::TBK);
-  // ~4096 workgroups for the calls of per-point layers (4096 .. 8192 rows each: halving that count cost the step 0.3 ms),
+  // ~8192 workgroups for the calls of per-point layers (4096 .. 8192 rows each; they run on a side stream underneath the
+  // backbone's backward pass: step 11.15 / 10.85 / 10.76 / 10.81 ms with ~2048 / 4096 / 8192 / 16384),
   // ~2048 for calls that carry SA-stage layers (measured on their 13-problem call, tools/bench_tn_grouped.py: slabs of
   // 40 / 75 / 150 / 300 K-steps = ~8000 / 4100 / 2050 / 1030 workgroups: 791 / 746 / 702 / 761 us)
   int max_p = 0;
   for (int i = 0; i < nprob; ++i) max_p = pr[i].P > max_p ? pr[i].P : max_p;
-  const long long target = max_p >= 65536 ? 2048 : 4096;
+  const long long target = max_p >= 65536 ? 2048 : 8192;
   long long steps = (tile_steps + target - 1) / target;
   if (steps < 16) steps = 16;
   if (steps > 1024) steps = 1024;
