@@ -193,6 +193,11 @@ def _grad_descriptors(gs, n2):
 
 _FUSED_DECODE = True       # False: the op-by-op decode of the reference (tests compare the two)
 _WGRAD_SIDE = True
+# The early weight-gradient flush runs on a stream of its own ("own"; "sampling" = behind the next batch's sampling chain on
+# the backbone's side stream, as until the end of round 3: 10.77 vs 10.69 ms).  More flush points, in front of decoder layers,
+# were measured and lost: one 11.04 ms, two 13.6, five 15.0 -- every fork / join pair inside the captured step costs more
+# than the overlap returns.
+_FLUSH_STREAM = "own"
 
 
 class HeadDecode(torch.autograd.Function):
@@ -650,10 +655,10 @@ class PQ_Transformer(nn.Module):
         seed_features = end_points['fp2_features']
         if _WGRAD_SIDE and seed_features.is_cuda and seed_features.requires_grad:
             # backward: when the gradient reaches this point the decoder, the heads and the voting module are done --
-            # their collected weight gradients (sa_fused.deferred_wgrads) start on the sampling stream underneath the
+            # their collected weight gradients (sa_fused.deferred_wgrads) start on a side stream underneath the
             # backbone's backward pass
             seed_features = sa_fused.WgradFlushPoint.apply(
-                seed_features, lambda dev=seed_features.device: self.backbone._side_stream(dev))
+                seed_features, lambda dev=seed_features.device: self._flush_stream(dev))
 
         # layout branch: FPS over the seeds
         quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features, self.backbone.take_extra("sa2"))
@@ -718,6 +723,20 @@ class PQ_Transformer(nn.Module):
             base_xyz = base_xyz.detach()
             base_xyz_q = base_xyz_q.detach()
         return end_points
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_omnipq_flush_streams", None)        # streams do not travel with a copy of the module (EMA teacher, torch.save)
+        return state
+
+    def _flush_stream(self, device):
+        """The stream early weight-gradient flushes run on (sa_fused.WgradFlushPoint)."""
+        if _FLUSH_STREAM == "sampling":
+            return self.backbone._side_stream(device)
+        streams = self.__dict__.setdefault("_omnipq_flush_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device=device)
+        return streams[device]
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
