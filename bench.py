@@ -492,8 +492,9 @@ class _RawScenes(torch.utils.data.Dataset):
 class HostFeeder:
     """The input side of the step on the host, as the reference has it (train.py:230-275, 465-472): a
     torch DataLoader whose `workers` processes sub-sample raw scenes (random_sampling per item) and collate batches,
-    its pin-memory thread stages them, and the step issues ONE host-to-device copy on its own stream into the static
-    buffer the captured step (and the next sampling plan) reads."""
+    its pin-memory thread stages them, and every step consumes ONE host-to-device copy: issued one batch ahead on a copy
+    stream (underneath the step before), handed to the static buffer the captured step and the next sampling plan read by
+    a device-to-device copy."""
 
     def __init__(self, args, device, rank):
         import synth
@@ -505,16 +506,38 @@ class HostFeeder:
                                                   persistent_workers=args.loader_workers > 0,
                                                   prefetch_factor=4 if args.loader_workers > 0 else None)
         self.it = iter(self.loader)
-        self.keep = collections.deque(maxlen=3)      # pinned batches whose copy may still be in flight
+        self.keep = collections.deque(maxlen=4)      # pinned batches whose copy may still be in flight
         self.host_wait_s = 0.0
+        # one batch ahead: the host-to-device copy of the batch AFTER the one handed out runs on a copy stream underneath
+        # the step (as input_pipeline.InputPipeline does); the step itself only pays a device-to-device copy
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.staging = None
+        self.ready = torch.cuda.Event()
+        self.consumed = torch.cuda.Event()
 
-    def next_into(self, dst):
-        """dst (device, static buffer) <- the next host batch, asynchronously on the current stream."""
+    def _stage_next(self):
         t0 = time.perf_counter()
         host = next(self.it)
         self.host_wait_s += time.perf_counter() - t0
-        dst.copy_(host, non_blocking=True)
+        if self.staging is None:
+            self.staging = torch.empty(host.shape, device=self.device, dtype=host.dtype)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.consumed)        # the previous contents have been handed out
+            self.staging.copy_(host, non_blocking=True)
+            self.ready.record(self.copy_stream)
         self.keep.append(host)
+
+    def next_into(self, dst):
+        """dst (device, static buffer) <- the next host batch.  Its host-to-device copy was started one call earlier on the
+        copy stream; the current stream waits for it, copies device-to-device, and the following batch's copy starts."""
+        cur = torch.cuda.current_stream(self.device)
+        if self.staging is None:
+            self.consumed.record(cur)
+            self._stage_next()
+        cur.wait_event(self.ready)
+        dst.copy_(self.staging, non_blocking=True)
+        self.consumed.record(cur)
+        self._stage_next()
 
     def close(self):
         self.it = None
