@@ -897,7 +897,7 @@ def main():
                       f"host pipeline INSIDE the timed region: torch DataLoader, {args.loader_workers} worker processes doing "
                       f"random_sampling {args.raw_points} -> {args.points} points per scene, pinned batches, one "
                       f"host-to-device copy of {args.batch * args.points * (3 + args.extra_channels) * 4 / 1e6:.2f} MB per "
-                      f"step; the main thread waited {1e3 * args.feeder.host_wait_s / max(args.steps + args.warmup, 1):.3f} "
+                      f"step (copy stream, one batch ahead); the main thread waited {1e3 * args.feeder.host_wait_s / max(args.steps + args.warmup, 1):.3f} "
                       "ms per step for the loader"),
             "data_parallel": (None if not distributed else
                               (f"{dp_counts}, all inside the graph (RCCL graph probe passed)"
