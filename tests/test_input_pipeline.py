@@ -106,3 +106,61 @@ def test_pipeline_delivers_the_batches_and_their_sampling_plans():
     fresh = [torch.full((2, 2048), -7, device=dev, dtype=torch.int32) for _ in range(8)]
     torch.cuda.synchronize()
     assert all(bool((t == -7).all()) for t in fresh)
+
+
+@pytest.mark.gpu
+def test_sampling_plans_started_inside_forward_give_the_same_step_as_no_prefetch():
+    """The captured benchmark step starts the NEXT batch's sampling chain inside the running batch's forward
+    (`prefetch(at_next_forward=True)`: small-footprint sampling on the side stream, the running plan's buffers copied out
+    first).  A sequence of steps run that way equals the same steps without any prefetch -- indices and features bit for
+    bit, a gradient to run-to-run noise -- and so does the plain `prefetch()` between forward and backward, with either
+    footprint."""
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    import synth
+    from procedural import load_procedural
+    dev = torch.device("cuda", 0)
+    pcs = [synth.make_clouds(40 + i, 2, 20000, kind="room").to(dev) for i in range(4)]
+
+    def run(mode):
+        net = load_procedural(bench.build_model(0)).to(dev).train()
+        outs = []
+        if mode in ("inside", "inside-fast"):
+            net.prefetch({"point_clouds": pcs[0]}, trusted=True)
+        for i, pc in enumerate(pcs):
+            for p in net.parameters():
+                p.grad = None
+            nxt = pcs[i + 1] if i + 1 < len(pcs) else None
+            if mode.startswith("inside") and nxt is not None:
+                net.prefetch({"point_clouds": nxt}, trusted=True, at_next_forward=True,
+                             footprint="fast" if mode == "inside-fast" else None)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                ep = net.backbone(pc)
+            if mode == "between" and nxt is not None:
+                net.prefetch({"point_clouds": nxt}, footprint="small" if i % 2 else "fast")
+            ep["fp2_features"].float().square().mean().backward()
+            outs.append((ep["sa1_inds"].clone(), ep["sa2_inds"].clone(), ep["fp2_inds"].clone(),
+                         ep["sa4_xyz"].clone(), ep["fp2_features"].detach().clone(),
+                         net.backbone.sa2.mlp_module[1].conv.weight.grad.clone()))
+        net.join_prefetch()
+        torch.cuda.synchronize()
+        return outs
+
+    want = run("none")
+    again = run("none")
+    names = ("sa1_inds", "sa2_inds", "fp2_inds", "sa4_xyz", "fp2_features", "grad")
+
+    def rel(x, y):
+        return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
+
+    # the backward pass is not bit-reproducible from run to run (f32 atomics in the scatter-adds, then bf16 roundings that
+    # flip on a last-bit difference): the yardstick for the gradient is what two identical runs differ by
+    noise = max(rel(a[-1], b[-1]) for a, b in zip(want, again))
+    assert noise < 2e-2, noise
+    for mode in ("inside", "inside-fast", "between"):
+        got = run(mode)
+        for step, (a, b) in enumerate(zip(want, got)):
+            for nm, x, y in zip(names[:-1], a, b):
+                assert torch.equal(x, y), (mode, step, nm)
+            assert rel(b[-1], a[-1]) <= 3 * noise + 1e-4, (mode, step, rel(b[-1], a[-1]), noise)
