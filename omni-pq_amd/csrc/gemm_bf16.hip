@@ -840,7 +840,8 @@ struct SplitPlan {
 };
 static SplitPlan gemm_nt_split_plan(int M, int N, int K) {
   const int tiles = ((M + omnipq::GBM - 1) / omnipq::GBM) * ((N + omnipq::GBN - 1) / omnipq::GBN);
-  if (K < 1024 || tiles > 128) return SplitPlan{1, 128};
+  // (K >= 768: also the data gradients of the packed q|k|v projections, 4096 x 288 x 864, 27 K-steps on 320 workgroups)
+  if (K < 768 || tiles > 128) return SplitPlan{1, 128};
   // 64 x 64 tiles put four times as many workgroups on a slab, so ~1000 workgroups take fewer slabs (less partial traffic,
   // a shorter reduction) and each runs a third of the K-steps: 4096 x 288 x 2048 (the feed-forward's second layer and its
   // data gradient) 21.7 + 5.1 us with five slabs of 128 x 128 tiles -> three slabs of 64 x 64
