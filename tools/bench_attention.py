@@ -29,5 +29,5 @@ def run(L, S, N, H, D, p, iters=50):
     print(f"L={L} S={S} N={N} H={H} D={D} p={p}: fwd {e[0].elapsed_time(e[1]) / iters * 1e3:.1f} us  bwd {e[1].elapsed_time(e[2]) / iters * 1e3:.1f} us")
 
 for p in (0.0, 0.1):
-    run(256, 256, 8, 8, 36, p)
-    run(256, 1024, 8, 8, 36, p)
+    run(512, 512, 8, 8, 36, p)         # the decoder's joint queries: 256 object + 256 quad proposals
+    run(512, 1024, 8, 8, 36, p)
