@@ -549,16 +549,12 @@ EMA_DECAY, EMA_STEP = 0.999, 100_000          # steady state of train.py:437: al
 
 def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_graph=False, teacher=None,
               teacher_pool=None, ddp=False, labels_pool=None):
-    """-> (step(i) -> loss tensor, launch mode string).  Eager: forward, loss, prefetch of the next
-    batch's sampling, backward.  Graph: the same sequence captured once and replayed -- always for a
-    single process; under torch.distributed only when `dist_graph` (the probe passed), with the
-    SyncBatchNorm all-reduces and the flat gradient all-reduce inside the graph."""
-    def teacher_forward(batch):
-        with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-            return teacher({"point_clouds": batch})            # train mode, no grad (train.py:462,490-491)
-
-    # DistributedDataParallel (--eager-dp ddp) needs the per-parameter hooks: no deferral there
-    defer = not ddp
+    """-> (step(i) -> loss tensor, launch mode string).  The step itself -- capture / replay, deferred grouped weight
+    gradients, the next batch's sampling chain started inside forward, gradient buckets -- is the product's
+    `train_step.CapturedStep` (omni-pq_amd/train_step.py); this function only cycles the benchmark's resident pool of
+    batches through it.  Graph: always for a single process; under torch.distributed only when `dist_graph` (the probe
+    passed), with the SyncBatchNorm all-reduces and the gradient-bucket all-reduces inside the graph."""
+    import train_step
     # multi-rank steps without DDP: two gradient buckets, the first (everything but the backbone: 15.4 M of 17.9 M
     # parameters) all-reduced on the side stream underneath the backbone's backward pass (data_parallel.GradientBuckets)
     buckets = None
@@ -576,147 +572,50 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
         return loss_helper_pq.get_loss(gt, LossConfig, pc_loss=True)[0]
 
     scale = float(getattr(args, "loss_scale", 0.0) or (16384.0 if getattr(args, "dtype", "bf16") == "fp16" else 1.0))
-
-    def backward(loss):
-        if buckets is not None:
-            buckets.collectives = 0
-        if scale != 1.0:
-            loss = loss * scale                      # static loss scaling (fp16): see --loss-scale
-        if defer:
-            import sa_fused
-            # ~130 weight gradients as a few grouped launches; under data parallelism the first gradient bucket is
-            # all-reduced from the block's early flush
-            with sa_fused.deferred_wgrads(on_early_flush=buckets.on_early_flush if buckets is not None else None):
-                loss.backward()
-        else:
-            loss.backward()
-        if buckets is not None:
-            buckets.finish()
-
-    def step(i):
-        for p in net.parameters():
-            p.grad = None
-        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-            ep = model({"point_clouds": pool[i % len(pool)]})
-            loss = criterion(ep, labels_pool[i % len(pool)] if labels_pool is not None else None)
-        if teacher is not None:
-            teacher_forward(teacher_pool[i % len(teacher_pool)])
-        if not args.no_prefetch:
-            # software pipelining across steps: the NEXT batch's furthest-point sampling (coordinates
-            # only) runs on a side stream underneath this batch's backward.  Every step still does
-            # one batch worth of sampling inside the timed region.
-            net.prefetch({"point_clouds": pool[(i + 1) % len(pool)]})
-            if teacher is not None:
-                teacher.prefetch({"point_clouds": teacher_pool[(i + 1) % len(teacher_pool)]})
-        backward(loss)
-        if teacher is not None:
-            import ema
-            ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)       # train.py:576
-        return loss
-
     use_graph = args.graph in ("on", "auto") and (not distributed or dist_graph)
+    prefetch = None if args.no_prefetch else (getattr(args, "prefetch_at", "forward") if use_graph else "backward")
+    footprint = getattr(args, "fps_footprint", "auto")
+    if footprint == "auto":
+        footprint = None       # Pointnet2Backbone.prefetch: small for a chain started inside forward (measured: default step
+                               # 11.52 -> 11.23 ms, configs[4] 19.65 -> 19.20, mean-teacher step 15.85 either way)
+    n = len(pool)
+    captured = True
+    stepper = None
+    try:
+        stepper = train_step.CapturedStep(
+            net, criterion, {"point_clouds": pool[0]}, labels_pool[0] if labels_pool is not None else None, model=model,
+            amp_dtype=amp_dtype, loss_scale=scale, graph=use_graph, prefetch=prefetch, fps_footprint=footprint,
+            teacher=teacher, teacher_example=None if teacher is None else {"point_clouds": teacher_pool[0]},
+            ema=(EMA_DECAY, EMA_STEP) if teacher is not None else None, buckets=buckets, defer=not ddp,
+            warmup=args.warmup, distributed=distributed)
+    except Exception as exc:       # noqa: BLE001 -- whatever refused the capture, the eager path still works
+        if not (distributed and use_graph):
+            raise
+        captured = False
+        print(f"bench.py: graph capture failed on this rank ({exc!r}); falling back to eager", file=sys.stderr)
+    if distributed and use_graph:
+        flag = torch.tensor([1 if captured else 0], device=pool[0].device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            raise GraphUnavailable()
+    args.stepper = stepper
+    feeder = getattr(args, "feeder", None)
+
     if use_graph:
-        # The whole step (forward, loss, next batch's sampling, backward; ~3000 launches) is captured ONCE
-        # into a hipGraph and replayed: same kernels, same order, no per-launch host work.  Two static
-        # input buffers: `cur` feeds forward/backward, `nxt` feeds the sampling plan of the following
-        # step (side stream, underneath backward), whose indices land in the backbone's persistent plan
-        # buffers and are consumed by the next replay.  Per step two 3.84 MB device-to-device copies refill
-        # the buffers inside the timed region.
-        cur = pool[0].clone()
-        nxt = pool[0].clone()
-        cur_t = teacher_pool[0].clone() if teacher is not None else None
-        nxt_t = teacher_pool[0].clone() if teacher is not None else None
-        lab_cur = {k: v.clone() for k, v in labels_pool[0].items()} if labels_pool is not None else None
-
-        early = not args.no_prefetch and getattr(args, "prefetch_at", "forward") == "forward"
-        footprint = getattr(args, "fps_footprint", "auto")
-        if footprint == "auto":
-            footprint = None       # Pointnet2Backbone.prefetch: small for a chain started inside forward (measured: default step
-                                   # 11.52 -> 11.23 ms, configs[4] 19.65 -> 19.20, mean-teacher step 15.85 either way)
-
-        def graph_body():
-            for p in net.parameters():
-                p.grad = None
-            if early:
-                # the next batch's sampling chain starts inside forward(), as soon as this batch's plan has been taken
-                net.prefetch({"point_clouds": nxt}, trusted=True, at_next_forward=True, footprint=footprint)
-                if teacher is not None:
-                    teacher.prefetch({"point_clouds": nxt_t}, trusted=True, at_next_forward=True, footprint=footprint)
-            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                ep = model({"point_clouds": cur})
-                loss = criterion(ep, lab_cur)
-            if teacher is not None:
-                teacher_forward(cur_t)
-            if not args.no_prefetch and not early:
-                net.prefetch({"point_clouds": nxt}, trusted=True)
-                if teacher is not None:
-                    teacher.prefetch({"point_clouds": nxt_t}, trusted=True)
-            backward(loss)
-            net.join_prefetch()
-            if teacher is not None:
-                teacher.join_prefetch()
-                import ema
-                ema.update_ema_variables(net, teacher, EMA_DECAY, EMA_STEP)
-            return loss
-
-        feeder = getattr(args, "feeder", None)
-
-        def feed(i):
-            cur.copy_(nxt)
-            if feeder is not None:
-                feeder.next_into(nxt)              # host batch -> pinned -> device, inside the timed region
-            else:
-                nxt.copy_(pool[(i + 1) % len(pool)])
-            if lab_cur is not None:
-                for k, v in labels_pool[i % len(pool)].items():
-                    lab_cur[k].copy_(v)
-            if teacher is not None:
-                cur_t.copy_(nxt_t)
-                nxt_t.copy_(teacher_pool[(i + 1) % len(teacher_pool)])
-
-        nxt.copy_(pool[0])
-        if teacher is not None:
-            nxt_t.copy_(teacher_pool[0])
-        if not args.no_prefetch:
-            net.prefetch({"point_clouds": nxt}, trusted=True)      # plan of the first batch
-            if teacher is not None:
-                teacher.prefetch({"point_clouds": nxt_t}, trusted=True)
-        for i in range(max(args.warmup, 3)):          # eager warm-up: allocator, workspaces, autotuning
-            feed(i)
-            graph_body()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-            # let the process group's watchdog thread retire the warm-up steps' collectives before the capture starts: it
-            # polls their completion events every ~100 ms, and a poll that overlaps the beginning of the capture has been
-            # seen to abort the process ("operation not permitted on an event last recorded in a capturing stream")
-            # -- measured round 3 on a 1-rank group: 2 of 4 runs aborted without the pause, 0 of 6 with it
-            time.sleep(1.5)
-        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        import sa_fused
-        sa_fused.reset_pools()
-        graph = torch.cuda.CUDAGraph()
-        captured = True
-        try:
-            with torch.cuda.graph(graph):
-                static_loss = graph_body()
-        except Exception as exc:       # noqa: BLE001 -- whatever refused the capture, the eager path still works
-            if not distributed:
-                raise
-            captured = False
-            print(f"bench.py: graph capture failed on this rank ({exc!r}); falling back to eager", file=sys.stderr)
-        if distributed:
-            flag = torch.tensor([1 if captured else 0], device=cur.device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if not bool(flag.item()):
-                raise GraphUnavailable()
-
-        def step(i):                                   # noqa: F811
-            feed(i)
-            graph.replay()
-            return static_loss
-    return step, ("hipGraph replay" if use_graph else "eager")
+        def step(i):
+            # the batch run now was announced by the previous call (the first one by the capture); the batch after it is
+            # handed over for its sampling plan: from the resident pool (3.84 MB device-to-device inside the timed region)
+            # or from the host pipeline
+            return stepper.step(None, labels_pool[i % n] if labels_pool is not None else None,
+                                next_inputs=feeder.next_into if feeder is not None else pool[(i + 1) % n],
+                                next_teacher_inputs=None if teacher is None else teacher_pool[(i + 1) % n])
+    else:
+        def step(i):
+            return stepper.step(pool[i % n], labels_pool[i % n] if labels_pool is not None else None,
+                                next_inputs=pool[(i + 1) % n],
+                                teacher_inputs=None if teacher is None else teacher_pool[i % n],
+                                next_teacher_inputs=None if teacher is None else teacher_pool[(i + 1) % n])
+    return step, stepper.launch
 
 
 def main():
@@ -878,7 +777,8 @@ def main():
         b = getattr(args, "buckets", None)
         dp_counts = (f"{sa_fused.COLLECTIVES_LAST_STEP} SyncBN statistics all-reduces (<= 4 KB each) + "
                      f"{b.collectives if b is not None else 0} gradient-bucket all-reduces per step (bucket 0 = everything but "
-                     "the backbone, issued on the side stream when backward reaches the seed features; bucket 1 = backbone; "
+                     "the backbone, issued on the side stream when backward reaches the seed features; bucket 1 = backbone + "
+                     f"the {b.late_arrivals if b is not None else 0} bucket-0 gradients that arrive after that flush; "
                      + ("buckets on a communicator of their own" if getattr(args, "bucket_group", None) is not None else
                         "buckets on the default communicator") + ")")
     if rank == 0:

@@ -45,10 +45,11 @@ def _read(path, trust_pickle):
     module.  Try the safe loader first (tensors, containers, Namespace); only an explicit `trust_pickle=True` falls
     back to full unpickling -- which executes code from the file."""
     import argparse
+    import pickle
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as safe_err:
+    except pickle.UnpicklingError as safe_err:      # what a weights_only rejection raises; I/O errors and corrupt archives propagate
         if not trust_pickle:
             raise RuntimeError(
                 f"{path}: not loadable with weights_only=True ({type(safe_err).__name__}: {safe_err}).  If the file "

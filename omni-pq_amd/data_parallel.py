@@ -11,7 +11,9 @@ model's backward completes its gradients:
                heads, query / key projections, six decoder layers, twelve prediction heads: 15.4 M of 17.9 M parameters.
                Complete when backward reaches the seed features (`sa_fused.WgradFlushPoint`): packed and all-reduced on
                the side stream there, underneath the backbone's backward pass (feature propagation + four SA stages).
-    bucket 1   the backbone (2.4 M parameters): packed and all-reduced when the block has ended.
+    bucket 1   the backbone (2.4 M parameters) plus whatever reached a bucket-0 parameter AFTER the early flush (the
+               vote aggregation is a fused SA stage: its conv weights' gradients are launched with the other SA stages'
+               when the block ends): packed and all-reduced when the block has ended.
 
 On eight MI355X a ring all-reduce of bucket 0 (62 MB f32) is per-link bound at ~0.7 ms (7 xGMI links x ~153 GB/s:
 SURVEY.md section 5) against ~4 ms of backbone backward left to run; only bucket 1 (10 MB) is exposed.  Gradients come
@@ -38,43 +40,74 @@ class GradientBuckets:
         self.flat = [None, None]
         self.early_done = False
         self.collectives = 0          # all-reduces issued by the last step (reported by bench.py)
+        self.late_arrivals = 0        # bucket-0 parameters whose gradient (or part of it) arrived after the early flush
+        self._packed = [set(), set()]  # ids of the parameters that had a gradient when their bucket was packed
+        self._hold = None             # the local .grad tensors bucket 0 was packed from (alive until the block has ended)
 
     # ---- called by sa_fused.deferred_wgrads.flush_on, on the side stream, after the early grouped launch ----------
     def on_early_flush(self, dfr):
-        """Bucket 0 is complete: autograd has accumulated its share into `.grad` (the side stream waited for the main
-        stream), the deferred share sits in `dfr._assign` as (parameter, f32 buffer) pairs computed on this stream."""
+        """Bucket 0 is (almost) complete: autograd has accumulated its share into `.grad` (the side stream waited for
+        the main stream), the deferred share sits in `dfr._assign` as (parameter, f32 buffer) pairs computed on this
+        stream.  What is packed here leaves `.grad` (set to None; the tensors stay referenced until `finish`, they were
+        allocated on the main stream): a gradient that reaches a bucket-0 parameter AFTERWARDS -- the vote aggregation
+        is a fused SA stage, its three conv weights' gradients are collected by `deferred_wgrads.add_sa` and only
+        launched when the block ends -- is then exactly what `finish` finds in `.grad`, and travels with bucket 1."""
         if self.early_done or not EARLY_BUCKET:
             return
         mine = {id(p) for p in self.buckets[0]}
         assign = getattr(dfr, "_assign", None) or []
         take = [(p, g) for p, g in assign if id(p) in mine]
         dfr._assign = [(p, g) for p, g in assign if id(p) not in mine]
-        self.flat[0] = self._pack(self.buckets[0], take)
+        self.flat[0] = self._pack(self.buckets[0], take, self._packed[0])
+        self._hold = [p.grad for p in self.buckets[0]]
+        for p in self.buckets[0]:
+            p.grad = None
         self._reduce(self.flat[0])
         self.early_done = True
 
     # ---- called by the step once the deferred_wgrads block has ended ------------------------------------------------
     def finish(self):
+        late = []
         if not self.early_done:                   # no flush point was hit (eager helper paths): everything now
-            self.flat[0] = self._pack(self.buckets[0], [])
+            self.flat[0] = self._pack(self.buckets[0], [], self._packed[0])
             self._reduce(self.flat[0])
-        self.flat[1] = self._pack(self.buckets[1], [])
+        else:
+            late = [p for p in self.buckets[0] if p.grad is not None]
+        self.late_arrivals = len(late)
+        # bucket 1 = the backbone + whatever reached bucket-0 parameters after the early flush
+        self.flat[1] = self._pack(self.buckets[1] + late, [], self._packed[1])
         self._reduce(self.flat[1])
         inv = 1.0 / self.world
-        for flat, params in zip(self.flat, self.buckets):
+        for flat in self.flat:
             if flat.is_cuda and not torch.cuda.is_current_stream_capturing():
                 flat.record_stream(torch.cuda.current_stream(flat.device))     # bucket 0 was allocated on the side stream
             flat.mul_(inv)
+        late_views, off = {}, sum(p.numel() for p in self.buckets[1])
+        for p in late:
+            late_views[id(p)] = self.flat[1][off:off + p.numel()]
+            off += p.numel()
+        for b, (flat, params) in enumerate(zip(self.flat, self.buckets)):
             off = 0
             for p in params:
                 n = p.numel()
-                p.grad = flat[off:off + n].view_as(p)
+                view = flat[off:off + n]
                 off += n
+                extra = late_views.get(id(p)) if b == 0 else None
+                if id(p) not in self._packed[b] and extra is None:
+                    p.grad = None             # no gradient reached this parameter on this step (DDP leaves None too)
+                    continue
+                if extra is not None:
+                    view.add_(extra)
+                g = view.view_as(p)
+                p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
         self.early_done = False
+        self._hold = None
+        self._packed = [set(), set()]
 
     # -------------------------------------------------------------------------------------------------------------------
-    def _pack(self, params, extra):
-        """One flat f32 buffer holding, per parameter, `.grad` (if any) plus the deferred gradients in `extra`."""
+    def _pack(self, params, extra, had):
+        """One flat f32 buffer holding, per parameter, `.grad` (if any) plus the deferred gradients in `extra`; the ids of
+        the parameters that had either are added to `had`."""
         by_param = {}
         for p, g in extra:
             by_param.setdefault(id(p), []).append(g)
@@ -84,6 +117,7 @@ class GradientBuckets:
             if not gs:
                 pieces.append(torch.zeros(p.numel(), device=p.device, dtype=torch.float32))
                 continue
+            had.add(id(p))
             pieces.append(gs[0].reshape(-1).float())
             again.extend((len(pieces) - 1, g) for g in gs[1:])
         flat = torch.cat(pieces)

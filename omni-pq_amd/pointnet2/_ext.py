@@ -13,6 +13,7 @@ raises.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -43,12 +44,14 @@ if os.path.exists(_LIB_F16_PATH):
     _LIBS[torch.float16] = _load(_LIB_F16_PATH)
 
 
-class _Elem16:
+class _Elem16(threading.local):
     """The element type the hand-written 16-bit kernels are running in: `E16.dtype`.  It follows torch.autocast:
     every entry into the hand-written path asks `E16.autocast()` -- True when CUDA autocast is on with a dtype a library
     exists for, which also makes that dtype current -- and the autograd nodes re-select the type their saved tensors
     have before they launch anything in backward.  Two element types interleaved on ONE thread between a forward and its
-    backward are therefore fine; two threads running different types at once are not supported (module state)."""
+    backward are therefore fine, and the state is per thread (`threading.local`: every thread starts at bfloat16 and
+    the autograd engine's worker threads re-select per node), so a teacher in fp16 next to a student in bf16 on two
+    threads do not see each other's choice."""
 
     def __init__(self):
         self.dtype = torch.bfloat16

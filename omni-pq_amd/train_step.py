@@ -1,0 +1,265 @@
+"""The fast training step as a product API: one object that runs `model(inputs)` -> `criterion` -> `backward` of
+`PQ_Transformer` the way the benchmark does -- captured once into a hipGraph and replayed, the ~130 weight gradients as a
+few grouped launches (`sa_fused.deferred_wgrads`), the NEXT batch's furthest-point sampling chain started inside the
+current forward on a side stream, and under `torch.distributed` the gradients reduced in two buckets of which the first
+travels underneath the backbone's backward pass (`data_parallel.GradientBuckets`).
+
+Where it goes in the reference's driver (train.py:456-576): the three lines
+
+    end_points = model(inputs)                              # train.py:489
+    loss, end_points = criterion(end_points, ...)           # train.py:497-503
+    loss.backward()                                         # train.py:559
+
+become `loss = stepper.step(batch, labels, next_inputs=next_batch)`; `optimizer.step()` (train.py:560-563) stays where
+it is and finds the gradients in `.grad` of the bare model's parameters, averaged over the ranks.  INTEGRATION.md shows
+the whole change.  The model is NOT wrapped in DistributedDataParallel: DDP reduces from per-parameter autograd hooks,
+which a captured step with deferred weight gradients never fires (`deferred_wgrads` refuses DDP parameters).
+
+Launched kernel by kernel (`graph=False`, or under DDP) the same step is host-bound (about 2.3x slower at batch 8 x
+40 000 points on MI355X); the capture is what makes the 650 dependent launches of 3-150 us run back to back.
+"""
+import torch
+import torch.distributed as dist
+
+
+def lookahead(iterable):
+    """(item, next item or None) pairs: the captured step wants to know the batch AFTER the one it runs."""
+    it = iter(iterable)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
+def _cloud(inputs):
+    return inputs["point_clouds"] if isinstance(inputs, dict) else inputs
+
+
+class CapturedStep:
+    """stepper = CapturedStep(net, criterion, example_inputs, example_labels)
+       loss = stepper.step(inputs, labels, next_inputs=...)         # gradients in net's parameters' .grad
+
+    net              the bare PQ_Transformer (train mode).  `model` (default: net) is what is called -- pass a wrapper only if
+                     it forwards to `net` without hooks of its own.
+    criterion        criterion(end_points, labels) -> scalar loss tensor; must not read the device from the host
+                     (loss_helper_pq.get_loss qualifies; `labels` is a dict of tensors or None).
+    example_inputs   {'point_clouds': (B, N, 3 + C) f32 on the GPU} (or the tensor): fixes the batch shape; its contents
+                     are only used for the warm-up steps.
+    amp_dtype        torch.bfloat16 / torch.float16 / None (strict f32); loss_scale: static scale applied to the loss before
+                     backward (fp16: 2^14, what torch.amp.GradScaler would settle on; gradients come back scaled).
+    graph            True: capture + replay; False: the same step launched eagerly (debugging, A/B).
+    prefetch         "forward": the next batch's sampling chain starts inside forward() (default), "backward": between
+                     forward and backward, None: no prefetch (every forward samples its own batch: +5 ms at 40 000 points).
+    teacher          optional mean-teacher copy (train.py:480-491): its train-mode no-grad forward runs after the student's
+                     and `ema=(decay, global_step)` updates it after backward (ema.update_ema_variables, train.py:576).
+    world / buckets  data parallelism: `buckets` = data_parallel.GradientBuckets(net, world, group) or None (single rank).
+    defer            False: leave the weight gradients to autograd (needed under DistributedDataParallel).
+    """
+
+    def __init__(self, net, criterion, example_inputs, example_labels=None, *, model=None, amp_dtype=torch.bfloat16,
+                 loss_scale=1.0, graph=True, prefetch="forward", fps_footprint=None, teacher=None, teacher_example=None,
+                 ema=None, buckets=None, defer=True, warmup=3, distributed=False, before_capture=None):
+        self.net, self.model, self.criterion = net, (model if model is not None else net), criterion
+        self.amp_dtype, self.scale = amp_dtype, float(loss_scale)
+        self.prefetch_at, self.footprint = prefetch, fps_footprint
+        self.teacher, self.ema = teacher, ema
+        self.buckets, self.defer = buckets, defer
+        self.distributed = distributed
+        pc = _cloud(example_inputs)
+        self.cur, self.nxt = pc.clone(), pc.clone()
+        self.lab = {k: v.clone() for k, v in example_labels.items()} if example_labels is not None else None
+        self.cur_t = self.nxt_t = None
+        if teacher is not None:
+            tpc = _cloud(teacher_example if teacher_example is not None else example_inputs)
+            self.cur_t, self.nxt_t = tpc.clone(), tpc.clone()
+        self.graph = None
+        self.static_loss = None
+        self.end_points = None
+        self.launch = "eager"
+        self.replays = 0
+        self._promised = None          # identity of the tensor announced as `next_inputs` by the previous call
+        self._have_next = False        # does `nxt` (and the plan in flight) hold the batch the next call will run?
+        if graph:
+            self._capture(warmup, before_capture)
+
+    # ---- the step body (what is captured) ----------------------------------------------------------------------------------
+    def _backward(self, loss):
+        import sa_fused
+        if self.buckets is not None:
+            self.buckets.collectives = 0
+        if self.scale != 1.0:
+            loss = loss * self.scale
+        if self.defer:
+            with sa_fused.deferred_wgrads(on_early_flush=self.buckets.on_early_flush if self.buckets is not None else None):
+                loss.backward()
+        else:
+            loss.backward()
+        if self.buckets is not None:
+            self.buckets.finish()
+
+    def _teacher_forward(self, batch):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            return self.teacher({"point_clouds": batch})            # train mode, no grad (train.py:462, 490-491)
+
+    def _body(self, cur, nxt, lab, cur_t, nxt_t, trusted):
+        """forward + loss (+ teacher forward) + backward (+ EMA) on `cur`, with the sampling plan of `nxt` started on the
+        side stream.  trusted: the plan in flight IS the plan of `cur` whatever tensor object forward() is handed."""
+        net, teacher = self.net, self.teacher
+        for p in net.parameters():
+            p.grad = None
+        early = self.prefetch_at == "forward" and nxt is not None
+        if early:
+            net.prefetch({"point_clouds": nxt}, trusted=trusted, at_next_forward=True, footprint=self.footprint)
+            if teacher is not None:
+                teacher.prefetch({"point_clouds": nxt_t}, trusted=trusted, at_next_forward=True, footprint=self.footprint)
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            ep = self.model({"point_clouds": cur})
+            loss = self.criterion(ep, lab)
+        # the outputs, detached: in graph mode static tensors that every replay rewrites in place.  (Detached on purpose:
+        # holding the attached tensors -- i.e. the step's autograd graph with its custom nodes -- past the end of a capture
+        # made hipStreamEndCapture segfault; the nodes must die inside the capture, as they do when only the loss leaves.)
+        self.end_points = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ep.items()} if isinstance(ep, dict) else None
+        if teacher is not None:
+            self._teacher_forward(cur_t)
+        if self.prefetch_at == "backward" and nxt is not None:
+            net.prefetch({"point_clouds": nxt}, trusted=trusted)
+            if teacher is not None:
+                teacher.prefetch({"point_clouds": nxt_t}, trusted=trusted)
+        self._backward(loss)
+        if not self._capturing:
+            return loss                              # eager mode: the plan keeps running underneath whatever comes next
+        net.join_prefetch()
+        if teacher is not None:
+            teacher.join_prefetch()
+        if teacher is not None and self.ema is not None:
+            import ema as _ema
+            _ema.update_ema_variables(net, teacher, *self.ema)      # train.py:576
+        return loss
+
+    _capturing = False
+
+    def _capture(self, warmup, before_capture):
+        import sa_fused
+        net, teacher = self.net, self.teacher
+        self._capturing = True
+        try:
+            self.nxt.copy_(self.cur)
+            if teacher is not None:
+                self.nxt_t.copy_(self.cur_t)
+            if self.prefetch_at is not None:
+                net.prefetch({"point_clouds": self.nxt}, trusted=True)          # plan of the first batch
+                if teacher is not None:
+                    teacher.prefetch({"point_clouds": self.nxt_t}, trusted=True)
+            for _ in range(max(int(warmup), 3)):          # eager warm-up: allocator pools, workspaces, weight arenas
+                self.cur.copy_(self.nxt)
+                if teacher is not None:
+                    self.cur_t.copy_(self.nxt_t)
+                self._body(self.cur, self.nxt if self.prefetch_at else None, self.lab, self.cur_t, self.nxt_t, True)
+            torch.cuda.synchronize()
+            if self.distributed:
+                _quiesce_process_groups(self.cur.device)
+            if before_capture is not None:
+                before_capture()
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            sa_fused.reset_pools()
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: only THIS thread's calls are checked against the capture.  Under torch.distributed the process
+            # group's watchdog thread polls completion events of earlier collectives; in the default (global) mode such a
+            # query from any thread while a capture is open is an error that aborts the process ("operation not permitted
+            # ... capturing stream": 2 of 4 runs in round 3 before a 1.5 s pause was put here).  The autograd engine's worker
+            # thread only launches kernels on the capturing stream and allocates through the caching allocator, which guards
+            # its own hipMalloc calls -- both fine in this mode.
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.distributed else "global"):
+                self.static_loss = self._body(self.cur, self.nxt if self.prefetch_at else None, self.lab, self.cur_t,
+                                              self.nxt_t, True)
+            self.graph = graph
+            self.launch = "hipGraph replay"
+            self._have_next = True                   # `nxt` holds the example batch, its plan was started by the capture run
+        finally:
+            self._capturing = False
+
+    # ---- one training step -------------------------------------------------------------------------------------------------
+    def step(self, inputs=None, labels=None, next_inputs=None, teacher_inputs=None, next_teacher_inputs=None):
+        """Forward + loss + backward of `inputs`; returns the loss (graph mode: a static tensor, overwritten by the next
+        call).  next_inputs: the batch the NEXT call will run (tensor / dict / callable(dst) filling the static buffer) -- its
+        coordinate-only sampling runs underneath this step.  inputs=None or the very object announced as `next_inputs` last
+        time: the announced batch is taken as is; any other input is copied in and its sampling plan recomputed up front
+        (correct, and ~5 ms slower for that call at 40 000 points).  next_inputs=None: nothing to announce (last batch)."""
+        if self.graph is None:
+            return self._eager_step(inputs, labels, next_inputs, teacher_inputs, next_teacher_inputs)
+        net, teacher = self.net, self.teacher
+        pc = None if inputs is None else _cloud(inputs)
+        announced = self._have_next and (pc is None or (self._promised is not None and self._promised == _ident(pc)))
+        if announced:
+            self.cur.copy_(self.nxt)
+            if teacher is not None:
+                self.cur_t.copy_(self.nxt_t)
+        else:
+            if pc is None:
+                raise ValueError("CapturedStep.step: no batch was announced by the previous call; pass `inputs`")
+            self.cur.copy_(pc)
+            if teacher is not None:
+                self.cur_t.copy_(_cloud(teacher_inputs if teacher_inputs is not None else inputs))
+            if self.prefetch_at is not None:
+                # the plan in flight belongs to some other batch: sample this one now, ahead of the replay
+                net.prefetch({"point_clouds": self.cur}, trusted=True)
+                net.join_prefetch()
+                if teacher is not None:
+                    teacher.prefetch({"point_clouds": self.cur_t}, trusted=True)
+                    teacher.join_prefetch()
+        if self.lab is not None:
+            if labels is None:
+                raise ValueError("CapturedStep.step: this step was captured with labels")
+            for k, dst in self.lab.items():
+                dst.copy_(labels[k])
+        self._fill(self.nxt, next_inputs)
+        if teacher is not None:
+            self._fill(self.nxt_t, next_teacher_inputs if next_teacher_inputs is not None else next_inputs)
+        self._promised = _ident(_cloud(next_inputs)) if (next_inputs is not None and not callable(next_inputs)) else None
+        self._have_next = next_inputs is not None
+        self.graph.replay()
+        self.replays += 1
+        return self.static_loss
+
+    @staticmethod
+    def _fill(dst, src):
+        if src is None:
+            return
+        if callable(src):
+            src(dst)
+        else:
+            dst.copy_(_cloud(src))
+
+    def _eager_step(self, inputs, labels, next_inputs, teacher_inputs, next_teacher_inputs):
+        """The same sequence launched kernel by kernel (no static buffers: the caller's tensors are used directly)."""
+        if inputs is None:
+            raise ValueError("CapturedStep.step (eager): pass `inputs`")
+        pc = _cloud(inputs)
+        nxt = None
+        if next_inputs is not None and not callable(next_inputs) and self.prefetch_at is not None:
+            nxt = _cloud(next_inputs)
+        t_cur = _cloud(teacher_inputs) if teacher_inputs is not None else pc
+        t_nxt = _cloud(next_teacher_inputs) if next_teacher_inputs is not None else nxt
+        loss = self._body(pc, nxt, labels, t_cur, t_nxt, False)
+        if self.teacher is not None and self.ema is not None:
+            import ema as _ema
+            _ema.update_ema_variables(self.net, self.teacher, *self.ema)
+        return loss
+
+
+def _ident(t):
+    return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _quiesce_process_groups(device):
+    """Before a capture that will hold collectives: nothing of the warm-up steps' collectives may still be pending in the
+    process group's watchdog -- its thread polls completion events of enqueued work, and a poll that overlaps the beginning
+    of the capture aborted the process in round 3 (avoided there by a 1.5 s pause).  A barrier fences the ranks and a device
+    synchronisation completes every collective on the device; what the watchdog still polls afterwards is harmless because
+    the capture below runs in thread_local error mode (see _capture)."""
+    dist.barrier()
+    torch.cuda.synchronize(device)

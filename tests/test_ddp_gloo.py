@@ -91,6 +91,7 @@ def _worker(rank, world, port, out_dir):
                 self.backbone = torch.nn.Linear(6, 5)
                 self.head = torch.nn.Linear(5, 3)
                 self.extra = torch.nn.Linear(3, 2)
+                self.unused = torch.nn.Linear(2, 2)      # takes no part in the step: .grad stays None, as under DDP
 
         two = Two()
         gen = torch.Generator().manual_seed(300 + rank)
@@ -99,7 +100,7 @@ def _worker(rank, world, port, out_dir):
         for n, g in local.items():
             dist.all_gather(stacked[n], g)
         buckets = data_parallel.GradientBuckets(two, world)
-        assert [len(b) for b in buckets.buckets] == [4, 2]
+        assert [len(b) for b in buckets.buckets] == [6, 2]
 
         class FakeBlock:                       # what deferred_wgrads looks like to the early-flush callback
             _assign = None
@@ -108,16 +109,32 @@ def _worker(rank, world, port, out_dir):
         two.head.weight.grad = 0.5 * local["head.weight"]
         blk._assign = [(two.head.weight, 0.5 * local["head.weight"]), (two.head.bias, local["head.bias"].clone()),
                        (two.backbone.weight, local["backbone.weight"].clone())]
-        two.extra.weight.grad, two.extra.bias.grad = local["extra.weight"].clone(), local["extra.bias"].clone()
+        # extra.weight: half before the early flush, half AFTER it (a fused SA stage downstream of the flush point, whose
+        # grouped weight gradients are launched when the block ends: the vote aggregation); extra.bias: only after it
+        two.extra.weight.grad = 0.25 * local["extra.weight"]
         buckets.on_early_flush(blk)
         assert buckets.early_done and buckets.collectives == 1
         assert [p is two.backbone.weight for p, _ in blk._assign] == [True]          # bucket-1 entries stay with the block
+        assert all(p.grad is None for p in buckets.buckets[0])                       # packed gradients have left .grad
         two.backbone.weight.grad, two.backbone.bias.grad = blk._assign[0][1], local["backbone.bias"].clone()
+        two.extra.weight.grad = 0.75 * local["extra.weight"]                         # what deferred_wgrads.__exit__ does
+        two.extra.bias.grad = local["extra.bias"].clone()
         buckets.finish()
-        assert buckets.collectives == 2
+        assert buckets.collectives == 2 and buckets.late_arrivals == 2
         for n, p in two.named_parameters():
+            if n.startswith("unused"):
+                assert p.grad is None, n
+                continue
             want_n = torch.stack(stacked[n]).mean(0)
+            assert p.grad is not None and p.grad.dtype == p.dtype, n
             assert torch.allclose(p.grad, want_n, rtol=1e-6, atol=1e-7), n
+        # a second step reuses the object: nothing of the first one is left behind
+        for p in two.parameters():
+            p.grad = None
+        two.head.bias.grad = local["head.bias"].clone()
+        buckets.finish()                                                             # no early flush this time
+        assert torch.allclose(two.head.bias.grad, torch.stack(stacked["head.bias"]).mean(0), rtol=1e-6, atol=1e-7)
+        assert two.extra.weight.grad is None and buckets.late_arrivals == 0
 
         # 2d) deferred_wgrads refuses parameters of a DistributedDataParallel module (their hooks would never fire)
         with sa_fused.deferred_wgrads() as blk2:

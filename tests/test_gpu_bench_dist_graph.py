@@ -26,15 +26,10 @@ def run_bench(port):
 
 
 def test_step_with_rccl_collectives_captures_and_replays():
-    # the capture is gated by a probe in a child process with its own rendezvous and time limit
-    # (tools/rccl_graph_probe.py); on a box that is still paging the image in it can time out, and a rendezvous port can
-    # be busy: up to three attempts on different ports, every failure reported with the child's stderr
-    rec, errs = None, []
-    for port in (29641, 29647, 29653):
-        rec, err = run_bench(port)
-        errs.append(err[-1500:])
-        if rec is not None and rec["launch"] == "hipGraph replay":
-            break
+    # ONE attempt: the capture no longer races the process group's watchdog (train_step.CapturedStep captures in
+    # thread_local error mode behind a barrier + device synchronisation; round 3 slept 1.5 s and this test retried)
+    rec, err = run_bench(29641)
+    errs = [err[-3000:]]
     assert rec is not None, errs
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     # the probe passed and the captured step holds the collectives
@@ -42,3 +37,5 @@ def test_step_with_rccl_collectives_captures_and_replays():
     assert rec["data_parallel"] and "inside the graph" in rec["data_parallel"], rec["data_parallel"]
     # 88 SyncBatchNorm statistics exchanges (61 layers, forward + backward = 122, minus the 28 the seven object / quad head pairs and the 6 the three pairs of key-position embeddings share) and the two gradient buckets
     assert "88 SyncBN" in rec["data_parallel"] and "2 gradient-bucket" in rec["data_parallel"], rec["data_parallel"]
+    # the vote aggregation's three conv weights get their gradients after the early flush: they travel with bucket 1
+    assert "the 3 bucket-0 gradients that arrive after that flush" in rec["data_parallel"], rec["data_parallel"]
