@@ -733,6 +733,7 @@ def main():
         step(i)
     fence()
     sink = None
+    eager_ms = None
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -755,6 +756,12 @@ def main():
                                   teacher_pool=teacher_pool, labels_pool=labels_pool)
         eager_step(0)
         fence()
+        # the same step launched kernel by kernel (what a caller without train_step.CapturedStep gets): host-bound
+        te = time.perf_counter()
+        for i in range(3):
+            eager_step(1 + i)
+        fence()
+        eager_ms = (time.perf_counter() - te) / 3 * 1e3
         sink = []
         ext.set_timing_sink(sink)
         timing_steps = min(args.steps, 5)
@@ -792,6 +799,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "launch": "hipGraph replay" if use_graph else "eager",
+            "eager_ms_per_step": eager_ms,
             "input": ("resident: a pool of batches in HBM before the timed region (3.84 MB device-to-device per step inside it)"
                       if args.feeder is None else
                       f"host pipeline INSIDE the timed region: torch DataLoader, {args.loader_workers} worker processes doing "

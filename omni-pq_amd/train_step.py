@@ -167,13 +167,7 @@ class CapturedStep:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             sa_fused.reset_pools()
             graph = torch.cuda.CUDAGraph()
-            # thread_local: only THIS thread's calls are checked against the capture.  Under torch.distributed the process
-            # group's watchdog thread polls completion events of earlier collectives; in the default (global) mode such a
-            # query from any thread while a capture is open is an error that aborts the process ("operation not permitted
-            # ... capturing stream": 2 of 4 runs in round 3 before a 1.5 s pause was put here).  The autograd engine's worker
-            # thread only launches kernels on the capturing stream and allocates through the caching allocator, which guards
-            # its own hipMalloc calls -- both fine in this mode.
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.distributed else "global"):
+            with torch.cuda.graph(graph):
                 self.static_loss = self._body(self.cur, self.nxt if self.prefetch_at else None, self.lab, self.cur_t,
                                               self.nxt_t, True)
             self.graph = graph
@@ -256,10 +250,17 @@ def _ident(t):
 
 
 def _quiesce_process_groups(device):
-    """Before a capture that will hold collectives: nothing of the warm-up steps' collectives may still be pending in the
-    process group's watchdog -- its thread polls completion events of enqueued work, and a poll that overlaps the beginning
-    of the capture aborted the process in round 3 (avoided there by a 1.5 s pause).  A barrier fences the ranks and a device
-    synchronisation completes every collective on the device; what the watchdog still polls afterwards is harmless because
-    the capture below runs in thread_local error mode (see _capture)."""
+    """Before a capture that will hold collectives.  What goes wrong otherwise (ROCm 7.0 / torch 2.10, seen in 1 of 7 runs
+    on a 1-rank RCCL group, `Process group watchdog thread terminated with exception: HIP error: operation not permitted
+    on an event last recorded in a capturing stream`): every process group's watchdog thread polls the end-events of the
+    collectives issued EAGERLY on its RCCL stream (the warm-up steps' SyncBatchNorm exchanges and bucket all-reduces, the
+    barrier below) until they have completed, once per 100 ms cycle.  The capture pulls those RCCL streams into capture
+    mode, and HIP answers hipEventQuery on an event of a stream that has meanwhile entered capture with
+    hipErrorCapturedEvent -- even though the event itself was recorded long before -- which the watchdog turns into a
+    process abort.  So no eagerly issued collective may still sit in a watchdog's list when the capture begins: fence the
+    ranks, complete everything on the device, then give every watchdog three of its cycles to retire the completed work.
+    (Round 3 paused 1.5 s on a guess; the process-group API has no call that reports or drains that list.)"""
+    import time
     dist.barrier()
     torch.cuda.synchronize(device)
+    time.sleep(0.35)

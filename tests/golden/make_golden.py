@@ -336,17 +336,37 @@ def crosscheck():
 
 
 if __name__ == "__main__":
-    op_case("ops_room512", synth.make_clouds(11, 2, 512, kind="room"), 128, 0.4, 16)
-    op_case("ops_room4096", synth.make_clouds(12, 2, 4096, kind="room"), 1024, 0.2, 32)
-    op_case("ops_adv600", synth.adversarial_cloud(1, 2, 600), 150, 0.3, 8, channels=3)
-    op_case("ops_adv2048", synth.adversarial_cloud(2, 2, 2048), 512, 0.25, 64, channels=4)
+    only = set(sys.argv[1:])          # python tests/golden/make_golden.py [case ...]: regenerate only these
+
+    def want(name):
+        return not only or name in only
+
+    if want("ops_room512"):
+        op_case("ops_room512", synth.make_clouds(11, 2, 512, kind="room"), 128, 0.4, 16)
+    if want("ops_room4096"):
+        op_case("ops_room4096", synth.make_clouds(12, 2, 4096, kind="room"), 1024, 0.2, 32)
+    if want("ops_adv600"):
+        op_case("ops_adv600", synth.adversarial_cloud(1, 2, 600), 150, 0.3, 8, channels=3)
+    if want("ops_adv2048"):
+        op_case("ops_adv2048", synth.adversarial_cloud(2, 2, 2048), 512, 0.25, 64, channels=4)
     # config 1 of BASELINE.json: one SA layer with the sa1 spec on a 4096-point uniform cloud
-    sa_case("sa1_uniform4096", synth.make_clouds(1, 2, 4096, kind="uniform"), None,
-            dict(npoint=2048, radius=0.2, nsample=64, mlp=[0, 128, 128, 256], use_xyz=True, normalize_xyz=True))
-    c4 = synth.make_clouds(4, 2, 2048, extra_channels=6, kind="room")
-    sa_case("sa_feat_room2048", c4[..., :3].contiguous(), c4[..., 3:].transpose(1, 2).contiguous(),
-            dict(npoint=512, radius=0.4, nsample=32, mlp=[6, 32, 32, 64], use_xyz=True, normalize_xyz=True))
-    fp_case("fp2_like", 2, 1024, 512, 64, 96, [160, 128, 72])
-    model_case("model_eval_8192", synth.make_clouds(21, 2, 8192, kind="room"), train=False)
-    model_case("model_train_8192", synth.make_clouds(21, 2, 8192, kind="room"), train=True)
-    crosscheck()
+    if want("sa1_uniform4096"):
+        sa_case("sa1_uniform4096", synth.make_clouds(1, 2, 4096, kind="uniform"), None,
+                dict(npoint=2048, radius=0.2, nsample=64, mlp=[0, 128, 128, 256], use_xyz=True, normalize_xyz=True))
+    if want("sa_feat_room2048"):
+        c4 = synth.make_clouds(4, 2, 2048, extra_channels=6, kind="room")
+        sa_case("sa_feat_room2048", c4[..., :3].contiguous(), c4[..., 3:].transpose(1, 2).contiguous(),
+                dict(npoint=512, radius=0.4, nsample=32, mlp=[6, 32, 32, 64], use_xyz=True, normalize_xyz=True))
+    # round 4: the stage the roofline is quoted on, at the benchmark's own size -- sa1 of the backbone
+    # (backbone_module.py:38-47) on two 40 000-point room scenes, i.e. BASELINE configs[1] with two scenes instead of eight
+    if want("sa1_room40000_b2"):
+        sa_case("sa1_room40000_b2", synth.make_clouds(31, 2, 40000, kind="room"), None,
+                dict(npoint=2048, radius=0.2, nsample=64, mlp=[0, 128, 128, 256], use_xyz=True, normalize_xyz=True))
+    if want("fp2_like"):
+        fp_case("fp2_like", 2, 1024, 512, 64, 96, [160, 128, 72])
+    if want("model_eval_8192"):
+        model_case("model_eval_8192", synth.make_clouds(21, 2, 8192, kind="room"), train=False)
+    if want("model_train_8192"):
+        model_case("model_train_8192", synth.make_clouds(21, 2, 8192, kind="room"), train=True)
+    if want("crosscheck"):
+        crosscheck()

@@ -26,8 +26,8 @@ def run_bench(port):
 
 
 def test_step_with_rccl_collectives_captures_and_replays():
-    # ONE attempt: the capture no longer races the process group's watchdog (train_step.CapturedStep captures in
-    # thread_local error mode behind a barrier + device synchronisation; round 3 slept 1.5 s and this test retried)
+    # ONE attempt: the capture no longer races the process groups' watchdogs (train_step._quiesce_process_groups; round 3
+    # this test retried up to three times)
     rec, err = run_bench(29641)
     errs = [err[-3000:]]
     assert rec is not None, errs

@@ -3,8 +3,9 @@
 tests/test_gpu_parity.py compares the f32 mode (native ops + library conv / BN / attention) with the fixtures at the
 north star's 1e-4.  The benchmark times the bf16 mode: fused set-abstraction stage, rows engine, attention and decoder
 kernels.  This file runs THAT mode (torch.autocast(bfloat16), as bench.py does) on the same fixtures:
-`sa1_uniform4096` and `sa_feat_room2048` (PointnetSAModuleVotes, the second with 6 extra input channels as BASELINE
-configs[3]), `fp2_like` (PointnetFPModule) and `model_train_8192` (whole PQ_Transformer, train mode, dropout 0, votes
+`sa1_uniform4096`, `sa_feat_room2048` (PointnetSAModuleVotes, the second with 6 extra input channels as BASELINE
+configs[3]) and `sa1_room40000_b2` (round 4: the backbone's sa1 at the benchmark's own size, two 40 000-point scenes -- the
+stage the roofline is quoted on against the REFERENCE, with the coordinate-generated first layer engaged), `fp2_like` (PointnetFPModule) and `model_train_8192` (whole PQ_Transformer, train mode, dropout 0, votes
 forced) -- outputs AND gradients, the gradients by direction (cosine per tensor), not by norm only.
 
 Tolerances are bf16 tolerances and are stated: activations and GEMM operands carry an 8-bit mantissa (relative step
@@ -94,7 +95,7 @@ def run_sa(name, fx):
     return res, hasattr(new_feats, "omnipq_rows16")
 
 
-@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048"])
+@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048", "sa1_room40000_b2"])
 def test_fused_bf16_sa_stage_matches_reference_fixture(name):
     fx = load_golden(name)
     out = fx["outputs"]

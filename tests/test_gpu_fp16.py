@@ -74,3 +74,6 @@ def test_every_fp16_stage_matches_the_reference_at_single_stage_tolerance():
     for k, e in got["rows"]:
         assert e <= 3e-3, (k, e)                     # 2^-11 relative steps: measured ~1e-3
     assert got["worst_cos"] >= 0.995, (got["worst_name"], got["worst_cos"])
+    print(f"  gradient norms: worst | |g|/|g_ref| - 1 | {got['worst_norm']:.2e} ({got['worst_norm_name']}; bf16 "
+          f"{bf['worst_norm']:.2e}); pred_size rows compared: {got['n_size_rows']} of {got['n_size_total']}")
+    assert got["worst_norm"] <= forced.GRAD_NORM["fp16"], (got["worst_norm_name"], got["worst_norm"])

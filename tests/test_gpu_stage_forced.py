@@ -12,6 +12,10 @@ bounds below are SINGLE-STAGE bf16 bounds (8-bit mantissa through <= 3 conv+BN+R
     integer end_points                   exact
     every parameter gradient             cosine >= GRAD_COS against the reference's f32 gradient, and
                                          1 - cos <= 2 x (1 - cos of torch's bf16 autocast, worst tensor of the segment) + 5e-3
+                                         AND its norm: | |g| / |g_ref| - 1 | <= GRAD_NORM (5e-2 bf16, 2e-2 fp16; a cosine cannot see a
+                                         gradient that is twice too large, a wrong 1 / keep or a missed 1 / world: VERDICT r3 weak 1)
+    `*pred_size` rows                    gathered by an arg-max over the size scores: compared on every row whose arg-max margin
+                                         in the REFERENCE exceeds the 16-bit rounding step of the scores (the rest can flip)
 
 A kernel that is 30 % wrong, a transposed layout, a mis-paired launch or a dropped weight-gradient fails these; the
 un-forced whole-model test (test_gpu_bf16_fixtures.py) could not.
@@ -30,6 +34,13 @@ OUT_TOL = 1.5e-2          # one segment in bf16.  Measured (MI355X, round 3): SA
                           # layers (projections + self/cross attention + FFN + 3 LayerNorms) 8.2e-3 .. 1.05e-2, head outputs
                           # 5e-3 .. 9.4e-3 -- torch's own bf16 autocast over the composition: the same figures within 10 %
 GRAD_COS = 0.975          # measured: worst tensor per segment 0.983 (sa4 / sa3 BatchNorm biases) .. 0.998; torch autocast 0.985
+# per-tensor bound on | |g| / |g_ref| - 1 |.  Measured (MI355X, round 4) over the 300+ tensors: bf16 <= 2.3e-2 except decoder[3]
+# 4.0e-2, decoder[5] 3.3e-2, proposal 3.5e-2 and one head bias at 7.3e-2 where torch's own bf16 autocast is at 7.6e-2 -- hence
+# 5e-2, or 1.5 x autocast's worst of the segment + 1e-2 where that is larger; a doubled gradient, a wrong 1 / keep (0.9) or a
+# missed 1 / world read 1.0, 0.11 and >= 1.0 on this scale
+# fp16: measured worst 1.2e-2 (sa1's first BatchNorm weight: a sum over 262 144 positions that cancels to 1e-3 of its terms --
+# the reference's own f32 gradient of such tensors is up to 1.1e-2 away from its f64 evaluation), everything else <= 5e-3
+GRAD_NORM = {"bf16": 5e-2, "autocast": 5e-2, "fp16": 2e-2, "f32": 5e-3}
 GRAD_FLOOR = 1e-5         # relative to the largest gradient norm: below it a gradient is analytically zero (conv / linear
                           # biases in front of a BatchNorm) and its direction is rounding noise on both sides
 
@@ -147,7 +158,7 @@ def check(fx, mode, train=True):
         e = rel_l2(out[pre + "own." + k], own[k])
         rows.append((k, e))
         worst_out = max(worst_out, e)
-    n_int = n_float = 0
+    n_int = n_float = n_size_rows = n_size_total = 0
     for k in out["keys"]:
         ref = out[pre + "ep." + k]
         v = ep[k]
@@ -157,13 +168,32 @@ def check(fx, mode, train=True):
             n_int += 1
             continue
         if k.endswith("pred_size"):
-            continue            # gathered by an arg-max over size scores: one flipped near-tie swaps a whole row
+            # gathered by an arg-max over size scores: a flipped near-tie swaps a whole row, so only the rows whose arg-max
+            # margin in the reference exceeds the rounding step of the scores (2^-7 of the largest score for bf16 / autocast,
+            # 2^-10 for fp16, nothing to exclude in f32) are compared -- those must agree like any other output
+            # (margins from THIS run's size scores -- checked against the reference's a few lines down like every other
+            # float output; the fixture keeps every second score only)
+            if "full" not in ref:
+                continue
+            sc = ep[k[:-len("pred_size")] + "size_scores"].detach().double().cpu()
+            top2 = sc.topk(2, dim=-1).values
+            step = {"bf16": 2.0 ** -7, "autocast": 2.0 ** -7, "fp16": 2.0 ** -10, "f32": 1e-5}[mode] * float(sc.abs().max())
+            keep = (top2[..., 0] - top2[..., 1]) > 4 * step
+            want = ref["full"].reshape(ref["shape"]).double()[keep]
+            have = v.detach().double().cpu()[keep]
+            e = float((have - want).norm() / (want.norm() + 1e-30))
+            rows.append(("ep." + k, e))
+            worst_out = max(worst_out, e)
+            n_size_rows += int(keep.sum())
+            n_size_total += keep.numel()
+            continue
         e = rel_l2(ref, v)
         rows.append(("ep." + k, e))
         worst_out = max(worst_out, e)
         n_float += 1
     floor = GRAD_FLOOR * max(out[k] for k in out if k.startswith("gradnorm."))
     worst_cos, worst_name, n_grad, per_seg = 1.0, "", 0, {}
+    worst_norm, worst_norm_name, per_seg_norm = 0.0, "", {}
     for k in sorted(grads):
         ref = out.get("grad." + k)
         if ref is None or out["gradnorm." + k] < floor:
@@ -174,8 +204,14 @@ def check(fx, mode, train=True):
         per_seg[seg] = min(per_seg.get(seg, 1.0), c)
         if c < worst_cos:
             worst_cos, worst_name = c, k
+        # magnitude: the whole tensor's norm against the reference's (gradnorm.* is the norm of the FULL reference gradient)
+        dev = abs(float(grads[k].double().norm()) / float(out["gradnorm." + k]) - 1.0)
+        per_seg_norm[seg] = max(per_seg_norm.get(seg, 0.0), dev)
+        if dev > worst_norm:
+            worst_norm, worst_norm_name = dev, k
     return dict(rows=rows, worst_out=worst_out, worst_cos=worst_cos, worst_name=worst_name, per_seg=per_seg,
-                n_int=n_int, n_float=n_float, n_grad=n_grad)
+                n_int=n_int, n_float=n_float, n_grad=n_grad, worst_norm=worst_norm, worst_norm_name=worst_norm_name,
+                per_seg_norm=per_seg_norm, n_size_rows=n_size_rows, n_size_total=n_size_total)
 
 
 def test_every_bf16_stage_matches_the_reference_at_single_stage_tolerance():
@@ -195,7 +231,16 @@ def test_every_bf16_stage_matches_the_reference_at_single_stage_tolerance():
               f"{ac['per_seg'].get(seg, float('nan')):.5f}")
     print(f"  gradients: worst cosine {got['worst_cos']:.5f} ({got['worst_name']}) over {got['n_grad']} tensors; "
           f"autocast {ac['worst_cos']:.5f} ({ac['worst_name']})")
+    for seg in sorted(got["per_seg_norm"]):
+        print(f"  grad norm ratio, worst | |g|/|g_ref| - 1 | of {seg:28s} fused {got['per_seg_norm'][seg]:.2e} | autocast "
+              f"{ac['per_seg_norm'].get(seg, float('nan')):.2e}")
+    print(f"  gradient norms: worst deviation {got['worst_norm']:.2e} ({got['worst_norm_name']}); autocast "
+          f"{ac['worst_norm']:.2e} ({ac['worst_norm_name']}); pred_size rows compared: {got['n_size_rows']} of "
+          f"{got['n_size_total']}")
     assert got["n_int"] >= 4 and got["n_float"] >= 90 and got["n_grad"] >= 300
+    assert got["n_size_rows"] >= 0.5 * got["n_size_total"] > 0, (got["n_size_rows"], got["n_size_total"])
+    for seg, dev in got["per_seg_norm"].items():
+        assert dev <= max(GRAD_NORM["bf16"], 1.5 * ac["per_seg_norm"][seg] + 1e-2), (seg, dev, ac["per_seg_norm"][seg])
     for k, e in got["rows"]:
         assert e <= OUT_TOL, (k, e)
         assert e <= 1.3 * ac_rows[k] + 2e-3, (k, e, ac_rows[k])
