@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=40000)
@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="thread count tried next to 'all cores'")
     ap.add_argument("--no-op-timing", action="store_true")
+    ap.add_argument("--sa-markers", action="store_true",
+                    help="measurement runs under rocprofv3 only: bracket every SA-stage span with one-wave marker kernels "
+                         "(sa_fused.SPAN_MARKERS) so that tools/sa_replay_timing.py can sum the stage's kernels inside the "
+                         "REPLAYED step; never in a timed run (32 extra launches per step)")
     ap.add_argument("--no-prefetch", action="store_true", help="do not overlap next-batch FPS with backward")
     ap.add_argument("--fps-footprint", default="auto", choices=["auto", "small", "fast"],
                     help="compute units per scene of the prefetched sampling chain (Pointnet2Backbone.prefetch): auto = small "
@@ -300,6 +304,27 @@ def pmc_traffic(kind):
             return json.load(fh), os.path.relpath(files[-1], REPO)
     except (OSError, ValueError):
         return None, None
+
+
+def replay_timing(args):
+    """The SA stage's kernel time INSIDE the replayed step from the newest committed `profiles/r*_sa_stage_replay_timing.json`
+    (tools/sa_replay_timing.py over a `rocprofv3 --kernel-trace` of `bench.py --sa-markers`), if it was taken on this
+    configuration; None otherwise.  The line's own `avg_ms` comes from events around every C-ABI launch in eager steps (a
+    replay cannot host events); this is the same sum measured where the headline is measured."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_sa_stage_replay_timing.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if (rec.get("batch"), rec.get("points"), rec.get("dtype")) != (args.batch, args.points, args.dtype):
+        return None
+    return {"sa_kernel_ms_per_step": rec["sa_kernel_ms_per_step"], "sa_span_ms_per_step": rec.get("sa_span_ms_per_step"),
+            "steps": rec.get("steps"), "kernels_ms_per_step": rec.get("kernels_ms_per_step"),
+            "timing_source": os.path.relpath(files[-1], REPO), "stale": counters_stale(rec)}
 
 
 def counters_stale(summary):
@@ -671,6 +696,9 @@ def main():
         assert hasattr(m, attr), f"--set: {mod} has no attribute {attr}"
         setattr(m, attr, ast.literal_eval(value))
 
+    if args.sa_markers:
+        import sa_fused
+        sa_fused.SPAN_MARKERS = True
     torch.manual_seed(1234)
     net = build_model(args.extra_channels).to(dev)
     net.train()
@@ -734,11 +762,17 @@ def main():
     fence()
     sink = None
     eager_ms = None
+    # >= 50 steps, device events around every one of them, the median reported (`median_ms_per_step`); `value`
+    # stays the mean over the wall clock between the two fences, which is what the driver's own clock checks
+    marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
+        marks[i][0].record()
         loss = step(args.warmup + i)
+        marks[i][1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(a.elapsed_time(b) for a, b in marks)
     ext.set_timing_sink(None)
     ext.fps_check()
     if args.feeder is not None:
@@ -800,6 +834,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "launch": "hipGraph replay" if use_graph else "eager",
             "eager_ms_per_step": eager_ms,
+            "median_ms_per_step": per_step[len(per_step) // 2],
+            "p10_p90_ms_per_step": [per_step[len(per_step) // 10], per_step[(9 * len(per_step)) // 10]],
             "input": ("resident: a pool of batches in HBM before the timed region (3.84 MB device-to-device per step inside it)"
                       if args.feeder is None else
                       f"host pipeline INSIDE the timed region: torch DataLoader, {args.loader_workers} worker processes doing "
@@ -857,6 +893,7 @@ def main():
             sa_bytes = sa_stage_algorithmic_bytes(args.batch, args.points, args.extra_channels, e)
             sa_gbs = sa_bytes / (sa_ms * 1e-3) / 1e9 if sa_ms > 0 else None
             ceiling = hbm_copy_ceiling(dev)
+            replay_rec = replay_timing(args)
             # `roofline`: the SA stage (ball query + group + shared MLP + pool, fwd+bwd, of sa1..sa4 and the vote
             # aggregation) -- the stage north_star's >= 60 % target is quoted on -- as ONE unit: algorithmic bytes of
             # SURVEY 8d over the event-timed duration of all its kernels.
@@ -870,7 +907,13 @@ def main():
                                "hbm_copy_ceiling_gbs": ceiling,
                                "frac_of_copy_ceiling": sa_gbs / ceiling if sa_gbs else None,
                                "timing": timing_note,
+                               # the same stage INSIDE the replayed step: a rocprofv3 kernel trace of
+                               # `bench.py --sa-markers` reduced by tools/sa_replay_timing.py (sum of the kernels between the
+                               # marker kernels of the 16 SA spans, median over the traced replays), read from profiles/
+                               "replayed_step": replay_rec,
                                "largest_kernel": dominant}
+            if replay_rec is not None:
+                replay_rec["frac"] = sa_bytes / (replay_rec["sa_kernel_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             sa_pmc, sa_file = pmc_traffic("sa_stage")
             if sa_pmc is not None and args.batch == 8 and args.points == 40000 and args.dtype == "bf16":
                 rec["roofline"]["traffic"] = sa_pmc["total_traffic_bytes_per_step"]

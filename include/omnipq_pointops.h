@@ -47,6 +47,9 @@ const char *omnipq_error_string(int code);
 /* Measurement helper: dst[0..bytes) = src[0..bytes) (bytes % 16 == 0) with the streaming shape that reaches this chip's
  * highest copy rate -- the "measured copy ceiling" bench.py reports next to the 8 TB/s datasheet peak. */
 int omnipq_copy_probe(const void *src, void *dst, long long bytes, void *stream);
+/* measurement helper: a one-wave no-op kernel (omnipq::sa_span_begin_kernel, end != 0: _end_kernel) on `stream`, so that a
+ * kernel trace of a hipGraph replay shows where a span of launches begins and ends (tools/sa_replay_timing.py) */
+int omnipq_span_marker(int end, void *stream);
 
 /* cuda_utils.h:20-24 opt_n_threads(): the reference's block size for `work_size`
  * items, 2^floor(log2) clamped to [1, 512].  Exposed because the FPS tie rule is

@@ -35,3 +35,20 @@ extern "C" int omnipq_copy_probe(const void *src, void *dst, long long bytes, vo
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
+
+// Measurement helper (sa_fused.SPAN_MARKERS, tools/sa_replay_timing.py): one-wave kernels that do nothing, launched on the
+// stream of a span of work right before and right after it, so that a kernel trace of a hipGraph replay -- which cannot host
+// timing events -- shows where the span begins and ends in stream order.
+namespace omnipq {
+__global__ __launch_bounds__(64) void sa_span_begin_kernel() {}
+__global__ __launch_bounds__(64) void sa_span_end_kernel() {}
+}  // namespace omnipq
+
+extern "C" int omnipq_span_marker(int end, void *stream) {
+  if (end)
+    omnipq::sa_span_end_kernel<<<1, 64, 0, (hipStream_t)stream>>>();
+  else
+    omnipq::sa_span_begin_kernel<<<1, 64, 0, (hipStream_t)stream>>>();
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}

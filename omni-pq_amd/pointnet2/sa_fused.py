@@ -41,18 +41,36 @@ def _call(fn, anchor, *args):
     _ext._run(fn, anchor, *args)
 
 
+# Measuring the SA stages INSIDE the replayed step.  A hipGraph replay cannot host timing events
+# (torch refuses external events on ROCm), so the spans are made visible to a kernel trace instead: with SPAN_MARKERS set
+# (bench.py --sa-markers; env OMNIPQ_SA_MARKERS=1) every "@sa" span -- ball query, fused forward, fused backward of each of the
+# five stages, and the grouped weight-gradient launch: 16 per step -- starts and ends with a one-wave marker kernel
+# (omnipq::sa_span_begin_kernel / _end_kernel) on the stream the span's kernels are launched on.  Captured with the step the
+# markers are graph nodes in stream order, so in a `rocprofv3 --kernel-trace` of the replays the kernels of a span are exactly
+# those between its two markers on the markers' queue (tools/sa_replay_timing.py -> profiles/r*_sa_stage_replay_timing.json,
+# which bench.py reports as `roofline.replayed_step`).  Off in the product path and in every timed run.
+SPAN_MARKERS = os.environ.get("OMNIPQ_SA_MARKERS") == "1"
+
+
 class _tagged:
     """Label the timing-sink entries of everything launched inside (bench.py's per-stage accounting)."""
 
     def __init__(self, tag):
         self.tag = tag
+        self.marked = False
 
     def __enter__(self):
         self.prev = _ext.timing_tag
         _ext.timing_tag = self.tag
+        if SPAN_MARKERS and self.tag == "@sa" and torch.cuda.is_available():
+            self.marked = True
+            _lib.omnipq_span_marker(0, _ext._stream())
 
     def __exit__(self, *exc):
         _ext.timing_tag = self.prev
+        if self.marked:
+            self.marked = False
+            _lib.omnipq_span_marker(1, _ext._stream())
 
 
 _SYNC = True       # set by run() per stage: do this stage's BatchNorm layers synchronise across ranks (SyncBatchNorm)?

@@ -5,11 +5,14 @@ composition, the FP module on rows, and the whole model cut at the reference's s
 (tests/golden/model_stages_8192.pt) with every stage teacher-forced -- in fp16 the single-stage errors must come out
 BELOW the bf16 ones (10-bit mantissa instead of 7).  Upstream gradients are scaled by 2^10 as torch.amp.GradScaler would
 (a procedural upstream gradient of ~1e-3 spread over 64 samples per ball falls under fp16's normal range, 6.1e-5)."""
+import os
+
 import pytest
 import torch
 
 from conftest import load_golden
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 SCALE = 1024.0
@@ -77,3 +80,58 @@ def test_every_fp16_stage_matches_the_reference_at_single_stage_tolerance():
     print(f"  gradient norms: worst | |g|/|g_ref| - 1 | {got['worst_norm']:.2e} ({got['worst_norm_name']}; bf16 "
           f"{bf['worst_norm']:.2e}); pred_size rows compared: {got['n_size_rows']} of {got['n_size_total']}")
     assert got["worst_norm"] <= forced.GRAD_NORM["fp16"], (got["worst_norm_name"], got["worst_norm"])
+
+
+def test_whole_model_at_configs4_as_written_80k_points_batch_16_fp16():
+    """BASELINE configs[4] exactly as written -- 16 scenes x 80 000 points, fp16 -- through the whole PQ_Transformer, forward
+    and backward (until round 4 this shape ran only in the builder's bench lines).  Properties that
+    do not need a reference at this size: every float end_point and every parameter gradient is finite and non-trivial, the
+    index end_points of the backbone equal the ORACLE's furthest-point sampling on the same clouds (checked on two of the 16
+    scenes: the CPU restatement needs ~1 s per scene at 80 000 points), seeds are the first 1024 sa1 picks, and the
+    sampled centres are the clouds' own points."""
+    import sys
+    sys.path.insert(0, REPO)
+    import _ext
+    if not _ext.E16.available(torch.float16):
+        pytest.skip("the IEEE-half library is not built")
+    import bench
+    import sa_fused
+    import synth
+    from oracle import oracle_ext
+    dev = torch.device("cuda", 0)
+    B, N = 16, 80000
+    pc = synth.make_clouds(500, B, N, kind="uniform")
+    net = bench.build_model(0).to(dev).train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        ep = net({"point_clouds": pc.to(dev)})
+        loss = bench.loss_of(ep)
+    with sa_fused.deferred_wgrads():
+        (loss * 16384.0).backward()                  # static loss scale 2^14, as bench.py --dtype fp16
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).item()
+    n_float = 0
+    for k, v in ep.items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            assert torch.isfinite(v).all().item(), k
+            n_float += 1
+    assert n_float >= 100 and len(ep) >= 119
+    n_grad = 0
+    for name, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all().item(), name
+            n_grad += 1
+    assert n_grad >= 300
+    assert float(net.backbone.sa1.mlp_module.layer1.conv.weight.grad.abs().sum()) > 0
+    # index keys: int32, oracle-exact on scenes 0 and 15
+    for k in ("sa1_inds", "sa2_inds", "fp2_inds", "seed_inds"):
+        assert ep[k].dtype == torch.int32, k
+    assert tuple(ep["sa1_inds"].shape) == (B, 2048) and tuple(ep["sa2_inds"].shape) == (B, 1024)
+    assert torch.equal(ep["seed_inds"], ep["sa1_inds"][:, :1024])
+    for scene in (0, 15):
+        cloud = pc[scene:scene + 1].contiguous()
+        want1 = oracle_ext.furthest_point_sampling(cloud, 2048)
+        assert torch.equal(ep["sa1_inds"][scene:scene + 1].cpu(), want1), scene
+        centres = cloud[0, want1[0].long()].unsqueeze(0).contiguous()
+        assert torch.equal(ep["sa1_xyz"][scene:scene + 1].cpu(), centres), scene
+        want2 = oracle_ext.furthest_point_sampling(centres, 1024)
+        assert torch.equal(ep["sa2_inds"][scene:scene + 1].cpu(), want2), scene

@@ -56,15 +56,24 @@ if [ "${2:-}" != "--collect" ]; then
     python $R/tools/rocprof_summary.py $D 6 $OUT/${m}_steady.csv $OUT/${m}_summary.md
     rm -rf $OUT/$m
   done
+  # 13. the SA stages INSIDE the replayed step: marker kernels around every SA span (bench.py --sa-markers), kernel trace,
+  #     reduced by tools/sa_replay_timing.py -> the `timing_source` of the bench line's roofline.replayed_step
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/markers -o t -- python $R/bench.py --sa-markers --steps 12 --warmup 3 --no-cpu-baseline --no-op-timing > $OUT/markers.log 2>&1
+  python $R/tools/sa_replay_timing.py $OUT/markers $OUT/sa_stage_replay_timing.json > $OUT/sa_stage_replay_timing.log 2>&1
+  D=$(dirname $(find $OUT/markers -name "*_kernel_trace.csv" | head -1))
+  python $R/tools/step_timeline.py $OUT/markers $OUT/step_timeline.md > /dev/null 2>&1
+  rm -rf $OUT/markers
   : > $OUT/other_lines.jsonl
   for F in "--mean-teacher" "--loss supervised" "--input-pipeline" "--dtype fp16 --batch 16 --points 80000" "--dtype bf16 --batch 16 --points 80000" "--batch 4 --points 50000 --extra-channels 6" "--dtype fp16" "--prefetch-at backward" "--fps-footprint fast"; do
-    python $R/bench.py --no-cpu-baseline $F 2>/dev/null | grep "^{" | python -c "
+    # every line carries its own event-timed roofline (never --no-op-timing for a line that goes into profiles/)
+    python $R/bench.py --no-cpu-baseline --steps 30 $F 2>/dev/null | grep "^{" | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l)
-    keep = {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'launch', 'input', 'config') if k in d}
+    keep = {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'median_ms_per_step', 'eager_ms_per_step', 'steps', 'dtype', 'launch', 'input', 'config') if k in d}
     keep['flags'] = '$F'
-    keep['sa_stage'] = {k: d['sa_stage'][k] for k in ('avg_ms', 'frac', 'algorithmic_bytes')} if 'sa_stage' in d else None
+    r = d.get('roofline') or {}
+    keep['roofline'] = {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'algorithmic_bytes_per_launch', 'feature_bytes', 'hbm_copy_ceiling_gbs', 'timing')}
     print(json.dumps(keep))" >> $OUT/other_lines.jsonl
   done
   du -sh $OUT
@@ -87,3 +96,5 @@ python $R/tools/pmc_issue.py $R/gpurun_out/issue_refresh_bench 0.4 3 $P/${TAG}_b
 cp $OUT/mean_teacher_summary.md $P/${TAG}_mean_teacher_summary.md
 cp $OUT/supervised_summary.md $P/${TAG}_supervised_summary.md
 cp $OUT/other_lines.jsonl $P/${TAG}_bench_lines_other_configs.jsonl
+cp $OUT/sa_stage_replay_timing.json $P/${TAG}_sa_stage_replay_timing.json
+cp $OUT/step_timeline.md $P/${TAG}_step_timeline.md
