@@ -107,6 +107,8 @@ typedef struct {
                               * first layer of an SA stage multiplies rows laid out [features(split) | xyz(rot) | 0...]
                               * while the parameter's columns are [xyz(rot) | features] */
   const float *ba, *bb;      /* both NULL, or float[N]: B stands for relu(ba .* B + bb) (see ..._affine below) */
+  const int *rows_dev;       /* NULL, or the row plan of the stage the operands belong to (omnipq_sa_ball_plan): the positions
+                              * in use are the first *rows_dev (device memory) of P */
 } omnipq_tn_problem;
 long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);
 
@@ -161,6 +163,21 @@ int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const fl
 int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
+
+/* Row plan of a stage whose balls hold duplicate rows (csrc/common.h: RowPlan).  ball_query pads a ball with copies of its
+ * first neighbour, so the grouped rows behind the real neighbours duplicate the ball's row 0.  omnipq_sa_ball_plan derives
+ * the COMPACT row space of a stage from its ball-query indices idx (int32 [balls][nsample], nsample % 16 == 0): ball b keeps
+ * its first 16 * g_b rows, g_b = ceil(real neighbours / 16); goff (int32 [balls + 1]) = first 16-row group of every ball,
+ * rows_dev (int32 [1], device) = 16 * goff[balls] rows in use, row_w (uint8 per compact row) = how many rows of the full
+ * layout the row stands for (1 + dropped copies on a ball's first row, else 1); scratch = int32 [balls].
+ * omnipq_sa_row_plan(rows_dev, row_w, goff, rows) makes a plan current for the CALLING THREAD: the stage's kernels launched
+ * with exactly `rows` rows (the full count: grids stay static, graph-capturable) work on *rows_dev rows -- workgroups past
+ * them leave at once --, weight the BatchNorm statistics and the constant backward terms by row_w, and the ball-structured
+ * ones (omnipq_sa_gather, omnipq_sa_pool_select_finalize, omnipq_sa_pool_bwd_apply) address balls through goff.
+ * rows_dev == NULL clears it.  Results equal the full computation up to the order of the f32 sums. */
+int omnipq_sa_ball_plan(long long balls, int nsample, const int *idx, int *goff, int *rows_dev, void *row_w, int *scratch,
+                        void *stream);
+void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows);
 
 /* Row-strip GEMMs (csrc/gemm_strip.hip): the same contraction C = f(A) B^T as the omnipq_gemm_nt_e16* family for the
  * shared-MLP layers of a set-abstraction stage (pytorch_utils.py:11-36), with a workgroup owning 128 rows and ALL N

@@ -167,6 +167,24 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Row plan of a set-abstraction stage (include/omnipq_sa.h: omnipq_sa_row_plan): ball_query pads a ball that holds fewer than
+// nsample points with copies of its FIRST neighbour (ball_query_gpu.cu:36-45), so the grouped rows behind the real
+// neighbours are duplicates of the ball's row 0 and every per-row result computed from them is a duplicate too.  A planned
+// stage runs on a COMPACT row space: ball b keeps its first 16 * g_b rows (g_b = ceil(real neighbours / 16) groups of 16),
+// the balls' groups are laid out back to back (goff = exclusive scan of g_b, in groups), and the number of rows in use lives
+// in device memory (`rows_dev`): launches keep their static grids for the full row count `rows`, workgroups past *rows_dev
+// leave at once.  The dropped rows are accounted for through `row_w` (one byte per compact row: how many rows of the full
+// layout it stands for -- 1, or 1 + dropped copies for a ball's first row): BatchNorm statistics are sums of w * y and
+// w * y^2, and the constant term of the BatchNorm backward, which every copy contributes once, is multiplied by w; everything
+// else downstream is linear in the rows.  Thread-local; applies to launches whose row count equals `rows`.
+struct RowPlan {
+  const int *rows_dev = nullptr;                 // device: rows in use (a multiple of 16)
+  const unsigned char *row_w = nullptr;          // [rows]
+  const int *goff = nullptr;                     // [balls + 1]: first 16-row group of every ball
+  long long rows = 0;                            // the static row count the stage's launches are issued with
+};
+RowPlan &row_plan();                            // capi.hip; thread-local
+
 // Pair launches (include/omnipq_sa.h: omnipq_pair_hold): one launch of the calling thread held back for a partner of the
 // same kind.  `blob` holds the kernel-specific problem record, `single` sends it out on its own.
 struct HeldLaunch {

@@ -41,6 +41,10 @@ struct GemmArgs {
   unsigned drop_thresh = 0, drop_salt = 0;
   float drop_keep_inv = 1.f;
   const unsigned long long *drop_seed = nullptr;
+  // row plan of a set-abstraction stage (common.h: RowPlan; the PLAN instantiations, T = 128): the rows in use are the first
+  // *rows_dev of M (tiles past them leave at once), row_w weights the statistics
+  const int *rows_dev = nullptr;
+  const unsigned char *row_w = nullptr;
 };
 
 __device__ __forceinline__ uint4 ldg16(const e16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -151,7 +155,7 @@ constexpr int kResMaxSteps = 10;
 
 // The workgroup program of every NT GEMM variant; `bid` = this workgroup's index within ITS problem (blockIdx.x of a
 // plain launch; the pair launch below runs two problems in one grid).
-template <bool OUT_F32, int STATS, bool AFF, int T, int XG, bool KRES>
+template <bool OUT_F32, int STATS, bool AFF, int T, int XG, bool KRES, bool PLAN = false>
 __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__restrict__ A, const e16_t *__restrict__ B,
                                              void *__restrict__ Cout, const float *__restrict__ bias,
                                              void *__restrict__ stats_out, const BnBwdEpilogue &bn, const AffineIn &aff,
@@ -211,6 +215,19 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   NT_STAMP(0);
+  // row plan: the rows in use (device memory: the grid was sized for all g.M rows)
+  static_assert(!PLAN || (T == 128 && !OUT_F32 && !KRES), "row plans: 128 x 128 tiles with e16 output");
+  constexpr bool planned = PLAN;                 // (the launchers pick the PLAN instantiation iff g.rows_dev is set)
+  const int Meff = planned ? *g.rows_dev : g.M;
+  if (planned && m0 >= Meff) {
+    // nothing to do -- but the reductions that follow read this tile's partial sums
+    if (STATS == 2 || STATS == 4) {
+      const int col = tid % T;
+      for (int which = tid / T; which < NS; which += 256 / T)
+        if (n0 + col < g.N) reinterpret_cast<float *>(stats_out)[((size_t)mt * NS + which) * g.N + n0 + col] = 0.f;
+    }
+    return;
+  }
 
   // staging assignment: chunk q = tid + i*256 -> row q>>2, 16-byte piece q&3
   // Rows past M (or N) are clamped to the last valid row instead of being zero-filled: whatever they
@@ -224,7 +241,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
     srow[i] = q >> 2;
     skc[i] = q & 3;
     int ar = m0 + srow[i], br = n0 + srow[i];
-    ar = ar < g.M ? ar : g.M - 1;
+    ar = ar < Meff ? ar : Meff - 1;
     br = br < g.N ? br : g.N - 1;
     ga[i] = A + (size_t)ar * g.lda + kbeg + skc[i] * 8;
     gb[i] = B + (size_t)br * g.ldb + kbeg + skc[i] * 8;
@@ -251,7 +268,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       int ar = m0 + srow[i];
-      ar = ar < g.M ? ar : g.M - 1;
+      ar = ar < Meff ? ar : Meff - 1;
       const uint2 v = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)ar * xg.ldx);
       x0r[i][0] = e16_lo(v.x);
       x0r[i][1] = e16_hi(v.x);
@@ -540,7 +557,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
         const int q = tid + it * 256;
         const int row = q / PIECES, piece = q % PIECES;
         int gr = m0 + row, gc = n0 + piece * 8;
-        gr = gr < g.M ? gr : g.M - 1;                     // clamped: the value is only used under the bounds test below
+        gr = gr < Meff ? gr : Meff - 1;                   // clamped: the value is only used under the bounds test below
         gc = gc < g.N ? gc : 0;
         ypre[it] = *reinterpret_cast<const uint4 *>(bn.Y + (size_t)gr * g.ldc + gc);
       }
@@ -550,7 +567,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
       const int q = tid + it * 256;
       const int row = q / PIECES, piece = q % PIECES;
       const int gr = m0 + row, gc = n0 + piece * 8;
-      if (gr < g.M && gc < g.N) {
+      if (gr < Meff && gc < g.N) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * CP + piece * 8);
         if (STATS == 5) {
           // C = (H > 0) ? C / (1 - p) : 0 with H (bn.Y, same shape and pitch as C) the stored output of dropout(relu(.)):
@@ -597,6 +614,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
           }
         } else if (STATS >= 1 && STATS <= 2) {
           const unsigned w[4] = {v.x, v.y, v.z, v.w};
+          if (planned && g.row_w) {
+            const float wr = (float)g.row_w[gr];          // rows of the full layout this row stands for
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = e16_lo(w[e]), hi = e16_hi(w[e]);
+              cs[2 * e] = __builtin_fmaf(wr, lo, cs[2 * e]);
+              cs2[2 * e] = __builtin_fmaf(wr * lo, lo, cs2[2 * e]);
+              cs[2 * e + 1] = __builtin_fmaf(wr, hi, cs[2 * e + 1]);
+              cs2[2 * e + 1] = __builtin_fmaf(wr * hi, hi, cs2[2 * e + 1]);
+            }
+          } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float lo = e16_lo(w[e]), hi = e16_hi(w[e]);
@@ -604,6 +632,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
             cs2[2 * e] += lo * lo;
             cs[2 * e + 1] += hi;
             cs2[2 * e + 1] += hi * hi;
+          }
           }
         }
       }
@@ -735,8 +764,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   NT_STAMP(7);
 }
 
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false>
-__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? 4 : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false, bool PLAN = false>
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? ((PLAN && XG == 1) ? 3 : 4) : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
                                                         const e16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
@@ -745,7 +774,7 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? 4 : 2) voi
                                                         AffineIn aff = AffineIn(),
                                                         PoolOut pool = PoolOut(),
                                                         XyzGen xg = XyzGen()) {
-  gemm_nt_body<OUT_F32, STATS, AFF, T, XG, KRES>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, (int)blockIdx.x);
+  gemm_nt_body<OUT_F32, STATS, AFF, T, XG, KRES, PLAN>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, (int)blockIdx.x);
 }
 
 // Two INDEPENDENT small problems of the same variant in one grid (64 x 64 tiles, K-resident): the per-point stacks of
@@ -892,6 +921,15 @@ static bool gemm_nt_small_tiles(int M, int N) {
   return (long long)((M + 127) / 128) * ((N + 127) / 128) <= 256;
 }
 
+// the calling thread's row plan (common.h: RowPlan), if it was made for this many rows
+static void plan_rows(omnipq::GemmArgs &g) {
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  if (rp.rows_dev && rp.rows == g.M && g.m_tiles > 64) {      // (> kStatsDirectTiles: the partial-sum paths)
+    g.rows_dev = rp.rows_dev;
+    g.row_w = rp.row_w;
+  }
+}
+
 static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int ldc, int T) {
   return omnipq::GemmArgs{M, N, K, lda, ldb, ldc, K, (M + T - 1) / T, (N + T - 1) / T};
 }
@@ -990,9 +1028,14 @@ extern "C" int omnipq_gemm_nt_e16(int M, int N, int K, const void *A, int lda, c
     const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
     launch_small<0, false>(g, A, B, C, nullptr, nullptr, BnBwdEpilogue(), AffineIn(), stream);
   } else {
-    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
-    gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
-                                                                          nullptr);
+    GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
+    plan_rows(g);
+    if (g.rows_dev)
+      gemm_nt_kernel<false, 0, false, 128, 0, false, true><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+          g, (const e16_t *)A, (const e16_t *)B, C, nullptr);
+    else
+      gemm_nt_kernel<false><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C,
+                                                                            nullptr);
   }
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
@@ -1017,6 +1060,7 @@ extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int 
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || !sums || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   if (g.m_tiles <= kStatsDirectTiles) {
@@ -1031,8 +1075,12 @@ extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int 
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
-                                                              workspace);
+  if (g.rows_dev)
+    gemm_nt_kernel<false, 2, false, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, C, bias, workspace);
+  else
+    gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
+                                                                workspace);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1051,6 +1099,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8) || K > kAffMaxK) return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   const bool small = pool.s == 0 && gemm_nt_small_tiles(M, N);
@@ -1076,8 +1125,12 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
-                                                                    workspace, BnBwdEpilogue(), aff, pool);
+  if (g.rows_dev)
+    gemm_nt_kernel<false, 2, true, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, C, bias, workspace, BnBwdEpilogue(), aff, pool);
+  else
+    gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
+                                                                      workspace, BnBwdEpilogue(), aff, pool);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1190,6 +1243,7 @@ extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A,
   const int rc = pool_out_check(M, N, s, ymax, ymin, amax, amin, &pool);
   if (rc) return rc;
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   if (g.m_tiles <= kStatsDirectTiles) {
@@ -1199,8 +1253,12 @@ extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A,
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
-                                                              workspace, BnBwdEpilogue(), AffineIn(), pool);
+  if (g.rows_dev)
+    gemm_nt_kernel<false, 2, false, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, C, bias, workspace, BnBwdEpilogue(), AffineIn(), pool);
+  else
+    gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
+                                                                workspace, BnBwdEpilogue(), AffineIn(), pool);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1226,6 +1284,7 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
   if (!A || !B || !C || !sums || !Y || !a || !b || !mean || !invstd) return OMNIPQ_EINVAL;
   if ((K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   BnBwdEpilogue bn{(const e16_t *)Y, a, b, mean, invstd};
@@ -1241,8 +1300,12 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
-  gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, nullptr,
-                                                              workspace, bn);
+  if (g.rows_dev)
+    gemm_nt_kernel<false, 4, false, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, C, nullptr, workspace, bn);
+  else
+    gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, nullptr,
+                                                                workspace, bn);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1278,6 +1341,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
   if (!fin_sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out || !(count > 0)) return OMNIPQ_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, 0, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
   if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
   AffineIn aff{};
   aff.sums = fin_sums;
@@ -1295,8 +1359,12 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
   const XyzGen xg{(const e16_t *)X0, ldx, (const e16_t *)W0, ldw0};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false, 2, true, 128, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
-      g, (const e16_t *)B, (const e16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
+  if (g.rows_dev)
+    gemm_nt_kernel<false, 2, true, 128, 1, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)B, (const e16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
+  else
+    gemm_nt_kernel<false, 2, true, 128, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)B, (const e16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
@@ -1321,13 +1389,18 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, 
   if ((K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || N > kXgMaxC || (ldx % 4) || (ldw0 % 4) || ldx < 3 || ldw0 < 3)
     return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, N, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
   if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
   const XyzGen xg{(const e16_t *)X0, ldx, (const e16_t *)W0, ldw0};
   const BnBwdEpilogue bn{nullptr, a, b, mean, invstd};
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
-  gemm_nt_kernel<false, 4, false, 128, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
-      g, (const e16_t *)A, (const e16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
+  if (g.rows_dev)
+    gemm_nt_kernel<false, 4, false, 128, 2, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
+  else
+    gemm_nt_kernel<false, 4, false, 128, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;

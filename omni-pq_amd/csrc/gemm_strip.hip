@@ -28,6 +28,8 @@ struct StripArgs {
   int M, N, K;
   int lda, ldb, ldc;
   int strips, n_tiles;
+  const int *rows_dev;            // row plan of the stage (common.h: RowPlan): rows in use, or NULL
+  const unsigned char *row_w;     // ... and their weights in the statistics
   int debug;                      // tools/bench_strip.py --ablate: 1 no C stores, 2 no weight fetches after the first two,
                                   // 4 no strip load, 8 no MFMAs (0 in the product path)
 };
@@ -104,7 +106,7 @@ __device__ __forceinline__ void strip_wait_dyn(int n) {
 #undef OMNIPQ_W
 }
 
-template <int NKF, bool AFF, bool STATS, bool POOL>
+template <int NKF, bool AFF, bool STATS, bool POOL, bool PLAN = false>
 __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e16_t *__restrict__ A,
                                                             const e16_t *__restrict__ B, e16_t *__restrict__ C,
                                                             float *__restrict__ part, StripAffine aff, StripPool pool) {
@@ -121,6 +123,13 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
   const int wm = wave >> 1, wn = wave & 1;
   const int strip = (int)blockIdx.x;
   const int m0 = strip * SBM;
+  // row plan (common.h: RowPlan): the rows in use live in device memory, the grid was sized for all g.M rows
+  const int Meff = PLAN ? *g.rows_dev : g.M;
+  if (PLAN && m0 >= Meff) {
+    if (STATS)                                    // the reduction that follows reads this strip's two partial rows
+      for (int c = tid; c < 4 * g.N; c += 256) part[(size_t)strip * 4 * g.N + c] = 0.f;
+    return;
+  }
 
   if ((g.debug >> 8) && strip >= 256 && strip < 512) {
     // experiment: the second residency slot of every CU starts late by (debug >> 8) x 8128 cycles
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
       const int q = tid + it * 256;
       const int row = q / PPR, piece = q % PPR;
       int gr = m0 + row;
-      gr = gr < g.M ? gr : g.M - 1;
+      gr = gr < Meff ? gr : Meff - 1;
       ld[it] = (g.debug & 4) ? make_uint4(0u, 0u, 0u, 0u) : sldg16(A + (size_t)gr * g.lda + piece * 8);
     }
 #pragma unroll
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
         v.z = strip_affine_pair(v.z, a1[0], b1[0], a1[1], b1[1]);
         v.w = strip_affine_pair(v.w, a1[2], b1[2], a1[3], b1[3]);
       }
-      if (m0 + row >= g.M) v = make_uint4(0u, 0u, 0u, 0u);       // rows past M: zero AFTER the transform (statistics stay clean)
+      if (m0 + row >= Meff) v = make_uint4(0u, 0u, 0u, 0u);      // rows past M: zero AFTER the transform (statistics stay clean)
       *reinterpret_cast<uint4 *>(sA + row * APITCH + piece * 8) = v;
     }
   }
@@ -240,6 +249,19 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
   int q = 0;
 
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+  // PLAN: the statistics weights of this lane's accumulator rows, as pairs (row r, r + 1) per block and register pair
+  float wrow[2][8][2];
+  if (PLAN) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int r = 2 * h;
+        const int gr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+        wrow[i][h][0] = gr < Meff ? (float)g.row_w[gr] : 0.f;
+        wrow[i][h][1] = gr + 1 < Meff ? (float)g.row_w[gr + 1] : 0.f;
+      }
+  }
   const bool odd = lane & 1;
   const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;
   unsigned *const ct32 = reinterpret_cast<unsigned *>(cpatch + wave * (64 * SCPITCH * 2));
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
   // the patch of column tile `t` as 128-byte row segments: lane -> (row it * 8 + lane / 8, piece lane % 8)
   // `full`: the whole strip lies inside M and N is a multiple of 128 -- every store below is issued by every lane, so the
   // number of memory instructions a wave has in flight is known exactly and the counted waits can step over its stores
-  const bool full = (m0 + SBM <= g.M) && (g.N % SBN == 0) && !(g.debug & 1) && !(g.debug & 32);
+  const bool full = (m0 + SBM <= Meff) && (g.N % SBN == 0) && !(g.debug & 1) && !(g.debug & 32);
   auto store_patch = [&](int t) {
     const e16_t *ct = reinterpret_cast<const e16_t *>(ct32);
     if (full) {
@@ -263,9 +285,10 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
       const int row = it * 8 + (lane >> 3), piece = lane & 7;
       const int gr = m0 + wm * 64 + row, gc = t * SBN + wn * 64 + piece * 8;
       const uint4 v = *reinterpret_cast<const uint4 *>(ct + row * SCPITCH + piece * 8);
-      if (gr < g.M && gc < g.N && !(g.debug & 1)) *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;
+      if (gr < Meff && gc < g.N && !(g.debug & 1)) *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;
     }
   };
+  const int patch_stores = 8;                                        // C stores of one patch (exact when `full`)
   // memory instructions of one epilogue (statistics and ball-extrema stores), exact when `full`
   const int epi_ops = (STATS ? 4 : 0) + (POOL ? (16 / (pool.s >> 4)) : 0);
 
@@ -293,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
         if (full) {
           const int cm1 = (c + NCH - 1) % NCH, cm2 = (c + 2 * NCH - 2) % NCH;          // c of iterations q - 1, q - 2
           const int ntm1 = nt - (c < 1 ? 1 : 0), ntm2 = nt - (c < 2 ? (NCH >= 2 ? 1 : 2) : 0);   // their column tiles
-          if (q >= 1 && cm1 == 0 && ntm1 > 0) younger += 8;
-          if (q >= 2 && cm2 == 0 && ntm2 > 0) younger += 8;
+          if (q >= 1 && cm1 == 0 && ntm1 > 0) younger += patch_stores;
+          if (q >= 2 && cm2 == 0 && ntm2 > 0) younger += patch_stores;
           if (q >= 1 && cm1 == NCH - 1) younger += epi_ops;
           if (q >= 2 && cm2 == NCH - 1) younger += epi_ops;
         }
@@ -353,8 +376,14 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
             const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
             cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (SCPITCH / 2) + j * 16] = __builtin_amdgcn_perm(other, mine, pair_sel);
             if (STATS) {
-              cs += v0 + v1;
-              cq = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, cq));
+              if (PLAN) {                            // weighted: a ball's first row stands for its dropped copies too
+                const float w0 = wrow[i][r >> 1][0], w1 = wrow[i][r >> 1][1];
+                cs += __builtin_fmaf(w0, v0, w1 * v1);
+                cq = __builtin_fmaf(w0 * v0, v0, __builtin_fmaf(w1 * v1, v1, cq));
+              } else {
+                cs += v0 + v1;
+                cq = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, cq));
+              }
             }
             if (POOL) {
               const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, mine) >> 15);
@@ -437,10 +466,10 @@ __global__ __launch_bounds__(256) void strip_partial_reduce_kernel(int rows, int
                             (((double)acc[4] + (double)acc[5]) + ((double)acc[6] + (double)acc[7])));
 }
 
-template <int NKF, bool AFF, bool STATS, bool POOL>
+template <int NKF, bool AFF, bool STATS, bool POOL, bool PLAN = false>
 static int launch_strip(const StripArgs &g, const void *A, const void *B, void *C, float *part, const StripAffine &aff,
                         const StripPool &pool, hipStream_t stream) {
-  auto kern = gemm_strip_kernel<NKF, AFF, STATS, POOL>;
+  auto kern = gemm_strip_kernel<NKF, AFF, STATS, POOL, PLAN>;
   constexpr int lds = StripGeom<NKF>::LDS_BYTES;
   static const hipError_t prepared =
       hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -453,6 +482,15 @@ static int launch_strip(const StripArgs &g, const void *A, const void *B, void *
 template <int NKF>
 static int dispatch_strip(const StripArgs &g, const void *A, const void *B, void *C, float *part, bool has_aff,
                           const StripAffine &aff, bool stats, const StripPool &pool, hipStream_t stream) {
+  if (g.rows_dev) {                               // row plan: the statistics variants (a planned layer always has statistics)
+    if (!stats) return OMNIPQ_EINVAL;
+    if (has_aff) {
+      if (pool.s) return launch_strip<NKF, true, true, true, true>(g, A, B, C, part, aff, pool, stream);
+      return launch_strip<NKF, true, true, false, true>(g, A, B, C, part, aff, pool, stream);
+    }
+    if (pool.s) return launch_strip<NKF, false, true, true, true>(g, A, B, C, part, aff, pool, stream);
+    return launch_strip<NKF, false, true, false, true>(g, A, B, C, part, aff, pool, stream);
+  }
   if (has_aff) {
     if (pool.s) return launch_strip<NKF, true, true, true>(g, A, B, C, part, aff, pool, stream);
     if (stats) return launch_strip<NKF, true, true, false>(g, A, B, C, part, aff, pool, stream);
@@ -540,7 +578,15 @@ extern "C" int omnipq_gemm_strip_e16(int M, int N, int K, const void *A, int lda
     pool.amin = amin;
   }
   if (sums && !workspace) return OMNIPQ_EINVAL;
-  StripArgs g{M, N, K, lda, ldb, ldc, (M + SBM - 1) / SBM, (N + SBN - 1) / SBN, g_strip_debug};
+  StripArgs g{M, N, K, lda, ldb, ldc, (M + SBM - 1) / SBM, (N + SBN - 1) / SBN, nullptr, nullptr, g_strip_debug};
+  {
+    const RowPlan &rp = row_plan();               // the calling thread's row plan, if it was made for this many rows
+    if (rp.rows_dev && rp.rows == M) {
+      if (s != 0 && s != 16) return OMNIPQ_EINVAL;  // a planned stage records its ball extrema per 16-row group
+      g.rows_dev = rp.rows_dev;
+      g.row_w = rp.row_w;
+    }
+  }
   int rc;
   if (K == 128)
     rc = dispatch_strip<8>(g, A, B, C, workspace, has_aff, aff, sums != nullptr, pool, (hipStream_t)stream);

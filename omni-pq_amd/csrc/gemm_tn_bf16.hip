@@ -32,6 +32,9 @@ struct TnArgs {
   int lda, ldb;       // row pitch (elements) of A and B
   int p_chunk;        // positions per slab, multiple of TBK
   int m_tiles, n_tiles;
+  // row plan of the stage (common.h: RowPlan) or NULL: the positions in use are the first *rows_dev of P (slabs past them
+  // contribute zero tiles)
+  const int *rows_dev = nullptr;
 };
 
 // colsum (may be NULL): float[M], receives (ADDED, f32 atomics) the column sums of A over all positions --
@@ -82,10 +85,19 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const e16_t *__restrict
   if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
   const int mt = tile / g.n_tiles, nt = tile % g.n_tiles;
   const int m0 = mt * 128, n0 = nt * 128;
-  const int pbeg = slab * g.p_chunk;
-  int pend = pbeg + g.p_chunk;
-  if (pend > g.P) pend = g.P;
-  const int nk = (pend - pbeg + TBK - 1) / TBK;
+  // row plan: the positions in use are spread evenly over the slabs the launch was planned with (all of them do the same
+  // amount of work; cut at the planned length the later slabs would be empty and the first ones as long as before)
+  const int Peff = g.rows_dev ? *g.rows_dev : g.P;
+  int chunk = g.p_chunk;
+  if (g.rows_dev) {
+    const int nslab = (g.P + g.p_chunk - 1) / g.p_chunk;
+    chunk = ((Peff + nslab - 1) / nslab + TBK - 1) / TBK * TBK;
+    if (chunk < TBK) chunk = TBK;
+  }
+  const int pbeg = slab * chunk;
+  int pend = pbeg + chunk;
+  if (pend > Peff) pend = Peff;
+  const int nk = pend > pbeg ? (pend - pbeg + TBK - 1) / TBK : 0;
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -152,7 +164,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const e16_t *__restrict
     for (int i = 0; i < 2; ++i) {
       const int p = pbeg + kt * TBK + spos[i];
       keep[i] = p < pend ? 0xFFFFFFFFu : 0u;
-      const int pc = p < pend ? p : g.P - 1;
+      const int pc = p < pend ? p : (Peff > 0 ? Peff - 1 : 0);
       ra[i] = *reinterpret_cast<const uint4 *>(A + (size_t)pc * g.lda + acol[i]);
       if (XGB) {
         const uint2 xv = *reinterpret_cast<const uint2 *>(B + (size_t)pc * g.ldb);       // x0[p][0..2]
@@ -315,11 +327,12 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_xyz_kernel(TnArgs g, const e16
 // depends on a weight gradient until the optimizer, so they are collected during backward and run here as ONE
 // grid (descriptors by value in the kernel arguments, <= kGroupMax per launch), followed by ONE reduction that
 // also crops the padded rows / columns and writes the gradient in the parameter's own shape.
-constexpr int kGroupMax = 32;
+constexpr int kGroupMax = 31;            // 31 x 128-byte items + header fit the 4 KB of kernel arguments
 struct TnGroupItem {
   const e16_t *A, *B;
   float *part, *colsum, *out;
   const float *ba, *bb;         // AFFB launches only
+  const int *rows_dev;          // row plan of the problem's stage (TnArgs::rows_dev) or NULL
   int M, N, P, lda, ldb, p_chunk, m_tiles, n_tiles;
   int wg_begin;                 // first workgroup of this problem (multiple of 8: the XCD mapping above stays valid)
   int slabs;                    // slabs in use
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) 
     if (a.item[mid].wg_begin <= id) lo = mid; else hi = mid - 1;
   }
   const TnGroupItem &it = a.item[lo];
-  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles};
+  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles, it.rows_dev};
   tn_tile<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
 }
 
@@ -473,6 +486,10 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
   if (M == 0 || N == 0) return OMNIPQ_OK;
   if (!A || !B || !C || !workspace || (M % 8) || (N % 8) || (lda % 8) || (!W0 && (ldb % 8))) return OMNIPQ_EINVAL;
   TnArgs g{M, N, P, lda, ldb, 0, (M + 127) / 128, (N + 127) / 128};
+  {
+    const RowPlan &rp = row_plan();               // the calling thread's row plan, if it was made for this many positions
+    if (rp.rows_dev && rp.rows == P) g.rows_dev = rp.rows_dev;
+  }
   const int tiles = g.m_tiles * g.n_tiles;
   const int slabs = tn_slabs(tiles, P);
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
@@ -515,6 +532,7 @@ struct omnipq_tn_problem_ {
   int flags;                // bit 0: out += C
   int rot;                  // rot | split << 8 (0: none): out column c = C column (c < rot ? split + c : c - rot)
   const float *ba, *bb;     // NULL, or: B stands for relu(ba .* B + bb)
+  const int *rows_dev;      // NULL, or the row plan of the stage the operands belong to: positions in use (device memory)
 };
 
 // Positions per workgroup in a grouped launch, the same for every problem of the call (balance): at least 16 K-steps
@@ -591,6 +609,7 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
           it.out = q.out;
           it.ba = q.ba;
           it.bb = q.bb;
+          it.rows_dev = q.rows_dev;
           it.M = q.M; it.N = q.N; it.P = q.P; it.lda = q.lda; it.ldb = q.ldb;
           it.m_tiles = (q.M + 127) / 128;
           it.n_tiles = (q.N + 127) / 128;

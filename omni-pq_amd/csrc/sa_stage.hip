@@ -81,6 +81,40 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(long long chunks, int n,
   }
 }
 
+// The same into the COMPACT row space of a row plan (common.h: RowPlan): ball bm writes the rows t < 16 (goff[bm + 1] - goff[bm])
+// of its neighbour list to rows 16 goff[bm] + t.  One lane per 16-byte piece of a row of the FULL layout; lanes of dropped
+// rows leave.
+__global__ __launch_bounds__(256) void sa_gather_compact_kernel(long long chunks, int n, int m, int s, int cin,
+                                                               int kpad, float inv_r,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz,
+                                                               const int *__restrict__ idx,
+                                                               const e16_t *__restrict__ feat,
+                                                               const int *__restrict__ goff,
+                                                               e16_t *__restrict__ X) {
+  const int cpr = kpad >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
+    const long long p = q / cpr;
+    const int c8 = (int)(q - p * cpr);
+    const int bm = (int)(p / s);
+    const int t = (int)(p - (long long)bm * s);
+    const int g0 = goff[bm];
+    if (t >= (goff[bm + 1] - g0) * 16) continue;
+    const int b = bm / m;
+    const int k = idx[p];
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (c8 * 8 < cin) {
+      out = *reinterpret_cast<const uint4 *>(feat + ((size_t)b * n + k) * cin + c8 * 8);
+    } else if (c8 * 8 == cin) {
+      const float *pk = xyz + ((size_t)b * n + k) * 3;
+      const float *pc = new_xyz + (size_t)bm * 3;
+      float f[8] = {(pk[0] - pc[0]) * inv_r, (pk[1] - pc[1]) * inv_r, (pk[2] - pc[2]) * inv_r, 0, 0, 0, 0, 0};
+      out = pack8(f);
+    }
+    *reinterpret_cast<uint4 *>(X + ((size_t)g0 * 16 + t) * kpad + c8 * 8) = out;
+  }
+}
+
 // ------------------------------------------------------------------------------- column sums
 // Shared tail of the statistic kernels: every thread holds 8 partial (u, v) sums for channels
 // cg*8..cg*8+7; fold the row-groups of the block through LDS, then one f64 atomic per channel.
@@ -321,7 +355,10 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ a_out, float *__restrict__ b_out,
     float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ out_f32, e16_t *__restrict__ out_pm,
-    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel) {
+    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel, const int *__restrict__ goff) {
+  // goff (row plan, common.h: RowPlan) or NULL: the extrema arrays hold one entry per 16-row GROUP, ball bm owns the groups
+  // goff[bm] .. goff[bm + 1] and its extrema are merged here (strict comparisons: an earlier group wins a tie, as the first
+  // row does inside a group), the row within the ball = 16 * (group within the ball) + row within the group
   __shared__ __attribute__((aligned(16))) float s_a[kFinMaxC], s_b[kFinMaxC];
   for (int c = (int)threadIdx.x; c < C; c += 256) {
     const double mu = sums[c] / cnt;
@@ -352,10 +389,39 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
     float av[8], bv[8], hi[8], lo[8], best[8], sel[8];
     load8f(s_a + c0, av);
     load8f(s_b + c0, bv);
-    unpack8(*reinterpret_cast<const uint4 *>(ymax + o), hi);
-    unpack8(*reinterpret_cast<const uint4 *>(ymin + o), lo);
-    const unsigned long long ph = *reinterpret_cast<const unsigned long long *>(amax + o);
-    const unsigned long long pl = *reinterpret_cast<const unsigned long long *>(amin + o);
+    unsigned long long ph, pl;
+    if (goff) {
+      const int g0 = goff[bm], ng = goff[bm + 1] - g0;
+      const size_t og = (size_t)g0 * C + c0;
+      unpack8(*reinterpret_cast<const uint4 *>(ymax + og), hi);
+      unpack8(*reinterpret_cast<const uint4 *>(ymin + og), lo);
+      ph = *reinterpret_cast<const unsigned long long *>(amax + og);
+      pl = *reinterpret_cast<const unsigned long long *>(amin + og);
+      for (int gi = 1; gi < ng; ++gi) {
+        float h2[8], l2[8];
+        const size_t o2 = og + (size_t)gi * C;
+        unpack8(*reinterpret_cast<const uint4 *>(ymax + o2), h2);
+        unpack8(*reinterpret_cast<const uint4 *>(ymin + o2), l2);
+        const unsigned long long ph2 = *reinterpret_cast<const unsigned long long *>(amax + o2);
+        const unsigned long long pl2 = *reinterpret_cast<const unsigned long long *>(amin + o2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (h2[e] > hi[e]) {
+            hi[e] = h2[e];
+            ph = (ph & ~(0xFFull << (8 * e))) | ((((ph2 >> (8 * e)) & 0xFF) + 16ull * gi) << (8 * e));
+          }
+          if (l2[e] < lo[e]) {
+            lo[e] = l2[e];
+            pl = (pl & ~(0xFFull << (8 * e))) | ((((pl2 >> (8 * e)) & 0xFF) + 16ull * gi) << (8 * e));
+          }
+        }
+      }
+    } else {
+      unpack8(*reinterpret_cast<const uint4 *>(ymax + o), hi);
+      unpack8(*reinterpret_cast<const uint4 *>(ymin + o), lo);
+      ph = *reinterpret_cast<const unsigned long long *>(amax + o);
+      pl = *reinterpret_cast<const unsigned long long *>(amin + o);
+    }
     unsigned long long packed = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -452,6 +518,10 @@ struct ApplyProblem {
   const double *sums;
   e16_t *dY;
   float *dbeta_dgamma;
+  // row plan of the stage (common.h: RowPlan; big problems only): the rows in use are the first *rows_dev, and the constant
+  // term of the BatchNorm backward is multiplied by the row's weight
+  const int *rows_dev = nullptr;
+  const unsigned char *row_w = nullptr;
 };
 // bid / nblocks: this workgroup's index and the number of workgroups of ITS problem (a pair launch runs two in one grid)
 // Streaming shape (tools/probe/copy_bw.hip on this chip: one 16-byte piece per thread over a grid that covers the tensor
@@ -462,7 +532,7 @@ struct ApplyProblem {
 // instead of four 32-byte global loads and sixteen conflicting scalar LDS reads per piece.
 typedef float st_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
-template <int U, bool NT>
+template <int U, bool NT, bool PLAN = false>
 __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, int bid, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float st_raw[];
   st_f32x4 *tab = reinterpret_cast<st_f32x4 *>(st_raw);      // [C]
@@ -482,12 +552,15 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
   const st_u32x4 *__restrict__ Y = reinterpret_cast<const st_u32x4 *>(p.Y);
   const st_u32x4 *__restrict__ dX = reinterpret_cast<const st_u32x4 *>(p.dX);
   st_u32x4 *__restrict__ dY = reinterpret_cast<st_u32x4 *>(p.dY);
-  for (long long q0 = (long long)bid * (256 * U) + threadIdx.x; q0 < p.chunks; q0 += (long long)nblocks * (256 * U)) {
+  const long long chunks = PLAN ? (long long)*p.rows_dev * cpr : p.chunks;
+  for (long long q0 = (long long)bid * (256 * U) + threadIdx.x; q0 < chunks; q0 += (long long)nblocks * (256 * U)) {
     st_u32x4 yv[U], dv[U];
+    bool on[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long q = q0 + u * 256;
-      if (q < p.chunks) {
+      on[u] = q < chunks;
+      if (on[u]) {
         yv[u] = Y[q];
         dv[u] = NT ? __builtin_nontemporal_load(dX + q) : dX[q];
       }
@@ -495,8 +568,9 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long q = q0 + u * 256;
-      if (q >= p.chunks) continue;
+      if (!on[u]) continue;
       const int c0 = (int)(q % cpr) * 8;
+      const float wr = PLAN ? (float)p.row_w[q / cpr] : 1.f;       // copies of this row in the full layout
       st_u32x4 o;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -505,16 +579,20 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
         const float d0 = e16_lo(dv[u][w]), d1 = e16_hi(dv[u][w]);
         const float z0 = __builtin_fmaf(t0[0], y0, t0[1]) > 0.f ? d0 : 0.f;
         const float z1 = __builtin_fmaf(t1[0], y1, t1[1]) > 0.f ? d1 : 0.f;
-        o[w] = pack_e16x2(__builtin_fmaf(t0[0], z0, __builtin_fmaf(t0[2], y0, t0[3])),
-                          __builtin_fmaf(t1[0], z1, __builtin_fmaf(t1[2], y1, t1[3])));
+        if (PLAN)
+          o[w] = pack_e16x2(__builtin_fmaf(t0[0], z0, wr * __builtin_fmaf(t0[2], y0, t0[3])),
+                            __builtin_fmaf(t1[0], z1, wr * __builtin_fmaf(t1[2], y1, t1[3])));
+        else
+          o[w] = pack_e16x2(__builtin_fmaf(t0[0], z0, __builtin_fmaf(t0[2], y0, t0[3])),
+                            __builtin_fmaf(t1[0], z1, __builtin_fmaf(t1[2], y1, t1[3])));
       }
       dY[q] = o;
     }
   }
 }
-template <int U, bool NT>
+template <int U, bool NT, bool PLAN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(ApplyProblem p) {
-  bn_bwd_apply_fused_body<U, NT>(p, (int)blockIdx.x, (int)gridDim.x);
+  bn_bwd_apply_fused_body<U, NT, PLAN>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // two independent problems in one grid (see gemm_bf16.hip: gemm_nt_pair_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(ApplyProblem p0, ApplyProblem p1, int n0) {
@@ -648,7 +726,11 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
                                                             const float *__restrict__ g_out,
                                                             const e16_t *__restrict__ out_pm,
                                                             const unsigned char *__restrict__ arg,
-                                                            e16_t *__restrict__ dY) {
+                                                            e16_t *__restrict__ dY,
+                                                            const int *__restrict__ goff,
+                                                            const unsigned char *__restrict__ row_w) {
+  // row plan (common.h: RowPlan): ball bm keeps the rows of its 16-row groups goff[bm] .. goff[bm + 1], and its first row
+  // gets the constant term of all the copies it stands for
   // the means S / P, T / P straight from the f64 totals (16 loads per ball and channel piece, amortised over the ball's
   // s rows: the separate f64 -> f32 means launch is gone); the items of ball 0 also publish dbeta | dgamma when asked to
   const int cpr = C >> 3;
@@ -680,16 +762,20 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
       Tv[e] *= av[e] * is[e];                                                // a * invstd * T/P
       gg[e] *= av[e];
     }
-    const e16_t *src = Y + ((size_t)bm * s) * C + c0;
-    e16_t *dst = dY + ((size_t)bm * s) * C + c0;
-    for (int t = 0; t < s; ++t) {
+    const size_t row0 = goff ? (size_t)goff[bm] * 16 : (size_t)bm * s;
+    const e16_t *src = Y + row0 * C + c0;
+    e16_t *dst = dY + row0 * C + c0;
+    const int kept = goff ? (goff[bm + 1] - goff[bm]) * 16 : s;
+    const float w0 = goff ? (float)row_w[row0] : 1.f;
+    for (int t = 0; t < kept; ++t) {
       float y[8];
       unpack8(*reinterpret_cast<const uint4 *>(src + (size_t)t * C), y);
+      const float wt = t == 0 ? w0 : 1.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         // a (dz - S/P - yhat T/P) with yhat = (y - mean) invstd
         const float dz = hit_t[e] == t ? gg[e] : 0.f;
-        y[e] = dz - Sv[e] - (y[e] - mu[e]) * Tv[e];
+        y[e] = goff ? dz - wt * (Sv[e] + (y[e] - mu[e]) * Tv[e]) : dz - Sv[e] - (y[e] - mu[e]) * Tv[e];
       }
       *reinterpret_cast<uint4 *>(dst + (size_t)t * C) = pack8(y);
     }
@@ -850,8 +936,21 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(long long P, int n, int m
 // b * n scratch counters less per call.
 constexpr int kCsrLdsMax = 8192;
 
+// Row plan (common.h: RowPlan): position p of scene b (ball bm = b m + p / s, neighbour slot t = p % s) exists in the compact row
+// space iff t < 16 (goff[bm + 1] - goff[bm]); dropped positions are copies whose gradient the ball's first row carries
+struct CsrPlan {
+  const int *goff;       // NULL: every position exists
+  int m, s;
+};
+__device__ __forceinline__ bool csr_kept(const CsrPlan &pl, int b, int p) {
+  if (!pl.goff) return true;
+  const int bm = b * pl.m + p / pl.s;
+  return p % pl.s < 16 * (pl.goff[bm + 1] - pl.goff[bm]);
+}
+
 __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, const int *__restrict__ idx,
-                                                            int *__restrict__ offsets, int *__restrict__ order) {
+                                                            int *__restrict__ offsets, int *__restrict__ order,
+                                                            CsrPlan pl) {
   __shared__ int cnt[kCsrLdsMax];
   __shared__ int wsum[16];
   __shared__ int carry;
@@ -866,7 +965,7 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, cons
   for (int p = tid; p < ms; p += U * 1024) {
     int k[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+    for (int u = 0; u < U; ++u) k[u] = (p + u * 1024 < ms && csr_kept(pl, b, p + u * 1024)) ? idx[p + u * 1024] : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (k[u] >= 0) atomicAdd(&cnt[k[u]], 1);
@@ -898,7 +997,7 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, cons
   for (int p = tid; p < ms; p += U * 1024) {
     int k[U], slot[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+    for (int u = 0; u < U; ++u) k[u] = (p + u * 1024 < ms && csr_kept(pl, b, p + u * 1024)) ? idx[p + u * 1024] : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u) slot[u] = k[u] >= 0 ? atomicAdd(&cnt[k[u]], 1) : 0;
 #pragma unroll
@@ -914,7 +1013,8 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, cons
 // 8 x 32768 entries of sa2, 55 us for the 8 x 40000 points of the ball-query grid).
 template <int G>
 __global__ __launch_bounds__(1024) void csr_build_split_kernel(int n, int ms, const int *__restrict__ idx,
-                                                              int *__restrict__ offsets, int *__restrict__ order) {
+                                                              int *__restrict__ offsets, int *__restrict__ order,
+                                                              CsrPlan pl) {
   constexpr int R = kCsrLdsMax / G;
   __shared__ int cnt[R];
   __shared__ int wsum[16];
@@ -935,7 +1035,7 @@ __global__ __launch_bounds__(1024) void csr_build_split_kernel(int n, int ms, co
   for (int p = tid; p < ms; p += U * 1024) {
     int k[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+    for (int u = 0; u < U; ++u) k[u] = (p + u * 1024 < ms && csr_kept(pl, b, p + u * 1024)) ? idx[p + u * 1024] : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       below += (k[u] >= 0 && k[u] < lo) ? 1 : 0;
@@ -972,7 +1072,7 @@ __global__ __launch_bounds__(1024) void csr_build_split_kernel(int n, int ms, co
   for (int p = tid; p < ms; p += U * 1024) {
     int k[U], slot[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) k[u] = p + u * 1024 < ms ? idx[p + u * 1024] : -1;
+    for (int u = 0; u < U; ++u) k[u] = (p + u * 1024 < ms && csr_kept(pl, b, p + u * 1024)) ? idx[p + u * 1024] : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u) slot[u] = (k[u] >= lo && k[u] < hi) ? atomicAdd(&cnt[k[u] - lo], 1) : -1;
 #pragma unroll
@@ -987,7 +1087,14 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
                                                             float inv_r, const int *__restrict__ offsets,
                                                             const int *__restrict__ order,
                                                             const e16_t *__restrict__ dX,
-                                                            float *__restrict__ dfeat, float *__restrict__ dxyz) {
+                                                            float *__restrict__ dfeat, float *__restrict__ dxyz,
+                                                            CsrPlan pl) {
+  // (row plan: position o of scene b lives in compact row 16 goff[ball] + slot)
+  auto row_of = [&](int b, int o) -> size_t {
+    if (!pl.goff) return (size_t)b * ms + o;
+    const int bm = b * pl.m + o / pl.s;
+    return (size_t)pl.goff[bm] * 16 + o % pl.s;
+  };
   const int cpr = (cin >> 3) + 1;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
     const long long bk = q / cpr;
@@ -1007,7 +1114,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
       for (int u = 0; u < 4; ++u) o[u] = ord[t + u];
       uint4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(dX + ((size_t)b * ms + o[u]) * kpad + c8 * 8);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(dX + row_of(b, o[u]) * kpad + c8 * 8);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float d[8];
@@ -1017,7 +1124,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
       }
     }
     for (; t < end; ++t) {
-      const size_t p = (size_t)b * ms + ord[t];
+      const size_t p = row_of(b, ord[t]);
       float d[8];
       unpack8(*reinterpret_cast<const uint4 *>(dX + p * kpad + c8 * 8), d);
 #pragma unroll
@@ -1098,8 +1205,13 @@ extern "C" int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, f
   if (P == 0) return OMNIPQ_OK;
   if (!xyz || !new_xyz || !idx || !X || (cin > 0 && !feat_pm)) return OMNIPQ_EINVAL;
   const long long chunks = P * (kpad / 8);
-  sa_gather_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-      chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, (e16_t *)X);
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  if (rp.rows_dev && rp.goff && rp.rows == P)       // the stage's row plan: into the compact row space
+    sa_gather_compact_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+        chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, rp.goff, (e16_t *)X);
+  else
+    sa_gather_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+        chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, (e16_t *)X);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1192,7 +1304,8 @@ extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *y
   const int grid = items == 0 ? 1 : grid_for(items);           // an empty batch still finalises the layer
   pool_select_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
       items, C, (const e16_t *)ymax, (const e16_t *)ymin, amax, amin, sums, count, gamma, beta, eps, momentum, running_mean,
-      running_var, a_out, b_out, mean_out, invstd_out, out_f32, (e16_t *)out_pm, arg, (e16_t *)ysel);
+      running_var, a_out, b_out, mean_out, invstd_out, out_f32, (e16_t *)out_pm, arg, (e16_t *)ysel,
+      omnipq::row_plan().rows_dev ? omnipq::row_plan().goff : nullptr);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1258,9 +1371,11 @@ static int pool_bwd_apply_impl(int b, int m, int s, int C, double total_position
   if (chunks == 0) return OMNIPQ_OK;
   if (!Y || !a || !mean || !invstd || !sums || !g_out || !out_pm || !arg || !dY) return OMNIPQ_EINVAL;
   const long long items = chunks / s;                   // (ball, 8-channel piece)
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  const bool planned = rp.rows_dev && rp.goff && rp.rows == (long long)b * m * s;
   pool_bwd_apply_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
       items, m, s, C, (const e16_t *)Y, a, mean, invstd, sums, 1.0 / total_positions, gb_out, g_out,
-      (const e16_t *)out_pm, arg, (e16_t *)dY);
+      (const e16_t *)out_pm, arg, (e16_t *)dY, planned ? rp.goff : nullptr, planned ? rp.row_w : nullptr);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1332,12 +1447,16 @@ extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, i
   if (!idx || !offsets || !order || !scratch) return OMNIPQ_EINVAL;
   const long long P = (long long)b * m * s;
   const int ms = m * s;
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  const bool planned = rp.rows_dev && rp.goff && rp.rows == P;
+  const omnipq::CsrPlan pl{planned ? rp.goff : nullptr, m, s};
+  if (planned && !(n <= omnipq::kCsrLdsMax && b <= 8191)) return OMNIPQ_EINVAL;      // (the LDS builders know the plan)
   if (n <= omnipq::kCsrLdsMax && b <= 8191) {
     constexpr int split = 8;
     if (split == 8 && n >= 1024 && ms >= 8192)
-      omnipq::csr_build_split_kernel<8><<<b * 8, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
+      omnipq::csr_build_split_kernel<8><<<b * 8, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order, pl);
     else
-      omnipq::csr_build_lds_kernel<<<b, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order);
+      omnipq::csr_build_lds_kernel<<<b, 1024, 0, (hipStream_t)stream>>>(n, ms, idx, offsets, order, pl);
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }
@@ -1365,8 +1484,12 @@ extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kp
   if (b == 0) return OMNIPQ_OK;
   if (!offsets || !order || !dX || (dxyz && !dnew_xyz)) return OMNIPQ_EINVAL;
   const long long items = (long long)b * n * (cin / 8 + 1);
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  const bool planned = rp.rows_dev && rp.goff && rp.rows == (long long)b * m * s;
+  if (planned && dxyz) return OMNIPQ_EINVAL;          // (the centre-gradient kernel does not know the plan)
   sa_scatter_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
-      items, n, m * s, cin, kpad, inv_radius, offsets, order, (const e16_t *)dX, dfeat_pm, dxyz);
+      items, n, m * s, cin, kpad, inv_radius, offsets, order, (const e16_t *)dX, dfeat_pm, dxyz,
+      omnipq::CsrPlan{planned ? rp.goff : nullptr, m, s});
   OMNIPQ_LAUNCH_CHECK();
   if (dnew_xyz) {
     const long long BM = (long long)b * m;
@@ -1479,7 +1602,15 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
     }
     // (measured round 3, 1 M x 128 / 262 144 x 256: 153 / 83 us = 5.3 / 4.8 TB/s on the three streams; a capped grid with a
     // grid-stride loop and plain loads are within 2 % of it -- two reads per write do not reach the 6.2 TB/s of a 1 : 1 copy)
-    bn_bwd_apply_fused_kernel<4, true><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
+    const omnipq::RowPlan &rp = omnipq::row_plan();
+    if (rp.rows_dev && rp.rows == P) {
+      omnipq::ApplyProblem pp = q.p;
+      pp.rows_dev = rp.rows_dev;
+      pp.row_w = rp.row_w;
+      bn_bwd_apply_fused_kernel<4, true, true><<<grid, 256, lds, (hipStream_t)stream>>>(pp);
+    } else {
+      bn_bwd_apply_fused_kernel<4, true><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
+    }
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;
   }

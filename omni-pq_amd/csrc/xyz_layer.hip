@@ -15,24 +15,30 @@ namespace omnipq {
 
 
 // mom[0..2] = S1, mom[3..11] = M2 (row major), f64, added to (zero on entry)
+// rows_dev / row_w: the stage's row plan (common.h: RowPlan) or NULL -- the rows in use and how many rows of the full layout
+// each stands for (the moments are sums over the FULL layout)
 __global__ __launch_bounds__(256) void xyz_moments_kernel(long long P, int ldx, const e16_t *__restrict__ X0,
-                                                          double *__restrict__ mom) {
+                                                          double *__restrict__ mom, const int *__restrict__ rows_dev,
+                                                          const unsigned char *__restrict__ row_w) {
   __shared__ float red[4][9];
   float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // x y z xx xy xz yy yz zz
+  if (rows_dev) P = *rows_dev;
 #pragma unroll 4
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
     const uint2 v = *reinterpret_cast<const uint2 *>(X0 + (size_t)p * ldx);
     const float x = e16_lo(v.x), y = e16_hi(v.x);
     const float z = e16_lo(v.y);
-    s[0] += x;
-    s[1] += y;
-    s[2] += z;
-    s[3] = __builtin_fmaf(x, x, s[3]);
-    s[4] = __builtin_fmaf(x, y, s[4]);
-    s[5] = __builtin_fmaf(x, z, s[5]);
-    s[6] = __builtin_fmaf(y, y, s[6]);
-    s[7] = __builtin_fmaf(y, z, s[7]);
-    s[8] = __builtin_fmaf(z, z, s[8]);
+    const float w = row_w ? (float)row_w[p] : 1.f;
+    const float wx = w * x, wy = w * y, wz = w * z;
+    s[0] += wx;
+    s[1] += wy;
+    s[2] += wz;
+    s[3] = __builtin_fmaf(wx, x, s[3]);
+    s[4] = __builtin_fmaf(wx, y, s[4]);
+    s[5] = __builtin_fmaf(wx, z, s[5]);
+    s[6] = __builtin_fmaf(wy, y, s[6]);
+    s[7] = __builtin_fmaf(wy, z, s[7]);
+    s[8] = __builtin_fmaf(wz, z, s[8]);
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -110,7 +116,11 @@ extern "C" int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, doubl
   // (1 M positions); 256 blocks of 16 positions per thread stream the 16 MB in ~10
   long long blocks = (P + 255) / 256;
   if (blocks > 256) blocks = 256;
-  xyz_moments_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(P, ldx, (const e16_t *)X0, mom);
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  const bool planned = rp.rows_dev && rp.rows == P;
+  xyz_moments_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(P, ldx, (const e16_t *)X0, mom,
+                                                                      planned ? rp.rows_dev : nullptr,
+                                                                      planned ? rp.row_w : nullptr);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -260,6 +260,68 @@ strip_uses = 0
 _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 
 
+# Row plan (csrc/common.h: RowPlan, include/omnipq_sa.h: omnipq_sa_ball_plan).  ball_query pads a ball that holds fewer than
+# nsample points with copies of its first neighbour (ball_query_gpu.cu:36-45; pointnet2_utils.py:317-376 groups them like any
+# other index), so the shared MLP of the reference runs on duplicate rows: on the benchmark's 40 000-point room scenes a ball
+# of sa1 (radius 0.2, nsample 64) holds 27 real neighbours on average and a ball of sa2 (0.4, 32) seven (tools/ball_fill.py).
+# A planned stage keeps, per ball, its first 16 * ceil(real neighbours / 16) rows, packs the balls' rows back to back
+# (COMPACT row space) and runs every kernel on that: 54 % of sa1's rows on those scenes.  The number of rows in use is
+# data-dependent, so it lives in device memory and the launches keep the static grids of the full row count -- workgroups
+# past it leave at once -- which keeps the step capturable into a hipGraph.  The dropped rows are accounted for exactly: they
+# are copies of their ball's first row, so BatchNorm statistics weight that row by 1 + dropped copies, the max-pool is
+# unchanged (a copy never beats the first row under the first-row tie rule), and in backward every copy contributes the
+# constant term -a (m1 + yhat m2) of the BatchNorm backward once, i.e. (1 + copies) times on the first row; everything
+# downstream (data gradients, weight gradients, BatchNorm-backward sums) is linear in those rows.  Results equal the full
+# computation up to the order of the f32 sums (tests/test_gpu_fused_sa.py::test_row_plan_equals_the_full_stage).
+# ROW_PLAN = False: every row is computed.
+ROW_PLAN = True
+row_plan_uses = 0
+_lib.omnipq_sa_row_plan.restype = None
+
+
+def row_plan_ok(training, S, P, L, needs_input_grad, pooled):
+    """at least two 16-row groups per ball, the partial-sum kernel paths (many rows), the dataflow without stored activations
+    and with the ball extrema in the last GEMM (the kernels that know the plan), no gradient into the stage's coordinates (the
+    centre-gradient kernel does not know it; feature gradients: the caller also asks for at most 8192 source points, the CSR
+    builders that do)"""
+    return ROW_PLAN and training and S % 16 == 0 and 32 <= S <= 128 and P >= (1 << 18) and P % 128 == 0 and L >= 2 and \
+        AFFINE_OPERANDS and POOL_EPILOGUE and _FOLD_SMALL and pooled and not needs_input_grad
+
+
+class _Plan:
+    __slots__ = ("goff", "rows_dev", "row_w", "scratch")
+
+
+def make_row_plan(idx, P):
+    """idx (B, M, S) int32 -> the stage's _Plan (three tiny launches)"""
+    B, M, S = idx.shape
+    dev = idx.device
+    plan = _Plan()
+    plan.goff = torch.empty((B * M + 1,), device=dev, dtype=torch.int32)
+    plan.rows_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+    plan.row_w = torch.empty((P,), device=dev, dtype=torch.uint8)
+    plan.scratch = torch.empty((B * M,), device=dev, dtype=torch.int32)
+    _call(_lib.omnipq_sa_ball_plan, idx, ctypes.c_longlong(B * M), S, _p(idx), _p(plan.goff), _p(plan.rows_dev),
+          _p(plan.row_w), _p(plan.scratch))
+    return plan
+
+
+class _row_plan:
+    """Make `plan` the calling thread's row plan for the launches inside the block."""
+
+    def __init__(self, plan, rows):
+        self.plan, self.rows = plan, rows
+
+    def __enter__(self):
+        if self.plan is not None:
+            _lib.omnipq_sa_row_plan(_p(self.plan.rows_dev), _p(self.plan.row_w), _p(self.plan.goff),
+                                    ctypes.c_longlong(self.rows))
+
+    def __exit__(self, *exc):
+        if self.plan is not None:
+            _lib.omnipq_sa_row_plan(_p(None), _p(None), _p(None), ctypes.c_longlong(0))
+
+
 def strip_pays(M, N, K, with_pool):
     if not STRIP_GEMM:
         return False
@@ -371,7 +433,8 @@ class _TnProblem(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
                 ("out_rows", ctypes.c_int), ("out_cols", ctypes.c_int), ("out_ld", ctypes.c_int),
-                ("flags", ctypes.c_int), ("rot", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p)]
+                ("flags", ctypes.c_int), ("rot", ctypes.c_int), ("ba", ctypes.c_void_p), ("bb", ctypes.c_void_p),
+                ("rows_dev", ctypes.c_void_p)]
 
 
 _lib.omnipq_gemm_tn_grouped_workspace_floats.restype = ctypes.c_longlong
@@ -547,7 +610,7 @@ class deferred_wgrads:
     def __enter__(self):
         if deferred_wgrads.active is not None:
             raise RuntimeError("deferred_wgrads blocks do not nest")
-        self.items = []             # (dY, X, M, N, P, weight target, (cout, cin[, rot]), bias target | None, affine | None)
+        self.items = []             # (dY, X, M, N, P, weight target, (cout, cin[, rot]), bias target | None, affine | None, row plan | None)
         self.sa_items = []          # the same for the SA stages' layers: a grouped launch of their own (see add_sa)
         self.ln_items = []          # (partials [blocks][2C], blocks, C, gamma, beta): LayerNorm parameter gradients
         deferred_wgrads.active = self
@@ -560,15 +623,16 @@ class deferred_wgrads:
     def add(self, dY, X, M, N, P, wt, crop, bt, below=None):
         """below: X is that layer's pre-BN output and stands for relu(below.a * X + below.b)"""
         _refuse_ddp(wt)
-        self.items.append((dY, X, M, N, P, wt, crop, bt, None if below is None else (below.a, below.b)))
+        self.items.append((dY, X, M, N, P, wt, crop, bt, None if below is None else (below.a, below.b), None))
 
-    def add_sa(self, dY, X, M, N, P, wt, crop, below=None):
+    def add_sa(self, dY, X, M, N, P, wt, crop, below=None, blk=None):
         """A layer of a fused SA stage (up to a million positions): collected apart from the per-point layers and run
         as ONE grouped launch for all stages when the block ends.  One by one these GEMMs are split into ~512
         workgroups each -- two per CU, the launch's tail and its slab reduction paid 14 times per step; together
         they fill the chip with ~4000 workgroups cut for balance.  crop = (cout, cin, rot): see omnipq_tn_problem."""
         _refuse_ddp(wt)
-        self.sa_items.append((dY, X, M, N, P, wt, crop, None, None if below is None else (below.a, below.b)))
+        # blk: the stage's row plan (_Plan: the positions in use live in device memory), or None
+        self.sa_items.append((dY, X, M, N, P, wt, crop, None, None if below is None else (below.a, below.b), blk))
 
     def __exit__(self, et, ev, tb):
         deferred_wgrads.active = None
@@ -653,7 +717,7 @@ class deferred_wgrads:
         # which packed weights are covered completely by the row ranges collected (q | k,v of a cross-attention):
         # those buffers need no clearing
         covered = {}
-        for (_, _, _, _, _, wt, crop, _, _) in items:
+        for (_, _, _, _, _, wt, crop, _, _, _) in items:
             cout, cin = crop[0], crop[1]
             if wt[0] == "param":
                 covered.setdefault(id(wt[1]), {})[wt[2]] = cout * cin
@@ -675,9 +739,10 @@ class deferred_wgrads:
             return ent
 
         probs = (_TnProblem * len(items))()
-        for i, (dY, X, M, N, P, wt, crop, bt, aff) in enumerate(items):
+        for i, (dY, X, M, N, P, wt, crop, bt, aff, blk) in enumerate(items):
             cout, cin = crop[0], crop[1]
             q = probs[i]
+            q.rows_dev = 0 if blk is None else blk.rows_dev.data_ptr()
             q.rot = crop[2] if len(crop) > 2 else 0
             q.A, q.B = dY.data_ptr(), X.data_ptr()
             q.ba, q.bb = (0, 0) if aff is None else (aff[0].data_ptr(), aff[1].data_ptr())
@@ -1048,12 +1113,28 @@ class FusedSAStage(torch.autograd.Function):
         if xgen:
             global xyzgen_uses
             xyzgen_uses += 1
+        plan = None
+        xyz_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        feat_grad = features is not None and ctx.needs_input_grad[2]
+        if row_plan_ok(training, S, P, L, xyz_grad or (feat_grad and N > 8192), 128 % S == 0):
+            global row_plan_uses
+            row_plan_uses += 1
+            plan = make_row_plan(idx, P)
+        ctx.plan = plan
         X = torch.empty((P, xpad), device=dev, dtype=E16.dtype)
-        _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, xpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
-              _p(idx), _p(feat_pm), _p(X))
+        with _row_plan(plan, P):
+            # (with a plan: the gather writes the compact row space, every launch below works on the rows in use)
+            _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, xpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
+                  _p(idx), _p(feat_pm), _p(X))
+            X0 = X
+            layers, pool, X = FusedSAStage._forward_layers(ctx, params, bn_cfg, L, X, X0, P, B, M, S, cin, cin_raw, kpad,
+                                                           training, xgen, xpad, world, dev)
+            return FusedSAStage._forward_tail(ctx, layers, pool, X0, xgen, params, L, training, cin_raw, B, N, M, S, P, cin,
+                                              kpad, inv_r, world, idx, features, dev)
 
+    @staticmethod
+    def _forward_layers(ctx, params, bn_cfg, L, X, X0, P, B, M, S, cin, cin_raw, kpad, training, xgen, xpad, world, dev):
         layers = []
-        X0 = X
         pool = None
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
@@ -1076,9 +1157,12 @@ class FusedSAStage(torch.autograd.Function):
                 pool = None
                 if l == L - 1 and POOL_EPILOGUE and 128 % S == 0 and (X is not None or layers[l - 1].fin is not None):
                     # the last layer's GEMM also records every ball's extrema: the pooling pass below needs no Y
-                    ext16 = torch.empty((2, B * M, cout), device=dev, dtype=E16.dtype)
-                    ext8 = torch.empty((2, B * M, cout), device=dev, dtype=torch.uint8)
-                    pool = (S, ext16[0], ext16[1], ext8[0], ext8[1])
+                    # (a planned stage records them per 16-row group of the compact row space; pool_select merges a ball's)
+                    planned = getattr(ctx, "plan", None) is not None
+                    slots = P // 16 if planned else B * M
+                    ext16 = torch.empty((2, slots, cout), device=dev, dtype=E16.dtype)
+                    ext8 = torch.empty((2, slots, cout), device=dev, dtype=torch.uint8)
+                    pool = (16 if planned else S, ext16[0], ext16[1], ext8[0], ext8[1])
                 if xgen and l == 0:
                     # never materialised (see XYZGEN): statistics from the moments of the grouped coordinates
                     lay.mom = torch.empty((12,), device=dev, dtype=torch.float64)
@@ -1134,7 +1218,11 @@ class FusedSAStage(torch.autograd.Function):
             else:
                 lay.X = None
             layers.append(lay)
+        return layers, pool, X
 
+    @staticmethod
+    def _forward_tail(ctx, layers, pool, X0, xgen, params, L, training, cin_raw, B, N, M, S, P, cin, kpad, inv_r, world, idx,
+                      features, dev):
         last = layers[-1]
         out_f32 = torch.empty((B, M, last.C), device=dev, dtype=torch.float32)
         out_pm = torch.empty((B * M, last.C), device=dev, dtype=E16.dtype)
@@ -1182,7 +1270,7 @@ class FusedSAStage(torch.autograd.Function):
         E16.select(ctx.e16)
         if g_out is None:                       # the stage's output took no part in the loss
             return (None,) * ctx.n_inputs
-        with _tagged("@sa"):
+        with _tagged("@sa"), _row_plan(getattr(ctx, "plan", None), ctx.geom[4]):
             return FusedSAStage._backward(ctx, g_out)
 
     @staticmethod
@@ -1258,10 +1346,11 @@ class FusedSAStage(torch.autograd.Function):
             wt = ctx.wtargets[l] if (dfr is not None and SA_WGRADS_GROUPED) else None
             if wt is not None and ctx.needs_input_grad[9 + 3 * l]:
                 # collected: one grouped launch for the layers of ALL SA stages when the deferred_wgrads block ends
+                blk = ctx.plan if getattr(ctx, "plan", None) is not None else None
                 if l == 0:
-                    dfr.add_sa(dY, Xin, lay.C, lay.K, P, wt, (lay.C, ctx.cin_raw + 3, 3 | (cin << 8)))
+                    dfr.add_sa(dY, Xin, lay.C, lay.K, P, wt, (lay.C, ctx.cin_raw + 3, 3 | (cin << 8)), blk=blk)
                 else:
-                    dfr.add_sa(dY, Xin, lay.C, lay.K, P, wt, (lay.C, lay.K), below)
+                    dfr.add_sa(dY, Xin, lay.C, lay.K, P, wt, (lay.C, lay.K), below, blk=blk)
             else:
                 dWp = _gemm_tn(dY, Xin, lay.C, lay.K, P, below=below)      # [Cout][K]
                 wk = cin + 3 if l == 0 else lay.K

@@ -889,3 +889,72 @@ def test_build_csr_groups_every_position_under_its_source_point(B, n, m, s):
         assert torch.equal(torch.sort(o).values, torch.arange(m * s, device=dev()))
         key_of_slot = torch.searchsorted(want[b, 1:].contiguous(), torch.arange(m * s, device=dev()), right=True)
         assert torch.equal(flat[b][o], key_of_slot)
+
+
+@pytest.mark.parametrize("case", ["coordinates_only", "six_extra_channels", "deferred_grouped", "sa2_feature_gradient"])
+def test_row_plan_equals_the_full_stage(case, monkeypatch):
+    """sa_fused.ROW_PLAN: for nsample == 64 the second 32-row block of every ball with at most 32 real neighbours holds copies of
+    the ball's first row (ball_query pads with the first neighbour) and is skipped by every kernel of the stage; the copies are
+    accounted for by row weights.  The stage must give what the full computation gives -- same pooled arg-max rows, outputs and
+    gradients equal up to the order of the f32 sums (statistics: weighted instead of repeated rows) and the bf16 roundings
+    that order can flip -- on the backbone's sa1 at the benchmark's per-scene size, with the coordinate-generated first layer,
+    with extra input channels (BASELINE configs[3]: no gradient into the raw features), and through the deferred grouped
+    weight-gradient launch."""
+    import pointnet2_modules
+    import sa_fused
+    cin = 6 if case == "six_extra_channels" else 0
+    spec = dict(npoint=2048, radius=0.2, nsample=64, mlp=[cin, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+    B, n = 2, 40000
+    if case == "sa2_feature_gradient":
+        # the backbone's sa2 (nsample 32: two 16-row groups per ball at most) with a gradient into its input features: the
+        # data-gradient GEMM of the first layer and the CSR scatter run on the compact rows too
+        cin, B, n = 256, 8, 2048
+        spec = dict(npoint=1024, radius=0.4, nsample=32, mlp=[cin, 256, 256, 512], use_xyz=True, normalize_xyz=True)
+    xyz = synth.make_clouds(77, B, n, kind="room").to(dev())
+    feats = procedural_tensor("plan.feats", (B, cin, n), torch.float32).to(dev()) if cin else None
+    if case == "sa2_feature_gradient":
+        feats = (feats * 0.5).requires_grad_(True)
+    monkeypatch.setenv("OMNIPQ_SA", "fused")
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(sa_fused, "ROW_PLAN", on)
+        mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
+            mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}), 3).to(dev()).train()
+        uses = sa_fused.row_plan_uses
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            _, out, inds = mod(xyz, feats)
+        assert (sa_fused.row_plan_uses > uses) == on
+        g_up = procedural_tensor("plan.g_up", tuple(out.shape), torch.float32).to(dev())
+        if feats is not None and feats.requires_grad:
+            feats.grad = None
+        if case == "deferred_grouped":
+            with sa_fused.deferred_wgrads():
+                out.backward(g_up)
+        else:
+            out.backward(g_up)
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in mod.named_parameters()}
+        if feats is not None and feats.requires_grad:
+            grads["features"] = feats.grad.detach().clone()
+        res[on] = (out.detach().clone(), inds.clone(), grads,
+                   {k: b.detach().clone() for k, b in mod.named_buffers() if b.is_floating_point()})
+    full, plan = res[False], res[True]
+    assert torch.equal(full[1], plan[1])
+    e_out = rel_l2(plan[0], full[0])
+    print(f"\n{case}: output rel-L2 plan vs full {e_out:.2e}")
+    assert e_out < 3e-3, e_out
+    for k in full[2]:
+        e = rel_l2(plan[2][k], full[2][k])
+        print(f"  grad {k:40s} rel-L2 {e:.2e}")
+        # two runs of the FULL stage differ by up to ~5e-3 on a weight gradient (order of the f32 sums, flipped bf16 roundings)
+        assert e < 2e-2, (k, e)
+    for k in full[3]:
+        assert rel_l2(plan[3][k], full[3][k]) < 1e-4, k       # running statistics: weighted sums == repeated rows
+    # the plan did drop something on this cloud: most balls are far from full
+    idx = pointnet2_modules.pointnet2_utils.ball_query(spec["radius"], spec["nsample"], xyz,
+                                                       pointnet2_modules.pointnet2_utils.gather_operation(
+        xyz.transpose(1, 2).contiguous(), full[1]).transpose(1, 2).contiguous())
+    cnt = 1 + (idx[..., 1:] != idx[..., :1]).sum(-1)
+    kept = ((cnt + 15) // 16 * 16).float().mean() / spec["nsample"]
+    print(f"  rows kept: {float(kept):.3f} of the full layout")
+    assert 0.2 < float(kept) < 0.9
