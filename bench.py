@@ -912,6 +912,15 @@ def main():
                                # marker kernels of the 16 SA spans, median over the traced replays), read from profiles/
                                "replayed_step": replay_rec,
                                "largest_kernel": dominant}
+            # row plan (sa_fused.ROW_PLAN): the share of the grouped rows the planned stages computed on the last step's
+            # scenes -- the rest are the copies ball_query's padding creates; data-dependent, so it is reported
+            if sa_fused.row_plan_last:
+                rec["roofline"]["row_plan"] = {
+                    "group_rows": sa_fused.PLAN_GROUP,
+                    "rows_in_use_frac": {str(P): round(int(pl.rows_dev.item()) / P, 4)
+                                         for P, pl in sorted(sa_fused.row_plan_last.items())},
+                    "note": "planned SA stages run on the rows up to each ball's last real neighbour (in whole groups); "
+                            "keys = grouped rows of the stage's full layout (batch x npoint x nsample)"}
             if replay_rec is not None:
                 replay_rec["frac"] = sa_bytes / (replay_rec["sa_kernel_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             sa_pmc, sa_file = pmc_traffic("sa_stage")

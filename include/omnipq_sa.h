@@ -166,18 +166,19 @@ int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void 
 
 /* Row plan of a stage whose balls hold duplicate rows (csrc/common.h: RowPlan).  ball_query pads a ball with copies of its
  * first neighbour, so the grouped rows behind the real neighbours duplicate the ball's row 0.  omnipq_sa_ball_plan derives
- * the COMPACT row space of a stage from its ball-query indices idx (int32 [balls][nsample], nsample % 16 == 0): ball b keeps
- * its first 16 * g_b rows, g_b = ceil(real neighbours / 16); goff (int32 [balls + 1]) = first 16-row group of every ball,
- * rows_dev (int32 [1], device) = 16 * goff[balls] rows in use, row_w (uint8 per compact row) = how many rows of the full
- * layout the row stands for (1 + dropped copies on a ball's first row, else 1); scratch = int32 [balls].
- * omnipq_sa_row_plan(rows_dev, row_w, goff, rows) makes a plan current for the CALLING THREAD: the stage's kernels launched
+ * the COMPACT row space of a stage from its ball-query indices idx (int32 [balls][nsample], nsample 16, 32, 64 or 128) in
+ * groups of gs = 8 or 16 rows: ball b keeps its first gs * g_b rows, g_b = ceil(real neighbours / gs); goff (int32
+ * [balls + 1]) = first group of every ball, rows_dev (int32 [1], device) = gs * goff[balls] rows in use, row_w (uint8 per
+ * compact row) = how many rows of the full layout the row stands for (1 + dropped copies on a ball's first row, else 1);
+ * scratch = int32 [balls].  The ball extrema of a planned stage are recorded per group (s = gs in the ..._pool entry points).
+ * omnipq_sa_row_plan(rows_dev, row_w, goff, rows, gs) makes a plan current for the CALLING THREAD: the stage's kernels launched
  * with exactly `rows` rows (the full count: grids stay static, graph-capturable) work on *rows_dev rows -- workgroups past
  * them leave at once --, weight the BatchNorm statistics and the constant backward terms by row_w, and the ball-structured
  * ones (omnipq_sa_gather, omnipq_sa_pool_select_finalize, omnipq_sa_pool_bwd_apply) address balls through goff.
  * rows_dev == NULL clears it.  Results equal the full computation up to the order of the f32 sums. */
-int omnipq_sa_ball_plan(long long balls, int nsample, const int *idx, int *goff, int *rows_dev, void *row_w, int *scratch,
-                        void *stream);
-void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows);
+int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
+                        int *scratch, void *stream);
+void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows, int gs);
 
 /* Row-strip GEMMs (csrc/gemm_strip.hip): the same contraction C = f(A) B^T as the omnipq_gemm_nt_e16* family for the
  * shared-MLP layers of a set-abstraction stage (pytorch_utils.py:11-36), with a workgroup owning 128 rows and ALL N

@@ -58,21 +58,26 @@ static thread_local omnipq::RowPlan t_row_plan;
 namespace omnipq {
 RowPlan &row_plan() { return t_row_plan; }
 
-// one thread per ball: real neighbours = 1 + #{t > 0: idx[t] != idx[0]} (the real ones are distinct points in increasing
-// index order, the padding repeats idx[0]) -> groups of 16 rows the ball keeps
-__global__ __launch_bounds__(256) void sa_plan_count_kernel(long long balls, int s, const int *__restrict__ idx,
+// real neighbours of a ball = 1 + #{t > 0: idx[t] != idx[0]} (the real ones are distinct points in increasing index order, the
+// padding repeats idx[0]) -> groups of `gs` rows the ball keeps.  s / 4 lanes per ball (s in {16, 32, 64, 128}), 16 bytes each:
+// the whole index tensor is read in full lines (one thread per ball walked its 256-byte row alone: 38 us for sa1's 4 MB).
+__global__ __launch_bounds__(256) void sa_plan_count_kernel(long long balls, int s, int gs, const int *__restrict__ idx,
                                                            int *__restrict__ gcount) {
-  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (b >= balls) return;
-  const int *row = idx + b * s;
-  const int first = row[0];
-  int cnt = 1;
-  for (int t = 1; t < s; ++t) cnt += row[t] != first;
-  gcount[b] = (cnt + 15) >> 4;
+  const int lpb = s >> 2;                                   // lanes per ball
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long b = q / lpb;
+  const int l = (int)(q - b * lpb);
+  int4 v = make_int4(0, 0, 0, 0);
+  if (b < balls) v = *reinterpret_cast<const int4 *>(idx + b * s + 4 * l);
+  const int lane = (int)threadIdx.x & 63;
+  const int first = __shfl(v.x, lane - l, 64);            // element 0 of this lane's ball
+  int cnt = (v.x != first) + (v.y != first) + (v.z != first) + (v.w != first);
+  for (int d = 1; d < lpb; d <<= 1) cnt += __shfl_xor(cnt, d, 64);
+  if (b < balls && l == 0) gcount[b] = (cnt + gs) / gs;   // ceil((cnt + 1) / gs)
 }
 
-// exclusive scan of the group counts (one workgroup: up to a few 10^4 balls), rows in use = 16 * total
-__global__ __launch_bounds__(1024) void sa_plan_scan_kernel(int balls, const int *__restrict__ gcount, int *__restrict__ goff,
+// exclusive scan of the group counts (one workgroup: up to a few 10^4 balls), rows in use = gs * total
+__global__ __launch_bounds__(1024) void sa_plan_scan_kernel(int balls, int gs, const int *__restrict__ gcount, int *__restrict__ goff,
                                                            int *__restrict__ rows_dev) {
   __shared__ int s_part[1024];
   const int tid = (int)threadIdx.x;
@@ -96,47 +101,51 @@ __global__ __launch_bounds__(1024) void sa_plan_scan_kernel(int balls, const int
     }
   if (tid == 1023) {
     goff[balls] = s_part[1023];
-    rows_dev[0] = 16 * s_part[1023];
+    rows_dev[0] = gs * s_part[1023];
   }
 }
 
-// one thread per (ball, 16-row group): the group's weights; a ball's first row stands for itself and the dropped copies
-__global__ __launch_bounds__(256) void sa_plan_weights_kernel(long long balls, int s, const int *__restrict__ goff,
+// one thread per (ball, 8 rows): their weights; a ball's first row stands for itself and the dropped copies
+__global__ __launch_bounds__(256) void sa_plan_weights_kernel(long long balls, int s, int gs, const int *__restrict__ goff,
                                                              unsigned char *__restrict__ row_w) {
   const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int gmax = s >> 4;
-  const long long b = q / gmax;
-  const int g = (int)(q - b * gmax);
+  const int omax = s >> 3;
+  const long long b = q / omax;
+  const int o = (int)(q - b * omax);                        // octet of the ball's rows
   if (b >= balls) return;
-  const int g0 = goff[b], n = goff[b + 1] - g0;
-  if (g >= n) return;
-  uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-  *reinterpret_cast<uint4 *>(row_w + (size_t)(g0 + g) * 16) = ones;
-  if (g == 0) row_w[(size_t)g0 * 16] = (unsigned char)(1 + s - 16 * n);
+  const int g0 = goff[b], kept = (goff[b + 1] - g0) * gs;
+  if (o * 8 >= kept) return;
+  uint2 ones = make_uint2(0x01010101u, 0x01010101u);
+  if (o == 0) ones.x += (unsigned)(s - kept);               // byte 0: 1 + dropped copies (<= 1 + 128 - 8)
+  *reinterpret_cast<uint2 *>(row_w + (size_t)g0 * gs + o * 8) = ones;
 }
 }  // namespace omnipq
 
-extern "C" void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows) {
+extern "C" void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows, int gs) {
   t_row_plan.rows_dev = rows_dev;
   t_row_plan.row_w = (const unsigned char *)row_w;
   t_row_plan.goff = goff;
   t_row_plan.rows = rows_dev ? rows : 0;
+  t_row_plan.gs = gs == 8 ? 8 : 16;
 }
 
-// Plan of a stage from its ball-query indices idx (int32 [balls][nsample], nsample a multiple of 16, <= 240): goff (int32
-// [balls + 1]), rows_dev (int32 [1]), row_w (uint8 [balls * nsample]: valid for the rows in use), scratch (int32 [balls]).
-extern "C" int omnipq_sa_ball_plan(long long balls, int nsample, const int *idx, int *goff, int *rows_dev, void *row_w,
+// Plan of a stage from its ball-query indices idx (int32 [balls][nsample], nsample 16, 32, 64 or 128) in groups of gs = 8 or
+// 16 rows: goff (int32 [balls + 1]), rows_dev (int32 [1]), row_w (uint8 [balls * nsample]: valid for the rows in use), scratch
+// (int32 [balls]).
+extern "C" int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
                                    int *scratch, void *stream) {
-  if (balls < 0 || balls > (1 << 22) || nsample <= 0 || (nsample % 16) || nsample > 240) return OMNIPQ_EINVAL;
+  if (balls < 0 || balls > (1 << 22) || (gs != 8 && gs != 16)) return OMNIPQ_EINVAL;
+  if (nsample != 16 && nsample != 32 && nsample != 64 && nsample != 128) return OMNIPQ_EINVAL;
   if (balls == 0) return OMNIPQ_OK;
   if (!idx || !goff || !rows_dev || !row_w || !scratch) return OMNIPQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  omnipq::sa_plan_count_kernel<<<(unsigned)((balls + 255) / 256), 256, 0, st>>>(balls, nsample, idx, scratch);
+  const long long lanes = balls * (nsample >> 2);
+  omnipq::sa_plan_count_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, st>>>(balls, nsample, gs, idx, scratch);
   OMNIPQ_LAUNCH_CHECK();
-  omnipq::sa_plan_scan_kernel<<<1, 1024, 0, st>>>((int)balls, scratch, goff, rows_dev);
+  omnipq::sa_plan_scan_kernel<<<1, 1024, 0, st>>>((int)balls, gs, scratch, goff, rows_dev);
   OMNIPQ_LAUNCH_CHECK();
-  const long long items = balls * (nsample >> 4);
-  omnipq::sa_plan_weights_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(balls, nsample, goff,
+  const long long items = balls * (nsample >> 3);
+  omnipq::sa_plan_weights_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(balls, nsample, gs, goff,
                                                                                  (unsigned char *)row_w);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;

@@ -170,7 +170,8 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // Row plan of a set-abstraction stage (include/omnipq_sa.h: omnipq_sa_row_plan): ball_query pads a ball that holds fewer than
 // nsample points with copies of its FIRST neighbour (ball_query_gpu.cu:36-45), so the grouped rows behind the real
 // neighbours are duplicates of the ball's row 0 and every per-row result computed from them is a duplicate too.  A planned
-// stage runs on a COMPACT row space: ball b keeps its first 16 * g_b rows (g_b = ceil(real neighbours / 16) groups of 16),
+// stage runs on a COMPACT row space: ball b keeps its first gs * g_b rows (g_b = ceil(real neighbours / gs) groups of gs = 8 or
+// 16 rows: 8 is the finest unit the accumulator layout of the extrema epilogue holds in one register quad across a wave),
 // the balls' groups are laid out back to back (goff = exclusive scan of g_b, in groups), and the number of rows in use lives
 // in device memory (`rows_dev`): launches keep their static grids for the full row count `rows`, workgroups past *rows_dev
 // leave at once.  The dropped rows are accounted for through `row_w` (one byte per compact row: how many rows of the full
@@ -178,9 +179,10 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // w * y^2, and the constant term of the BatchNorm backward, which every copy contributes once, is multiplied by w; everything
 // else downstream is linear in the rows.  Thread-local; applies to launches whose row count equals `rows`.
 struct RowPlan {
-  const int *rows_dev = nullptr;                 // device: rows in use (a multiple of 16)
+  const int *rows_dev = nullptr;                 // device: rows in use (a multiple of gs)
   const unsigned char *row_w = nullptr;          // [rows]
-  const int *goff = nullptr;                     // [balls + 1]: first 16-row group of every ball
+  const int *goff = nullptr;                     // [balls + 1]: first group of every ball
+  int gs = 16;                                   // rows per group: 8 or 16
   long long rows = 0;                            // the static row count the stage's launches are issued with
 };
 RowPlan &row_plan();                            // capi.hip; thread-local

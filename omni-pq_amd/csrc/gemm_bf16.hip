@@ -638,7 +638,45 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
       }
     }
     NT_STAMP(5);
-    if ((STATS == 1 || STATS == 2) && T == 128 && !bias && (pool.s == 16 || pool.s == 32 || pool.s == 64)) {
+    if (PLAN && (STATS == 1 || STATS == 2) && T == 128 && !bias && pool.s == 8) {
+      // Groups of 8 rows (the finest unit of a row plan, common.h: RowPlan): rows 0-3 of a group are one register quad of the
+      // lower lane half, rows 4-7 the same quad of the upper half.  Same keys as below, emitted group by group.
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      const unsigned hbit = (unsigned)crow0;
+      const bool upper = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int q8 = 0; q8 < 4; ++q8) {
+            unsigned mx = 0u, mn = 0xffffffffu;
+#pragma unroll
+            for (int r = 4 * q8; r < 4 * q8 + 4; r += 2) {
+              const unsigned pw = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
+              const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, pw) >> 15);
+              const unsigned o = pw ^ (sg | 0x80008000u);
+              const unsigned row = (unsigned)(r & 3);
+              const unsigned olo = o << 16, ohi = o & 0xffff0000u;
+              mx = max(max(mx, olo | (7u - row)), ohi | (6u - row));
+              mn = min(min(mn, olo | row), ohi | (row + 1u));
+            }
+            unsigned a = mx ^ hbit, b = mn | hbit;                 // 7 - (row + 4 h) | row + 4 h
+            a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
+            b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
+            const unsigned key = upper ? b : a;
+            const unsigned o = key >> 16;
+            const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
+            const unsigned low = key & 7u;
+            const unsigned char row = (unsigned char)(upper ? low : 7u - low);
+            const int r0 = wm * (T / 2) + i * 32 + q8 * 8, gc = n0 + wn * (T / 2) + j * 32 + ccol;
+            if (m0 + r0 < g.M && gc < g.N) {
+              const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
+              (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
+              (upper ? pool.amin : pool.amax)[oidx] = row;
+            }
+          }
+    } else if ((STATS == 1 || STATS == 2) && T == 128 && !bias && (pool.s == 16 || pool.s == 32 || pool.s == 64)) {
       // Ball extrema from the accumulators (no LDS read, no serial walk over the ball).  A lane holds 32 rows of each of
       // its two columns.  Two rows of one column are rounded together (the pair word equals what the C tile holds), the
       // two bf16 are mapped to order-preserving unsigned 16-bit values (negative: all bits flipped, else the sign bit

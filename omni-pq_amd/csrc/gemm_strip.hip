@@ -48,7 +48,7 @@ struct StripAffine {
 };
 
 struct StripPool {
-  int s;                          // rows per ball (16, 32 or 64); 0: none
+  int s;                          // rows per ball (16, 32 or 64; 8: the groups of a row plan); 0: none
   e16_t *ymax, *ymin;             // [M / s][N]
   unsigned char *amax, *amin;     // [M / s][N]
 };
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
   };
   const int patch_stores = 8;                                        // C stores of one patch (exact when `full`)
   // memory instructions of one epilogue (statistics and ball-extrema stores), exact when `full`
-  const int epi_ops = (STATS ? 4 : 0) + (POOL ? (16 / (pool.s >> 4)) : 0);
+  const int epi_ops = (STATS ? 4 : 0) + (POOL ? 256 / pool.s : 0);      // (value, row) x groups of 64 rows x 2 column blocks
 
   for (int nt = 0; nt < g.n_tiles; ++nt) {
     sf32x16 acc[2][2];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const unsigned hbit = (unsigned)crow0;
     const int s_ = POOL ? pool.s : 16;
-    const int gstep = s_ >> 4;
+    const int gstep = s_ >> 4;                                        // (0 for groups of 8 rows: emitted quad by quad)
     const bool upper = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -398,6 +398,38 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
             kmx[2 * i + gq] = mx ^ hbit;
             kmn[2 * i + gq] = mn | hbit;
           }
+          if (POOL && PLAN && s_ == 8) {
+            // groups of 8 rows (row plan, common.h: RowPlan): rows 0-3 one register quad of the lower lane half, rows 4-7 of
+            // the upper half -- the quad's keys again, with the row within the group in the low 3 bits
+#pragma unroll
+            for (int h8 = 0; h8 < 2; ++h8) {
+              unsigned qx = 0u, qn = 0xffffffffu;
+#pragma unroll
+              for (int r = 8 * gq + 4 * h8; r < 8 * gq + 4 * h8 + 4; r += 2) {
+                const unsigned mine = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
+                const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, mine) >> 15);
+                const unsigned o = mine ^ (sg | 0x80008000u);
+                const unsigned row = (unsigned)(r & 3);
+                const unsigned olo = o << 16, ohi = o & 0xffff0000u;
+                qx = max(max(qx, olo | (7u - row)), ohi | (6u - row));
+                qn = min(min(qn, olo | row), ohi | (row + 1u));
+              }
+              unsigned a = qx ^ hbit, b = qn | hbit;
+              a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
+              b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
+              const unsigned key = upper ? b : a;
+              const unsigned o = key >> 16;
+              const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
+              const unsigned low = key & 7u;
+              const unsigned char row = (unsigned char)(upper ? low : 7u - low);
+              const int r0 = wm * 64 + i * 32 + (2 * gq + h8) * 8, gc = n0 + wn * 64 + j * 32 + ccol;
+              if (m0 + r0 < g.M && gc < g.N) {
+                const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
+                (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
+                (upper ? pool.amin : pool.amax)[oidx] = row;
+              }
+            }
+          }
         }
       if (STATS) {
         cs += __shfl_xor(cs, 32, 64);
@@ -423,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
         }
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
-          if (gi % gstep) continue;
+          if ((PLAN && s_ == 8) || gi % gstep) continue;
           unsigned a = kmx[gi], b = kmn[gi];
           a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
           b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
@@ -570,7 +602,7 @@ extern "C" int omnipq_gemm_strip_e16(int M, int N, int K, const void *A, int lda
   }
   StripPool pool{};
   if (s) {
-    if (!sums || !(s == 16 || s == 32 || s == 64) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
+    if (!sums || !(s == 8 || s == 16 || s == 32 || s == 64) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
     pool.s = s;
     pool.ymax = (e16_t *)ymax;
     pool.ymin = (e16_t *)ymin;
@@ -582,7 +614,7 @@ extern "C" int omnipq_gemm_strip_e16(int M, int N, int K, const void *A, int lda
   {
     const RowPlan &rp = row_plan();               // the calling thread's row plan, if it was made for this many rows
     if (rp.rows_dev && rp.rows == M) {
-      if (s != 0 && s != 16) return OMNIPQ_EINVAL;  // a planned stage records its ball extrema per 16-row group
+      if (s != 0 && s != rp.gs) return OMNIPQ_EINVAL;  // a planned stage records its ball extrema per group of the plan
       g.rows_dev = rp.rows_dev;
       g.row_w = rp.row_w;
     }

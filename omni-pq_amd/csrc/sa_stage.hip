@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(long long chunks, int n,
   }
 }
 
-// The same into the COMPACT row space of a row plan (common.h: RowPlan): ball bm writes the rows t < 16 (goff[bm + 1] - goff[bm])
-// of its neighbour list to rows 16 goff[bm] + t.  One lane per 16-byte piece of a row of the FULL layout; lanes of dropped
+// The same into the COMPACT row space of a row plan (common.h: RowPlan): ball bm writes the rows t < gs (goff[bm + 1] - goff[bm])
+// of its neighbour list to rows gs goff[bm] + t.  One lane per 16-byte piece of a row of the FULL layout; lanes of dropped
 // rows leave.
 __global__ __launch_bounds__(256) void sa_gather_compact_kernel(long long chunks, int n, int m, int s, int cin,
                                                                int kpad, float inv_r,
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void sa_gather_compact_kernel(long long chunks
                                                                const float *__restrict__ new_xyz,
                                                                const int *__restrict__ idx,
                                                                const e16_t *__restrict__ feat,
-                                                               const int *__restrict__ goff,
+                                                               const int *__restrict__ goff, int gs,
                                                                e16_t *__restrict__ X) {
   const int cpr = kpad >> 3;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < chunks; q += (long long)gridDim.x * 256) {
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void sa_gather_compact_kernel(long long chunks
     const int bm = (int)(p / s);
     const int t = (int)(p - (long long)bm * s);
     const int g0 = goff[bm];
-    if (t >= (goff[bm + 1] - g0) * 16) continue;
+    if (t >= (goff[bm + 1] - g0) * gs) continue;
     const int b = bm / m;
     const int k = idx[p];
     uint4 out = make_uint4(0, 0, 0, 0);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void sa_gather_compact_kernel(long long chunks
       float f[8] = {(pk[0] - pc[0]) * inv_r, (pk[1] - pc[1]) * inv_r, (pk[2] - pc[2]) * inv_r, 0, 0, 0, 0, 0};
       out = pack8(f);
     }
-    *reinterpret_cast<uint4 *>(X + ((size_t)g0 * 16 + t) * kpad + c8 * 8) = out;
+    *reinterpret_cast<uint4 *>(X + ((size_t)g0 * gs + t) * kpad + c8 * 8) = out;
   }
 }
 
@@ -355,10 +355,10 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ a_out, float *__restrict__ b_out,
     float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ out_f32, e16_t *__restrict__ out_pm,
-    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel, const int *__restrict__ goff) {
-  // goff (row plan, common.h: RowPlan) or NULL: the extrema arrays hold one entry per 16-row GROUP, ball bm owns the groups
+    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel, const int *__restrict__ goff, int gs) {
+  // goff (row plan, common.h: RowPlan) or NULL: the extrema arrays hold one entry per gs-row GROUP, ball bm owns the groups
   // goff[bm] .. goff[bm + 1] and its extrema are merged here (strict comparisons: an earlier group wins a tie, as the first
-  // row does inside a group), the row within the ball = 16 * (group within the ball) + row within the group
+  // row does inside a group), the row within the ball = gs * (group within the ball) + row within the group
   __shared__ __attribute__((aligned(16))) float s_a[kFinMaxC], s_b[kFinMaxC];
   for (int c = (int)threadIdx.x; c < C; c += 256) {
     const double mu = sums[c] / cnt;
@@ -408,11 +408,11 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
         for (int e = 0; e < 8; ++e) {
           if (h2[e] > hi[e]) {
             hi[e] = h2[e];
-            ph = (ph & ~(0xFFull << (8 * e))) | ((((ph2 >> (8 * e)) & 0xFF) + 16ull * gi) << (8 * e));
+            ph = (ph & ~(0xFFull << (8 * e))) | ((((ph2 >> (8 * e)) & 0xFF) + (unsigned long long)(gs * gi)) << (8 * e));
           }
           if (l2[e] < lo[e]) {
             lo[e] = l2[e];
-            pl = (pl & ~(0xFFull << (8 * e))) | ((((pl2 >> (8 * e)) & 0xFF) + 16ull * gi) << (8 * e));
+            pl = (pl & ~(0xFFull << (8 * e))) | ((((pl2 >> (8 * e)) & 0xFF) + (unsigned long long)(gs * gi)) << (8 * e));
           }
         }
       }
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
                                                             const unsigned char *__restrict__ arg,
                                                             e16_t *__restrict__ dY,
                                                             const int *__restrict__ goff,
-                                                            const unsigned char *__restrict__ row_w) {
-  // row plan (common.h: RowPlan): ball bm keeps the rows of its 16-row groups goff[bm] .. goff[bm + 1], and its first row
+                                                            const unsigned char *__restrict__ row_w, int gs) {
+  // row plan (common.h: RowPlan): ball bm keeps the rows of its gs-row groups goff[bm] .. goff[bm + 1], and its first row
   // gets the constant term of all the copies it stands for
   // the means S / P, T / P straight from the f64 totals (16 loads per ball and channel piece, amortised over the ball's
   // s rows: the separate f64 -> f32 means launch is gone); the items of ball 0 also publish dbeta | dgamma when asked to
@@ -762,10 +762,10 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
       Tv[e] *= av[e] * is[e];                                                // a * invstd * T/P
       gg[e] *= av[e];
     }
-    const size_t row0 = goff ? (size_t)goff[bm] * 16 : (size_t)bm * s;
+    const size_t row0 = goff ? (size_t)goff[bm] * gs : (size_t)bm * s;
     const e16_t *src = Y + row0 * C + c0;
     e16_t *dst = dY + row0 * C + c0;
-    const int kept = goff ? (goff[bm + 1] - goff[bm]) * 16 : s;
+    const int kept = goff ? (goff[bm + 1] - goff[bm]) * gs : s;
     const float w0 = goff ? (float)row_w[row0] : 1.f;
     for (int t = 0; t < kept; ++t) {
       float y[8];
@@ -937,15 +937,15 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(long long P, int n, int m
 constexpr int kCsrLdsMax = 8192;
 
 // Row plan (common.h: RowPlan): position p of scene b (ball bm = b m + p / s, neighbour slot t = p % s) exists in the compact row
-// space iff t < 16 (goff[bm + 1] - goff[bm]); dropped positions are copies whose gradient the ball's first row carries
+// space iff t < gs (goff[bm + 1] - goff[bm]); dropped positions are copies whose gradient the ball's first row carries
 struct CsrPlan {
   const int *goff;       // NULL: every position exists
-  int m, s;
+  int m, s, gs;
 };
 __device__ __forceinline__ bool csr_kept(const CsrPlan &pl, int b, int p) {
   if (!pl.goff) return true;
   const int bm = b * pl.m + p / pl.s;
-  return p % pl.s < 16 * (pl.goff[bm + 1] - pl.goff[bm]);
+  return p % pl.s < pl.gs * (pl.goff[bm + 1] - pl.goff[bm]);
 }
 
 __global__ __launch_bounds__(1024) void csr_build_lds_kernel(int n, int ms, const int *__restrict__ idx,
@@ -1089,11 +1089,11 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
                                                             const e16_t *__restrict__ dX,
                                                             float *__restrict__ dfeat, float *__restrict__ dxyz,
                                                             CsrPlan pl) {
-  // (row plan: position o of scene b lives in compact row 16 goff[ball] + slot)
+  // (row plan: position o of scene b lives in compact row gs goff[ball] + slot)
   auto row_of = [&](int b, int o) -> size_t {
     if (!pl.goff) return (size_t)b * ms + o;
     const int bm = b * pl.m + o / pl.s;
-    return (size_t)pl.goff[bm] * 16 + o % pl.s;
+    return (size_t)pl.goff[bm] * pl.gs + o % pl.s;
   };
   const int cpr = (cin >> 3) + 1;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
@@ -1208,7 +1208,7 @@ extern "C" int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, f
   const omnipq::RowPlan &rp = omnipq::row_plan();
   if (rp.rows_dev && rp.goff && rp.rows == P)       // the stage's row plan: into the compact row space
     sa_gather_compact_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
-        chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, rp.goff, (e16_t *)X);
+        chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, rp.goff, rp.gs, (e16_t *)X);
   else
     sa_gather_kernel<<<grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
         chunks, n, m, s, cin, kpad, inv_radius, xyz, new_xyz, idx, (const e16_t *)feat_pm, (e16_t *)X);
@@ -1305,7 +1305,7 @@ extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *y
   pool_select_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
       items, C, (const e16_t *)ymax, (const e16_t *)ymin, amax, amin, sums, count, gamma, beta, eps, momentum, running_mean,
       running_var, a_out, b_out, mean_out, invstd_out, out_f32, (e16_t *)out_pm, arg, (e16_t *)ysel,
-      omnipq::row_plan().rows_dev ? omnipq::row_plan().goff : nullptr);
+      omnipq::row_plan().rows_dev ? omnipq::row_plan().goff : nullptr, omnipq::row_plan().gs);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1375,7 +1375,7 @@ static int pool_bwd_apply_impl(int b, int m, int s, int C, double total_position
   const bool planned = rp.rows_dev && rp.goff && rp.rows == (long long)b * m * s;
   pool_bwd_apply_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
       items, m, s, C, (const e16_t *)Y, a, mean, invstd, sums, 1.0 / total_positions, gb_out, g_out,
-      (const e16_t *)out_pm, arg, (e16_t *)dY, planned ? rp.goff : nullptr, planned ? rp.row_w : nullptr);
+      (const e16_t *)out_pm, arg, (e16_t *)dY, planned ? rp.goff : nullptr, planned ? rp.row_w : nullptr, rp.gs);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1449,7 +1449,7 @@ extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, i
   const int ms = m * s;
   const omnipq::RowPlan &rp = omnipq::row_plan();
   const bool planned = rp.rows_dev && rp.goff && rp.rows == P;
-  const omnipq::CsrPlan pl{planned ? rp.goff : nullptr, m, s};
+  const omnipq::CsrPlan pl{planned ? rp.goff : nullptr, m, s, rp.gs};
   if (planned && !(n <= omnipq::kCsrLdsMax && b <= 8191)) return OMNIPQ_EINVAL;      // (the LDS builders know the plan)
   if (n <= omnipq::kCsrLdsMax && b <= 8191) {
     constexpr int split = 8;
@@ -1489,7 +1489,7 @@ extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kp
   if (planned && dxyz) return OMNIPQ_EINVAL;          // (the centre-gradient kernel does not know the plan)
   sa_scatter_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
       items, n, m * s, cin, kpad, inv_radius, offsets, order, (const e16_t *)dX, dfeat_pm, dxyz,
-      omnipq::CsrPlan{planned ? rp.goff : nullptr, m, s});
+      omnipq::CsrPlan{planned ? rp.goff : nullptr, m, s, rp.gs});
   OMNIPQ_LAUNCH_CHECK();
   if (dnew_xyz) {
     const long long BM = (long long)b * m;

@@ -264,8 +264,9 @@ _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 # nsample points with copies of its first neighbour (ball_query_gpu.cu:36-45; pointnet2_utils.py:317-376 groups them like any
 # other index), so the shared MLP of the reference runs on duplicate rows: on the benchmark's 40 000-point room scenes a ball
 # of sa1 (radius 0.2, nsample 64) holds 27 real neighbours on average and a ball of sa2 (0.4, 32) seven (tools/ball_fill.py).
-# A planned stage keeps, per ball, its first 16 * ceil(real neighbours / 16) rows, packs the balls' rows back to back
-# (COMPACT row space) and runs every kernel on that: 54 % of sa1's rows on those scenes.  The number of rows in use is
+# A planned stage keeps, per ball, its first G * ceil(real neighbours / G) rows (G = PLAN_GROUP = 8: the finest unit the
+# extrema epilogue of the GEMMs resolves), packs the balls' rows back to back (COMPACT row space) and runs every kernel on
+# that: 48 % of sa1's rows and 31 % of sa2's on those scenes (54 % / 50 % with groups of 16).  The number of rows in use is
 # data-dependent, so it lives in device memory and the launches keep the static grids of the full row count -- workgroups
 # past it leave at once -- which keeps the step capturable into a hipGraph.  The dropped rows are accounted for exactly: they
 # are copies of their ball's first row, so BatchNorm statistics weight that row by 1 + dropped copies, the max-pool is
@@ -275,21 +276,23 @@ _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 # computation up to the order of the f32 sums (tests/test_gpu_fused_sa.py::test_row_plan_equals_the_full_stage).
 # ROW_PLAN = False: every row is computed.
 ROW_PLAN = True
+PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
 row_plan_uses = 0
+row_plan_last = {}              # P of the stage -> its latest _Plan (bench.py reads the rows in use from it)
 _lib.omnipq_sa_row_plan.restype = None
 
 
 def row_plan_ok(training, S, P, L, needs_input_grad, pooled):
-    """at least two 16-row groups per ball, the partial-sum kernel paths (many rows), the dataflow without stored activations
+    """at least two 16-row blocks per ball, the partial-sum kernel paths (many rows), the dataflow without stored activations
     and with the ball extrema in the last GEMM (the kernels that know the plan), no gradient into the stage's coordinates (the
     centre-gradient kernel does not know it; feature gradients: the caller also asks for at most 8192 source points, the CSR
     builders that do)"""
-    return ROW_PLAN and training and S % 16 == 0 and 32 <= S <= 128 and P >= (1 << 18) and P % 128 == 0 and L >= 2 and \
+    return ROW_PLAN and training and S in (32, 64, 128) and P >= (1 << 18) and P % 128 == 0 and L >= 2 and \
         AFFINE_OPERANDS and POOL_EPILOGUE and _FOLD_SMALL and pooled and not needs_input_grad
 
 
 class _Plan:
-    __slots__ = ("goff", "rows_dev", "row_w", "scratch")
+    __slots__ = ("goff", "rows_dev", "row_w", "scratch", "gs")
 
 
 def make_row_plan(idx, P):
@@ -297,12 +300,14 @@ def make_row_plan(idx, P):
     B, M, S = idx.shape
     dev = idx.device
     plan = _Plan()
+    plan.gs = PLAN_GROUP
     plan.goff = torch.empty((B * M + 1,), device=dev, dtype=torch.int32)
     plan.rows_dev = torch.empty((1,), device=dev, dtype=torch.int32)
     plan.row_w = torch.empty((P,), device=dev, dtype=torch.uint8)
     plan.scratch = torch.empty((B * M,), device=dev, dtype=torch.int32)
-    _call(_lib.omnipq_sa_ball_plan, idx, ctypes.c_longlong(B * M), S, _p(idx), _p(plan.goff), _p(plan.rows_dev),
+    _call(_lib.omnipq_sa_ball_plan, idx, ctypes.c_longlong(B * M), S, plan.gs, _p(idx), _p(plan.goff), _p(plan.rows_dev),
           _p(plan.row_w), _p(plan.scratch))
+    row_plan_last[P] = plan
     return plan
 
 
@@ -313,17 +318,26 @@ class _row_plan:
         self.plan, self.rows = plan, rows
 
     def __enter__(self):
+        global _plan_active
+        _plan_active = self.plan is not None
         if self.plan is not None:
             _lib.omnipq_sa_row_plan(_p(self.plan.rows_dev), _p(self.plan.row_w), _p(self.plan.goff),
-                                    ctypes.c_longlong(self.rows))
+                                    ctypes.c_longlong(self.rows), self.plan.gs)
 
     def __exit__(self, *exc):
+        global _plan_active
+        _plan_active = False
         if self.plan is not None:
-            _lib.omnipq_sa_row_plan(_p(None), _p(None), _p(None), ctypes.c_longlong(0))
+            _lib.omnipq_sa_row_plan(_p(None), _p(None), _p(None), ctypes.c_longlong(0), 16)
+
+
+_plan_active = False
 
 
 def strip_pays(M, N, K, with_pool):
-    if not STRIP_GEMM:
+    # (not inside a planned stage: the planned strip kernels -- row weights on top of the register-resident strip -- spill
+    # 40 to 130 registers, tools/spills.sh, and the shapes the strip wins on do not occur in the stages a plan covers)
+    if not STRIP_GEMM or _plan_active:
         return False
     if K == 256 and N >= 512 and N % 128 == 0 and M >= 65536:
         return True
@@ -1157,12 +1171,13 @@ class FusedSAStage(torch.autograd.Function):
                 pool = None
                 if l == L - 1 and POOL_EPILOGUE and 128 % S == 0 and (X is not None or layers[l - 1].fin is not None):
                     # the last layer's GEMM also records every ball's extrema: the pooling pass below needs no Y
-                    # (a planned stage records them per 16-row group of the compact row space; pool_select merges a ball's)
-                    planned = getattr(ctx, "plan", None) is not None
-                    slots = P // 16 if planned else B * M
+                    # (a planned stage records them per group of the compact row space; pool_select merges a ball's)
+                    plan = getattr(ctx, "plan", None)
+                    planned = plan is not None
+                    slots = P // plan.gs if planned else B * M
                     ext16 = torch.empty((2, slots, cout), device=dev, dtype=E16.dtype)
                     ext8 = torch.empty((2, slots, cout), device=dev, dtype=torch.uint8)
-                    pool = (16 if planned else S, ext16[0], ext16[1], ext8[0], ext8[1])
+                    pool = (plan.gs if planned else S, ext16[0], ext16[1], ext8[0], ext8[1])
                 if xgen and l == 0:
                     # never materialised (see XYZGEN): statistics from the moments of the grouped coordinates
                     lay.mom = torch.empty((12,), device=dev, dtype=torch.float64)

@@ -891,11 +891,13 @@ def test_build_csr_groups_every_position_under_its_source_point(B, n, m, s):
         assert torch.equal(flat[b][o], key_of_slot)
 
 
+@pytest.mark.parametrize("group", [8, 16])
 @pytest.mark.parametrize("case", ["coordinates_only", "six_extra_channels", "deferred_grouped", "sa2_feature_gradient"])
-def test_row_plan_equals_the_full_stage(case, monkeypatch):
-    """sa_fused.ROW_PLAN: for nsample == 64 the second 32-row block of every ball with at most 32 real neighbours holds copies of
-    the ball's first row (ball_query pads with the first neighbour) and is skipped by every kernel of the stage; the copies are
-    accounted for by row weights.  The stage must give what the full computation gives -- same pooled arg-max rows, outputs and
+def test_row_plan_equals_the_full_stage(case, group, monkeypatch):
+    """sa_fused.ROW_PLAN: the rows of a ball behind its real neighbours hold copies of the ball's first row (ball_query pads with
+    the first neighbour); a planned stage keeps whole groups of `group` rows (sa_fused.PLAN_GROUP) up to the last real
+    neighbour, packs them into a compact row space every kernel of the stage works on, and accounts for the dropped copies by
+    row weights.  The stage must give what the full computation gives -- same pooled arg-max rows, outputs and
     gradients equal up to the order of the f32 sums (statistics: weighted instead of repeated rows) and the bf16 roundings
     that order can flip -- on the backbone's sa1 at the benchmark's per-scene size, with the coordinate-generated first layer,
     with extra input channels (BASELINE configs[3]: no gradient into the raw features), and through the deferred grouped
@@ -915,6 +917,7 @@ def test_row_plan_equals_the_full_stage(case, monkeypatch):
     if case == "sa2_feature_gradient":
         feats = (feats * 0.5).requires_grad_(True)
     monkeypatch.setenv("OMNIPQ_SA", "fused")
+    monkeypatch.setattr(sa_fused, "PLAN_GROUP", group)
     res = {}
     for on in (False, True):
         monkeypatch.setattr(sa_fused, "ROW_PLAN", on)
@@ -955,6 +958,8 @@ def test_row_plan_equals_the_full_stage(case, monkeypatch):
                                                        pointnet2_modules.pointnet2_utils.gather_operation(
         xyz.transpose(1, 2).contiguous(), full[1]).transpose(1, 2).contiguous())
     cnt = 1 + (idx[..., 1:] != idx[..., :1]).sum(-1)
-    kept = ((cnt + 15) // 16 * 16).float().mean() / spec["nsample"]
+    kept = ((cnt + group - 1) // group * group).float().mean() / spec["nsample"]
     print(f"  rows kept: {float(kept):.3f} of the full layout")
+    P = cnt.numel() * spec["nsample"]
+    assert int(sa_fused.row_plan_last[P].rows_dev.item()) == int(((cnt + group - 1) // group * group).sum())
     assert 0.2 < float(kept) < 0.9
