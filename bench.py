@@ -914,6 +914,7 @@ def main():
                                "largest_kernel": dominant}
             # row plan (sa_fused.ROW_PLAN): the share of the grouped rows the planned stages computed on the last step's
             # scenes -- the rest are the copies ball_query's padding creates; data-dependent, so it is reported
+            import sa_fused
             if sa_fused.row_plan_last:
                 rec["roofline"]["row_plan"] = {
                     "group_rows": sa_fused.PLAN_GROUP,

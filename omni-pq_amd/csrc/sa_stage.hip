@@ -530,9 +530,14 @@ struct ApplyProblem {
 // non-temporally (this kernel is its only reader).  Per channel ONE 16-byte LDS entry (a, b, beta', gamma') with
 //   dY = a dz + beta' y + gamma',  beta' = -a invstd T/P,  gamma' = -a S/P + a invstd T/P mean
 // instead of four 32-byte global loads and sixteen conflicting scalar LDS reads per piece.
+// REGTAB (C / 8 divides 256: a thread's pieces then all lie in the same 8 channels, so it can hold its eight entries in
+// registers and the loop touches no LDS) removes the table reads whose 128-byte lane stride keeps the LDS pipe 65 % busy,
+// 87 % of it bank conflicts (profiles/r04_sa_stage_pmc_issue.md) -- and is SLOWER: 0.283 -> 0.321 ms per step over the SA
+// stages (round 4, bench.py op timing).  The conflicts sit under the memory wait (the kernel streams at 4.8-5.3 TB/s), the 32
+// extra registers cost two of seven resident waves per SIMD.  Kept as a template switch, not launched.
 typedef float st_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
-template <int U, bool NT, bool PLAN = false>
+template <int U, bool NT, bool PLAN = false, bool REGTAB = false>
 __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, int bid, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float st_raw[];
   st_f32x4 *tab = reinterpret_cast<st_f32x4 *>(st_raw);      // [C]
@@ -553,6 +558,11 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
   const st_u32x4 *__restrict__ dX = reinterpret_cast<const st_u32x4 *>(p.dX);
   st_u32x4 *__restrict__ dY = reinterpret_cast<st_u32x4 *>(p.dY);
   const long long chunks = PLAN ? (long long)*p.rows_dev * cpr : p.chunks;
+  st_f32x4 mine[8];
+  if (REGTAB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mine[e] = tab[((int)threadIdx.x % cpr) * 8 + e];
+  }
   for (long long q0 = (long long)bid * (256 * U) + threadIdx.x; q0 < chunks; q0 += (long long)nblocks * (256 * U)) {
     st_u32x4 yv[U], dv[U];
     bool on[U];
@@ -574,7 +584,7 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
       st_u32x4 o;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const st_f32x4 t0 = tab[c0 + 2 * w], t1 = tab[c0 + 2 * w + 1];
+        const st_f32x4 t0 = REGTAB ? mine[2 * w] : tab[c0 + 2 * w], t1 = REGTAB ? mine[2 * w + 1] : tab[c0 + 2 * w + 1];
         const float y0 = e16_lo(yv[u][w]), y1 = e16_hi(yv[u][w]);
         const float d0 = e16_lo(dv[u][w]), d1 = e16_hi(dv[u][w]);
         const float z0 = __builtin_fmaf(t0[0], y0, t0[1]) > 0.f ? d0 : 0.f;
@@ -590,9 +600,9 @@ __device__ __forceinline__ void bn_bwd_apply_fused_body(const ApplyProblem &p, i
     }
   }
 }
-template <int U, bool NT, bool PLAN = false>
+template <int U, bool NT, bool PLAN = false, bool REGTAB = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(ApplyProblem p) {
-  bn_bwd_apply_fused_body<U, NT, PLAN>(p, (int)blockIdx.x, (int)gridDim.x);
+  bn_bwd_apply_fused_body<U, NT, PLAN, REGTAB>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // two independent problems in one grid (see gemm_bf16.hip: gemm_nt_pair_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(ApplyProblem p0, ApplyProblem p1, int n0) {
@@ -767,9 +777,9 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
     e16_t *dst = dY + row0 * C + c0;
     const int kept = goff ? (goff[bm + 1] - goff[bm]) * gs : s;
     const float w0 = goff ? (float)row_w[row0] : 1.f;
-    for (int t = 0; t < kept; ++t) {
+    auto one = [&](int t, const uint4 &raw) {
       float y[8];
-      unpack8(*reinterpret_cast<const uint4 *>(src + (size_t)t * C), y);
+      unpack8(raw, y);
       const float wt = t == 0 ? w0 : 1.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -778,7 +788,18 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(long long items, in
         y[e] = goff ? dz - wt * (Sv[e] + (y[e] - mu[e]) * Tv[e]) : dz - Sv[e] - (y[e] - mu[e]) * Tv[e];
       }
       *reinterpret_cast<uint4 *>(dst + (size_t)t * C) = pack8(y);
+    };
+    // four rows requested before the first is used: the walk down a ball is a chain of dependent-looking 16-byte accesses
+    // at a stride of C elements, and one in flight per thread left the kernel parked on memory 80 % of its cycles
+    int t = 0;
+    for (; t + 4 <= kept; t += 4) {
+      uint4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(t + u) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(t + u, raw[u]);
     }
+    for (; t < kept; ++t) one(t, *reinterpret_cast<const uint4 *>(src + (size_t)t * C));
   }
 }
 
@@ -1603,13 +1624,16 @@ extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positi
     // (measured round 3, 1 M x 128 / 262 144 x 256: 153 / 83 us = 5.3 / 4.8 TB/s on the three streams; a capped grid with a
     // grid-stride loop and plain loads are within 2 % of it -- two reads per write do not reach the 6.2 TB/s of a 1 : 1 copy)
     const omnipq::RowPlan &rp = omnipq::row_plan();
+    const bool regtab = false;                      // (see bn_bwd_apply_fused_body: measured slower)
     if (rp.rows_dev && rp.rows == P) {
       omnipq::ApplyProblem pp = q.p;
       pp.rows_dev = rp.rows_dev;
       pp.row_w = rp.row_w;
-      bn_bwd_apply_fused_kernel<4, true, true><<<grid, 256, lds, (hipStream_t)stream>>>(pp);
+      if (regtab) bn_bwd_apply_fused_kernel<4, true, true, true><<<grid, 256, lds, (hipStream_t)stream>>>(pp);
+      else bn_bwd_apply_fused_kernel<4, true, true><<<grid, 256, lds, (hipStream_t)stream>>>(pp);
     } else {
-      bn_bwd_apply_fused_kernel<4, true><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
+      if (regtab) bn_bwd_apply_fused_kernel<4, true, false, true><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
+      else bn_bwd_apply_fused_kernel<4, true><<<grid, 256, lds, (hipStream_t)stream>>>(q.p);
     }
     OMNIPQ_LAUNCH_CHECK();
     return OMNIPQ_OK;

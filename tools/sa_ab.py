@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--extra", type=int, default=0)
     ap.add_argument("--flag", default="XYZGEN", help="sa_fused module switch to A/B (XYZGEN, AFFINE_OPERANDS, POOL_EPILOGUE, ...)")
+    ap.add_argument("--values", nargs=2, default=None, help="the two values to compare instead of False / True (ints)")
     ap.add_argument("--per-stage", action="store_true", help="after the A/B, split the default path's time by stage")
     args = ap.parse_args()
     import pointnet2_utils
@@ -70,8 +71,9 @@ def main():
             grads["seed_feat"] = seed_feat.grad.detach().clone()
             return [o.detach().float().clone() for o in outs], grads
 
+    modes = (False, True) if args.values is None else tuple(int(v) for v in args.values)
     res = {}
-    for mode in (False, True):
+    for mode in modes:
         setattr(sa_fused, args.flag, mode)
         # running statistics must start equal in both modes
         torch.manual_seed(1)
@@ -82,24 +84,24 @@ def main():
         torch.cuda.synchronize()
     names = ["sa1", "sa2", "sa3", "sa4", "vote"]
     ok = True
-    for n, a, b in zip(names, res[False][0], res[True][0]):
+    for n, a, b in zip(names, res[modes[0]][0], res[modes[1]][0]):
         d = (a - b).abs().max().item()
         print(f"out {n}: max|diff| {d:.3e}  max|ref| {a.abs().max().item():.3e}  equal={torch.equal(a, b)}")
         ok &= d <= 2e-2 * a.abs().max().item()
     worst = 0.0
-    for k in sorted(res[False][1]):
-        a, b = res[False][1][k].float().flatten(), res[True][1][k].float().flatten()
+    for k in sorted(res[modes[0]][1]):
+        a, b = res[modes[0]][1][k].float().flatten(), res[modes[1]][1][k].float().flatten()
         rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
         cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
         worst = max(worst, rel)
         if rel > 2e-2 or cos < 0.999:
             print(f"grad {k}: rel-L2 {rel:.3e} cos {cos:.6f} |ref| {a.norm().item():.3e}")
-    print(f"grads: worst rel-L2 {worst:.3e} over {len(res[False][1])} tensors")
+    print(f"grads: worst rel-L2 {worst:.3e} over {len(res[modes[0]][1])} tensors")
     ok &= worst < 5e-2
     print("PARITY", "OK" if ok else "FAIL")
 
     ext = pointnet2_utils._ext
-    for mode in (False, True):
+    for mode in modes:
         setattr(sa_fused, args.flag, mode)
         for _ in range(2):
             step()
