@@ -163,6 +163,10 @@ int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const fl
 int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
+/* Timing aid (tools/bench_tn_grouped.py): bit 0 selects the register-prefetch workgroup program of the TN kernels instead of
+ * the LDS-DMA ring they run by default (csrc/gemm_tn_bf16.hip: tn_tile / tn_tile_dma); process-wide, not for production. */
+void omnipq_tn_debug(int flags);
+int omnipq_tn_occupancy(int which);   /* workgroups per CU of the grouped TN kernel: 0 plain, 1 affine, + 2 register program */
 
 /* Row plan of a stage whose balls hold duplicate rows (csrc/common.h: RowPlan).  ball_query pads a ball with copies of its
  * first neighbour, so the grouped rows behind the real neighbours duplicate the ball's row 0.  omnipq_sa_ball_plan derives

@@ -35,6 +35,7 @@ struct TnArgs {
   // row plan of the stage (common.h: RowPlan) or NULL: the positions in use are the first *rows_dev of P (slabs past them
   // contribute zero tiles)
   const int *rows_dev = nullptr;
+  int debug = 0;      // omnipq_tn_debug: bit 1 no fetches after the first two, bit 2 no fragment reads / MFMAs, bit 3 no C stores
 };
 
 // colsum (may be NULL): float[M], receives (ADDED, f32 atomics) the column sums of A over all positions --
@@ -299,18 +300,225 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const e16_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(TnArgs g, const e16_t *__restrict__ A,
-                                                        const e16_t *__restrict__ B,
-                                                        float *__restrict__ part, float *__restrict__ colsum) {
-  tn_tile<false>(g, A, B, part, colsum, (int)blockIdx.x);
+// ---- the same workgroup program with the operands streamed by LDS-DMA ------------------------------------------------------
+// tn_tile above is bound by the latency of its global loads: one K-step (32 positions, 16 KB) is requested into registers
+// while the previous one is multiplied, so a workgroup has ONE step in flight and every step lasts a trip to memory; 123-126
+// VGPRs leave no room for a second set of prefetch registers at four workgroups per CU.  Here a K-step's two blocks
+// ([32 positions][128 channels] of A and of B, rows of 256 bytes) go from memory straight into a THREE-deep LDS ring
+// (global_load_lds_dwordx4, four instructions per lane and step, no registers): two steps are in flight per workgroup behind
+// a counted s_waitcnt vmcnt and one raw s_barrier per step, three workgroups per CU (48 KB each).  An LDS-DMA instruction
+// writes wave-uniform base + lane * 16, i.e. the image is linear without padding; the four rows a transpose read
+// (ds_read_b64_tr_b16) touches would then lie 256 bytes = one pass over all banks apart, so the 16-byte slot of a row is
+// XOR-ed with 4 * (row & 3) -- on the SOURCE address of the DMA and on the read address.  The instruction is served in two
+// groups of 32 lanes (MI355X_MICROARCH.md, LDS): a group reads 8 pieces of 32 bytes -- rows r = 0..3 at the columns of the
+// two 16-lane halves h -- and with the XOR their 32-byte positions within the 256-byte bank row are
+// (column block ^ r) * 2 + h: all eight different, no conflict (the 288-byte pitch of the register path leaves half 0 of
+// row r + 1 on the banks of half 1 of row r: two-way conflicts, 37 % of the kernel's LDS cycles).
+// What the register path did between load and LDS store moves behind the fragment reads: the affine + ReLU of AFFB is
+// applied to the B fragments (a lane holds ONE channel at 8 positions: one (a, b) pair per lane and column block), the tail
+// of a ragged last step is zeroed in the A fragments, and the column sums of A are taken from the A fragments.
+constexpr int TD_NBUF = 3;
+constexpr int TD_STAGE_ELEMS = 2 * TBK * 128;      // 8192 e16 = 16 KB per K-step
+
+template <int N_>
+__device__ __forceinline__ void tn_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_affine_kernel(TnArgs g, const e16_t *__restrict__ A,
-                                                               const e16_t *__restrict__ B,
-                                                               float *__restrict__ part, float *__restrict__ colsum,
-                                                               const float *__restrict__ ba,
-                                                               const float *__restrict__ bb) {
-  tn_tile<true>(g, A, B, part, colsum, (int)blockIdx.x, ba, bb);
+template <bool AFFB>
+__device__ __forceinline__ void tn_tile_dma(const TnArgs &g, const e16_t *__restrict__ A, const e16_t *__restrict__ B,
+                                            float *__restrict__ part, float *__restrict__ colsum, const int id,
+                                            const float *__restrict__ ba = nullptr, const float *__restrict__ bb = nullptr) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TD_NBUF * TD_STAGE_ELEMS * 2];      // the ONLY LDS object
+  e16_t *const stage = reinterpret_cast<e16_t *>(smem);
+
+  const int tiles = g.m_tiles * g.n_tiles;                     // (XCD-aware order, slabs and the row plan: as in tn_tile)
+  const int xcd = id & 7, local = id >> 3;
+  const int slab = xcd + 8 * (local / tiles), tile = local % tiles;
+  if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
+  const int mt = tile / g.n_tiles, nt = tile % g.n_tiles;
+  const int m0 = mt * 128, n0 = nt * 128;
+  const int Peff = g.rows_dev ? *g.rows_dev : g.P;
+  int chunk = g.p_chunk;
+  if (g.rows_dev) {
+    const int nslab = (g.P + g.p_chunk - 1) / g.p_chunk;
+    chunk = ((Peff + nslab - 1) / nslab + TBK - 1) / TBK * TBK;
+    if (chunk < TBK) chunk = TBK;
+  }
+  const int pbeg = slab * chunk;
+  int pend = pbeg + chunk;
+  if (pend > Peff) pend = Peff;
+  const int nk = pend > pbeg ? (pend - pbeg + TBK - 1) / TBK : 0;
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // fetch: instruction j of wave w covers the rows 8 w + 4 j .. + 3 of a block, lane -> (row lane >> 4, LDS slot lane & 15)
+  int fcolA[2], fcolB[2], frow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    frow[j] = 8 * wave + 4 * j + (lane >> 4);
+    const int slot = (lane & 15) ^ (4 * (frow[j] & 3));        // the source slot that belongs into this LDS slot
+    fcolA[j] = m0 + slot * 8 < g.M ? m0 + slot * 8 : 0;        // (pieces past M / N feed C entries that are never stored)
+    fcolB[j] = n0 + slot * 8 < g.N ? n0 + slot * 8 : 0;
+  }
+  const int plast = Peff > 0 ? Peff - 1 : 0;
+  auto fetch = [&](int kt, int buf) {
+    e16_t *const sa = stage + buf * TD_STAGE_ELEMS;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int p = pbeg + kt * TBK + frow[j];
+      p = p < pend ? p : plast;                                // rows past the slab: any valid row (zeroed after the read)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + (size_t)p * g.lda + fcolA[j]),
+                                       (__attribute__((address_space(3))) void *)(sa + (8 * wave + 4 * j) * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (size_t)p * g.ldb + fcolB[j]),
+                                       (__attribute__((address_space(3))) void *)(sa + TBK * 128 + (8 * wave + 4 * j) * 128), 16,
+                                       0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) fetch(0, 0);
+  if (nk > 1) fetch(1, 1);
+
+  // transpose-read offsets (elements within a block), see tn_tile: row 8 (grp >> 1) + (l16 >> 2) (+ 4, + 16 kk), the lane's
+  // 8-byte piece at column 32 i + 64 wm/wn + 16 (grp & 1) + 4 (l16 & 3), its 16-byte slot swizzled with the row
+  const int grp = lane >> 4, l16 = lane & 15;
+  const int tr_row = 8 * (grp >> 1) + (l16 >> 2);
+  int offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = wm * 64 + i * 32 + 16 * (grp & 1) + (l16 & 3) * 4, cb = wn * 64 + i * 32 + 16 * (grp & 1) + (l16 & 3) * 4;
+    offA[i] = tr_row * 128 + (((ca >> 3) ^ (4 * (tr_row & 3))) << 3) + (ca & 7);
+    offB[i] = TBK * 128 + tr_row * 128 + (((cb >> 3) ^ (4 * (tr_row & 3))) << 3) + (cb & 7);
+  }
+  float afa[2] = {1.f, 1.f}, afb[2] = {0.f, 0.f};             // AFFB: this lane's channel of column block i
+  if (AFFB) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = n0 + wn * 64 + i * 32 + (lane & 31);
+      afa[i] = ba[c < g.N ? c : 0];
+      afb[i] = bb[c < g.N ? c : 0];
+    }
+  }
+  const bool do_colsum = colsum != nullptr && nt == 0 && wn == 0;
+  float csum[2] = {0.f, 0.f};
+  const int ragged = (pend - pbeg) & (TBK - 1);                // positions of the last step if it is not full
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // step kt has landed once this wave's own four instructions for it are done (the four of step kt + 1 may stay in
+    // flight) and every wave has said so; the barrier also frees the buffer of step kt - 1 for step kt + 2
+    if (kt + 1 < nk && !(g.debug & 2)) tn_wait_vm<4>(); else tn_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk && !(g.debug & 2)) fetch(kt + 2, (kt + 2) % TD_NBUF);
+    if (g.debug & 4) continue;
+    const e16_t *sa = stage + (kt % TD_NBUF) * TD_STAGE_ELEMS;
+    const bool tail = ragged != 0 && kt == nk - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      e16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const e16_t *pa = sa + kk * 16 * 128 + offA[i];
+        const e16_t *pb = sa + kk * 16 * 128 + offB[i];
+        const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pa);
+        const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pa + 4 * 128));
+        const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pb);
+        const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pb + 4 * 128));
+        fa[i] = __builtin_bit_cast(e16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        fb[i] = __builtin_bit_cast(e16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      if (tail) {
+        // the lane's eight values are the positions 16 kk + 8 (lane >> 5) + 0..7 of the step
+        const int first = 16 * kk + 8 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          uint4 w = __builtin_bit_cast(uint4, fa[i]);
+          unsigned *wp = &w.x;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int e0 = first + 2 * d;
+            wp[d] = e0 >= ragged ? 0u : (e0 + 1 >= ragged ? (wp[d] & 0xFFFFu) : wp[d]);
+          }
+          fa[i] = __builtin_bit_cast(e16x8, w);
+        }
+      }
+      if (AFFB) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          uint4 w = __builtin_bit_cast(uint4, fb[i]);
+          w.x = tn_affine_relu_pair(w.x, afa[i], afb[i], afa[i], afb[i]);
+          w.y = tn_affine_relu_pair(w.y, afa[i], afb[i], afa[i], afb[i]);
+          w.z = tn_affine_relu_pair(w.z, afa[i], afb[i], afa[i], afb[i]);
+          w.w = tn_affine_relu_pair(w.w, afa[i], afb[i], afa[i], afb[i]);
+          fb[i] = __builtin_bit_cast(e16x8, w);
+        }
+      }
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 w = __builtin_bit_cast(uint4, fa[i]);
+          csum[i] += ((e16_lo(w.x) + e16_hi(w.x)) + (e16_lo(w.y) + e16_hi(w.y))) +
+                     ((e16_lo(w.z) + e16_hi(w.z)) + (e16_lo(w.w) + e16_hi(w.w)));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = mfma_e16_32x32x16(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float t = csum[i] + __shfl_xor(csum[i], 32, 64);   // the two k-halves of the channel
+      const int ch = m0 + wm * 64 + i * 32 + lane;
+      if (lane < 32 && ch < g.M) atomicAdd(colsum + ch, t);
+    }
+  }
+  float *C = part + (size_t)slab * g.M * g.N;
+  const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+  if (g.debug & 8) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gc = n0 + wn * 64 + j * 32 + ccol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+        if (gr < g.M && gc < g.N) C[(size_t)gr * g.N + gc] = acc[i][j][r];
+      }
+    }
+}
+
+// REG: the register-prefetch program (tools/bench_tn_grouped.py compares the two; omnipq_tn_debug(1) selects it)
+template <bool REG>
+__global__ __launch_bounds__(256, REG ? 4 : 3) void gemm_tn_kernel(TnArgs g, const e16_t *__restrict__ A,
+                                                                  const e16_t *__restrict__ B, float *__restrict__ part,
+                                                                  float *__restrict__ colsum) {
+  if (REG) tn_tile<false>(g, A, B, part, colsum, (int)blockIdx.x);
+  else tn_tile_dma<false>(g, A, B, part, colsum, (int)blockIdx.x);
+}
+
+template <bool REG>
+__global__ __launch_bounds__(256, REG ? 4 : 3) void gemm_tn_affine_kernel(TnArgs g, const e16_t *__restrict__ A,
+                                                                         const e16_t *__restrict__ B,
+                                                                         float *__restrict__ part, float *__restrict__ colsum,
+                                                                         const float *__restrict__ ba,
+                                                                         const float *__restrict__ bb) {
+  if (REG) tn_tile<true>(g, A, B, part, colsum, (int)blockIdx.x, ba, bb);
+  else tn_tile_dma<true>(g, A, B, part, colsum, (int)blockIdx.x, ba, bb);
 }
 
 __global__ __launch_bounds__(256, 4) void gemm_tn_xyz_kernel(TnArgs g, const e16_t *__restrict__ A,
@@ -348,8 +556,8 @@ struct TnGroupArgs {
 };
 static_assert(sizeof(TnGroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <bool AFFB>
-__global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) {
+template <bool AFFB, bool REG = false>
+__global__ __launch_bounds__(256, REG ? 4 : 3) void gemm_tn_grouped_kernel(TnGroupArgs a) {
   const int id = (int)blockIdx.x;
   int lo = 0, hi = a.n - 1;          // last item with wg_begin <= id
   while (lo < hi) {
@@ -357,8 +565,9 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_grouped_kernel(TnGroupArgs a) 
     if (a.item[mid].wg_begin <= id) lo = mid; else hi = mid - 1;
   }
   const TnGroupItem &it = a.item[lo];
-  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles, it.rows_dev};
-  tn_tile<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
+  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles, it.rows_dev, a.pad_};
+  if (REG) tn_tile<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
+  else tn_tile_dma<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
 }
 
 // out[r][c] (+)= sum over slabs of part[z][r][c], r < out_rows, c < out_cols: fixed order, no atomics
@@ -416,6 +625,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int
 }
 
 }  // namespace omnipq
+
+// bit 0: the register-prefetch workgroup program (tn_tile) instead of the LDS-DMA one (tn_tile_dma); for A/B timing only
+static int g_tn_debug = 0;
+extern "C" void omnipq_tn_debug(int flags) { g_tn_debug = flags; }
+// workgroups of the grouped kernel (which: 0 plain / 1 affine, + 2 for the register-prefetch program) one CU holds
+extern "C" int omnipq_tn_occupancy(int which) {
+  int n = -1;
+  const void *k = which == 0   ? reinterpret_cast<const void *>(omnipq::gemm_tn_grouped_kernel<false, false>)
+                  : which == 1 ? reinterpret_cast<const void *>(omnipq::gemm_tn_grouped_kernel<true, false>)
+                  : which == 2 ? reinterpret_cast<const void *>(omnipq::gemm_tn_grouped_kernel<false, true>)
+                               : reinterpret_cast<const void *>(omnipq::gemm_tn_grouped_kernel<true, true>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, 0) != hipSuccess) return -1;
+  return n;
+}
 
 // C[M][N] (f32) = A[P][M]^T * B[P][N]; M, N multiples of 8; lda, ldb multiples of 8.
 // `workspace` must hold omnipq_gemm_tn_workspace_floats(M, N, P) floats.
@@ -499,10 +722,11 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
     gemm_tn_xyz_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace, ba, bb,
                                                             TnXyz{(const e16_t *)W0, ldw0});
   else if (ba)
-    gemm_tn_affine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace,
-                                                               colsum, ba, bb);
+    (g_tn_debug & 1 ? gemm_tn_affine_kernel<true> : gemm_tn_affine_kernel<false>)<<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, workspace, colsum, ba, bb);
   else
-    gemm_tn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, workspace, colsum);
+    (g_tn_debug & 1 ? gemm_tn_kernel<true> : gemm_tn_kernel<false>)<<<grid, 256, 0, (hipStream_t)stream>>>(
+        g, (const e16_t *)A, (const e16_t *)B, workspace, colsum);
   OMNIPQ_LAUNCH_CHECK();
   const int n4 = M * N / 4;        // M, N multiples of 8
   const f32x4 *part = reinterpret_cast<const f32x4 *>(workspace);
@@ -596,7 +820,7 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
     for (;;) {
       TnGroupArgs a;
       a.n = 0;
-      a.pad_ = 0;
+      a.pad_ = g_tn_debug;
       int wg = 0, blk = 0;
       while (next < nprob && a.n < kGroupMax) {
         const omnipq_tn_problem_ &q = pr[next];
@@ -628,9 +852,9 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
       }
       if (a.n == 0) break;
       if (pass == 0)
-        gemm_tn_grouped_kernel<false><<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
+        (g_tn_debug & 1 ? gemm_tn_grouped_kernel<false, true> : gemm_tn_grouped_kernel<false, false>)<<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
       else
-        gemm_tn_grouped_kernel<true><<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
+        (g_tn_debug & 1 ? gemm_tn_grouped_kernel<true, true> : gemm_tn_grouped_kernel<true, false>)<<<dim3(wg), 256, 0, (hipStream_t)stream>>>(a);
       OMNIPQ_LAUNCH_CHECK();
       tn_grouped_reduce_kernel<<<dim3(blk), 256, 0, (hipStream_t)stream>>>(a);
       OMNIPQ_LAUNCH_CHECK();

@@ -58,18 +58,47 @@ def main():
         q = pr[i]
         tot += 2 * q.P * (q.M + q.N)
         print(f"  problem {i:2d}: P {q.P:8d}  M {q.M:4d}  N {q.N:4d}  affine {bool(q.ba)}  rot {q.rot}")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
+    print("workgroups per CU (plain, affine, register plain, register affine):", [sa_fused._lib.omnipq_tn_occupancy(w) for w in range(4)])
+    res = {}
+    for mode, name in ((1, "register prefetch (tn_tile)"), (2, "ablation: no fetches"), (4, "ablation: fetches only"),
+                       (8, "ablation: no C stores"), (6, "ablation: loop skeleton + C stores + reduce"), (14, "ablation: loop skeleton + reduce"), (0, "LDS-DMA ring (tn_tile_dma)")):
+        sa_fused._lib.omnipq_tn_debug(mode)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            real_call(orig, items[0][0], n, probs, ws)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.reps):
+            real_call(orig, items[0][0], n, probs, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        print(f"{name}: {n} problems, {tot / 1e9:.2f} GB of operands in the full layout (each read once), "
+              f"{ms * 1e3:.1f} us per call = {tot / ms / 1e6:.0f} GB/s")
+        # the problems accumulate into their outputs (flag bit 0) or overwrite them: compare one more call's increments
+        snap0 = []
+        for i in range(n):
+            q = pr[i]
+            snap0.append(_read(q.out, q.out_rows * q.out_ld, dev))
         real_call(orig, items[0][0], n, probs, ws)
+        torch.cuda.synchronize()
+        res[mode] = [(_read(pr[i].out, pr[i].out_rows * pr[i].out_ld, dev) - (snap0[i] if pr[i].flags & 1 else 0)) for i in range(n)]
+    sa_fused._lib.omnipq_tn_debug(0)
+    worst = 0.0
+    for i in range(n):
+        a, b = res[1][i], res[0][i]
+        worst = max(worst, float((a - b).norm() / (a.norm() + 1e-30)))
+    print(f"LDS-DMA vs register path: worst rel-L2 over the {n} gradients {worst:.2e}")
+
+
+def _read(ptr, count, dev):
+    """count floats at device address ptr -> a tensor copy"""
+    out = torch.empty((count,), device=dev)
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(args.reps):
-        real_call(orig, items[0][0], n, probs, ws)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / args.reps
-    print(f"grouped SA weight gradients: {n} problems, {tot / 1e9:.2f} GB of operands (each read once), {ms * 1e3:.1f} us per "
-          f"call = {tot / ms / 1e6:.0f} GB/s")
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(4 * count), C.c_int(3))
+    return out
 
 
 if __name__ == "__main__":
