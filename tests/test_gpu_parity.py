@@ -226,6 +226,37 @@ def test_group_and_gather_exact_and_grads(b, c, n, m, s):
     assert rel_err(gg1, oracle_ext.gather_points_grad(go1, idx1, n)) <= TOL
 
 
+@pytest.mark.parametrize("b,c,n,m,s,empty_balls", [(2, 5, 512, 128, 16, 0), (8, 3, 40000, 2048, 64, 0), (2, 19, 2048, 1024, 32, 300),
+                                                   (1, 8, 4096, 1024, 64, 1024)])
+def test_group_and_gather_gradients_are_bit_reproducible(b, c, n, m, s, empty_balls):
+    """the scatter-add gradients of gather / group are sums in a FIXED order (positions sorted by source
+    point with a stable sort, one owner per source point) instead of f32 atomics: two runs are bit-equal, and runs of up to
+    128 positions -- the owner thread adds them in ascending position order, as the oracle's loop does -- are bit-equal to the
+    oracle.  `empty_balls` balls name source point 0 in every slot (what ball_query returns for a ball without neighbours):
+    that run is longer than 128 and goes to the workgroup-per-run kernel (a fixed tree: reproducible, equal to the oracle to
+    rounding)."""
+    gen = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, n, (b, m, s), generator=gen, dtype=torch.int32)
+    idx[:, :, 1:4] = idx[:, :, :1]                    # repeated targets inside a ball, as ball_query's padding makes them
+    idx[:, :empty_balls] = 0
+    go = torch.randn((b, c, m, s), generator=gen)
+    d = dev()
+    runs = [capi.group_points_grad(go.to(d), idx.to(d), n) for _ in range(2)]
+    assert torch.equal(runs[0], runs[1])
+    want = oracle_ext.group_points_grad(go, idx, n)
+    counts = torch.zeros(b, n, dtype=torch.long).scatter_add_(1, idx.reshape(b, -1).long(), torch.ones(b, m * s, dtype=torch.long))
+    short = (counts <= 128)[:, None, :].expand(b, c, n)
+    assert torch.equal(runs[0].cpu()[short], want[short])
+    assert rel_err(runs[0], want) <= TOL
+    if empty_balls:
+        assert int(counts.max()) > 128
+    idx1 = idx[:, :, 0].contiguous()
+    go1 = torch.randn((b, c, m), generator=gen)
+    runs1 = [capi.gather_points_grad(go1.to(d), idx1.to(d), n) for _ in range(2)]
+    assert torch.equal(runs1[0], runs1[1])
+    assert rel_err(runs1[0], oracle_ext.gather_points_grad(go1, idx1, n)) <= TOL
+
+
 @pytest.mark.parametrize("kind,b,n,m", [("room", 2, 512, 256), ("room", 8, 1024, 512), ("adv", 2, 600, 150),
                                         ("uniform", 1, 70, 2), ("uniform", 1, 5, 1), ("room", 1, 3000, 2500)])
 def test_three_nn_exact_and_interpolate(kind, b, n, m):
