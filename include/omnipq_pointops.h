@@ -83,6 +83,14 @@ int omnipq_fps_init(void);
  * per thread -- 3 workgroups per 40 000-point scene instead of 5, ~40 % longer rounds, identical indices -- until
  * omnipq_fps_footprint(0).  For a chain that runs underneath other work and ends before it. */
 void omnipq_fps_footprint(int small);
+/* omnipq_fps_pruned(1), CALLING THREAD only: clouds of more than 8192 points are sampled by csrc/fps.hip: fps_pruned_kernel
+ * (points in Morton order, 20 480 per workgroup, a round visits only the cells of 256 points whose running distances the new
+ * pick can change; same indices and the same `temp`).  Exact but slower than the default kernels on MI355X (measured: the
+ * note in fps.hip); 0 restores the default. */
+void omnipq_fps_pruned(int on);
+/* {cells visited, workgroup-rounds} of the pruned sampling launches since the last call: visited / rounds = cells of 256
+ * points a workgroup updates per round (of its 80).  Synchronises the device and resets the counters (tools/bench_fps.py). */
+int omnipq_fps_pruned_stats(unsigned long long *out2);
 
 /* replaces gather_points_kernel_wrapper (sampling.cpp:11-13).
  *   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */

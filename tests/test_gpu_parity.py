@@ -84,6 +84,27 @@ def test_fps_small_footprint_variant_gives_the_same_indices(kind, b, n, m):
     assert torch.equal(fast, got) and torch.equal(tmp, tmp_fast)
 
 
+@pytest.mark.parametrize("kind,b,n,m", [("room", 2, 20000, 600), ("room", 8, 40000, 2048), ("adv", 2, 8193, 400),
+                                        ("uniform", 2, 80000, 300), ("room", 1, 50000, 700)])
+def test_fps_pruned_rounds_equal_the_exhaustive_kernels(kind, b, n, m):
+    """csrc/fps.hip: fps_pruned_kernel (omnipq_fps_pruned(1): a round visits only the cells the new pick can change) against
+    the default kernels that visit every point every round and against the oracle: the same indices and running distances."""
+    xyz = cloud(kind, 9, b, n)
+    want, want_tmp = capi.fps(xyz.to(dev()), m)
+    capi.lib().omnipq_fps_pruned(1)
+    try:
+        got, tmp = capi.fps(xyz.to(dev()), m)
+        import ctypes as C
+        st = (C.c_ulonglong * 2)()
+        assert capi.lib().omnipq_fps_pruned_stats(st) == 0
+    finally:
+        capi.lib().omnipq_fps_pruned(0)
+    assert st[1] > 0 and st[0] < 80 * st[1]           # the pruned kernel ran, and it skipped cells
+    assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[:3].tolist()}"
+    assert torch.equal(tmp, want_tmp)
+    assert torch.equal(got.cpu(), oracle_ext.furthest_point_sampling(xyz, m))
+
+
 def test_fps_all_points_inside_skip_ball_yields_zeros():
     xyz = torch.rand(2, 500, 3) * 0.01            # |p|^2 <= 1e-3 everywhere
     got, _ = capi.fps(xyz.to(dev()), 40)
