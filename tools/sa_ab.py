@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--extra", type=int, default=0)
     ap.add_argument("--flag", default="XYZGEN", help="sa_fused module switch to A/B (XYZGEN, AFFINE_OPERANDS, POOL_EPILOGUE, ...)")
     ap.add_argument("--values", nargs=2, default=None, help="the two values to compare instead of False / True (ints)")
+    ap.add_argument("--capi", default=None, help="instead of a module switch: a C-ABI setter fn(int) called with the two --values")
     ap.add_argument("--per-stage", action="store_true", help="after the A/B, split the default path's time by stage")
     args = ap.parse_args()
     import pointnet2_utils
@@ -72,9 +73,15 @@ def main():
             return [o.detach().float().clone() for o in outs], grads
 
     modes = (False, True) if args.values is None else tuple(int(v) for v in args.values)
+    def setmode(mode):
+        if args.capi:
+            getattr(sa_fused._lib, args.capi)(int(mode))
+        else:
+            setattr(sa_fused, args.flag, mode)
+
     res = {}
     for mode in modes:
-        setattr(sa_fused, args.flag, mode)
+        setmode(mode)
         # running statistics must start equal in both modes
         torch.manual_seed(1)
         for m in net.modules():
@@ -102,7 +109,7 @@ def main():
 
     ext = pointnet2_utils._ext
     for mode in modes:
-        setattr(sa_fused, args.flag, mode)
+        setmode(mode)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -116,7 +123,7 @@ def main():
         for name, _, e0, e1 in sink:
             tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
         sa_ms = sum(v for k, v in tot.items() if k.endswith("@sa")) / args.steps
-        print(f"{args.flag}={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
+        print(f"{args.capi or args.flag}={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
         for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]:
             print(f"    {k:50s} {v / args.steps * 1e3:9.1f} us/step")
 
