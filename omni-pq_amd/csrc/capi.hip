@@ -76,32 +76,60 @@ __global__ __launch_bounds__(256) void sa_plan_count_kernel(long long balls, int
   if (b < balls && l == 0) gcount[b] = (cnt + gs) / gs;   // ceil((cnt + 1) / gs)
 }
 
-// exclusive scan of the group counts (one workgroup: up to a few 10^4 balls), rows in use = gs * total
+// exclusive scan of the group counts (one workgroup: up to a few 10^4 balls), rows in use = gs * total.  A thread owns `per`
+// consecutive balls (all its loads requested before the first add), the 1024 thread totals are scanned with wave shuffles
+// (6 steps) and one pass over the 16 wave totals -- two barriers instead of the twenty of a Hillis-Steele scan over LDS
+// (19 us per stage before, measured inside the replayed step).
 __global__ __launch_bounds__(1024) void sa_plan_scan_kernel(int balls, int gs, const int *__restrict__ gcount, int *__restrict__ goff,
                                                            int *__restrict__ rows_dev) {
-  __shared__ int s_part[1024];
-  const int tid = (int)threadIdx.x;
+  constexpr int kMaxPer = 16;                      // 16 384 balls per launch without the tail loop below
+  __shared__ int s_wave[16];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (balls + 1023) / 1024;
   const int b0 = tid * per;
+  int v[kMaxPer];
   int sum = 0;
-  for (int i = 0; i < per; ++i) sum += (b0 + i < balls) ? gcount[b0 + i] : 0;
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {                  // Hillis-Steele inclusive scan of the 1024 partials
-    const int v = tid >= d ? s_part[tid - d] : 0;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
+  if (per <= kMaxPer) {
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) v[i] = (i < per && b0 + i < balls) ? gcount[b0 + i] : 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) sum += v[i];
+  } else {
+    for (int i = 0; i < per; ++i) sum += (b0 + i < balls) ? gcount[b0 + i] : 0;
   }
-  int run = s_part[tid] - sum;
-  for (int i = 0; i < per; ++i)
-    if (b0 + i < balls) {
-      goff[b0 + i] = run;
-      run += gcount[b0 + i];
-    }
-  if (tid == 1023) {
-    goff[balls] = s_part[1023];
-    rows_dev[0] = gs * s_part[1023];
+  int incl = sum;                                  // inclusive scan of the thread totals within the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int t = s_wave[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  int run = base + incl - sum;
+  if (per <= kMaxPer) {
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+      if (i < per && b0 + i < balls) {
+        goff[b0 + i] = run;
+        run += v[i];
+      }
+  } else {
+    for (int i = 0; i < per; ++i)
+      if (b0 + i < balls) {
+        goff[b0 + i] = run;
+        run += gcount[b0 + i];
+      }
+  }
+  if (tid == 0) {
+    goff[balls] = total;
+    rows_dev[0] = gs * total;
   }
 }
 
