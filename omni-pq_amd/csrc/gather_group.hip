@@ -140,6 +140,39 @@ __global__ __launch_bounds__(256) void scatter_big_runs_kernel(int c, int n, int
   }
 }
 
+// Few positions per scene (the model's own calls: gather of 1024 / 256 sampled points): no sort -- the scene's indices sit in LDS,
+// thread p owns source point idx[p] iff no earlier position names it, and an owner adds the positions that name its point in
+// ascending order (two scans of <= kSmallP LDS words per thread; one launch, ~the time of the atomic kernel it replaces).
+constexpr int kSmallP = 4096;
+__global__ __launch_bounds__(1024) void scatter_small_kernel(int c, int n, int P, const float *__restrict__ grad_out,
+                                                            const int *__restrict__ idx, float *__restrict__ grad_points) {
+  __shared__ int s_idx[kSmallP];
+  const int scene = (int)blockIdx.y, c0 = (int)blockIdx.x * kCT;
+  for (int p = (int)threadIdx.x; p < P; p += 1024) s_idx[p] = idx[(size_t)scene * P + p];
+  __syncthreads();
+  const int cend = c - c0 < kCT ? c - c0 : kCT;
+  const float *src = grad_out + ((size_t)scene * c + c0) * P;
+  for (int p = (int)threadIdx.x; p < P; p += 1024) {
+    const int a = s_idx[p];
+    bool first = true;
+    for (int q = 0; q < p; ++q) first &= s_idx[q] != a;
+    if (!first) continue;
+    float acc[kCT];
+#pragma unroll
+    for (int l = 0; l < kCT; ++l) acc[l] = l < cend ? src[(size_t)l * P + p] : 0.f;
+    for (int q = p + 1; q < P; ++q)
+      if (s_idx[q] == a) {
+#pragma unroll
+        for (int l = 0; l < kCT; ++l)
+          if (l < cend) acc[l] += src[(size_t)l * P + q];
+      }
+    float *dst = grad_points + ((size_t)scene * c + c0) * n + a;
+#pragma unroll
+    for (int l = 0; l < kCT; ++l)
+      if (l < cend) dst[(size_t)l * n] += acc[l];
+  }
+}
+
 // grow-only scratch of the calling thread's sorts (keys / values in and out, hipCUB's temporary storage, the long-run list);
 // growth allocates -- a warm-up call at the largest size makes later calls capture-safe, as for the sampling workspace
 struct ScatterScratch {
@@ -179,6 +212,11 @@ static int launch_scatter(int b, int c, int n, int P, const float *grad_out, con
   if (b == 0 || c == 0 || P == 0) return OMNIPQ_OK;
   if (!grad_out || !idx || !grad_points || n == 0) return OMNIPQ_EINVAL;
   if (b > 65535 || (c + kCT - 1) / kCT > 65535) return OMNIPQ_ETOOLARGE;
+  if (P <= kSmallP) {
+    scatter_small_kernel<<<dim3((c + kCT - 1) / kCT, b), 1024, 0, stream>>>(c, n, P, grad_out, idx, grad_points);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
   const long long total = (long long)b * P;
   if (total > 0x7FFFFFFFll || (long long)b * n > 0xFFFFFFFFll) return OMNIPQ_ETOOLARGE;
   int bits = 1;

@@ -29,6 +29,8 @@ _ext = pointnet2_utils._load_ext()      # always the product binding, whatever p
 _lib = _ext._lib
 E16 = _ext.E16                         # the 16-bit element type the hand-written kernels run in (bfloat16 / float16)
 _lib.omnipq_gemm_tn_workspace_floats.restype = ctypes.c_longlong
+if os.environ.get("OMNIPQ_TN_DEBUG"):          # A/B runs only: bit 0 = the register-prefetch program of the weight-gradient kernels
+    _lib.omnipq_tn_debug(int(os.environ["OMNIPQ_TN_DEBUG"]))
 _lib.omnipq_gemm_nt_stats_workspace_floats.restype = ctypes.c_longlong
 _lib.omnipq_gemm_nt_workspace_floats.restype = ctypes.c_longlong
 
@@ -277,6 +279,7 @@ _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 # ROW_PLAN = False: every row is computed.
 ROW_PLAN = True
 PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
+PLAN_MIN_ROWS = 1 << 18         # grouped rows from which a stage is planned
 row_plan_uses = 0
 row_plan_last = {}              # P of the stage -> its latest _Plan (bench.py reads the rows in use from it)
 _lib.omnipq_sa_row_plan.restype = None
@@ -287,7 +290,7 @@ def row_plan_ok(training, S, P, L, needs_input_grad, pooled):
     and with the ball extrema in the last GEMM (the kernels that know the plan), no gradient into the stage's coordinates (the
     centre-gradient kernel does not know it; feature gradients: the caller also asks for at most 8192 source points, the CSR
     builders that do)"""
-    return ROW_PLAN and training and S in (32, 64, 128) and P >= (1 << 18) and P % 128 == 0 and L >= 2 and \
+    return ROW_PLAN and training and S in (32, 64, 128) and P >= PLAN_MIN_ROWS and P % 128 == 0 and L >= 2 and \
         AFFINE_OPERANDS and POOL_EPILOGUE and _FOLD_SMALL and pooled and not needs_input_grad
 
 
