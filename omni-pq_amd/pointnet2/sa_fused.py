@@ -279,7 +279,8 @@ _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 # ROW_PLAN = False: every row is computed.
 ROW_PLAN = True
 PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
-PLAN_MIN_ROWS = 1 << 18         # grouped rows from which a stage is planned
+PLAN_MIN_ROWS = 1 << 17         # grouped rows from which a stage is planned (BASELINE configs[3], batch 4: sa2 has 2^17 --
+                                # SA stages 2.65 -> 2.28 ms there; below that the statistics take the direct-atomics paths)
 row_plan_uses = 0
 row_plan_last = {}              # P of the stage -> its latest _Plan (bench.py reads the rows in use from it)
 _lib.omnipq_sa_row_plan.restype = None

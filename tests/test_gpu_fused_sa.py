@@ -892,7 +892,8 @@ def test_build_csr_groups_every_position_under_its_source_point(B, n, m, s):
 
 
 @pytest.mark.parametrize("group", [8, 16])
-@pytest.mark.parametrize("case", ["coordinates_only", "six_extra_channels", "deferred_grouped", "sa2_feature_gradient"])
+@pytest.mark.parametrize("case", ["coordinates_only", "six_extra_channels", "deferred_grouped", "sa2_feature_gradient",
+                                  "sa2_batch_4"])
 def test_row_plan_equals_the_full_stage(case, group, monkeypatch):
     """sa_fused.ROW_PLAN: the rows of a ball behind its real neighbours hold copies of the ball's first row (ball_query pads with
     the first neighbour); a planned stage keeps whole groups of `group` rows (sa_fused.PLAN_GROUP) up to the last real
@@ -907,14 +908,14 @@ def test_row_plan_equals_the_full_stage(case, group, monkeypatch):
     cin = 6 if case == "six_extra_channels" else 0
     spec = dict(npoint=2048, radius=0.2, nsample=64, mlp=[cin, 128, 128, 256], use_xyz=True, normalize_xyz=True)
     B, n = 2, 40000
-    if case == "sa2_feature_gradient":
+    if case in ("sa2_feature_gradient", "sa2_batch_4"):
         # the backbone's sa2 (nsample 32: two 16-row groups per ball at most) with a gradient into its input features: the
         # data-gradient GEMM of the first layer and the CSR scatter run on the compact rows too
-        cin, B, n = 256, 8, 2048
+        cin, B, n = 256, (4 if case == "sa2_batch_4" else 8), 2048         # batch 4: 2^17 grouped rows, the smallest planned stage
         spec = dict(npoint=1024, radius=0.4, nsample=32, mlp=[cin, 256, 256, 512], use_xyz=True, normalize_xyz=True)
     xyz = synth.make_clouds(77, B, n, kind="room").to(dev())
     feats = procedural_tensor("plan.feats", (B, cin, n), torch.float32).to(dev()) if cin else None
-    if case == "sa2_feature_gradient":
+    if case in ("sa2_feature_gradient", "sa2_batch_4"):
         feats = (feats * 0.5).requires_grad_(True)
     monkeypatch.setenv("OMNIPQ_SA", "fused")
     monkeypatch.setattr(sa_fused, "PLAN_GROUP", group)
