@@ -28,8 +28,6 @@ struct StripArgs {
   int M, N, K;
   int lda, ldb, ldc;
   int strips, n_tiles;
-  const int *rows_dev;            // row plan of the stage (common.h: RowPlan): rows in use, or NULL
-  const unsigned char *row_w;     // ... and their weights in the statistics
   int debug;                      // tools/bench_strip.py --ablate: 1 no C stores, 2 no weight fetches after the first two,
                                   // 4 no strip load, 8 no MFMAs (0 in the product path)
 };
@@ -48,7 +46,7 @@ struct StripAffine {
 };
 
 struct StripPool {
-  int s;                          // rows per ball (16, 32 or 64; 8: the groups of a row plan); 0: none
+  int s;                          // rows per ball (16, 32 or 64); 0: none
   e16_t *ymax, *ymin;             // [M / s][N]
   unsigned char *amax, *amin;     // [M / s][N]
 };
@@ -106,7 +104,7 @@ __device__ __forceinline__ void strip_wait_dyn(int n) {
 #undef OMNIPQ_W
 }
 
-template <int NKF, bool AFF, bool STATS, bool POOL, bool PLAN = false>
+template <int NKF, bool AFF, bool STATS, bool POOL>
 __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e16_t *__restrict__ A,
                                                             const e16_t *__restrict__ B, e16_t *__restrict__ C,
                                                             float *__restrict__ part, StripAffine aff, StripPool pool) {
@@ -123,13 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
   const int wm = wave >> 1, wn = wave & 1;
   const int strip = (int)blockIdx.x;
   const int m0 = strip * SBM;
-  // row plan (common.h: RowPlan): the rows in use live in device memory, the grid was sized for all g.M rows
-  const int Meff = PLAN ? *g.rows_dev : g.M;
-  if (PLAN && m0 >= Meff) {
-    if (STATS)                                    // the reduction that follows reads this strip's two partial rows
-      for (int c = tid; c < 4 * g.N; c += 256) part[(size_t)strip * 4 * g.N + c] = 0.f;
-    return;
-  }
+  const int Meff = g.M;                           // (planned stages, common.h: RowPlan, run on the tile kernels)
 
   if ((g.debug >> 8) && strip >= 256 && strip < 512) {
     // experiment: the second residency slot of every CU starts late by (debug >> 8) x 8128 cycles
@@ -249,19 +241,6 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
   int q = 0;
 
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
-  // PLAN: the statistics weights of this lane's accumulator rows, as pairs (row r, r + 1) per block and register pair
-  float wrow[2][8][2];
-  if (PLAN) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const int r = 2 * h;
-        const int gr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
-        wrow[i][h][0] = gr < Meff ? (float)g.row_w[gr] : 0.f;
-        wrow[i][h][1] = gr + 1 < Meff ? (float)g.row_w[gr + 1] : 0.f;
-      }
-  }
   const bool odd = lane & 1;
   const unsigned pair_sel = odd ? 0x03020706u : 0x05040100u;
   unsigned *const ct32 = reinterpret_cast<unsigned *>(cpatch + wave * (64 * SCPITCH * 2));
@@ -358,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const unsigned hbit = (unsigned)crow0;
     const int s_ = POOL ? pool.s : 16;
-    const int gstep = s_ >> 4;                                        // (0 for groups of 8 rows: emitted quad by quad)
+    const int gstep = s_ >> 4;
     const bool upper = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -376,14 +355,8 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
             const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
             cbase[(i * 32 + (r & 3) + 8 * (r >> 2)) * (SCPITCH / 2) + j * 16] = __builtin_amdgcn_perm(other, mine, pair_sel);
             if (STATS) {
-              if (PLAN) {                            // weighted: a ball's first row stands for its dropped copies too
-                const float w0 = wrow[i][r >> 1][0], w1 = wrow[i][r >> 1][1];
-                cs += __builtin_fmaf(w0, v0, w1 * v1);
-                cq = __builtin_fmaf(w0 * v0, v0, __builtin_fmaf(w1 * v1, v1, cq));
-              } else {
-                cs += v0 + v1;
-                cq = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, cq));
-              }
+              cs += v0 + v1;
+              cq = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, cq));
             }
             if (POOL) {
               const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, mine) >> 15);
@@ -397,38 +370,6 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
           if (POOL) {
             kmx[2 * i + gq] = mx ^ hbit;
             kmn[2 * i + gq] = mn | hbit;
-          }
-          if (POOL && PLAN && s_ == 8) {
-            // groups of 8 rows (row plan, common.h: RowPlan): rows 0-3 one register quad of the lower lane half, rows 4-7 of
-            // the upper half -- the quad's keys again, with the row within the group in the low 3 bits
-#pragma unroll
-            for (int h8 = 0; h8 < 2; ++h8) {
-              unsigned qx = 0u, qn = 0xffffffffu;
-#pragma unroll
-              for (int r = 8 * gq + 4 * h8; r < 8 * gq + 4 * h8 + 4; r += 2) {
-                const unsigned mine = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
-                const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, mine) >> 15);
-                const unsigned o = mine ^ (sg | 0x80008000u);
-                const unsigned row = (unsigned)(r & 3);
-                const unsigned olo = o << 16, ohi = o & 0xffff0000u;
-                qx = max(max(qx, olo | (7u - row)), ohi | (6u - row));
-                qn = min(min(qn, olo | row), ohi | (row + 1u));
-              }
-              unsigned a = qx ^ hbit, b = qn | hbit;
-              a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
-              b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
-              const unsigned key = upper ? b : a;
-              const unsigned o = key >> 16;
-              const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
-              const unsigned low = key & 7u;
-              const unsigned char row = (unsigned char)(upper ? low : 7u - low);
-              const int r0 = wm * 64 + i * 32 + (2 * gq + h8) * 8, gc = n0 + wn * 64 + j * 32 + ccol;
-              if (m0 + r0 < g.M && gc < g.N) {
-                const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
-                (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
-                (upper ? pool.amin : pool.amax)[oidx] = row;
-              }
-            }
           }
         }
       if (STATS) {
@@ -455,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(StripArgs g, const e
         }
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
-          if ((PLAN && s_ == 8) || gi % gstep) continue;
+          if (gi % gstep) continue;
           unsigned a = kmx[gi], b = kmn[gi];
           a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
           b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
@@ -498,10 +439,10 @@ __global__ __launch_bounds__(256) void strip_partial_reduce_kernel(int rows, int
                             (((double)acc[4] + (double)acc[5]) + ((double)acc[6] + (double)acc[7])));
 }
 
-template <int NKF, bool AFF, bool STATS, bool POOL, bool PLAN = false>
+template <int NKF, bool AFF, bool STATS, bool POOL>
 static int launch_strip(const StripArgs &g, const void *A, const void *B, void *C, float *part, const StripAffine &aff,
                         const StripPool &pool, hipStream_t stream) {
-  auto kern = gemm_strip_kernel<NKF, AFF, STATS, POOL, PLAN>;
+  auto kern = gemm_strip_kernel<NKF, AFF, STATS, POOL>;
   constexpr int lds = StripGeom<NKF>::LDS_BYTES;
   static const hipError_t prepared =
       hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -514,15 +455,6 @@ static int launch_strip(const StripArgs &g, const void *A, const void *B, void *
 template <int NKF>
 static int dispatch_strip(const StripArgs &g, const void *A, const void *B, void *C, float *part, bool has_aff,
                           const StripAffine &aff, bool stats, const StripPool &pool, hipStream_t stream) {
-  if (g.rows_dev) {                               // row plan: the statistics variants (a planned layer always has statistics)
-    if (!stats) return OMNIPQ_EINVAL;
-    if (has_aff) {
-      if (pool.s) return launch_strip<NKF, true, true, true, true>(g, A, B, C, part, aff, pool, stream);
-      return launch_strip<NKF, true, true, false, true>(g, A, B, C, part, aff, pool, stream);
-    }
-    if (pool.s) return launch_strip<NKF, false, true, true, true>(g, A, B, C, part, aff, pool, stream);
-    return launch_strip<NKF, false, true, false, true>(g, A, B, C, part, aff, pool, stream);
-  }
   if (has_aff) {
     if (pool.s) return launch_strip<NKF, true, true, true>(g, A, B, C, part, aff, pool, stream);
     if (stats) return launch_strip<NKF, true, true, false>(g, A, B, C, part, aff, pool, stream);
@@ -602,7 +534,7 @@ extern "C" int omnipq_gemm_strip_e16(int M, int N, int K, const void *A, int lda
   }
   StripPool pool{};
   if (s) {
-    if (!sums || !(s == 8 || s == 16 || s == 32 || s == 64) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
+    if (!sums || !(s == 16 || s == 32 || s == 64) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
     pool.s = s;
     pool.ymax = (e16_t *)ymax;
     pool.ymin = (e16_t *)ymin;
@@ -610,15 +542,10 @@ extern "C" int omnipq_gemm_strip_e16(int M, int N, int K, const void *A, int lda
     pool.amin = amin;
   }
   if (sums && !workspace) return OMNIPQ_EINVAL;
-  StripArgs g{M, N, K, lda, ldb, ldc, (M + SBM - 1) / SBM, (N + SBN - 1) / SBN, nullptr, nullptr, g_strip_debug};
-  {
-    const RowPlan &rp = row_plan();               // the calling thread's row plan, if it was made for this many rows
-    if (rp.rows_dev && rp.rows == M) {
-      if (s != 0 && s != rp.gs) return OMNIPQ_EINVAL;  // a planned stage records its ball extrema per group of the plan
-      g.rows_dev = rp.rows_dev;
-      g.row_w = rp.row_w;
-    }
-  }
+  // planned stages (common.h: RowPlan) run on the tile kernels: with the row weights on top of the register-resident strip the
+  // planned instantiations spilled 40-130 registers (round 4), and the shapes the strip wins on do not occur in a planned stage
+  if (row_plan().rows_dev && row_plan().rows == M) return OMNIPQ_EINVAL;
+  StripArgs g{M, N, K, lda, ldb, ldc, (M + SBM - 1) / SBM, (N + SBN - 1) / SBN, g_strip_debug};
   int rc;
   if (K == 128)
     rc = dispatch_strip<8>(g, A, B, C, workspace, has_aff, aff, sums != nullptr, pool, (hipStream_t)stream);
