@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=40000)
+    ap.add_argument("--cloud", default="room", choices=["room", "uniform"],
+                    help="synthetic scenes: room (walls / floor / furniture surfaces, as a depth scan; the benchmark's) or points "
+                         "uniform in the volume (fills the balls: the row plan of the SA stages saves less, DESIGN 4.2)")
     ap.add_argument("--extra-channels", type=int, default=0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="GEMM/MLP compute dtype (xyz, indices, BN statistics stay f32); bf16 and fp16 run the hand-written "
@@ -716,7 +719,7 @@ def main():
 
     # a small pool of distinct batches, resident in HBM before anything is timed
     pool = [synth.make_clouds(100 + i, args.batch, args.points, extra_channels=args.extra_channels,
-                              kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
+                              kind=args.cloud, first_scene=rank * args.batch).to(dev) for i in range(3)]
 
     teacher = teacher_pool = None
     if args.mean_teacher:
@@ -726,7 +729,7 @@ def main():
             p.detach_()                                   # ... train.py:340-342
         teacher.train()
         teacher_pool = [synth.make_clouds(200 + i, args.batch, args.points, extra_channels=args.extra_channels,
-                                          kind="room", first_scene=rank * args.batch).to(dev) for i in range(3)]
+                                          kind=args.cloud, first_scene=rank * args.batch).to(dev) for i in range(3)]
     labels_pool = None
     if args.loss == "supervised":
         LossConfig.mean_size_arr = mean_size_arr()
@@ -849,7 +852,7 @@ def main():
                                ("DistributedDataParallel, eager" if ddp else f"{dp_counts}, eager launches") +
                                (" (RCCL graph probe passed)" if probe_ok else " (RCCL graph probe failed or skipped)"))),
             "config": {"workload": f"{workload_name(args)}: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
-                                   f"room scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
+                                   f"{args.cloud} scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,
                        "parallelism": f"dp{world}",
                        "loss": ("sum of output means (SURVEY 8d)" if args.loss == "means" else
