@@ -16,6 +16,10 @@
 
 #include "common.h"
 
+// omnipq_tn_debug: bit 0: the register-prefetch workgroup program (tn_tile) instead of the LDS-DMA one (tn_tile_dma); bits
+// 1-3 ablations; bits 8-15: workgroup target of the grouped launch in units of 256.  A/B timing only.
+static int g_tn_debug = 0;
+
 namespace omnipq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -626,8 +630,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int n4, int slabs, int
 
 }  // namespace omnipq
 
-// bit 0: the register-prefetch workgroup program (tn_tile) instead of the LDS-DMA one (tn_tile_dma); for A/B timing only
-static int g_tn_debug = 0;
 extern "C" void omnipq_tn_debug(int flags) { g_tn_debug = flags; }
 // workgroups of the grouped kernel (which: 0 plain / 1 affine, + 2 for the register-prefetch program) one CU holds
 extern "C" int omnipq_tn_occupancy(int which) {
@@ -774,7 +776,8 @@ static int tng_chunk(int nprob, const omnipq_tn_problem_ *pr) {
   // 40 / 75 / 150 / 300 K-steps = ~8000 / 4100 / 2050 / 1030 workgroups: 791 / 746 / 702 / 761 us)
   int max_p = 0;
   for (int i = 0; i < nprob; ++i) max_p = pr[i].P > max_p ? pr[i].P : max_p;
-  const long long target = max_p >= 65536 ? 2048 : 8192;
+  long long target = max_p >= 65536 ? 2048 : 8192;
+  if ((g_tn_debug >> 8) & 0xFF) target = 256LL * ((g_tn_debug >> 8) & 0xFF);      // (A/B runs: tools/bench_tn_grouped.py --target)
   long long steps = (tile_steps + target - 1) / target;
   if (steps < 16) steps = 16;
   if (steps > 1024) steps = 1024;

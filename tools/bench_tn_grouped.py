@@ -84,6 +84,21 @@ def main():
         torch.cuda.synchronize()
         res[mode] = [(_read(pr[i].out, pr[i].out_rows * pr[i].out_ld, dev) - (snap0[i] if pr[i].flags & 1 else 0)) for i in range(n)]
     sa_fused._lib.omnipq_tn_debug(0)
+    # workgroup target of the grouped launch (slabs): the default against fewer / more
+    for tgt in (4, 6, 8, 12, 16, 24):
+        sa_fused._lib.omnipq_tn_debug(tgt << 8)
+        ws2 = torch.empty((int(sa_fused._lib.omnipq_gemm_tn_grouped_workspace_floats(n, probs)),), device=dev)
+        for _ in range(3):
+            real_call(orig, items[0][0], n, probs, sa_fused._p(ws2))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            real_call(orig, items[0][0], n, probs, sa_fused._p(ws2))
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"workgroup target {256 * tgt:5d}: {e0.elapsed_time(e1) / args.reps * 1e3:.1f} us per call")
+    sa_fused._lib.omnipq_tn_debug(0)
     worst = 0.0
     for i in range(n):
         a, b = res[1][i], res[0][i]
