@@ -309,6 +309,25 @@ def pmc_traffic(kind):
         return None, None
 
 
+def gpu_stall_cycles(dev, ms):
+    """argument of torch.cuda._sleep for a stall of about `ms` milliseconds on this device (calibrated once), 0 if unavailable"""
+    if not hasattr(torch.cuda, "_sleep"):
+        return 0
+    try:
+        probe = 10_000_000
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(probe)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        per_ms = probe / max(e0.elapsed_time(e1), 1e-3)
+        return int(min(per_ms * ms, 2e9))
+    except Exception:
+        return 0
+
+
 def replay_timing(args):
     """The SA stage's kernel time INSIDE the replayed step from the newest committed `profiles/r*_sa_stage_replay_timing.json`
     (tools/sa_replay_timing.py over a `rocprofv3 --kernel-trace` of `bench.py --sa-markers`), if it was taken on this
@@ -799,15 +818,23 @@ def main():
             eager_step(1 + i)
         fence()
         eager_ms = (time.perf_counter() - te) / 3 * 1e3
+        # Every timed step starts behind a device-side stall as long as the host needs to enqueue the step (x 1.5): the
+        # launches then wait in the queue and run back to back, as they do in a replay.  Without it an event pair also
+        # measures whatever the host took between recording the first event and launching the kernel -- on a busy host
+        # (eager step 36 instead of 24 ms) the same kernels read 3.32 instead of 3.10 ms for the SA stages.
+        stall = gpu_stall_cycles(dev, eager_ms * 1.5)
         sink = []
         ext.set_timing_sink(sink)
         timing_steps = min(args.steps, 5)
         for i in range(timing_steps):
+            if stall:
+                torch.cuda._sleep(stall)
             eager_step(1 + i)
-        fence()
+            fence()
         ext.set_timing_sink(None)
         timing_note = (f"events around every C-ABI launch in {timing_steps} eager steps run right after the timed "
-                       + ("hipGraph replays (a replay cannot host events)" if use_graph else "steps"))
+                       + ("hipGraph replays (a replay cannot host events)" if use_graph else "steps")
+                       + (", each enqueued behind a device-side stall so that the launches run back to back" if stall else ""))
     assert torch.isfinite(loss.detach()).item(), "non-finite loss"
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

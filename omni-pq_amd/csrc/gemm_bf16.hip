@@ -219,15 +219,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   static_assert(!PLAN || (T == 128 && !OUT_F32 && !KRES), "row plans: 128 x 128 tiles with e16 output");
   constexpr bool planned = PLAN;                 // (the launchers pick the PLAN instantiation iff g.rows_dev is set)
   const int Meff = planned ? *g.rows_dev : g.M;
-  if (planned && m0 >= Meff) {
-    // nothing to do -- but the reductions that follow read this tile's partial sums
-    if (STATS == 2 || STATS == 4) {
-      const int col = tid % T;
-      for (int which = tid / T; which < NS; which += 256 / T)
-        if (n0 + col < g.N) reinterpret_cast<float *>(stats_out)[((size_t)mt * NS + which) * g.N + n0 + col] = 0.f;
-    }
-    return;
-  }
+  if (planned && m0 >= Meff) return;            // (partial_reduce_kernel reads the partial rows of the tiles in use only)
 
   // staging assignment: chunk q = tid + i*256 -> row q>>2, 16-byte piece q&3
   // Rows past M (or N) are clamped to the last valid row instead of being zero-filled: whatever they
@@ -847,10 +839,15 @@ namespace omnipq {
 #endif
 
 // sums[j] += sum over the M-tiles of part[t][j],  j in [0, 2N): grid (ceil(2N/256), slabs)
+// rows_dev (row plan, common.h: RowPlan) or NULL: only the tiles that hold rows in use wrote their partial row
 __global__ __launch_bounds__(256) void partial_reduce_kernel(int m_tiles, int n2, const float *__restrict__ part,
-                                                            double *__restrict__ sums) {
+                                                            double *__restrict__ sums, const int *__restrict__ rows_dev) {
   const int j = (int)(blockIdx.x * 256 + threadIdx.x);
   if (j >= n2) return;
+  if (rows_dev) {
+    const int used = (*rows_dev + GBM - 1) / GBM;
+    m_tiles = used < m_tiles ? used : m_tiles;
+  }
   const int per = (m_tiles + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t0 = (int)blockIdx.y * per;
   int t1 = t0 + per;
@@ -1124,7 +1121,7 @@ extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int 
   if (slabs > 128) slabs = 128;
   if (slabs < 1) slabs = 1;
   partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums);
+                                                                                    sums, g.rows_dev);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1174,7 +1171,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
   if (slabs > 128) slabs = 128;
   if (slabs < 1) slabs = 1;
   partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums);
+                                                                                    sums, g.rows_dev);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1302,7 +1299,7 @@ extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A,
   if (slabs > 128) slabs = 128;
   if (slabs < 1) slabs = 1;
   partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums);
+                                                                                    sums, g.rows_dev);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1349,7 +1346,7 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
   if (slabs > 128) slabs = 128;
   if (slabs < 1) slabs = 1;
   partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums);
+                                                                                    sums, g.rows_dev);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1407,7 +1404,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
   partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums);
+                                                                                    sums, g.rows_dev);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -1443,7 +1440,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, 
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;
   partial_reduce_kernel<<<dim3((5 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 5 * N, workspace,
-                                                                                    sums5);
+                                                                                    sums5, g.rows_dev);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -454,16 +454,35 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, i
     float mu[8], is[8];
     load8f(mean + cg * 8, mu);
     load8f(invstd + cg * 8, is);
-    for (long long bm = (long long)blockIdx.x * rpb + rsub; bm < BM; bm += (long long)gridDim.x * rpb) {
-      float o[8], gg[8], y[8];
-      unpack8(*reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + cg * 8), o);
-      unpack8(*reinterpret_cast<const uint4 *>(ysel + (size_t)bm * C + cg * 8), y);
-      load8f(g_out + (size_t)bm * C + cg * 8, gg);
+    // four balls per iteration, their sixteen loads requested before the first is used: with at most 128 workgroups (the
+    // atomics of the fold) a thread walks 16-32 balls, and one ball per iteration was one memory round trip per ball
+    const long long step = (long long)gridDim.x * rpb;
+    for (long long bm0 = (long long)blockIdx.x * rpb + rsub; bm0 < BM; bm0 += 4 * step) {
+      uint4 ro[4], ry[4];
+      float4 g0[4], g1[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float g = o[e] > 0.f ? gg[e] : 0.f;
-        u[e] += g;
-        v[e] = __builtin_fmaf(g, (y[e] - mu[e]) * is[e], v[e]);
+      for (int q = 0; q < 4; ++q) {
+        const long long bm = bm0 + q * step;
+        if (bm < BM) {
+          ro[q] = *reinterpret_cast<const uint4 *>(out_pm + (size_t)bm * C + cg * 8);
+          ry[q] = *reinterpret_cast<const uint4 *>(ysel + (size_t)bm * C + cg * 8);
+          g0[q] = *reinterpret_cast<const float4 *>(g_out + (size_t)bm * C + cg * 8);
+          g1[q] = *reinterpret_cast<const float4 *>(g_out + (size_t)bm * C + cg * 8 + 4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (bm0 + q * step >= BM) continue;
+        float o[8], y[8];
+        unpack8(ro[q], o);
+        unpack8(ry[q], y);
+        const float gg[8] = {g0[q].x, g0[q].y, g0[q].z, g0[q].w, g1[q].x, g1[q].y, g1[q].z, g1[q].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = o[e] > 0.f ? gg[e] : 0.f;
+          u[e] += g;
+          v[e] = __builtin_fmaf(g, (y[e] - mu[e]) * is[e], v[e]);
+        }
       }
     }
   }
