@@ -136,7 +136,8 @@ int omnipq_gemm_nt_e16_bnaffine(int M, int N, int K, const void *A, int lda, con
  * attaining each (ymax / ymin e16 [M/s][N], amax / amin uint8 [M/s][N]); once the BatchNorm constants exist,
  * omnipq_sa_pool_select takes relu(a y* + b) with y* = max where a >= 0, min where a < 0 -- the max-pool of
  * pointnet2_modules.py:259-262 over relu(bn(.)) -- and writes what omnipq_sa_pool writes (out_f32 / out_pm / arg) plus
- * ysel = y*; omnipq_sa_pool_bwd_stats_sel is omnipq_sa_pool_bwd_stats reading ysel instead of gathering from Y. */
+ * ysel = y*; omnipq_sa_pool_bwd_stats_sel is omnipq_sa_pool_bwd_stats reading ysel instead of gathering from Y (zeroed != 0:
+ * `sums` is zero on entry, the call does not clear it). */
 int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                                    const float *bias, double *sums, float *workspace, int s, void *ymax, void *ymin,
                                    unsigned char *amax, unsigned char *amin, void *stream);
@@ -159,7 +160,7 @@ int omnipq_sa_pool_select_finalize(long long BM, int C, const void *ymax, const 
                                    void *out_pm, unsigned char *arg, void *ysel, void *stream);
 
 int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
-                                 const float *g_out, const void *out_pm, double *sums, void *stream);
+                                 const float *g_out, const void *out_pm, double *sums, int zeroed, void *stream);
 int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);

@@ -1351,10 +1351,10 @@ extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *y
 }
 
 extern "C" int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
-                                            const float *g_out, const void *out_pm, double *sums, void *stream) {
+                                            const float *g_out, const void *out_pm, double *sums, int zeroed, void *stream) {
   if (BM < 0 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
   if (!ysel || !mean || !invstd || !g_out || !out_pm || !sums) return OMNIPQ_EINVAL;
-  OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (!zeroed) OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
   if (BM == 0) return OMNIPQ_OK;
   // few blocks: each ends with 2C f64 atomics on the same 2C addresses, and with 512 blocks those 262 144 contended
   // atomics cost more (27 us) than streaming the 32 MB of per-ball data (8 us)

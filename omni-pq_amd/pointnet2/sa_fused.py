@@ -1305,11 +1305,12 @@ class FusedSAStage(torch.autograd.Function):
         grads = [None] * (3 * L)
 
         last = layers[-1]
-        sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)     # [S | T | scratch]
         if ctx.ysel is not None:
+            sums = zeros_f64(3, last.C, dev)                                     # [S | T | scratch], zero from the arena
             _call(_lib.omnipq_sa_pool_bwd_stats_sel, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
-                  _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums))
+                  _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), 1)
         else:
+            sums = torch.empty((3, last.C), device=dev, dtype=torch.float64)
             _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
                   _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
         # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce

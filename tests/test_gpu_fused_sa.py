@@ -858,7 +858,7 @@ def test_ball_extrema_epilogue_and_pool_select_equal_the_pooling_pass(M, N, K, S
     capi.ok("omnipq_sa_pool_bwd_stats", 1, BM, S, N, capi.P(Y), capi.P(mean), capi.P(invstd), capi.P(g), capi.P(want16),
             capi.P(got_arg), capi.P(s0))
     capi.ok("omnipq_sa_pool_bwd_stats_sel", ctypes.c_longlong(BM), N, capi.P(ysel), capi.P(mean), capi.P(invstd), capi.P(g),
-            capi.P(got16), capi.P(s1))
+            capi.P(got16), capi.P(s1), 0)
     scale = s0[:2].abs().max(dim=1, keepdim=True).values + 1e-3
     assert float(((s1[:2] - s0[:2]).abs() / scale).max()) < 1e-6
 
