@@ -18,6 +18,7 @@ parity mode keeps the reference's op-by-op composition (pointnet2_modules.py).
 """
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -322,26 +323,28 @@ class _row_plan:
         self.plan, self.rows = plan, rows
 
     def __enter__(self):
-        global _plan_active
-        _plan_active = self.plan is not None
+        _plan_state.active = self.plan is not None
         if self.plan is not None:
             _lib.omnipq_sa_row_plan(_p(self.plan.rows_dev), _p(self.plan.row_w), _p(self.plan.goff),
                                     ctypes.c_longlong(self.rows), self.plan.gs)
 
     def __exit__(self, *exc):
-        global _plan_active
-        _plan_active = False
+        _plan_state.active = False
         if self.plan is not None:
             _lib.omnipq_sa_row_plan(_p(None), _p(None), _p(None), ctypes.c_longlong(0), 16)
 
 
-_plan_active = False
+class _PlanState(threading.local):       # per thread, like the C side's row plan (forward thread / autograd thread)
+    active = False
+
+
+_plan_state = _PlanState()
 
 
 def strip_pays(M, N, K, with_pool):
     # (not inside a planned stage: the planned strip kernels -- row weights on top of the register-resident strip -- spill
     # 40 to 130 registers, tools/spills.sh, and the shapes the strip wins on do not occur in the stages a plan covers)
-    if not STRIP_GEMM or _plan_active:
+    if not STRIP_GEMM or _plan_state.active:
         return False
     if K == 256 and N >= 512 and N % 128 == 0 and M >= 65536:
         return True
