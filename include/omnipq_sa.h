@@ -184,6 +184,12 @@ int omnipq_tn_occupancy(int which);   /* workgroups per CU of the grouped TN ker
 int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
                         int *scratch, void *stream);
 void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows, int gs);
+/* With a plan of 8-row groups current: `gamma` = the BatchNorm weight (float [N]) of the layer whose ball extrema the next
+ * ..._pool GEMM records (or NULL).  a = gamma * invstd has gamma's sign, so per (group, column) only the maximum (gamma >= 0)
+ * or the minimum (gamma < 0) can be selected by the max-pool: the GEMM then stores just that one (value into ymax, row into
+ * amax; ymin / amin are not written) and omnipq_sa_pool_select_finalize reads just those -- half the extrema traffic.
+ * Cleared by omnipq_sa_row_plan. */
+void omnipq_sa_plan_pool_gamma(const float *gamma);
 
 /* Row-strip GEMMs (csrc/gemm_strip.hip): the same contraction C = f(A) B^T as the omnipq_gemm_nt_e16* family for the
  * shared-MLP layers of a set-abstraction stage (pytorch_utils.py:11-36), with a workgroup owning 128 rows and ALL N

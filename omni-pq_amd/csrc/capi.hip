@@ -155,7 +155,10 @@ extern "C" void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const
   t_row_plan.goff = goff;
   t_row_plan.rows = rows_dev ? rows : 0;
   t_row_plan.gs = gs == 8 ? 8 : 16;
+  t_row_plan.pool_gamma = nullptr;
 }
+
+extern "C" void omnipq_sa_plan_pool_gamma(const float *gamma) { t_row_plan.pool_gamma = gamma; }
 
 // Plan of a stage from its ball-query indices idx (int32 [balls][nsample], nsample 16, 32, 64 or 128) in groups of gs = 8 or
 // 16 rows: goff (int32 [balls + 1]), rows_dev (int32 [1]), row_w (uint8 [balls * nsample]: valid for the rows in use), scratch

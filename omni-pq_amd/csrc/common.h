@@ -183,6 +183,10 @@ struct RowPlan {
   const unsigned char *row_w = nullptr;          // [rows]
   const int *goff = nullptr;                     // [balls + 1]: first group of every ball
   int gs = 16;                                   // rows per group: 8 or 16
+  // BatchNorm weight of the layer whose ball extrema are being recorded, or NULL (omnipq_sa_plan_pool_gamma): with it the
+  // GEMM records per (group, column) only the extremum the max-pool can select -- the maximum where gamma >= 0, else the
+  // minimum (a = gamma * invstd has gamma's sign) -- into ymax / amax, and pool_select_finalize reads only those
+  const float *pool_gamma = nullptr;
   long long rows = 0;                            // the static row count the stage's launches are issued with
 };
 RowPlan &row_plan();                            // capi.hip; thread-local

@@ -119,6 +119,7 @@ struct PoolOut {
   int s;
   e16_t *ymax, *ymin;            // [M / s][N]
   unsigned char *amax, *amin;     // [M / s][N] row within the ball
+  const float *gamma = nullptr;   // s == 8 (row plan) only: one-sided extrema, see common.h: RowPlan::pool_gamma
 };
 
 // XG: the FIRST layer of a stage whose input is coordinates only (sa1: conv 3 -> C0) is never materialised.  Its pre-BN
@@ -636,6 +637,14 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
       typedef short s16x2 __attribute__((ext_vector_type(2)));
       const unsigned hbit = (unsigned)crow0;
       const bool upper = lane >> 5;
+      // one-sided (pool.gamma): columns with a negative BatchNorm weight look for the minimum -- their order-preserving
+      // 16-bit values are complemented, so the "maximum" below is the minimum and the tie rule (first row) is unchanged
+      unsigned flip[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int gc = n0 + wn * (T / 2) + j * 32 + ccol;
+        flip[j] = (pool.gamma && gc < g.N && pool.gamma[gc] < 0.f) ? 0xFFFFFFFFu : 0u;
+      }
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -647,7 +656,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
             for (int r = 4 * q8; r < 4 * q8 + 4; r += 2) {
               const unsigned pw = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
               const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, pw) >> 15);
-              const unsigned o = pw ^ (sg | 0x80008000u);
+              const unsigned o = (pw ^ (sg | 0x80008000u)) ^ flip[j];
               const unsigned row = (unsigned)(r & 3);
               const unsigned olo = o << 16, ohi = o & 0xffff0000u;
               mx = max(max(mx, olo | (7u - row)), ohi | (6u - row));
@@ -655,15 +664,26 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
             }
             unsigned a = mx ^ hbit, b = mn | hbit;                 // 7 - (row + 4 h) | row + 4 h
             a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
+            const int r0 = wm * (T / 2) + i * 32 + q8 * 8, gc = n0 + wn * (T / 2) + j * 32 + ccol;
+            const bool inside = m0 + r0 < g.M && gc < g.N;
+            const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
+            if (pool.gamma) {
+              // the selectable extremum only: the lower lane half stores its value, the upper half its row
+              const unsigned o = ((a >> 16) ^ flip[j]) & 0xFFFFu;
+              const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
+              if (inside) {
+                if (!upper) pool.ymax[oidx] = __builtin_bit_cast(e16_t, bits);
+                else pool.amax[oidx] = (unsigned char)(7u - (a & 7u));
+              }
+              continue;
+            }
             b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
             const unsigned key = upper ? b : a;
             const unsigned o = key >> 16;
             const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
             const unsigned low = key & 7u;
             const unsigned char row = (unsigned char)(upper ? low : 7u - low);
-            const int r0 = wm * (T / 2) + i * 32 + q8 * 8, gc = n0 + wn * (T / 2) + j * 32 + ccol;
-            if (m0 + r0 < g.M && gc < g.N) {
-              const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
+            if (inside) {
               (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
               (upper ? pool.amin : pool.amax)[oidx] = row;
             }
@@ -1196,6 +1216,10 @@ static int pool_out_check(int M, int N, int s, void *ymax, void *ymin, unsigned 
                           omnipq::PoolOut *out) {
   if (s <= 0 || (128 % s) || (M % s) || !ymax || !ymin || !amax || !amin) return OMNIPQ_EINVAL;
   *out = omnipq::PoolOut{s, (omnipq::e16_t *)ymax, (omnipq::e16_t *)ymin, amax, amin};
+  {
+    const omnipq::RowPlan &rp = omnipq::row_plan();
+    if (rp.rows_dev && rp.rows == M && s == 8 && rp.gs == 8) out->gamma = rp.pool_gamma;
+  }
   (void)N;
   return OMNIPQ_OK;
 }

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ a_out, float *__restrict__ b_out,
     float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ out_f32, e16_t *__restrict__ out_pm,
-    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel, const int *__restrict__ goff, int gs) {
+    unsigned char *__restrict__ arg, e16_t *__restrict__ ysel, const int *__restrict__ goff, int gs, int one_sided) {
   // goff (row plan, common.h: RowPlan) or NULL: the extrema arrays hold one entry per gs-row GROUP, ball bm owns the groups
   // goff[bm] .. goff[bm + 1] and its extrema are merged here (strict comparisons: an earlier group wins a tie, as the first
   // row does inside a group), the row within the ball = gs * (group within the ball) + row within the group
@@ -390,7 +390,29 @@ __global__ __launch_bounds__(256) void pool_select_finalize_kernel(
     load8f(s_a + c0, av);
     load8f(s_b + c0, bv);
     unsigned long long ph, pl;
-    if (goff) {
+    if (goff && one_sided) {
+      // (common.h: RowPlan::pool_gamma) ymax / amax hold, per column, the extremum of the side a's sign selects
+      const int g0 = goff[bm], ng = goff[bm + 1] - g0;
+      const size_t og = (size_t)g0 * C + c0;
+      unpack8(*reinterpret_cast<const uint4 *>(ymax + og), hi);
+      ph = *reinterpret_cast<const unsigned long long *>(amax + og);
+      for (int gi = 1; gi < ng; ++gi) {
+        float h2[8];
+        const size_t o2 = og + (size_t)gi * C;
+        unpack8(*reinterpret_cast<const uint4 *>(ymax + o2), h2);
+        const unsigned long long ph2 = *reinterpret_cast<const unsigned long long *>(amax + o2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (av[e] >= 0.f ? h2[e] > hi[e] : h2[e] < hi[e]) {
+            hi[e] = h2[e];
+            ph = (ph & ~(0xFFull << (8 * e))) | ((((ph2 >> (8 * e)) & 0xFF) + (unsigned long long)(gs * gi)) << (8 * e));
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lo[e] = hi[e];
+      pl = ph;
+    } else if (goff) {
       const int g0 = goff[bm], ng = goff[bm + 1] - g0;
       const size_t og = (size_t)g0 * C + c0;
       unpack8(*reinterpret_cast<const uint4 *>(ymax + og), hi);
@@ -1345,7 +1367,8 @@ extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *y
   pool_select_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
       items, C, (const e16_t *)ymax, (const e16_t *)ymin, amax, amin, sums, count, gamma, beta, eps, momentum, running_mean,
       running_var, a_out, b_out, mean_out, invstd_out, out_f32, (e16_t *)out_pm, arg, (e16_t *)ysel,
-      omnipq::row_plan().rows_dev ? omnipq::row_plan().goff : nullptr, omnipq::row_plan().gs);
+      omnipq::row_plan().rows_dev ? omnipq::row_plan().goff : nullptr, omnipq::row_plan().gs,
+      omnipq::row_plan().rows_dev && omnipq::row_plan().gs == 8 && omnipq::row_plan().pool_gamma != nullptr);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

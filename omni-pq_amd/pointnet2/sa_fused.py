@@ -280,11 +280,13 @@ _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 # ROW_PLAN = False: every row is computed.
 ROW_PLAN = True
 PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
+ONE_SIDED_EXTREMA = True        # planned stages with 8-row groups: record max OR min per column, by the sign of gamma
 PLAN_MIN_ROWS = 1 << 17         # grouped rows from which a stage is planned (BASELINE configs[3], batch 4: sa2 has 2^17 --
                                 # SA stages 2.65 -> 2.28 ms there; below that the statistics take the direct-atomics paths)
 row_plan_uses = 0
 row_plan_last = {}              # P of the stage -> its latest _Plan (bench.py reads the rows in use from it)
 _lib.omnipq_sa_row_plan.restype = None
+_lib.omnipq_sa_plan_pool_gamma.restype = None
 
 
 def row_plan_ok(training, S, P, L, needs_input_grad, pooled):
@@ -1185,6 +1187,9 @@ class FusedSAStage(torch.autograd.Function):
                     ext16 = torch.empty((2, slots, cout), device=dev, dtype=E16.dtype)
                     ext8 = torch.empty((2, slots, cout), device=dev, dtype=torch.uint8)
                     pool = (plan.gs if planned else S, ext16[0], ext16[1], ext8[0], ext8[1])
+                    if planned and plan.gs == 8 and ONE_SIDED_EXTREMA:
+                        # only the extremum gamma's sign can select is recorded (include/omnipq_sa.h: omnipq_sa_plan_pool_gamma)
+                        _lib.omnipq_sa_plan_pool_gamma(_p(gamma.detach()))
                 if xgen and l == 0:
                     # never materialised (see XYZGEN): statistics from the moments of the grouped coordinates
                     lay.mom = torch.empty((12,), device=dev, dtype=torch.float64)

@@ -919,11 +919,19 @@ def test_row_plan_equals_the_full_stage(case, group, monkeypatch):
         feats = (feats * 0.5).requires_grad_(True)
     monkeypatch.setenv("OMNIPQ_SA", "fused")
     monkeypatch.setattr(sa_fused, "PLAN_GROUP", group)
+    if case == "sa2_batch_4":
+        monkeypatch.setattr(sa_fused, "ONE_SIDED_EXTREMA", False)      # (every other case runs the one-sided extrema)
     res = {}
     for on in (False, True):
         monkeypatch.setattr(sa_fused, "ROW_PLAN", on)
         mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
             mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}), 3).to(dev()).train()
+        with torch.no_grad():
+            # every third BatchNorm weight negative: the max-pool of those columns selects the ball's MINIMUM
+            # (the one-sided extrema of a planned stage must pick that side)
+            for name, prm in mod.named_parameters():
+                if name.endswith("bn.bn.weight"):
+                    prm[::3] *= -1.0
         uses = sa_fused.row_plan_uses
         with torch.autocast("cuda", dtype=torch.bfloat16):
             _, out, inds = mod(xyz, feats)
