@@ -795,6 +795,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     per_step = sorted(a.elapsed_time(b) for a, b in marks)
+    if distributed and not ddp:
+        import sa_fused as _sf
+        timed_collectives = _sf.COLLECTIVES_LAST_STEP        # of the step that was timed (the op-timing steps below run eagerly)
     ext.set_timing_sink(None)
     ext.fps_check()
     if args.feeder is not None:
@@ -846,7 +849,7 @@ def main():
     if distributed and not ddp:
         import sa_fused
         b = getattr(args, "buckets", None)
-        dp_counts = (f"{sa_fused.COLLECTIVES_LAST_STEP} SyncBN statistics all-reduces (<= 4 KB each) + "
+        dp_counts = (f"{timed_collectives} SyncBN statistics all-reduces (<= 4 KB each) + "
                      f"{b.collectives if b is not None else 0} gradient-bucket all-reduces per step (bucket 0 = everything but "
                      "the backbone, issued on the side stream when backward reaches the seed features; bucket 1 = backbone + "
                      f"the {b.late_arrivals if b is not None else 0} bucket-0 gradients that arrive after that flush; "
