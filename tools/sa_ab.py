@@ -106,6 +106,14 @@ def main():
     print(f"grads: worst rel-L2 {worst:.3e} over {len(res[modes[0]][1])} tensors")
     ok &= worst < 5e-2
     print("PARITY", "OK" if ok else "FAIL")
+    if not ok:
+        # Four chained stages with random-signed upstream gradients: a switch that changes any rounding in the forward pass
+        # (XYZGEN, ROW_PLAN, PLAN_GROUP: different order of the f32 statistics sums -> a few bf16 outputs flip by one ulp)
+        # re-routes max-pool arg-maxes downstream, and the weight gradients -- sums of ~10^6 random-signed terms -- move by
+        # tens of percent (XYZGEN 0.74, ROW_PLAN 0.41; the same switch twice: 0.0, ONE_SIDED_EXTREMA: 1e-7).  The parity tests
+        # of these switches compare ONE stage on identical inputs (tests/test_gpu_fused_sa.py) and the model against the
+        # reference's fixtures (tests/test_gpu_stage_forced.py, test_gpu_bf16_fixtures.py).
+        print("(chained stages amplify one-ulp differences of the forward pass; see the note in tools/sa_ab.py)")
 
     ext = pointnet2_utils._ext
     for mode in modes:
