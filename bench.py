@@ -633,7 +633,7 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             net, criterion, {"point_clouds": pool[0]}, labels_pool[0] if labels_pool is not None else None, model=model,
             amp_dtype=amp_dtype, loss_scale=scale, graph=use_graph, prefetch=prefetch, fps_footprint=footprint,
             teacher=teacher, teacher_example=None if teacher is None else {"point_clouds": teacher_pool[0]},
-            ema=(EMA_DECAY, EMA_STEP) if teacher is not None else None, buckets=buckets, defer=not ddp,
+            ema=EMA_DECAY if teacher is not None else None, buckets=buckets, defer=not ddp,
             warmup=args.warmup, distributed=distributed)
     except Exception as exc:       # noqa: BLE001 -- whatever refused the capture, the eager path still works
         if not (distributed and use_graph):
@@ -653,15 +653,21 @@ def make_step(net, model, pool, args, amp_dtype, world, distributed=False, dist_
             # the batch run now was announced by the previous call (the first one by the capture); the batch after it is
             # handed over for its sampling plan: from the resident pool (3.84 MB device-to-device inside the timed region)
             # or from the host pipeline
-            return stepper.step(None, labels_pool[i % n] if labels_pool is not None else None,
+            loss = stepper.step(None, labels_pool[i % n] if labels_pool is not None else None,
                                 next_inputs=feeder.next_into if feeder is not None else pool[(i + 1) % n],
                                 next_teacher_inputs=None if teacher is None else teacher_pool[(i + 1) % n])
+            if teacher is not None:
+                stepper.update_teacher(EMA_STEP + i)          # train.py:576 (after optimizer.step(), which the metric leaves out)
+            return loss
     else:
         def step(i):
-            return stepper.step(pool[i % n], labels_pool[i % n] if labels_pool is not None else None,
+            loss = stepper.step(pool[i % n], labels_pool[i % n] if labels_pool is not None else None,
                                 next_inputs=pool[(i + 1) % n],
                                 teacher_inputs=None if teacher is None else teacher_pool[i % n],
                                 next_teacher_inputs=None if teacher is None else teacher_pool[(i + 1) % n])
+            if teacher is not None:
+                stepper.update_teacher(EMA_STEP + i)
+            return loss
     return step, stepper.launch
 
 

@@ -43,6 +43,8 @@ class GradientBuckets:
         self.late_arrivals = 0        # bucket-0 parameters whose gradient (or part of it) arrived after the early flush
         self._packed = [set(), set()]  # ids of the parameters that had a gradient when their bucket was packed
         self._hold = None             # the local .grad tensors bucket 0 was packed from (alive until the block has ended)
+        self._late_ids = None         # ids of the bucket-0 parameters that also travel with bucket 1 (fixed by the first step)
+        self._used_ids = None         # ids of the parameters some rank has a gradient for (fixed by the first uncaptured step)
 
     # ---- called by sa_fused.deferred_wgrads.flush_on, on the side stream, after the early grouped launch ----------
     def on_early_flush(self, dfr):
@@ -67,14 +69,28 @@ class GradientBuckets:
 
     # ---- called by the step once the deferred_wgrads block has ended ------------------------------------------------
     def finish(self):
+        """Both buckets reduced and averaged; a parameter gets its averaged view as `.grad` when ANY rank produced a
+        gradient for it (DDP hands every rank the averaged gradient: a rank-local "nothing arrived, leave None" makes that
+        rank skip the optimizer update -- weight decay and moments included -- and the replicas drift apart).
+        Which parameters take part at all is agreed on once, by the first step that is not being captured (one MAX
+        all-reduce of a mask and a host read), and kept: only a parameter no rank ever touched keeps `.grad = None`.  The set of bucket-0 parameters that travel again with bucket 1 is STRUCTURAL -- fixed by the
+        first step that saw late arrivals and asserted equal on every later step -- because it sizes a collective: ranks
+        that disagreed about it would hang in the all-reduce."""
         late = []
         if not self.early_done:                   # no flush point was hit (eager helper paths): everything now
             self.flat[0] = self._pack(self.buckets[0], [], self._packed[0])
             self._reduce(self.flat[0])
         else:
-            late = [p for p in self.buckets[0] if p.grad is not None]
+            arrived = [p for p in self.buckets[0] if p.grad is not None]
+            if self._late_ids is None:
+                self._late_ids = self._agree(self.buckets[0], {id(p) for p in arrived})
+            stray = [p for p in arrived if id(p) not in self._late_ids]
+            if stray:
+                raise RuntimeError(f"GradientBuckets: {len(stray)} bucket-0 gradients arrived after the early flush that "
+                                   "did not on the first step; the late set sizes bucket 1's all-reduce and must not change")
+            late = [p for p in self.buckets[0] if id(p) in self._late_ids]
         self.late_arrivals = len(late)
-        # bucket 1 = the backbone + whatever reached bucket-0 parameters after the early flush
+        # bucket 1 = the backbone + whatever reaches bucket-0 parameters after the early flush
         self.flat[1] = self._pack(self.buckets[1] + late, [], self._packed[1])
         self._reduce(self.flat[1])
         inv = 1.0 / self.world
@@ -82,6 +98,9 @@ class GradientBuckets:
             if flat.is_cuda and not torch.cuda.is_current_stream_capturing():
                 flat.record_stream(torch.cuda.current_stream(flat.device))     # bucket 0 was allocated on the side stream
             flat.mul_(inv)
+        if self._used_ids is None and not (self.flat[1].is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._used_ids = self._agree(self.buckets[0] + self.buckets[1], self._packed[0] | self._packed[1])
+        used = self._used_ids
         late_views, off = {}, sum(p.numel() for p in self.buckets[1])
         for p in late:
             late_views[id(p)] = self.flat[1][off:off + p.numel()]
@@ -93,16 +112,25 @@ class GradientBuckets:
                 view = flat[off:off + n]
                 off += n
                 extra = late_views.get(id(p)) if b == 0 else None
-                if id(p) not in self._packed[b] and extra is None:
-                    p.grad = None             # no gradient reached this parameter on this step (DDP leaves None too)
-                    continue
                 if extra is not None:
                     view.add_(extra)
+                if used is not None and id(p) not in used:
+                    p.grad = None             # no rank has a gradient for this parameter (DDP leaves None too)
+                    continue
                 g = view.view_as(p)
                 p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
         self.early_done = False
         self._hold = None
         self._packed = [set(), set()]
+
+    def _agree(self, params, mine):
+        """ids of `params` that are in `mine` on ANY rank (union: a rank without a gradient for a parameter another rank
+        has one for packs zeros for it)."""
+        if self.world > 1 and dist.is_initialized() and params:
+            mask = torch.tensor([1 if id(p) in mine else 0 for p in params], dtype=torch.int32, device=params[0].device)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+            return {id(p) for p, m in zip(params, mask.tolist()) if m}
+        return {id(p) for p in params if id(p) in mine}
 
     # -------------------------------------------------------------------------------------------------------------------
     def _pack(self, params, extra, had):

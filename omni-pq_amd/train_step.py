@@ -54,19 +54,29 @@ class CapturedStep:
     graph            True: capture + replay; False: the same step launched eagerly (debugging, A/B).
     prefetch         "forward": the next batch's sampling chain starts inside forward() (default), "backward": between
                      forward and backward, None: no prefetch (every forward samples its own batch: +5 ms at 40 000 points).
-    teacher          optional mean-teacher copy (train.py:480-491): its train-mode no-grad forward runs after the student's
-                     and `ema=(decay, global_step)` updates it after backward (ema.update_ema_variables, train.py:576).
+    teacher          optional mean-teacher copy (train.py:480-491): its train-mode no-grad forward runs right after the
+                     student's forward, BEFORE the criterion; with `teacher_to_criterion=True` the criterion is called as
+                     criterion(end_points, labels, teacher_end_points) (train.py:530-538: the consistency loss reads both).
+                     The weight averaging is NOT part of the captured step: call `stepper.update_teacher(global_step)`
+                     after `optimizer.step()`, where the reference calls update_ema_variables (train.py:560-576) -- one
+                     launch, alpha = min(1 - 1/(global_step + 1), ema) evaluated per call.  `ema` = the decay (a
+                     (decay, step) pair is accepted for old callers; its step is ignored).
     world / buckets  data parallelism: `buckets` = data_parallel.GradientBuckets(net, world, group) or None (single rank).
     defer            False: leave the weight gradients to autograd (needed under DistributedDataParallel).
     """
 
     def __init__(self, net, criterion, example_inputs, example_labels=None, *, model=None, amp_dtype=torch.bfloat16,
                  loss_scale=1.0, graph=True, prefetch="forward", fps_footprint=None, teacher=None, teacher_example=None,
-                 ema=None, buckets=None, defer=True, warmup=3, distributed=False, before_capture=None):
+                 ema=None, buckets=None, defer=True, warmup=3, distributed=False, before_capture=None,
+                 teacher_to_criterion=False):
         self.net, self.model, self.criterion = net, (model if model is not None else net), criterion
         self.amp_dtype, self.scale = amp_dtype, float(loss_scale)
         self.prefetch_at, self.footprint = prefetch, fps_footprint
-        self.teacher, self.ema = teacher, ema
+        self.teacher = teacher
+        self.ema = ema[0] if isinstance(ema, (tuple, list)) else ema
+        self.teacher_to_criterion = bool(teacher_to_criterion)
+        self.teacher_end_points = None
+        self._grads = None             # graph mode: (parameter, static gradient tensor) pairs, re-attached after every replay
         self.buckets, self.defer = buckets, defer
         self.distributed = distributed
         pc = _cloud(example_inputs)
@@ -81,7 +91,7 @@ class CapturedStep:
         self.end_points = None
         self.launch = "eager"
         self.replays = 0
-        self._promised = None          # identity of the tensor announced as `next_inputs` by the previous call
+        self._promised = None          # the tensor announced as `next_inputs` by the previous call (kept alive: compared with `is`)
         self._have_next = False        # does `nxt` (and the plan in flight) hold the batch the next call will run?
         if graph:
             self._capture(warmup, before_capture)
@@ -118,13 +128,17 @@ class CapturedStep:
                 teacher.prefetch({"point_clouds": nxt_t}, trusted=trusted, at_next_forward=True, footprint=self.footprint)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             ep = self.model({"point_clouds": cur})
-            loss = self.criterion(ep, lab)
+        if teacher is not None:
+            tep = self._teacher_forward(cur_t)                  # train.py:489-491: before the losses, which may read both
+            self.teacher_end_points = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in tep.items()} \
+                if isinstance(tep, dict) else None
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            loss = self.criterion(ep, lab, self.teacher_end_points) if (teacher is not None and self.teacher_to_criterion) \
+                else self.criterion(ep, lab)
         # the outputs, detached: in graph mode static tensors that every replay rewrites in place.  (Detached on purpose:
         # holding the attached tensors -- i.e. the step's autograd graph with its custom nodes -- past the end of a capture
         # made hipStreamEndCapture segfault; the nodes must die inside the capture, as they do when only the loss leaves.)
         self.end_points = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ep.items()} if isinstance(ep, dict) else None
-        if teacher is not None:
-            self._teacher_forward(cur_t)
         if self.prefetch_at == "backward" and nxt is not None:
             net.prefetch({"point_clouds": nxt}, trusted=trusted)
             if teacher is not None:
@@ -135,10 +149,17 @@ class CapturedStep:
         net.join_prefetch()
         if teacher is not None:
             teacher.join_prefetch()
-        if teacher is not None and self.ema is not None:
-            import ema as _ema
-            _ema.update_ema_variables(net, teacher, *self.ema)      # train.py:576
         return loss
+
+    def update_teacher(self, global_step):
+        """ema_model <- alpha * ema_model + (1 - alpha) * model, alpha = min(1 - 1/(global_step + 1), decay): the
+        reference's update_ema_variables (train.py:435-439), to be called where the reference calls it -- after
+        optimizer.step() (train.py:560-576).  One launch on the current stream, outside the captured step: alpha is a
+        kernel ARGUMENT and changes with every call, which a replayed launch could not follow."""
+        if self.teacher is None or self.ema is None:
+            return None
+        import ema as _ema
+        return _ema.update_ema_variables(self.net, self.teacher, self.ema, global_step)
 
     _capturing = False
 
@@ -146,6 +167,9 @@ class CapturedStep:
         import sa_fused
         net, teacher = self.net, self.teacher
         self._capturing = True
+        # the warm-up steps run the model in train mode on the EXAMPLE batch: what they do to the BatchNorm running
+        # statistics / step counters of both networks is undone after the capture
+        keep = [(b, b.detach().clone()) for m in (net, teacher) if m is not None for b in m.buffers()]
         try:
             self.nxt.copy_(self.cur)
             if teacher is not None:
@@ -173,6 +197,13 @@ class CapturedStep:
             self.graph = graph
             self.launch = "hipGraph replay"
             self._have_next = True                   # `nxt` holds the example batch, its plan was started by the capture run
+            # the gradients the graph writes: static tensors (views of the bucket buffers under data parallelism).  A
+            # caller's optimizer.zero_grad() (set_to_none=True is torch's default) detaches them from the parameters, so
+            # every replay hands them back.
+            self._grads = [(p, p.grad) for p in net.parameters() if p.grad is not None]
+            with torch.no_grad():
+                for b, saved in keep:
+                    b.copy_(saved)
         finally:
             self._capturing = False
 
@@ -187,7 +218,8 @@ class CapturedStep:
             return self._eager_step(inputs, labels, next_inputs, teacher_inputs, next_teacher_inputs)
         net, teacher = self.net, self.teacher
         pc = None if inputs is None else _cloud(inputs)
-        announced = self._have_next and (pc is None or (self._promised is not None and self._promised == _ident(pc)))
+        announced = self._have_next and (pc is None or (self._promised is not None and self._promised[0] is pc
+                                                        and self._promised[1] == pc._version))
         if announced:
             self.cur.copy_(self.nxt)
             if teacher is not None:
@@ -213,10 +245,16 @@ class CapturedStep:
         self._fill(self.nxt, next_inputs)
         if teacher is not None:
             self._fill(self.nxt_t, next_teacher_inputs if next_teacher_inputs is not None else next_inputs)
-        self._promised = _ident(_cloud(next_inputs)) if (next_inputs is not None and not callable(next_inputs)) else None
+        if next_inputs is not None and not callable(next_inputs):
+            t = _cloud(next_inputs)
+            self._promised = (t, t._version)         # the object itself, kept alive until the next call: an address can be reused
+        else:
+            self._promised = None
         self._have_next = next_inputs is not None
         self.graph.replay()
         self.replays += 1
+        for p, g in self._grads:
+            p.grad = g
         return self.static_loss
 
     @staticmethod
@@ -238,15 +276,7 @@ class CapturedStep:
             nxt = _cloud(next_inputs)
         t_cur = _cloud(teacher_inputs) if teacher_inputs is not None else pc
         t_nxt = _cloud(next_teacher_inputs) if next_teacher_inputs is not None else nxt
-        loss = self._body(pc, nxt, labels, t_cur, t_nxt, False)
-        if self.teacher is not None and self.ema is not None:
-            import ema as _ema
-            _ema.update_ema_variables(self.net, self.teacher, *self.ema)
-        return loss
-
-
-def _ident(t):
-    return (t.data_ptr(), t._version, tuple(t.shape))
+        return self._body(pc, nxt, labels, t_cur, t_nxt, False)
 
 
 def _quiesce_process_groups(device):

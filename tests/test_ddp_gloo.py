@@ -134,7 +134,26 @@ def _worker(rank, world, port, out_dir):
         two.head.bias.grad = local["head.bias"].clone()
         buckets.finish()                                                             # no early flush this time
         assert torch.allclose(two.head.bias.grad, torch.stack(stacked["head.bias"]).mean(0), rtol=1e-6, atol=1e-7)
-        assert two.extra.weight.grad is None and buckets.late_arrivals == 0
+        # (the set of parameters that take part was agreed on by the first step: extra.* now gets the average of nothing,
+        # zeros, on every rank alike -- never a rank-local None; `unused`, which no rank ever touched, stays None)
+        assert float(two.extra.weight.grad.abs().max()) == 0.0 and buckets.late_arrivals == 0
+        assert two.unused.weight.grad is None
+
+        # 2c') a gradient only ONE rank produced reaches every rank (averaged), and the late set is the union over ranks
+        three = Two()
+        b3 = data_parallel.GradientBuckets(three, world)
+        blk3 = FakeBlock()
+        blk3._assign = []
+        if rank == 0:
+            three.head.bias.grad = torch.ones(3)
+        b3.on_early_flush(blk3)
+        if rank == 1 % world:
+            three.extra.bias.grad = torch.full((2,), 4.0)          # a late arrival on one rank only
+        three.backbone.bias.grad = torch.ones(5)
+        b3.finish()
+        assert torch.allclose(three.head.bias.grad, torch.full((3,), 1.0 / world))
+        assert torch.allclose(three.extra.bias.grad, torch.full((2,), 4.0 / world)), three.extra.bias.grad
+        assert b3.late_arrivals == 1 and three.head.weight.grad is None and three.unused.bias.grad is None
 
         # 2d) deferred_wgrads refuses parameters of a DistributedDataParallel module (their hooks would never fire)
         with sa_fused.deferred_wgrads() as blk2:

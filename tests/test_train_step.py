@@ -97,3 +97,63 @@ def test_replayed_captured_step_equals_the_eager_step():
             for n in watch:
                 assert b[2][n].abs().sum() > 0, (announce, i, n)
                 assert rel(b[2][n], a[2][n]) <= 3 * noise + 1e-4, (announce, i, n, rel(b[2][n], a[2][n]), noise)
+
+
+@pytest.mark.gpu
+def test_captured_step_trains_through_zero_grad_and_keeps_the_teacher_semantics():
+    """(a) `optimizer.zero_grad()` (set_to_none=True, torch's default) before every replay must not orphan the
+    graph's static gradient buffers -- the weights have to move; (b) the warm-up / capture runs on the example batch leave
+    the BatchNorm running statistics and step counters of both networks untouched; (c) the teacher's weight averaging
+    runs where the reference runs it (after optimizer.step(), train.py:560-576) with alpha = min(1 - 1/(step+1), decay)
+    evaluated per call, and its forward's outputs reach the criterion."""
+    sys.path.insert(0, REPO)
+    import copy
+    import bench
+    import ema
+    import synth
+    import train_step
+    from procedural import load_procedural
+    from test_oracle_golden import zero_dropout
+    dev = torch.device("cuda", 0)
+    pcs = [synth.make_clouds(80 + i, 2, 8192, kind="room").to(dev) for i in range(3)]
+    net = load_procedural(bench.build_model(0)).to(dev).train()
+    zero_dropout(net)
+    teacher = copy.deepcopy(net)
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+    before = {k: v.detach().clone() for k, v in list(net.state_dict().items()) + [("t." + k, v) for k, v in teacher.state_dict().items()]}
+    seen = []
+
+    def criterion(ep, labels, teacher_ep):
+        seen.append(teacher_ep)
+        assert teacher_ep is not None and set(teacher_ep) == set(ep)
+        return bench.loss_of(ep) + 0.1 * (ep["last_center"].float() - teacher_ep["last_center"].float()).square().mean()
+
+    st = train_step.CapturedStep(net, criterion, {"point_clouds": pcs[0]}, teacher=teacher, ema=0.999,
+                                 teacher_to_criterion=True)
+    assert st.launch == "hipGraph replay" and seen
+    after = dict(list(net.state_dict().items()) + [("t." + k, v) for k, v in teacher.state_dict().items()])
+    for k, v in before.items():            # nothing moved: no optimizer yet, BatchNorm buffers restored, no EMA in the capture
+        assert torch.equal(v, after[k]), k
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    w0 = net.decoder[0].linear1.weight.detach().clone()
+    t0 = teacher.decoder[0].linear1.weight.detach().clone()
+    for i, (pc, nxt) in enumerate(train_step.lookahead(pcs)):
+        opt.zero_grad()                                            # set_to_none=True
+        loss = st.step({"point_clouds": pc}, None, next_inputs=None if nxt is None else {"point_clouds": nxt})
+        assert torch.isfinite(loss).item()
+        assert all(p.grad is not None for p in net.decoder[0].parameters())
+        opt.step()
+        alpha = st.update_teacher(i)
+        assert alpha == ema.ema_alpha(0.999, i) and (i > 0 or alpha == 0.0)
+        if i == 0:                                                 # alpha = 0: the teacher IS the student after the first step
+            assert torch.equal(teacher.decoder[0].linear1.weight, net.decoder[0].linear1.weight)
+    torch.cuda.synchronize()
+    assert not torch.equal(net.decoder[0].linear1.weight, w0), "the optimizer did not see the replay's gradients"
+    assert not torch.equal(teacher.decoder[0].linear1.weight, t0)
+    w1 = net.decoder[0].linear1.weight.detach().clone()
+    t1 = teacher.decoder[0].linear1.weight.detach().clone()
+    st.update_teacher(5)                                           # alpha = min(1 - 1/6, 0.999)
+    a = 1.0 - 1.0 / 6.0
+    want = t1 * a + (1.0 - a) * w1
+    assert torch.allclose(teacher.decoder[0].linear1.weight, want, rtol=1e-6, atol=1e-8)
