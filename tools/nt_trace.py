@@ -24,13 +24,19 @@ def read():
 
 
 def report(name, us, tiles):
-    t = read()
+    t = read()[:min(tiles, 4096)]
     if os.environ.get('NT_RAW'):
         print(t[:3], t[4000:4002])
     d = np.diff(t, axis=1).astype(np.float64)
     per_cycle = 1.0 / 2400.0                     # s_memtime ticks at the shader clock (2.4 GHz); every XCD has its own base
     life = (t[:, 7] - t[:, 0]).mean()
     print(f"{name}: {us:.0f} us, {tiles} tiles; a workgroup lives {life * per_cycle:.2f} us on average")
+    # when do workgroups start / end relative to the first start ON THEIR XCD (s_memtime bases differ per XCD: take the spread
+    # of starts within the tiles that share id % 8)
+    for x in range(2):
+        sel = t[x::8]
+        st, en = sel[:, 0] - sel[:, 0].min(), sel[:, 7] - sel[:, 0].min()
+        print(f"    xcd {x}: starts spread {st.max() * per_cycle:5.2f} us (median {np.median(st) * per_cycle:5.2f}), last end {en.max() * per_cycle:5.2f} us")
     for i, ph in enumerate(PHASES[1:]):
         print(f"    {ph:24s} {d[:, i].mean() * per_cycle:6.2f} us   (median {np.median(d[:, i]) * per_cycle:5.2f})")
 
@@ -75,6 +81,10 @@ def dgrad(M, N, K):
     report(f"bnbwd {M} x {N} x {K}", timed(run), (M // 128) * ((N + 127) // 128))
 
 
+if "--ring" in sys.argv:                       # (with tools/probe/gemm_nt_ring.patch applied: the LDS-DMA ring variants)
+    lib.omnipq_nt_ring(2)
+elif "--no-ring" in sys.argv and hasattr(lib, "omnipq_nt_ring"):
+    lib.omnipq_nt_ring(0)
 if "--small" in sys.argv:                      # sa4 / vote aggregation: 32 768 grouped positions, one round of workgroups
     forward_pool(1 << 15, 512, 256, 16)
     dgrad(1 << 15, 256, 512)
