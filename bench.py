@@ -235,21 +235,52 @@ SA_STAGE_CALLS = ("omnipq_ball_query", "omnipq_sa_gather", "omnipq_gemm_nt_e16",
                   "omnipq_group_points", "omnipq_group_points_grad")
 
 
-def sa_stage_algorithmic_bytes(batch, points, extra_channels, e):
+SA_STAGE_NAMES = ("sa1", "sa2", "sa3", "sa4", "vote")
+
+
+def sa_stage_algorithmic_bytes(batch, points, extra_channels, e, per_stage=False):
     """SA stage fwd+bwd = ball_query + 2*group_points + 3*MLP for the five SA layers,
-    features of e bytes, per batch of `batch` scenes."""
+    features of e bytes, per batch of `batch` scenes.  per_stage: -> {stage: (all bytes, the MLP term of ONE pass -- the share
+    by which the grouped weight-gradient launch's time is apportioned)}."""
     layers = [  # (N, M, S, [C0 (incl. xyz), C1, C2, C3])
         (points, 2048, 64, [3 + extra_channels, 128, 128, 256]), (2048, 1024, 32, [259, 256, 256, 512]),
         (1024, 512, 16, [515, 256, 256, 512]), (512, 256, 16, [515, 256, 256, 512]),
         (1024, 256, 16, [291, 288, 288, 288])]
-    total = 0
-    for n, m, sm, ch in layers:
+    total, split = 0, {}
+    for name, (n, m, sm, ch) in zip(SA_STAGE_NAMES, layers):
         P = m * sm
         bq = 12 * n + 12 * m + 4 * P
         gp = 4 * P + e * ch[0] * min(n, P) + e * ch[0] * P
         mlp = sum(e * (ch[i - 1] + ch[i]) * P for i in range(1, len(ch))) + e * ch[-1] * P + e * ch[-1] * m
         total += bq + 2 * gp + 3 * mlp
-    return total * batch
+        split[name] = ((bq + 2 * gp + 3 * mlp) * batch, mlp * batch)
+    return split if per_stage else total * batch
+
+
+def sa_per_stage(table, timing_steps, batch, points, extra_channels, e):
+    """The SA stage's time and roofline fraction stage by stage.  The timing sink labels every launch of a
+    stage "<call>@<stage>@sa" (sa_fused.run); the grouped weight-gradient launch at the end of backward serves all five stages
+    ("<call>@sa"): its time is apportioned by the stages' MLP bytes."""
+    split = sa_stage_algorithmic_bytes(batch, points, extra_channels, e, per_stage=True)
+    ms = {k: 0.0 for k in split}
+    launches = {k: 0.0 for k in split}
+    shared = 0.0
+    for (nm, _), v in table.items():
+        parts = nm.split("@")
+        if len(parts) == 3 and parts[2] == "sa" and parts[1] in ms:
+            ms[parts[1]] += v[0] / timing_steps
+            launches[parts[1]] += v[1] / timing_steps
+        elif nm.endswith("@sa"):
+            shared += v[0] / timing_steps
+    mlp_total = sum(m for _, m in split.values())
+    out = {}
+    for k, (nbytes, mlp) in split.items():
+        own = shared * mlp / mlp_total if mlp_total else 0.0
+        t = ms[k] + own
+        out[k] = {"ms": round(t, 4), "ms_own_launches": round(ms[k], 4), "ms_of_grouped_weight_gradients": round(own, 4),
+                  "launches": round(launches[k], 1), "algorithmic_bytes": nbytes,
+                  "frac": round(nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None}
+    return out
 
 
 def pmc_mfma(kind):
@@ -984,6 +1015,13 @@ def main():
                                                                     "traffic_source", "traffic_stale", "feature_bytes")}
             rec["sa_stage"]["ms_per_step"] = sa_ms
             rec["sa_stage"]["algorithmic_bytes"] = sa_bytes
+            if True:
+                rec["sa_stage"]["per_stage"] = sa_per_stage(table, timing_steps, args.batch, args.points,
+                                                            args.extra_channels, e)
+                rec["sa_stage"]["per_stage_note"] = (
+                    "event-timed launches of each stage (ball query, first layer, GEMMs, BatchNorm, pool, scatter: fwd + bwd) "
+                    "+ its share (by MLP bytes) of the ONE grouped weight-gradient launch that serves all five stages; frac "
+                    "= SURVEY 8d's algorithmic bytes of the stage / that time / 8 TB/s")
             if args.breakdown:
                 for (nm, aa), (ms_, calls_, nb) in sorted(table.items(), key=lambda kv: -kv[1][0]):
                     print(f"{nm:38s} {str(aa):34s} {ms_ / timing_steps:9.3f} ms/step  x{calls_ / timing_steps:4.1f}"

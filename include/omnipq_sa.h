@@ -164,6 +164,31 @@ int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const fl
 int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
+/* First layer of a stage WITH features, computed on the source points (round 5).  The first conv of the shared MLP
+ * (pytorch_utils.py:11-36) is linear in the grouped row [features(idx) | (xyz(idx) - centre) / r] that QueryAndGroup builds
+ * (pointnet2_utils.py:317-376), so it commutes with the grouping: Z = features W_f^T once per source point (every point is
+ * read by 4 .. 16 balls), then per grouped row  y = Z[idx] + W_x . xrel.  The grouped input rows are never materialised, and
+ * in backward the rows' gradients are summed per point BEFORE the weight-gradient / data-gradient contractions.
+ *   omnipq_gemm_nt_e16_f32     C (f32 [M][ldc]) = A B^T: Z above, and the feature gradient dZ W_f that leaves the stage
+ *   omnipq_sa_l1_rows          Y (e16 [rows][C]) = Z[b][idx] + W1x . xrel; Xrel (e16 [rows][8]) = xrel | 0; sums (f64 [2][C],
+ *                              zero on entry) += column sum / sum of squares of the stored Y.  W1x: element (c, j) at
+ *                              W1x[c * ldw + j].  rows_dev != NULL: the stage's row plan, passed EXPLICITLY (rows in use,
+ *                              unit_src and row_w of omnipq_sa_ball_plan_src): its compact rows are written and walked.
+ *                              workspace: omnipq_sa_l1_rows_workspace_bytes() bytes of per-workgroup partial sums; tickets:
+ *                              ZERO on entry, one 32-bit word per 16 workgroups.
+ *   omnipq_sa_scatter_rows_csr the adjoint over the CSR of omnipq_sa_build_csr: dfeat32 (f32) and / or dfeat16 (e16)
+ *                              [b][n][C] = per-point sums of dY's rows; dxyz / dnew_xyz (both or neither; not with a plan)
+ *                              from dXr (e16 [rows][8]) = dY W_x, the gradient of the relative coordinates. */
+int omnipq_gemm_nt_e16_f32(int M, int N, int K, const void *A, int lda, const void *B, int ldb, float *C, int ldc,
+                            void *stream);
+long long omnipq_sa_l1_rows_workspace_bytes(int b, int m, int s, int C);
+int omnipq_sa_l1_rows(int b, int n, int m, int s, int C, float inv_radius, const float *xyz, const float *new_xyz,
+                      const int *idx, const float *Z, const void *W1x, int ldw, const int *rows_dev, const int *unit_src,
+                      const unsigned char *row_w, void *Y, void *Xrel, double *sums, void *workspace, void *tickets,
+                      void *stream);
+int omnipq_sa_scatter_rows_csr(int b, int n, int m, int s, int C, float inv_radius, const int *offsets, const int *order,
+                               const void *dY, const void *dXr, const int *goff, int gs, float *dfeat32, void *dfeat16,
+                               float *dxyz, float *dnew_xyz, void *stream);
 /* Timing aid (tools/bench_tn_grouped.py): bit 0 selects the register-prefetch workgroup program of the TN kernels instead of
  * the LDS-DMA ring they run by default (csrc/gemm_tn_bf16.hip: tn_tile / tn_tile_dma); process-wide, not for production. */
 void omnipq_tn_debug(int flags);
@@ -183,6 +208,10 @@ int omnipq_tn_occupancy(int which);   /* workgroups per CU of the grouped TN ker
  * rows_dev == NULL clears it.  Results equal the full computation up to the order of the f32 sums. */
 int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
                         int *scratch, void *stream);
+/* ... and unit_src (int32 [balls * nsample / 8], may be NULL): compact rows 8 u .. 8 u + 7 = positions 8 unit_src[u] .. + 7 of
+ * the full layout, for kernels that walk the compact rows (omnipq_sa_l1_rows). */
+int omnipq_sa_ball_plan_src(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
+                            int *unit_src, int *scratch, void *stream);
 void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows, int gs);
 /* With a plan of 8-row groups current: `gamma` = the BatchNorm weight (float [N]) of the layer whose ball extrema the next
  * ..._pool GEMM records (or NULL).  a = gamma * invstd has gamma's sign, so per (group, column) only the maximum (gamma >= 0)

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(1024) void sa_plan_scan_kernel(int balls, int gs, c
 
 // one thread per (ball, 8 rows): their weights; a ball's first row stands for itself and the dropped copies
 __global__ __launch_bounds__(256) void sa_plan_weights_kernel(long long balls, int s, int gs, const int *__restrict__ goff,
-                                                             unsigned char *__restrict__ row_w) {
+                                                             unsigned char *__restrict__ row_w,
+                                                             int *__restrict__ unit_src) {
   const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
   const int omax = s >> 3;
   const long long b = q / omax;
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(256) void sa_plan_weights_kernel(long long balls, i
   uint2 ones = make_uint2(0x01010101u, 0x01010101u);
   if (o == 0) ones.x += (unsigned)(s - kept);               // byte 0: 1 + dropped copies (<= 1 + 128 - 8)
   *reinterpret_cast<uint2 *>(row_w + (size_t)g0 * gs + o * 8) = ones;
+  // where the 8 compact rows of this octet come from: position / 8 in the full layout (kernels that walk the compact rows)
+  if (unit_src) unit_src[((size_t)g0 * gs >> 3) + o] = (int)(b * omax + o);
 }
 }  // namespace omnipq
 
@@ -163,8 +166,17 @@ extern "C" void omnipq_sa_plan_pool_gamma(const float *gamma) { t_row_plan.pool_
 // Plan of a stage from its ball-query indices idx (int32 [balls][nsample], nsample 16, 32, 64 or 128) in groups of gs = 8 or
 // 16 rows: goff (int32 [balls + 1]), rows_dev (int32 [1]), row_w (uint8 [balls * nsample]: valid for the rows in use), scratch
 // (int32 [balls]).
+extern "C" int omnipq_sa_ball_plan_src(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev,
+                                       void *row_w, int *unit_src, int *scratch, void *stream);
 extern "C" int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
                                    int *scratch, void *stream) {
+  return omnipq_sa_ball_plan_src(balls, nsample, gs, idx, goff, rows_dev, row_w, nullptr, scratch, stream);
+}
+
+// The same, and unit_src (int32 [balls * nsample / 8], may be NULL; valid for the rows in use): compact rows 8 u .. 8 u + 7 are
+// positions 8 unit_src[u] .. + 7 of the full layout (a ball's kept rows are its first ones, in groups of 8 or 16).
+extern "C" int omnipq_sa_ball_plan_src(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev,
+                                       void *row_w, int *unit_src, int *scratch, void *stream) {
   if (balls < 0 || balls > (1 << 22) || (gs != 8 && gs != 16)) return OMNIPQ_EINVAL;
   if (nsample != 16 && nsample != 32 && nsample != 64 && nsample != 128) return OMNIPQ_EINVAL;
   if (balls == 0) return OMNIPQ_OK;
@@ -177,7 +189,7 @@ extern "C" int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const i
   OMNIPQ_LAUNCH_CHECK();
   const long long items = balls * (nsample >> 3);
   omnipq::sa_plan_weights_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(balls, nsample, gs, goff,
-                                                                                 (unsigned char *)row_w);
+                                                                                 (unsigned char *)row_w, unit_src);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -1565,6 +1565,33 @@ extern "C" int omnipq_gemm_nt_e16_ws(int M, int N, int K, const void *A, int lda
   return OMNIPQ_OK;
 }
 
+// C (f32 [M][ldc]) = A[M][K] B[N][K]^T, one workgroup per tile over the whole contraction (no split): the per-point first
+// layer of a set-abstraction stage (csrc/sa_stage.hip: sa_l1_rows_kernel) and the data gradient that leaves it.  N % 4 == 0.
+extern "C" int omnipq_gemm_nt_e16_f32(int M, int N, int K, const void *A, int lda, const void *B, int ldb, float *C, int ldc,
+                                       void *stream) {
+  using namespace omnipq;
+  if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
+  if (M == 0 || N == 0) return OMNIPQ_OK;
+  if (!A || !B || !C || (K % GBK) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4) || ldc < N) return OMNIPQ_EINVAL;
+  {
+    HeldLaunch &h = held_launch();
+    if (h.full) {
+      h.full = h.armed = false;
+      h.single(h);
+    }
+  }
+  if (gemm_nt_small_tiles(M, N)) {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 64);
+    gemm_nt_kernel<true, 0, false, 64><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B,
+                                                                                        C, nullptr);
+  } else {
+    const GemmArgs g = gemm_nt_args(M, N, K, lda, ldb, ldc, 128);
+    gemm_nt_kernel<true><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, nullptr);
+  }
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
 // C[M][N] (f32) = A[M][K] * B[N][K]^T with K split into `slabs` slices; `workspace` holds
 // slabs*M*N floats.  Used for the weight gradient, where K = number of grouped positions.
 extern "C" int omnipq_gemm_nt_e16_splitk(int M, int N, int K, const void *A, int lda, const void *B, int ldb,

@@ -141,6 +141,65 @@ __device__ __forceinline__ void fold_and_publish(float (&u)[8], float (&v)[8], i
 
 constexpr int kMaxC = 640;
 
+// The same tail for launches of MANY workgroups (one trip of loads per lane instead of a chain of them).  f64 atomics on the
+// same 2 C addresses cost ~0.1 us per thousand whatever their layout (512 workgroups x 2 C = 262 144 of them: 22-27 us;
+// sixteen replicas of the sums on different cache lines: no change), so here every workgroup leaves its 2 C partial sums as
+// plain f32 rows, and of every GROUP of kFoldGroup consecutive workgroups the one that arrives last (a ticket per group) adds the
+// group's rows up in row order and issues the group's 2 C atomics: 16 times fewer.  `part`: f32 [gridDim.x][2 C], `tickets`:
+// zero on entry, one unsigned per group.  No fences: rows and tickets travel as device-scope relaxed atomics (write-through
+// stores / coherent loads), each wave waits for the acknowledgement of its own stores (vmcnt) before the barrier in front of
+// the ticket.  live_blocks: workgroups that hold rows (the others of a static grid skip the stores; their rows are not read).
+constexpr int kFoldGroup = 16;
+__device__ __forceinline__ void fold_groups_and_publish(float (&u)[8], float (&v)[8], int cg, int rsub, int rpb, int cgs,
+                                                        int C, int live_blocks, float *__restrict__ part,
+                                                        unsigned *__restrict__ tickets, double *__restrict__ sums) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [u|v][rpb row groups][C]
+  __shared__ int s_last;
+  const int bid = (int)blockIdx.x, nthreads = (int)blockDim.x;
+  const bool live = rsub < rpb && cg < cgs;
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(0 * rpb + rsub) * C + cg * 8 + e] = u[e];
+      red[(1 * rpb + rsub) * C + cg * 8 + e] = v[e];
+    }
+  }
+  __syncthreads();
+  if (bid < live_blocks) {
+    for (int c = (int)threadIdx.x; c < 2 * C; c += nthreads) {
+      const int which = c / C, ch = c - which * C;
+      float acc = 0.f;
+      for (int r = 0; r < rpb; ++r) acc += red[(which * rpb + r) * C + ch];
+      __hip_atomic_store(part + (size_t)bid * 2 * C + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int grp = bid / kFoldGroup, g0 = grp * kFoldGroup;
+  int gsize = (int)gridDim.x - g0;
+  gsize = gsize < kFoldGroup ? gsize : kFoldGroup;
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == (unsigned)(gsize - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  int rows = live_blocks - g0;
+  rows = rows < gsize ? rows : gsize;
+  if (rows <= 0) return;
+  for (int c = (int)threadIdx.x; c < 2 * C; c += nthreads) {
+    float vals[kFoldGroup];
+#pragma unroll
+    for (int r = 0; r < kFoldGroup; ++r)
+      vals[r] = r < rows ? __hip_atomic_load(part + (size_t)(g0 + r) * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : 0.f;
+    double tot = 0.0;
+#pragma unroll
+    for (int r = 0; r < kFoldGroup; ++r) tot += (double)vals[r];
+    atomicAdd(sums + c, tot);
+  }
+}
+
 __device__ __forceinline__ void row_partition(int C, int &cgs, int &rpb, int &cg, int &rsub) {
   cgs = C >> 3;
   rpb = 256 / cgs;
@@ -1220,6 +1279,172 @@ __global__ __launch_bounds__(256) void sa_centre_grad_kernel(long long BM, int s
   dcentre[bm * 3 + 2] = -acc[2] * inv_r;
 }
 
+// ------------------------------------------------------------------------------- first layer on the SOURCE points
+// The first conv of a stage WITH features is linear in the grouped row [features(idx) | (xyz(idx) - centre) / r], so it
+// commutes with the grouping (reference pointnet2_utils.py:317-376 groups first, pytorch_utils.py:11-36 convolves every
+// grouped copy): Z = features W_f^T is computed ONCE per source point (b n rows: a point is read by 4 .. 16 balls, so 4 .. 16
+// times fewer rows than grouped positions) and a grouped row's pre-BatchNorm output is
+//     y[p][c] = Z[idx[p]][c] + W_x[c] . xrel[p],      xrel[p] = e16((xyz[idx[p]] - centre) * inv_r)
+// -- the same f32 sum the grouped GEMM forms, in another order, rounded to e16 once.  The grouped input rows are never
+// materialised.  This kernel: gather + the three coordinate FMAs + the row's e16 output + the layer's BatchNorm statistics
+// (weighted by row_w in a planned stage, common.h: RowPlan) + the relative coordinates the backward pass needs (Xrel, 16 B
+// per row).  One lane per 16-byte piece of an output row, four rows in flight per lane.
+// One trip of loads per lane (eight rows in flight), as many workgroups as that takes; the statistics leave through
+// fold_groups_and_publish.  A planned stage walks its COMPACT rows (unit_src: position / 8 of every 8 compact rows,
+// omnipq_sa_ball_plan_src), not all positions of the full layout; the grid stays that of the full row count (the rows in use
+// are only known on the device) and workgroups past them leave after taking their ticket.
+template <bool PLAN>
+__global__ __launch_bounds__(256) void sa_l1_rows_kernel(int P, int n, int m, int s, int C, float inv_r,
+                                                        const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                        const int *__restrict__ idx, const float *__restrict__ Z,
+                                                        const e16_t *__restrict__ W1x, int ldw,
+                                                        const int *__restrict__ rows_dev, const int *__restrict__ unit_src,
+                                                        const unsigned char *__restrict__ row_w, e16_t *__restrict__ Y,
+                                                        e16_t *__restrict__ Xrel, float *__restrict__ part,
+                                                        unsigned *__restrict__ tickets, double *__restrict__ sums) {
+  int cgs, rpb, cg, rsub;
+  row_partition(C, cgs, rpb, cg, rsub);
+  constexpr int U = 8;
+  // (32-bit positions: the entry point refuses more than 2^31 - 1 of them; 64-bit divisions were most of this kernel's time)
+  const int R = PLAN ? *rows_dev : P;
+  const int per_block = rpb * U;
+  const int live_blocks = (R + per_block - 1) / per_block;
+  float u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rsub < rpb && (int)blockIdx.x < live_blocks) {
+    float w[8][3];
+    {
+      // the coordinate columns of this lane's 8 channels: element (c, j) at W1x[c * ldw + j]; two 4-byte loads per channel
+      // (ldw and the column offset are even: the prepared weight's rows are 16-byte aligned)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned *pw = reinterpret_cast<const unsigned *>(W1x + (size_t)(cg * 8 + e) * ldw);
+        const unsigned w01 = pw[0], w2x = pw[1];
+        w[e][0] = e16_lo(w01);
+        w[e][1] = e16_hi(w01);
+        w[e][2] = e16_lo(w2x);
+      }
+    }
+    // rows r0 + q * rpb, q < 8, of this workgroup's block of rpb * 8 rows: loads in waves WITHOUT branches in between (rows past
+    // the end are clamped to a valid address and masked at the store): [source position] -> [neighbour index] -> [Z piece |
+    // coordinates | centre | weight]
+    const int r0 = (int)blockIdx.x * per_block + rsub;
+    int rc[U], pc[U];
+    bool ok[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int r = r0 + q * rpb;
+      ok[q] = r < R;
+      rc[q] = ok[q] ? r : R - 1;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) pc[q] = PLAN ? unit_src[rc[q] >> 3] * 8 + (rc[q] & 7) : rc[q];
+    int bm[U], k[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      bm[q] = (int)((unsigned)pc[q] / (unsigned)s);
+      k[q] = idx[pc[q]];
+    }
+    float z[U][8], xr[U][3], wr[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int b = (int)((unsigned)bm[q] / (unsigned)m);
+      load8f(Z + ((size_t)b * n + k[q]) * C + cg * 8, z[q]);
+      const float *pk = xyz + ((size_t)b * n + k[q]) * 3;
+      const float *pcn = new_xyz + (size_t)bm[q] * 3;
+      // rounded exactly like the coordinate columns of the grouped rows (sa_gather_kernel)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xr[q][j] = (float)(e16_t)((pk[j] - pcn[j]) * inv_r);
+      wr[q] = PLAN ? (float)row_w[rc[q]] : 1.f;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        y[e] = __builtin_fmaf(w[e][2], xr[q][2], __builtin_fmaf(w[e][1], xr[q][1], __builtin_fmaf(w[e][0], xr[q][0], z[q][e])));
+      const uint4 o = pack8(y);
+      float f[8];
+      unpack8(o, f);                                    // the statistics are those of the STORED values
+      const float wq = ok[q] ? wr[q] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        u[e] = __builtin_fmaf(wq, f[e], u[e]);
+        v[e] = __builtin_fmaf(wq * f[e], f[e], v[e]);
+      }
+      if (ok[q]) {
+        *reinterpret_cast<uint4 *>(Y + (size_t)rc[q] * C + cg * 8) = o;
+        if (cg == 0) {
+          const float xx[8] = {xr[q][0], xr[q][1], xr[q][2], 0, 0, 0, 0, 0};
+          *reinterpret_cast<uint4 *>(Xrel + (size_t)rc[q] * 8) = pack8(xx);
+        }
+      }
+    }
+  }
+  fold_groups_and_publish(u, v, cg, rsub, rpb, cgs, C, live_blocks, part, tickets, sums);
+}
+
+// Adjoint of the gather above, without atomics: dZ[b][k][c0..c0+8) = sum over the positions that read point k of dY[row][..]
+// (f32 sums; written as f32 and / or e16), and -- when the coordinates take a gradient -- dxyz[b][k] = inv_r * sum of
+// dXr[row][0..3) with dXr = dY W_x the gradient of the relative coordinates (e16 [rows][8]).
+__global__ __launch_bounds__(256) void sa_scatter_rows_csr_kernel(long long items, int n, int ms, int C, float inv_r,
+                                                                 const int *__restrict__ offsets,
+                                                                 const int *__restrict__ order,
+                                                                 const e16_t *__restrict__ dY, const e16_t *__restrict__ dXr,
+                                                                 float *__restrict__ dfeat32, e16_t *__restrict__ dfeat16,
+                                                                 float *__restrict__ dxyz, CsrPlan pl) {
+  auto row_of = [&](int b, int o) -> size_t {
+    if (!pl.goff) return (size_t)b * ms + o;
+    const int bm = b * pl.m + o / pl.s;
+    return (size_t)pl.goff[bm] * pl.gs + o % pl.s;
+  };
+  const int cpr = (C >> 3) + 1;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
+    const long long bk = q / cpr;
+    const int c8 = (int)(q - bk * cpr);
+    const int b = (int)(bk / n), k = (int)(bk - (long long)b * n);
+    const bool coord = c8 * 8 >= C;
+    if (coord && dxyz == nullptr) continue;
+    const e16_t *src = coord ? dXr : dY + c8 * 8;
+    const int pitch = coord ? 8 : C;
+    const int beg = offsets[(size_t)b * (n + 1) + k], end = offsets[(size_t)b * (n + 1) + k + 1];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int *ord = order + (size_t)b * ms;
+    int t = beg;
+    for (; t + 3 < end; t += 4) {
+      int o[4];
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) o[uu] = ord[t + uu];
+      uint4 vv[4];
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) vv[uu] = *reinterpret_cast<const uint4 *>(src + row_of(b, o[uu]) * pitch);
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        float d[8];
+        unpack8(vv[uu], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += d[e];
+      }
+    }
+    for (; t < end; ++t) {
+      float d[8];
+      unpack8(*reinterpret_cast<const uint4 *>(src + row_of(b, ord[t]) * pitch), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += d[e];
+    }
+    if (!coord) {
+      if (dfeat32) {
+        float *dst = dfeat32 + (size_t)bk * C + c8 * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      }
+      if (dfeat16) *reinterpret_cast<uint4 *>(dfeat16 + (size_t)bk * C + c8 * 8) = pack8(acc);
+    } else {
+      float *dst = dxyz + (size_t)bk * 3;
+      dst[0] = acc[0] * inv_r; dst[1] = acc[1] * inv_r; dst[2] = acc[2] * inv_r;
+    }
+  }
+}
+
 // f32 per-channel means for the *_bwd_apply kernels live right behind the f64 sums: the `sums` buffer of
 // the backward entry points has THREE rows of C doubles, [sum dz | sum dz*yhat | scratch] (omnipq_sa.h).
 static inline float *means_scratch(const double *sums, int C) {
@@ -1559,6 +1784,73 @@ extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kp
     if (BM > 0) {
       sa_centre_grad_kernel<<<(int)((BM + 255) / 256), 256, 0, (hipStream_t)stream>>>(BM, s, cin, kpad, inv_radius,
                                                                                   (const e16_t *)dX, dnew_xyz);
+      OMNIPQ_LAUNCH_CHECK();
+    }
+  }
+  return OMNIPQ_OK;
+}
+
+// ---- first layer of a stage with features on the source points (see sa_l1_rows_kernel) -------------------------------------
+// Y[row][0..C) (e16) = Z[b][idx][0..C) + W1x[c][0..3) . xrel,  Xrel[row][0..8) = e16 xrel | 0,  sums (f64 [2][C], ZERO on entry)
+// += the (row_w-weighted) column sum / sum of squares of the stored Y.  Z f32 [b*n][C]; W1x: e16, element (c, j) at
+// W1x[c * ldw + j], j < 3 (the coordinate columns of the prepared first-layer weight).  rows_dev != NULL: the stage's row plan
+// (omnipq_sa_ball_plan_src: rows in use, source position / 8 of every 8 compact rows, row weights) -- the compact rows are
+// written; passed explicitly, the calling thread's ambient plan is not consulted.
+extern "C" long long omnipq_sa_l1_rows_workspace_bytes(int b, int m, int s, int C) {
+  if (b <= 0 || m <= 0 || s <= 0 || C < 32 || (C % 8)) return 0;
+  const long long P = (long long)b * m * s;
+  const long long blocks = (P + 8LL * rows_per_block(C) - 1) / (8LL * rows_per_block(C));
+  return blocks * 2 * C * (long long)sizeof(float);
+}
+
+// workspace: omnipq_sa_l1_rows_workspace_bytes(b, m, s, C) bytes (per-workgroup partial sums; need not be cleared);
+// tickets: ZERO on entry, one 32-bit word per 16 workgroups (ceil(workspace rows / 16) words).
+extern "C" int omnipq_sa_l1_rows(int b, int n, int m, int s, int C, float inv_radius, const float *xyz,
+                                 const float *new_xyz, const int *idx, const float *Z, const void *W1x, int ldw,
+                                 const int *rows_dev, const int *unit_src, const unsigned char *row_w, void *Y, void *Xrel,
+                                 double *sums, void *workspace, void *tickets, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || s <= 0 || C < 32 || (C % 8) || C > kMaxC || ldw < 4 || (ldw % 2)) return OMNIPQ_EINVAL;
+  const long long P = (long long)b * m * s;
+  if (P == 0) return OMNIPQ_OK;
+  if (!xyz || !new_xyz || !idx || !Z || !W1x || !Y || !Xrel || !sums || !workspace || !tickets) return OMNIPQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(W1x) & 3) != 0) return OMNIPQ_EINVAL;
+  if (rows_dev && (!row_w || !unit_src || (s % 8))) return OMNIPQ_EINVAL;
+  const int rpb = rows_per_block(C);
+  const long long blocks = (P + 8LL * rpb - 1) / (8LL * rpb);
+  if (blocks > (1 << 20) || P > 0x7fffffffLL) return OMNIPQ_ETOOLARGE;
+  if (rows_dev)
+    sa_l1_rows_kernel<true><<<(int)blocks, 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+        (int)P, n, m, s, C, inv_radius, xyz, new_xyz, idx, Z, (const e16_t *)W1x, ldw, rows_dev, unit_src, row_w, (e16_t *)Y,
+        (e16_t *)Xrel, (float *)workspace, (unsigned *)tickets, sums);
+  else
+    sa_l1_rows_kernel<false><<<(int)blocks, 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+        (int)P, n, m, s, C, inv_radius, xyz, new_xyz, idx, Z, (const e16_t *)W1x, ldw, nullptr, nullptr, nullptr, (e16_t *)Y,
+        (e16_t *)Xrel, (float *)workspace, (unsigned *)tickets, sums);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// Its adjoint over the CSR of omnipq_sa_build_csr: dfeat32 (f32) and / or dfeat16 (e16) [b][n][C] = per-point sums of the rows
+// of dY (e16 [rows][C]); with dxyz != NULL also dxyz [b][n][3] and dnew_xyz [b][m][3] from dXr (e16 [rows][8], the gradient of
+// the relative coordinates).  goff / gs: the row plan the CSR was built under (NULL: none; coordinates then take no gradient).
+extern "C" int omnipq_sa_scatter_rows_csr(int b, int n, int m, int s, int C, float inv_radius, const int *offsets,
+                                          const int *order, const void *dY, const void *dXr, const int *goff, int gs,
+                                          float *dfeat32, void *dfeat16, float *dxyz, float *dnew_xyz, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || s <= 0 || C <= 0 || (C % 8)) return OMNIPQ_EINVAL;
+  if (b == 0) return OMNIPQ_OK;
+  if (!offsets || !order || !dY || (!dfeat32 && !dfeat16) || ((dxyz != nullptr) != (dnew_xyz != nullptr)) || (dxyz && !dXr))
+    return OMNIPQ_EINVAL;
+  if (goff && dxyz) return OMNIPQ_EINVAL;             // (the centre-gradient kernel does not know the plan)
+  const long long items = (long long)b * n * (C / 8 + 1);
+  sa_scatter_rows_csr_kernel<<<grid_for(items), 256, 0, (hipStream_t)stream>>>(
+      items, n, m * s, C, inv_radius, offsets, order, (const e16_t *)dY, (const e16_t *)dXr, dfeat32, (e16_t *)dfeat16, dxyz,
+      omnipq::CsrPlan{goff, m, s, gs});
+  OMNIPQ_LAUNCH_CHECK();
+  if (dnew_xyz) {
+    const long long BM = (long long)b * m;
+    if (BM > 0) {
+      sa_centre_grad_kernel<<<(int)((BM + 255) / 256), 256, 0, (hipStream_t)stream>>>(BM, s, 0, 8, inv_radius,
+                                                                                  (const e16_t *)dXr, dnew_xyz);
       OMNIPQ_LAUNCH_CHECK();
     }
   }

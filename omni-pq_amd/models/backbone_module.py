@@ -38,6 +38,8 @@ class Pointnet2Backbone(nn.Module):
             setattr(self, name, PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=nsample,
                                                       mlp=[ci] + cm + [co], use_xyz=True,
                                                       normalize_xyz=True))
+        for name_ in ("sa1", "sa2", "sa3", "sa4"):
+            getattr(self, name_).omnipq_stage = name_      # label of the stage in per-stage timings (sa_fused.run)
         self.fp1 = PointnetFPModule(mlp=[256 * width + 256 * width, 256 * width, 256 * width])
         self.fp2 = PointnetFPModule(mlp=[256 * width + 256 * width, 256 * width, 288])
 

@@ -619,6 +619,7 @@ class PQ_Transformer(nn.Module):
         self.vote_aggregation = PointnetSAModuleVotes(npoint=self.num_proposal, radius=0.3, nsample=16,
                                                       mlp=[288, 288, 288, 288], use_xyz=True,
                                                       normalize_xyz=True)
+        self.vote_aggregation.omnipq_stage = "vote"
         self.quad_proposal = QuadPredictHead(hidden_dim)
         self.proposal = PredictHead(hidden_dim, num_heading_bin, num_size_cluster, num_class, mean_size_arr)
 

@@ -58,13 +58,14 @@ SPAN_MARKERS = os.environ.get("OMNIPQ_SA_MARKERS") == "1"
 class _tagged:
     """Label the timing-sink entries of everything launched inside (bench.py's per-stage accounting)."""
 
-    def __init__(self, tag):
+    def __init__(self, tag, stage=None):
         self.tag = tag
+        self.stage = stage            # "@sa" spans: which stage (bench.py's per-stage split: sink names read "<call>@<stage>@sa")
         self.marked = False
 
     def __enter__(self):
         self.prev = _ext.timing_tag
-        _ext.timing_tag = self.tag
+        _ext.timing_tag = ("@" + self.stage + self.tag) if self.stage else self.tag
         if SPAN_MARKERS and self.tag == "@sa" and torch.cuda.is_available():
             self.marked = True
             _lib.omnipq_span_marker(0, _ext._stream())
@@ -76,6 +77,7 @@ class _tagged:
             _lib.omnipq_span_marker(1, _ext._stream())
 
 
+_STAGE_LABEL = None  # set by run(): the stage's name for the timing sink ("sa1" .. "vote", or m<npoint>s<nsample>)
 _SYNC = True       # set by run() per stage: do this stage's BatchNorm layers synchronise across ranks (SyncBatchNorm)?
 
 
@@ -299,7 +301,7 @@ def row_plan_ok(training, S, P, L, needs_input_grad, pooled):
 
 
 class _Plan:
-    __slots__ = ("goff", "rows_dev", "row_w", "scratch", "gs")
+    __slots__ = ("goff", "rows_dev", "row_w", "scratch", "gs", "unit_src")
 
 
 def make_row_plan(idx, P):
@@ -312,8 +314,9 @@ def make_row_plan(idx, P):
     plan.rows_dev = torch.empty((1,), device=dev, dtype=torch.int32)
     plan.row_w = torch.empty((P,), device=dev, dtype=torch.uint8)
     plan.scratch = torch.empty((B * M,), device=dev, dtype=torch.int32)
-    _call(_lib.omnipq_sa_ball_plan, idx, ctypes.c_longlong(B * M), S, plan.gs, _p(idx), _p(plan.goff), _p(plan.rows_dev),
-          _p(plan.row_w), _p(plan.scratch))
+    plan.unit_src = torch.empty((P // 8,), device=dev, dtype=torch.int32)
+    _call(_lib.omnipq_sa_ball_plan_src, idx, ctypes.c_longlong(B * M), S, plan.gs, _p(idx), _p(plan.goff), _p(plan.rows_dev),
+          _p(plan.row_w), _p(plan.unit_src), _p(plan.scratch))
     row_plan_last[P] = plan
     return plan
 
@@ -405,12 +408,37 @@ def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=N
 XYZGEN = True
 xyzgen_uses = 0            # forwards that took the path (tests check that it is the one that ran)
 _lib.omnipq_gemm_nt_xyz_workspace_floats.restype = ctypes.c_longlong
+_lib.omnipq_sa_l1_rows_workspace_bytes.restype = ctypes.c_longlong
 
 
 def xyzgen_ok(P, L, c0, needs_input_grad):
     """first layer generated from coordinates: training, no features, at least three layers (the second is not the pooled
     one), more than 64 row tiles (the kernels' partial-sum path), no gradient into the coordinates"""
     return XYZGEN and L >= 3 and P > 64 * 128 and c0 <= 256 and c0 % 8 == 0 and not needs_input_grad
+
+
+# The first layer of a stage WITH features on the SOURCE points (round 5; include/omnipq_sa.h: omnipq_sa_l1_rows).  The first
+# conv is linear in the grouped row [features(idx) | xrel], so it commutes with the grouping: Z = features W_f^T once per
+# source point -- a point is read by 4 (vote aggregation) to 16 (sa2) balls, so the contraction runs over 4 .. 16 times fewer
+# rows -- then y = Z[idx] + W_x . xrel per grouped row (gather + 3 FMAs + the statistics, one streaming launch).  The grouped
+# input rows X0 (sa2: 151 MB, written once and read twice per step) never exist; in backward the rows of dY1 are summed per
+# point first (the CSR scatter, now over C1 channels instead of cin + 3), and the weight gradient and the feature gradient
+# are contractions over the points.  Same values up to the order of the f32 sums (one e16 rounding of y, as before).
+# HOIST_L1 = False restores the grouped first layer (tests compare the two).
+HOIST_L1 = True
+hoist_uses = 0
+
+
+def hoist_ok(training, features, cin, cin_raw, L, c1, xgen):
+    return HOIST_L1 and training and features is not None and not xgen and cin == cin_raw and cin % 32 == 0 and cin > 0 and \
+        L >= 2 and AFFINE_OPERANDS and c1 % 32 == 0 and 32 <= c1 <= 640
+
+
+def gemm_nt_f32(A, B, M, N, K, lda, ldb):
+    """f32 C[M][N] = A[M][K] B[N][K]^T (16-bit operands, whole contraction per tile)"""
+    C = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    _call(_lib.omnipq_gemm_nt_e16_f32, A, M, N, K, _p(A), lda, _p(B), ldb, _p(C), N)
+    return C
 
 
 def gemm_nt_xyz(X0c, below, Bw, M, N, K, sums):
@@ -743,7 +771,8 @@ class deferred_wgrads:
         for (_, _, _, _, _, wt, crop, _, _, _) in items:
             cout, cin = crop[0], crop[1]
             if wt[0] == "param":
-                covered.setdefault(id(wt[1]), {})[wt[2]] = cout * cin
+                # (crop of five: a column range [off, off + cin) of a matrix of pitch ld -- see the loop below)
+                covered.setdefault(id(wt[1]), {})[(wt[2], crop[3] if len(crop) > 3 else 0)] = cout * cin
         complete = {k for k, v in covered.items() if sum(v.values()) == next(
             it[5][1] for it in items if it[5][0] == "param" and id(it[5][1]) == k).numel()}
 
@@ -771,7 +800,17 @@ class deferred_wgrads:
             q.ba, q.bb = (0, 0) if aff is None else (aff[0].data_ptr(), aff[1].data_ptr())
             q.M, q.N, q.P, q.lda, q.ldb = M, N, P, dY.stride(0), X.stride(0)
             q.out_rows, q.out_cols, q.out_ld, q.flags, q.colsum = cout, cin, cin, 0, 0
-            if wt[0] == "param":
+            if wt[0] == "param" and len(crop) > 3:
+                # a COLUMN range of the parameter's matrix: crop = (rows, columns, rot, first column, pitch).  Several
+                # problems cover one gradient (the hoisted first layer of an SA stage: features | coordinates)
+                _, wp, woff = wt
+                ent = buffer_of(wp, False)
+                key = (woff, crop[3])
+                assert key not in ent[2], "column ranges of one weight must be disjoint"
+                ent[2].add(key)
+                q.out_ld = crop[4]
+                q.out = ent[1].data_ptr() + 4 * (woff + crop[3])
+            elif wt[0] == "param":
                 _, wp, woff = wt
                 ent = buffer_of(wp, woff == 0 and cout * cin == wp.numel())
                 if woff in ent[2]:
@@ -1104,7 +1143,8 @@ class FusedSAStage(torch.autograd.Function):
     def forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training, bn_cfg, *params):
         ctx.e16 = E16.dtype
         ctx.n_inputs = 9 + len(params)
-        with _tagged("@sa"):
+        ctx.stage_label = _STAGE_LABEL
+        with _tagged("@sa", ctx.stage_label):
             return FusedSAStage._forward(ctx, xyz, new_xyz, features, feat_pm, idx, radius, normalize_xyz, training,
                                          bn_cfg, *params)
 
@@ -1144,11 +1184,20 @@ class FusedSAStage(torch.autograd.Function):
             row_plan_uses += 1
             plan = make_row_plan(idx, P)
         ctx.plan = plan
-        X = torch.empty((P, xpad), device=dev, dtype=E16.dtype)
+        hoist = hoist_ok(training, features, cin, cin_raw, L, params[0].shape[0], xgen) and \
+            (plan is None or not xyz_grad)
+        ctx.hoist = None
+        if hoist:
+            global hoist_uses
+            hoist_uses += 1
+            # (layer 0 of _forward_layers gathers Z rows instead of contracting grouped rows; nothing is gathered here)
+            ctx.hoist = (xyz_c, cen_c, idx, feat_pm.reshape(B * N, cin), N, M, S, inv_r)
+        X = None if hoist else torch.empty((P, xpad), device=dev, dtype=E16.dtype)
         with _row_plan(plan, P):
             # (with a plan: the gather writes the compact row space, every launch below works on the rows in use)
-            _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, xpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
-                  _p(idx), _p(feat_pm), _p(X))
+            if not hoist:
+                _call(_lib.omnipq_sa_gather, xyz_c, B, N, M, S, cin, xpad, ctypes.c_float(inv_r), _p(xyz_c), _p(cen_c),
+                      _p(idx), _p(feat_pm), _p(X))
             X0 = X
             layers, pool, X = FusedSAStage._forward_layers(ctx, params, bn_cfg, L, X, X0, P, B, M, S, cin, cin_raw, kpad,
                                                            training, xgen, xpad, world, dev)
@@ -1196,6 +1245,21 @@ class FusedSAStage(torch.autograd.Function):
                     _call(_lib.omnipq_sa_xyz_moments, X, ctypes.c_longlong(P), _p(X), xpad, _p(lay.mom))
                     _call(_lib.omnipq_sa_xyz_stats, X, cout, _p(lay.Wp), K, _p(lay.mom), _p(sums))
                     lay.Y = None
+                elif l == 0 and getattr(ctx, "hoist", None) is not None:
+                    hx, hc, hidx, hfeat, hN, hM, hS, hinv = ctx.hoist
+                    Z = gemm_nt_f32(hfeat, lay.Wp, hfeat.shape[0], cout, cin, cin, K)     # W_f = the first cin prepared columns
+
+                    lay.Y = torch.empty((P, cout), device=dev, dtype=E16.dtype)
+                    Xrel = torch.empty((P, 8), device=dev, dtype=E16.dtype)
+                    plan = getattr(ctx, "plan", None)
+                    nws = int(_lib.omnipq_sa_l1_rows_workspace_bytes(B, hM, hS, cout))
+                    ws_ = torch.empty((nws // 4,), device=dev, dtype=torch.float32)
+                    tk_ = zeros_f32(nws // (8 * cout * 16) + 1, dev)          # one zero word per 16 workgroups
+                    _call(_lib.omnipq_sa_l1_rows, Z, B, hN, hM, hS, cout, ctypes.c_float(hinv), _p(hx), _p(hc), _p(hidx), _p(Z),
+                          ctypes.c_void_p(lay.Wp.data_ptr() + cin * lay.Wp.element_size()), K,
+                          _p(plan.rows_dev if plan is not None else None), _p(plan.unit_src if plan is not None else None),
+                          _p(plan.row_w if plan is not None else None), _p(lay.Y), _p(Xrel), _p(sums), _p(ws_), _p(tk_))
+                    ctx.hoist = ctx.hoist + (Xrel,)
                 elif xgen and l == 1:
                     lay.Y = gemm_nt_xyz(X0, layers[0], lay.Wp, P, cout, K, sums)
                 elif l > 0 and X is None:
@@ -1297,7 +1361,7 @@ class FusedSAStage(torch.autograd.Function):
         E16.select(ctx.e16)
         if g_out is None:                       # the stage's output took no part in the loss
             return (None,) * ctx.n_inputs
-        with _tagged("@sa"), _row_plan(getattr(ctx, "plan", None), ctx.geom[4]):
+        with _tagged("@sa", getattr(ctx, "stage_label", None)), _row_plan(getattr(ctx, "plan", None), ctx.geom[4]):
             return FusedSAStage._backward(ctx, g_out)
 
     @staticmethod
@@ -1369,6 +1433,9 @@ class FusedSAStage(torch.autograd.Function):
                       _p(prev.mean), _p(prev.invstd), ctypes.c_double(1.0 / (float(P) * world)), _p(dW0))
                 grads[0] = dW0
                 break
+            if l == 0 and getattr(ctx, "hoist", None) is not None:
+                d_xyz, d_cen, d_feat = FusedSAStage._backward_hoisted(ctx, dY, lay, grads, dfr, dev)
+                break
             below = layers[l - 1] if (l > 0 and layers[l - 1].X is None) else None
             Xin = below.Y if below is not None else (layers[l - 1].X if l > 0 else ctx.X0)
             wt = ctx.wtargets[l] if (dfr is not None and SA_WGRADS_GROUPED) else None
@@ -1412,6 +1479,59 @@ class FusedSAStage(torch.autograd.Function):
                     d_feat = dfeat_pm[..., :ctx.cin_raw].transpose(1, 2).to(ctx.feat_dtype)      # (B, cin, N) view, see forward
         ctx.layers = None
         return (d_xyz, d_cen, d_feat, None, None, None, None, None, None, *grads)
+
+
+def _backward_hoisted(ctx, dY, lay, grads, dfr, dev):
+    """Layer 0 of a stage whose first layer ran on the source points (HOIST_L1): dY = the gradient w.r.t. its pre-BatchNorm
+    output, (rows, C1) 16-bit.  Per-point sums of dY's rows first (CSR, no atomics), then everything is a contraction over
+    the B * N points: dW_f = dZ^T features, d features = dZ W_f; the three coordinate columns of the weight take
+    dW_x = dY^T xrel over the rows.  -> (d_xyz, d_cen, d_feat)"""
+    B, N, M, S, P, cin, kpad, inv_r, world = ctx.geom
+    xyz_c, cen_c, idx, feat2d, _, _, _, _, Xrel = ctx.hoist
+    plan = getattr(ctx, "plan", None)
+    C1 = lay.C
+    want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+    want_feat = ctx.has_features and ctx.needs_input_grad[2]
+    want_w = ctx.needs_input_grad[9]
+    d_xyz = d_cen = d_feat = None
+    if not (want_xyz or want_feat or want_w):
+        return d_xyz, d_cen, d_feat
+    offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
+    order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
+    scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
+    _call(_lib.omnipq_sa_build_csr, dY, B, N, M, S, _p(idx), _p(offsets), _p(order), _p(scratch))
+    dXr = None
+    if want_xyz:
+        # gradient of the relative coordinates: dY W_x (the rows cin .. cin + 7 of the transposed prepared weight: W_x^T | 0)
+        dXr = torch.empty((P, 8), device=dev, dtype=E16.dtype)
+        _call(_lib.omnipq_gemm_nt_e16, dY, P, 8, C1, _p(dY), C1,
+              ctypes.c_void_p(lay.Wt.data_ptr() + cin * C1 * lay.Wt.element_size()), C1, _p(dXr), 8)
+        d_xyz = torch.empty((B, N, 3), device=dev)
+        d_cen = torch.empty((B, M, 3), device=dev)
+    dZ = torch.empty((B * N, C1), device=dev, dtype=E16.dtype)
+    _call(_lib.omnipq_sa_scatter_rows_csr, dY, B, N, M, S, C1, ctypes.c_float(inv_r), _p(offsets), _p(order), _p(dY), _p(dXr),
+          _p(plan.goff if plan is not None else None), plan.gs if plan is not None else 16, _p(None), _p(dZ), _p(d_xyz),
+          _p(d_cen))
+    if want_w:
+        wt = ctx.wtargets[0] if (dfr is not None and SA_WGRADS_GROUPED) else None
+        ld = ctx.cin_raw + 3
+        if wt is not None:
+            # the parameter's columns are [xyz(3) | features(cin)] (pointnet2_utils.py:357-359): two problems of the grouped
+            # launch write the two column ranges of one gradient buffer
+            dfr.add_sa(dZ, feat2d, C1, cin, B * N, wt, (C1, cin, 0, 3, ld))
+            dfr.add_sa(dY, Xrel, C1, 8, P, wt, (C1, 3, 0, 0, ld), blk=plan)
+        else:
+            dWf = _gemm_tn(dZ, feat2d, C1, cin, B * N)
+            dWx = _gemm_tn(dY, Xrel, C1, 8, P)              # (inside backward()'s _row_plan block: the rows in use)
+            grads[0] = torch.cat([dWx[:, :3], dWf], 1).view(C1, ld, 1, 1)
+    if want_feat:
+        # d features = dZ W_f: the first cin rows of the transposed prepared weight are W_f^T, K-contiguous over C1
+        dfeat = gemm_nt_f32(dZ, lay.Wt, B * N, cin, C1, C1, C1)
+        d_feat = dfeat.view(B, N, cin).transpose(1, 2).to(ctx.feat_dtype)
+    return d_xyz, d_cen, d_feat
+
+
+FusedSAStage._backward_hoisted = staticmethod(_backward_hoisted)
 
 
 def _bn_of(layer):
@@ -1469,7 +1589,9 @@ def eligible(module, xyz, features):
 
 def run(module, xyz, new_xyz, features):
     """ball query + fused stage -> (B, C_out, npoint) f32"""
-    with _tagged("@sa"):
+    global _STAGE_LABEL
+    _STAGE_LABEL = getattr(module, "omnipq_stage", None) or f"m{module.npoint}s{module.nsample}"
+    with _tagged("@sa", _STAGE_LABEL):
         idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
     params, bn_cfg = [], []
     for layer in module.mlp_module:

@@ -352,8 +352,10 @@ def test_sa_weight_gradients_deferred_into_one_grouped_launch_equal_the_immediat
         mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
             mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}), 9).to(dev()).train()
         f = None if feats is None else feats.clone().requires_grad_(True)
+        h0 = sa_fused.hoist_uses
         with torch.autocast("cuda", dtype=torch.bfloat16):
             _, out, _ = mod(xyz, f)
+        hoisted = sa_fused.hoist_uses > h0
         g_up = procedural_tensor("defer.g_up", tuple(out.shape), torch.float32).to(dev())
         if mode == "deferred":
             with sa_fused.deferred_wgrads() as dfr:
@@ -361,6 +363,8 @@ def test_sa_weight_gradients_deferred_into_one_grouped_launch_equal_the_immediat
                 # sa1-like stages generate their first layer from coordinates: its gradient comes from moments, the second
                 # layer's from the coordinate-generating GEMM -- only the third is an ordinary weight-gradient problem
                 expect = 1 if case == "sa1_like" else len(spec["mlp"]) - 1
+                if hoisted:
+                    expect += 1        # the first layer on the source points hands over two problems (features | coordinates)
                 assert len(dfr.sa_items) == expect, "the stage did not hand its weight gradients over"
                 assert all(p.grad is None for k, p in mod.named_parameters() if k.endswith("conv.weight")
                            and not (case == "sa1_like" and ("layer0" in k or "layer1" in k)))
@@ -972,3 +976,71 @@ def test_row_plan_equals_the_full_stage(case, group, monkeypatch):
     P = cnt.numel() * spec["nsample"]
     assert int(sa_fused.row_plan_last[P].rows_dev.item()) == int(((cnt + group - 1) // group * group).sum())
     assert 0.2 < float(kept) < 0.9
+
+
+@pytest.mark.parametrize("case", ["sa2_planned", "sa4", "vote_with_coordinate_gradient", "sa3_deferred_grouped"])
+def test_first_layer_on_the_source_points_equals_the_grouped_first_layer(case, monkeypatch):
+    """sa_fused.HOIST_L1 (round 5): the first conv of a stage with features is linear in the grouped row, so it is computed once
+    per SOURCE point and gathered (omnipq_sa_l1_rows), and in backward the rows' gradients are summed per point before the
+    weight-gradient / data-gradient contractions.  Must equal the grouped first layer (reference pointnet2_modules.py:243-257
+    groups first) up to the order of the f32 sums: same pooled rows' outputs, every parameter gradient, the feature gradient and
+    -- for the vote aggregation, whose coordinates are learned -- the coordinate gradients; with a row plan (sa2), without one,
+    and through the deferred grouped weight-gradient launch."""
+    import pointnet2_modules
+    import sa_fused
+    spec, B, n, cin = {
+        "sa2_planned": (dict(npoint=1024, radius=0.4, nsample=32, mlp=[256, 256, 256, 512]), 8, 2048, 256),
+        "sa4": (dict(npoint=256, radius=1.2, nsample=16, mlp=[512, 256, 256, 512]), 8, 512, 512),
+        "sa3_deferred_grouped": (dict(npoint=512, radius=0.8, nsample=16, mlp=[512, 256, 256, 512]), 4, 1024, 512),
+        "vote_with_coordinate_gradient": (dict(npoint=256, radius=0.3, nsample=16, mlp=[288, 288, 288, 288]), 8, 1024, 288),
+    }[case]
+    xyz = synth.make_clouds(91, B, n, kind="room").to(dev())
+    want_xyz = case == "vote_with_coordinate_gradient"
+    feats = (procedural_tensor("hoist.feats", (B, cin, n), torch.float32).to(dev()) * 0.5).requires_grad_(True)
+    monkeypatch.setenv("OMNIPQ_SA", "fused")
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(sa_fused, "HOIST_L1", on)
+        mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
+            mlp=list(spec["mlp"]), use_xyz=True, normalize_xyz=True, **{k: v for k, v in spec.items() if k != "mlp"}), 3)
+        mod = mod.to(dev()).train()
+        with torch.no_grad():
+            for name, prm in mod.named_parameters():
+                if name.endswith("bn.bn.weight"):
+                    prm[::3] *= -1.0
+        pts = xyz.clone().requires_grad_(want_xyz)
+        uses, plans = sa_fused.hoist_uses, sa_fused.row_plan_uses
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            new_xyz, out, inds = mod(pts, feats)
+        assert (sa_fused.hoist_uses > uses) == on
+        assert (sa_fused.row_plan_uses > plans) == (case == "sa2_planned")
+        g_up = procedural_tensor("hoist.g_up", tuple(out.shape), torch.float32).to(dev())
+        feats.grad = None
+        loss_terms = (out.float() * g_up).sum()
+        if want_xyz:
+            loss_terms = loss_terms + (new_xyz * procedural_tensor("hoist.g_xyz", tuple(new_xyz.shape), torch.float32).to(dev())).sum()
+        if case == "sa3_deferred_grouped":
+            with sa_fused.deferred_wgrads():
+                loss_terms.backward()
+        else:
+            loss_terms.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in mod.named_parameters()}
+        grads["features"] = feats.grad.detach().clone()
+        if want_xyz:
+            grads["xyz"] = pts.grad.detach().clone()
+        res[on] = (out.detach().clone(), inds.clone(), grads,
+                   {k: b.detach().clone() for k, b in mod.named_buffers() if b.is_floating_point()})
+    grouped, hoisted = res[False], res[True]
+    assert torch.equal(grouped[1], hoisted[1])
+    e_out = rel_l2(hoisted[0], grouped[0])
+    print(f"\n{case}: output rel-L2 hoisted vs grouped {e_out:.2e}")
+    assert e_out < 3e-3, e_out
+    assert set(grouped[2]) == set(hoisted[2])
+    for k in grouped[2]:
+        e = rel_l2(hoisted[2][k], grouped[2][k])
+        print(f"  grad {k:40s} rel-L2 {e:.2e}  |g| {float(grouped[2][k].norm()):.3e}")
+        assert torch.isfinite(hoisted[2][k]).all(), k
+        assert e < 2e-2, (k, e)
+    for k in grouped[3]:
+        assert rel_l2(hoisted[3][k], grouped[3][k]) < 1e-4, k
