@@ -156,6 +156,16 @@ class Pointnet2Backbone(nn.Module):
         else:
             self._plan = self._launch_plan(pointcloud, trusted, small)
 
+    def forget_plan(self):
+        """Drop the HOST-side record of a plan in flight / pending (not the device work).  A captured step replays its
+        sampling chains from the graph; the plan record its capture run (or an up-front `prefetch` before a replay) left behind
+        is marked `trusted` and would hand a LATER eager forward() -- an evaluation pass between two training steps -- the
+        indices of whatever batch the static buffers held last.  train_step.CapturedStep calls this after the capture and
+        after every replay."""
+        self._plan = None
+        self._pending = None
+        self._extra = None
+
     def join(self, device=None):
         """Make the current stream wait for everything queued on the sampling stream."""
         if self._side is not None:

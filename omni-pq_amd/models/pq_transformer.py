@@ -754,6 +754,10 @@ class PQ_Transformer(nn.Module):
         next forward() call (of the CURRENT batch) instead of now, see Pointnet2Backbone.prefetch."""
         self.backbone.prefetch(inputs['point_clouds'], trusted, at_next_forward, footprint)
 
+    def forget_prefetch(self):
+        """Forget the host-side record of a sampling plan in flight (Pointnet2Backbone.forget_plan)."""
+        self.backbone.forget_plan()
+
     def join_prefetch(self):
         """Order the current stream after the sampling stream (needed before a graph capture ends)."""
         self.backbone.join()

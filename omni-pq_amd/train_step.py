@@ -201,6 +201,7 @@ class CapturedStep:
             # caller's optimizer.zero_grad() (set_to_none=True is torch's default) detaches them from the parameters, so
             # every replay hands them back.
             self._grads = [(p, p.grad) for p in net.parameters() if p.grad is not None]
+            self._forget_plans()
             with torch.no_grad():
                 for b, saved in keep:
                     b.copy_(saved)
@@ -255,7 +256,16 @@ class CapturedStep:
         self.replays += 1
         for p, g in self._grads:
             p.grad = g
+        self._forget_plans()
         return self.static_loss
+
+    def _forget_plans(self):
+        """The replayed graph owns the sampling chains; what the capture run (or the up-front sampling of an unannounced batch)
+        left in the networks' host-side plan records must not reach a later EAGER forward of the same network (an evaluation
+        pass between steps would silently take the indices of another batch)."""
+        for m in (self.net, self.teacher):
+            if m is not None and hasattr(m, "forget_prefetch"):
+                m.forget_prefetch()
 
     @staticmethod
     def _fill(dst, src):

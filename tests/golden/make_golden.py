@@ -97,13 +97,17 @@ def op_case(name, xyz, npoint, radius, nsample, channels=5):
                 "channels": channels}, out)
 
 
-def sa_case(name, xyz, feats, spec):
+def sa_case(name, xyz, feats, spec, feats_procedural=None):
+    """feats_procedural = (tensor name, shape, scale): the features are NOT stored in the fixture (16 MB for sa2 at batch 8),
+    the tests regenerate them (tests/procedural.py: features_of)."""
     B = xyz.shape[0]
     spec = dict(spec)
     mlp = list(spec.pop("mlp"))
     mod = ref_modules.PointnetSAModuleVotes(mlp=list(mlp), **spec)
     load_procedural(mod)
     mod.train()
+    if feats_procedural is not None:
+        feats = procedural_tensor(feats_procedural[0], tuple(feats_procedural[1]), torch.float32) * feats_procedural[2]
     f = None if feats is None else feats.clone().requires_grad_(True)
     new_xyz, new_feats, inds = mod(xyz, f)
     g_up = procedural_tensor(name + ".g_out", tuple(new_feats.shape), torch.float32)
@@ -119,7 +123,10 @@ def sa_case(name, xyz, feats, spec):
         if "running" in k:
             out["buf." + k] = summarize(v)
     spec["mlp"] = mlp
-    save(name, {"xyz": xyz, "features": feats, "spec": spec}, out)
+    if feats_procedural is not None:
+        save(name, {"xyz": xyz, "features": None, "features_procedural": tuple(feats_procedural), "spec": spec}, out)
+    else:
+        save(name, {"xyz": xyz, "features": feats, "spec": spec}, out)
 
 
 def fp_case(name, B, n, m, c_unknown, c_known, mlp):
@@ -362,6 +369,12 @@ if __name__ == "__main__":
     if want("sa1_room40000_b2"):
         sa_case("sa1_room40000_b2", synth.make_clouds(31, 2, 40000, kind="room"), None,
                 dict(npoint=2048, radius=0.2, nsample=64, mlp=[0, 128, 128, 256], use_xyz=True, normalize_xyz=True))
+    # round 5: the backbone's sa2 (backbone_module.py:49-58) at the benchmark's batch of 8 -- 2^18 grouped
+    # rows, the stage whose fused run drops the most duplicate rows (row plan) and computes its first layer on the source points
+    if want("sa2_room2048_b8"):
+        sa_case("sa2_room2048_b8", synth.make_clouds(32, 8, 2048, kind="room"), None,
+                dict(npoint=1024, radius=0.4, nsample=32, mlp=[256, 256, 256, 512], use_xyz=True, normalize_xyz=True),
+                feats_procedural=("sa2_room2048_b8.feats", (8, 256, 2048), 0.5))
     if want("fp2_like"):
         fp_case("fp2_like", 2, 1024, 512, 64, 96, [160, 128, 72])
     if want("model_eval_8192"):

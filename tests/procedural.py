@@ -56,3 +56,13 @@ def summarize(t, max_full=8192):
         out["absmax"] = float(d.abs().max())
         out["sum"] = float(d.sum())
     return out
+
+
+def features_of(inputs, device="cpu"):
+    """The feature tensor of an SA fixture: stored, or regenerated from its procedural spec (name, shape, scale)."""
+    if inputs.get("features") is not None:
+        return inputs["features"].to(device)
+    spec = inputs.get("features_procedural")
+    if spec is None:
+        return None
+    return (procedural_tensor(spec[0], tuple(spec[1]), torch.float32) * spec[2]).to(device)

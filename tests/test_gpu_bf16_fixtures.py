@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from procedural import load_procedural, procedural_tensor
+from procedural import features_of, load_procedural, procedural_tensor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -81,7 +81,8 @@ def run_sa(name, fx):
     load_procedural(mod)
     mod.to(DEV).train()
     xyz = inp["xyz"].to(DEV)
-    f = None if inp["features"] is None else inp["features"].to(DEV).clone().requires_grad_(True)
+    f = features_of(inp, DEV)
+    f = None if f is None else f.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         new_xyz, new_feats, inds = mod(xyz, f)
     g_up = procedural_tensor(name + ".g_out", tuple(new_feats.shape), torch.float32).to(DEV)
@@ -95,12 +96,18 @@ def run_sa(name, fx):
     return res, hasattr(new_feats, "omnipq_rows16")
 
 
-@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048", "sa1_room40000_b2"])
+@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048", "sa1_room40000_b2", "sa2_room2048_b8"])
 def test_fused_bf16_sa_stage_matches_reference_fixture(name):
+    import sa_fused
     fx = load_golden(name)
     out = fx["outputs"]
+    plans, hoists = sa_fused.row_plan_uses, sa_fused.hoist_uses
     ours, fused = run_sa(name, fx)
     assert fused, "the fused bf16 stage did not engage"
+    if name == "sa2_room2048_b8":
+        # round 5: the REFERENCE's sa2 at batch 8 against the fused stage WITH its row plan (2^18 grouped
+        # rows) and its first layer on the source points -- not only plan == full stage chained to full == reference
+        assert sa_fused.row_plan_uses > plans and sa_fused.hoist_uses > hoists
     with composed():
         theirs, fused_c = run_sa(name, fx)
     assert not fused_c

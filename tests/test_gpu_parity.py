@@ -366,7 +366,7 @@ def test_ops_through_python_layers_match_reference_fixture(name):
     run_op_case(name, load_golden(name), pointnet2_utils, device="cuda", tol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048", "sa1_room40000_b2"])
+@pytest.mark.parametrize("name", ["sa1_uniform4096", "sa_feat_room2048", "sa1_room40000_b2", "sa2_room2048_b8"])
 def test_sa_module_on_gpu_matches_reference_fixture(name):
     import pointnet2_modules
     from test_oracle_golden import run_sa_case

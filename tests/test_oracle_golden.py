@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import check_summary, load_golden
-from procedural import load_procedural, procedural_tensor
+from procedural import features_of, load_procedural, procedural_tensor
 
 OP_CASES = ["ops_room512", "ops_room4096", "ops_adv600", "ops_adv2048"]
 
@@ -66,7 +66,8 @@ def run_sa_case(name, fx, modules, device="cpu", tol=1e-5, grad_tol=None, grad_m
     load_procedural(mod)
     mod.to(device).train()
     xyz = inp["xyz"].to(device)
-    f = None if inp["features"] is None else inp["features"].to(device).clone().requires_grad_(True)
+    f = features_of(inp, device)
+    f = None if f is None else f.clone().requires_grad_(True)
     new_xyz, new_feats, inds = mod(xyz, f)
     check_summary(inds, out["inds"], "inds")
     check_summary(new_xyz, out["new_xyz"], "new_xyz", 0.0)

@@ -157,3 +157,77 @@ def test_captured_step_trains_through_zero_grad_and_keeps_the_teacher_semantics(
     a = 1.0 - 1.0 / 6.0
     want = t1 * a + (1.0 - a) * w1
     assert torch.allclose(teacher.decoder[0].linear1.weight, want, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_whole_model_at_configs1_as_written_40k_points_batch_8_bf16_through_the_captured_step():
+    """BASELINE configs[1] exactly as written -- 8 scenes x 40 000 points, bf16, forward + backward -- the shape the headline is
+    measured on, through `CapturedStep` replays (until round 5 this shape ran only under bench.py, which
+    asserts a finite loss and nothing else).  Properties that need no reference at this size: every float end_point and every
+    parameter gradient of a REPLAYED step is finite and non-trivial; the backbone's index end_points equal the ORACLE's
+    furthest-point sampling on the same clouds (two of the 8 scenes), seeds are the first 1024 sa1 picks, centres are the
+    clouds' own points; and a replay gives the index keys of the same batch launched eagerly."""
+    sys.path.insert(0, REPO)
+    import bench
+    import synth
+    import train_step
+    from oracle import oracle_ext
+    dev = torch.device("cuda", 0)
+    B, N = 8, 40000
+    pcs = [synth.make_clouds(700 + i, B, N, kind="room") for i in range(3)]
+    dpcs = [p.to(dev) for p in pcs]
+    torch.manual_seed(3)
+    net = bench.build_model(0).to(dev).train()
+
+    def criterion(ep, labels):
+        return bench.loss_of(ep)
+
+    st = train_step.CapturedStep(net, criterion, {"point_clouds": dpcs[0]})
+    assert st.launch == "hipGraph replay"
+    int_keys = ("sa1_inds", "sa2_inds", "fp2_inds", "seed_inds")
+    replayed = []
+    for pc, nxt in train_step.lookahead(dpcs):
+        loss = st.step({"point_clouds": pc}, None, next_inputs=None if nxt is None else {"point_clouds": nxt})
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).item()
+        ep = st.end_points
+        n_float = 0
+        for k, v in ep.items():
+            if torch.is_tensor(v) and v.is_floating_point():
+                assert torch.isfinite(v).all().item(), k
+                n_float += 1
+        assert n_float >= 100 and len(ep) >= 119
+        n_grad = 0
+        for name, p in net.named_parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all().item(), name
+                n_grad += 1
+        assert n_grad >= 300
+        for name in ("backbone.sa1.mlp_module.layer1.conv.weight", "backbone.sa2.mlp_module.layer0.conv.weight",
+                     "vote_aggregation.mlp_module.layer0.conv.weight", "decoder.5.linear2.weight"):
+            assert float(dict(net.named_parameters())[name].grad.abs().sum()) > 0, name
+        replayed.append({k: ep[k].clone() for k in int_keys + ("sa1_xyz", "aggregated_vote_xyz")})
+    assert st.replays == 3
+    # index keys of the replays: int32, oracle-exact on scenes 0 and 7 of every batch
+    for i, (pc, got) in enumerate(zip(pcs, replayed)):
+        for k in int_keys:
+            assert got[k].dtype == torch.int32, k
+        assert tuple(got["sa1_inds"].shape) == (B, 2048) and tuple(got["sa2_inds"].shape) == (B, 1024)
+        assert torch.equal(got["seed_inds"], got["sa1_inds"][:, :1024])
+        for scene in (0, 7):
+            cloud = pc[scene:scene + 1].contiguous()
+            want1 = oracle_ext.furthest_point_sampling(cloud, 2048)
+            assert torch.equal(got["sa1_inds"][scene:scene + 1].cpu(), want1), (i, scene)
+            centres = cloud[0, want1[0].long()].unsqueeze(0).contiguous()
+            assert torch.equal(got["sa1_xyz"][scene:scene + 1].cpu(), centres), (i, scene)
+            want2 = oracle_ext.furthest_point_sampling(centres, 1024)
+            assert torch.equal(got["sa2_inds"][scene:scene + 1].cpu(), want2), (i, scene)
+    # the same batches launched eagerly by the same network (weights unchanged: no optimizer ran): same index keys
+    eager = train_step.CapturedStep(net, criterion, {"point_clouds": dpcs[0]}, graph=False)
+    for pc, got in zip(dpcs, replayed):
+        seen = {}
+        hook = net.register_forward_hook(lambda m, a, out: seen.update({k: out[k].detach().clone() for k in int_keys}))
+        eager.step({"point_clouds": pc}, None)
+        hook.remove()
+        for k in int_keys:
+            assert torch.equal(seen[k], got[k]), k
