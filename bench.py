@@ -204,6 +204,8 @@ def _loss_weights(sizes, device):
 def algorithmic_bytes(name, a):
     """SURVEY.md 8(d) per-call bytes (f32 features, e = 4) from the C-ABI integer arguments."""
     name = name.split("@")[0]
+    if name == "omnipq_furthest_point_sampling_ex":      # (the binding calls the variant with the explicit flags word)
+        name = "omnipq_furthest_point_sampling"
     if name == "omnipq_furthest_point_sampling":
         b, n, m = a[:3]
         return b * (12 * n + 4 * m)
@@ -394,7 +396,7 @@ def counters_stale(summary):
 
 
 # C-ABI entry point -> substring of the device kernel it launches for the benchmark's shapes
-PMC_KERNEL_OF = {"omnipq_furthest_point_sampling": "fps_kernel<1024, "}
+PMC_KERNEL_OF = {"omnipq_furthest_point_sampling": "fps_kernel<1024, ", "omnipq_furthest_point_sampling_ex": "fps_kernel<1024, "}
 
 
 def summarize_ops(sink, steps):
@@ -417,7 +419,7 @@ def stage_breakdown(table, steps):
         "head decode", "other native"))
     for (nm, _), v in table.items():
         base, sa = nm.split("@")[0], nm.endswith("@sa")
-        if base == "omnipq_furthest_point_sampling":
+        if base in ("omnipq_furthest_point_sampling", "omnipq_furthest_point_sampling_ex"):
             k = "fps"
         elif base.startswith("omnipq_ball_query"):
             k = "ball_query"
@@ -943,7 +945,7 @@ def main():
                         "launches_per_step": calls / timing_steps, "algorithmic_bytes_per_launch": nbytes}
             native_ms = sum(v[0] for v in table.values()) / timing_steps
             rec["native_ops_ms_per_step"] = native_ms
-            if name.split("@")[0] == "omnipq_furthest_point_sampling":
+            if name.split("@")[0] in ("omnipq_furthest_point_sampling", "omnipq_furthest_point_sampling_ex"):
                 # latency bound by construction (m - 1 dependent argmax rounds): SURVEY 8d asks for rounds/s too
                 dominant["rounds_per_s"] = (a[2] - 1) / (avg_ms * 1e-3)
                 dominant["us_per_round"] = avg_ms * 1e3 / (a[2] - 1)

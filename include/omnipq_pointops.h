@@ -78,19 +78,15 @@ int omnipq_fps_check(void *stream);
  * sizes the multi-workgroup launches (occupancy query); call it once per device outside any stream capture. */
 int omnipq_fps_poll(void);
 int omnipq_fps_init(void);
-/* Extension (the reference's FPS is one block per scene, sampling_gpu.cu:168-176; there is nothing to choose): for the
- * CALLING THREAD, sampling launches on clouds of more than 8192 points issued after omnipq_fps_footprint(1) use 16 points
- * per thread -- 3 workgroups per 40 000-point scene instead of 5, ~40 % longer rounds, identical indices -- until
- * omnipq_fps_footprint(0).  For a chain that runs underneath other work and ends before it. */
-void omnipq_fps_footprint(int small);
-/* omnipq_fps_pruned(1), CALLING THREAD only: clouds of more than 8192 points are sampled by csrc/fps.hip: fps_pruned_kernel
- * (points in Morton order, 20 480 per workgroup, a round visits only the cells of 256 points whose running distances the new
- * pick can change; same indices and the same `temp`).  Exact but slower than the default kernels on MI355X (measured: the
- * note in fps.hip); 0 restores the default. */
-void omnipq_fps_pruned(int on);
-/* {cells visited, workgroup-rounds} of the pruned sampling launches since the last call: visited / rounds = cells of 256
- * points a workgroup updates per round (of its 80).  Synchronises the device and resets the counters (tools/bench_fps.py). */
-int omnipq_fps_pruned_stats(unsigned long long *out2);
+/* Extension (the reference's FPS is one block per scene, sampling_gpu.cu:168-176; there is nothing to choose): the same
+ * sampling with an explicit `flags` word -- no per-thread mode (round 5; replaces omnipq_fps_footprint).
+ *   OMNIPQ_FPS_SMALL_FOOTPRINT   clouds of more than 8192 points use 16 points per thread: 3 workgroups per 40 000-point scene
+ *                                instead of 5, ~40 % longer rounds, identical indices and `temp`.  For a chain that runs
+ *                                underneath other work and ends before it.
+ * omnipq_furthest_point_sampling(...) == omnipq_furthest_point_sampling_ex(..., 0, stream). */
+#define OMNIPQ_FPS_SMALL_FOOTPRINT 1u
+int omnipq_furthest_point_sampling_ex(int b, int n, int m, const float *dataset, float *temp, int *idxs, unsigned flags,
+                                      void *stream);
 
 /* replaces gather_points_kernel_wrapper (sampling.cpp:11-13).
  *   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */

@@ -220,26 +220,6 @@ void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff,
  * Cleared by omnipq_sa_row_plan. */
 void omnipq_sa_plan_pool_gamma(const float *gamma);
 
-/* Row-strip GEMMs (csrc/gemm_strip.hip): the same contraction C = f(A) B^T as the omnipq_gemm_nt_e16* family for the
- * shared-MLP layers of a set-abstraction stage (pytorch_utils.py:11-36), with a workgroup owning 128 rows and ALL N
- * columns -- the strip of A is fetched, transformed and staged once and kept as MFMA fragments in registers, only the
- * weights stream (LDS-DMA ring).  K in {128, 256, 288} (omnipq_gemm_strip_ok).
- *   f = identity                      a_in == NULL and fin_sums == NULL
- *   f = relu(a_in .* A + b_in)        a_in / b_in given
- *   f = relu(bn(A)), the BatchNorm finalize of the layer below in the prologue: fin_sums ... invstd_out exactly as
- *       omnipq_gemm_nt_e16_bnaffine (a_in / b_in ignored)
- * sums (f64 [2][N], zero on entry) != NULL: += column sum / sum of squares of C, taken from the f32 accumulators;
- * workspace = omnipq_gemm_strip_workspace_floats(M, N) floats.  s in {16, 32, 64}: ball extrema as
- * omnipq_gemm_nt_e16_bnaffine_pool (requires sums, M % s == 0). */
-int omnipq_gemm_strip_ok(int M, int N, int K);
-long long omnipq_gemm_strip_workspace_floats(int M, int N);
-int omnipq_gemm_strip_e16(int M, int N, int K, const void *A, int lda, const float *a_in, const float *b_in,
-                          const double *fin_sums, double count, const float *gamma, const float *beta, float eps,
-                          float momentum, float *running_mean, float *running_var, const float *conv_bias, float *a_out,
-                          float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C, int ldc,
-                          double *sums, float *workspace, int s, void *ymax, void *ymin, unsigned char *amax,
-                          unsigned char *amin, void *stream);
-
 /* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares
  * of the e16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of
  * omnipq_gemm_nt_stats_workspace_floats(M, N) elements (0 for few rows: then it may be NULL). */

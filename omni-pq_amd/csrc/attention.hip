@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const e16_t *
       for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kl + (long long)k1 * g.k_sl, j, h, g.D, kv);
       vn = stage_load(sp, Vb, g.v_sl, k1, g.S);
     }
-    __syncthreads();                                        // previous block's LDS reads are done
+    // (the staging area `vs` is private to this wave and a wave's LDS instructions execute in program order: the previous
+    // block's reads are ahead of these writes in the queue -- no workgroup barrier, the four waves are free to drift apart)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     stage_store(sp, vc, vs);
     f32x16 st;
 #pragma unroll
@@ -276,7 +279,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const e16_t *
       for (int r = 0; r < 16; ++r)
         p[r] = drop_hash_mix(base + (unsigned)acc_row(r, 0)) >= g.drop_thresh ? p[r] * g.keep_inv : 0.f;
     }
-    __syncthreads();                                        // V block staged
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // V block staged (by this wave, for this wave)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
       const e16x8 pf = pack_regs(p, j2);
@@ -381,7 +385,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_
       }
       kn = stage_load(sp, Kb, g.k_sl, k1, g.S);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // wave-private staging area: see attn_fwd_kernel
+    __builtin_amdgcn_wave_barrier();
     stage_store(sp, kc, ks);
     f32x16 st, dp;
 #pragma unroll
@@ -402,7 +407,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_
       if (g.drop_thresh) d = drop_hash_mix(base + (unsigned)acc_row(r, 0)) >= g.drop_thresh ? d * g.keep_inv : 0.f;
       ds[r] = p * (d - dl);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
       const e16x8 df = pack_regs(ds, j2);

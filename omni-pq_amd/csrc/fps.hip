@@ -25,7 +25,6 @@
 //     error word that omnipq_fps_check() reports as OMNIPQ_ETIMEOUT.
 #include <stdlib.h>
 
-#include <hipcub/hipcub.hpp>
 
 #include <string.h>
 
@@ -351,364 +350,6 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
   }
 }
 
-// ---- pruned rounds: a round touches only the cells the new pick can change ------------------------------------------------
-//   In the kernel above a round costs the same whether the pick changes 40 000 running distances or 40:
-// every lane updates all its points, and a scene is spread over 3-5 workgroups whose winners meet through memory.  Here the
-// points of a scene are sorted along a Morton curve first; a CELL is 256 consecutive sorted points, a workgroup (256 threads)
-// owns 80 cells = 20 480 points and keeps them in registers as 80 SLOTS per thread -- slot i of thread t is point t of cell i --
-// so 40 000 points are TWO workgroups.  Per cell the workgroup keeps (LDS) the bounding box and the cell's current WINNER:
-// the largest running distance of its live points with the tie key and the coordinates of the point that holds it.
-//   * A pick p can lower a running distance t_k only if |p_k - p|^2 < t_k; with L = squared distance from p to the cell's box
-//     and W = the cell winner's distance (>= every t_k of the cell) nothing in the cell changes when L >= W.  Evaluated in
-//     f32 with a 1e-5 safety factor on L (rounding of L and of the reference's own |p_k - p|^2 is < 4e-7 relative), per cell
-//     by one lane, `__ballot` -> the wave-uniform set of cells to visit: ~2 of 160 per round once the sampling is under way.
-//   * A visited cell is updated exactly as above (one point per thread) and its winner recomputed (wave argmax -> LDS ->
-//     after the round's barrier wave 0 folds the 4 wave winners).  The workgroup's winner is the argmax over its 80 cell
-//     winners (one wave argmax); with two workgroups they exchange through the tagged granules of the kernel above.
-//   * Unvisited points keep min(t, d) = t: `temp` leaves exactly as the reference leaves it, and picks, tie keys and the skip
-//     ball are untouched -- the result is the same index for index.
-// MEASURED (round 4, tools/bench_fps.py, 8 x 40 000 -> 2048): exact -- every sampling test passes on it, indices and `temp`
-// -- and the pruning works (5.0 of a workgroup's 80 cells visited per round, 2.3 late in the run), but a round takes 7.05 us
-// against 2.59 us for the kernel above: the cost of a round was never the distance updates (8 per lane: ~0.2 us) but the
-// block-wide argmax (0.6-0.7 us: wave argmax on the DPP network, LDS, barrier, fold) plus the exchange between workgroups
-// (~1.5 us of store -> L2 -> poll latency, the same for 2 and for 5 workgroups), and this kernel runs one block-wide argmax
-// PER VISITED CELL (0.74 us each, measured as the slope between 7.8 and 15.1 visits per round) where the exhaustive kernel
-// runs one per round.  Variants that keep one argmax per round need either per-thread rescans over 40-80 slots (0.3-0.5 us)
-// or lazily re-evaluated cell bounds (~1.5 cell evaluations per round): 2.3-2.7 us per round on paper, no better than today,
-// because the floor is the exchange -- and one workgroup per scene (no exchange: 0.77 us rounds) does not fit: 40 000 points
-// x (x, y, z, t) = 160 000 dwords against 131 072 of registers + 40 960 of LDS per CU.  Kept selectable
-// (omnipq_fps_pruned(1)) with its parity test; NOT the default.
-constexpr int PR_THREADS = 256;          // one wave per SIMD: the 512-register budget holds 80 slots x (x, y, z, t, key)
-constexpr int PR_SLOTS = 80;
-constexpr int PR_NW = PR_THREADS / 64;
-constexpr int PR_PER_WG = PR_THREADS * PR_SLOTS;          // 20 480 points per workgroup
-// cells visited / rounds run by all pruned launches since the last read (tools/bench_fps.py: how well the pruning works)
-__device__ unsigned long long g_pr_stats[2];
-
-template <bool MULTI>
-__global__ __launch_bounds__(PR_THREADS) void fps_pruned_kernel(
-    int n, int m, int bs_mask, int G, const float *__restrict__ dataset, float *__restrict__ temp, int *__restrict__ idxs,
-    const unsigned *__restrict__ perm,        // [scenes of the launch][n]: sorted position -> point
-    const float *__restrict__ boxes,          // [scenes of the launch][G * PR_SLOTS][8]: lo xyz, hi xyz
-    unsigned long long *__restrict__ slots, int *__restrict__ err_word, int scene0, int spin_limit) {
-  __shared__ __attribute__((aligned(16))) float s_box[PR_SLOTS][8];
-  __shared__ __attribute__((aligned(16))) float s_cell[PR_SLOTS][8];          // cell winners {t, key, x, y, z}
-  __shared__ __attribute__((aligned(16))) float s_cand[PR_SLOTS][PR_NW][8];   // per-wave winners of the visited cells
-  __shared__ __attribute__((aligned(16))) float s_w[8];                       // the round's pick
-  constexpr int IDXBUF = 1024;
-  __shared__ int s_idx[IDXBUF];
-  __shared__ unsigned s_key[PR_SLOTS][PR_THREADS];                            // tie keys (80 KB): registers hold x, y, z, t
-
-  const int scene_local = (int)blockIdx.x / G;
-  const int g = (int)blockIdx.x % G;
-  const int scene = scene0 + scene_local;
-  const int nscenes = (int)gridDim.x / G;
-  dataset += (size_t)scene * n * 3;
-  temp += (size_t)scene * n;
-  idxs += (size_t)scene * m;
-  perm += (size_t)scene_local * n;
-  boxes += ((size_t)scene_local * G + g) * PR_SLOTS * 8;
-
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float px[PR_SLOTS], py[PR_SLOTS], pz[PR_SLOTS], pt[PR_SLOTS];
-  unsigned long long live[2] = {0, 0};
-  static_assert(PR_SLOTS > 64 && PR_SLOTS <= 128, "two 64-bit words of cells");
-#pragma unroll
-  for (int i = 0; i < PR_SLOTS; ++i) {
-    const int sp = (g * PR_SLOTS + i) * PR_THREADS + tid;
-    px[i] = py[i] = pz[i] = 0.f;
-    pt[i] = 0.f;
-    unsigned key = kNoKey;
-    if (sp < n) {
-      const int k = (int)perm[sp];
-      px[i] = dataset[k * 3 + 0];
-      py[i] = dataset[k * 3 + 1];
-      pz[i] = dataset[k * 3 + 2];
-      pt[i] = temp[k];
-      key = tie_key(k, bs_mask);
-      const float mag = sumsq3(px[i], py[i], pz[i]);
-      if (!((double)mag <= 1e-3)) live[i >> 6] |= 1ull << (i & 63);
-    }
-    s_key[i][tid] = key;
-  }
-  for (int t = tid; t < PR_SLOTS * 8; t += PR_THREADS) (&s_box[0][0])[t] = boxes[t];
-  if (tid < PR_SLOTS) {                       // (PR_SLOTS <= PR_THREADS)
-    // a cell that exists starts with "anything may change"; one that does not never wins and is never visited
-    const bool exists = (g * PR_SLOTS + tid) * PR_THREADS < n;
-    s_cell[tid][0] = exists ? 3.0e38f : -1.f;
-    s_cell[tid][1] = __builtin_bit_cast(float, kNoKey);
-    s_cell[tid][2] = s_cell[tid][3] = s_cell[tid][4] = 0.f;
-  }
-  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
-  float x1 = x0, y1 = y0, z1 = z0;
-  if (tid == 0) s_idx[0] = 0;
-  __syncthreads();
-
-  unsigned nvisit = 0;
-  for (int j = 1; j < m; ++j) {
-    const int par = j & 1;
-    if ((j & (IDXBUF - 1)) == 0) {
-      __syncthreads();
-      if (g == 0)
-        for (int t = tid; t < IDXBUF; t += PR_THREADS) idxs[j - IDXBUF + t] = s_idx[t];
-      __syncthreads();
-    }
-    // which cells can this pick change?  lane l decides for the cells l and l + 64; every wave computes the same set
-    unsigned long long visit[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      bool need = false;
-      const int cell = lane + 64 * h;
-      if (cell < PR_SLOTS) {
-        const float4 lo = *reinterpret_cast<const float4 *>(&s_box[cell][0]);      // {lo.x, lo.y, lo.z, hi.x}
-        const float4 hi = *reinterpret_cast<const float4 *>(&s_box[cell][4]);      // {hi.y, hi.z, -, -}
-        const float ax = fmaxf(0.f, fmaxf(lo.x - x1, x1 - lo.w));
-        const float ay = fmaxf(0.f, fmaxf(lo.y - y1, y1 - hi.x));
-        const float az = fmaxf(0.f, fmaxf(lo.z - z1, z1 - hi.y));
-        const float L = ax * ax + ay * ay + az * az;
-        need = !(L * 0.99999f >= s_cell[cell][0]);                                  // (a NaN anywhere means "visit")
-      }
-      visit[h] = __ballot(need);
-    }
-    nvisit += (unsigned)(__builtin_popcountll(visit[0]) + __builtin_popcountll(visit[1]));
-    // visit them.  The register arrays want constant indices: 80 copies of the update behind wave-uniform tests, the tests
-    // of eight cells behind one test of their group (a round visits 2-5 cells: ~10 + 8 x groups-hit scalar branches)
-#pragma unroll
-    for (int grp = 0; grp < PR_SLOTS / 8; ++grp) {
-      const unsigned bits8 = (unsigned)(visit[grp >> 3] >> ((grp & 7) * 8)) & 0xFFu;
-      if (!bits8) continue;                                              // wave-uniform
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int i = grp * 8 + e;
-        if (!((bits8 >> e) & 1u)) continue;                              // wave-uniform
-        float xq = x1, yq = y1, zq = z1;          // opaque copies: without them hipcc hoists all 80 distance computations
-        asm volatile("; cell" : "+v"(xq), "+v"(yq), "+v"(zq));
-        const float d = sumsq3(px[i] - xq, py[i] - yq, pz[i] - zq);
-        const bool on = (live[i >> 6] >> (i & 63)) & 1ull;
-        const float t = (on && d < pt[i]) ? d : pt[i];                   // min(d, temp[k])
-        pt[i] = t;
-        const Winner w = wave_winner(on ? t : -1.f, on ? s_key[i][tid] : kNoKey, px[i], py[i], pz[i]);
-        if (lane == 0) {
-          *reinterpret_cast<float4 *>(&s_cand[i][wave][0]) = make_float4(w.d2, __builtin_bit_cast(float, w.c), w.x, w.y);
-          s_cand[i][wave][4] = w.z;
-        }
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        unsigned long long todo = visit[h];
-        while (todo) {
-          const int i = (int)__builtin_ctzll(todo) + 64 * h;
-          todo &= todo - 1;
-          const float4 c4 = *reinterpret_cast<const float4 *>(&s_cand[i][lane & (PR_NW - 1)][0]);
-          const float cz = s_cand[i][lane & (PR_NW - 1)][4];
-          // (lanes past the wave winners hold no candidate: the winner is then unique and wave_argmax takes its short path)
-          const Winner cw = wave_winner<true>(lane < PR_NW ? c4.x : -2.f,
-                                              lane < PR_NW ? __builtin_bit_cast(unsigned, c4.y) : kNoKey, c4.z, c4.w, cz);
-          if (lane == 0) {
-            *reinterpret_cast<float4 *>(&s_cell[i][0]) = make_float4(cw.d2, __builtin_bit_cast(float, cw.c), cw.x, cw.y);
-            s_cell[i][4] = cw.z;
-          }
-        }
-      }
-      // this workgroup's winner: argmax over its cell winners (LDS accesses of one wave complete in order); a lane first
-      // takes the better of its two cells
-      float ct = -1.f, cx = 0.f, cy = 0.f, cz = 0.f;
-      unsigned cc = kNoKey;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cell = lane + 64 * h;
-        if (cell < PR_SLOTS) {
-          const float4 c4 = *reinterpret_cast<const float4 *>(&s_cell[cell][0]);
-          const unsigned k2 = __builtin_bit_cast(unsigned, c4.y);
-          if (better(c4.x, k2, ct, cc)) {
-            ct = c4.x;
-            cc = k2;
-            cx = c4.z;
-            cy = c4.w;
-            cz = s_cell[cell][4];
-          }
-        }
-      }
-      const Winner gw = wave_winner(ct, cc, cx, cy, cz);
-      float fd2 = gw.d2, fx = gw.x, fy = gw.y, fz = gw.z;
-      unsigned fc = gw.c;
-      bool failed = false;
-      if (MULTI) {
-        // the exchange of fps_kernel's XG variant: 5 granules {value, tag = round} per workgroup, one polling wave
-        const unsigned tag = (unsigned)j;
-        gu64 *row = (gu64 *)(slots + ((size_t)par * nscenes + scene_local) * 5 * G);
-        if (lane < 5) {
-          unsigned val = __builtin_bit_cast(unsigned, gw.d2);
-          if (lane == 1) val = gw.c;
-          if (lane == 2) val = __builtin_bit_cast(unsigned, gw.x);
-          if (lane == 3) val = __builtin_bit_cast(unsigned, gw.y);
-          if (lane == 4) val = __builtin_bit_cast(unsigned, gw.z);
-          __hip_atomic_store(row + lane * G + g, ((unsigned long long)tag << 32) | val, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned myval = 0;
-        const int npoll = 5 * G;
-        int spins = 0;
-        for (;;) {
-          bool ok = true;
-          if (lane < npoll) {
-            const unsigned long long v = __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = (unsigned)(v >> 32) == tag;
-            myval = (unsigned)v;
-          }
-          if (__all(ok)) break;
-          if (++spins > spin_limit) {
-            failed = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        const unsigned cval = (unsigned)__shfl((int)myval, lane + G);
-        float d2 = -1.f;
-        unsigned c = kNoKey;
-        if (lane < G && !failed) {
-          d2 = __builtin_bit_cast(float, myval);
-          c = cval;
-        }
-        const float md2 = d2;
-        const unsigned mc = c;
-        wave_argmax(d2, c);
-        const unsigned long long owners = __ballot(md2 == d2 && mc == c && lane < G);
-        const int gs = owners ? (int)__builtin_ctzll(owners) : 0;
-        fd2 = d2;
-        fc = c;
-        fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)myval, 2 * G + gs));
-        fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)myval, 3 * G + gs));
-        fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)myval, 4 * G + gs));
-      }
-      if (lane == 0) {
-        s_w[0] = failed ? -2.f : fd2;
-        s_w[1] = __builtin_bit_cast(float, fc);
-        s_w[2] = fx;
-        s_w[3] = fy;
-        s_w[4] = fz;
-        if (failed) atomicExch(err_word, 1);
-      }
-    }
-    __syncthreads();
-    const float sd2 = s_w[0];
-    if (sd2 == -2.f) break;
-    const bool none = sd2 < 0.f;
-    const int kk = none ? 0 : (int)(__builtin_bit_cast(unsigned, s_w[1]) & kKMask);
-    x1 = none ? x0 : s_w[2];
-    y1 = none ? y0 : s_w[3];
-    z1 = none ? z0 : s_w[4];
-    if (tid == 0) s_idx[j & (IDXBUF - 1)] = kk;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    atomicAdd(&g_pr_stats[0], (unsigned long long)nvisit);
-    atomicAdd(&g_pr_stats[1], (unsigned long long)(m > 1 ? m - 1 : 0));
-  }
-  if (g == 0) {
-    const int done = ((m - 1) / IDXBUF) * IDXBUF;
-    for (int t = done + tid; t < m; t += PR_THREADS) idxs[t] = s_idx[t - done];
-  }
-#pragma unroll
-  for (int i = 0; i < PR_SLOTS; ++i) {
-    const int sp = (g * PR_SLOTS + i) * PR_THREADS + tid;
-    if (sp < n) temp[(int)perm[sp]] = pt[i];
-  }
-}
-
-// Morton order of a scene's points.  scene_box: {lo xyz, hi xyz} of every scene (one workgroup per scene).
-__global__ __launch_bounds__(1024) void fps_scene_box_kernel(int n, const float *__restrict__ dataset,
-                                                            float *__restrict__ scene_box) {
-  __shared__ float red[6][16];
-  const float *p = dataset + (size_t)blockIdx.x * n * 3;
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = (int)threadIdx.x; k < n; k += 1024)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float v = p[k * 3 + a];
-      lo[a] = fminf(lo[a], v);
-      hi[a] = fmaxf(hi[a], v);
-    }
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float l = -wave_max_f32(-lo[a]), h = wave_max_f32(hi[a]);
-    if (lane == 0) {
-      red[a][wave] = l;
-      red[3 + a][wave] = h;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float v = red[threadIdx.x][0];
-    for (int w = 1; w < 16; ++w) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
-    scene_box[blockIdx.x * 6 + threadIdx.x] = v;
-  }
-}
-
-__device__ __forceinline__ unsigned morton_spread10(unsigned v) {       // 10 bits -> every third bit
-  v = (v | (v << 16)) & 0x030000FFu;
-  v = (v | (v << 8)) & 0x0300F00Fu;
-  v = (v | (v << 4)) & 0x030C30C3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-
-// key = 30-bit Morton code of the point within its scene's box, value = the point; seg[s] = s * n
-__global__ __launch_bounds__(256) void fps_morton_kernel(long long total, int n, int nscenes, const float *__restrict__ dataset,
-                                                        const float *__restrict__ scene_box, unsigned *__restrict__ key,
-                                                        unsigned *__restrict__ val, int *__restrict__ seg) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t <= nscenes) seg[t] = (int)(t * n);
-  if (t >= total) return;
-  const int s = (int)(t / n), k = (int)(t - (long long)s * n);
-  const float *b = scene_box + s * 6;
-  unsigned q[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float ext = b[3 + a] - b[a];
-    float u = ext > 0.f ? (dataset[t * 3 + a] - b[a]) / ext : 0.f;
-    u = fminf(fmaxf(u, 0.f), 1.f);                                       // (NaN -> 0)
-    q[a] = (unsigned)(u * 1023.f);
-  }
-  key[t] = morton_spread10(q[0]) | (morton_spread10(q[1]) << 1) | (morton_spread10(q[2]) << 2);
-  val[t] = (unsigned)k;
-}
-
-// box of every cell (512 consecutive sorted points); cells without points get an empty box
-__global__ __launch_bounds__(PR_THREADS) void fps_cell_box_kernel(int n, int cells_per_scene, const float *__restrict__ dataset,
-                                                                 const unsigned *__restrict__ perm,
-                                                                 float *__restrict__ boxes) {
-  __shared__ float red[6][PR_NW];
-  const int scene = (int)blockIdx.x / cells_per_scene, cell = (int)blockIdx.x % cells_per_scene;
-  const int sp = cell * PR_THREADS + (int)threadIdx.x;
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  if (sp < n) {
-    const float *p = dataset + ((size_t)scene * n + perm[(size_t)scene * n + sp]) * 3;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = p[a];
-  }
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float l = -wave_max_f32(-lo[a]), h = wave_max_f32(hi[a]);
-    if (lane == 0) {
-      red[a][wave] = l;
-      red[3 + a][wave] = h;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float v = red[threadIdx.x][0];
-    for (int w = 1; w < PR_NW; ++w) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
-    boxes[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
-  }
-  if (threadIdx.x >= 6 && threadIdx.x < 8) boxes[(size_t)blockIdx.x * 8 + threadIdx.x] = 0.f;
-}
-
 // ---- host side ---------------------------------------------------------------------
 // Exchange slots of the multi-workgroup kernel.  One block per (device, STREAM): launches on one stream run one
 // after the other and may share it, launches on different streams may overlap (a model and its EMA teacher
@@ -823,60 +464,6 @@ static int launch_multi(int b, int n, int m, int bs_mask, int G, const float *da
 
 // Pruned sampling of scenes with more than 8192 points: Morton sort (hipCUB segmented radix sort: plumbing), cell boxes, then
 // G = ceil(n / 20 480) workgroups per scene.
-static int launch_pruned(int b, int n, int m, int bs_mask, const float *dataset, float *temp, int *idxs,
-                         hipStream_t stream) {
-  const int G = (n + PR_PER_WG - 1) / PR_PER_WG;
-  if (5 * G > 64) return OMNIPQ_ETOOLARGE;
-  int chunk = fps_resident_blocks() * 7 / 8 / G;
-  if (chunk < 1) chunk = 1;
-  if (chunk > b) chunk = b;
-  const long long total = (long long)chunk * n;
-  if (total > 0x7FFFFFFFll) return OMNIPQ_ETOOLARGE;
-  size_t tmp_bytes = 0;
-  if (hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                                  (const unsigned *)nullptr, (unsigned *)nullptr, (int)total, chunk,
-                                                  (const int *)nullptr, (const int *)nullptr, 0, 30, stream) != hipSuccess)
-    return (int)hipErrorUnknown;
-  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  const size_t slot_b = up((size_t)2 * chunk * 5 * G * sizeof(unsigned long long));
-  const size_t arr = up((size_t)total * 4);
-  const size_t seg_b = up((size_t)(chunk + 1) * 4), sbox_b = up((size_t)chunk * 6 * 4);
-  const size_t box_b = up((size_t)chunk * G * PR_SLOTS * 8 * 4);
-  FpsWorkspace *ws = nullptr;
-  int rc = get_workspace(slot_b + 4 * arr + seg_b + sbox_b + box_b + up(tmp_bytes), stream, &ws);
-  if (rc) return rc;
-  unsigned char *base = (unsigned char *)ws->slots;
-  unsigned *key_in = (unsigned *)(base + slot_b), *val_in = (unsigned *)(base + slot_b + arr),
-           *key_out = (unsigned *)(base + slot_b + 2 * arr), *val_out = (unsigned *)(base + slot_b + 3 * arr);
-  int *seg = (int *)(base + slot_b + 4 * arr);
-  float *scene_box = (float *)(base + slot_b + 4 * arr + seg_b);
-  float *boxes = (float *)(base + slot_b + 4 * arr + seg_b + sbox_b);
-  void *tmp = base + slot_b + 4 * arr + seg_b + sbox_b + box_b;
-  for (int s0 = 0; s0 < b; s0 += chunk) {
-    const int ns = (b - s0 < chunk) ? (b - s0) : chunk;
-    const float *data = dataset + (size_t)s0 * n * 3;
-    const long long tot = (long long)ns * n;
-    OMNIPQ_HIP(hipMemsetAsync(ws->slots, 0, (size_t)2 * ns * 5 * G * sizeof(unsigned long long), stream));
-    fps_scene_box_kernel<<<ns, 1024, 0, stream>>>(n, data, scene_box);
-    OMNIPQ_LAUNCH_CHECK();
-    fps_morton_kernel<<<(unsigned)((tot + 256) / 256), 256, 0, stream>>>(tot, n, ns, data, scene_box, key_in, val_in, seg);
-    OMNIPQ_LAUNCH_CHECK();
-    if (hipcub::DeviceSegmentedRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)tot, ns, seg,
-                                                    seg + 1, 0, 30, stream) != hipSuccess)
-      return (int)hipErrorUnknown;
-    fps_cell_box_kernel<<<ns * G * PR_SLOTS, PR_THREADS, 0, stream>>>(n, G * PR_SLOTS, data, val_out, boxes);
-    OMNIPQ_LAUNCH_CHECK();
-    if (G > 1)
-      fps_pruned_kernel<true><<<ns * G, PR_THREADS, 0, stream>>>(n, m, bs_mask, G, dataset, temp, idxs, val_out, boxes,
-                                                                  ws->slots, ws->err, s0, 1 << 22);
-    else
-      fps_pruned_kernel<false><<<ns, PR_THREADS, 0, stream>>>(n, m, bs_mask, 1, dataset, temp, idxs, val_out, boxes,
-                                                               ws->slots, ws->err, s0, 1 << 22);
-    OMNIPQ_LAUNCH_CHECK();
-  }
-  return OMNIPQ_OK;
-}
-
 }  // namespace omnipq
 
 #ifdef OMNIPQ_FPS_TRACE
@@ -943,25 +530,21 @@ extern "C" int omnipq_fps_check(void *stream) {
   return omnipq_fps_poll();
 }
 
-static thread_local int t_small_footprint = 0;
-static thread_local int t_pruned = 0;
-// Calling thread only: 1 = clouds of more than 8192 points are sampled by fps_pruned_kernel (slower today: see its note)
-extern "C" void omnipq_fps_pruned(int on) { t_pruned = on ? 1 : 0; }
-// {cells visited, workgroup-rounds} of the pruned launches since the last call (synchronises the device; resets the counters)
-extern "C" int omnipq_fps_pruned_stats(unsigned long long *out2) {
-  OMNIPQ_HIP(hipDeviceSynchronize());
-  OMNIPQ_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(omnipq::g_pr_stats), 16));
-  unsigned long long z[2] = {0, 0};
-  OMNIPQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(omnipq::g_pr_stats), z, 16));
-  return OMNIPQ_OK;
+extern "C" int omnipq_furthest_point_sampling_ex(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                                                 unsigned flags, void *stream_);
+
+// The reference-shaped entry point (sampling.cpp:11-20 + stream): the fastest rounds.
+extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                                              void *stream_) {
+  return omnipq_furthest_point_sampling_ex(b, n, m, dataset, temp, idxs, 0u, stream_);
 }
 
-// Calling thread only: sampling launches issued after omnipq_fps_footprint(1) trade round time for compute units (see
-// omnipq_furthest_point_sampling); 0 restores the fastest rounds.  Results are the same indices either way.
-extern "C" void omnipq_fps_footprint(int small) { t_small_footprint = small ? 1 : 0; }
-
-extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *dataset,
-                                              float *temp, int *idxs, void *stream_) {
+// flags: OMNIPQ_FPS_SMALL_FOOTPRINT (bit 0) -- clouds of more than 8192 points are sampled with 16 points per thread on
+// fewer workgroups per scene: same indices, longer rounds, fewer compute units (a chain that runs underneath other work and
+// ends before it).  An explicit argument: no per-thread mode (round 5; was omnipq_fps_footprint).
+extern "C" int omnipq_furthest_point_sampling_ex(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                                                 unsigned flags, void *stream_) {
+  const bool t_small_footprint = (flags & 1u) != 0;
   using namespace omnipq;
   hipStream_t stream = (hipStream_t)stream_;
   if (b < 0 || n < 0 || m < 0) return OMNIPQ_EINVAL;
@@ -979,9 +562,6 @@ extern "C" int omnipq_furthest_point_sampling(int b, int n, int m, const float *
   if (n <= 2048) return launch_single<512, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 4096) return launch_single<1024, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_single<1024, 8>(b, n, m, bs_mask, dataset, temp, idxs, stream);
-  // pruned rounds (fps_pruned_kernel; opt-in, see its MEASURED note): up to 12 workgroups x 20 480 points per scene
-  if (t_pruned && (n + PR_PER_WG - 1) / PR_PER_WG <= 12)
-    return launch_pruned(b, n, m, bs_mask, dataset, temp, idxs, stream);
   // several workgroups per scene, every point visited every round
   // up to 12 workgroups the exchange also carries the winner's coordinates (5*G polling lanes)
   const int per4 = 1024 * 4, per8 = 1024 * 8;

@@ -254,7 +254,7 @@ def furthest_point_sampling(points, nsamples, out=None, small_footprint=False):
     """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:72-93].  `out` (extension): write into an existing
     int32 tensor instead of allocating one.  small_footprint (extension): for clouds of more than 8192 points, fewer
     workgroups per scene with more points each -- same indices, ~40 % longer rounds on 40 % fewer compute units: for a
-    sampling chain that runs underneath other work with time to spare (omnipq_fps_footprint)."""
+    sampling chain that runs underneath other work with time to spare (omnipq_furthest_point_sampling_ex: flags)."""
     _check(points, "points", torch.float32)
     _need_gpu(points)
     _fps_prepare(points.device)
@@ -265,13 +265,8 @@ def furthest_point_sampling(points, nsamples, out=None, small_footprint=False):
         _check(out, "out", torch.int32, cuda_like=points)
         assert tuple(out.shape) == (b, int(nsamples))
     tmp = torch.full((b, n), 1e10, device=points.device, dtype=torch.float32)
-    if small_footprint:
-        _lib0.omnipq_fps_footprint(1)
-    try:
-        _run(_lib0.omnipq_furthest_point_sampling, points, b, n, int(nsamples), _ptr(points), _ptr(tmp), _ptr(out))
-    finally:
-        if small_footprint:
-            _lib0.omnipq_fps_footprint(0)
+    _run(_lib0.omnipq_furthest_point_sampling_ex, points, b, n, int(nsamples), _ptr(points), _ptr(tmp), _ptr(out),
+         ctypes.c_uint(1 if small_footprint else 0))          # flags: OMNIPQ_FPS_SMALL_FOOTPRINT
     return out
 
 

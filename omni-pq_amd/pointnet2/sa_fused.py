@@ -253,18 +253,6 @@ POOL_EPILOGUE = True
 _FOLD_SMALL = True
 
 
-# Row-strip GEMMs (csrc/gemm_strip.hip: a workgroup owns 128 rows and all N columns, the A strip lives in registers, the
-# weights stream through an LDS-DMA ring) for the forward layers where they were measured faster than the 128 x 128 tiles
-# (tools/bench_strip.py, MI355X, event-timed, BatchNorm prologue + statistics [+ ball extrema]):
-#     262144 x 512 x 256   169 vs 182 us      65536 x 512 x 256   46.6 vs 50.9 us     1048576 x 256 x 128   261 vs 289 us
-# and slower elsewhere (N = 256 at K = 256: 0.94x; 32768 rows: 0.89x; K = 288: 0.8x): one round of workgroups cannot hide a
-# strip's serial phases.  C is bit-identical to the tile kernel's; the statistics are summed from the f32 accumulators
-# instead of the rounded outputs (differences within the rounding noise of the sum).
-STRIP_GEMM = True
-strip_uses = 0
-_lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
-
-
 # Row plan (csrc/common.h: RowPlan, include/omnipq_sa.h: omnipq_sa_ball_plan).  ball_query pads a ball that holds fewer than
 # nsample points with copies of its first neighbour (ball_query_gpu.cu:36-45; pointnet2_utils.py:317-376 groups them like any
 # other index), so the shared MLP of the reference runs on duplicate rows: on the benchmark's 40 000-point room scenes a ball
@@ -346,32 +334,9 @@ class _PlanState(threading.local):       # per thread, like the C side's row pla
 _plan_state = _PlanState()
 
 
-def strip_pays(M, N, K, with_pool):
-    # (not inside a planned stage: the planned strip kernels -- row weights on top of the register-resident strip -- spill
-    # 40 to 130 registers, tools/spills.sh, and the shapes the strip wins on do not occur in the stages a plan covers)
-    if not STRIP_GEMM or _plan_state.active:
-        return False
-    if K == 256 and N >= 512 and N % 128 == 0 and M >= 65536:
-        return True
-    return K == 128 and N == 256 and M >= (1 << 19) and with_pool
-
-
 def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None):
     """bf16 C = relu(below.a * Y + below.b) Bw^T (+ bias); sums (f64 [2][N], zero on entry): also C's statistics."""
     C = torch.empty((M, N), device=Y.device, dtype=E16.dtype) if out is None else out
-    if bias is None and sums is not None and getattr(below, "fin", None) is not None and \
-            strip_pays(M, N, K, pool is not None) and (pool is None or pool[0] in (16, 32, 64)):
-        global strip_uses
-        strip_uses += 1
-        fsums, count, gamma, beta, eps, momentum, rm, rv, cb = below.fin
-        below.fin = None
-        ws = torch.empty((int(_lib.omnipq_gemm_strip_workspace_floats(M, N)),), device=Y.device, dtype=torch.float32)
-        S, ymax, ymin, amax, amin = pool if pool is not None else (0, None, None, None, None)
-        _call(_lib.omnipq_gemm_strip_e16, Y, M, N, K, _p(Y), K, _p(None), _p(None), _p(fsums), ctypes.c_double(count),
-              _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum), _p(rm), _p(rv), _p(cb), _p(below.a),
-              _p(below.b), _p(below.mean), _p(below.invstd), _p(Bw), K, _p(C), N, _p(sums), _p(ws), S, _p(ymax), _p(ymin),
-              _p(amax), _p(amin))
-        return C
     ws = None
     if sums is not None:
         n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))

@@ -51,11 +51,14 @@ def ok(name, *args):
     assert rc == 0, f"{name} -> {rc}: {lib().omnipq_error_string(rc).decode()}"
 
 
-def fps(xyz, m):
+def fps(xyz, m, flags=None):
     b, n, _ = xyz.shape
     out = torch.full((b, m), -7, device=xyz.device, dtype=torch.int32)
     tmp = torch.full((b, n), 1e10, device=xyz.device, dtype=torch.float32)
-    ok("omnipq_furthest_point_sampling", b, n, m, P(xyz), P(tmp), P(out))
+    if flags is None:
+        ok("omnipq_furthest_point_sampling", b, n, m, P(xyz), P(tmp), P(out))
+    else:
+        ok("omnipq_furthest_point_sampling_ex", b, n, m, P(xyz), P(tmp), P(out), ctypes.c_uint(flags))
     rc = lib().omnipq_fps_check(stream())
     assert rc == 0, lib().omnipq_error_string(rc).decode()
     return out, tmp

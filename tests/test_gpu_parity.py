@@ -70,39 +70,17 @@ def test_fps_index_exact(kind, b, n, m):
 
 @pytest.mark.parametrize("kind,b,n,m", [c for c in FPS_CASES if c[2] > 8192])
 def test_fps_small_footprint_variant_gives_the_same_indices(kind, b, n, m):
-    """omnipq_fps_footprint(1): 16 points per thread, fewer workgroups per scene (what the prefetched sampling chain of a
-    training step runs on) -- indices and running distances equal the oracle's, and the switch is per thread and resets."""
+    """omnipq_furthest_point_sampling_ex(flags = OMNIPQ_FPS_SMALL_FOOTPRINT): 16 points per thread, fewer workgroups per scene
+    (what the prefetched sampling chain of a training step runs on) -- indices and running distances equal the oracle's and
+    the default launch's; the choice is an ARGUMENT of the call, nothing lingers for the next one."""
     xyz = cloud(kind, 5, b, n)
     want = oracle_ext.furthest_point_sampling(xyz, m)
-    capi.lib().omnipq_fps_footprint(1)
-    try:
-        got, tmp = capi.fps(xyz.to(dev()), m)
-    finally:
-        capi.lib().omnipq_fps_footprint(0)
+    got, tmp = capi.fps(xyz.to(dev()), m, flags=1)
     fast, tmp_fast = capi.fps(xyz.to(dev()), m)
+    again, tmp_again = capi.fps(xyz.to(dev()), m, flags=0)
     assert torch.equal(got.cpu(), want), f"first mismatch at {(got.cpu() != want).nonzero()[:3].tolist()}"
     assert torch.equal(fast, got) and torch.equal(tmp, tmp_fast)
-
-
-@pytest.mark.parametrize("kind,b,n,m", [("room", 2, 20000, 600), ("room", 8, 40000, 2048), ("adv", 2, 8193, 400),
-                                        ("uniform", 2, 80000, 300), ("room", 1, 50000, 700)])
-def test_fps_pruned_rounds_equal_the_exhaustive_kernels(kind, b, n, m):
-    """csrc/fps.hip: fps_pruned_kernel (omnipq_fps_pruned(1): a round visits only the cells the new pick can change) against
-    the default kernels that visit every point every round and against the oracle: the same indices and running distances."""
-    xyz = cloud(kind, 9, b, n)
-    want, want_tmp = capi.fps(xyz.to(dev()), m)
-    capi.lib().omnipq_fps_pruned(1)
-    try:
-        got, tmp = capi.fps(xyz.to(dev()), m)
-        import ctypes as C
-        st = (C.c_ulonglong * 2)()
-        assert capi.lib().omnipq_fps_pruned_stats(st) == 0
-    finally:
-        capi.lib().omnipq_fps_pruned(0)
-    assert st[1] > 0 and st[0] < 80 * st[1]           # the pruned kernel ran, and it skipped cells
-    assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[:3].tolist()}"
-    assert torch.equal(tmp, want_tmp)
-    assert torch.equal(got.cpu(), oracle_ext.furthest_point_sampling(xyz, m))
+    assert torch.equal(again, got) and torch.equal(tmp, tmp_again)
 
 
 def test_fps_all_points_inside_skip_ball_yields_zeros():

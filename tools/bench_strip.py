@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Row-strip GEMM (csrc/gemm_strip.hip) against the tile GEMM (csrc/gemm_bf16.hip) on the SA stages' layer shapes:
+"""PROBE (round 5: the strip kernel left the product library; build it with `bash tools/probe/build_strip.sh`, this tool then
+loads tools/probe/libomnipq_strip.so for the strip entry points).
+Row-strip GEMM (tools/probe/src/gemm_strip.hip) against the tile GEMM (csrc/gemm_bf16.hip) on the SA stages' layer shapes:
 outputs (bit-equal C, statistics to f32 summation noise, identical ball extrema) and event-timed duration.
 
     python tools/bench_strip.py [--quick]
@@ -17,6 +19,9 @@ import sa_fused  # noqa: E402
 from sa_fused import _lib, _p, _call  # noqa: E402
 
 dev = torch.device("cuda", 0)
+_probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "libomnipq_strip.so"))
+for _n in ("omnipq_gemm_strip_workspace_floats", "omnipq_gemm_strip_e16", "omnipq_strip_debug", "omnipq_strip_occupancy"):
+    setattr(_lib, _n, getattr(_probe, _n))          # (the probe library carries its own copy of the product objects)
 _lib.omnipq_gemm_strip_workspace_floats.restype = ctypes.c_longlong
 cd, cf = ctypes.c_double, ctypes.c_float
 
