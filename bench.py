@@ -867,6 +867,8 @@ def main():
         stall = gpu_stall_cycles(dev, eager_ms * 1.5)
         sink = []
         ext.set_timing_sink(sink)
+        import sa_fused as _sf
+        _sf.KEEP_LAST_PLANS = True        # (these eager steps' plans: the line reports the share of rows they kept)
         timing_steps = min(args.steps, 5)
         for i in range(timing_steps):
             if stall:

@@ -271,10 +271,16 @@ _FOLD_SMALL = True
 ROW_PLAN = True
 PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
 ONE_SIDED_EXTREMA = True        # planned stages with 8-row groups: record max OR min per column, by the sign of gamma
+# (A BatchNorm weight of EXACTLY zero makes every row of a ball tie after BatchNorm + ReLU; the reference's max-pool then picks
+# row 0, the extrema paths -- one- and two-sided -- the first row that attains the raw maximum.  The pooled VALUE is the same
+# (relu(beta)), the gradient of that gamma differs by the choice of yhat; a weight does not sit at exactly 0.0 during training,
+# and nothing else depends on the choice.  ADVICE r4.)
 PLAN_MIN_ROWS = 1 << 17         # grouped rows from which a stage is planned (BASELINE configs[3], batch 4: sa2 has 2^17 --
                                 # SA stages 2.65 -> 2.28 ms there; below that the statistics take the direct-atomics paths)
 row_plan_uses = 0
-row_plan_last = {}              # P of the stage -> its latest _Plan (bench.py reads the rows in use from it)
+KEEP_LAST_PLANS = False         # diagnostics (bench.py sets it): remember the latest plan of every stage size in row_plan_last
+row_plan_last = {}              # P of the stage -> its latest _Plan, only while KEEP_LAST_PLANS (a kept plan pins its tensors --
+                                # inside a captured step: blocks of the graph's memory pool -- for as long as it is the latest)
 _lib.omnipq_sa_row_plan.restype = None
 _lib.omnipq_sa_plan_pool_gamma.restype = None
 
@@ -305,7 +311,8 @@ def make_row_plan(idx, P):
     plan.unit_src = torch.empty((P // 8,), device=dev, dtype=torch.int32)
     _call(_lib.omnipq_sa_ball_plan_src, idx, ctypes.c_longlong(B * M), S, plan.gs, _p(idx), _p(plan.goff), _p(plan.rows_dev),
           _p(plan.row_w), _p(plan.unit_src), _p(plan.scratch))
-    row_plan_last[P] = plan
+    if KEEP_LAST_PLANS:
+        row_plan_last[P] = plan
     return plan
 
 

@@ -922,6 +922,7 @@ def test_row_plan_equals_the_full_stage(case, group, monkeypatch):
     if case in ("sa2_feature_gradient", "sa2_batch_4"):
         feats = (feats * 0.5).requires_grad_(True)
     monkeypatch.setenv("OMNIPQ_SA", "fused")
+    monkeypatch.setattr(sa_fused, "KEEP_LAST_PLANS", True)
     monkeypatch.setattr(sa_fused, "PLAN_GROUP", group)
     if case == "sa2_batch_4":
         monkeypatch.setattr(sa_fused, "ONE_SIDED_EXTREMA", False)      # (every other case runs the one-sided extrema)
