@@ -16,6 +16,7 @@ for i in range(3): step(i)
 torch.cuda.synchronize()
 agg=collections.defaultdict(lambda:[0,0])
 shapes=collections.Counter()
+seq=[]
 WATCH=("copy_","_to_copy","clone","cat","fill_","zeros","add","div","mul","zero_")
 class M(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -30,6 +31,11 @@ class M(TorchDispatchMode):
             n=0
             if torch.is_tensor(out): n=out.numel()*out.element_size()
             agg[(base,fr)][0]+=1; agg[(base,fr)][1]+=n
+            if os.environ.get("TRACE_ALL"):
+                node=None
+                try: node=torch._C._current_autograd_node()
+                except Exception: pass
+                seq.append((base, fr, tuple(out.shape), str(out.dtype).replace("torch.",""), node.name() if node is not None else "fwd"))
             if fr=="?" and os.environ.get("TRACE_SHAPES"):
                 node=None
                 try: node=torch._C._current_autograd_node()
@@ -51,3 +57,8 @@ if shapes:
     print("ops issued from autograd's backward (no repo frame), by shape:")
     for (b,sh,dt),c in shapes.most_common(40):
         print(f"{c:5d}x  {b:10s} {dt} {sh}")
+
+if seq:
+    print("every watched op in issue order (op, site, shape, dtype, autograd node):")
+    for i, r in enumerate(seq):
+        print(f"{i:4d} {r[0]:14s} {r[1]:28s} {str(r[2]):22s} {r[3]:9s} {r[4]}")
