@@ -240,8 +240,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs g, const float *__re
 
 // out[item][j] += sum over the item's blocks of part[block][j], j < 2 C: grid (ceil(2C / 64), items, kLnSplit).
 // A thread owns one column of a quarter of its split's blocks (consecutive lanes = consecutive columns: 256-byte
-// rows), the four quarters meet in LDS, the splits through kLnSplit-way atomics on a zero-initialised output.
-constexpr int kLnItems = 32, kLnSplit = 8;
+// rows), the four quarters meet in LDS; kLnSplit > 1 would let the splits meet through atomics on the zero-initialised output.
+constexpr int kLnItems = 32, kLnSplit = 1;      // (8 until round 5: the splits met through f32 atomics, i.e. in any order --
+                                                 // the LayerNorm parameter gradients were the last tensors of a step that
+                                                 // differed from run to run, tools/repro_check.py; one split = one fixed order)
 struct LnReduceItem {
   const float *part;
   float *out;

@@ -40,6 +40,9 @@ struct TnArgs {
   // contribute zero tiles)
   const int *rows_dev = nullptr;
   int debug = 0;      // omnipq_tn_debug: bit 1 no fetches after the first two, bit 2 no fragment reads / MFMAs, bit 3 no C stores
+  // grouped launches: `colsum` points at per-slab partial rows float[slabs][M] (plain stores; the launch's reduction adds them
+  // up in slab order) instead of at the totals (f32 atomics, i.e. any order: the bias gradients differed from run to run)
+  int colsum_rows = 0;
 };
 
 // colsum (may be NULL): float[M], receives (ADDED, f32 atomics) the column sums of A over all positions --
@@ -281,7 +284,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs &g, const e16_t *__restrict
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
-      atomicAdd(colsum + m0 + tid, t);
+      if (g.colsum_rows) colsum[(size_t)slab * g.M + m0 + tid] = t;
+      else atomicAdd(colsum + m0 + tid, t);
     }
     __syncthreads();
   }
@@ -487,7 +491,10 @@ __device__ __forceinline__ void tn_tile_dma(const TnArgs &g, const e16_t *__rest
     for (int i = 0; i < 2; ++i) {
       const float t = csum[i] + __shfl_xor(csum[i], 32, 64);   // the two k-halves of the channel
       const int ch = m0 + wm * 64 + i * 32 + lane;
-      if (lane < 32 && ch < g.M) atomicAdd(colsum + ch, t);
+      if (lane < 32 && ch < g.M) {
+        if (g.colsum_rows) colsum[(size_t)slab * g.M + ch] = t;
+        else atomicAdd(colsum + ch, t);
+      }
     }
   }
   float *C = part + (size_t)slab * g.M * g.N;
@@ -550,7 +557,8 @@ struct TnGroupItem {
   int slabs;                    // slabs in use
   int out_rows, out_cols, out_ld;
   int blk_begin;                // first block of this problem in the reduction grid
-  int flags;                    // bit 0: add to `out` instead of overwriting it
+  int flags;                    // bit 0: add to `out` instead of overwriting it; bits 8..: slabs ALLOCATED to the problem (the
+                                // column-sum partial rows lie behind them)
   int rot;                      // rot | split << 8: output column c takes C's column (c < rot ? split + c : c - rot)
 };
 struct TnGroupArgs {
@@ -569,9 +577,12 @@ __global__ __launch_bounds__(256, REG ? 4 : 3) void gemm_tn_grouped_kernel(TnGro
     if (a.item[mid].wg_begin <= id) lo = mid; else hi = mid - 1;
   }
   const TnGroupItem &it = a.item[lo];
-  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles, it.rows_dev, a.pad_};
-  if (REG) tn_tile<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
-  else tn_tile_dma<AFFB>(g, it.A, it.B, it.part, it.colsum, id - it.wg_begin, it.ba, it.bb);
+  const TnArgs g{it.M, it.N, it.P, it.lda, it.ldb, it.p_chunk, it.m_tiles, it.n_tiles, it.rows_dev, a.pad_,
+                 it.colsum ? 1 : 0};
+  // column sums of A (the bias gradient): per-slab partial rows right behind the problem's C slabs
+  float *cpart = it.colsum ? it.part + (size_t)(it.flags >> 8) * it.M * it.N : nullptr;
+  if (REG) tn_tile<AFFB>(g, it.A, it.B, it.part, cpart, id - it.wg_begin, it.ba, it.bb);
+  else tn_tile_dma<AFFB>(g, it.A, it.B, it.part, cpart, id - it.wg_begin, it.ba, it.bb);
 }
 
 // out[r][c] (+)= sum over slabs of part[z][r][c], r < out_rows, c < out_cols: fixed order, no atomics
@@ -584,6 +595,21 @@ __global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(TnGroupArgs a) {
   }
   const TnGroupItem &it = a.item[lo];
   const int e = (blk - it.blk_begin) * 256 + (int)threadIdx.x;
+  const int nmain = (it.out_rows * it.out_cols + 255) / 256 * 256;
+  if (e >= nmain) {
+    // the column sums (bias gradient): partial rows of the slabs in use, added in slab order INTO colsum (zero or a running
+    // total on entry): a fixed order per problem -- the same bits every run
+    const int c = e - nmain;
+    if (it.colsum && c < it.M) {
+      const float *cp = it.part + (size_t)(it.flags >> 8) * it.M * it.N + c;
+      float v = 0.f;
+      for (int z = 0; z < it.slabs; ++z) v += cp[(size_t)z * it.M];
+      // (an atomic: a weight used twice in the graph has two problems with the SAME bias target in one launch; two addends
+      // commute exactly, so the result does not depend on which lands first)
+      atomicAdd(it.colsum + c, v);
+    }
+    return;
+  }
   if (e >= it.out_rows * it.out_cols) return;
   const int r = e / it.out_cols, c = e - r * it.out_cols;
   // the first layer of an SA stage multiplies rows ordered [features(split, zero-padded) | xyz(rot) | 0...] where the
@@ -793,7 +819,10 @@ extern "C" long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const vo
   const omnipq_tn_problem_ *pr = (const omnipq_tn_problem_ *)probs_;
   const int chunk = tng_chunk(nprob, pr);
   long long total = 0;
-  for (int i = 0; i < nprob; ++i) total += (long long)tng_slabs(pr[i].P, chunk) * pr[i].M * pr[i].N;
+  for (int i = 0; i < nprob; ++i) {
+    const long long slabs = tng_slabs(pr[i].P, chunk);
+    total += slabs * pr[i].M * pr[i].N + (pr[i].colsum ? slabs * pr[i].M : 0);      // + the column-sum partial rows
+  }
   return total;
 }
 
@@ -816,7 +845,8 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
   ws_off.resize(nprob);
   for (int i = 0; i < nprob; ++i) {
     ws_off[i] = off;
-    off += (size_t)tng_slabs(pr[i].P, chunk) * pr[i].M * pr[i].N;
+    const size_t slabs_i = (size_t)tng_slabs(pr[i].P, chunk);
+    off += slabs_i * pr[i].M * pr[i].N + (pr[i].colsum ? slabs_i * pr[i].M : 0);
   }
   for (int pass = 0; pass < 2; ++pass) {              // plain problems, then the ones with a transformed B operand
     int next = 0;
@@ -847,8 +877,8 @@ extern "C" int omnipq_gemm_tn_grouped(int nprob, const void *probs_, float *work
           wg += it.m_tiles * it.n_tiles * ((it.slabs + 7) / 8) * 8;
           it.out_rows = q.out_rows; it.out_cols = q.out_cols; it.out_ld = q.out_ld;
           it.blk_begin = blk;
-          blk += (q.out_rows * q.out_cols + 255) / 256;
-          it.flags = q.flags;
+          blk += (q.out_rows * q.out_cols + 255) / 256 + (q.colsum ? (q.M + 255) / 256 : 0);
+          it.flags = (q.flags & 0xff) | (slabs << 8);
           it.rot = q.rot;
         }
         ++next;

@@ -44,6 +44,11 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return v;
 }
 
+__device__ __forceinline__ uint4 pack8f(const double (&d)[8]) {
+  const float f[8] = {(float)d[0], (float)d[1], (float)d[2], (float)d[3], (float)d[4], (float)d[5], (float)d[6], (float)d[7]};
+  return pack8(f);
+}
+
 __device__ __forceinline__ void load8f(const float *p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4 *>(p);
   const float4 b = *reinterpret_cast<const float4 *>(p + 4);
@@ -1224,7 +1229,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
     const bool coord = c8 * 8 >= cin;
     if (coord ? dxyz == nullptr : dfeat == nullptr) continue;
     const int beg = offsets[(size_t)b * (n + 1) + k], end = offsets[(size_t)b * (n + 1) + k + 1];
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // order-independent sums: see interp_rows_grad_csr_kernel
     // four bucket entries per trip: index loads first, then the four row loads (one entry at a time the loop is a chain
     // of two dependent round trips per 16 bytes: 149 us for the 151 MB of sa2)
     const int *ord = order + (size_t)b * ms;
@@ -1241,7 +1246,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
         float d[8];
         unpack8(v[u], d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += d[e];
+        for (int e = 0; e < 8; ++e) acc[e] += (double)d[e];
       }
     }
     for (; t < end; ++t) {
@@ -1249,15 +1254,15 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(long long items, in
       float d[8];
       unpack8(*reinterpret_cast<const uint4 *>(dX + p * kpad + c8 * 8), d);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += d[e];
+      for (int e = 0; e < 8; ++e) acc[e] += (double)d[e];
     }
     if (!coord) {
       float *dst = dfeat + (size_t)bk * cin + c8 * 8;
-      *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      *reinterpret_cast<float4 *>(dst) = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
     } else {
       float *dst = dxyz + (size_t)bk * 3;
-      dst[0] = acc[0] * inv_r; dst[1] = acc[1] * inv_r; dst[2] = acc[2] * inv_r;
+      dst[0] = (float)acc[0] * inv_r; dst[1] = (float)acc[1] * inv_r; dst[2] = (float)acc[2] * inv_r;
     }
   }
 }
@@ -1407,7 +1412,7 @@ __global__ __launch_bounds__(256) void sa_scatter_rows_csr_kernel(long long item
     const e16_t *src = coord ? dXr : dY + c8 * 8;
     const int pitch = coord ? 8 : C;
     const int beg = offsets[(size_t)b * (n + 1) + k], end = offsets[(size_t)b * (n + 1) + k + 1];
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // order-independent sums: see interp_rows_grad_csr_kernel
     const int *ord = order + (size_t)b * ms;
     int t = beg;
     for (; t + 3 < end; t += 4) {
@@ -1422,25 +1427,25 @@ __global__ __launch_bounds__(256) void sa_scatter_rows_csr_kernel(long long item
         float d[8];
         unpack8(vv[uu], d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += d[e];
+        for (int e = 0; e < 8; ++e) acc[e] += (double)d[e];
       }
     }
     for (; t < end; ++t) {
       float d[8];
       unpack8(*reinterpret_cast<const uint4 *>(src + row_of(b, ord[t]) * pitch), d);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += d[e];
+      for (int e = 0; e < 8; ++e) acc[e] += (double)d[e];
     }
     if (!coord) {
       if (dfeat32) {
         float *dst = dfeat32 + (size_t)bk * C + c8 * 8;
-        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        *reinterpret_cast<float4 *>(dst) = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
       }
-      if (dfeat16) *reinterpret_cast<uint4 *>(dfeat16 + (size_t)bk * C + c8 * 8) = pack8(acc);
+      if (dfeat16) *reinterpret_cast<uint4 *>(dfeat16 + (size_t)bk * C + c8 * 8) = pack8f(acc);
     } else {
       float *dst = dxyz + (size_t)bk * 3;
-      dst[0] = acc[0] * inv_r; dst[1] = acc[1] * inv_r; dst[2] = acc[2] * inv_r;
+      dst[0] = (float)acc[0] * inv_r; dst[1] = (float)acc[1] * inv_r; dst[2] = (float)acc[2] * inv_r;
     }
   }
 }
@@ -2216,18 +2221,22 @@ __global__ __launch_bounds__(256) void interp_rows_grad_csr_kernel(long long ite
     const long long b = bj / m;
     const int j = (int)(bj - b * m);
     const int beg = offsets[b * (m + 1) + j], end = offsets[b * (m + 1) + j + 1];
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // f64 accumulators: the bucket's entries arrive in the order the CSR builder's LDS atomics happened to run, and an f32
+    // sum of them depends on that order in its last bit -- which the e16 roundings downstream amplify to ~1e-2 on the
+    // backbone's gradients (tools/repro_check.py).  Products of an f32 weight and a 16-bit value are exact in f64 and their
+    // f64 sum is order-independent far below one f32 ulp: the same bits every run.
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = beg; t < end; ++t) {
       const long long pos = b * n3 + order[b * n3 + t];         // (unknown point, slot) = pos / 3, pos % 3
-      const float wk = w[pos];
+      const double wk = (double)w[pos];
       float gv[8];
       unpack8(*reinterpret_cast<const uint4 *>(g + (size_t)(pos / 3) * ldg + col0 + c0), gv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(wk, gv[e], acc[e]);
+      for (int e = 0; e < 8; ++e) acc[e] += wk * (double)gv[e];
     }
     float *dst = dfeat + (size_t)bj * C + c0;
-    *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    *reinterpret_cast<float4 *>(dst) = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
   }
 }
 

@@ -79,12 +79,23 @@ def test_replayed_captured_step_equals_the_eager_step():
         return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
 
     want, again = run(False, True), run(False, True)
-    noise = max(rel(a[2][n], b[2][n]) for a, b in zip(want, again) for n in watch)
-    assert noise < 3e-2, noise
-    fwd_noise = max(rel(a[1][k], b[1][k]) for a, b in zip(want, again) for k in a[1] if a[1][k].is_floating_point())
-    assert fwd_noise < 1e-3, fwd_noise
+    # round 5: a step is bit-reproducible run to run -- forward (since round 4) AND backward (the CSR scatters accumulate in
+    # f64, the LayerNorm / bias gradient reductions run in a fixed order; tools/repro_check.py: 0 of 519 gradients differ)
+    for a, b in zip(want, again):
+        # (the scalar is bench.py's stand-in loss: omnipq_sum_of_means folds its blocks with f32 atomics)
+        assert abs(float(a[0]) - float(b[0])) <= 1e-6 * abs(float(a[0]))
+        for k in a[1]:
+            assert torch.equal(a[1][k], b[1][k]), k
+        for n in watch:
+            assert torch.equal(a[2][n], b[2][n]), n
+    # A replay is NOT bit-equal to the eager launches: under capture the six layers' key sides are precomputed as pair launches on
+    # a side stream (pq_transformer._OVERLAP_KEY_SIDE == "capture"), another -- equivalent -- order of the same f32 sums; the
+    # e16 roundings of the backward pass amplify a last-bit difference to ~1e-2 on the backbone's weight gradients.
+    noise, fwd_noise = 1e-2, 3e-7
+    replays = {}
     for announce in (True, False):
         got = run(True, announce)
+        replays[announce] = got
         for i, (a, b) in enumerate(zip(want, got)):
             # index outputs exact; float outputs and the loss to the forward pass's own run-to-run noise (the BatchNorm
             # statistics are folded with f64 atomics, whose order can move a last bit and with it a bf16 rounding)
@@ -97,6 +108,13 @@ def test_replayed_captured_step_equals_the_eager_step():
             for n in watch:
                 assert b[2][n].abs().sum() > 0, (announce, i, n)
                 assert rel(b[2][n], a[2][n]) <= 3 * noise + 1e-4, (announce, i, n, rel(b[2][n], a[2][n]), noise)
+    # ... but two CAPTURED steppers agree bit for bit, announced batches or not
+    for a, b in zip(replays[True], replays[False]):
+        assert abs(float(a[0]) - float(b[0])) <= 1e-6 * abs(float(a[0]))
+        for k in a[1]:
+            assert torch.equal(a[1][k], b[1][k]), k
+        for n in watch:
+            assert torch.equal(a[2][n], b[2][n]), n
 
 
 @pytest.mark.gpu
