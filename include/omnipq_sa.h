@@ -21,12 +21,24 @@
 #define OMNIPQ_SA_H
 #ifdef __cplusplus
 extern "C" {
+
+/* The row plan of a set-abstraction stage (see omnipq_sa_ball_plan below): plain device pointers and sizes.  Passed by pointer,
+ * read during the call only. */
+typedef struct omnipq_row_plan {
+  const int *rows_dev;         /* device: rows in use (a multiple of gs) */
+  const void *row_w;           /* uint8 [rows]: rows of the full layout a compact row stands for */
+  const int *goff;             /* int32 [balls + 1]: first group of every ball */
+  long long rows;              /* the static row count the stage's launches are issued with */
+  int gs;                      /* rows per group: 8 or 16 */
+  const float *pool_gamma;     /* see below; may be NULL */
+} omnipq_row_plan;
+
 #endif
 
 /* X[p][0..cin) = feat_pm[b][idx[p]][:]; X[p][cin..cin+3) = (xyz[b][idx[p]] - new_xyz[b][j]) * inv_radius;
  * columns up to kpad zero.  feat_pm is [b][n][cin] e16 (NULL when cin == 0); idx is (b,m,s) i32. */
 int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const float *xyz,
-                     const float *new_xyz, const int *idx, const void *feat_pm, void *X, void *stream);
+                     const float *new_xyz, const int *idx, const void *feat_pm, void *X, const omnipq_row_plan *plan, void *stream);
 
 /* adjoint of omnipq_sa_gather: atomically adds dX[p][0..cin) into dfeat_pm[b][idx[p]][:] (f32, may be
  * NULL) and the coordinate part into dxyz[b][idx[p]] / -dnew_xyz[b][j] (f32, may be NULL together). */
@@ -36,10 +48,10 @@ int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, float inv_r
 /* CSR of "which grouped positions read point k": offsets (b, n+1) i32, order (b, m*s) i32 (position
  * index within the scene); scratch: b*n ints.  Lets the adjoint of the gather run without atomics. */
 int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, int *offsets, int *order, int *scratch,
-                        void *stream);
+                        const omnipq_row_plan *plan, void *stream);
 int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float inv_radius, const int *offsets,
                           const int *order, const void *dX, float *dfeat_pm, float *dxyz, float *dnew_xyz,
-                          void *stream);
+                          const omnipq_row_plan *plan, void *stream);
 
 /* Pair launches.  omnipq_pair_hold(): the NEXT GEMM of the calling thread that takes the small-tile path (any
  * omnipq_gemm_nt_e16* entry point on a few thousand rows) is held back instead of launched; the GEMM after it -- if it is
@@ -55,7 +67,7 @@ long long omnipq_pair_flush(void);
 
 /* C[M][N] (e16) = A[M][K] * B[N][K]^T on MFMA (K % 32 == 0, N % 8 == 0). */
 int omnipq_gemm_nt_e16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
-                        void *stream);
+                        const omnipq_row_plan *plan, void *stream);
 
 /* C = A B^T + bias[n] (f32 bias added before the e16 rounding) */
 int omnipq_gemm_nt_e16_bias(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
@@ -85,10 +97,10 @@ long long omnipq_gemm_tn_workspace_floats(int M, int N, int P);
  * output tiles, k_step = positions per K-step of the kernel). */
 int omnipq_gemm_tn_slabs(int tiles, long long P, int k_step);
 int omnipq_gemm_tn_e16(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
-                        float *workspace, void *stream);
+                        float *workspace, const omnipq_row_plan *plan, void *stream);
 /* the same, and colsum[m] += sum_p A[p][m] (f32): weight AND bias gradient of a linear layer from one pass */
 int omnipq_gemm_tn_e16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb, float *C,
-                               float *workspace, float *colsum, void *stream);
+                               float *workspace, float *colsum, const omnipq_row_plan *plan, void *stream);
 
 /* Many independent weight gradients in ONE grid plus ONE reduction (the ~115 small dW = dY^T X of the per-point
  * MLPs outside the SA stages: torch autograd runs them one by one, `loss.backward()` of train.py:571; nothing
@@ -121,7 +133,7 @@ long long omnipq_gemm_tn_grouped_workspace_floats(int nprob, const void *probs);
  *   ..._tn_..._affine:  C = A^T relu(ba .* B + bb) (+ colsum as omnipq_gemm_tn_e16_colsum, may be NULL) */
 int omnipq_gemm_nt_e16_affine(int M, int N, int K, const void *A, int lda, const float *a_in, const float *b_in,
                                const void *B, int ldb, void *C, int ldc, const float *bias, double *sums,
-                               float *workspace, void *stream);
+                               float *workspace, const omnipq_row_plan *plan, void *stream);
 /* ..._bnaffine: as ..._nt_..._affine, with the BatchNorm finalize of the layer that produced A folded into the
  * prologue (replaces one omnipq_bn_finalize launch per BatchNorm layer): a / b are derived from that layer's totals
  * fin_sums (double[2][K] over `count` rows, all-reduced by the caller under SyncBatchNorm) and stored with mean /
@@ -130,7 +142,7 @@ int omnipq_gemm_nt_e16_bnaffine(int M, int N, int K, const void *A, int lda, con
                                  const float *gamma, const float *beta, float eps, float momentum,
                                  float *running_mean, float *running_var, const float *conv_bias, float *a_out,
                                  float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
-                                 int ldc, const float *bias, double *sums, float *workspace, void *stream);
+                                 int ldc, const float *bias, double *sums, float *workspace, const omnipq_row_plan *plan, void *stream);
 /* Max-pool without re-reading the layer: the ..._pool variants of the statistics GEMMs also record, per ball of `s`
  * consecutive rows (s divides 128 and M) and column, the maximum and minimum of the stored outputs and the first row
  * attaining each (ymax / ymin e16 [M/s][N], amax / amin uint8 [M/s][N]); once the BatchNorm constants exist,
@@ -140,13 +152,13 @@ int omnipq_gemm_nt_e16_bnaffine(int M, int N, int K, const void *A, int lda, con
  * `sums` is zero on entry, the call does not clear it). */
 int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C, int ldc,
                                    const float *bias, double *sums, float *workspace, int s, void *ymax, void *ymin,
-                                   unsigned char *amax, unsigned char *amin, void *stream);
+                                   unsigned char *amax, unsigned char *amin, const omnipq_row_plan *plan, void *stream);
 int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void *A, int lda, const double *fin_sums, double count,
                                       const float *gamma, const float *beta, float eps, float momentum,
                                       float *running_mean, float *running_var, const float *conv_bias, float *a_out,
                                       float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
                                       int ldc, const float *bias, double *sums, float *workspace, int s, void *ymax,
-                                      void *ymin, unsigned char *amax, unsigned char *amin, void *stream);
+                                      void *ymin, unsigned char *amax, unsigned char *amin, const omnipq_row_plan *plan, void *stream);
 int omnipq_sa_pool_select(long long BM, int C, const void *ymax, const void *ymin, const unsigned char *amax,
                           const unsigned char *amin, const float *a, const float *bshift, float *out_f32, void *out_pm,
                           unsigned char *arg, void *ysel, void *stream);
@@ -157,12 +169,12 @@ int omnipq_sa_pool_select_finalize(long long BM, int C, const void *ymax, const 
                                    const unsigned char *amin, const double *sums, double count, const float *gamma,
                                    const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                                    float *a_out, float *b_out, float *mean_out, float *invstd_out, float *out_f32,
-                                   void *out_pm, unsigned char *arg, void *ysel, void *stream);
+                                   void *out_pm, unsigned char *arg, void *ysel, const omnipq_row_plan *plan, void *stream);
 
 int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
                                  const float *g_out, const void *out_pm, double *sums, int zeroed, void *stream);
 int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
-                               const float *bb, float *C, float *workspace, float *colsum, void *stream);
+                               const float *bb, float *C, float *workspace, float *colsum, const omnipq_row_plan *plan, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
 /* First layer of a stage WITH features, computed on the source points (round 5).  The first conv of the shared MLP
  * (pytorch_utils.py:11-36) is linear in the grouped row [features(idx) | (xyz(idx) - centre) / r] that QueryAndGroup builds
@@ -201,31 +213,31 @@ int omnipq_tn_occupancy(int which);   /* workgroups per CU of the grouped TN ker
  * [balls + 1]) = first group of every ball, rows_dev (int32 [1], device) = gs * goff[balls] rows in use, row_w (uint8 per
  * compact row) = how many rows of the full layout the row stands for (1 + dropped copies on a ball's first row, else 1);
  * scratch = int32 [balls].  The ball extrema of a planned stage are recorded per group (s = gs in the ..._pool entry points).
- * omnipq_sa_row_plan(rows_dev, row_w, goff, rows, gs) makes a plan current for the CALLING THREAD: the stage's kernels launched
- * with exactly `rows` rows (the full count: grids stay static, graph-capturable) work on *rows_dev rows -- workgroups past
- * them leave at once --, weight the BatchNorm statistics and the constant backward terms by row_w, and the ball-structured
- * ones (omnipq_sa_gather, omnipq_sa_pool_select_finalize, omnipq_sa_pool_bwd_apply) address balls through goff.
- * rows_dev == NULL clears it.  Results equal the full computation up to the order of the f32 sums. */
+ * A plan is an ARGUMENT (`const omnipq_row_plan *plan`, NULL = none) of every entry point that honours one (round 5; until
+ * round 4 a per-thread mode set by omnipq_sa_row_plan): a launch with exactly `plan->rows` rows (the full count: grids stay
+ * static, graph-capturable) works on *rows_dev rows -- workgroups past them leave at once --, weights the BatchNorm
+ * statistics and the constant backward terms by row_w, and the ball-structured ones (omnipq_sa_gather,
+ * omnipq_sa_pool_select_finalize, omnipq_sa_pool_bwd_apply) address balls through goff; a launch with another row count
+ * ignores the plan.  pool_gamma (may be NULL; gs == 8 only): the BatchNorm weight of the layer whose ball extrema are being
+ * recorded -- the GEMM then records per (group, column) only the extremum the max-pool can select (the maximum where gamma >=
+ * 0, else the minimum) and omnipq_sa_pool_select_finalize reads only those.  Results equal the full computation up to the
+ * order of the f32 sums. */
 int omnipq_sa_ball_plan(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
                         int *scratch, void *stream);
 /* ... and unit_src (int32 [balls * nsample / 8], may be NULL): compact rows 8 u .. 8 u + 7 = positions 8 unit_src[u] .. + 7 of
  * the full layout, for kernels that walk the compact rows (omnipq_sa_l1_rows). */
 int omnipq_sa_ball_plan_src(long long balls, int nsample, int gs, const int *idx, int *goff, int *rows_dev, void *row_w,
                             int *unit_src, int *scratch, void *stream);
-void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows, int gs);
-/* With a plan of 8-row groups current: `gamma` = the BatchNorm weight (float [N]) of the layer whose ball extrema the next
- * ..._pool GEMM records (or NULL).  a = gamma * invstd has gamma's sign, so per (group, column) only the maximum (gamma >= 0)
- * or the minimum (gamma < 0) can be selected by the max-pool: the GEMM then stores just that one (value into ymax, row into
- * amax; ymin / amin are not written) and omnipq_sa_pool_select_finalize reads just those -- half the extrema traffic.
- * Cleared by omnipq_sa_row_plan. */
-void omnipq_sa_plan_pool_gamma(const float *gamma);
+/* (pool_gamma of a plan: a = gamma * invstd has gamma's sign, so per (group, column) only the maximum (gamma >= 0) or the
+ * minimum (gamma < 0) can be selected by the max-pool: the ..._pool GEMM then stores just that one (value into ymax, row into
+ * amax; ymin / amin are not written) and omnipq_sa_pool_select_finalize reads just those -- half the extrema traffic.) */
 
 /* GEMM + BatchNorm statistics in one pass: C = A B^T (+ bias), and the per-column sum / sum of squares
  * of the e16 values stored are ADDED to sums = double[2][N] (zero on entry).  workspace: float buffer of
  * omnipq_gemm_nt_stats_workspace_floats(M, N) elements (0 for few rows: then it may be NULL). */
 long long omnipq_gemm_nt_stats_workspace_floats(int M, int N);
 int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
-                              int ldc, const float *bias, double *sums, float *workspace, void *stream);
+                              int ldc, const float *bias, double *sums, float *workspace, const omnipq_row_plan *plan, void *stream);
 
 /* Data-gradient GEMM + BatchNorm-backward sums of the layer below in one pass:
  *   dX = dY Wt^T (e16, [M][N]),  dz = dX * [a y + b > 0],
@@ -233,7 +245,7 @@ int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int lda, const 
  * Y: that layer's pre-BN activations, [M][N] with pitch ldc.  sums / workspace as above. */
 int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, void *C,
                               int ldc, const void *Y, const float *a, const float *b, const float *mean,
-                              const float *invstd, double *sums, float *workspace, void *stream);
+                              const float *invstd, double *sums, float *workspace, const omnipq_row_plan *plan, void *stream);
 
 /* ---- The first layer of a coordinates-only stage WITHOUT its output (sa1: Conv2d 3 -> C0 + BatchNorm + ReLU over all
  * grouped positions; reference pointnet2_modules.py:243-257, pytorch_utils.py:11-36).  y[p][c] = W0[c] . x0[p] is three
@@ -251,19 +263,19 @@ int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int lda, const 
  *   omnipq_gemm_tn_e16_xyz_affine     the second layer's weight gradient C = A^T relu(ba .* (X0 W0^T) + bb)
  *   omnipq_sa_xyz_bwd        dW0 f32 [C0][3] from sums5 (rows 0, 1 global under SyncBatchNorm, inv_count = 1 / global
  *                            positions), the moments and the layer's a / mean / invstd */
-int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, double *mom, void *stream);
+int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, double *mom, const omnipq_row_plan *plan, void *stream);
 int omnipq_sa_xyz_stats(int C, const void *W0, int ldw0, const double *mom, double *sums, void *stream);
 int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *X0, int ldx, const void *W0, int ldw0,
                                      const double *fin_sums, double count, const float *gamma, const float *beta,
                                      float eps, float momentum, float *running_mean, float *running_var, float *a_out,
                                      float *b_out, float *mean_out, float *invstd_out, const void *B, int ldb, void *C,
-                                     int ldc, double *sums, float *workspace, void *stream);
+                                     int ldc, double *sums, float *workspace, const omnipq_row_plan *plan, void *stream);
 long long omnipq_gemm_nt_xyz_workspace_floats(int M, int N);
 int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb, const void *X0,
                                   int ldx, const void *W0, int ldw0, const float *a, const float *b, const float *mean,
-                                  const float *invstd, double *sums5, float *workspace, void *stream);
+                                  const float *invstd, double *sums5, float *workspace, const omnipq_row_plan *plan, void *stream);
 int omnipq_gemm_tn_e16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx, const void *W0,
-                                   int ldw0, const float *ba, const float *bb, float *C, float *workspace, void *stream);
+                                   int ldw0, const float *ba, const float *bb, float *C, float *workspace, const omnipq_row_plan *plan, void *stream);
 int omnipq_sa_xyz_bwd(int C, const void *W0, int ldw0, const double *mom, const double *sums5, const float *a,
                       const float *mean, const float *invstd, double inv_count, float *dW, void *stream);
 
@@ -287,7 +299,7 @@ int omnipq_bn_finalize_relu(long long P, int C, double count, const double *sums
  * receiving (float) sums[0], sums[1] -- only meaningful when `sums` are this rank's own totals. */
 int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positions, const void *dX, const void *Y,
                               const float *a, const float *b, const float *mean, const float *invstd,
-                              const double *sums, void *dY, float *dbeta_dgamma, void *stream);
+                              const double *sums, void *dY, float *dbeta_dgamma, const omnipq_row_plan *plan, void *stream);
 
 /* Weight preparation in one pass: W f32 [cout][cin] (row pitch ldw) -> Wp e16 [cp][k] zero-padded with its
  * columns rotated left by `rot` (SA layer 0: [xyz, feat] -> [feat, xyz]) and, if Wt != NULL, Wt e16 [k][cp]
@@ -328,12 +340,12 @@ int omnipq_sa_pool_bwd_stats(int b, int m, int s, int C, const void *Y, const fl
                              void *stream);
 int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
                              const float *mean, const float *invstd, const double *sums, const float *g_out,
-                             const void *out_pm, const unsigned char *arg, void *dY, void *stream);
+                             const void *out_pm, const unsigned char *arg, void *dY, const omnipq_row_plan *plan, void *stream);
 /* The same; additionally gb_out float[2][C] = (dbeta | dgamma), the totals as f32 -- the layer's affine gradients when
  * `sums` are this rank's own totals (no process group); saves the omnipq_sums_to_f32 launch. */
 int omnipq_sa_pool_bwd_apply_gb(int b, int m, int s, int C, double total_positions, const void *Y, const float *a,
                                 const float *mean, const float *invstd, const double *sums, const float *g_out,
-                                const void *out_pm, const unsigned char *arg, void *dY, float *gb_out, void *stream);
+                                const void *out_pm, const unsigned char *arg, void *dY, float *gb_out, const omnipq_row_plan *plan, void *stream);
 
 
 /* backward of ReLU + BatchNorm for the inner layers (dX -> dY, may be in place) */

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void bq_grid_kernel(int n, int m, float inv_h,
 }  // namespace omnipq
 
 extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, int *offsets, int *order, int *scratch,
-                                   void *stream);
+                                   const omnipq_row_plan *plan, void *stream);
 
 // Workspace of omnipq_ball_query_grid in bytes.
 extern "C" long long omnipq_ball_query_grid_workspace_bytes(int b, int n) {
@@ -267,7 +267,7 @@ extern "C" int omnipq_ball_query_grid(int b, int n, int m, float radius, int nsa
   const long long total = (long long)b * n;
   bq_cell_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(total, inv_h, xyz, bucket);
   OMNIPQ_LAUNCH_CHECK();
-  const int rc = omnipq_sa_build_csr(b, kBqBuckets, n, 1, bucket, offsets, order, bucket, stream);
+  const int rc = omnipq_sa_build_csr(b, kBqBuckets, n, 1, bucket, offsets, order, bucket, nullptr, stream);
   if (rc) return rc;
   bq_sorted_xyz_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(total, n, xyz, order, sorted);
   OMNIPQ_LAUNCH_CHECK();

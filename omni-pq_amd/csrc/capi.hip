@@ -54,9 +54,22 @@ extern "C" int omnipq_span_marker(int end, void *stream) {
 }
 
 // ---- row plan of a set-abstraction stage (common.h: RowPlan) ----------------------------------------------------------------
-static thread_local omnipq::RowPlan t_row_plan;
+static thread_local omnipq::RowPlan t_row_plan;        // the plan of the call in progress (PlanScope): empty between calls
 namespace omnipq {
 RowPlan &row_plan() { return t_row_plan; }
+PlanScope::PlanScope(const omnipq_row_plan *plan) : saved_(t_row_plan) {
+  RowPlan rp;
+  if (plan && plan->rows_dev) {
+    rp.rows_dev = plan->rows_dev;
+    rp.row_w = (const unsigned char *)plan->row_w;
+    rp.goff = plan->goff;
+    rp.rows = plan->rows;
+    rp.gs = plan->gs == 8 ? 8 : 16;
+    rp.pool_gamma = plan->pool_gamma;
+  }
+  t_row_plan = rp;
+}
+PlanScope::~PlanScope() { t_row_plan = saved_; }
 
 // real neighbours of a ball = 1 + #{t > 0: idx[t] != idx[0]} (the real ones are distinct points in increasing index order, the
 // padding repeats idx[0]) -> groups of `gs` rows the ball keeps.  s / 4 lanes per ball (s in {16, 32, 64, 128}), 16 bytes each:
@@ -151,17 +164,6 @@ __global__ __launch_bounds__(256) void sa_plan_weights_kernel(long long balls, i
   if (unit_src) unit_src[((size_t)g0 * gs >> 3) + o] = (int)(b * omax + o);
 }
 }  // namespace omnipq
-
-extern "C" void omnipq_sa_row_plan(const int *rows_dev, const void *row_w, const int *goff, long long rows, int gs) {
-  t_row_plan.rows_dev = rows_dev;
-  t_row_plan.row_w = (const unsigned char *)row_w;
-  t_row_plan.goff = goff;
-  t_row_plan.rows = rows_dev ? rows : 0;
-  t_row_plan.gs = gs == 8 ? 8 : 16;
-  t_row_plan.pool_gamma = nullptr;
-}
-
-extern "C" void omnipq_sa_plan_pool_gamma(const float *gamma) { t_row_plan.pool_gamma = gamma; }
 
 // Plan of a stage from its ball-query indices idx (int32 [balls][nsample], nsample 16, 32, 64 or 128) in groups of gs = 8 or
 // 16 rows: goff (int32 [balls + 1]), rows_dev (int32 [1]), row_w (uint8 [balls * nsample]: valid for the rows in use), scratch

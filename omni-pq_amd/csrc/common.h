@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "omnipq_pointops.h"
+#include "omnipq_sa.h"
 
 #define OMNIPQ_LAUNCH_CHECK()                    \
   do {                                           \
@@ -167,7 +168,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// Row plan of a set-abstraction stage (include/omnipq_sa.h: omnipq_sa_row_plan): ball_query pads a ball that holds fewer than
+// Row plan of a set-abstraction stage (include/omnipq_sa.h: omnipq_row_plan): ball_query pads a ball that holds fewer than
 // nsample points with copies of its FIRST neighbour (ball_query_gpu.cu:36-45), so the grouped rows behind the real
 // neighbours are duplicates of the ball's row 0 and every per-row result computed from them is a duplicate too.  A planned
 // stage runs on a COMPACT row space: ball b keeps its first gs * g_b rows (g_b = ceil(real neighbours / gs) groups of gs = 8 or
@@ -177,19 +178,31 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // leave at once.  The dropped rows are accounted for through `row_w` (one byte per compact row: how many rows of the full
 // layout it stands for -- 1, or 1 + dropped copies for a ball's first row): BatchNorm statistics are sums of w * y and
 // w * y^2, and the constant term of the BatchNorm backward, which every copy contributes once, is multiplied by w; everything
-// else downstream is linear in the rows.  Thread-local; applies to launches whose row count equals `rows`.
+// else downstream is linear in the rows.  Applies to launches whose row count equals `rows`.
 struct RowPlan {
   const int *rows_dev = nullptr;                 // device: rows in use (a multiple of gs)
   const unsigned char *row_w = nullptr;          // [rows]
   const int *goff = nullptr;                     // [balls + 1]: first group of every ball
   int gs = 16;                                   // rows per group: 8 or 16
-  // BatchNorm weight of the layer whose ball extrema are being recorded, or NULL (omnipq_sa_plan_pool_gamma): with it the
+  // BatchNorm weight of the layer whose ball extrema are being recorded, or NULL (omnipq_row_plan.pool_gamma): with it the
   // GEMM records per (group, column) only the extremum the max-pool can select -- the maximum where gamma >= 0, else the
   // minimum (a = gamma * invstd has gamma's sign) -- into ymax / amax, and pool_select_finalize reads only those
   const float *pool_gamma = nullptr;
   long long rows = 0;                            // the static row count the stage's launches are issued with
 };
-RowPlan &row_plan();                            // capi.hip; thread-local
+// The plan of the CALL in progress on this thread.  A plan is an argument of the public entry points (include/omnipq_sa.h:
+// omnipq_row_plan); every such entry point opens a PlanScope for its duration, so the internals below it read row_plan()
+// instead of passing the pointer down six levels.  Nothing survives the call: no ambient state a caller can observe.
+RowPlan &row_plan();                            // capi.hip
+struct PlanScope {
+  explicit PlanScope(const omnipq_row_plan *plan);
+  ~PlanScope();
+  PlanScope(const PlanScope &) = delete;
+  PlanScope &operator=(const PlanScope &) = delete;
+
+ private:
+  RowPlan saved_;
+};
 
 // Pair launches (include/omnipq_sa.h: omnipq_pair_hold): one launch of the calling thread held back for a partner of the
 // same kind.  `blob` holds the kernel-specific problem record, `single` sends it out on its own.

@@ -1074,7 +1074,8 @@ extern "C" long long omnipq_pair_flush(void) {
 
 // C[M][N] (bf16) = A[M][K] * B[N][K]^T.   K % 32 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned.
 extern "C" int omnipq_gemm_nt_e16(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
-                                   void *C, int ldc, void *stream) {
+                                   void *C, int ldc, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -1109,7 +1110,8 @@ extern "C" long long omnipq_gemm_nt_stats_workspace_floats(int M, int N) {
 // omnipq_gemm_nt_stats_workspace_floats(M, N) floats (may be NULL when that is 0).
 extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                          void *C, int ldc, const float *bias, double *sums, float *workspace,
-                                         void *stream) {
+                                         const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -1200,7 +1202,8 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
 // (double[2][N], zero on entry) also the BatchNorm statistics of C as in omnipq_gemm_nt_e16_stats.
 extern "C" int omnipq_gemm_nt_e16_affine(int M, int N, int K, const void *A, int lda, const float *a_in,
                                           const float *b_in, const void *B, int ldb, void *C, int ldc,
-                                          const float *bias, double *sums, float *workspace, void *stream) {
+                                          const float *bias, double *sums, float *workspace, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!a_in || !b_in) return OMNIPQ_EINVAL;
   omnipq::AffineIn aff{};
   aff.a = a_in;
@@ -1230,14 +1233,15 @@ extern "C" int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void 
                                                  const float *conv_bias, float *a_out, float *b_out, float *mean_out,
                                                  float *invstd_out, const void *B, int ldb, void *C, int ldc,
                                                  const float *bias, double *sums, float *workspace, int s, void *ymax,
-                                                 void *ymin, unsigned char *amax, unsigned char *amin, void *stream);
+                                                 void *ymin, unsigned char *amax, unsigned char *amin, const omnipq_row_plan *plan, void *stream);
 
 extern "C" int omnipq_gemm_nt_e16_bnaffine(int M, int N, int K, const void *A, int lda, const double *fin_sums,
                                             double count, const float *gamma, const float *beta, float eps,
                                             float momentum, float *running_mean, float *running_var,
                                             const float *conv_bias, float *a_out, float *b_out, float *mean_out,
                                             float *invstd_out, const void *B, int ldb, void *C, int ldc,
-                                            const float *bias, double *sums, float *workspace, void *stream) {
+                                            const float *bias, double *sums, float *workspace, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!fin_sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out || !(count > 0)) return OMNIPQ_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
   omnipq::AffineIn aff{};
@@ -1265,7 +1269,8 @@ extern "C" int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void 
                                                  const float *conv_bias, float *a_out, float *b_out, float *mean_out,
                                                  float *invstd_out, const void *B, int ldb, void *C, int ldc,
                                                  const float *bias, double *sums, float *workspace, int s, void *ymax,
-                                                 void *ymin, unsigned char *amax, unsigned char *amin, void *stream) {
+                                                 void *ymin, unsigned char *amax, unsigned char *amin, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!fin_sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out || !(count > 0) || !sums)
     return OMNIPQ_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return OMNIPQ_EINVAL;
@@ -1293,7 +1298,8 @@ extern "C" int omnipq_gemm_nt_e16_bnaffine_pool(int M, int N, int K, const void 
 extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                               void *C, int ldc, const float *bias, double *sums, float *workspace,
                                               int s, void *ymax, void *ymin, unsigned char *amax, unsigned char *amin,
-                                              void *stream) {
+                                              const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -1336,7 +1342,8 @@ extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A,
 extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                          void *C, int ldc, const void *Y, const float *a, const float *b,
                                          const float *mean, const float *invstd, double *sums, float *workspace,
-                                         void *stream) {
+                                         const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -1390,7 +1397,8 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
                                                 const float *beta, float eps, float momentum, float *running_mean,
                                                 float *running_var, float *a_out, float *b_out, float *mean_out,
                                                 float *invstd_out, const void *B, int ldb, void *C, int ldc, double *sums,
-                                                float *workspace, void *stream) {
+                                                float *workspace, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
@@ -1440,7 +1448,8 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
 extern "C" int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, int lda, const void *B, int ldb,
                                              const void *X0, int ldx, const void *W0, int ldw0, const float *a,
                                              const float *b, const float *mean, const float *invstd, double *sums5,
-                                             float *workspace, void *stream) {
+                                             float *workspace, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;

@@ -699,14 +699,16 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
                         const void *W0 = nullptr, int ldw0 = 0);
 
 extern "C" int omnipq_gemm_tn_e16(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
-                                   float *C, float *workspace, void *stream) {
+                                   float *C, float *workspace, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, nullptr, nullptr, nullptr, stream);
 }
 
 // The same, and colsum[m] += sum_p A[p][m] (f32, zero or a running total on entry): weight and bias gradient
 // of a linear layer from one pass over dY.
 extern "C" int omnipq_gemm_tn_e16_colsum(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
-                                          float *C, float *workspace, float *colsum, void *stream) {
+                                          float *C, float *workspace, float *colsum, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!colsum) return OMNIPQ_EINVAL;
   return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, nullptr, nullptr, stream);
 }
@@ -715,7 +717,8 @@ extern "C" int omnipq_gemm_tn_e16_colsum(int M, int N, int P, const void *A, int
 // pre-BatchNorm output on the fly; colsum may be NULL.
 extern "C" int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb,
                                           const float *ba, const float *bb, float *C, float *workspace,
-                                          float *colsum, void *stream) {
+                                          float *colsum, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!ba || !bb) return OMNIPQ_EINVAL;
   return gemm_tn_impl(M, N, P, A, lda, B, ldb, C, workspace, colsum, ba, bb, stream);
 }
@@ -724,7 +727,8 @@ extern "C" int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int
 // X0 bf16 [P][ldx] (columns 0..2), W0 bf16 [N][ldw0] (columns 0..2).
 extern "C" int omnipq_gemm_tn_e16_xyz_affine(int M, int N, int P, const void *A, int lda, const void *X0, int ldx,
                                               const void *W0, int ldw0, const float *ba, const float *bb, float *C,
-                                              float *workspace, void *stream) {
+                                              float *workspace, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!ba || !bb || !W0 || (ldx % 4) || (ldw0 % 4) || ldx < 3 || ldw0 < 3) return OMNIPQ_EINVAL;
   return gemm_tn_impl(M, N, P, A, lda, X0, ldx, C, workspace, nullptr, ba, bb, stream, W0, ldw0);
 }

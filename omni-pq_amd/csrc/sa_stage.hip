@@ -1490,7 +1490,8 @@ using namespace omnipq;
 
 extern "C" int omnipq_sa_gather(int b, int n, int m, int s, int cin, int kpad, float inv_radius,
                                 const float *xyz, const float *new_xyz, const int *idx, const void *feat_pm,
-                                void *X, void *stream) {
+                                void *X, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (b < 0 || n <= 0 || m < 0 || s < 0 || cin < 0 || (cin % 8) || (kpad % 8) || kpad < cin + 3)
     return OMNIPQ_EINVAL;
   const long long P = (long long)b * m * s;
@@ -1586,7 +1587,8 @@ extern "C" int omnipq_sa_pool_select_finalize(long long BM, int C, const void *y
                                               double count, const float *gamma, const float *beta, float eps,
                                               float momentum, float *running_mean, float *running_var, float *a_out,
                                               float *b_out, float *mean_out, float *invstd_out, float *out_f32, void *out_pm,
-                                              unsigned char *arg, void *ysel, void *stream) {
+                                              unsigned char *arg, void *ysel, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (BM < 0 || C <= 0 || (C % 8) || C > kFinMaxC || !(count > 0)) return OMNIPQ_EINVAL;
   const long long items = BM * (C / 8);
   if (!ymax || !ymin || !amax || !amin || !sums || !gamma || !beta || !a_out || !b_out || !mean_out || !invstd_out ||
@@ -1642,7 +1644,8 @@ static int pool_bwd_apply_impl(int b, int m, int s, int C, double total_position
 extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total_positions, const void *Y,
                                         const float *a, const float *mean, const float *invstd,
                                         const double *sums, const float *g_out, const void *out_pm,
-                                        const unsigned char *arg, void *dY, void *stream) {
+                                        const unsigned char *arg, void *dY, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   return pool_bwd_apply_impl(b, m, s, C, total_positions, Y, a, mean, invstd, sums, g_out, out_pm, arg, dY, nullptr, stream);
 }
 
@@ -1651,7 +1654,8 @@ extern "C" int omnipq_sa_pool_bwd_apply(int b, int m, int s, int C, double total
 extern "C" int omnipq_sa_pool_bwd_apply_gb(int b, int m, int s, int C, double total_positions, const void *Y,
                                            const float *a, const float *mean, const float *invstd, const double *sums,
                                            const float *g_out, const void *out_pm, const unsigned char *arg, void *dY,
-                                           float *gb_out, void *stream) {
+                                           float *gb_out, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (!gb_out) return OMNIPQ_EINVAL;
   return pool_bwd_apply_impl(b, m, s, C, total_positions, Y, a, mean, invstd, sums, g_out, out_pm, arg, dY, gb_out, stream);
 }
@@ -1734,7 +1738,8 @@ extern "C" int omnipq_sa_scatter(int b, int n, int m, int s, int cin, int kpad, 
 // Buckets the b*m*s grouped positions by source point: offsets (b, n+1) and order (b, m*s) form a CSR
 // of "which positions read point k".  scratch: b*n ints.  Built once per forward, reused by the backward.
 extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, int *offsets, int *order,
-                                   int *scratch, void *stream) {
+                                   int *scratch, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (b < 0 || n <= 0 || m < 0 || s < 0) return OMNIPQ_EINVAL;
   if (b == 0) return OMNIPQ_OK;
   if (!idx || !offsets || !order || !scratch) return OMNIPQ_EINVAL;
@@ -1771,7 +1776,8 @@ extern "C" int omnipq_sa_build_csr(int b, int n, int m, int s, const int *idx, i
 // Writes EVERY entry of dfeat_pm / dxyz / dnew_xyz (no zero-fill needed); NULL outputs are skipped.
 extern "C" int omnipq_sa_scatter_csr(int b, int n, int m, int s, int cin, int kpad, float inv_radius,
                                      const int *offsets, const int *order, const void *dX, float *dfeat_pm,
-                                     float *dxyz, float *dnew_xyz, void *stream) {
+                                     float *dxyz, float *dnew_xyz, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (b < 0 || n <= 0 || m < 0 || s < 0 || cin < 0 || (cin % 8) || (kpad % 8) || kpad < cin + 3)
     return OMNIPQ_EINVAL;
   if (b == 0) return OMNIPQ_OK;
@@ -1937,7 +1943,8 @@ extern "C" int omnipq_bn_finalize_relu(long long P, int C, double count, const d
 // THIS rank's totals (single process); under a process group take the gradients before the all-reduce.
 extern "C" int omnipq_bn_bwd_apply_fused(long long P, int C, double total_positions, const void *dX, const void *Y,
                                          const float *a, const float *b, const float *mean, const float *invstd,
-                                         const double *sums, void *dY, float *dbeta_dgamma, void *stream) {
+                                         const double *sums, void *dY, float *dbeta_dgamma, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (P < 0 || C <= 0 || (C % 8) || C > 4096) return OMNIPQ_EINVAL;
   if (!dX || !Y || !a || !b || !mean || !invstd || !sums || !dY) return OMNIPQ_EINVAL;
   const long long chunks = P * (C / 8);

@@ -107,7 +107,8 @@ __global__ void xyz_bwd_kernel(int C, const e16_t *__restrict__ W0, int ldw, con
 using namespace omnipq;
 
 // X0 bf16 [P][ldx] (columns 0..2 = the grouped, normalised coordinates; ldx % 4 == 0) -> mom double[12] = (S1[3], M2[3][3])
-extern "C" int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, double *mom, void *stream) {
+extern "C" int omnipq_sa_xyz_moments(long long P, const void *X0, int ldx, double *mom, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);            // the row plan is an ARGUMENT of the call (no ambient state)
   if (P < 0 || !mom || (ldx % 4) || ldx < 3) return OMNIPQ_EINVAL;
   OMNIPQ_HIP(hipMemsetAsync(mom, 0, 12 * sizeof(double), (hipStream_t)stream));
   if (P == 0) return OMNIPQ_OK;

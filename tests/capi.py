@@ -41,13 +41,26 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def call(name, *args):
+def plan_aware():
+    """Entry points of include/omnipq_sa.h that take `const omnipq_row_plan *plan` (the argument before the stream)."""
+    text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(INCLUDE, "omnipq_sa.h")).read(), flags=re.S)
+    return frozenset(m.group(1) for m in re.finditer(r"\b(omnipq_\w+)\s*\(([^;{}()]*)\)\s*;", text)
+                     if "omnipq_row_plan *plan" in m.group(2))
+
+
+PLAN_AWARE = plan_aware()
+
+
+def call(name, *args, plan=None):
+    """plan: a ctypes pointer to an omnipq_row_plan for the plan-aware entry points (None = every row)"""
+    if name in PLAN_AWARE:
+        args = args + (plan,)
     rc = getattr(lib(), name)(*args, stream())
     return rc
 
 
-def ok(name, *args):
-    rc = call(name, *args)
+def ok(name, *args, plan=None):
+    rc = call(name, *args, plan=plan)
     assert rc == 0, f"{name} -> {rc}: {lib().omnipq_error_string(rc).decode()}"
 
 

@@ -74,9 +74,9 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert lib.omnipq_attn_fwd(8, 8, 256, 256, 36, p, p, p, p, strides, p, f(0.1), null, 0, null) == EINVAL   # no seed
     assert lib.omnipq_attn_fwd(64, 16, 4096, 4096, 36, p, p, p, p, strides, p, f(0.0), null, 0, null) == ETOOLARGE
     # GEMMs: contraction length must be a multiple of the K step, leading dimensions of 8
-    assert lib.omnipq_gemm_nt_e16(128, 128, 33, p, 40, p, 40, p, 128, null) == EINVAL
-    assert lib.omnipq_gemm_nt_e16_stats(128, 128, 32, p, 32, p, 32, p, 128, null, null, null, null) == EINVAL  # no sums
-    assert lib.omnipq_gemm_tn_e16(100, 128, 64, p, 100, p, 128, p, p, null) == EINVAL                          # M % 8
+    assert lib.omnipq_gemm_nt_e16(128, 128, 33, p, 40, p, 40, p, 128, null, null) == EINVAL
+    assert lib.omnipq_gemm_nt_e16_stats(128, 128, 32, p, 32, p, 32, p, 128, null, null, null, null, null) == EINVAL  # no sums
+    assert lib.omnipq_gemm_tn_e16(100, 128, 64, p, 100, p, 128, p, p, null, null) == EINVAL                      # M % 8
     lib.omnipq_gemm_nt_stats_workspace_floats.restype = ll
     assert lib.omnipq_gemm_nt_stats_workspace_floats(64 * 128, 256) == 0
     assert lib.omnipq_gemm_nt_stats_workspace_floats(64 * 128 + 1, 256) == 65 * 2 * 256
@@ -95,6 +95,6 @@ def test_argument_validation_needs_no_gpu(built_lib):
     flags = (ctypes.c_int * 73)()
     assert lib.omnipq_sum_of_means(73, ptrs, ones, ones, flags, p, null) == EINVAL
     # zero-sized problems are no-ops that succeed without a device
-    assert lib.omnipq_gemm_nt_e16(0, 128, 32, p, 32, p, 32, p, 128, null) == 0
+    assert lib.omnipq_gemm_nt_e16(0, 128, 32, p, 32, p, 32, p, 128, null, null) == 0
     assert lib.omnipq_interp_rows(0, 10, 5, 64, p, p, p, p, 64, 0, null) == 0
     assert lib.omnipq_relu_dropout(ll(0), p, f(0.0), null, 0, null) == 0

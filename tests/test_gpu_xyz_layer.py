@@ -133,9 +133,9 @@ def test_data_gradient_sums_weight_gradient_above_and_first_layer_weight_gradien
 def test_argument_validation():
     lib = capi.lib()
     p, null = ctypes.c_void_p(0x1000), ctypes.c_void_p(0)
-    assert lib.omnipq_sa_xyz_moments(ctypes.c_longlong(100), p, 6, p, null) == 10001                # ldx % 4
+    assert lib.omnipq_sa_xyz_moments(ctypes.c_longlong(100), p, 6, p, null, null) == 10001                # ldx % 4
     assert lib.omnipq_sa_xyz_stats(128, p, 32, null, p, null) == 10001
     # the generated-operand GEMMs only exist on the many-tile path
-    assert lib.omnipq_gemm_nt_e16_xyz_bnbwd(4096, 128, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null) == 10001
-    assert lib.omnipq_gemm_nt_e16_xyz_bnbwd(128 * 70, 320, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null) == 10001
-    assert lib.omnipq_gemm_tn_e16_xyz_affine(128, 128, 9000, p, 128, p, 8, null, 32, p, p, p, p, null) == 10001
+    assert lib.omnipq_gemm_nt_e16_xyz_bnbwd(4096, 128, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null, null) == 10001
+    assert lib.omnipq_gemm_nt_e16_xyz_bnbwd(128 * 70, 320, 128, p, 128, p, 128, p, 8, p, 32, p, p, p, p, p, p, null, null) == 10001
+    assert lib.omnipq_gemm_tn_e16_xyz_affine(128, 128, 9000, p, 128, p, 8, null, 32, p, p, p, p, null, null) == 10001

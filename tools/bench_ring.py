@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """NEGATIVE RESULT, kept as a probe (round 5).  Needs tools/probe/gemm_nt_ring.patch applied to csrc/gemm_bf16.hip +
-include/omnipq_sa.h (`git apply tools/probe/gemm_nt_ring.patch`), which is NOT part of the product library: the ring is
+include/omnipq_sa.h (`git apply tools/probe/gemm_nt_ring.patch` on commit 7329141: the entry points have since gained the
+`plan` argument, so the patch needs a rebase on a later tree), which is NOT part of the product library: the ring is
 bit-identical and never faster (profiles/r05_nt_ring_ab.txt, r05_nt_ring_phase_trace.txt).
 
 A/B of the LDS-DMA ring variants of the NT GEMMs (csrc/gemm_bf16.hip: RING) against the register-staged tiles on the

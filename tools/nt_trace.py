@@ -62,7 +62,7 @@ def forward_pool(M, N, K, S):
         sums.zero_()
         rc = lib.omnipq_gemm_nt_e16_bnaffine_pool(M, N, K, P(Y), K, P(fin), ctypes.c_double(M), P(gamma), P(beta), ctypes.c_float(1e-5),
             ctypes.c_float(0.1), P(None), P(None), P(None), P(outs[0]), P(outs[1]), P(outs[2]), P(outs[3]), P(W), K, P(C), N, P(None),
-            P(sums), P(ws), S, P(ext16[0]), P(ext16[1]), P(ext8[0]), P(ext8[1]), st)
+            P(sums), P(ws), S, P(ext16[0]), P(ext16[1]), P(ext8[0]), P(ext8[1]), None, st)
         assert rc == 0, rc
     report(f"bnaffine_pool {M} x {N} x {K}, balls of {S}", timed(run), (M // 128) * ((N + 127) // 128))
 
@@ -76,7 +76,7 @@ def dgrad(M, N, K):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
         sums.zero_()
-        rc = lib.omnipq_gemm_nt_e16_bnbwd(M, N, K, P(dY), K, P(Wt), K, P(C), N, P(Y), P(a), P(b), P(mu), P(isd), P(sums), P(ws), st)
+        rc = lib.omnipq_gemm_nt_e16_bnbwd(M, N, K, P(dY), K, P(Wt), K, P(C), N, P(Y), P(a), P(b), P(mu), P(isd), P(sums), P(ws), None, st)
         assert rc == 0, rc
     report(f"bnbwd {M} x {N} x {K}", timed(run), (M // 128) * ((N + 127) // 128))
 

@@ -32,10 +32,10 @@ def probe(P, C, K):
 
     def nt(stream):
         return lib.omnipq_gemm_nt_e16_bnbwd(P, K, C, _p(dY), C, _p(Wt), C, _p(dX), K, _p(Y1), _p(a), _p(b), _p(mu), _p(isd),
-                                             _p(sums), _p(ws1), ctypes.c_void_p(stream.cuda_stream))
+                                             _p(sums), _p(ws1), None, ctypes.c_void_p(stream.cuda_stream))
 
     def tn(stream):
-        return lib.omnipq_gemm_tn_e16_affine(C, K, P, _p(dY), C, _p(Y1), K, _p(a), _p(b), _p(dW), _p(ws2), _p(None),
+        return lib.omnipq_gemm_tn_e16_affine(C, K, P, _p(dY), C, _p(Y1), K, _p(a), _p(b), _p(dW), _p(ws2), _p(None), None,
                                               ctypes.c_void_p(stream.cuda_stream))
 
     def timed(fn, iters=10):
