@@ -29,7 +29,7 @@ namespace omnipq {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ATT_DMAX = 48;        // padded head dim of the q.k contraction
-constexpr int ATT_PITCH = 52;       // LDS row pitch (bf16) of a staged [32 tokens][<=48 channels] block
+constexpr int ATT_PITCH = 56;       // LDS row pitch (bf16) of a staged [32 tokens][<=48 channels] block: 112 bytes
 
 struct AttnArgs {
   int N, H, L, S, D;
@@ -63,13 +63,33 @@ __device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) { ret
 // row of accumulator register r for a lane in half h of the 32x32 MFMA result
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// Fragment with lane = token, k = channels [16 j + 8 h, +8): two 8-byte loads, zero where channel >= D
-// (D % 4 == 0) or the token is out of range.
-__device__ __forceinline__ e16x8 frag_tok(const e16_t *row, int j, int h, int D, bool valid) {
+// ---- memory access: buffer loads -----------------------------------------------------------------------------------------
+// Every global read of these kernels goes through a buffer descriptor of the (batch, head) slice it belongs to (base =
+// tensor + n * batch stride + head * D; num_records = the bytes up to the last token's last channel).  A lane's address is a
+// 32-bit byte offset in a VGPR; a token past the end of the tensor is past num_records and the hardware returns zeros --
+// so the loops carry no predicates, no exec-mask juggling and no 64-bit address arithmetic (they were half of the
+// instructions the loops issued).  The pieces are 8 bytes = 4 channels and D % 4 == 0, so a piece never straddles the
+// slice's end.  Descriptors are built from wave-uniform values only (blockIdx, readfirstlane'd wave id, loop counters).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr unsigned ATT_OOB = 0x80000000u;      // a byte offset past every descriptor's num_records: the load returns zeros
+
+// descriptor of tokens [t0, T) of a slice whose token stride is s_tok elements (nothing if t0 >= T)
+__device__ __forceinline__ rsrc_t att_rsrc(const e16_t *slice, long long s_tok, int t0, int T, int D) {
+  const long long bytes = t0 < T ? ((long long)(T - 1 - t0) * s_tok + D) * 2 : 0;
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(slice + (long long)t0 * s_tok), (short)0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ v2u att_load8(rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
+}
+
+// Loop-invariant operand fragment (prologues only): lane = token at byte offset `tok_off` of the descriptor, k = channels
+// [16 j + 8 h, +8), EXACTLY zero where channel >= D (these zeros are what makes the padding of the streamed side harmless).
+__device__ __forceinline__ e16x8 frag_tok(rsrc_t r, unsigned tok_off, int j, int h, int D) {
   const int d0 = 16 * j + 8 * h;
-  uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-  if (valid && d0 < D) lo = *reinterpret_cast<const uint2 *>(row + d0);
-  if (valid && d0 + 4 < D) hi = *reinterpret_cast<const uint2 *>(row + d0 + 4);
+  const v2u lo = att_load8(r, d0 < D ? tok_off + 2u * d0 : ATT_OOB);
+  const v2u hi = att_load8(r, d0 + 4 < D ? tok_off + 2u * d0 + 8u : ATT_OOB);
   uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return __builtin_bit_cast(e16x8, v);
 }
@@ -94,16 +114,18 @@ __device__ __forceinline__ e16x8 pack_regs(const float *p, int j2) {
   return f;
 }
 
-// Staging of one wave's [32 tokens][D channels] block into its private LDS area in 8-byte pieces, split
-// into the global loads (issued one iteration ahead, results parked in registers) and the LDS stores.
-// A lane owns pieces id = lane + 64 i, i < 6 (32 * 48/4 = 384 pieces at most); token / offset per piece
-// are loop invariants.
+// Staging of one wave's [32 tokens][D channels] block into its private LDS area in 8-byte pieces, split into the global
+// loads (issued one iteration ahead, results parked in registers) and the LDS stores.  Consecutive lanes take consecutive
+// pieces of a token's row (id = lane + 64 i, i < 6: 32 * 48/4 = 384 pieces at most), so one load instruction touches the
+// ~8 cache lines of ~7 tokens -- the fragments the MFMAs need (lane = token) are then read from LDS, 16 bytes per lane,
+// instead of from memory with 32 cache lines per instruction (that access pattern kept the CU's address unit busy for most
+// of the loop).  A staged area is [33][ATT_PITCH]: lanes without a piece load zeros (offset ATT_OOB) and park them in the
+// spare row 32; channels [D, ATT_PITCH) of the rows are zeroed once by stage_clear and never written again.
 constexpr int ATT_NP = 6;
+constexpr int ATT_AREA = 33 * ATT_PITCH;      // elements of one staged area
 struct StagePlan {
-  int tok[ATT_NP];        // token within the block, or -1 if the lane has no such piece
-  int off[ATT_NP];        // channel offset (elements)
-  long long rel[ATT_NP];  // tok * token stride + off: the lane's part of the address; the block's part (t0 * stride) is
-                          // wave-uniform, so a load costs one 64-bit add instead of a 64-bit multiply per piece
+  unsigned voff[ATT_NP];     // byte offset of the lane's piece within the block's descriptor, or ATT_OOB
+  int lds[ATT_NP];           // element offset within the staged area
 };
 
 __device__ __forceinline__ StagePlan stage_plan(int D, int lane, long long s_tok) {
@@ -112,34 +134,39 @@ __device__ __forceinline__ StagePlan stage_plan(int D, int lane, long long s_tok
 #pragma unroll
   for (int i = 0; i < ATT_NP; ++i) {
     const int id = lane + 64 * i;
-    const int tok = id / ppr;
-    sp.tok[i] = id < 32 * ppr ? tok : -1;
-    sp.off[i] = (id - tok * ppr) * 4;
-    sp.rel[i] = (long long)tok * s_tok + sp.off[i];
+    const int tok = id / ppr, off = (id - tok * ppr) * 4;
+    const bool has = id < 32 * ppr;
+    sp.voff[i] = has ? (unsigned)(tok * (int)s_tok + off) * 2u : ATT_OOB;
+    sp.lds[i] = has ? tok * ATT_PITCH + off : 32 * ATT_PITCH;
   }
   return sp;
 }
 
 struct StageRegs {
-  uint2 v[ATT_NP];
+  v2u v[ATT_NP];
 };
 
-__device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, const e16_t *base, long long s_tok, int t0,
-                                                int T) {
+__device__ __forceinline__ StageRegs stage_load(const StagePlan &sp, rsrc_t block) {
   StageRegs r;
 #pragma unroll
-  for (int i = 0; i < ATT_NP; ++i) {
-    r.v[i] = make_uint2(0u, 0u);
-    if (sp.tok[i] >= 0 && t0 + sp.tok[i] < T)
-      r.v[i] = *reinterpret_cast<const uint2 *>(base + (long long)t0 * s_tok + sp.rel[i]);
-  }
+  for (int i = 0; i < ATT_NP; ++i) r.v[i] = att_load8(block, sp.voff[i]);
   return r;
 }
 
 __device__ __forceinline__ void stage_store(const StagePlan &sp, const StageRegs &r, e16_t *lds) {
 #pragma unroll
-  for (int i = 0; i < ATT_NP; ++i)
-    if (sp.tok[i] >= 0) *reinterpret_cast<uint2 *>(lds + sp.tok[i] * ATT_PITCH + sp.off[i]) = r.v[i];
+  for (int i = 0; i < ATT_NP; ++i) *reinterpret_cast<v2u *>(lds + sp.lds[i]) = r.v[i];
+}
+
+// zero `areas` consecutive staged areas (one wave, 8 bytes per lane and store)
+__device__ __forceinline__ void stage_clear(e16_t *lds, int areas, int lane) {
+  for (int o = lane * 4; o < areas * ATT_AREA; o += 256) *reinterpret_cast<v2u *>(lds + o) = v2u{0u, 0u};
+}
+
+// Fragment with lane = token `row` of a staged area, k = channels [16 j + 8 h, +8): one 16-byte read (ATT_PITCH * 2 bytes
+// is a multiple of 16; 16 lanes x 28-dword row stride cover the 64 banks exactly once)
+__device__ __forceinline__ e16x8 frag_lds_tok(const e16_t *lds, int row, int j, int h) {
+  return *reinterpret_cast<const e16x8 *>(lds + row * ATT_PITCH + 16 * j + 8 * h);
 }
 
 // Operand with lane = channel (tile t: channel 32 t + lane&31), contraction index = accumulator row order of
@@ -177,13 +204,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const e16_t *
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
   const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
-  const bool qv = q < g.L;
   const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
-  e16_t *vs = reinterpret_cast<e16_t *>(smem) + wave * 32 * ATT_PITCH;
+  e16_t *ks = reinterpret_cast<e16_t *>(smem) + wave * 2 * ATT_AREA, *vs = ks + ATT_AREA;     // this wave's staged K / V block
+  stage_clear(ks, 2, lane);
 
   e16x8 qf[3];
+  {
+    const rsrc_t rq = att_rsrc(Qb, g.q_sl, q0, g.L, g.D);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) qf[j] = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
+    for (int j = 0; j < 3; ++j) qf[j] = frag_tok(rq, (unsigned)(ql * (int)g.q_sl) * 2u, j, h, g.D);
+  }
 
   const unsigned seed = drop_seed(g);
   float m = -1e30f, lsum = 0.f;
@@ -194,41 +224,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const e16_t *
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
-  const StagePlan sp = stage_plan(g.D, lane, g.v_sl);
-  const e16_t *Kl = Kb + (long long)ql * g.k_sl;          // the lane's key row of block 0 (blocks add a uniform offset)
-  // software pipeline: the K fragments and the V block of iteration it+1 are loaded while it computes
-  e16x8 kfn[3];
-  StageRegs vn;
-  {
-    const int k0 = wave * 32, key = k0 + ql;
-    const bool kv = key < g.S;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kl + (long long)k0 * g.k_sl, j, h, g.D, kv);
-    vn = stage_load(sp, Vb, g.v_sl, k0, g.S);
-  }
+  const StagePlan spk = stage_plan(g.D, lane, g.k_sl), spv = stage_plan(g.D, lane, g.v_sl);
+  // software pipeline: the K and V blocks of iteration it+1 are loaded (into registers) while it computes
+  StageRegs kn = stage_load(spk, att_rsrc(Kb, g.k_sl, wave * 32, g.S, g.D));
+  StageRegs vn = stage_load(spv, att_rsrc(Vb, g.v_sl, wave * 32, g.S, g.D));
   for (int it = 0; it < iters; ++it) {
     const int k0 = (it * 4 + wave) * 32;
-    e16x8 kf[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) kf[j] = kfn[j];
-    const StageRegs vc = vn;
+    const StageRegs kc = kn, vc = vn;
     if (it + 1 < iters) {
-      const int k1 = k0 + 128, key = k1 + ql;
-      const bool kv = key < g.S;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) kfn[j] = frag_tok(Kl + (long long)k1 * g.k_sl, j, h, g.D, kv);
-      vn = stage_load(sp, Vb, g.v_sl, k1, g.S);
+      kn = stage_load(spk, att_rsrc(Kb, g.k_sl, k0 + 128, g.S, g.D));
+      vn = stage_load(spv, att_rsrc(Vb, g.v_sl, k0 + 128, g.S, g.D));
     }
-    // (the staging area `vs` is private to this wave and a wave's LDS instructions execute in program order: the previous
+    // (the staging areas are private to this wave and a wave's LDS instructions execute in program order: the previous
     // block's reads are ahead of these writes in the queue -- no workgroup barrier, the four waves are free to drift apart)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    stage_store(sp, vc, vs);
+    stage_store(spk, kc, ks);
+    stage_store(spv, vc, vs);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) st = MFMA(kf[j], qf[j], st);      // S^T: rows = keys, cols = queries
+    for (int j = 0; j < 3; ++j) st = MFMA(frag_lds_tok(ks, ql, j, h), qf[j], st);      // S^T: rows = keys, cols = queries
     float p[16], bm = -1e30f;
     const bool full = k0 + 32 <= g.S;                       // wave-uniform: no key of this block is out of range
     if (full) {
@@ -333,15 +352,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_
   const bool qv = q < g.L;
   const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
   const e16_t *Ob = O + n * g.o_sn + hd * g.D, *dOb = dO + n * g.o_sn + hd * g.D;
-  e16_t *ks = reinterpret_cast<e16_t *>(smem) + wave * 32 * ATT_PITCH;
+  e16_t *ks = reinterpret_cast<e16_t *>(smem) + wave * 2 * ATT_AREA, *vs = ks + ATT_AREA;     // this wave's staged K / V block
+  stage_clear(ks, 2, lane);
 
   e16x8 qf[3], dof[3];
   float dl = 0.f;
+  {
+    const rsrc_t rq = att_rsrc(Qb, g.q_sl, q0, g.L, g.D), ro = att_rsrc(Ob, g.o_sl, q0, g.L, g.D);
+    const rsrc_t rdo = att_rsrc(dOb, g.o_sl, q0, g.L, g.D);
+    const unsigned qoff = (unsigned)(ql * (int)g.q_sl) * 2u, ooff = (unsigned)(ql * (int)g.o_sl) * 2u;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    qf[j] = frag_tok(Qb + (long long)(qv ? q : 0) * g.q_sl, j, h, g.D, qv);
-    dof[j] = frag_tok(dOb + (long long)(qv ? q : 0) * g.o_sl, j, h, g.D, qv);
-    dl += frag_dot(dof[j], frag_tok(Ob + (long long)(qv ? q : 0) * g.o_sl, j, h, g.D, qv));
+    for (int j = 0; j < 3; ++j) {
+      qf[j] = frag_tok(rq, qoff, j, h, g.D);
+      dof[j] = frag_tok(rdo, ooff, j, h, g.D);
+      dl += frag_dot(dof[j], frag_tok(ro, ooff, j, h, g.D));
+    }
   }
   dl += xor32(dl);
   if (wave == 0 && h == 0 && qv) delta[(long long)nh * g.L + q] = dl;
@@ -355,60 +380,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nkb = (g.S + 31) >> 5, iters = (nkb + 3) >> 2;
-  const StagePlan sp = stage_plan(g.D, lane, g.k_sl);
-  const e16_t *Kl = Kb + (long long)ql * g.k_sl, *Vl = Vb + (long long)ql * g.v_sl;
-  e16x8 kfn[3], vfn[3];
-  StageRegs kn;
-  {
-    const int k0 = wave * 32, key = k0 + ql;
-    const bool kv = key < g.S;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      kfn[j] = frag_tok(Kl + (long long)k0 * g.k_sl, j, h, g.D, kv);
-      vfn[j] = frag_tok(Vl + (long long)k0 * g.v_sl, j, h, g.D, kv);
-    }
-    kn = stage_load(sp, Kb, g.k_sl, k0, g.S);
-  }
+  const StagePlan spk = stage_plan(g.D, lane, g.k_sl), spv = stage_plan(g.D, lane, g.v_sl);
+  StageRegs kn = stage_load(spk, att_rsrc(Kb, g.k_sl, wave * 32, g.S, g.D));
+  StageRegs vn = stage_load(spv, att_rsrc(Vb, g.v_sl, wave * 32, g.S, g.D));
   for (int it = 0; it < iters; ++it) {
     const int k0 = (it * 4 + wave) * 32;
-    e16x8 kf[3], vf[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) kf[j] = kfn[j], vf[j] = vfn[j];
-    const StageRegs kc = kn;
+    const StageRegs kc = kn, vc = vn;
     if (it + 1 < iters) {
-      const int k1 = k0 + 128, key = k1 + ql;
-      const bool kv = key < g.S;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        kfn[j] = frag_tok(Kl + (long long)k1 * g.k_sl, j, h, g.D, kv);
-        vfn[j] = frag_tok(Vl + (long long)k1 * g.v_sl, j, h, g.D, kv);
-      }
-      kn = stage_load(sp, Kb, g.k_sl, k1, g.S);
+      kn = stage_load(spk, att_rsrc(Kb, g.k_sl, k0 + 128, g.S, g.D));
+      vn = stage_load(spv, att_rsrc(Vb, g.v_sl, k0 + 128, g.S, g.D));
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // wave-private staging area: see attn_fwd_kernel
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // wave-private staging areas: see attn_fwd_kernel
     __builtin_amdgcn_wave_barrier();
-    stage_store(sp, kc, ks);
+    stage_store(spk, kc, ks);
+    stage_store(spv, vc, vs);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      st = MFMA(kf[j], qf[j], st);                          // S^T
-      dp = MFMA(vf[j], dof[j], dp);                         // (dO V^T)^T
+      st = MFMA(frag_lds_tok(ks, ql, j, h), qf[j], st);      // S^T
+      dp = MFMA(frag_lds_tok(vs, ql, j, h), dof[j], dp);     // (dO V^T)^T
     }
     float ds[16];
     const unsigned base = ((unsigned)nh * (unsigned)g.L + (unsigned)q) * (unsigned)g.S + (unsigned)k0 + seed + 4u * h;
     const bool full = q0 + 32 <= g.L && k0 + 32 <= g.S;    // wave-uniform: nothing of this tile is out of range
+    // (the wave-uniform cases are whole loops, not branches inside one: sixteen independent chains for the scheduler)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = fast_exp2(__builtin_fmaf(st[r], g.scale_log2, -lse));
-      if (!full) p = (qv && k0 + acc_row(r, h) < g.S) ? p : 0.f;
-      float d = dp[r];
-      if (g.drop_thresh) d = drop_hash_mix(base + (unsigned)acc_row(r, 0)) >= g.drop_thresh ? d * g.keep_inv : 0.f;
-      ds[r] = p * (d - dl);
+    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(st[r], g.scale_log2, -lse));
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] = (qv && k0 + acc_row(r, h) < g.S) ? ds[r] : 0.f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if (g.drop_thresh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dp[r] = drop_hash_mix(base + (unsigned)acc_row(r, 0)) >= g.drop_thresh ? dp[r] * g.keep_inv : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] *= dp[r] - dl;
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
       const e16x8 df = pack_regs(ds, j2);
@@ -436,36 +448,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_
 // ---- backward, dK and dV --------------------------------------------------------------------------------
 // grid (ceil(S/128), N*H).  Each WAVE owns 32 keys and walks over all query blocks, so there is nothing to
 // merge; the four waves of a workgroup share the staged Q / dO block and the per-query lse / delta.
-__device__ __forceinline__ e16x8 frag_lds_tok(const e16_t *lds, int row, int j, int h, int D) {
-  const int d0 = 16 * j + 8 * h;
-  uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-  if (d0 < D) lo = *reinterpret_cast<const uint2 *>(lds + row * ATT_PITCH + d0);
-  if (d0 + 4 < D) hi = *reinterpret_cast<const uint2 *>(lds + row * ATT_PITCH + d0 + 4);
-  uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-  return __builtin_bit_cast(e16x8, v);
-}
-
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const e16_t *__restrict__ Q,
                                                            const e16_t *__restrict__ K, const e16_t *__restrict__ V,
                                                            const e16_t *__restrict__ dO, const float *__restrict__ lse2,
                                                            const float *__restrict__ delta, e16_t *__restrict__ dK,
                                                            long long dk_sl, long long dk_sn, e16_t *__restrict__ dV,
                                                            long long dv_sl, long long dv_sn) {
-  __shared__ __attribute__((aligned(16))) e16_t qs[32 * ATT_PITCH];
-  __shared__ __attribute__((aligned(16))) e16_t dos[32 * ATT_PITCH];
+  __shared__ __attribute__((aligned(16))) e16_t qs[2 * ATT_AREA];       // the staged Q block, then the dO block
   __shared__ float rowv[64];                                               // [0,32) lse2, [32,64) delta
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, kl = lane & 31;
   const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
-  const int k0 = ((int)blockIdx.x * 4 + wave) * 32, key = k0 + kl;
+  const int kb0 = (int)blockIdx.x * 128, k0 = kb0 + wave * 32, key = k0 + kl;
   const bool kv = key < g.S;
   const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
   const e16_t *dOb = dO + n * g.o_sn + hd * g.D;
+  e16_t *dos = qs + ATT_AREA;
+  for (int o = tid * 4; o < 2 * ATT_AREA; o += 1024) *reinterpret_cast<v2u *>(qs + o) = v2u{0u, 0u};   // the pad channels stay zero
 
   e16x8 kf[3], vf[3];
+  {
+    const rsrc_t rk = att_rsrc(Kb, g.k_sl, kb0, g.S, g.D), rv = att_rsrc(Vb, g.v_sl, kb0, g.S, g.D);
+    const unsigned koff = (unsigned)((wave * 32 + kl) * (int)g.k_sl) * 2u, voff = (unsigned)((wave * 32 + kl) * (int)g.v_sl) * 2u;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    kf[j] = frag_tok(Kb + (long long)(kv ? key : 0) * g.k_sl, j, h, g.D, kv);
-    vf[j] = frag_tok(Vb + (long long)(kv ? key : 0) * g.v_sl, j, h, g.D, kv);
+    for (int j = 0; j < 3; ++j) {
+      kf[j] = frag_tok(rk, koff, j, h, g.D);
+      vf[j] = frag_tok(rv, voff, j, h, g.D);
+    }
   }
   const unsigned seed = drop_seed(g);
   f32x16 accv[2], acck[2];
@@ -474,48 +482,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const e1
 #pragma unroll
     for (int r = 0; r < 16; ++r) accv[t][r] = acck[t][r] = 0.f;
 
-  // cooperative staging: 256 threads, pieces id = tid + 256 i (i < 2) of the [32][D] block
+  // cooperative staging: 256 threads, pieces id = tid + 256 i (i < 2) of the [32][D] block; threads without a piece load
+  // zeros and park them in the spare row
   const int ppr = g.D >> 2;
-  int ptok[2], poff[2];
-  long long qrel[2], drel[2];                               // the thread's part of the Q / dO addresses
+  unsigned qvo[2], dvo[2];                                  // byte offsets of the thread's pieces within a block's descriptor
+  int plds[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int id = tid + 256 * i, tok = id / ppr;
-    ptok[i] = id < 32 * ppr ? tok : -1;
-    poff[i] = (id - tok * ppr) * 4;
-    qrel[i] = (long long)tok * g.q_sl + poff[i];
-    drel[i] = (long long)tok * g.o_sl + poff[i];
+    const int id = tid + 256 * i, tok = id / ppr, off = (id - tok * ppr) * 4;
+    const bool has = id < 32 * ppr;
+    qvo[i] = has ? (unsigned)(tok * (int)g.q_sl + off) * 2u : ATT_OOB;
+    dvo[i] = has ? (unsigned)(tok * (int)g.o_sl + off) * 2u : ATT_OOB;
+    plds[i] = has ? tok * ATT_PITCH + off : 32 * ATT_PITCH;
   }
   const float *rowsrc = (tid < 32 ? lse2 : delta) + (long long)nh * g.L;
-  uint2 qn[2], dn[2];
+  v2u qn[2], dn[2];
   float rown = 0.f;
   auto fetch = [&](int q0) {
+    const rsrc_t rq = att_rsrc(Qb, g.q_sl, q0, g.L, g.D), rdo = att_rsrc(dOb, g.o_sl, q0, g.L, g.D);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      qn[i] = dn[i] = make_uint2(0u, 0u);
-      if (ptok[i] >= 0 && q0 + ptok[i] < g.L) {
-        qn[i] = *reinterpret_cast<const uint2 *>(Qb + (long long)q0 * g.q_sl + qrel[i]);
-        dn[i] = *reinterpret_cast<const uint2 *>(dOb + (long long)q0 * g.o_sl + drel[i]);
-      }
+      qn[i] = att_load8(rq, qvo[i]);
+      dn[i] = att_load8(rdo, dvo[i]);
     }
     rown = (tid < 64 && q0 + (tid & 31) < g.L) ? rowsrc[q0 + (tid & 31)] : 0.f;
   };
   fetch(0);
   const int nqb = (g.L + 31) >> 5;
+  __syncthreads();                                          // the areas are cleared
   for (int it = 0; it < nqb; ++it) {
     const int q0 = it * 32;
-    uint2 qc[2], dc[2];
+    v2u qc[2], dc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) qc[i] = qn[i], dc[i] = dn[i];
     const float rowc = rown;
     if (it + 1 < nqb) fetch(q0 + 32);
     __syncthreads();                                        // the previous block has been consumed
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (ptok[i] >= 0) {
-        *reinterpret_cast<uint2 *>(qs + ptok[i] * ATT_PITCH + poff[i]) = qc[i];
-        *reinterpret_cast<uint2 *>(dos + ptok[i] * ATT_PITCH + poff[i]) = dc[i];
-      }
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<v2u *>(qs + plds[i]) = qc[i];
+      *reinterpret_cast<v2u *>(dos + plds[i]) = dc[i];
+    }
     if (tid < 64) rowv[tid] = rowc;
     __syncthreads();
     f32x16 s, dp;
@@ -523,28 +530,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const e1
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      s = MFMA(frag_lds_tok(qs, kl, j, h, g.D), kf[j], s);        // S: rows = queries, cols = keys
-      dp = MFMA(frag_lds_tok(dos, kl, j, h, g.D), vf[j], dp);     // dO V^T
+      s = MFMA(frag_lds_tok(qs, kl, j, h), kf[j], s);             // S: rows = queries, cols = keys
+      dp = MFMA(frag_lds_tok(dos, kl, j, h), vf[j], dp);          // dO V^T
     }
     float pt[16], ds[16];
     const bool full = q0 + 32 <= g.L && k0 + 32 <= g.S;    // wave-uniform
     // element index + seed: the lane's part once, acc_row(r, 0) * S is wave-uniform
     const unsigned hbase = ((unsigned)nh * (unsigned)g.L + (unsigned)(q0 + 4 * h)) * (unsigned)g.S + (unsigned)key + seed;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, h);
-      float p = fast_exp2(__builtin_fmaf(s[r], g.scale_log2, -rowv[row]));
-      if (!full) p = (kv && q0 + row < g.L) ? p : 0.f;
-      float d = dp[r];
-      float pk = p;
-      if (g.drop_thresh) {
-        const bool keep = drop_hash_mix(hbase + (unsigned)acc_row(r, 0) * (unsigned)g.S) >= g.drop_thresh;
-        d = keep ? d * g.keep_inv : 0.f;
-        pk = keep ? p * g.keep_inv : 0.f;
-      }
-      pt[r] = pk;
-      ds[r] = p * (d - rowv[32 + row]);
+    for (int r = 0; r < 16; ++r) pt[r] = fast_exp2(__builtin_fmaf(s[r], g.scale_log2, -rowv[acc_row(r, h)]));
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pt[r] = (kv && q0 + acc_row(r, h) < g.L) ? pt[r] : 0.f;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = pt[r];
+    if (g.drop_thresh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float km = drop_hash_mix(hbase + (unsigned)acc_row(r, 0) * (unsigned)g.S) >= g.drop_thresh ? g.keep_inv : 0.f;
+        dp[r] *= km;
+        pt[r] *= km;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] *= dp[r] - rowv[32 + acc_row(r, h)];
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
       const e16x8 pf = pack_regs(pt, j2), df = pack_regs(ds, j2);

@@ -52,6 +52,7 @@ __device__ __forceinline__ uint4 ldg16(const e16_t *p) { return *reinterpret_cas
 #ifdef OMNIPQ_NT_TRACE
 // Debug build only (tools/nt_trace.py): cycle stamps of a workgroup's phases, thread 0 of the first 4096 workgroups.
 __device__ long long g_nt_trace[4096 * 8];
+__device__ long long g_nt_real[4096 * 2];     // s_memrealtime (100 MHz, one base for the whole device) at slot 0 and slot 7
 __device__ __forceinline__ long long nt_now() {
   long long t;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
@@ -61,6 +62,10 @@ __device__ __forceinline__ long long nt_now() {
   {                                                                                       \
     const long long now_ = nt_now();                                                      \
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_nt_trace[blockIdx.x * 8 + (slot)] = now_; \
+    if ((slot) == 0 || (slot) == 7) {                                                     \
+      const long long real_ = (long long)__builtin_amdgcn_s_memrealtime();                \
+      if (threadIdx.x == 0 && blockIdx.x < 4096) g_nt_real[blockIdx.x * 2 + ((slot) == 7)] = real_; \
+    }                                                                                     \
   }
 #else
 #define NT_STAMP(slot)
@@ -854,6 +859,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pair_kernel(SmallProblem p0, S
 }  // namespace omnipq
 extern "C" int omnipq_debug_read_nt_trace(long long *host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(omnipq::g_nt_trace), sizeof(long long) * 4096 * 8);
+}
+extern "C" int omnipq_debug_read_nt_real(long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(omnipq::g_nt_real), sizeof(long long) * 4096 * 2);
 }
 namespace omnipq {
 #endif

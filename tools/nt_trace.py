@@ -31,12 +31,14 @@ def report(name, us, tiles):
     per_cycle = 1.0 / 2400.0                     # s_memtime ticks at the shader clock (2.4 GHz); every XCD has its own base
     life = (t[:, 7] - t[:, 0]).mean()
     print(f"{name}: {us:.0f} us, {tiles} tiles; a workgroup lives {life * per_cycle:.2f} us on average")
-    # when do workgroups start / end relative to the first start ON THEIR XCD (s_memtime bases differ per XCD: take the spread
-    # of starts within the tiles that share id % 8)
-    for x in range(2):
-        sel = t[x::8]
-        st, en = sel[:, 0] - sel[:, 0].min(), sel[:, 7] - sel[:, 0].min()
-        print(f"    xcd {x}: starts spread {st.max() * per_cycle:5.2f} us (median {np.median(st) * per_cycle:5.2f}), last end {en.max() * per_cycle:5.2f} us")
+    # when do workgroups start / end?  (s_memtime bases differ per CU; s_memrealtime: one 100 MHz clock for the device)
+    real = np.zeros(4096 * 2, dtype=np.int64)
+    assert lib.omnipq_debug_read_nt_real(real.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))) == 0
+    real = real.reshape(4096, 2)[:min(tiles, 4096)].astype(np.float64) * 0.01
+    st, en = real[:, 0] - real[:, 0].min(), real[:, 1] - real[:, 0].min()
+    q = np.percentile(st, [10, 50, 90])
+    print(f"    device clock: workgroup starts 10/50/90 % at {q[0]:5.2f} / {q[1]:5.2f} / {q[2]:5.2f} us, last start {st.max():5.2f} us; "
+          f"ends 10/50/90 % at {np.percentile(en, 10):5.2f} / {np.percentile(en, 50):5.2f} / {np.percentile(en, 90):5.2f}, last {en.max():5.2f} us")
     for i, ph in enumerate(PHASES[1:]):
         print(f"    {ph:24s} {d[:, i].mean() * per_cycle:6.2f} us   (median {np.median(d[:, i]) * per_cycle:5.2f})")
 

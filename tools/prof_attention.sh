@@ -5,6 +5,9 @@ for r in csv.DictReader(open("/tmp/pa/pa_kernel_trace.csv")):
     n=r["Kernel_Name"]
     if "attn" in n:
         d[(n.split("(")[0], r["Grid_Size_X"])].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
+cfg=["S=512 p=0","S=1024 p=0","S=512 p=.1","S=1024 p=.1"]
 for k,v in d.items():
-    v=sorted(v); print(k, len(v), "median %.1f us"%v[len(v)//2], "min %.1f"%v[0], "p25 %.1f p75 %.1f"%(v[len(v)//4], v[3*len(v)//4]))
+    n=len(v)//4 if "dkdv" not in k[0] else len(v)//2
+    for c in range(len(v)//n):
+        w=sorted(v[c*n:(c+1)*n]); print(k, "chunk",c, len(w), "median %.1f us"%w[len(w)//2], "min %.1f"%w[0])
 EOP
