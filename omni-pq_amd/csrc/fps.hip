@@ -77,6 +77,26 @@ __device__ __forceinline__ void wave_argmax(float &d2, unsigned &c) {
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
+// Granule traffic of a scene whose workgroups all sit on ONE XCD: served by that XCD's L2 instead of by memory.  The
+// agent-scope (sc1) stores and loads of the general path go out to the memory side because the eight L2s are not coherent
+// with each other; inside one XCD the L2 is the point of coherence, and only the reading CU's L1 has to be passed
+// (buffer_inv sc1 drops it: nothing else in this kernel uses the L1 between rounds).  0.62 instead of ~0.9 us per hand-off.
+__device__ __forceinline__ unsigned long long granule_load_l2(const gu64 *p) {
+  unsigned long long v;
+  asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void granule_store_l2(gu64 *p, unsigned long long v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+}
+// the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xFu;
+}
+constexpr unsigned kTagRound = 0x00FFFFFFu;     // tag = round | xcc id << 24 (rounds < 2^20)
+
 #ifdef OMNIPQ_FPS_TRACE
 // Debug build only (tools/probe): cycle stamps of the phases of rounds 1..16, thread 0 of block 0.
 __device__ long long g_fps_trace[16 * 8];
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     int n, int m, int bs_mask, int G, const float *__restrict__ dataset,
     float *__restrict__ temp, int *__restrict__ idxs,
     unsigned long long *__restrict__ slots,  // [2][scenes][5][G] {value, tag} granules (MULTI only)
-    int *__restrict__ err_word, int scene0, int spin_limit) {
+    int *__restrict__ err_word, int scene0, int spin_limit, int nscenes_multi) {
   constexpr int NW = THREADS / 64;
   // per-wave winners {d2, c (bits), x, y, z, pad}: one 16-byte + one 4-byte LDS access each way, read
   // UNCONDITIONALLY by every lane (slot = lane mod NW; duplicates are harmless in a max) -- predicated
@@ -134,10 +154,16 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
   constexpr int IDXBUF = 1024;
   __shared__ int s_idx[IDXBUF];
 
-  const int scene_local = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x;
-  const int g = MULTI ? (int)blockIdx.x % G : 0;
+  // MULTI: the G workgroups of a scene exchange their winners every round, so they sit on ONE XCD (one L2): workgroups are
+  // dealt to the eight XCDs round-robin by blockIdx, XCD x = blockIdx % 8 gets the scenes x, x + 8, ... and the k-th
+  // workgroup on it (k = blockIdx / 8) is part k % G of its scene number k / G.  Grid = 8 * G * ceil(scenes / 8); the
+  // workgroups of scenes past the end leave at once.
+  const int xk = (int)blockIdx.x >> 3;
+  const int scene_local = MULTI ? ((int)blockIdx.x & 7) + 8 * (xk / G) : (int)blockIdx.x;
+  const int g = MULTI ? xk % G : 0;
   const int scene = scene0 + scene_local;
-  const int nscenes = MULTI ? (int)gridDim.x / G : (int)gridDim.x;
+  const int nscenes = MULTI ? nscenes_multi : (int)gridDim.x;
+  if (MULTI && scene_local >= nscenes) return;
   dataset += (size_t)scene * n * 3;
   temp += (size_t)scene * n;
   idxs += (size_t)scene * m;
@@ -174,6 +200,9 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
   float x1 = x0, y1 = y0, z1 = z0;
   if (tid == 0) s_idx[0] = 0;
 
+  const unsigned my_xcc = MULTI ? xcc_id() : 0u;
+  bool same_xcd = false;               // wave 0 (MULTI): the hand-offs of rounds >= 2 go through this XCD's L2
+  unsigned peer_xcc = 0;
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
     if ((j & (IDXBUF - 1)) == 0) {      // flush picks j-1024 .. j-1
@@ -233,7 +262,11 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
       if (wave == 0) {
         const Winner gw = wave_winner<true>(slot4.x, __builtin_bit_cast(unsigned, slot4.y), slot4.z, slot4.w, slotz);
         FPS_STAMP(4);
-        const unsigned tag = (unsigned)j;      // rounds start at 1, slots start zeroed
+        // rounds start at 1, slots start zeroed.  The tag also carries the writer's XCD: round 1 goes through memory
+        // (agent scope, right wherever the workgroups are) and tells every workgroup of the scene whether all of them share
+        // an XCD (the launch deals them that way, see above; verified here rather than assumed); the later rounds then
+        // hand off through that XCD's L2
+        const unsigned tag = (unsigned)j | (my_xcc << 24);
         gu64 *row = (gu64 *)(slots + ((size_t)par * nscenes + scene_local) * 5 * G);
         const int nvals = XG ? 5 : 2;
         if (lane < nvals) {
@@ -242,8 +275,11 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
           if (lane == 2) val = __builtin_bit_cast(unsigned, gw.x);
           if (lane == 3) val = __builtin_bit_cast(unsigned, gw.y);
           if (lane == 4) val = __builtin_bit_cast(unsigned, gw.z);
-          __hip_atomic_store(row + lane * G + g, ((unsigned long long)tag << 32) | val, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long granule = ((unsigned long long)tag << 32) | val;
+          if (same_xcd)
+            granule_store_l2(row + lane * G + g, granule);
+          else
+            __hip_atomic_store(row + lane * G + g, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // poll: lane L watches granule L (value v = L / G of workgroup L % G)
         float fd2 = -1.f;
@@ -255,10 +291,11 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
           for (;;) {
             bool ok = true;
             if (lane < npoll) {
-              const unsigned long long v =
-                  __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ok = (unsigned)(v >> 32) == tag;
+              const unsigned long long v = same_xcd ? granule_load_l2(row + lane)
+                                                    : __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ((unsigned)(v >> 32) & kTagRound) == (unsigned)j;
               myval = (unsigned)v;
+              peer_xcc = (unsigned)(v >> 56) & 0xFu;
             }
             if (__all(ok)) break;
             if (++spins > spin_limit) {
@@ -267,6 +304,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
             }
             __builtin_amdgcn_s_sleep(1);
           }
+          if (j == 1 && !failed) same_xcd = __all(lane >= npoll || peer_xcc == my_xcc);
           const unsigned cval = (unsigned)__shfl((int)myval, lane + G);   // tie key of workgroup `lane`
           if (lane < G && !failed) {
             fd2 = __builtin_bit_cast(float, myval);
@@ -282,7 +320,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
               if (lane < G) {
                 const unsigned long long q =
                     __hip_atomic_load(row + v * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (unsigned)(q >> 32) == tag;
+                ok = ((unsigned)(q >> 32) & kTagRound) == (unsigned)j;
                 vals[v] = (unsigned)q;
               }
               if (__all(ok)) break;
@@ -429,7 +467,7 @@ template <int THREADS, int PPT>
 static int launch_single(int b, int n, int m, int bs_mask, const float *dataset, float *temp,
                          int *idxs, hipStream_t stream) {
   fps_kernel<THREADS, PPT, false, false><<<b, THREADS, 0, stream>>>(n, m, bs_mask, 1, dataset, temp, idxs,
-                                                                    nullptr, nullptr, 0, 0);
+                                                                    nullptr, nullptr, 0, 0, 0);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
@@ -452,11 +490,11 @@ static int launch_multi(int b, int n, int m, int bs_mask, int G, const float *da
     const int ns = (b - s0 < chunk) ? (b - s0) : chunk;
     OMNIPQ_HIP(hipMemsetAsync(ws->slots, 0, (size_t)2 * ns * 5 * G * sizeof(unsigned long long), stream));
     if (5 * G <= 64)
-      fps_kernel<THREADS, PPT, true, true><<<ns * G, THREADS, 0, stream>>>(
-          n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22);
+      fps_kernel<THREADS, PPT, true, true><<<8 * G * ((ns + 7) / 8), THREADS, 0, stream>>>(
+          n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22, ns);
     else
-      fps_kernel<THREADS, PPT, true, false><<<ns * G, THREADS, 0, stream>>>(
-          n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22);
+      fps_kernel<THREADS, PPT, true, false><<<8 * G * ((ns + 7) / 8), THREADS, 0, stream>>>(
+          n, m, bs_mask, G, dataset, temp, idxs, ws->slots, ws->err, s0, 1 << 22, ns);
     OMNIPQ_LAUNCH_CHECK();
   }
   return OMNIPQ_OK;
