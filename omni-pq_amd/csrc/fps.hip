@@ -143,6 +143,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     unsigned long long *__restrict__ slots,  // [2][scenes][5][G] {value, tag} granules (MULTI only)
     int *__restrict__ err_word, int scene0, int spin_limit, int nscenes_multi) {
   constexpr int NW = THREADS / 64;
+  constexpr bool LEAN = MULTI;       // MULTI kernels run 1024 threads: a multiple of every block size of the reference
   // per-wave winners {d2, c (bits), x, y, z, pad}: one 16-byte + one 4-byte LDS access each way, read
   // UNCONDITIONALLY by every lane (slot = lane mod NW; duplicates are harmless in a max) -- predicated
   // reads cost a branch and a full LDS round trip each.
@@ -191,6 +192,13 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
       const float mag = sumsq3(px[i], py[i], pz[i]);
       if (!((double)mag <= 1e-3)) live |= 1u << i;  // sampling_gpu.cu:105-106
     }
+    if (LEAN && !((live >> i) & 1u)) {
+      // LEAN rounds carry no per-point mask: a point that cannot be selected (outside the cloud, or inside the 1e-3 ball)
+      // gets NaN coordinates -- its distance never compares below its running minimum, which therefore stays at the
+      // sentinel -2 < the "no candidate" value -1 -- and is left out when temp is written back
+      px[i] = py[i] = pz[i] = __builtin_nanf("");
+      pt[i] = -2.f;
+    }
   }
 
   // round 0: the seed is point 0 (sampling_gpu.cu:87-88).  Its coordinates stay in registers: a round
@@ -214,30 +222,69 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
     FPS_STAMP(0);
     float bd2 = -1.f;  // "no candidate", as the reference's best = -1 (:96)
     unsigned bc = kNoKey;
+    Winner ww;
+    if (LEAN) {
+      // THREADS is a multiple of the reference's block size bs, so the points of a lane (k = base + i * THREADS) share
+      // k mod bs: among them the tie order (bitrev(k mod bs), k) is the order of i, and a strict '>' over increasing i keeps
+      // the right one -- the round tracks a 3-bit slot number instead of comparing 32-bit keys per point, and unselectable
+      // points need no mask (see above): 11 instead of 19 VALU instructions per point
+      int bi = 0;
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = sumsq3(px[i] - x1, py[i] - y1, pz[i] - z1);
-      const bool on = (live >> i) & 1u;
-      const float t = (on && d < pt[i]) ? d : pt[i];  // min(d, temp[k])
-      pt[i] = t;
-      const float cd2 = on ? t : -1.f;
-      const unsigned cc = on ? pc[i] : kNoKey;
-      if (better(cd2, cc, bd2, bc)) {
-        bd2 = cd2;
-        bc = cc;
+      for (int i = 0; i < PPT; ++i) {
+        const float d = sumsq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+        const float t = d < pt[i] ? d : pt[i];          // min(d, temp[k]); NaN < x is false
+        pt[i] = t;
+        if (t > bd2) {
+          bd2 = t;
+          bi = i;
+        }
       }
+      bc = bd2 < 0.f ? kNoKey : tie_key(base + bi * THREADS, bs_mask);
+      FPS_STAMP(1);
+      // wave argmax, then the winner's coordinates straight out of the owning lane's slot `bi` (wave-uniform after the
+      // readlane: one scalar branch instead of a per-lane selection over the PPT slots)
+      const float md2 = bd2;
+      const unsigned mc = bc;
+      wave_argmax(bd2, bc);
+      const unsigned long long owners = __ballot(md2 == bd2 && mc == bc);
+      const int src = owners ? (int)__builtin_ctzll(owners) : 0;
+      const int slot = __builtin_amdgcn_readlane(bi, src);
+      ww.d2 = bd2;
+      ww.c = bc;
+      ww.x = ww.y = ww.z = 0.f;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i)
+        if (slot == i) {
+          ww.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px[i]), src));
+          ww.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py[i]), src));
+          ww.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz[i]), src));
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float d = sumsq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+        const bool on = (live >> i) & 1u;
+        const float t = (on && d < pt[i]) ? d : pt[i];  // min(d, temp[k])
+        pt[i] = t;
+        const float cd2 = on ? t : -1.f;
+        const unsigned cc = on ? pc[i] : kNoKey;
+        if (better(cd2, cc, bd2, bc)) {
+          bd2 = cd2;
+          bc = cc;
+        }
+      }
+      // coordinates of this lane's candidate (only the winning lane's are ever read)
+      float cx = px[0], cy = py[0], cz = pz[0];
+#pragma unroll
+      for (int i = 1; i < PPT; ++i)
+        if (pc[i] == bc) {
+          cx = px[i];
+          cy = py[i];
+          cz = pz[i];
+        }
+      FPS_STAMP(1);
+      ww = wave_winner(bd2, bc, cx, cy, cz);
     }
-    // coordinates of this lane's candidate (only the winning lane's are ever read)
-    float cx = px[0], cy = py[0], cz = pz[0];
-#pragma unroll
-    for (int i = 1; i < PPT; ++i)
-      if (pc[i] == bc) {
-        cx = px[i];
-        cy = py[i];
-        cz = pz[i];
-      }
-    FPS_STAMP(1);
-    const Winner ww = wave_winner(bd2, bc, cx, cy, cz);
     FPS_STAMP(2);
     if (lane == 0) {
       *reinterpret_cast<float4 *>(&s_f[par][wave][0]) =
@@ -384,7 +431,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = base + i * THREADS;
-    if (k < n) temp[k] = pt[i];
+    if (k < n && (!LEAN || ((live >> i) & 1u))) temp[k] = pt[i];      // (LEAN: an unselectable point's temp never changes)
   }
 }
 
