@@ -294,6 +294,7 @@ class XyzGradSink:
 
     def __init__(self):
         self.buf = None
+        self.stream = None          # the stream the decodes add on, if it is not the stream SinkFlush's backward runs on
 
 
 class SinkFlush(torch.autograd.Function):
@@ -310,6 +311,8 @@ class SinkFlush(torch.autograd.Function):
     def backward(ctx, g):
         E16.select(ctx.e16)
         buf, ctx.sink.buf = ctx.sink.buf, None
+        if ctx.sink.stream is not None and g.is_cuda:
+            torch.cuda.current_stream(g.device).wait_stream(ctx.sink.stream)      # the adds are side effects autograd does not see
         return g, buf, None
 
 
@@ -392,6 +395,15 @@ _HEAD_KEYS = ("objectness_scores", "center", "heading_scores", "heading_residual
               "size_scores", "size_residuals_normalized", "size_residuals", "pred_size", "sem_cls_scores")
 _QUAD_KEYS = ("quad_scores", "quad_center", "normal_vector", "quad_size")
 _PAIR_DECODE = True        # module switches, toggled by tests/test_gpu_decoder.py to compare with the separate launches
+# The prediction heads of a decoder stage read the stage's output and feed nothing but the loss and (detached) the next
+# layer's query positions.  Run on a stream of their own they change nothing in forward (the next layer waits for the
+# centres), but autograd runs a node's backward on the stream of its forward: the seven head stacks' backward passes (~0.1 ms
+# of small launches each) then run UNDERNEATH the decoder layers' backward chain instead of in line with it.
+# MEASURED (round 5, profiles/r05_heads_side_stream_ab.txt): the replayed step gets 2.4 ms SLOWER (8.43 -> 10.85 ms) -- the 14
+# fork / join pairs and the per-gradient event waits between the two branches cost far more in the graph executor than the
+# overlap returns (the key sides' 7 and the weight-gradient flush's 2 cross-stream edges do pay: +0.31 / +0.22 ms without
+# them).  Off; kept as a switch.
+_HEADS_SIDE = "never"      # "always" | "capture" (inside a hipGraph capture only, like the key sides) | "never"
 _XYZ_SINK = True
 _PAIR_STACKS = True
 
@@ -680,7 +692,25 @@ class PQ_Transformer(nn.Module):
             # every stage decodes against cluster_xyz: its seven gradients are summed by the decode kernels themselves
             sink = XyzGradSink()
             cluster_feature = SinkFlush.apply(cluster_feature, cluster_xyz, sink)
-        center, center_q, end_points, pos_joint = predict_pair(
+        heads_side = cluster_feature.is_cuda and torch.is_grad_enabled() and cluster_feature.requires_grad and \
+            (_HEADS_SIDE == "always" or (_HEADS_SIDE == "capture" and torch.cuda.is_current_stream_capturing()))
+        hstream = self._heads_stream(cluster_feature.device) if heads_side else None
+        if sink is not None:
+            sink.stream = hstream
+
+        def predict(*a, **kw):
+            if hstream is None:
+                return predict_pair(*a, **kw)
+            cur = torch.cuda.current_stream(hstream.device)
+            hstream.wait_stream(cur)
+            with torch.cuda.stream(hstream):
+                out = predict_pair(*a, **kw)
+            cur.wait_stream(hstream)
+            for v in list(out[:2]) + ([out[3]] if out[3] is not None else []):
+                v.record_stream(cur)
+            return out
+
+        center, center_q, end_points, pos_joint = predict(
             self.proposal, self.quad_proposal, cluster_feature, quad_feature, cluster_xyz, quad_xyz, end_points,
             'proposal_', sink=sink, want_pos=True)
         # the reference clones here (:236-237); nothing writes into these tensors afterwards, a detached alias suffices
@@ -718,7 +748,7 @@ class PQ_Transformer(nn.Module):
                 query_joint.omnipq_rows16 = alias
             elif rows16 is not None:
                 rows_obj, rows_quad = torch.split(rows16, [n_obj, n_quad], dim=1)
-            base_xyz, base_xyz_q, end_points, pos_joint = predict_pair(
+            base_xyz, base_xyz_q, end_points, pos_joint = predict(
                 self.prediction_heads[i], self.prediction_quad_heads[i], query, query_q, cluster_xyz, quad_xyz,
                 end_points, prefix, rows_obj, rows_quad, sink=sink, want_pos=i + 1 < self.num_layer)
             base_xyz = base_xyz.detach()
@@ -729,6 +759,13 @@ class PQ_Transformer(nn.Module):
         state = self.__dict__.copy()
         state.pop("_omnipq_flush_streams", None)        # streams do not travel with a copy of the module (EMA teacher, torch.save)
         return state
+
+    def _heads_stream(self, device):
+        """The stream the prediction heads run on (_HEADS_SIDE)."""
+        streams = self.__dict__.setdefault("_omnipq_flush_streams", {})
+        if ("heads", device) not in streams:
+            streams[("heads", device)] = torch.cuda.Stream(device=device)
+        return streams[("heads", device)]
 
     def _flush_stream(self, device):
         """The stream early weight-gradient flushes run on (sa_fused.WgradFlushPoint)."""

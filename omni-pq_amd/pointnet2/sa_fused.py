@@ -667,16 +667,25 @@ class deferred_wgrads:
         self.items = []             # (dY, X, M, N, P, weight target, (cout, cin[, rot]), bias target | None, affine | None, row plan | None)
         self.sa_items = []          # the same for the SA stages' layers: a grouped launch of their own (see add_sa)
         self.ln_items = []          # (partials [blocks][2C], blocks, C, gamma, beta): LayerNorm parameter gradients
+        self.producers = set()      # streams other than the flushing one on which collected operands were produced
         deferred_wgrads.active = self
         return self
 
+    def _note_producer(self, t):
+        """Operands are recorded on whatever stream their backward node runs on (the prediction heads have their own,
+        models/pq_transformer.py: _HEADS_SIDE); a flush waits for those streams as well."""
+        if t.is_cuda:
+            self.producers.add(torch.cuda.current_stream(t.device))
+
     def add_layernorm(self, part, blocks, C, gamma, beta):
         """dgamma | dbeta of one LayerNorm as per-workgroup partial sums (omnipq_add_dropout_layernorm_bwd_partials)."""
+        self._note_producer(part)
         self.ln_items.append((part, blocks, C, gamma, beta))
 
     def add(self, dY, X, M, N, P, wt, crop, bt, below=None):
         """below: X is that layer's pre-BN output and stands for relu(below.a * X + below.b)"""
         _refuse_ddp(wt)
+        self._note_producer(dY)
         self.items.append((dY, X, M, N, P, wt, crop, bt, None if below is None else (below.a, below.b), None))
 
     def add_sa(self, dY, X, M, N, P, wt, crop, below=None, blk=None):
@@ -685,6 +694,7 @@ class deferred_wgrads:
         workgroups each -- two per CU, the launch's tail and its slab reduction paid 14 times per step; together
         they fill the chip with ~4000 workgroups cut for balance.  crop = (cout, cin, rot): see omnipq_tn_problem."""
         _refuse_ddp(wt)
+        self._note_producer(dY)
         # blk: the stage's row plan (_Plan: the positions in use live in device memory), or None
         self.sa_items.append((dY, X, M, N, P, wt, crop, None, None if below is None else (below.a, below.b), blk))
 
@@ -693,6 +703,7 @@ class deferred_wgrads:
         global COLLECTIVES_LAST_STEP, _COLLECTIVES_MARK
         COLLECTIVES_LAST_STEP, _COLLECTIVES_MARK = COLLECTIVES - _COLLECTIVES_MARK, COLLECTIVES
         if et is None:
+            self._wait_producers(None)
             self.flush()
         # early flushes run on side streams: join them on BOTH paths (after an exception their launches must not
         # outlive the operands this block releases below)
@@ -708,6 +719,13 @@ class deferred_wgrads:
         self._assign = None
         return False
 
+    def _wait_producers(self, stream):
+        """`stream` (None: the current one) waits for every stream operands were recorded on."""
+        for ps in self.producers:
+            st = stream if stream is not None else torch.cuda.current_stream(ps.device)
+            if ps != st:
+                st.wait_stream(ps)
+
     def flush_on(self, stream):
         """Compute what has been collected so far on `stream` (ordered after the current stream), e.g. the decoder's
         and heads' gradients underneath the backbone's backward pass.  Operands stay referenced until the block
@@ -716,6 +734,7 @@ class deferred_wgrads:
             return
         cur = torch.cuda.current_stream(stream.device)
         stream.wait_stream(cur)
+        self._wait_producers(stream)
         self.__dict__.setdefault("_inflight", []).extend(self.items)
         self._inflight.extend(self.ln_items)
         streams = self.__dict__.setdefault("_side_streams", [])
