@@ -197,9 +197,12 @@ _SIDE = {}
 
 
 def _side_stream(device):
-    s = _SIDE.get(device)
+    """one side stream per stream the decoder is called on (a teacher network running next to its student on a stream of
+    its own must not share -- and thereby serialise on -- the student's)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    s = _SIDE.get(key)
     if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device)
+        s = _SIDE[key] = torch.cuda.Stream(device)
     return s
 
 

@@ -20,20 +20,44 @@ class _DropoutState:
     def __init__(self):
         self.state = {}
         self.cur = {}
-        self.salt = 0
+        self.salts = {}
+        self.slot = None            # `use(slot)`: a second, independent counter (see there)
+
+    @property
+    def salt(self):
+        return self.salts.get(self.slot, 0)
+
+    @salt.setter
+    def salt(self, v):
+        self.salts[self.slot] = v
+
+    def use(self, slot):
+        """with STATE.use("teacher"): ...  -- the forward passes issued inside draw from a counter of their own (device
+        memory and host-side salt).  For a network whose forward runs on ANOTHER STREAM at the same time as the main
+        network's (the mean-teacher step, train_step.CapturedStep): two streams adding to one device counter would race."""
+        state = self
+
+        class _Use:
+            def __enter__(self):
+                self.prev, state.slot = state.slot, slot
+
+            def __exit__(self, *exc):
+                state.slot = self.prev
+
+        return _Use()
 
     def _state(self, device):
-        t = self.state.get(device)
+        t = self.state.get((self.slot, device))
         if t is None:
             t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-            self.state[device] = t
+            self.state[(self.slot, device)] = t
         return t
 
     def seed(self, device):
         device = torch.device(device)
-        t = self.cur.get(device)
+        t = self.cur.get((self.slot, device))
         if t is None:
-            t = self.cur[device] = self._state(device).clone()
+            t = self.cur[(self.slot, device)] = self._state(device).clone()
         return t
 
     def advance(self, device):
@@ -41,20 +65,20 @@ class _DropoutState:
         device = torch.device(device)
         st = self._state(device)
         st.add_(0x9E3779B97F4A7C15 >> 2)
-        self.cur[device] = st.clone()
+        self.cur[(self.slot, device)] = st.clone()
         self.salt = 0
 
     def set_state(self, device, value):
         """(tests) restart the counter from a known value"""
         device = torch.device(device)
         self._state(device).fill_(int(value))
-        self.cur.pop(device, None)
+        self.cur.pop((self.slot, device), None)
 
     def reset(self):
         """(tests) forget every counter: the next use draws a new one from torch's generator"""
         self.state.clear()
         self.cur.clear()
-        self.salt = 0
+        self.salts.clear()
 
     def next_salt(self):
         self.salt += 1

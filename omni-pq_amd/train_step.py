@@ -111,9 +111,35 @@ class CapturedStep:
         if self.buckets is not None:
             self.buckets.finish()
 
-    def _teacher_forward(self, batch):
-        with torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            return self.teacher({"point_clouds": batch})            # train mode, no grad (train.py:462, 490-491)
+    # The teacher's no-grad forward does not depend on the student's: issued on a stream of its own BEFORE the student's
+    # forward it could run next to it (one fork, one join in front of the losses).  MEASURED (round 5, replayed graph): the
+    # mean-teacher step gets SLOWER, 12.0 -> 15.2 ms -- the graph executor does not run two long branches side by side the way
+    # two eager streams would -- and with the decoder's own key-side fork nested inside the forked branch hipStreamEndCapture
+    # segfaults.  Off; kept as a switch (its dropout sites draw from a counter of their own: dropout_state.use).
+    TEACHER_SIDE = False
+
+    def _teacher_forward(self, batch, nested=False):
+        """nested: the call is made on a forked stream -- the decoder's own fork for the key sides stays off (a fork inside
+        a fork made hipStreamEndCapture segfault)"""
+        import dropout_state
+        import sys
+        pqt = sys.modules.get("pq_transformer") or sys.modules.get("models.pq_transformer")
+        keep = getattr(pqt, "_OVERLAP_KEY_SIDE", None)
+        if nested and pqt is not None:
+            pqt._OVERLAP_KEY_SIDE = "never"
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None), \
+                    dropout_state.STATE.use("teacher"):
+                return self.teacher({"point_clouds": batch})            # train mode, no grad (train.py:462, 490-491)
+        finally:
+            if nested and pqt is not None:
+                pqt._OVERLAP_KEY_SIDE = keep
+
+    def _teacher_stream(self, device):
+        st = getattr(self, "_tstream", None)
+        if st is None or st.device != device:
+            st = self._tstream = torch.cuda.Stream(device=device)
+        return st
 
     def _body(self, cur, nxt, lab, cur_t, nxt_t, trusted):
         """forward + loss (+ teacher forward) + backward (+ EMA) on `cur`, with the sampling plan of `nxt` started on the
@@ -126,10 +152,24 @@ class CapturedStep:
             net.prefetch({"point_clouds": nxt}, trusted=trusted, at_next_forward=True, footprint=self.footprint)
             if teacher is not None:
                 teacher.prefetch({"point_clouds": nxt_t}, trusted=trusted, at_next_forward=True, footprint=self.footprint)
+        tep = tside = None
+        if teacher is not None and self.TEACHER_SIDE and cur_t.is_cuda:
+            main = torch.cuda.current_stream(cur_t.device)
+            tside = self._teacher_stream(cur_t.device)
+            tside.wait_stream(main)
+            with torch.cuda.stream(tside):
+                tep = self._teacher_forward(cur_t, nested=True)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             ep = self.model({"point_clouds": cur})
         if teacher is not None:
-            tep = self._teacher_forward(cur_t)                  # train.py:489-491: before the losses, which may read both
+            if tside is not None:
+                main.wait_stream(tside)
+                if not torch.cuda.is_current_stream_capturing():
+                    for v in tep.values() if isinstance(tep, dict) else ():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
+            else:
+                tep = self._teacher_forward(cur_t)              # train.py:489-491: before the losses, which may read both
             self.teacher_end_points = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in tep.items()} \
                 if isinstance(tep, dict) else None
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
