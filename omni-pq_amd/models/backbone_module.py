@@ -18,6 +18,8 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
 from pointnet2_modules import PointnetSAModuleVotes, PointnetFPModule  # noqa: E402
 import pointnet2_utils  # noqa: E402
 
+GROUP_AHEAD = True          # prefetched sampling chains also make the stages' centres / ball queries / row plans (see _launch_plan)
+
 # (name, npoint, radius, nsample)
 _SA_GEOMETRY = (("sa1", 2048, 0.2, 64), ("sa2", 1024, 0.4, 32), ("sa3", 512, 0.8, 16),
                 ("sa4", 256, 1.2, 16))
@@ -84,16 +86,66 @@ class Pointnet2Backbone(nn.Module):
                                      dtype=torch.int32) for n in ("sa1", "sa2", "sa3", "sa4")]
         return bufs[key]
 
-    def _launch_plan(self, pointcloud, trusted=False, small=False):
+    # Grouping ahead of the stages (round 5).  The centres, the ball-query indices and the row plan of a stage depend on
+    # coordinates only, like the sampling itself: a chain started by prefetch() appends them for all four stages (gather_xyz,
+    # ball query, the plan's three small kernels: ~0.25 ms and ~14 launches that otherwise sit on the main stream between the
+    # stages' GEMMs) and leaves them in ONE flat persistent buffer; forward() takes it with one copy and hands every stage its
+    # views on the index tensor (`inds.omnipq_group`).  Same kernels, same inputs: identical results.  Switch: GROUP_AHEAD.
+
+    def _group_layout(self, B, n_points):
+        """-> (total int32 words, [(name, M, S, n_src, off_xyz, off_idx, off_plan | None)])"""
+        import sa_fused
+        r4 = lambda n: (n + 3) // 4 * 4
+        off, levels, n_src = 0, [], n_points
+        for name in ("sa1", "sa2", "sa3", "sa4"):
+            mod = getattr(self, name)
+            M, S = mod.npoint, mod.nsample
+            P = B * M * S
+            o_xyz, off = off, off + r4(B * M * 3)
+            o_idx, off = off, off + r4(P)
+            o_plan = None
+            if sa_fused.plan_static_ok(S, P):
+                o_plan, off = off, off + sum(sa_fused.plan_words(B, M, P))
+            levels.append((name, M, S, n_src, o_xyz, o_idx, o_plan))
+            n_src = M
+        return off, levels
+
+    def _group_views(self, flat, B, n_points):
+        """flat int32 -> [(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None)] per stage"""
+        import sa_fused
+        total, levels = self._group_layout(B, n_points)
+        out = []
+        for name, M, S, n_src, o_xyz, o_idx, o_plan in levels:
+            P = B * M * S
+            cen = flat[o_xyz:o_xyz + B * M * 3].view(torch.float32).view(B, M, 3)
+            idx = flat[o_idx:o_idx + P].view(B, M, S)
+            st = None if o_plan is None else flat[o_plan:o_plan + sum(sa_fused.plan_words(B, M, P))]
+            out.append((cen, idx, st))
+        return out
+
+    def _launch_plan(self, pointcloud, trusted=False, small=False, group=False):
         """FPS chain for `pointcloud` on the side stream -> {"key", "inds": [4 x (B,npoint) int32],
-        "events": [4 x Event]}; the caller's stream has to wait on events[i] before using inds[i]."""
+        "events": [4 x Event]}; the caller's stream has to wait on events[i] before using inds[i].
+        group: also the stages' centres / ball queries / row plans (GROUP_AHEAD) -> plan["group"] = (flat buffer, event)."""
         main = torch.cuda.current_stream(pointcloud.device)
         side = self._side_stream(pointcloud.device)
         side.wait_stream(main)
         bufs = self._plan_buffers(pointcloud)
         plan = {"key": self._key(pointcloud), "inds": [], "events": [], "src": pointcloud, "trusted": trusted,
-                "extra": None}
+                "extra": None, "group": None}
         ext = pointnet2_utils._ext
+        group = bool(group) and GROUP_AHEAD and hasattr(ext, "set_timing_sink")
+        gflat, gviews, gsrc = None, None, []
+        if group:
+            B0, n0 = pointcloud.shape[0], pointcloud.shape[1]
+            gkey = ("group", B0, n0, str(pointcloud.device))
+            store = self.__dict__.setdefault("_plan_bufs", {})
+            if gkey not in store:
+                store[gkey] = torch.zeros((self._group_layout(B0, n0)[0],), device=pointcloud.device, dtype=torch.int32)
+            gflat = store[gkey]
+            gviews = self._group_views(gflat, B0, n0)
+            if not torch.cuda.is_current_stream_capturing():
+                gflat.record_stream(side)
         if not torch.cuda.is_current_stream_capturing():
             # The cloud and the persistent index buffers come from the caller's stream's pool but are read / written
             # by the sampling stream: if either dies while a plan is still running (a model dropped right after a
@@ -114,7 +166,11 @@ class Pointnet2Backbone(nn.Module):
                 ev.record(side)
                 plan["inds"].append(inds)
                 plan["events"].append(ev)
-                if name != "sa4":
+                if group:
+                    src = xyz.contiguous()
+                    xyz = ext.gather_xyz(src, inds, out=gviews[li][0])
+                    gsrc.append(src)
+                elif name != "sa4":
                     if hasattr(ext, "gather_xyz"):
                         xyz = ext.gather_xyz(xyz.contiguous(), inds)
                     else:
@@ -134,6 +190,19 @@ class Pointnet2Backbone(nn.Module):
                     e_ev = torch.cuda.Event()
                     e_ev.record(side)
                     plan["extra"] = (name, e_inds, e_ev)
+            if group:
+                # behind every sampling level (their events fire first): ball query and row plan per stage
+                import sa_fused
+                for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
+                    mod = getattr(self, name)
+                    cen, idx, st = gviews[li]
+                    with sa_fused._tagged("@sa", name):
+                        ext.ball_query(cen, gsrc[li], mod.radius, mod.nsample, out=idx)
+                        if st is not None:
+                            sa_fused.make_row_plan(idx, idx.numel(), into=st)
+                g_ev = torch.cuda.Event()
+                g_ev.record(side)
+                plan["group"] = (gflat, g_ev)
         return plan
 
     def prefetch(self, pointcloud, trusted=False, at_next_forward=False, footprint=None):
@@ -152,9 +221,9 @@ class Pointnet2Backbone(nn.Module):
             return
         small = (footprint or ("small" if at_next_forward else "fast")) == "small"
         if at_next_forward:
-            self._pending = (pointcloud, trusted, small)
+            self._pending = (pointcloud, trusted, small, True)
         else:
-            self._plan = self._launch_plan(pointcloud, trusted, small)
+            self._plan = self._launch_plan(pointcloud, trusted, small, True)
 
     def forget_plan(self):
         """Drop the HOST-side record of a plan in flight / pending (not the device work).  A captured step replays its
@@ -205,6 +274,12 @@ class Pointnet2Backbone(nn.Module):
         if plan is not None and plan["extra"] is not None:
             self._extra = plan["extra"]
         taken = [None] * 4
+        groups = [None] * 4
+        if plan is not None and plan.get("group") is not None:
+            # made ahead of the stages (GROUP_AHEAD): one copy of the chain's flat buffer, views per stage
+            gflat, g_ev = plan["group"]
+            torch.cuda.current_stream(pointcloud.device).wait_event(g_ev)
+            groups = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1])
         pending, self._pending = getattr(self, "_pending", None), None
         if pending is not None:
             if plan is not None:
@@ -224,6 +299,8 @@ class Pointnet2Backbone(nn.Module):
             if plan is not None:
                 torch.cuda.current_stream(pointcloud.device).wait_event(plan["events"][li])
                 inds = plan["inds"][li].clone()        # the plan's buffers are reused by the next plan
+            if groups[li] is not None and inds is not None:
+                inds.omnipq_group = groups[li]
             xyz, features, inds = getattr(self, name)(xyz, features, inds)
             if name in ("sa1", "sa2"):          # the reference records inds for these two only
                 end_points[name + "_inds"] = inds

@@ -203,8 +203,9 @@ def gather_points(points, idx):
     return out
 
 
-def gather_xyz(xyz, idx):
-    """(B,N,3) f32, (B,M) i32 -> (B,M,3): xyz[b, idx[b, m]] (no gradient; the reference's transpose / gather / transpose)"""
+def gather_xyz(xyz, idx, out=None):
+    """(B,N,3) f32, (B,M) i32 -> (B,M,3): xyz[b, idx[b, m]] (no gradient; the reference's transpose / gather / transpose).
+    out: write into this contiguous (B,M,3) f32 tensor."""
     _check(xyz, "xyz", torch.float32)
     _check(idx, "idx", torch.int32, cuda_like=xyz)
     _need_gpu(xyz)
@@ -212,7 +213,10 @@ def gather_xyz(xyz, idx):
     if three != 3:
         raise ValueError("gather_xyz: xyz must be (B, N, 3)")
     m = idx.shape[1]
-    out = torch.empty((b, m, 3), device=xyz.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((b, m, 3), device=xyz.device, dtype=torch.float32)
+    elif not (out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (b, m, 3) and out.device == xyz.device):
+        raise ValueError("gather_xyz: out must be a contiguous (B, M, 3) float32 tensor on the inputs' device")
     _run(_lib0.omnipq_gather_xyz, xyz, b, n, m, _ptr(xyz), _ptr(idx), _ptr(out))
     return out
 
@@ -328,14 +332,20 @@ _BQ_GRID_MIN = 8192      # points per scene from which the grid pays
 _lib0.omnipq_ball_query_grid_workspace_bytes.restype = ctypes.c_longlong
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
-    """(B,M,3), (B,N,3) -> (B,M,nsample) i32   [ball_query.cpp:16-40]"""
+def ball_query(new_xyz, xyz, radius, nsample, out=None):
+    """(B,M,3), (B,N,3) -> (B,M,nsample) i32   [ball_query.cpp:16-40]; out: write into this contiguous int32 tensor"""
     _check(new_xyz, "new_xyz", torch.float32)
     _check(xyz, "xyz", torch.float32, cuda_like=new_xyz)
     _need_gpu(new_xyz)
     b, n = xyz.shape[0], xyz.shape[1]
     m = new_xyz.shape[1]
-    idx = torch.empty((b, m, int(nsample)), device=new_xyz.device, dtype=torch.int32)
+    if out is None:
+        idx = torch.empty((b, m, int(nsample)), device=new_xyz.device, dtype=torch.int32)
+    else:
+        if not (out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (b, m, int(nsample)) and
+                out.device == new_xyz.device):
+            raise ValueError("ball_query: out must be a contiguous (B, M, nsample) int32 tensor on the inputs' device")
+        idx = out
     if n >= _BQ_GRID_MIN and radius > 0 and b <= 65535:
         # large clouds: the same indices through a hash grid (csrc/ball_query.hip) instead of n tests per centre
         ws = torch.empty((int(_lib0.omnipq_ball_query_grid_workspace_bytes(b, n)),), device=new_xyz.device,

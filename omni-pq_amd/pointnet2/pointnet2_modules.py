@@ -163,10 +163,16 @@ class PointnetSAModuleVotes(nn.Module):
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         if inds is not None:
             assert inds.shape[1] == self.npoint
-        new_xyz, inds = _centres(xyz, self.npoint, inds)
+        # made ahead of the stage by the backbone's sampling chain: (centres, ball-query indices, row-plan state | None)
+        group = getattr(inds, "omnipq_group", None) if inds is not None else None
+        if group is not None and group[0] is not None and not (torch.is_grad_enabled() and xyz.requires_grad):
+            new_xyz = group[0]
+        else:
+            group = None
+            new_xyz, inds = _centres(xyz, self.npoint, inds)
         if self._fused(xyz, features):
             import sa_fused
-            return new_xyz, sa_fused.run(self, xyz, new_xyz, features), inds
+            return new_xyz, sa_fused.run(self, xyz, new_xyz, features, group=None if group is None else group[1:]), inds
         grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None
         grouped_features, grouped_xyz = grouped[0], grouped[1]

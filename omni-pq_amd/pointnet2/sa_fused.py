@@ -321,19 +321,52 @@ class _Plan:
     __slots__ = ("goff", "rows_dev", "row_w", "scratch", "gs", "unit_src")
 
 
-def make_row_plan(idx, P):
-    """idx (B, M, S) int32 -> the stage's _Plan (three tiny launches)"""
+def plan_static_ok(S, P):
+    """the part of row_plan_ok that depends on the stage's geometry only (what a plan made AHEAD of the stage can check)"""
+    return ROW_PLAN and S in (32, 64, 128) and P >= PLAN_MIN_ROWS and P % 128 == 0
+
+
+def plan_words(B, M, P):
+    """int32 words of a plan's device state, each piece a multiple of 4 words: goff | rows_dev | unit_src | row_w"""
+    r4 = lambda n: (n + 3) // 4 * 4
+    return r4(B * M + 1), 4, r4(P // 8), r4(P // 4)
+
+
+def make_row_plan(idx, P, into=None):
+    """idx (B, M, S) int32 -> the stage's _Plan (three tiny launches).  into: a flat int32 tensor of sum(plan_words) words
+    that receives the plan's state (a plan made ahead of its stage, in persistent memory: Pointnet2Backbone's sampling chain)"""
     B, M, S = idx.shape
     dev = idx.device
     plan = _Plan()
     plan.gs = PLAN_GROUP
-    plan.goff = torch.empty((B * M + 1,), device=dev, dtype=torch.int32)
-    plan.rows_dev = torch.empty((1,), device=dev, dtype=torch.int32)
-    plan.row_w = torch.empty((P,), device=dev, dtype=torch.uint8)
+    if into is None:
+        plan.goff = torch.empty((B * M + 1,), device=dev, dtype=torch.int32)
+        plan.rows_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+        plan.row_w = torch.empty((P,), device=dev, dtype=torch.uint8)
+        plan.unit_src = torch.empty((P // 8,), device=dev, dtype=torch.int32)
+    else:
+        plan.goff, plan.rows_dev, plan.unit_src, plan.row_w = plan_views(into, B, M, P)
     plan.scratch = torch.empty((B * M,), device=dev, dtype=torch.int32)
-    plan.unit_src = torch.empty((P // 8,), device=dev, dtype=torch.int32)
     _call(_lib.omnipq_sa_ball_plan_src, idx, ctypes.c_longlong(B * M), S, plan.gs, _p(idx), _p(plan.goff), _p(plan.rows_dev),
           _p(plan.row_w), _p(plan.unit_src), _p(plan.scratch))
+    if KEEP_LAST_PLANS:
+        row_plan_last[P] = plan
+    return plan
+
+
+def plan_views(flat, B, M, P):
+    """the four tensors of a plan inside its flat int32 state (plan_words)"""
+    w = plan_words(B, M, P)
+    o1, o2, o3 = w[0], w[0] + w[1], w[0] + w[1] + w[2]
+    return flat[:B * M + 1], flat[o1:o1 + 1], flat[o2:o2 + P // 8], flat[o3:o3 + w[3]].view(torch.uint8)[:P]
+
+
+def plan_from_state(flat, B, M, P):
+    """a _Plan over state some earlier launch wrote (a copy of what make_row_plan(into=) filled)"""
+    plan = _Plan()
+    plan.gs = PLAN_GROUP
+    plan.goff, plan.rows_dev, plan.unit_src, plan.row_w = plan_views(flat, B, M, P)
+    plan.scratch = None
     if KEEP_LAST_PLANS:
         row_plan_last[P] = plan
     return plan
@@ -1204,7 +1237,9 @@ class FusedSAStage(torch.autograd.Function):
         if row_plan_ok(training, S, P, L, xyz_grad or (feat_grad and N > 8192), 128 % S == 0):
             global row_plan_uses
             row_plan_uses += 1
-            plan = make_row_plan(idx, P)
+            plan = getattr(idx, "omnipq_plan", None)           # made ahead of the stage (run(group=)), or here
+            if plan is None or plan.gs != PLAN_GROUP:
+                plan = make_row_plan(idx, P)
         ctx.plan = plan
         hoist = hoist_ok(training, features, cin, cin_raw, L, params[0].shape[0], xgen) and \
             (plan is None or not xyz_grad)
@@ -1609,12 +1644,21 @@ def eligible(module, xyz, features):
     return True
 
 
-def run(module, xyz, new_xyz, features):
-    """ball query + fused stage -> (B, C_out, npoint) f32"""
+def run(module, xyz, new_xyz, features, group=None):
+    """ball query + fused stage -> (B, C_out, npoint) f32.  group = (idx (B, M, S) int32, plan state | None): the ball query
+    (and row plan) of this stage made ahead of it (they depend on coordinates only: Pointnet2Backbone's sampling chain)."""
     global _STAGE_LABEL
     _STAGE_LABEL = getattr(module, "omnipq_stage", None) or f"m{module.npoint}s{module.nsample}"
-    with _tagged("@sa", _STAGE_LABEL):
-        idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
+    idx = None
+    if group is not None and group[0] is not None and \
+            tuple(group[0].shape) == (xyz.shape[0], new_xyz.shape[1], module.nsample) and group[0].dtype == torch.int32:
+        idx = group[0]
+        if group[1] is not None:
+            B_, M_, S_ = idx.shape
+            idx.omnipq_plan = plan_from_state(group[1], B_, M_, B_ * M_ * S_)
+    if idx is None:
+        with _tagged("@sa", _STAGE_LABEL):
+            idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
     params, bn_cfg = [], []
     for layer in module.mlp_module:
         conv, bn = _bn_of(layer)
