@@ -106,21 +106,29 @@ class Pointnet2Backbone(nn.Module):
             o_plan = None
             if sa_fused.plan_static_ok(S, P):
                 o_plan, off = off, off + sum(sa_fused.plan_words(B, M, P))
-            levels.append((name, M, S, n_src, o_xyz, o_idx, o_plan))
+            o_csr = None
+            if name != "sa1":           # stages with features: the CSR "which grouped positions read point k" of their backward
+                o_csr, off = off, off + r4(B * (n_src + 1)) + r4(P)
+            levels.append((name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr))
             n_src = M
         return off, levels
 
     def _group_views(self, flat, B, n_points):
-        """flat int32 -> [(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None)] per stage"""
+        """flat int32 -> [(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None, (offsets, order) | None)] per stage"""
         import sa_fused
         total, levels = self._group_layout(B, n_points)
         out = []
-        for name, M, S, n_src, o_xyz, o_idx, o_plan in levels:
+        r4 = lambda n: (n + 3) // 4 * 4
+        for name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr in levels:
             P = B * M * S
             cen = flat[o_xyz:o_xyz + B * M * 3].view(torch.float32).view(B, M, 3)
             idx = flat[o_idx:o_idx + P].view(B, M, S)
             st = None if o_plan is None else flat[o_plan:o_plan + sum(sa_fused.plan_words(B, M, P))]
-            out.append((cen, idx, st))
+            csr = None
+            if o_csr is not None:
+                o2 = o_csr + r4(B * (n_src + 1))
+                csr = (flat[o_csr:o_csr + B * (n_src + 1)].view(B, n_src + 1), flat[o2:o2 + P].view(B, M * S))
+            out.append((cen, idx, st, csr))
         return out
 
     def _launch_plan(self, pointcloud, trusted=False, small=False, group=False):
@@ -193,16 +201,20 @@ class Pointnet2Backbone(nn.Module):
             if group:
                 # behind every sampling level (their events fire first): ball query and row plan per stage
                 import sa_fused
+                planned = []
                 for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
                     mod = getattr(self, name)
-                    cen, idx, st = gviews[li]
+                    cen, idx, st, csr = gviews[li]
                     with sa_fused._tagged("@sa", name):
                         ext.ball_query(cen, gsrc[li], mod.radius, mod.nsample, out=idx)
-                        if st is not None:
-                            sa_fused.make_row_plan(idx, idx.numel(), into=st)
+                        rp = sa_fused.make_row_plan(idx, idx.numel(), into=st) if st is not None else None
+                        if csr is not None:
+                            # in the row space the stage will run in: compact under a plan (a planned stage = training)
+                            sa_fused.build_csr_ahead(idx, gsrc[li].shape[1], rp if mod.training else None, csr[0], csr[1])
+                    planned.append(rp is not None and mod.training)
                 g_ev = torch.cuda.Event()
                 g_ev.record(side)
-                plan["group"] = (gflat, g_ev)
+                plan["group"] = (gflat, g_ev, planned)
         return plan
 
     def prefetch(self, pointcloud, trusted=False, at_next_forward=False, footprint=None):
@@ -277,9 +289,10 @@ class Pointnet2Backbone(nn.Module):
         groups = [None] * 4
         if plan is not None and plan.get("group") is not None:
             # made ahead of the stages (GROUP_AHEAD): one copy of the chain's flat buffer, views per stage
-            gflat, g_ev = plan["group"]
+            gflat, g_ev, planned = plan["group"]
             torch.cuda.current_stream(pointcloud.device).wait_event(g_ev)
-            groups = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1])
+            groups = [g + (pl,) for g, pl in
+                      zip(self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1]), planned)]
         pending, self._pending = getattr(self, "_pending", None), None
         if pending is not None:
             if plan is not None:

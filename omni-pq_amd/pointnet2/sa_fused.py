@@ -361,6 +361,29 @@ def plan_views(flat, B, M, P):
     return flat[:B * M + 1], flat[o1:o1 + 1], flat[o2:o2 + P // 8], flat[o3:o3 + w[3]].view(torch.uint8)[:P]
 
 
+def build_csr_ahead(idx, N, plan, offsets, order):
+    """The CSR of a stage's backward (omnipq_sa_build_csr) made ahead of the stage, in the row space of `plan` (None: every
+    row), into given (B, N + 1) / (B, M * S) int32 tensors."""
+    B, M, S = idx.shape
+    scratch = torch.empty((B, N), device=idx.device, dtype=torch.int32)
+    with _row_plan(plan, B * M * S):
+        _call(_lib.omnipq_sa_build_csr, idx, B, N, M, S, _p(idx), _p(offsets), _p(order), _p(scratch))
+
+
+def _csr_of(idx, B, N, M, S, planned, anchor):
+    """(offsets, order) of the stage's backward: the ones made ahead of the stage (run(group=)) if they were made in the row
+    space this backward runs in, else built now (inside the caller's _row_plan block)."""
+    pre = getattr(idx, "omnipq_csr", None)
+    if pre is not None and pre[2] == planned and tuple(pre[0].shape) == (B, N + 1) and tuple(pre[1].shape) == (B, M * S):
+        return pre[0], pre[1]
+    dev = idx.device
+    offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
+    order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
+    scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
+    _call(_lib.omnipq_sa_build_csr, anchor, B, N, M, S, _p(idx), _p(offsets), _p(order), _p(scratch))
+    return offsets, order
+
+
 def plan_from_state(flat, B, M, P):
     """a _Plan over state some earlier launch wrote (a copy of what make_row_plan(into=) filled)"""
     plan = _Plan()
@@ -1526,10 +1549,7 @@ class FusedSAStage(torch.autograd.Function):
                     d_cen = torch.empty((B, M, 3), device=dev)
                 # bucket the positions by source point, then every (point, 8-channel piece) sums its
                 # own bucket: no atomics, each dX row is read exactly once
-                offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
-                order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
-                scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
-                _call(_lib.omnipq_sa_build_csr, dX, B, N, M, S, _p(ctx.idx), _p(offsets), _p(order), _p(scratch))
+                offsets, order = _csr_of(ctx.idx, B, N, M, S, getattr(ctx, "plan", None) is not None, dX)
                 _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
                       _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
                 if dfeat_pm is not None:
@@ -1553,10 +1573,7 @@ def _backward_hoisted(ctx, dY, lay, grads, dfr, dev):
     d_xyz = d_cen = d_feat = None
     if not (want_xyz or want_feat or want_w):
         return d_xyz, d_cen, d_feat
-    offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
-    order = torch.empty((B, M * S), device=dev, dtype=torch.int32)
-    scratch = torch.empty((B, N), device=dev, dtype=torch.int32)
-    _call(_lib.omnipq_sa_build_csr, dY, B, N, M, S, _p(idx), _p(offsets), _p(order), _p(scratch))
+    offsets, order = _csr_of(idx, B, N, M, S, plan is not None, dY)
     dXr = None
     if want_xyz:
         # gradient of the relative coordinates: dY W_x (the rows cin .. cin + 7 of the transposed prepared weight: W_x^T | 0)
@@ -1656,6 +1673,8 @@ def run(module, xyz, new_xyz, features, group=None):
         if group[1] is not None:
             B_, M_, S_ = idx.shape
             idx.omnipq_plan = plan_from_state(group[1], B_, M_, B_ * M_ * S_)
+        if len(group) > 3 and group[2] is not None:
+            idx.omnipq_csr = (group[2][0], group[2][1], bool(group[3]))
     if idx is None:
         with _tagged("@sa", _STAGE_LABEL):
             idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)
