@@ -111,12 +111,23 @@ class Pointnet2Backbone(nn.Module):
                 o_csr, off = off, off + r4(B * (n_src + 1)) + r4(P)
             levels.append((name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr))
             n_src = M
-        return off, levels
+        # the two feature-propagation modules (fp1: sa3 <- sa4, fp2: sa2 <- sa3): 3-NN weights / indices and the CSR of their
+        # backward, per (unknown level, known level)
+        fps = []
+        for u, k in ((2, 3), (1, 2)):
+            n, m = levels[u][1], levels[k][1]
+            o_w, off = off, off + r4(B * n * 3)
+            o_i, off = off, off + r4(B * n * 3)
+            o_o, off = off, off + r4(B * (m + 1))
+            o_r, off = off, off + r4(B * n * 3)
+            fps.append((u, k, n, m, o_w, o_i, o_o, o_r))
+        return off, levels, fps
 
     def _group_views(self, flat, B, n_points):
-        """flat int32 -> [(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None, (offsets, order) | None)] per stage"""
+        """flat int32 -> ([(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None, (offsets, order) | None)] per stage,
+        [(unknown level, known level, weight (B,n,3) f32, idx (B,n,3) i32, offsets (B,m+1), order (B,3n))] per FP module)"""
         import sa_fused
-        total, levels = self._group_layout(B, n_points)
+        total, levels, fp_layout = self._group_layout(B, n_points)
         out = []
         r4 = lambda n: (n + 3) // 4 * 4
         for name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr in levels:
@@ -129,7 +140,12 @@ class Pointnet2Backbone(nn.Module):
                 o2 = o_csr + r4(B * (n_src + 1))
                 csr = (flat[o_csr:o_csr + B * (n_src + 1)].view(B, n_src + 1), flat[o2:o2 + P].view(B, M * S))
             out.append((cen, idx, st, csr))
-        return out
+        fp_views = []
+        for u, k, n, m, o_w, o_i, o_o, o_r in fp_layout:
+            fp_views.append((u, k, flat[o_w:o_w + B * n * 3].view(torch.float32).view(B, n, 3),
+                                   flat[o_i:o_i + B * n * 3].view(B, n, 3), flat[o_o:o_o + B * (m + 1)].view(B, m + 1),
+                                   flat[o_r:o_r + B * n * 3].view(B, n * 3)))
+        return out, fp_views
 
     def _launch_plan(self, pointcloud, trusted=False, small=False, group=False):
         """FPS chain for `pointcloud` on the side stream -> {"key", "inds": [4 x (B,npoint) int32],
@@ -143,7 +159,7 @@ class Pointnet2Backbone(nn.Module):
                 "extra": None, "group": None}
         ext = pointnet2_utils._ext
         group = bool(group) and GROUP_AHEAD and hasattr(ext, "set_timing_sink")
-        gflat, gviews, gsrc = None, None, []
+        gflat, gviews, gfp, gsrc = None, None, None, []
         if group:
             B0, n0 = pointcloud.shape[0], pointcloud.shape[1]
             gkey = ("group", B0, n0, str(pointcloud.device))
@@ -151,7 +167,7 @@ class Pointnet2Backbone(nn.Module):
             if gkey not in store:
                 store[gkey] = torch.zeros((self._group_layout(B0, n0)[0],), device=pointcloud.device, dtype=torch.int32)
             gflat = store[gkey]
-            gviews = self._group_views(gflat, B0, n0)
+            gviews, gfp = self._group_views(gflat, B0, n0)
             if not torch.cuda.is_current_stream_capturing():
                 gflat.record_stream(side)
         if not torch.cuda.is_current_stream_capturing():
@@ -212,6 +228,9 @@ class Pointnet2Backbone(nn.Module):
                             # in the row space the stage will run in: compact under a plan (a planned stage = training)
                             sa_fused.build_csr_ahead(idx, gsrc[li].shape[1], rp if mod.training else None, csr[0], csr[1])
                     planned.append(rp is not None and mod.training)
+                for u, k, w, i3, offs, order in gfp:
+                    ext.three_nn_weights(gviews[u][0], gviews[k][0], out=(w, i3))
+                    sa_fused.build_csr_ahead(i3, gviews[k][0].shape[1], None, offs, order)
                 g_ev = torch.cuda.Event()
                 g_ev.record(side)
                 plan["group"] = (gflat, g_ev, planned)
@@ -291,8 +310,10 @@ class Pointnet2Backbone(nn.Module):
             # made ahead of the stages (GROUP_AHEAD): one copy of the chain's flat buffer, views per stage
             gflat, g_ev, planned = plan["group"]
             torch.cuda.current_stream(pointcloud.device).wait_event(g_ev)
-            groups = [g + (pl,) for g, pl in
-                      zip(self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1]), planned)]
+            gv, gfp = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1])
+            groups = [g + (pl,) for g, pl in zip(gv, planned)]
+            for u, k, w, i3, offs, order in gfp:                         # the FP modules find theirs on the unknown centres
+                groups[u][0].omnipq_nn = (groups[k][0], w, i3, (offs, order))
         pending, self._pending = getattr(self, "_pending", None), None
         if pending is not None:
             if plan is not None:

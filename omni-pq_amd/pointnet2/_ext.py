@@ -287,17 +287,23 @@ def three_nn(unknowns, knows):
     return [dist2, idx]
 
 
-def three_nn_weights(unknowns, knows):
+def three_nn_weights(unknowns, knows, out=None):
     """(B,n,3), (B,m,3) -> (weight (B,n,3) f32, idx (B,n,3) i32): three_nn and the normalised inverse-distance weights of
-    pointnet2_modules.py:395-397 in one launch."""
+    pointnet2_modules.py:395-397 in one launch.  out = (weight, idx): write into these contiguous tensors."""
     _check(unknowns, "unknowns", torch.float32)
     _check(knows, "knows", torch.float32, cuda_like=unknowns)
     _need_gpu(unknowns)
     b, n = unknowns.shape[0], unknowns.shape[1]
     m = knows.shape[1]
-    idx = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.int32)
     dist2 = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
-    weight = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
+    if out is None:
+        idx = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.int32)
+        weight = torch.empty((b, n, 3), device=unknowns.device, dtype=torch.float32)
+    else:
+        weight, idx = out
+        if not (weight.dtype == torch.float32 and idx.dtype == torch.int32 and weight.is_contiguous() and idx.is_contiguous()
+                and tuple(weight.shape) == (b, n, 3) and tuple(idx.shape) == (b, n, 3)):
+            raise ValueError("three_nn_weights: out must be contiguous (B, n, 3) float32 / int32 tensors")
     _run(_lib0.omnipq_three_nn_weights, unknowns, b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), _ptr(weight))
     return weight, idx
 

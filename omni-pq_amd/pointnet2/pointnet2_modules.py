@@ -297,7 +297,11 @@ def _fp_forward_rows(self, unknown, known, unknow_feats, known_feats):
             return None
     if known_pm is None or C2 % 8:
         return None
-    if unknown.dtype == torch.float32 and known.dtype == torch.float32 and not (unknown.requires_grad or known.requires_grad):
+    pre = getattr(unknown, "omnipq_nn", None)        # made ahead by the backbone's sampling chain: (known, weight, idx, csr)
+    if pre is not None and pre[0] is known and not (unknown.requires_grad or known.requires_grad):
+        weight, idx = pre[1], pre[2]
+        idx.omnipq_csr3 = pre[3]
+    elif unknown.dtype == torch.float32 and known.dtype == torch.float32 and not (unknown.requires_grad or known.requires_grad):
         weight, idx = pointnet2_utils._ext.three_nn_weights(unknown.contiguous(), known.contiguous())   # one launch
     else:
         dist, idx = pointnet2_utils.three_nn(unknown, known)

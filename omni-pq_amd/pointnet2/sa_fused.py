@@ -1710,6 +1710,7 @@ class FPGatherRows(torch.autograd.Function):
         if C1:
             _call(_lib.omnipq_place_rows, rows, ctypes.c_longlong(B * n), C1, _p(skip_pm), _p(rows), C2 + C1, C2)
         ctx.save_for_backward(idx, weight)
+        ctx.pre_csr = getattr(idx, "omnipq_csr3", None)     # (offsets (B, m+1), order (B, 3n)) made ahead of the module, or None
         ctx.geom = (B, n, m, C2, C1, known_feats.dtype, None if skip_feats is None else skip_feats.dtype)
         return rows
 
@@ -1723,10 +1724,14 @@ class FPGatherRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # bucket the (unknown point, slot) pairs by the known point they read, then sum bucket-wise: no atomics
             dk = torch.empty((B, m, C2), device=g.device, dtype=torch.float32)
-            offsets = torch.empty((B, m + 1), device=g.device, dtype=torch.int32)
-            order = torch.empty((B, 3 * n), device=g.device, dtype=torch.int32)
-            scratch = torch.empty((B, m), device=g.device, dtype=torch.int32)
-            _call(_lib.omnipq_sa_build_csr, g, B, m, n, 3, _p(idx), _p(offsets), _p(order), _p(scratch))
+            pre = ctx.pre_csr
+            if pre is not None and tuple(pre[0].shape) == (B, m + 1) and tuple(pre[1].shape) == (B, 3 * n):
+                offsets, order = pre
+            else:
+                offsets = torch.empty((B, m + 1), device=g.device, dtype=torch.int32)
+                order = torch.empty((B, 3 * n), device=g.device, dtype=torch.int32)
+                scratch = torch.empty((B, m), device=g.device, dtype=torch.int32)
+                _call(_lib.omnipq_sa_build_csr, g, B, m, n, 3, _p(idx), _p(offsets), _p(order), _p(scratch))
             _call(_lib.omnipq_interp_rows_grad_csr, g, B, n, m, C2, _p(g), C2 + C1, 0, _p(offsets), _p(order), _p(weight),
                   _p(dk))
             d_known = dk.to(kdt).transpose(1, 2)
