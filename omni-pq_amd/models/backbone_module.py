@@ -101,6 +101,7 @@ class Pointnet2Backbone(nn.Module):
             mod = getattr(self, name)
             M, S = mod.npoint, mod.nsample
             P = B * M * S
+            o_inds, off = off, off + r4(B * M)
             o_xyz, off = off, off + r4(B * M * 3)
             o_idx, off = off, off + r4(P)
             o_plan = None
@@ -109,7 +110,7 @@ class Pointnet2Backbone(nn.Module):
             o_csr = None
             if name != "sa1":           # stages with features: the CSR "which grouped positions read point k" of their backward
                 o_csr, off = off, off + r4(B * (n_src + 1)) + r4(P)
-            levels.append((name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr))
+            levels.append((name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr, o_inds))
             n_src = M
         # the two feature-propagation modules (fp1: sa3 <- sa4, fp2: sa2 <- sa3): 3-NN weights / indices and the CSR of their
         # backward, per (unknown level, known level)
@@ -121,16 +122,22 @@ class Pointnet2Backbone(nn.Module):
             o_o, off = off, off + r4(B * (m + 1))
             o_r, off = off, off + r4(B * n * 3)
             fps.append((u, k, n, m, o_w, o_i, o_o, o_r))
-        return off, levels, fps
+        # the sampled indices themselves (copied in at the end of the chain) and the extra level's
+        extra = None
+        if self.plan_extra:
+            (ename, en), = list(self.plan_extra.items())[:1]
+            extra = (ename, en, off)
+            off += r4(B * en)
+        return off, levels, fps, extra
 
     def _group_views(self, flat, B, n_points):
         """flat int32 -> ([(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None, (offsets, order) | None)] per stage,
         [(unknown level, known level, weight (B,n,3) f32, idx (B,n,3) i32, offsets (B,m+1), order (B,3n))] per FP module)"""
         import sa_fused
-        total, levels, fp_layout = self._group_layout(B, n_points)
+        total, levels, fp_layout, extra_layout = self._group_layout(B, n_points)
         out = []
         r4 = lambda n: (n + 3) // 4 * 4
-        for name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr in levels:
+        for name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr, o_inds in levels:
             P = B * M * S
             cen = flat[o_xyz:o_xyz + B * M * 3].view(torch.float32).view(B, M, 3)
             idx = flat[o_idx:o_idx + P].view(B, M, S)
@@ -139,13 +146,15 @@ class Pointnet2Backbone(nn.Module):
             if o_csr is not None:
                 o2 = o_csr + r4(B * (n_src + 1))
                 csr = (flat[o_csr:o_csr + B * (n_src + 1)].view(B, n_src + 1), flat[o2:o2 + P].view(B, M * S))
-            out.append((cen, idx, st, csr))
+            out.append((cen, idx, st, csr, flat[o_inds:o_inds + B * M].view(B, M)))
         fp_views = []
         for u, k, n, m, o_w, o_i, o_o, o_r in fp_layout:
             fp_views.append((u, k, flat[o_w:o_w + B * n * 3].view(torch.float32).view(B, n, 3),
                                    flat[o_i:o_i + B * n * 3].view(B, n, 3), flat[o_o:o_o + B * (m + 1)].view(B, m + 1),
                                    flat[o_r:o_r + B * n * 3].view(B, n * 3)))
-        return out, fp_views
+        extra = None if extra_layout is None else \
+            (extra_layout[0], flat[extra_layout[2]:extra_layout[2] + B * extra_layout[1]].view(B, extra_layout[1]))
+        return out, fp_views, extra
 
     def _launch_plan(self, pointcloud, trusted=False, small=False, group=False):
         """FPS chain for `pointcloud` on the side stream -> {"key", "inds": [4 x (B,npoint) int32],
@@ -167,7 +176,7 @@ class Pointnet2Backbone(nn.Module):
             if gkey not in store:
                 store[gkey] = torch.zeros((self._group_layout(B0, n0)[0],), device=pointcloud.device, dtype=torch.int32)
             gflat = store[gkey]
-            gviews, gfp = self._group_views(gflat, B0, n0)
+            gviews, gfp, gextra = self._group_views(gflat, B0, n0)
             if not torch.cuda.is_current_stream_capturing():
                 gflat.record_stream(side)
         if not torch.cuda.is_current_stream_capturing():
@@ -220,7 +229,8 @@ class Pointnet2Backbone(nn.Module):
                 planned = []
                 for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
                     mod = getattr(self, name)
-                    cen, idx, st, csr = gviews[li]
+                    cen, idx, st, csr, ginds = gviews[li]
+                    ginds.copy_(plan["inds"][li])
                     with sa_fused._tagged("@sa", name):
                         ext.ball_query(cen, gsrc[li], mod.radius, mod.nsample, out=idx)
                         rp = sa_fused.make_row_plan(idx, idx.numel(), into=st) if st is not None else None
@@ -231,6 +241,8 @@ class Pointnet2Backbone(nn.Module):
                 for u, k, w, i3, offs, order in gfp:
                     ext.three_nn_weights(gviews[u][0], gviews[k][0], out=(w, i3))
                     sa_fused.build_csr_ahead(i3, gviews[k][0].shape[1], None, offs, order)
+                if gextra is not None and plan["extra"] is not None and plan["extra"][0] == gextra[0]:
+                    gextra[1].copy_(plan["extra"][1])
                 g_ev = torch.cuda.Event()
                 g_ev.record(side)
                 plan["group"] = (gflat, g_ev, planned)
@@ -310,8 +322,14 @@ class Pointnet2Backbone(nn.Module):
             # made ahead of the stages (GROUP_AHEAD): one copy of the chain's flat buffer, views per stage
             gflat, g_ev, planned = plan["group"]
             torch.cuda.current_stream(pointcloud.device).wait_event(g_ev)
-            gv, gfp = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1])
-            groups = [g + (pl,) for g, pl in zip(gv, planned)]
+            gv, gfp, gex = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1])
+            groups = [g[:4] + (pl,) for g, pl in zip(gv, planned)]
+            # the indices travel in the same copy: nothing else of this plan is read below
+            taken = [g[4] for g in gv]
+            if gex is not None and plan["extra"] is not None and plan["extra"][0] == gex[0]:
+                self._extra = (gex[0], gex[1], None)
+                plan = dict(plan, extra=None)
+            plan = dict(plan, inds=None)
             for u, k, w, i3, offs, order in gfp:                         # the FP modules find theirs on the unknown centres
                 groups[u][0].omnipq_nn = (groups[k][0], w, i3, (offs, order))
         pending, self._pending = getattr(self, "_pending", None), None
@@ -320,6 +338,8 @@ class Pointnet2Backbone(nn.Module):
                 # the next plan starts below and reuses this plan's buffers: copy everything it holds NOW
                 cur = torch.cuda.current_stream(pointcloud.device)
                 for li in range(4):
+                    if plan["inds"] is None:
+                        break                          # (they came with the group's copy)
                     cur.wait_event(plan["events"][li])
                     taken[li] = plan["inds"][li].clone()
                 if plan["extra"] is not None:
@@ -330,7 +350,7 @@ class Pointnet2Backbone(nn.Module):
             self._plan = self._launch_plan(*pending)
         for li, name in enumerate(("sa1", "sa2", "sa3", "sa4")):
             inds = taken[li]
-            if plan is not None:
+            if plan is not None and plan["inds"] is not None:
                 torch.cuda.current_stream(pointcloud.device).wait_event(plan["events"][li])
                 inds = plan["inds"][li].clone()        # the plan's buffers are reused by the next plan
             if groups[li] is not None and inds is not None:
