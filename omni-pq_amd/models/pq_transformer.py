@@ -40,6 +40,7 @@ from sa_fused import E16  # noqa: E402
 # "capture": overlap the decoder's key sides on a side stream while a hipGraph is being captured (in eager mode the
 # extra stream switches cost more host time than the overlap returns); tests set "always" / "inline"
 _OVERLAP_KEY_SIDE = "capture"
+_KEY_SIDE_EARLY = True      # fork the key sides right behind the backbone (see PQ_Transformer._forward)
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
 # here on row-major activations (points x channels) through F.linear -- one GEMM with the bias in its
 # epilogue -- instead of Conv1d on (B, C, K): same arithmetic, no layout-shuffling copies around every call,
@@ -673,6 +674,18 @@ class PQ_Transformer(nn.Module):
             seed_features = sa_fused.WgradFlushPoint.apply(
                 seed_features, lambda dev=seed_features.device: self._flush_stream(dev))
 
+        # The decoder's memory and the six layers' key / value sides depend on the seeds only: with _KEY_SIDE_EARLY their
+        # side-stream chain (~30 launches) forks HERE, underneath the voting module, the vote aggregation (whose sampling is
+        # 256 dependent rounds on eight CUs) and the proposal heads, instead of underneath the first decoder layers.
+        key = key_sides = None
+        key_pos = seed_xyz
+        overlap = _OVERLAP_KEY_SIDE == "always" or \
+            (_OVERLAP_KEY_SIDE == "capture" and seed_features.is_cuda and torch.cuda.is_current_stream_capturing())
+        if _KEY_SIDE_EARLY and overlap and transformer_mod._USE_ROWS:
+            key = conv1x1(seed_features, self.decoder_key_proj)
+            if all(decoder_rows.usable(layer, key, key) for layer in self.decoder):
+                key_sides = decoder_rows.precompute_key_sides(list(self.decoder), key, key_pos)
+
         # layout branch: FPS over the seeds
         quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features, self.backbone.take_extra("sa2"))
         end_points['aggregated_sample_xyz'] = quad_xyz
@@ -719,16 +732,15 @@ class PQ_Transformer(nn.Module):
 
         query_joint = torch.cat(conv1x1_pair(cluster_feature, self.decoder_query_proj,
                                              quad_feature, self.quad_decoder_query_proj), -1)
-        key = conv1x1(seed_features, self.decoder_key_proj)
-        key_pos = seed_xyz
+        if key is None:
+            key = conv1x1(seed_features, self.decoder_key_proj)
 
         # every layer attends to the same memory: their key/value sides run ahead on a side stream
-        key_sides = [None] * self.num_layer
-        overlap = _OVERLAP_KEY_SIDE == "always" or \
-            (_OVERLAP_KEY_SIDE == "capture" and key.is_cuda and torch.cuda.is_current_stream_capturing())
-        if overlap and transformer_mod._USE_ROWS and \
-                all(decoder_rows.usable(layer, query_joint, key) for layer in self.decoder):
-            key_sides = decoder_rows.precompute_key_sides(list(self.decoder), key, key_pos)
+        if key_sides is None:
+            key_sides = [None] * self.num_layer
+            if overlap and transformer_mod._USE_ROWS and \
+                    all(decoder_rows.usable(layer, query_joint, key) for layer in self.decoder):
+                key_sides = decoder_rows.precompute_key_sides(list(self.decoder), key, key_pos)
 
         for i in range(self.num_layer):
             prefix = 'last_' if (i == self.num_layer - 1) else f'{i}head_'
