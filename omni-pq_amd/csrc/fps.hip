@@ -435,6 +435,94 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(
   }
 }
 
+// ---- one WAVE per scene (256 < n <= 1024) ----------------------------------------------------------------------------------
+// The small clouds of the model (1024 seeds -> 512 / 256, 512 -> 256) are 255-511 rounds whose cost is synchronisation, not
+// arithmetic: with 512 threads a round was wave argmax -> LDS slot -> barrier -> second argmax over the eight wave winners
+// (0.6-0.9 us for 2 distance updates per lane).  A single wave holding PPT = 8 / 16 points per lane needs neither LDS nor a
+// barrier: a round is the lean update (see LEAN above; 11 VALU instructions per point), ONE argmax on the DPP network and three
+// readlanes.  Tie order: lane l holds the points k = l + 64 i; with the reference's block size bs = 64 r their tie keys are
+// (bitrev(l) << log2 r | bitrev_r(i mod r), k), so among a lane's points the order is (bitrev_r(i mod r), i / r): the register
+// slots are loaded in THAT order (slot j <-> i = bitrev_r(j / (PPT / r)) + r * (j % (PPT / r))) and a strict '>' over
+// increasing slots keeps the reference's winner.  One vote-aggregation sampling (1024 -> 256) sits on the main stream of a
+// training step: 226 -> ~130 us.
+__device__ __forceinline__ int wave_slot_point(int j, int r_log2, int ppt_log2, int lane) {
+  const int q_log2 = ppt_log2 - r_log2;                       // PPT / r points per residue class
+  const int a = j >> q_log2, b = j & ((1 << q_log2) - 1);
+  const int ra = r_log2 ? (int)(__brev((unsigned)a) >> (32 - r_log2)) : 0;
+  return lane + 64 * (ra + (b << r_log2));
+}
+
+template <int PPT>
+__global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int bs_mask, const float *__restrict__ dataset,
+                                                      float *__restrict__ temp, int *__restrict__ idxs) {
+  constexpr int PPT_LOG2 = PPT == 16 ? 4 : (PPT == 8 ? 3 : 2);
+  const int lane = (int)threadIdx.x;
+  const int scene = (int)blockIdx.x;
+  dataset += (size_t)scene * n * 3;
+  temp += (size_t)scene * n;
+  idxs += (size_t)scene * m;
+  const int r_log2 = __builtin_popcount((unsigned)bs_mask) - 6;        // bs = 64 r, 4 <= r <= PPT (the host checks)
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+  unsigned live = 0;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int k = wave_slot_point(j, r_log2, PPT_LOG2, lane);
+    px[j] = py[j] = pz[j] = __builtin_nanf("");                        // unselectable: see LEAN
+    pt[j] = -2.f;
+    if (k < n) {
+      const float x = dataset[k * 3 + 0], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
+      const float mag = sumsq3(x, y, z);
+      if (!((double)mag <= 1e-3)) {                                      // sampling_gpu.cu:105-106
+        live |= 1u << j;
+        px[j] = x, py[j] = y, pz[j] = z;
+        pt[j] = temp[k];
+      }
+    }
+  }
+  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+  float x1 = x0, y1 = y0, z1 = z0;
+  if (lane == 0) idxs[0] = 0;
+  for (int jr = 1; jr < m; ++jr) {
+    float bd2 = -1.f;
+    int bi = 0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const float d = sumsq3(px[j] - x1, py[j] - y1, pz[j] - z1);
+      const float t = d < pt[j] ? d : pt[j];
+      pt[j] = t;
+      if (t > bd2) {
+        bd2 = t;
+        bi = j;
+      }
+    }
+    unsigned bc = bd2 < 0.f ? kNoKey : tie_key(wave_slot_point(bi, r_log2, PPT_LOG2, lane), bs_mask);
+    const float md2 = bd2;
+    const unsigned mc = bc;
+    wave_argmax(bd2, bc);
+    const unsigned long long owners = __ballot(md2 == bd2 && mc == bc);
+    const int src = owners ? (int)__builtin_ctzll(owners) : 0;
+    const int slot = __builtin_amdgcn_readlane(bi, src);
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      if (slot == j) {
+        wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px[j]), src));
+        wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py[j]), src));
+        wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz[j]), src));
+      }
+    const bool none = bd2 < 0.f;         // nothing selectable: the reference falls back to index 0
+    x1 = none ? x0 : wx;
+    y1 = none ? y0 : wy;
+    z1 = none ? z0 : wz;
+    if (lane == 0) idxs[jr] = none ? 0 : (int)(bc & kKMask);
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int k = wave_slot_point(j, r_log2, PPT_LOG2, lane);
+    if (k < n && ((live >> j) & 1u)) temp[k] = pt[j];
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------
 // Exchange slots of the multi-workgroup kernel.  One block per (device, STREAM): launches on one stream run one
 // after the other and may share it, launches on different streams may overlap (a model and its EMA teacher
@@ -642,8 +730,17 @@ extern "C" int omnipq_furthest_point_sampling_ex(int b, int n, int m, const floa
   if (n <= 256) return launch_single<256, 1>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   // (measured per round at b = 8: 512 threads x 1-2 points beat 256 x 2-4 by ~7 %, 64-128 threads x 8-16 are
   // 25-65 % slower, 1024 x 1 is slower again: the per-lane update is short, the block argmax grows with waves)
-  if (n <= 512) return launch_single<512, 1>(b, n, m, bs_mask, dataset, temp, idxs, stream);
-  if (n <= 1024) return launch_single<512, 2>(b, n, m, bs_mask, dataset, temp, idxs, stream);
+  // 256 < n <= 1024: one wave per scene (fps_wave_kernel); bs = 256 / 512 / 1024 = 64 r with r <= PPT
+  if (n <= 512) {
+    fps_wave_kernel<8><<<b, 64, 0, stream>>>(n, m, bs_mask, dataset, temp, idxs);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
+  if (n <= 1024) {
+    fps_wave_kernel<16><<<b, 64, 0, stream>>>(n, m, bs_mask, dataset, temp, idxs);
+    OMNIPQ_LAUNCH_CHECK();
+    return OMNIPQ_OK;
+  }
   if (n <= 2048) return launch_single<512, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 4096) return launch_single<1024, 4>(b, n, m, bs_mask, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_single<1024, 8>(b, n, m, bs_mask, dataset, temp, idxs, stream);
