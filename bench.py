@@ -849,6 +849,11 @@ def main():
         # steps over the same batches (same kernels, same shapes; rocprofv3 of this command sees both and its
         # averages agree).  Under torch.distributed they are this rank's own steps (SyncBN collectives included,
         # no gradient all-reduce).
+        # (the per-kernel durations are taken with every SA-stage kernel IN LINE on the main stream: with GROUP_AHEAD the
+        # ball queries / row plans / CSR builds of the stages run inside the sampling chain, next to whatever the main stream
+        # is doing, and an event pair around them measures that contention, not the kernel)
+        import backbone_module as _bbm
+        _group_ahead, _bbm.GROUP_AHEAD = _bbm.GROUP_AHEAD, False
         eager_args = argparse.Namespace(**{**vars(args), "graph": "off"})
         eager_step, _ = make_step(net, net, pool, eager_args, amp_dtype, world, teacher=teacher,
                                   teacher_pool=teacher_pool, labels_pool=labels_pool)
@@ -876,9 +881,12 @@ def main():
             eager_step(1 + i)
             fence()
         ext.set_timing_sink(None)
+        _bbm.GROUP_AHEAD = _group_ahead
         timing_note = (f"events around every C-ABI launch in {timing_steps} eager steps run right after the timed "
                        + ("hipGraph replays (a replay cannot host events)" if use_graph else "steps")
-                       + (", each enqueued behind a device-side stall so that the launches run back to back" if stall else ""))
+                       + (", each enqueued behind a device-side stall so that the launches run back to back" if stall else "")
+                       + ("; the stages' ball queries / row plans / CSR builds, which the replayed step runs inside the sampling "
+                          "chain (backbone_module.GROUP_AHEAD), are timed in line here" if _group_ahead else ""))
     assert torch.isfinite(loss.detach()).item(), "non-finite loss"
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

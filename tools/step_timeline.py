@@ -25,7 +25,8 @@ def main():
     step = rows[a:b]
     t0 = step[0][0]
     span = (rows[b][0] - t0) / 1e3
-    other = [r for r in step if "fps_kernel" not in r[2]]
+    is_fps = lambda n: "fps_kernel" in n or "fps_wave_kernel" in n
+    other = [r for r in step if not is_fps(r[2])]
     cur_s, cur_e, busy = other[0][0], other[0][1], 0
     for s, e, _ in other[1:]:
         if s > cur_e:
@@ -34,12 +35,12 @@ def main():
         else:
             cur_e = max(cur_e, e)
     busy = (busy + cur_e - cur_s) / 1e3
-    fps = [(r[1] - r[0]) / 1e3 for r in step if "fps_kernel" in r[2]]
+    fps = [(r[1] - r[0]) / 1e3 for r in step if is_fps(r[2])]
     with open(out, "w") as fh:
         fh.write(f"One replayed step of `bench.py` under `rocprofv3 --kernel-trace` (launch to launch of the sa1 sampling kernel): "
                  f"{len(step)} launches, {span:.0f} us from sampling launch to sampling launch (the profiler stretches the step; "
                  f"unprofiled: the bench line's ms_per_step).\n\n")
-        fh.write(f"* sampling chain (side stream): {len(fps)} launches, {sum(fps):.0f} us, the first {fps[0]:.0f} us\n")
+        fh.write(f"* sampling kernels (the chain on the side stream + the vote aggregation's on the main stream; the chain's grouping kernels, backbone_module.GROUP_AHEAD, are counted with everything else): {len(fps)} launches, {sum(fps):.0f} us, the first {fps[0]:.0f} us\n")
         fh.write(f"* everything else: {len(other)} launches, sum of durations {sum((r[1] - r[0]) for r in other) / 1e3:.0f} us, "
                  f"union of their busy intervals {busy:.0f} us\n\n")
         fh.write("| launch duration | launches | sum us |\n|---|---|---|\n")
