@@ -355,6 +355,9 @@ class DecodePair(torch.autograd.Function):
         ctx.save_for_backward(yh, means, yq, norm)
         ctx.geom = (B, K, nh, ns, ncls, scale, Bq, Kq)
         ctx.sink = sink
+        # (an output nobody differentiates -- always the positions, with a supervised loss some of the others -- arrives in
+        # backward as None, which _grad_descriptors passes on as a null pointer, instead of as a zero tensor autograd fills)
+        ctx.set_materialize_grads(False)
         if pos is None:
             return tuple(outs_h) + tuple(outs_q)
         ctx.mark_non_differentiable(pos)
