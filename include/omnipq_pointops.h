@@ -98,6 +98,13 @@ int omnipq_gather_points(int b, int c, int n, int npoints, const float *points,
  * gradient flows into xyz (the backbone: raw coordinates). */
 int omnipq_gather_xyz(int b, int n, int npoints, const float *xyz, const int *idx, float *out, void *stream);
 
+/* Rows of a position-major 16-bit matrix by index, and the adjoint (FPSModule, reference models/utils/pointnet_util.py:52-69,
+ * on the position-major twin of the seed features): rows (b,n,C), idx (b,P) -> out (b,P,C); C % 8 == 0.  The adjoint WRITES
+ * every row of grad (b,n,C) -- zeros where nothing was selected, f32 sums where an index repeats -- so the caller neither
+ * zero-fills nor accumulates; n <= 16384. */
+int omnipq_gather_rows_e16(int b, int n, int P, int C, const void *rows, const int *idx, void *out, void *stream);
+int omnipq_gather_rows_e16_grad(int b, int n, int P, int C, const void *g, const int *idx, void *grad, void *stream);
+
 /* replaces gather_points_grad_kernel_wrapper (sampling.cpp:14-16).
  *   grad_out (b,c,npoints), idx (b,npoints) -> grad_points (b,c,n), which the caller
  *   zero-fills (sampling.cpp:57-59); contributions are accumulated with f32 atomics. */

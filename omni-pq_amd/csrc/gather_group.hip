@@ -257,6 +257,69 @@ static int launch_scatter(int b, int c, int n, int P, const float *grad_out, con
   return OMNIPQ_OK;
 }
 
+
+// ---- rows of a position-major 16-bit matrix by index, and the adjoint ----------------------------------------------------
+// out[b][p][:] = rows[b][idx[b][p]][:] (C % 8 == 0: 16-byte pieces).  What FPSModule (models/utils/pointnet_util.py:52-69:
+// gather_operation on the (B, C, K) features) is on the position-major twin: no f32 / (B, C, K) round trip.
+__global__ __launch_bounds__(256) void gather_rows16_kernel(int n, int P, int c8, long long pieces, const uint4 *__restrict__ rows,
+                                                           const int *__restrict__ idx, uint4 *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pieces) return;
+  const long long row = i / c8;
+  const int piece = (int)(i - row * c8);
+  const long long scene = row / P;
+  out[i] = rows[((size_t)scene * n + idx[row]) * c8 + piece];
+}
+
+// The adjoint: grad[b][k][:] = sum over p with idx[b][p] == k of g[b][p][:], zero for rows nobody selected -- every output
+// row is WRITTEN (no memset, no atomics on the gradient).  A workgroup builds the scene's inverse map in LDS (first selector
+// of every row: atomicMin) and handles a slice of the rows; a row selected more than once (furthest-point sampling repeats
+// an index only when nothing is selectable any more) takes the slow path of scanning the selections, in f32.
+__global__ __launch_bounds__(256) void gather_rows16_grad_kernel(int n, int P, int c8, int rows_per_wg, const uint4 *__restrict__ g,
+                                                                const int *__restrict__ idx, uint4 *__restrict__ grad) {
+  extern __shared__ int inv[];                  // [n] first selector of row k, or 0x7fffffff; [n] = the scene has duplicates
+  const int scene = (int)blockIdx.y, tid = (int)threadIdx.x;
+  const int *ids = idx + (size_t)scene * P;
+  for (int k = tid; k <= n; k += 256) inv[k] = k < n ? 0x7fffffff : 0;
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {
+    const int k = ids[p];
+    if (k >= 0 && k < n) atomicMin(&inv[k], p);
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {
+    const int k = ids[p];
+    if (k >= 0 && k < n && inv[k] != p) inv[n] = 1;
+  }
+  __syncthreads();
+  const bool dups = inv[n] != 0;
+  const int k0 = (int)blockIdx.x * rows_per_wg;
+  const int k1 = k0 + rows_per_wg < n ? k0 + rows_per_wg : n;
+  for (long long i = (long long)k0 * c8 + tid; i < (long long)k1 * c8; i += 256) {
+    const int k = (int)(i / c8), piece = (int)(i - (long long)k * c8);
+    const int p0 = inv[k];
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (p0 != 0x7fffffff) {
+      v = g[((size_t)scene * P + p0) * c8 + piece];
+      if (dups) {
+        float acc[8];
+        const unsigned w0[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[2 * e] = e16_lo(w0[e]), acc[2 * e + 1] = e16_hi(w0[e]);
+        for (int p = p0 + 1; p < P; ++p)
+          if (ids[p] == k) {
+            const uint4 u = g[((size_t)scene * P + p) * c8 + piece];
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[2 * e] += e16_lo(w[e]), acc[2 * e + 1] += e16_hi(w[e]);
+          }
+        v = make_uint4(pack_e16x2(acc[0], acc[1]), pack_e16x2(acc[2], acc[3]), pack_e16x2(acc[4], acc[5]), pack_e16x2(acc[6], acc[7]));
+      }
+    }
+    grad[((size_t)scene * n + k) * c8 + piece] = v;
+  }
+}
+
 }  // namespace omnipq
 
 extern "C" int omnipq_gather_xyz(int b, int n, int npoints, const float *xyz, const int *idx, float *out, void *stream) {
@@ -294,4 +357,30 @@ extern "C" int omnipq_group_points_grad(int b, int c, int n, int npoints, int ns
   if ((long long)npoints * nsample > 0x7FFFFFFFll) return OMNIPQ_ETOOLARGE;
   return omnipq::launch_scatter(b, c, n, npoints * nsample, grad_out, idx, grad_points,
                                 (hipStream_t)stream);
+}
+
+// out (b, P, C) = rows (b, n, C) at idx (b, P): 16-bit elements, C % 8 == 0.
+extern "C" int omnipq_gather_rows_e16(int b, int n, int P, int C, const void *rows, const int *idx, void *out, void *stream) {
+  if (b < 0 || n < 0 || P < 0 || C < 0 || (C % 8)) return OMNIPQ_EINVAL;
+  const long long pieces = (long long)b * P * (C / 8);
+  if (pieces == 0) return OMNIPQ_OK;
+  if (!rows || !idx || !out || n == 0) return OMNIPQ_EINVAL;
+  if (pieces > 0x7FFFFFFFll * 256) return OMNIPQ_ETOOLARGE;
+  omnipq::gather_rows16_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      n, P, C / 8, pieces, (const uint4 *)rows, idx, (uint4 *)out);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// The adjoint of omnipq_gather_rows_e16: grad (b, n, C), EVERY row written (zeros where nothing was selected); n <= 16384.
+extern "C" int omnipq_gather_rows_e16_grad(int b, int n, int P, int C, const void *g, const int *idx, void *grad, void *stream) {
+  if (b < 0 || n < 0 || P < 0 || C < 0 || (C % 8)) return OMNIPQ_EINVAL;
+  if (b == 0 || n == 0 || C == 0) return OMNIPQ_OK;
+  if (!idx || !grad || (P > 0 && !g)) return OMNIPQ_EINVAL;
+  if (n > 16384 || b > 65535) return OMNIPQ_ETOOLARGE;
+  const int rows_per_wg = 64;
+  omnipq::gather_rows16_grad_kernel<<<dim3((n + rows_per_wg - 1) / rows_per_wg, b), 256, sizeof(int) * (n + 1),
+                                      (hipStream_t)stream>>>(n, P, C / 8, rows_per_wg, (const uint4 *)g, idx, (uint4 *)grad);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
 }

@@ -70,6 +70,18 @@ class FanOut(torch.autograd.Function):
             return gs[0], None
         shape, dtype = ctx.meta
         numel = gs[0].numel()
+        if len(shape) == 3 and dtype in (E16.dtype, torch.float32) and numel % 8 == 0 and len(gs) <= 16 and \
+                all(g.is_cuda and g.dtype == dtype and tuple(g.shape) == shape for g in gs) and \
+                sum(g.transpose(1, 2).is_contiguous() for g in gs) * 2 > len(gs):
+            # (B, C, P) views of position-major data (the layout every row kernel hands its gradients back in): add them as
+            # the (B, P, C) matrices they are and return the sum as the same kind of view; a stray channel-major one is
+            # transposed first.  Autograd's own accumulation takes n - 1 strided adds of 12-14 us each here.
+            rows = [g.transpose(1, 2) if g.transpose(1, 2).is_contiguous() else g.transpose(1, 2).contiguous() for g in gs]
+            if all(r.data_ptr() % 16 == 0 for r in rows):
+                out = torch.empty(rows[0].shape, device=rows[0].device, dtype=dtype)
+                ptrs = (ctypes.c_void_p * len(rows))(*[r.data_ptr() for r in rows])
+                _call(_lib.omnipq_add_n, out, len(rows), ptrs, ctypes.c_longlong(numel), int(dtype == E16.dtype), _p(out))
+                return out.transpose(1, 2), None
         if dtype in (E16.dtype, torch.float32) and numel % 8 == 0 and len(gs) <= 16 and \
                 all(g.is_cuda and g.dtype == dtype and g.is_contiguous() and g.data_ptr() % 16 == 0 and
                     tuple(g.shape) == shape for g in gs):
@@ -81,6 +93,44 @@ class FanOut(torch.autograd.Function):
         for g in gs[1:]:
             total = total + g
         return total, None
+
+
+class GatherRows(torch.autograd.Function):
+    """feats (B, C, K) [the autograd edge], its position-major 16-bit twin (B, K, C), inds (B, P) int32 -> (B, C, P): the
+    features of the selected points as a view of gathered ROWS (omnipq_gather_rows_e16) -- FPSModule's gather_operation
+    (reference models/utils/pointnet_util.py:66) without the f32 / channel-major round trip.  Backward writes the whole
+    (B, K, C) gradient in one launch (zeros where nothing was selected) and returns it as a (B, C, K) view."""
+
+    @staticmethod
+    def forward(ctx, feats, rows16, inds):
+        ctx.e16 = E16.dtype
+        B, K, C = rows16.shape
+        P = inds.shape[1]
+        out = torch.empty((B, P, C), device=rows16.device, dtype=E16.dtype)
+        _call(_lib.omnipq_gather_rows_e16, out, B, K, P, C, _p(rows16), _p(inds), _p(out))
+        ctx.save_for_backward(inds)
+        ctx.geom = (B, K, P, C, feats.dtype)
+        res = out.transpose(1, 2)
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        E16.select(ctx.e16)
+        inds, = ctx.saved_tensors
+        B, K, P, C, fdt = ctx.geom
+        gr = g.transpose(1, 2)
+        gr = gr.to(E16.dtype).contiguous()
+        grad = torch.empty((B, K, C), device=g.device, dtype=E16.dtype)
+        _call(_lib.omnipq_gather_rows_e16_grad, grad, B, K, P, C, _p(gr), _p(inds), _p(grad))
+        d = grad.transpose(1, 2)
+        return (d if fdt == E16.dtype else d.to(fdt)), None, None
+
+
+def gather_rows_usable(feats, inds):
+    rows16 = getattr(feats, "omnipq_rows16", None)
+    return rows16 is not None and feats.is_cuda and rows16.dtype == E16.dtype and rows16.is_contiguous() and \
+        rows16.dim() == 3 and tuple(rows16.shape) == (feats.shape[0], feats.shape[2], feats.shape[1]) and \
+        rows16.shape[2] % 8 == 0 and rows16.shape[1] <= 16384 and inds.dtype == torch.int32 and inds.is_contiguous()
 
 
 class SplitRows(torch.autograd.Function):

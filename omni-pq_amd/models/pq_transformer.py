@@ -40,6 +40,7 @@ from sa_fused import E16  # noqa: E402
 # "capture": overlap the decoder's key sides on a side stream while a hipGraph is being captured (in eager mode the
 # extra stream switches cost more host time than the overlap returns); tests set "always" / "inline"
 _OVERLAP_KEY_SIDE = "capture"
+_SEED_FANOUT = True         # the seed features' three consumers behind one n-ary gradient add (decoder_rows.FanOut)
 _KEY_SIDE_EARLY = True      # fork the key sides right behind the backbone (see PQ_Transformer._forward)
 # The 1x1 convolutions of heads, position embeddings and projections are per-point linear layers.  They run
 # here on row-major activations (points x channels) through F.linear -- one GEMM with the bias in its
@@ -674,8 +675,19 @@ class PQ_Transformer(nn.Module):
             # backward: when the gradient reaches this point the decoder, the heads and the voting module are done --
             # their collected weight gradients (sa_fused.deferred_wgrads) start on a side stream underneath the
             # backbone's backward pass
+            twin = getattr(seed_features, "omnipq_rows16", None)
             seed_features = sa_fused.WgradFlushPoint.apply(
                 seed_features, lambda dev=seed_features.device: self._flush_stream(dev))
+            if twin is not None:
+                seed_features.omnipq_rows16 = twin
+        # three consumers (layout branch, voting, the decoder's memory): their gradients -- (B, C, K) views of position-major
+        # rows -- meet in ONE n-ary add (decoder_rows.FanOut) instead of autograd's two strided adds
+        sf_quad = sf_vote = sf_key = seed_features
+        if _SEED_FANOUT and seed_features.is_cuda and seed_features.requires_grad and torch.is_grad_enabled():
+            twin = getattr(seed_features, "omnipq_rows16", None)
+            sf_quad, sf_vote, sf_key = decoder_rows.FanOut.apply(seed_features, 3)
+            if twin is not None:
+                sf_quad.omnipq_rows16 = sf_vote.omnipq_rows16 = sf_key.omnipq_rows16 = twin
 
         # The decoder's memory and the six layers' key / value sides depend on the seeds only: with _KEY_SIDE_EARLY their
         # side-stream chain (~30 launches) forks HERE, underneath the voting module, the vote aggregation (whose sampling is
@@ -685,17 +697,17 @@ class PQ_Transformer(nn.Module):
         overlap = _OVERLAP_KEY_SIDE == "always" or \
             (_OVERLAP_KEY_SIDE == "capture" and seed_features.is_cuda and torch.cuda.is_current_stream_capturing())
         if _KEY_SIDE_EARLY and overlap and transformer_mod._USE_ROWS:
-            key = conv1x1(seed_features, self.decoder_key_proj)
+            key = conv1x1(sf_key, self.decoder_key_proj)
             if all(decoder_rows.usable(layer, key, key) for layer in self.decoder):
                 key_sides = decoder_rows.precompute_key_sides(list(self.decoder), key, key_pos)
 
         # layout branch: FPS over the seeds
-        quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, seed_features, self.backbone.take_extra("sa2"))
+        quad_xyz, quad_feature, _ = self.fps_module(seed_xyz, sf_quad, self.backbone.take_extra("sa2"))
         end_points['aggregated_sample_xyz'] = quad_xyz
 
         # object branch: vote, normalise, aggregate
         # vote + the reference's L2 normalisation over the channels (:216-217), fused on the row kernels
-        vote_xyz, vote_features = self.vote(seed_xyz, seed_features, normalized=True)
+        vote_xyz, vote_features = self.vote(seed_xyz, sf_vote, normalized=True)
         end_points['vote_xyz'] = vote_xyz
         end_points['vote_features'] = vote_features
         cluster_xyz, cluster_feature, _ = self.vote_aggregation(vote_xyz, vote_features)
@@ -736,7 +748,7 @@ class PQ_Transformer(nn.Module):
         query_joint = torch.cat(conv1x1_pair(cluster_feature, self.decoder_query_proj,
                                              quad_feature, self.quad_decoder_query_proj), -1)
         if key is None:
-            key = conv1x1(seed_features, self.decoder_key_proj)
+            key = conv1x1(sf_key, self.decoder_key_proj)
 
         # every layer attends to the same memory: their key/value sides run ahead on a side stream
         if key_sides is None:

@@ -13,7 +13,10 @@ for _p in (_ROOT, os.path.join(_ROOT, "pointnet2")):
     if _p not in sys.path:
         sys.path.append(_p)
 
+import torch  # noqa: E402
+
 import pointnet2_utils  # noqa: E402
+E16 = getattr(pointnet2_utils._ext, "E16", None)  # noqa: E402  (the kernels' 16-bit element type; .autocast(): bf16 / fp16 autocast active?)
 
 
 class FPSModule(nn.Module):
@@ -26,7 +29,20 @@ class FPSModule(nn.Module):
         inds (extension): the sampling already done elsewhere (the backbone's sampling plan), else computed here."""
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.num_proposal)
-        flipped = xyz.transpose(1, 2).contiguous()
-        new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
-        new_features = pointnet2_utils.gather_operation(features, inds).contiguous()
+        ext = pointnet2_utils._ext
+        if xyz.is_cuda and xyz.dtype == torch.float32 and not (torch.is_grad_enabled() and xyz.requires_grad) and \
+                hasattr(ext, "gather_xyz"):
+            new_xyz = ext.gather_xyz(xyz.contiguous(), inds.contiguous())          # one launch, no layout copies
+        else:
+            flipped = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
+        new_features = None
+        if features.is_cuda and E16 is not None and E16.autocast():
+            import decoder_rows
+            if decoder_rows.gather_rows_usable(features, inds):
+                # on the position-major 16-bit twin the row kernels left on the seed features: rows in, rows out
+                new_features = decoder_rows.GatherRows.apply(features, features.omnipq_rows16, inds)
+                new_features.omnipq_rows16 = new_features.transpose(1, 2)
+        if new_features is None:
+            new_features = pointnet2_utils.gather_operation(features, inds).contiguous()
         return new_xyz, new_features, inds
