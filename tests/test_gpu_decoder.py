@@ -712,3 +712,28 @@ def test_masked_data_gradient_gemm_equals_gemm_then_relu_dropout_bwd(M, N, K, p)
     capi.ok("omnipq_gemm_nt_e16_mask", M, N, K, capi.P(A), K, capi.P(B), K, capi.P(got), N, capi.P(H), ctypes.c_float(p))
     assert torch.equal(got, want)
     assert 0.3 < float((got == 0).float().mean()) < 0.7
+
+
+@pytest.mark.gpu
+def test_fan_out_adds_position_major_views_as_rows():
+    """decoder_rows.FanOut: (B, C, P) gradients that are views of position-major data meet in ONE n-ary add on their rows
+    (a channel-major one is transposed first) -- same sum as autograd's accumulation, returned as the same kind of view."""
+    import decoder_rows
+    torch.manual_seed(0)
+    B, C, P = 2, 288, 1024
+    base = torch.randn(B, P, C, device="cuda").bfloat16()
+    x = base.transpose(1, 2).requires_grad_(True)
+    a, b, c = decoder_rows.FanOut.apply(x, 3)
+    g1 = torch.randn(B, P, C, device="cuda").bfloat16().transpose(1, 2)          # rows view
+    g2 = torch.randn(B, P, C, device="cuda").bfloat16().transpose(1, 2)          # rows view
+    g3 = torch.randn(B, C, P, device="cuda").bfloat16()                          # channel-major
+    (gx,) = torch.autograd.grad([a, b, c], [x], [g1, g2, g3])
+    want = (g1.float() + g2.float() + g3.float())
+    assert gx.transpose(1, 2).is_contiguous()
+    assert float((gx.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    # two gradients only, both channel-major: the plain contiguous path
+    x2 = torch.randn(B, C, P, device="cuda").bfloat16().requires_grad_(True)
+    a, b = decoder_rows.FanOut.apply(x2, 2)
+    h1, h2 = torch.randn_like(x2), torch.randn_like(x2)
+    (gx2,) = torch.autograd.grad([a, b], [x2], [h1, h2])
+    assert float((gx2.float() - (h1.float() + h2.float())).abs().max()) <= 2.0 ** -7 * 8

@@ -448,3 +448,48 @@ def test_gather_xyz_equals_transpose_gather_transpose():
     want = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
     assert torch.equal(got, want)
     assert pointnet2_utils._ext.gather_xyz(xyz[:, :0], idx[:, :0]).shape == (3, 0, 3)
+
+
+def test_fps_one_wave_per_scene_sizes_and_ties():
+    """256 < n <= 1024 run one wave per scene (csrc/fps.hip: fps_wave_kernel) with the register slots loaded in the
+    reference's tie order: every residue-class count r = bs / 64 in {4, 8, 16}, ragged last slots, lattice ties, duplicates."""
+    g = torch.arange(11, dtype=torch.float32)
+    lat = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3) + 1.0
+    for n, m in ((257, 257), (300, 64), (511, 200), (512, 512), (513, 100), (777, 300), (1023, 256), (1024, 1024)):
+        for xyz in (lat[:, :n].contiguous().repeat(2, 1, 1), cloud("adv", 11 + n, 2, n)):
+            want = oracle_ext.furthest_point_sampling(xyz, m)
+            got, tmp = capi.fps(xyz.to(dev()), m)
+            assert torch.equal(got.cpu(), want), (n, m, (got.cpu() != want).nonzero()[:3].tolist())
+    dup = torch.ones(2, 900, 3)
+    dup[:, 450:] += 1.0
+    got, _ = capi.fps(dup.to(dev()), 30)
+    assert torch.equal(got.cpu(), oracle_ext.furthest_point_sampling(dup, 30))
+
+
+def test_gather_rows_e16_and_its_adjoint():
+    """omnipq_gather_rows_e16 == rows[b, idx[b, p]] bit for bit; the adjoint writes EVERY row: zeros where nothing was selected,
+    the f32 sum (rounded once) where an index repeats -- against index_add on a zero tensor."""
+    gen = torch.Generator().manual_seed(3)
+    d = dev()
+    for dt in (torch.bfloat16,):
+        for (b, n, p, c) in ((2, 1024, 256, 288), (3, 700, 700, 64), (1, 16384, 5, 8)):
+            rows = torch.randn(b, n, c, generator=gen).to(dt).to(d)
+            idx = torch.stack([torch.randperm(n, generator=gen)[:p] for _ in range(b)]).int().to(d)
+            out = torch.full((b, p, c), 7.0, device=d, dtype=dt)
+            capi.ok("omnipq_gather_rows_e16", b, n, p, c, capi.P(rows), capi.P(idx), capi.P(out))
+            want = torch.gather(rows, 1, idx.long().unsqueeze(-1).expand(b, p, c))
+            assert torch.equal(out, want)
+            for dups in (False, True):
+                if dups:
+                    idx[:, : p // 2] = idx[:, p - p // 2:][:, : p // 2] if p > 1 else idx[:, : p // 2]
+                    idx[0, :3] = idx[0, 3]
+                g = torch.randn(b, p, c, generator=gen).to(dt).to(d)
+                grad = torch.full((b, n, c), 5.0, device=d, dtype=dt)          # NOT zero-filled: every row must be written
+                capi.ok("omnipq_gather_rows_e16_grad", b, n, p, c, capi.P(g), capi.P(idx), capi.P(grad))
+                ref = torch.zeros(b, n, c, device=d, dtype=torch.float32)
+                for bi in range(b):
+                    ref[bi].index_add_(0, idx[bi].long(), g[bi].float())
+                assert torch.equal(grad, ref.to(dt)), (b, n, p, c, dups)
+    null = capi.P(None)
+    assert capi.call("omnipq_gather_rows_e16", 1, 8, 4, 12, null, null, null) == 10001          # C % 8
+    assert capi.call("omnipq_gather_rows_e16_grad", 1, 20000, 4, 8, null, null, null) != 0       # n too large / null
