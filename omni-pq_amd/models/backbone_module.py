@@ -130,11 +130,13 @@ class Pointnet2Backbone(nn.Module):
             off += r4(B * en)
         return off, levels, fps, extra
 
-    def _group_views(self, flat, B, n_points):
+    def _group_views(self, flat, B, n_points, layout=None):
         """flat int32 -> ([(centres (B,M,3) f32, idx (B,M,S) i32, plan state (flat i32) | None, (offsets, order) | None)] per stage,
         [(unknown level, known level, weight (B,n,3) f32, idx (B,n,3) i32, offsets (B,m+1), order (B,3n))] per FP module)"""
         import sa_fused
-        total, levels, fp_layout, extra_layout = self._group_layout(B, n_points)
+        # layout: the one the buffer was FILLED with (kept in the plan: a switch flipped between a chain's launch and the
+        # forward that consumes it must not move the pieces)
+        total, levels, fp_layout, extra_layout = layout if layout is not None else self._group_layout(B, n_points)
         out = []
         r4 = lambda n: (n + 3) // 4 * 4
         for name, M, S, n_src, o_xyz, o_idx, o_plan, o_csr, o_inds in levels:
@@ -173,10 +175,11 @@ class Pointnet2Backbone(nn.Module):
             B0, n0 = pointcloud.shape[0], pointcloud.shape[1]
             gkey = ("group", B0, n0, str(pointcloud.device))
             store = self.__dict__.setdefault("_plan_bufs", {})
-            if gkey not in store:
-                store[gkey] = torch.zeros((self._group_layout(B0, n0)[0],), device=pointcloud.device, dtype=torch.int32)
+            glayout = self._group_layout(B0, n0)
+            if gkey not in store or store[gkey].numel() < glayout[0]:
+                store[gkey] = torch.zeros((glayout[0],), device=pointcloud.device, dtype=torch.int32)
             gflat = store[gkey]
-            gviews, gfp, gextra = self._group_views(gflat, B0, n0)
+            gviews, gfp, gextra = self._group_views(gflat, B0, n0, glayout)
             if not torch.cuda.is_current_stream_capturing():
                 gflat.record_stream(side)
         if not torch.cuda.is_current_stream_capturing():
@@ -245,7 +248,7 @@ class Pointnet2Backbone(nn.Module):
                     gextra[1].copy_(plan["extra"][1])
                 g_ev = torch.cuda.Event()
                 g_ev.record(side)
-                plan["group"] = (gflat, g_ev, planned)
+                plan["group"] = (gflat, g_ev, planned, glayout, sa_fused.PLAN_GROUP)
         return plan
 
     def prefetch(self, pointcloud, trusted=False, at_next_forward=False, footprint=None):
@@ -320,10 +323,14 @@ class Pointnet2Backbone(nn.Module):
         groups = [None] * 4
         if plan is not None and plan.get("group") is not None:
             # made ahead of the stages (GROUP_AHEAD): one copy of the chain's flat buffer, views per stage
-            gflat, g_ev, planned = plan["group"]
+            gflat, g_ev, planned, glayout, gs_then = plan["group"]
             torch.cuda.current_stream(pointcloud.device).wait_event(g_ev)
-            gv, gfp, gex = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1])
-            groups = [g[:4] + (pl,) for g, pl in zip(gv, planned)]
+            gv, gfp, gex = self._group_views(gflat.clone(), pointcloud.shape[0], pointcloud.shape[1], glayout)
+            import sa_fused
+            if gs_then != sa_fused.PLAN_GROUP:        # plans (and the CSRs in their row space) of another group size: not these
+                groups = [(g[0], g[1], None, None, False) for g in gv]
+            else:
+                groups = [g[:4] + (pl,) for g, pl in zip(gv, planned)]
             # the indices travel in the same copy: nothing else of this plan is read below
             taken = [g[4] for g in gv]
             if gex is not None and plan["extra"] is not None and plan["extra"][0] == gex[0]:
