@@ -114,6 +114,11 @@ int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const floa
 int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_e16, const float *norm,
                            const float *g_xyz, const void *g_feat, void *dnet, int ldd, void *dseed_feat, void *stream);
 
+/* The same backward on position-major operands: vote_rows = the forward's twin16, g_rows / dseed_rows e16 [b*k][c] (what a
+ * (b,c,k) view of row data is underneath), c % 8 == 0, ldd % 8 == 0; g_xyz, g_rows, dseed_rows may be NULL. */
+int omnipq_vote_decode_bwd_rows(long long rows, int c, const void *vote_rows, const float *norm, const float *g_xyz,
+                                const void *g_rows, void *dnet, int ldd, void *dseed_rows, void *stream);
+
 /* out[i] = sum_s src[s][i], i < n: up to 16 sources of one type (e16: is_e16 != 0, f32 accumulation, one rounding;
  * else f32), n % 8 == 0, all pointers 16-byte aligned; out may be one of the sources.  The fan-in of a tensor that feeds
  * several consumers (autograd: count - 1 accumulation launches, each re-reading the running sum). */

@@ -675,6 +675,57 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
     dnet[((size_t)b * K + k0 + q) * ldd + c] = (e16_t)t;
   }
 }
+
+// The same gradient on POSITION-MAJOR operands (the twin the forward leaves, the (b, c, k) views of row data every row kernel
+// hands its gradients back in): one wave per point, 8 channels per lane, no transposes -- the channel-major kernel above reads
+// and writes 2-byte elements at stride k (43 us for 8 x 1024 points; this one moves the same 19 MB in full 16-byte pieces).
+// dnet's feature columns start at element 3, i.e. 6 bytes off the pieces' alignment: the row is assembled in LDS.
+__global__ __launch_bounds__(256) void vote_decode_bwd_rows_kernel(long long R, int C, const e16_t *__restrict__ out,
+                                                                  const float *__restrict__ norm,
+                                                                  const float *__restrict__ g_xyz,
+                                                                  const e16_t *__restrict__ g_feat, e16_t *__restrict__ dnet,
+                                                                  int ldd, e16_t *__restrict__ dseed) {
+  __shared__ __attribute__((aligned(16))) e16_t rowbuf[4][kVoteMaxC + 3 + 13];
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= R) return;
+  const int c8 = C >> 3;
+  float g[8], o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = o[e] = 0.f;
+  if (lane < c8 && g_feat) {
+    const uint4 gv = *reinterpret_cast<const uint4 *>(g_feat + row * C + lane * 8);
+    const uint4 ov = *reinterpret_cast<const uint4 *>(out + row * C + lane * 8);
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g[2 * e] = e16_lo(gw[e]), g[2 * e + 1] = e16_hi(gw[e]);
+      o[2 * e] = e16_lo(ow[e]), o[2 * e + 1] = e16_hi(ow[e]);
+    }
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dot = __builtin_fmaf(g[e], o[e], dot);
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 64);
+  const float rn = 1.0f / norm[row];
+  float t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = (g[e] - o[e] * dot) * rn;          // zero without a feature gradient
+  e16_t *rb = rowbuf[wave];
+  if (lane < c8) {
+    const uint4 pv = make_uint4(pack_e16x2(t[0], t[1]), pack_e16x2(t[2], t[3]), pack_e16x2(t[4], t[5]), pack_e16x2(t[6], t[7]));
+    if (dseed) *reinterpret_cast<uint4 *>(dseed + row * C + lane * 8) = pv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rb[3 + lane * 8 + e] = (e16_t)t[e];
+  }
+  if (lane < 3) rb[lane] = (e16_t)(g_xyz ? g_xyz[row * 3 + lane] : 0.f);
+  for (int c = 3 + C + lane; c < ldd; c += 64) rb[c] = (e16_t)0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < (ldd >> 3); i += 64)
+    *reinterpret_cast<uint4 *>(dnet + row * ldd + i * 8) = *reinterpret_cast<const uint4 *>(rb + i * 8);
+}
 }  // namespace omnipq
 
 extern "C" int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const float *seed_xyz,
@@ -709,6 +760,20 @@ extern "C" int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat
   else
     vote_decode_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(k, c, vote_feat, norm, g_xyz, g_feat,
                                                                          (e16_t *)dnet, ldd, dseed_feat);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// Backward of omnipq_vote_decode on position-major operands: vote_rows / g_rows / dseed_rows e16 [b*k][c] (c % 8 == 0), dnet as
+// above (ldd % 8 == 0); g_xyz, g_rows, dseed_rows may be NULL.
+extern "C" int omnipq_vote_decode_bwd_rows(long long rows, int c, const void *vote_rows, const float *norm, const float *g_xyz,
+                                           const void *g_rows, void *dnet, int ldd, void *dseed_rows, void *stream) {
+  using namespace omnipq;
+  if (rows < 0 || c <= 0 || c > kVoteMaxC || (c % 8) || ldd < c + 3 || (ldd % 8) || ldd > kVoteMaxC + 16) return OMNIPQ_EINVAL;
+  if (rows == 0) return OMNIPQ_OK;
+  if (!vote_rows || !norm || !dnet) return OMNIPQ_EINVAL;
+  vote_decode_bwd_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      rows, c, (const e16_t *)vote_rows, norm, g_xyz, (const e16_t *)g_rows, (e16_t *)dnet, ldd, (e16_t *)dseed_rows);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

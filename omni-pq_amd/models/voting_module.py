@@ -30,6 +30,9 @@ def _lin(x2d, conv):
     return rows_f32.linear(x2d, conv.weight, conv.bias)        # f32 mode: hand-written split-f32 GEMM on a GPU
 
 
+_ROWS_BACKWARD = True       # VoteDecode.backward on position-major operands (False: the channel-major kernel; tests compare)
+
+
 class VoteDecode(torch.autograd.Function):
     """(net rows (B*K, >= 3 + C) bf16, seed_xyz (B,K,3), seed_features (B,C,K)) -> (vote_xyz (B,K,3) f32, L2-normalised
     vote_features (B,C,K) f32, their bf16 row-major twin (B,K,C)): the tail of `VotingModule.forward` and the
@@ -56,7 +59,7 @@ class VoteDecode(torch.autograd.Function):
                        sa_fused._p(sf), int(bf), ctypes.c_longlong(sf.stride(0)), ctypes.c_longlong(sf.stride(1)),
                        ctypes.c_longlong(sf.stride(2)), sa_fused._p(vote_xyz), sa_fused._p(out), sa_fused._p(twin),
                        sa_fused._p(norm))
-        ctx.save_for_backward(out, norm)
+        ctx.save_for_backward(out, norm, twin)
         ctx.geom = (B, K, C, net.shape[1], bf)
         ctx.mark_non_differentiable(twin)
         ctx.set_materialize_grads(False)
@@ -66,9 +69,24 @@ class VoteDecode(torch.autograd.Function):
     def backward(ctx, g_xyz, g_feat, _g_twin):
         E16.select(ctx.e16)
         import sa_fused
-        out, norm = ctx.saved_tensors
+        out, norm, twin = ctx.saved_tensors
         B, K, C, ld, bf = ctx.geom
         g_xyz = None if g_xyz is None else g_xyz.float().contiguous()
+        if bf and C % 8 == 0 and ld % 8 == 0 and ld <= 336 and _ROWS_BACKWARD and \
+                (g_feat is None or (g_feat.dtype == E16.dtype and tuple(g_feat.shape) == (B, C, K))):
+            # everything position-major: the incoming gradient is a (B, C, K) view of rows already (the vote aggregation's
+            # backward) or is made one, the seed gradient goes back as such a view (what FanOut adds as rows)
+            import ctypes
+            g_rows = None
+            if g_feat is not None:
+                g_rows = g_feat.transpose(1, 2)
+                g_rows = g_rows if g_rows.is_contiguous() else g_rows.contiguous()
+            dnet = torch.empty((B * K, ld), device=out.device, dtype=E16.dtype)
+            dseed = torch.empty((B, K, C), device=out.device, dtype=E16.dtype) if ctx.needs_input_grad[2] else None
+            sa_fused._call(sa_fused._lib.omnipq_vote_decode_bwd_rows, twin, ctypes.c_longlong(B * K), C, sa_fused._p(twin),
+                           sa_fused._p(norm), sa_fused._p(g_xyz), sa_fused._p(g_rows), sa_fused._p(dnet), ld,
+                           sa_fused._p(dseed))
+            return dnet, (g_xyz if ctx.needs_input_grad[1] else None), (None if dseed is None else dseed.transpose(1, 2))
         g_feat = None if g_feat is None else g_feat.to(out.dtype).contiguous()
         dnet = torch.empty((B * K, ld), device=out.device, dtype=E16.dtype)
         dseed = torch.empty((B, C, K), device=out.device, dtype=out.dtype) if ctx.needs_input_grad[2] else None

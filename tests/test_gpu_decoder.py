@@ -610,6 +610,25 @@ def test_vote_decode_with_bf16_seed_features():
     assert got[1].dtype == torch.bfloat16
     assert rel_l2(got[0].float()[:, 3:3 + C], ref[0].float()[:, 3:3 + C]) < 8e-3
     assert rel_l2(got[1].float(), ref[1].float()) < 8e-3
+    # the position-major backward (the default: omnipq_vote_decode_bwd_rows) against the channel-major kernel, with the
+    # gradient arriving as a (B, C, K) view of rows (what the vote aggregation hands back) and with a coordinate gradient
+    import voting_module
+    g_rows = torch.randn(B, K, C, generator=gen).to(torch.bfloat16).to(dev()).transpose(1, 2)
+    g_xyz = torch.randn(B, K, 3, generator=gen).to(dev())
+    seed_xyz.requires_grad_(True)
+    res = {}
+    for rows in (True, False):
+        voting_module._ROWS_BACKWARD = rows
+        try:
+            vx, ft, _ = VoteDecode.apply(net, seed_xyz, seed_feat)
+            res[rows] = torch.autograd.grad([vx, ft], [net, seed_xyz, store], [g_xyz, g_rows])
+        finally:
+            voting_module._ROWS_BACKWARD = True
+    assert res[True][2].shape == res[False][2].shape and res[True][0].shape == res[False][0].shape
+    assert float(res[True][0][:, 3 + C:].abs().max()) == 0.0
+    assert torch.equal(res[True][0][:, :3], res[False][0][:, :3]) and torch.equal(res[True][1], res[False][1])
+    assert rel_l2(res[True][0].float(), res[False][0].float()) < 2e-3
+    assert rel_l2(res[True][2].float(), res[False][2].float()) < 2e-3
 
 
 @pytest.mark.parametrize("dtype,n,numel", [(torch.bfloat16, 6, 8192 * 288), (torch.float32, 3, 4096), (torch.bfloat16, 2, 40)])
