@@ -114,6 +114,11 @@ int omnipq_vote_decode(int b, int k, int c, const void *net, int ldn, const floa
 int omnipq_vote_decode_bwd(int b, int k, int c, const void *vote_feat, int feat_is_e16, const float *norm,
                            const float *g_xyz, const void *g_feat, void *dnet, int ldd, void *dseed_feat, void *stream);
 
+/* The forward on position-major operands (ldn % 8 == 0, c % 8 == 0): seed_rows e16 [rows][c] -> vote_rows e16 [rows][c]; the
+ * (b,c,k) tensor of the module's interface is a view of vote_rows. */
+int omnipq_vote_decode_rows(long long rows, int c, const void *net, int ldn, const float *seed_xyz, const void *seed_rows,
+                            float *vote_xyz, void *vote_rows, float *norm, void *stream);
+
 /* The same backward on position-major operands: vote_rows = the forward's twin16, g_rows / dseed_rows e16 [b*k][c] (what a
  * (b,c,k) view of row data is underneath), c % 8 == 0, ldd % 8 == 0; g_xyz, g_rows, dseed_rows may be NULL. */
 int omnipq_vote_decode_bwd_rows(long long rows, int c, const void *vote_rows, const float *norm, const float *g_xyz,

@@ -676,6 +676,47 @@ __global__ __launch_bounds__(256) void vote_decode_bwd_kernel(int K, int C, cons
   }
 }
 
+// The forward on position-major operands: seed rows e16 [R][C] (the twin of the seed features) -> vote rows e16 [R][C] (the
+// (b, c, k) output is a VIEW of them), one wave per point.  Same arithmetic as vote_decode_kernel<true> (f32 sum, sum of
+// squares, sqrt, multiply by the reciprocal), the summation order of the squares aside.
+__global__ __launch_bounds__(256) void vote_decode_rows_kernel(long long R, int C, const e16_t *__restrict__ net, int ldn,
+                                                              const float *__restrict__ seed_xyz,
+                                                              const e16_t *__restrict__ seed_rows, float *__restrict__ vote_xyz,
+                                                              e16_t *__restrict__ vote_rows, float *__restrict__ norm_out) {
+  __shared__ __attribute__((aligned(16))) e16_t rowbuf[4][kVoteMaxC + 3 + 13];
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= R) return;
+  const int c8 = C >> 3;
+  e16_t *rb = rowbuf[wave];
+  for (int i = lane; i < ((C + 3 + 7) >> 3); i += 64)
+    *reinterpret_cast<uint4 *>(rb + i * 8) = *reinterpret_cast<const uint4 *>(net + row * ldn + i * 8);
+  uint4 sv = make_uint4(0u, 0u, 0u, 0u);
+  if (lane < c8) sv = *reinterpret_cast<const uint4 *>(seed_rows + row * C + lane * 8);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 3) vote_xyz[row * 3 + lane] = seed_xyz[row * 3 + lane] + (float)rb[lane];
+  float t[8];
+  float ss = 0.f;
+  const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float sf = (e & 1) ? e16_hi(sw[e >> 1]) : e16_lo(sw[e >> 1]);
+    t[e] = lane < c8 ? sf + (float)rb[3 + lane * 8 + e] : 0.f;
+    ss = __builtin_fmaf(t[e], t[e], ss);
+  }
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+  const float n = __builtin_sqrtf(ss), inv = 1.0f / n;
+  if (lane == 0) norm_out[row] = n;
+  if (lane < c8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] *= inv;
+    *reinterpret_cast<uint4 *>(vote_rows + row * C + lane * 8) =
+        make_uint4(pack_e16x2(t[0], t[1]), pack_e16x2(t[2], t[3]), pack_e16x2(t[4], t[5]), pack_e16x2(t[6], t[7]));
+  }
+}
+
 // The same gradient on POSITION-MAJOR operands (the twin the forward leaves, the (b, c, k) views of row data every row kernel
 // hands its gradients back in): one wave per point, 8 channels per lane, no transposes -- the channel-major kernel above reads
 // and writes 2-byte elements at stride k (43 us for 8 x 1024 points; this one moves the same 19 MB in full 16-byte pieces).
@@ -774,6 +815,20 @@ extern "C" int omnipq_vote_decode_bwd_rows(long long rows, int c, const void *vo
   if (!vote_rows || !norm || !dnet) return OMNIPQ_EINVAL;
   vote_decode_bwd_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(
       rows, c, (const e16_t *)vote_rows, norm, g_xyz, (const e16_t *)g_rows, (e16_t *)dnet, ldd, (e16_t *)dseed_rows);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// omnipq_vote_decode on position-major operands: net e16 [rows][ldn] (ldn % 8 == 0), seed_rows e16 [rows][c] (c % 8 == 0)
+// -> vote_xyz f32 [rows][3], vote_rows e16 [rows][c], norm f32 [rows].
+extern "C" int omnipq_vote_decode_rows(long long rows, int c, const void *net, int ldn, const float *seed_xyz,
+                                       const void *seed_rows, float *vote_xyz, void *vote_rows, float *norm, void *stream) {
+  using namespace omnipq;
+  if (rows < 0 || c <= 0 || c > kVoteMaxC || (c % 8) || ldn < c + 3 || (ldn % 8)) return OMNIPQ_EINVAL;
+  if (rows == 0) return OMNIPQ_OK;
+  if (!net || !seed_xyz || !seed_rows || !vote_xyz || !vote_rows || !norm) return OMNIPQ_EINVAL;
+  vote_decode_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      rows, c, (const e16_t *)net, ldn, seed_xyz, (const e16_t *)seed_rows, vote_xyz, (e16_t *)vote_rows, norm);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

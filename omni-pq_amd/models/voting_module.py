@@ -30,6 +30,7 @@ def _lin(x2d, conv):
     return rows_f32.linear(x2d, conv.weight, conv.bias)        # f32 mode: hand-written split-f32 GEMM on a GPU
 
 
+_ROWS_FORWARD = True        # VoteDecode.forward on position-major operands when the seed features are a view of rows
 _ROWS_BACKWARD = True       # VoteDecode.backward on position-major operands (False: the channel-major kernel; tests compare)
 
 
@@ -52,6 +53,20 @@ class VoteDecode(torch.autograd.Function):
         sf = seed_features.detach()
         vote_xyz = torch.empty((B, K, 3), device=dev, dtype=torch.float32)
         bf = sf.dtype == E16.dtype
+        if bf and _ROWS_FORWARD and C % 8 == 0 and net.stride(0) % 8 == 0 and C <= 320 and sf.transpose(1, 2).is_contiguous():
+            # the seed features are a (B, C, K) view of position-major rows (the backbone's last FP module): rows in, rows out,
+            # and the (B, C, K) output is a view of the twin
+            twin = torch.empty((B, K, C), device=dev, dtype=E16.dtype)
+            norm = torch.empty((B, K), device=dev, dtype=torch.float32)
+            sa_fused._call(sa_fused._lib.omnipq_vote_decode_rows, net, ctypes.c_longlong(B * K), C, sa_fused._p(net),
+                           net.stride(0), sa_fused._p(sx), sa_fused._p(sf.transpose(1, 2)), sa_fused._p(vote_xyz),
+                           sa_fused._p(twin), sa_fused._p(norm))
+            out = twin.transpose(1, 2)
+            ctx.save_for_backward(out, norm, twin)
+            ctx.geom = (B, K, C, net.shape[1], bf)
+            ctx.mark_non_differentiable(twin)
+            ctx.set_materialize_grads(False)
+            return vote_xyz, out, twin
         out = torch.empty((B, C, K), device=dev, dtype=sf.dtype)
         twin = torch.empty((B, K, C), device=dev, dtype=E16.dtype)
         norm = torch.empty((B, K), device=dev, dtype=torch.float32)
@@ -88,6 +103,7 @@ class VoteDecode(torch.autograd.Function):
                            sa_fused._p(dseed))
             return dnet, (g_xyz if ctx.needs_input_grad[1] else None), (None if dseed is None else dseed.transpose(1, 2))
         g_feat = None if g_feat is None else g_feat.to(out.dtype).contiguous()
+        out = out.contiguous()                       # (a view of the twin after the position-major forward)
         dnet = torch.empty((B * K, ld), device=out.device, dtype=E16.dtype)
         dseed = torch.empty((B, C, K), device=out.device, dtype=out.dtype) if ctx.needs_input_grad[2] else None
         sa_fused._call(sa_fused._lib.omnipq_vote_decode_bwd, out, B, K, C, sa_fused._p(out), int(bf), sa_fused._p(norm),

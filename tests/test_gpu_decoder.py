@@ -599,7 +599,7 @@ def test_vote_decode_with_bf16_seed_features():
     store = torch.randn(B, K, C, generator=gen).to(torch.bfloat16).to(dev()).requires_grad_(True)
     seed_feat = store.transpose(1, 2)
     vote_xyz, feat, twin = VoteDecode.apply(net, seed_xyz, seed_feat)
-    assert feat.dtype == torch.bfloat16 and feat.is_contiguous()
+    assert feat.dtype == torch.bfloat16 and feat.transpose(1, 2).is_contiguous()       # a (B, C, K) view of the twin's rows
     v = seed_feat.float() + net.float().view(B, K, ld)[..., 3:3 + C].transpose(1, 2)
     want = v / torch.norm(v, p=2, dim=1, keepdim=True)
     assert float((feat.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-7
@@ -618,12 +618,16 @@ def test_vote_decode_with_bf16_seed_features():
     seed_xyz.requires_grad_(True)
     res = {}
     for rows in (True, False):
-        voting_module._ROWS_BACKWARD = rows
+        voting_module._ROWS_BACKWARD = voting_module._ROWS_FORWARD = rows
         try:
-            vx, ft, _ = VoteDecode.apply(net, seed_xyz, seed_feat)
-            res[rows] = torch.autograd.grad([vx, ft], [net, seed_xyz, store], [g_xyz, g_rows])
+            vx, ft, tw = VoteDecode.apply(net, seed_xyz, seed_feat)
+            res[rows] = torch.autograd.grad([vx, ft], [net, seed_xyz, store], [g_xyz, g_rows]) + (vx, ft, tw)
         finally:
-            voting_module._ROWS_BACKWARD = True
+            voting_module._ROWS_BACKWARD = voting_module._ROWS_FORWARD = True
+    # forward: the position-major kernel against the channel-major one (the sum of squares is taken in another order)
+    assert torch.equal(res[True][3], res[False][3]) and res[False][4].is_contiguous()
+    assert float((res[True][4].float() - res[False][4].float()).abs().max()) <= 2.0 ** -8 * float(res[False][4].float().abs().max())
+    assert torch.equal(res[True][5], res[True][4].transpose(1, 2))
     assert res[True][2].shape == res[False][2].shape and res[True][0].shape == res[False][0].shape
     assert float(res[True][0][:, 3 + C:].abs().max()) == 0.0
     assert torch.equal(res[True][0][:, :3], res[False][0][:, :3]) and torch.equal(res[True][1], res[False][1])
