@@ -143,24 +143,41 @@ __global__ __launch_bounds__(256) void scatter_big_runs_kernel(int c, int n, int
 // Few positions per scene (the model's own calls: gather of 1024 / 256 sampled points): no sort -- the scene's indices sit in LDS,
 // thread p owns source point idx[p] iff no earlier position names it, and an owner adds the positions that name its point in
 // ascending order (two scans of <= kSmallP LDS words per thread; one launch, ~the time of the atomic kernel it replaces).
-constexpr int kSmallP = 4096;
+constexpr int kSmallP = 4096, kSmallInvN = 8192;
 __global__ __launch_bounds__(1024) void scatter_small_kernel(int c, int n, int P, const float *__restrict__ grad_out,
                                                             const int *__restrict__ idx, float *__restrict__ grad_points) {
   __shared__ int s_idx[kSmallP];
+  __shared__ int s_inv[kSmallInvN + 1];         // n <= kSmallInvN: first position naming each source point; [n] = any repeats
   const int scene = (int)blockIdx.y, c0 = (int)blockIdx.x * kCT;
+  const bool inv = n <= kSmallInvN;
   for (int p = (int)threadIdx.x; p < P; p += 1024) s_idx[p] = idx[(size_t)scene * P + p];
+  if (inv)
+    for (int k = (int)threadIdx.x; k <= n; k += 1024) s_inv[k] = k < n ? 0x7fffffff : 0;
   __syncthreads();
+  if (inv) {
+    // (sampled indices are distinct but for degenerate clouds: one LDS atomic per position finds the owners, and without a
+    // repeat nobody scans -- the two scans of P words per thread below were 25 us for 256 positions)
+    for (int p = (int)threadIdx.x; p < P; p += 1024) atomicMin(&s_inv[s_idx[p]], p);
+    __syncthreads();
+    for (int p = (int)threadIdx.x; p < P; p += 1024)
+      if (s_inv[s_idx[p]] != p) s_inv[n] = 1;
+    __syncthreads();
+  }
+  const bool repeats = !inv || s_inv[n] != 0;
   const int cend = c - c0 < kCT ? c - c0 : kCT;
   const float *src = grad_out + ((size_t)scene * c + c0) * P;
   for (int p = (int)threadIdx.x; p < P; p += 1024) {
     const int a = s_idx[p];
     bool first = true;
-    for (int q = 0; q < p; ++q) first &= s_idx[q] != a;
+    if (inv)
+      first = s_inv[a] == p;
+    else
+      for (int q = 0; q < p; ++q) first &= s_idx[q] != a;
     if (!first) continue;
     float acc[kCT];
 #pragma unroll
     for (int l = 0; l < kCT; ++l) acc[l] = l < cend ? src[(size_t)l * P + p] : 0.f;
-    for (int q = p + 1; q < P; ++q)
+    for (int q = p + 1; repeats && q < P; ++q)
       if (s_idx[q] == a) {
 #pragma unroll
         for (int l = 0; l < kCT; ++l)
