@@ -493,3 +493,60 @@ def test_gather_rows_e16_and_its_adjoint():
     null = capi.P(None)
     assert capi.call("omnipq_gather_rows_e16", 1, 8, 4, 12, null, null, null) == 10001          # C % 8
     assert capi.call("omnipq_gather_rows_e16_grad", 1, 20000, 4, 8, null, null, null) != 0       # n too large / null
+
+
+def test_grouping_ahead_of_the_stages_is_taken_and_changes_nothing(monkeypatch):
+    """A prefetched sampling chain also makes the stages' centres, ball queries, row plans, backward CSRs and the FP modules'
+    3-NN (backbone_module.GROUP_AHEAD): training mode under bf16 autocast at the benchmark's shape (row plans engage), the
+    stages take what the chain made -- no ball query / plan / CSR launch of sa1..sa4 on the forward/backward path -- and every
+    backbone output and parameter gradient equals the run without it, bit for bit."""
+    import bench
+    import backbone_module
+    import pointnet2_utils
+    import sa_fused
+    torch.manual_seed(2)
+    net = bench.build_model(0).to(dev()).train()
+    pc = synth.make_clouds(77, 8, 40000, kind="room").to(dev())
+    keys = ("sa1_inds", "sa2_inds", "sa1_xyz", "sa2_xyz", "sa3_xyz", "sa4_xyz", "sa1_features", "sa2_features", "sa3_features",
+            "sa4_features", "fp2_features")
+    calls = {"bq": 0, "plan": 0, "csr": 0}
+    real_bq, real_plan, real_call = pointnet2_utils._ext.ball_query, sa_fused.make_row_plan, sa_fused._call
+
+    def spy_call(fn, *a):
+        if fn.__name__ == "omnipq_sa_build_csr":
+            calls["csr"] += 1
+        return real_call(fn, *a)
+
+    def run(group):
+        monkeypatch.setattr(backbone_module, "GROUP_AHEAD", group)
+        for p in net.parameters():
+            p.grad = None
+        net.prefetch({"point_clouds": pc})
+        torch.cuda.synchronize()
+        for k in calls:
+            calls[k] = 0
+        monkeypatch.setattr(pointnet2_utils._ext, "ball_query", lambda *a, **kw: (calls.__setitem__("bq", calls["bq"] + 1), real_bq(*a, **kw))[1])
+        monkeypatch.setattr(sa_fused, "make_row_plan", lambda *a, **kw: (calls.__setitem__("plan", calls["plan"] + 1), real_plan(*a, **kw))[1])
+        monkeypatch.setattr(sa_fused, "_call", spy_call)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                ep = net.backbone(pc, {})
+            loss = sum(ep[k].float().sum() for k in ("fp2_features", "sa4_features"))
+            loss.backward()
+        finally:
+            monkeypatch.setattr(pointnet2_utils._ext, "ball_query", real_bq)
+            monkeypatch.setattr(sa_fused, "make_row_plan", real_plan)
+            monkeypatch.setattr(sa_fused, "_call", real_call)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in net.backbone.named_parameters() if p.grad is not None}
+        return {k: ep[k].detach().clone() for k in keys}, grads, dict(calls)
+
+    want, gwant, c0 = run(False)
+    got, ggot, c1 = run(True)
+    assert c0["bq"] == 4 and c0["plan"] >= 2 and c0["csr"] >= 5          # in line: every stage makes its own
+    assert c1 == {"bq": 0, "plan": 0, "csr": 0}, c1                        # ahead: nothing left on the path
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    assert sorted(ggot) == sorted(gwant) and len(ggot) >= 30
+    for n in gwant:
+        assert torch.equal(ggot[n], gwant[n]), n
