@@ -124,26 +124,47 @@ class _MatmulNT(torch.autograd.Function):
         return da, db
 
 
+HEADS_IN_ONE_GEMM = True       # attention_core: the H heads of a batch element in one pair of GEMMs (False: one pair per head)
+
+
 def attention_core(q, k, v, num_heads, dropout_p=0.0):
     """softmax(q k^T / sqrt(D)) v per (batch, head) for f32 q (L, N, E), k / v (S, N, E) -> (L, N, E): the attention
-    core of models/utils/multi_head_attention.py:375-391 in the f32 mode, its two products per (batch, head) on the
-    hand-written split-f32 GEMM (softmax and dropout are PyTorch elementwise kernels).  A parity path, not a fast one:
-    N * H pairs of small GEMMs per call -- the measured step runs the fused bf16 / fp16 attention kernels."""
+    core of models/utils/multi_head_attention.py:375-391 in the f32 mode, its two products on the hand-written split-f32
+    GEMM (softmax and dropout are PyTorch elementwise kernels).  A parity path, not a fast one -- the measured step runs
+    the fused bf16 / fp16 attention kernels -- but usable: the H heads of a batch element share ONE pair of GEMMs.  The
+    queries are laid out block-diagonally, row (h, l) holding head h's D channels of query l and zeros elsewhere, so
+    Q' K^T (H L x S, contraction over all E channels) stacks the heads' score matrices -- the zero channels add exact zeros, the
+    sums are the per-head ones up to f32 rounding (other K-steps) -- and P' V (H L x E) carries head h's output in the diagonal blocks.  8 x the
+    multiplications of tiny GEMMs for 1/8 of the launches (N pairs per call instead of N * H: the f32 step 333 -> 144 ms)."""
     L, N, E = q.shape
     S = k.shape[0]
-    D = E // num_heads
+    H = num_heads
+    D = E // H
     scale = float(D) ** -0.5
-    qh = (q * scale).reshape(L, N * num_heads, D)
-    kh = k.reshape(S, N * num_heads, D)
-    vh = v.reshape(S, N * num_heads, D)
+    if not HEADS_IN_ONE_GEMM:
+        qh = (q * scale).reshape(L, N * H, D)
+        kh = k.reshape(S, N * H, D)
+        vh = v.reshape(S, N * H, D)
+        outs = []
+        for i in range(N * H):
+            scores = _MatmulNT.apply(qh[:, i].contiguous(), kh[:, i].contiguous())          # (L, S)
+            probs = F.softmax(scores, dim=-1)
+            if dropout_p > 0.0:
+                probs = F.dropout(probs, p=dropout_p, training=True)
+            outs.append(_MatmulNT.apply(probs, vh[:, i].t().contiguous()))                  # (L, D)
+        return torch.stack(outs, dim=1).reshape(L, N, E)
+    eye = torch.eye(H, device=q.device, dtype=q.dtype).view(H, 1, H, 1)
+    qs = (q * scale).view(L, N, H, D)
     outs = []
-    for i in range(N * num_heads):
-        scores = _MatmulNT.apply(qh[:, i].contiguous(), kh[:, i].contiguous())          # (L, S)
+    for n in range(N):
+        qb = (eye * qs[:, n].unsqueeze(0)).reshape(H * L, E)                  # row (h, l): head h's channels of query l
+        scores = _MatmulNT.apply(qb, k[:, n].contiguous())                    # (H L, S): the heads' score matrices, stacked
         probs = F.softmax(scores, dim=-1)
         if dropout_p > 0.0:
             probs = F.dropout(probs, p=dropout_p, training=True)
-        outs.append(_MatmulNT.apply(probs, vh[:, i].t().contiguous()))                  # (L, D)
-    return torch.stack(outs, dim=1).reshape(L, N, E)
+        ob = _MatmulNT.apply(probs, v[:, n].t().contiguous())                 # (H L, E): head h's output in block (h, h)
+        outs.append(ob.view(H, L, H, D).diagonal(dim1=0, dim2=2).permute(0, 2, 1).reshape(L, E))
+    return torch.stack(outs, dim=1)
 
 
 class _BNAct(torch.autograd.Function):

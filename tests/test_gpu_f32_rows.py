@@ -145,3 +145,23 @@ def test_f32_attention_core_matches_float64():
     want.backward(g.double())
     for name, a, b in (("out", out, want), ("dq", q.grad, q64.grad), ("dk", k.grad, k64.grad), ("dv", v.grad, v64.grad)):
         assert rel(a, b) < 5e-6, (name, rel(a, b))
+
+
+def test_f32_attention_core_heads_in_one_gemm_equals_one_gemm_per_head(monkeypatch):
+    """rows_f32.attention_core with the H heads of a batch element in one block-diagonal pair of GEMMs (the default) against
+    one pair per (batch, head): the zero channels add exact zeros; output and gradients agree to f32 rounding."""
+    import rows_f32
+    torch.manual_seed(1)
+    L, S, N, H, D = 64, 200, 3, 8, 36
+    res = {}
+    base = [torch.randn(L, N, H * D, device=DEV), torch.randn(S, N, H * D, device=DEV), torch.randn(S, N, H * D, device=DEV)]
+    g = torch.randn(L, N, H * D, device=DEV)
+    for joint in (True, False):
+        monkeypatch.setattr(rows_f32, "HEADS_IN_ONE_GEMM", joint)
+        q, k, v = (t.clone().requires_grad_(True) for t in base)
+        out = rows_f32.attention_core(q, k, v, H)
+        out.backward(g)
+        res[joint] = (out.detach(), q.grad, k.grad, v.grad)
+    for a, b, name in zip(res[True], res[False], ("out", "dq", "dk", "dv")):
+        assert a.shape == b.shape
+        assert rel(a, b) < 2e-6, (name, rel(a, b))          # (f32 rounding: the contraction is cut into other K-steps)
