@@ -117,6 +117,7 @@ class CapturedStep:
     # two eager streams would -- and with the decoder's own key-side fork nested inside the forked branch hipStreamEndCapture
     # segfaults.  Off; kept as a switch (its dropout sites draw from a counter of their own: dropout_state.use).
     TEACHER_SIDE = False
+    TEACHER_FIRST = True        # the teacher's forward in front of the student's (see _body)
 
     def _teacher_forward(self, batch, nested=False):
         """nested: the call is made on a forked stream -- the decoder's own fork for the key sides stays off (a fork inside
@@ -159,10 +160,18 @@ class CapturedStep:
             tside.wait_stream(main)
             with torch.cuda.stream(tside):
                 tep = self._teacher_forward(cur_t, nested=True)
+        if teacher is not None and tside is None and self.TEACHER_FIRST:
+            # The two forwards are independent (train.py:489-491 runs the student's first; nothing reads one from the other
+            # before the losses).  The teacher's goes FIRST here: its next sampling chain starts inside its forward, and behind
+            # the student's forward it started ~2.7 ms into the step and ended after everything else -- the chain, not the
+            # main stream, set the step's length (11.5 ms).  In front, both chains have the whole step to hide under.
+            tep = self._teacher_forward(cur_t)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             ep = self.model({"point_clouds": cur})
         if teacher is not None:
-            if tside is not None:
+            if tep is not None and tside is None:
+                pass
+            elif tside is not None:
                 main.wait_stream(tside)
                 if not torch.cuda.is_current_stream_capturing():
                     for v in tep.values() if isinstance(tep, dict) else ():
