@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define OMNIPQ_ABI_VERSION 1
+/* 2: round 5's signatures (21 entry points take `const omnipq_row_plan *plan` in front of the stream; omnipq_fps_footprint,
+ *    omnipq_sa_row_plan, omnipq_sa_plan_pool_gamma, omnipq_gemm_strip_* removed) + omnipq_plan_aware_entry_points().
+ * A binding must refuse a library whose version it was not written against: the argument lists differ. */
+#define OMNIPQ_ABI_VERSION 2
 
 #define OMNIPQ_OK 0
 #define OMNIPQ_EINVAL 10001     /* bad shape / null pointer */
@@ -44,6 +47,9 @@ extern "C" {
 
 int omnipq_abi_version(void);
 const char *omnipq_error_string(int code);
+/* space-separated names of the entry points of this build that take `const omnipq_row_plan *plan` (omnipq_sa.h) in front of
+ * the stream argument -- a binding asks the library it loaded instead of parsing a header */
+const char *omnipq_plan_aware_entry_points(void);
 /* Measurement helper: dst[0..bytes) = src[0..bytes) (bytes % 16 == 0) with the streaming shape that reaches this chip's
  * highest copy rate -- the "measured copy ceiling" bench.py reports next to the 8 TB/s datasheet peak. */
 int omnipq_copy_probe(const void *src, void *dst, long long bytes, void *stream);

@@ -66,6 +66,30 @@ def sources_digest():
     return h.hexdigest()
 
 
+def plan_aware_entry_points():
+    """Names of the entry points whose declaration in include/omnipq_sa.h takes `const omnipq_row_plan *plan` (in front of
+    the stream).  Evaluated at BUILD time and compiled into the library (csrc/capi.hip: omnipq_plan_aware_entry_points), so
+    that a binding asks the library it actually loaded how its entry points are called instead of parsing a header that may
+    belong to another build."""
+    import re
+    with open(os.path.join(REPO, "include", "omnipq_sa.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", " ", fh.read(), flags=re.S)
+    return sorted(m.group(1) for m in re.finditer(r"\b(omnipq_\w+)\s*\(([^;{}()]*)\)\s*;", text)
+                  if "omnipq_row_plan *plan" in m.group(2))
+
+
+def _write_generated():
+    """build/generated/plan_aware.inc: one string literal, rewritten only when its content changes."""
+    gen = os.path.join(OBJDIR, "generated")
+    os.makedirs(gen, exist_ok=True)
+    path = os.path.join(gen, "plan_aware.inc")
+    text = '"' + " ".join(plan_aware_entry_points()) + '"\n'
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as fh:
+            fh.write(text)
+    return gen
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -79,6 +103,8 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     inc = os.path.join(REPO, "include")
     headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    gen = _write_generated()
+    headers.append(os.path.join(gen, "plan_aware.inc"))
     procs, links = [], []
     for lib, sub, defines in VARIANTS:
         objdir = os.path.join(OBJDIR, sub)
@@ -89,7 +115,7 @@ def build(force=False, verbose=False):
             obj = os.path.join(objdir, src[:-4] + ".o")
             objs.append(obj)
             if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
-                cmd = [hipcc()] + COMMON + defines + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+                cmd = [hipcc()] + COMMON + ["-I", gen] + defines + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
                 if verbose:
                     print(" ".join(cmd))
                 procs.append((src, subprocess.Popen(cmd)))

@@ -3,6 +3,14 @@
 
 extern "C" int omnipq_abi_version(void) { return OMNIPQ_ABI_VERSION; }
 
+// The entry points of THIS build that take `const omnipq_row_plan *plan` in front of the stream: a space-separated list,
+// written by omni-pq_amd/build.py from include/omnipq_sa.h when the library is compiled.
+extern "C" const char *omnipq_plan_aware_entry_points(void) {
+  return
+#include "plan_aware.inc"
+      ;
+}
+
 extern "C" const char *omnipq_error_string(int code) {
   switch (code) {
     case OMNIPQ_OK: return "ok";

@@ -44,7 +44,9 @@ class GradientBuckets:
         self._packed = [set(), set()]  # ids of the parameters that had a gradient when their bucket was packed
         self._hold = None             # the local .grad tensors bucket 0 was packed from (alive until the block has ended)
         self._late_ids = None         # ids of the bucket-0 parameters that also travel with bucket 1 (fixed by the first step)
-        self._used_ids = None         # ids of the parameters some rank has a gradient for (fixed by the first uncaptured step)
+        self._used_ids = None         # ids of the parameters some rank has had a gradient for (agreed by the first uncaptured
+                                      # step, re-agreed -- it only grows -- whenever some rank sees a gradient outside it)
+        self._regrow = False
 
     # ---- called by sa_fused.deferred_wgrads.flush_on, on the side stream, after the early grouped launch ----------
     def on_early_flush(self, dfr):
@@ -72,22 +74,39 @@ class GradientBuckets:
         """Both buckets reduced and averaged; a parameter gets its averaged view as `.grad` when ANY rank produced a
         gradient for it (DDP hands every rank the averaged gradient: a rank-local "nothing arrived, leave None" makes that
         rank skip the optimizer update -- weight decay and moments included -- and the replicas drift apart).
-        Which parameters take part at all is agreed on once, by the first step that is not being captured (one MAX
-        all-reduce of a mask and a host read), and kept: only a parameter no rank ever touched keeps `.grad = None`.  The set of bucket-0 parameters that travel again with bucket 1 is STRUCTURAL -- fixed by the
+        Which parameters take part at all is agreed on by the first step that is not being captured (one MAX
+        all-reduce of a mask and a host read) and re-agreed whenever ANY rank packs a gradient outside that set (the set
+        only grows; a captured step cannot re-agree and raises): only a parameter no rank ever touched keeps `.grad = None`.  The set of bucket-0 parameters that travel again with bucket 1 is STRUCTURAL -- fixed by the
         first step that saw late arrivals and asserted equal on every later step -- because it sizes a collective: ranks
         that disagreed about it would hang in the all-reduce."""
         late = []
+        capturing = any(p.is_cuda for p in self.buckets[0][:1] + self.buckets[1][:1]) and torch.cuda.is_current_stream_capturing()
+        arrived = [p for p in self.buckets[0] if p.grad is not None] if self.early_done else []
+        if self.early_done and self._late_ids is None:
+            self._late_ids = self._agree(self.buckets[0], {id(p) for p in arrived})
+        stray = [p for p in arrived if id(p) not in self._late_ids]
+        # what this step is about to hand to the all-reduces that the agreed set of participating parameters does not
+        # know (ADVICE r5: such a gradient used to be reduced and then dropped by `p.grad = None` below, silently)
+        carrying = self._packed[0] | {id(p) for p in self.buckets[0] + self.buckets[1] if p.grad is not None}
+        fresh = self._used_ids is not None and not carrying <= self._used_ids
+        # Both conditions are rank-local observations that change what the ranks do NEXT (a raise, or another agreement
+        # round = a collective): they are made collective first -- one MAX all-reduce of two flags and a host read per
+        # uncaptured step -- so that no rank is left waiting in bucket 1's all-reduce for a peer that raised.
+        if not capturing:
+            any_stray, any_fresh = self._any_rank(bool(stray), fresh)
+        else:
+            any_stray, any_fresh = bool(stray), fresh
+        if any_stray:
+            raise RuntimeError(f"GradientBuckets: bucket-0 gradients arrived after the early flush that did not on the first "
+                               f"step ({len(stray)} on this rank); the late set sizes bucket 1's all-reduce and must not change")
+        if any_fresh:
+            if capturing:
+                raise RuntimeError("GradientBuckets: a parameter outside the agreed set got a gradient inside a capture")
+            self._regrow = True                     # agree again below, once both buckets are packed
         if not self.early_done:                   # no flush point was hit (eager helper paths): everything now
             self.flat[0] = self._pack(self.buckets[0], [], self._packed[0])
             self._reduce(self.flat[0])
         else:
-            arrived = [p for p in self.buckets[0] if p.grad is not None]
-            if self._late_ids is None:
-                self._late_ids = self._agree(self.buckets[0], {id(p) for p in arrived})
-            stray = [p for p in arrived if id(p) not in self._late_ids]
-            if stray:
-                raise RuntimeError(f"GradientBuckets: {len(stray)} bucket-0 gradients arrived after the early flush that "
-                                   "did not on the first step; the late set sizes bucket 1's all-reduce and must not change")
             late = [p for p in self.buckets[0] if id(p) in self._late_ids]
         self.late_arrivals = len(late)
         # bucket 1 = the backbone + whatever reaches bucket-0 parameters after the early flush
@@ -98,8 +117,12 @@ class GradientBuckets:
             if flat.is_cuda and not torch.cuda.is_current_stream_capturing():
                 flat.record_stream(torch.cuda.current_stream(flat.device))     # bucket 0 was allocated on the side stream
             flat.mul_(inv)
-        if self._used_ids is None and not (self.flat[1].is_cuda and torch.cuda.is_current_stream_capturing()):
-            self._used_ids = self._agree(self.buckets[0] + self.buckets[1], self._packed[0] | self._packed[1])
+        if (self._used_ids is None or self._regrow) and not capturing:
+            # the participating set only ever grows: a parameter some rank had a gradient for once keeps getting the
+            # average (zeros when no rank has one this step), never a rank-local None
+            self._used_ids = (self._used_ids or set()) | self._agree(self.buckets[0] + self.buckets[1],
+                                                                     self._packed[0] | self._packed[1])
+            self._regrow = False
         used = self._used_ids
         late_views, off = {}, sum(p.numel() for p in self.buckets[1])
         for p in late:
@@ -122,6 +145,15 @@ class GradientBuckets:
         self.early_done = False
         self._hold = None
         self._packed = [set(), set()]
+
+    def _any_rank(self, *flags):
+        """each flag OR-ed over the ranks (one small MAX all-reduce and a host read)"""
+        if self.world > 1 and dist.is_initialized():
+            ref = (self.buckets[0] + self.buckets[1])[0]
+            t = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32, device=ref.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return [bool(v) for v in t.tolist()]
+        return [bool(f) for f in flags]
 
     def _agree(self, params, mine):
         """ids of `params` that are in `mine` on ANY rank (union: a rank without a gradient for a parameter another rank

@@ -27,12 +27,17 @@ if not os.path.exists(_LIB_PATH):
         f"pointnet2._ext: {_LIB_PATH} not found -- build it with `python omni-pq_amd/build.py` "
         "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for these operators.")
 
+ABI_VERSION = 2          # include/omnipq_pointops.h: OMNIPQ_ABI_VERSION
+
+
 def _load(path):
     lib = ctypes.CDLL(path)
     lib.omnipq_error_string.restype = ctypes.c_char_p
     lib.omnipq_abi_version.restype = ctypes.c_int
-    if lib.omnipq_abi_version() != 1:
-        raise ImportError(f"pointnet2._ext: {path} has an unexpected ABI version")
+    if lib.omnipq_abi_version() != ABI_VERSION:
+        raise ImportError(f"pointnet2._ext: {path} reports ABI version {lib.omnipq_abi_version()}, this binding is written "
+                          f"against {ABI_VERSION} (include/omnipq_pointops.h) -- rebuild with `python omni-pq_amd/build.py`")
+    lib.omnipq_plan_aware_entry_points.restype = ctypes.c_char_p
     return lib
 
 
@@ -121,6 +126,11 @@ class _Libs:
 
 
 _lib = _Libs()
+# which entry points take a row plan in front of the stream: the loaded libraries say so themselves (build-time list)
+PLAN_AWARE = frozenset(_LIBS[torch.bfloat16].omnipq_plan_aware_entry_points().decode().split())
+for _l in _LIBS.values():
+    if frozenset(_l.omnipq_plan_aware_entry_points().decode().split()) != PLAN_AWARE:
+        raise ImportError("pointnet2._ext: the bf16 and f16 libraries were built from different headers")
 _lib0 = _LIBS[torch.bfloat16]        # element-type independent entry points (index ops, FPS state) always live here
 
 LIB_PATH = _LIB_PATH

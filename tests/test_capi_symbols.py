@@ -44,10 +44,26 @@ def test_libraries_have_gfx950_code_objects_with_their_mfma_opcode(built_lib, tm
         assert asm.count(opcode) >= 100 and other not in asm, (path, asm.count(opcode), asm.count(other))
 
 
+def test_library_names_its_plan_aware_entry_points(built_lib):
+    """the binding takes the set of plan-aware entry points from the LIBRARY it loaded (a build-time constant),
+    and refuses a library of another ABI version; here: that constant equals what the header of this tree declares, in
+    both element-type libraries, and the binding's set is the library's."""
+    import sys
+    for path in both(built_lib):
+        lib = ctypes.CDLL(path)
+        lib.omnipq_plan_aware_entry_points.restype = ctypes.c_char_p
+        names = frozenset(lib.omnipq_plan_aware_entry_points().decode().split())
+        assert names == capi.plan_aware() and len(names) >= 20, sorted(names ^ capi.plan_aware())
+        assert all(hasattr(lib, n) for n in names)
+    import pointnet2_utils
+    assert pointnet2_utils._ext.PLAN_AWARE == capi.plan_aware()
+    assert pointnet2_utils._ext.ABI_VERSION == lib.omnipq_abi_version() == 2
+
+
 def test_host_helpers_without_gpu(built_lib):
     from oracle import oracle_ext
     lib = capi.lib()
-    assert lib.omnipq_abi_version() == 1
+    assert lib.omnipq_abi_version() == 2
     assert b"invalid" in lib.omnipq_error_string(10001)
     # the FPS tie geometry must agree between library, oracle and the reference's formula
     for n in list(range(1, 70)) + [100, 127, 128, 255, 256, 511, 512, 513, 1000, 1024, 2048, 4096, 8192,

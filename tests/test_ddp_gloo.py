@@ -155,6 +155,31 @@ def _worker(rank, world, port, out_dir):
         assert torch.allclose(three.extra.bias.grad, torch.full((2,), 4.0 / world)), three.extra.bias.grad
         assert b3.late_arrivals == 1 and three.head.weight.grad is None and three.unused.bias.grad is None
 
+        # 2c'') ADVICE r5: on a LATER step one rank gets a gradient for a parameter outside the agreed set -- it used to be
+        # all-reduced and then dropped (`p.grad = None`) on every rank; now the set is re-agreed and the average arrives
+        for p in three.parameters():
+            p.grad = None
+        if rank == 0:
+            three.unused.bias.grad = torch.full((2,), 6.0)
+        three.backbone.bias.grad = torch.ones(5)
+        b3.finish()
+        assert three.unused.bias.grad is not None, "a gradient one rank produced on a later step was dropped"
+        assert torch.allclose(three.unused.bias.grad, torch.full((2,), 6.0 / world))
+        assert three.unused.weight.grad is None
+        # ... and a stray late arrival raises on EVERY rank (the rank that did not see it must not wait in an all-reduce)
+        for p in three.parameters():
+            p.grad = None
+        blk3._assign = []
+        b3.on_early_flush(blk3)
+        if rank == 0:
+            three.head.bias.grad = torch.ones(3)               # arrives after the early flush; was not late on step 1
+        try:
+            b3.finish()
+            raise AssertionError("a stray late arrival was accepted")
+        except RuntimeError as err:
+            assert "late set" in str(err), err
+        dist.barrier()
+
         # 2d) deferred_wgrads refuses parameters of a DistributedDataParallel module (their hooks would never fire)
         with sa_fused.deferred_wgrads() as blk2:
             w = net.fp.mlp.layer0.conv.weight            # `net` ran a forward pass under DDP above
