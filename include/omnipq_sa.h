@@ -372,6 +372,44 @@ int omnipq_interp_rows_grad_csr(int b, int n, int m, int C, const void *g, int l
                                 const int *order, const float *weight, float *dfeat, void *stream);
 int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd, int col0, void *stream);
 
+/* ---- the LAST layer of a planned stage, backward without its output gradient (round 6; csrc/sa_last_bwd.hip) ---------------
+ * Replaces, for the last conv + BatchNorm + ReLU + max-pool of a stage that runs on a row plan, omnipq_sa_pool_bwd_apply,
+ * the stored pre-BatchNorm output Y3 of that layer, its gradient dY3, and the two GEMMs that read dY3
+ * (reference pointnet2_modules.py:243-257, pytorch_utils.py:11-36 under autograd).  With hit = the max-pool's gradient at the
+ * selected row, w = the rows of the full layout a compact row stands for and X2 = relu(a2 Y2 + b2) the layer's input:
+ *     dY3 = a hit - w (alpha + beta Y3),  Y3 = X2 W3^T   =>
+ *     dX2 = [a hit] W3 - w (X2 G + v),            G = W3^T diag(beta) W3,  v = W3^T alpha
+ *     dW3 = [a hit]^T X2 - alpha (x) cs - diag(beta) W3 Gram,   Gram = X2^T diag(w) X2,  cs = X2^T w
+ *   omnipq_sa_last_bwd_prep       from the totals `sums` (double [2][C3] = sum dz | sum dz yhat of omnipq_sa_pool_bwd_stats_sel,
+ *                                 all-reduced by the caller under SyncBatchNorm) and the pool's (g_out f32, out_pm e16, arg u8,
+ *                                 all [balls][C3]): hot u32 [balls][C3] = e16(a dz) << 16 | arg;  B1 e16 [C2][ldb1 >= C2 + 32] =
+ *                                 [-G | -v_hi, -v_lo, 0..];  alpha, beta f32 [C3];  gb (may be NULL) f32 [2][C3] = dbeta | dgamma.
+ *                                 Wt = the layer's prepared TRANSPOSED weight e16 [C2][ldwt] (K-contiguous over C3).
+ *   omnipq_gemm_nt_e16_dz_bnbwd   dX2 (e16 [M][ldc], M = the plan's static row count, N = C2 columns) and the
+ *                                 BatchNorm-backward sums of the layer below, as omnipq_gemm_nt_e16_bnbwd; the A operand is
+ *                                 generated: Y2 (e16 [M][lda], lda == ldc), B1, B2 = Wt, hot, the plan's unit_src and nsample.
+ *   omnipq_gemm_tn_dz             workspace[0 .. (C3 + N) N) = R = [[a hit]^T X2 ; Gram] (f32, reduced over *slabs_out slabs),
+ *                                 workspace + *cs_offset_out = float[*slabs_out][C3 + N] partial rows of cs (entries C3 ..).
+ *                                 workspace: omnipq_gemm_tn_dz_workspace_floats(C3, N, P) floats.  C3, N multiples of 128.
+ *   omnipq_sa_last_wgrad_combine  out f32 [C3][out_ld] (+)= dW3 from R, the cs rows, alpha, beta and the prepared weight Wp
+ *                                 (e16 [C3][ldw], K-contiguous over C2).
+ * All four REQUIRE the stage's plan where they take one. */
+int omnipq_sa_last_bwd_prep(long long balls, int C3, int C2, const double *sums, double total_positions, const float *a,
+                            const float *mean, const float *invstd, const float *g_out, const void *out_pm,
+                            const unsigned char *arg, const void *Wt, int ldwt, unsigned *hot, void *B1, int ldb1,
+                            float *alpha, float *beta, float *gb, void *stream);
+int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2, int lda, const void *B1, int ldb1, const void *B2,
+                                 int ldb2, const unsigned *hot, const int *unit_src, int nsample, void *C, int ldc,
+                                 const float *a, const float *b, const float *mean, const float *invstd, double *sums,
+                                 float *workspace, const omnipq_row_plan *plan, void *stream);
+long long omnipq_gemm_tn_dz_workspace_floats(int C3, int N, int P);
+int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, const float *ba, const float *bb, const unsigned *hot,
+                      const int *unit_src, int nsample, float *workspace, int *slabs_out, long long *cs_offset_out,
+                      const omnipq_row_plan *plan, void *stream);
+int omnipq_sa_last_wgrad_combine(int C3, int C2, const float *R, const float *cs_part, int slabs, int cs_ld,
+                                 const float *alpha, const float *beta, const void *Wp, int ldw, float *out, int out_ld,
+                                 int accumulate, void *stream);
+
 /* out[0] += sum_i mean(tensor_i), i < nseg <= 72: the benchmark's stand-in loss in one launch over strided
  * views (<= 4 dims, f32 or e16; no casts, no concatenation).  HOST arrays: ptrs[nseg] device pointers,
  * sizes / strides [nseg][4] in elements (unused leading dims: size 1), is_e16[nseg].  The descriptors are

@@ -45,6 +45,9 @@ struct GemmArgs {
   // *rows_dev of M (tiles past them leave at once), row_w weights the statistics
   const int *rows_dev = nullptr;
   const unsigned char *row_w = nullptr;
+  // statistics variants with ball extrema: the tile itself is not stored (the last layer of a stage whose backward runs
+  // without dY / Y of that layer: omnipq_gemm_nt_e16_dz_bnbwd) -- statistics and extrema are all that leaves the kernel
+  int no_store = 0;
 };
 
 __device__ __forceinline__ uint4 ldg16(const e16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -114,6 +117,17 @@ __device__ __forceinline__ unsigned affine_relu_pair(unsigned w, float a0, float
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o), s16x2{0, 0}));
 }
 
+// ... times a positive row weight (DZ: the rows of the full layout a compact row stands for), applied in f32 before the
+// single rounding
+__device__ __forceinline__ unsigned affine_relu_pair_w(unsigned w, float a0, float b0, float a1, float b1, float rw) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  omnipq_f32x2 v = __builtin_elementwise_fma(omnipq_f32x2{a0, a1}, omnipq_f32x2{e16_lo(w), e16_hi(w)},
+                                            omnipq_f32x2{b0, b1});
+  v = v * omnipq_f32x2{rw, rw};
+  const unsigned o = pack_e16x2(v[0], v[1]);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o), s16x2{0, 0}));
+}
+
 // Ball extrema (statistics variants only, s > 0): the rows of C are grouped positions, `s` consecutive rows form a
 // ball (s divides 128, so balls never straddle tiles).  The max-pool over a ball of relu(a y + b) is relu(a y* + b)
 // with y* the ball's MAXIMUM of y where a >= 0 and its MINIMUM where a < 0 -- but a and b exist only after this
@@ -143,6 +157,25 @@ struct XyzGen {
 };
 constexpr int kXgMaxC = 256;
 
+// DZ (with AFF, STATS = 4, PLAN): the data gradient of the LAST layer of a planned stage without that layer's output
+// gradient.  With dz the max-pool's gradient (one nonzero per ball and column, at the row the pool selected) the BatchNorm
+// backward of the last layer is dY3 = a dz - w (alpha + beta Y3) per column (alpha = a (m1 - mean invstd m2),
+// beta = a invstd m2; w = the rows of the full layout a compact row stands for), and with Y3 = X2 W3^T
+//     dX2 = dY3 W3 = [a dz] W3 - w (X2 G + v),      G = W3^T diag(beta) W3  (C2 x C2),   v = W3^T alpha
+// -- ONE contraction over K = C2 + 32 + C3 whose A operand is never read from memory as such:
+//     k <  C2           w relu(a2 y2 + b2)   (AFF of the layer below, times the row's weight)      x  -G
+//     k in C2 .. C2+31  (w, w, 0, ...)                                                             x  (-v_hi, -v_lo, 0, ...)
+//     k >= C2 + 32      the row's one-hot slice of a dz, GENERATED from hot[ball][c] = e16(a dz) << 16 | row in ball
+//                       (omnipq_sa_last_bwd_prep)                                                   x  W3^T as prepared
+// so neither dY3 nor Y3 is ever written or read (sa1: 4 x 285 MB per step).  GemmArgs: K = C2 + 32, A / lda = Y2, B / ldb =
+// [-G | -v] (e16 [N][C2 + 32]); the BatchNorm-backward epilogue of the layer below (STATS = 4) is unchanged.
+struct DzGen {
+  const unsigned *hot = nullptr;      // [balls][C3]
+  const e16_t *B2 = nullptr;          // [N][ldb2]: prepared transposed weight of the last layer (K-contiguous over C3)
+  const int *unit_src = nullptr;      // row plan: compact rows 8 u .. 8 u + 7 = positions 8 unit_src[u] .. of the full layout
+  int C3 = 0, ldb2 = 0, s_shift = 0;  // nsample = 1 << s_shift
+};
+
 __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
   return pack_e16x2(lo, hi);
 }
@@ -161,11 +194,12 @@ constexpr int kResMaxSteps = 10;
 
 // The workgroup program of every NT GEMM variant; `bid` = this workgroup's index within ITS problem (blockIdx.x of a
 // plain launch; the pair launch below runs two problems in one grid).
-template <bool OUT_F32, int STATS, bool AFF, int T, int XG, bool KRES, bool PLAN = false>
+template <bool OUT_F32, int STATS, bool AFF, int T, int XG, bool KRES, bool PLAN = false, bool DZ = false>
 __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__restrict__ A, const e16_t *__restrict__ B,
                                              void *__restrict__ Cout, const float *__restrict__ bias,
                                              void *__restrict__ stats_out, const BnBwdEpilogue &bn, const AffineIn &aff,
-                                             const PoolOut &pool, const XyzGen &xg, const int bid) {
+                                             const PoolOut &pool, const XyzGen &xg, const int bid, const DzGen &dz = DzGen()) {
+  static_assert(!DZ || (AFF && STATS == 4 && T == 128 && PLAN && XG == 0 && !KRES && !OUT_F32), "DZ variant");
   static_assert(T == 128 || T == 64, "tile edge");
   static_assert(XG == 0 || (XG == 1 && AFF && T == 128) || (XG == 2 && STATS == 4 && T == 128), "XG variants");
   static_assert(!KRES || (T == 64 && XG == 0 && !OUT_F32), "KRES variants");
@@ -244,6 +278,24 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
     ga[i] = A + (size_t)ar * g.lda + kbeg + skc[i] * 8;
     gb[i] = B + (size_t)br * g.ldb + kbeg + skc[i] * 8;
   }
+  // DZ: this thread's staged rows -- weight, ball (its row of `hot`) and row within the ball; the second B operand's rows
+  float dzw[NI];
+  unsigned dzt[NI];
+  const unsigned *dzh[NI];
+  const e16_t *gb2[NI];
+  if (DZ) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int ar = m0 + srow[i], br = n0 + srow[i];
+      ar = ar < Meff ? ar : Meff - 1;
+      br = br < g.N ? br : g.N - 1;
+      dzw[i] = (float)g.row_w[ar];
+      const int pf = dz.unit_src[ar >> 3] * 8 + (ar & 7);
+      dzt[i] = (unsigned)(pf & ((1 << dz.s_shift) - 1));
+      dzh[i] = dz.hot + (size_t)(pf >> dz.s_shift) * dz.C3 + skc[i] * 8;
+      gb2[i] = dz.B2 + (size_t)br * dz.ldb2 + skc[i] * 8;
+    }
+  }
 
   f32x16 acc[NI][NI];
 #pragma unroll
@@ -275,7 +327,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   }
   if (AFF) {
     const bool first = bid == 0 && blockIdx.z == 0;
-    for (int c = tid; c < g.K; c += 256) {
+    const int kaff = DZ ? g.K - GBK : g.K;       // DZ: the last K-step of the first phase is the constant (w, w, 0, ...) step
+    for (int c = tid; c < kaff; c += 256) {
       float av, bv;
       if (aff.sums) {
         const double mu = aff.sums[c] / aff.count;
@@ -320,7 +373,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   {                                                                   \
     const int koff_ = (KT) * GBK;                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {               \
-      if (XG != 1) RA[i_] = ldg16(ga[i_] + koff_);                    \
+      if (XG != 1 && !(DZ && (KT) == nk - 1)) RA[i_] = ldg16(ga[i_] + koff_); \
       RB[i_] = ldg16(gb[i_] + koff_);                                 \
     }                                                                 \
   }
@@ -350,6 +403,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
           RA[i_].z = xg_pack2(y_[4], y_[5]);                                                            \
           RA[i_].w = xg_pack2(y_[6], y_[7]);                                                            \
         }                                                                                               \
+      } else if (DZ && (KT) == nk - 1) {                                                                \
+        /* the constant step: columns 0, 1 carry the row's weight (against -v_hi, -v_lo), the rest is zero */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_)                                               \
+          RA[i_] = make_uint4(skc[i_] == 0 ? pack_e16x2(dzw[i_], dzw[i_]) : 0u, 0u, 0u, 0u);            \
+      } else if (DZ) {                                                                                  \
+      _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                               \
+        RA[i_].x = affine_relu_pair_w(RA[i_].x, fa4_[0][0], fb4_[0][0], fa4_[0][1], fb4_[0][1], dzw[i_]); \
+        RA[i_].y = affine_relu_pair_w(RA[i_].y, fa4_[0][2], fb4_[0][2], fa4_[0][3], fb4_[0][3], dzw[i_]); \
+        RA[i_].z = affine_relu_pair_w(RA[i_].z, fa4_[1][0], fb4_[1][0], fa4_[1][1], fb4_[1][1], dzw[i_]); \
+        RA[i_].w = affine_relu_pair_w(RA[i_].w, fa4_[1][2], fb4_[1][2], fa4_[1][3], fb4_[1][3], dzw[i_]); \
+      }                                                                                                 \
       } else {                                                                                          \
       _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                               \
         RA[i_].x = affine_relu_pair(RA[i_].x, fa4_[0][0], fb4_[0][0], fa4_[0][1], fb4_[0][1]);          \
@@ -437,6 +501,49 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
     mma_step(buf);
     if (kt + 1 < nk) OMNIPQ_STORE_TILES(ra, rb, buf ^ 1, kt + 1)
     __syncthreads();
+  }
+  if (DZ) {
+    // second phase: K = C3, A = the rows' one-hot slices of a dz (generated), B = the last layer's transposed weight
+    const int nk2 = dz.C3 / GBK;
+    uint4 h0[NI], h1[NI];
+    auto dz_load = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint4 *hp = reinterpret_cast<const uint4 *>(dzh[i] + kt * GBK);
+        h0[i] = hp[0];
+        h1[i] = hp[1];
+        rb[i] = ldg16(gb2[i] + kt * GBK);
+      }
+    };
+    auto dz_store = [&](int buf) {
+      e16_t *sa_ = stage + buf * (2 * T * GPITCH);
+      e16_t *sb_ = sa_ + T * GPITCH;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const unsigned t = dzt[i];
+        // word e of the slice: (value << 16 | row) of column e; the value goes where the row matches
+        auto pick = [&](unsigned lo, unsigned hi) -> unsigned {
+          return (((lo & 0xFFu) == t) ? (lo >> 16) : 0u) | (((hi & 0xFFu) == t) ? (hi & 0xFFFF0000u) : 0u);
+        };
+        const uint4 v = make_uint4(pick(h0[i].x, h0[i].y), pick(h0[i].z, h0[i].w), pick(h1[i].x, h1[i].y),
+                                   pick(h1[i].z, h1[i].w));
+        *reinterpret_cast<uint4 *>(sa_ + srow[i] * GPITCH + skc[i] * 8) = v;
+        *reinterpret_cast<uint4 *>(sb_ + srow[i] * GPITCH + skc[i] * 8) = rb[i];
+      }
+    };
+    // (the first phase's last barrier has passed: both staging buffers are free)
+    if (nk2 > 0) {
+      dz_load(0);
+      dz_store(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk2; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk2) dz_load(kt + 1);
+      mma_step(buf);
+      if (kt + 1 < nk2) dz_store(buf ^ 1);
+      __syncthreads();
+    }
   }
   }
 #undef OMNIPQ_LOAD_TILES
@@ -582,7 +689,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
           *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = make_uint4(o[0], o[1], o[2], o[3]);
           continue;
         }
-        if (XG != 2) *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
+        if (XG != 2 && !((STATS == 1 || STATS == 2) && g.no_store))
+          *reinterpret_cast<uint4 *>(C + (size_t)gr * g.ldc + gc) = v;   // N is a multiple of 8
         if (XG == 2) {
           const uint2 xv = *reinterpret_cast<const uint2 *>(xg.X0 + (size_t)gr * xg.ldx);
           const float x0 = e16_lo(xv.x), x1 = e16_hi(xv.x);
@@ -819,8 +927,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   NT_STAMP(7);
 }
 
-template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false, bool PLAN = false>
-__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? ((PLAN && XG == 1) ? 3 : 4) : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
+template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false, bool PLAN = false, bool DZ = false>
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? (((PLAN && XG == 1) || DZ) ? 3 : 4) : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
                                                         const e16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
@@ -828,8 +936,9 @@ __global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? ((PLAN && 
                                                         BnBwdEpilogue bn = BnBwdEpilogue(),
                                                         AffineIn aff = AffineIn(),
                                                         PoolOut pool = PoolOut(),
-                                                        XyzGen xg = XyzGen()) {
-  gemm_nt_body<OUT_F32, STATS, AFF, T, XG, KRES, PLAN>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, (int)blockIdx.x);
+                                                        XyzGen xg = XyzGen(), DzGen dz = DzGen()) {
+  gemm_nt_body<OUT_F32, STATS, AFF, T, XG, KRES, PLAN, DZ>(g, A, B, Cout, bias, stats_out, bn, aff, pool, xg, (int)blockIdx.x,
+                                                          dz);
 }
 
 // Two INDEPENDENT small problems of the same variant in one grid (64 x 64 tiles, K-resident): the per-point stacks of
@@ -1025,7 +1134,7 @@ static void launch_small_single(const omnipq::SmallProblem &p, int lds, hipStrea
   static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)prepared;
-  kern<<<gemm_nt_grid(p.g), 256, lds, stream>>>(p.g, p.A, p.B, p.C, p.bias, p.stats, p.bn, p.aff, PoolOut(), XyzGen());
+  kern<<<gemm_nt_grid(p.g), 256, lds, stream>>>(p.g, p.A, p.B, p.C, p.bias, p.stats, p.bn, p.aff, PoolOut(), XyzGen(), DzGen());
 }
 
 template <int STATS, bool AFF>
@@ -1162,9 +1271,16 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
   using namespace omnipq;
   if (M < 0 || N < 0 || K < 0) return OMNIPQ_EINVAL;
   if (M == 0 || N == 0) return OMNIPQ_OK;
-  if (!A || !B || !C || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8) || K > kAffMaxK) return OMNIPQ_EINVAL;
+  // C == NULL with ball extrema: the tile is not stored (GemmArgs::no_store) -- statistics and extrema only; the
+  // partial-sum path (more than kStatsDirectTiles row tiles) only
+  const bool nostore = !C && pool.s > 0 && sums;
+  if (!A || !B || (!C && !nostore) || (K % GBK) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8) || K > kAffMaxK) return OMNIPQ_EINVAL;
   GemmArgs g{M, N, K, lda, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   plan_rows(g);
+  if (nostore) {
+    if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+    g.no_store = 1;
+  }
   const int groups = (g.m_tiles + 7) / 8;
   dim3 grid(groups * 8 * g.n_tiles, 1, 1);
   const bool small = pool.s == 0 && gemm_nt_small_tiles(M, N);
@@ -1380,6 +1496,54 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
   else
     gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, nullptr,
                                                                 workspace, bn);
+  OMNIPQ_LAUNCH_CHECK();
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  if (slabs < 1) slabs = 1;
+  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
+                                                                                    sums, g.rows_dev);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+
+// Data gradient of the LAST layer of a planned stage without its output gradient (see DzGen), with the BatchNorm-backward
+// sums of the layer below (as omnipq_gemm_nt_e16_bnbwd):
+//   dX2[M][N] = [w relu(a y2 + b) | w, w, 0.. | onehot(a3 dz)] [-G | -v_hi, -v_lo, 0.. | W3^T]^T
+// Y2 e16 [M][lda] (lda == ldc: the BatchNorm-backward epilogue reads it at C's pitch), B1 e16 [N][ldb1] with ldb1 >= N + 32 =
+// [-G | -v | 0], B2 e16 [N][ldb2] the last layer's prepared transposed weight (C3 columns), hot u32 [balls][C3], unit_src /
+// nsample of the stage's plan.  A plan is REQUIRED (M rows, the partial-sum path: more than 64 row tiles).
+extern "C" int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2, int lda, const void *B1, int ldb1,
+                                            const void *B2, int ldb2, const unsigned *hot, const int *unit_src, int nsample,
+                                            void *C, int ldc, const float *a, const float *b, const float *mean,
+                                            const float *invstd, double *sums, float *workspace,
+                                            const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);
+  using namespace omnipq;
+  if (M <= 0 || N <= 0 || C3 <= 0) return OMNIPQ_EINVAL;
+  if (!Y2 || !B1 || !B2 || !hot || !unit_src || !C || !sums || !workspace || !a || !b || !mean || !invstd) return OMNIPQ_EINVAL;
+  if ((N % GBK) || (C3 % GBK) || (lda % 8) || (ldb1 % 8) || (ldb2 % 8) || (ldc % 8) || lda != ldc || lda < N || ldb1 < N + GBK ||
+      ldb2 < C3 || N + GBK > kAffMaxK || nsample < 8 || (nsample & (nsample - 1)))
+    return OMNIPQ_EINVAL;
+  const int K = N + GBK;
+  GemmArgs g{M, N, K, lda, ldb1, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
+  plan_rows(g);
+  if (!g.rows_dev || !g.row_w || g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+  int sh = 0;
+  while ((1 << sh) < nsample) ++sh;
+  DzGen dz;
+  dz.hot = hot;
+  dz.B2 = (const e16_t *)B2;
+  dz.unit_src = unit_src;
+  dz.C3 = C3;
+  dz.ldb2 = ldb2;
+  dz.s_shift = sh;
+  BnBwdEpilogue bn{(const e16_t *)Y2, a, b, mean, invstd};
+  AffineIn aff{};
+  aff.a = a;
+  aff.b = b;
+  gemm_nt_kernel<false, 4, true, 128, 0, false, true, true><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
+      g, (const e16_t *)Y2, (const e16_t *)B1, C, nullptr, workspace, bn, aff, PoolOut(), XyzGen(), dz);
   OMNIPQ_LAUNCH_CHECK();
   int slabs = g.m_tiles / 64;
   if (slabs > 128) slabs = 128;

@@ -513,6 +513,270 @@ __device__ __forceinline__ void tn_tile_dma(const TnArgs &g, const e16_t *__rest
     }
 }
 
+// ---- weight gradient of the LAST layer of a planned stage without its output gradient (sa_last_bwd.hip) ---------------------
+// C[(C3 + N)][N] = [hit | w X2]^T X2 over the stage's compact rows, X2 = relu(ba Y2 + bb) rebuilt from the layer below's pre-BN
+// output Y2 (e16 [P][ldb], N channels) as in tn_tile_dma<AFFB>:
+//   M-tiles below C3 / 128   A = the one-hot gradient of the max-pool (one nonzero per ball and column): GENERATED as MFMA
+//                            fragments from hot[ball][c] = e16(a dz) << 16 | row in the ball -- a lane holds ONE column at the 8
+//                            rows of one plan unit, i.e. one word decides its fragment; no A block is fetched
+//   the N / 128 tiles above  A = w X2: the same Y2 block fetched at the tile's columns, affine + ReLU and the rows' weights
+//                            applied to the fragments (Gram = X2^T diag(w) X2); the tiles of the first column block also
+//                            leave the column sums of w X2 (cs)
+// Loads that feed registers (units, hot words, row weights) are issued BEFORE the LDS-DMA of the step after next, so that the
+// counted vmcnt wait that lets only that DMA stay in flight also covers them.
+struct TnDz {
+  const unsigned *hot;
+  const int *unit_src;
+  const unsigned char *row_w;
+  int C3, s_shift;
+};
+
+__device__ __forceinline__ unsigned tn_affine_relu_pair_w(unsigned w, float a, float b, float w0, float w1) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  omnipq_f32x2 v = __builtin_elementwise_fma(omnipq_f32x2{a, a}, omnipq_f32x2{e16_lo(w), e16_hi(w)}, omnipq_f32x2{b, b});
+  v = v * omnipq_f32x2{w0, w1};
+  const unsigned o = pack_e16x2(v[0], v[1]);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o), s16x2{0, 0}));
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_t *__restrict__ B, float *__restrict__ part,
+                                                           float *__restrict__ colsum, const float *__restrict__ ba,
+                                                           const float *__restrict__ bb, TnDz dz) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TD_NBUF * TD_STAGE_ELEMS * 2];
+  e16_t *const stage = reinterpret_cast<e16_t *>(smem);
+  const int id = (int)blockIdx.x;
+  const int tiles = g.m_tiles * g.n_tiles;
+  const int xcd = id & 7, local = id >> 3;
+  const int slab = xcd + 8 * (local / tiles), tile = local % tiles;
+  if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
+  const int mt = tile / g.n_tiles, nt = tile % g.n_tiles;
+  const int m0 = mt * 128, n0 = nt * 128;
+  const bool hit_tile = m0 < dz.C3;                              // wave-uniform (workgroup-uniform)
+  const int Peff = g.rows_dev ? *g.rows_dev : g.P;
+  int chunk = g.p_chunk;
+  if (g.rows_dev) {
+    const int nslab = (g.P + g.p_chunk - 1) / g.p_chunk;
+    chunk = ((Peff + nslab - 1) / nslab + TBK - 1) / TBK * TBK;
+    if (chunk < TBK) chunk = TBK;
+  }
+  const int pbeg = slab * chunk;
+  int pend = pbeg + chunk;
+  if (pend > Peff) pend = Peff;
+  const int nk = pend > pbeg ? (pend - pbeg + TBK - 1) / TBK : 0;
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int fcolA[2], fcolB[2], frow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    frow[j] = 8 * wave + 4 * j + (lane >> 4);
+    const int slot = (lane & 15) ^ (4 * (frow[j] & 3));
+    fcolA[j] = hit_tile ? 0 : (m0 - dz.C3) + slot * 8;           // Gram tiles: the A block is Y2 at the tile's own columns
+    fcolB[j] = n0 + slot * 8 < g.N ? n0 + slot * 8 : 0;
+  }
+  const int plast = Peff > 0 ? Peff - 1 : 0;
+  auto fetch = [&](int kt, int buf) {
+    e16_t *const sa = stage + buf * TD_STAGE_ELEMS;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int p = pbeg + kt * TBK + frow[j];
+      p = p < pend ? p : plast;
+      if (!hit_tile)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (size_t)p * g.ldb + fcolA[j]),
+                                         (__attribute__((address_space(3))) void *)(sa + (8 * wave + 4 * j) * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (size_t)p * g.ldb + fcolB[j]),
+                                       (__attribute__((address_space(3))) void *)(sa + TBK * 128 + (8 * wave + 4 * j) * 128), 16,
+                                       0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // this lane's fragments cover the 8 positions  pbeg + 32 kt + 16 kk + 8 (lane >> 5) + [0, 8)  = one plan unit
+  const int lhalf = lane >> 5;
+  const int units_in_use = Peff >> 3;
+  auto unit_of = [&](int kt, int kk) { return (pbeg + kt * TBK + 16 * kk + 8 * lhalf) >> 3; };
+  int us[2] = {0, 0}, us_next[2] = {0, 0};        // unit_src of the units of step kt (+1): hit tiles
+  unsigned hw[2][2] = {{0u, 0u}, {0u, 0u}};        // [kk][i]: the hot word of (unit's ball, this lane's column)
+  uint2 wq[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};       // [kk]: the 8 row weights (Gram tiles)
+  const int ccol[2] = {m0 + wm * 64 + (lane & 31), m0 + wm * 64 + 32 + (lane & 31)};      // hit tiles: the lane's columns
+  auto load_units = [&](int kt, int (&dst)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      int u = unit_of(kt, kk);
+      u = u < units_in_use ? u : (units_in_use > 0 ? units_in_use - 1 : 0);
+      dst[kk] = dz.unit_src[u];
+    }
+  };
+  auto load_step_regs = [&](int kt, const int (&usrc)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (hit_tile) {
+        const size_t ball = (size_t)((usrc[kk] * 8) >> dz.s_shift);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hw[kk][i] = dz.hot[ball * dz.C3 + ccol[i]];
+      } else {
+        int p = pbeg + kt * TBK + 16 * kk + 8 * lhalf;
+        p = p + 8 <= Peff ? p : (Peff >= 8 ? Peff - 8 : 0);
+        wq[kk] = *reinterpret_cast<const uint2 *>(dz.row_w + p);
+      }
+    }
+  };
+
+  if (nk > 0) {
+    if (hit_tile) {
+      load_units(0, us);
+      if (nk > 1) load_units(1, us_next);
+    }
+    load_step_regs(0, us);
+    fetch(0, 0);
+  }
+  if (nk > 1) fetch(1, 1);
+
+  const int grp = lane >> 4, l16 = lane & 15;
+  const int tr_row = 8 * (grp >> 1) + (l16 >> 2);
+  int offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = wm * 64 + i * 32 + 16 * (grp & 1) + (l16 & 3) * 4, cb = wn * 64 + i * 32 + 16 * (grp & 1) + (l16 & 3) * 4;
+    offA[i] = tr_row * 128 + (((ca >> 3) ^ (4 * (tr_row & 3))) << 3) + (ca & 7);
+    offB[i] = TBK * 128 + tr_row * 128 + (((cb >> 3) ^ (4 * (tr_row & 3))) << 3) + (cb & 7);
+  }
+  float afa[2], afb[2], aga[2] = {0.f, 0.f}, agb[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = n0 + wn * 64 + i * 32 + (lane & 31);
+    afa[i] = ba[c < g.N ? c : 0];
+    afb[i] = bb[c < g.N ? c : 0];
+    if (!hit_tile) {
+      const int ca = (m0 - dz.C3) + wm * 64 + i * 32 + (lane & 31);
+      aga[i] = ba[ca < g.N ? ca : 0];
+      agb[i] = bb[ca < g.N ? ca : 0];
+    }
+  }
+  const bool do_colsum = colsum != nullptr && !hit_tile && nt == 0 && wn == 0;
+  float csum[2] = {0.f, 0.f};
+  const unsigned smask = (1u << dz.s_shift) - 1u;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // what this step consumes has landed once everything but this wave's DMA instructions for step kt + 1 is done
+    if (kt + 1 < nk) {
+      if (hit_tile) tn_wait_vm<2>(); else tn_wait_vm<4>();
+    } else {
+      tn_wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    // the registers of THIS step (hot words / weights were requested one step ago)
+    unsigned cur_hw[2][2];
+    uint2 cur_wq[2];
+    int cur_us[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      cur_us[kk] = us[kk];
+      cur_wq[kk] = wq[kk];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) cur_hw[kk][i] = hw[kk][i];
+    }
+    // requests for the following steps: registers of step kt + 1, units of step kt + 2, then the DMA of step kt + 2
+    if (kt + 1 < nk) {
+      us[0] = us_next[0];
+      us[1] = us_next[1];
+      load_step_regs(kt + 1, us);
+      if (hit_tile && kt + 2 < nk) load_units(kt + 2, us_next);
+    }
+    if (kt + 2 < nk) fetch(kt + 2, (kt + 2) % TD_NBUF);
+    const e16_t *sa = stage + (kt % TD_NBUF) * TD_STAGE_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      e16x8 fa[2], fb[2];
+      const int first = pbeg + kt * TBK + 16 * kk + 8 * lhalf;   // the lane's 8 positions
+      const bool live = first < pend;                             // (pend is a multiple of 8: units are whole)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const e16_t *pb = sa + kk * 16 * 128 + offB[i];
+        const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pb);
+        const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pb + 4 * 128));
+        uint4 w = __builtin_bit_cast(uint4, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        w.x = tn_affine_relu_pair(w.x, afa[i], afb[i], afa[i], afb[i]);
+        w.y = tn_affine_relu_pair(w.y, afa[i], afb[i], afa[i], afb[i]);
+        w.z = tn_affine_relu_pair(w.z, afa[i], afb[i], afa[i], afb[i]);
+        w.w = tn_affine_relu_pair(w.w, afa[i], afb[i], afa[i], afb[i]);
+        fb[i] = __builtin_bit_cast(e16x8, w);
+      }
+      if (hit_tile) {
+        // the unit's first row within its ball; the column's hit lies in this unit iff its row is in [t0, t0 + 8)
+        const unsigned t0 = ((unsigned)cur_us[kk] * 8u) & smask;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned word = cur_hw[kk][i];
+          const unsigned d = (word & 0xFFu) - t0;
+          const bool in = live && d < 8u;
+          const unsigned v = (word >> 16) << ((d & 1u) * 16u);
+          const unsigned q = d >> 1;
+          const uint4 w = make_uint4((in && q == 0u) ? v : 0u, (in && q == 1u) ? v : 0u, (in && q == 2u) ? v : 0u,
+                                     (in && q == 3u) ? v : 0u);
+          fa[i] = __builtin_bit_cast(e16x8, w);
+        }
+      } else {
+        const unsigned lo = live ? cur_wq[kk].x : 0u, hi = live ? cur_wq[kk].y : 0u;   // rows past the slab: weight 0
+        const float w0 = (float)(lo & 0xFFu), w1 = (float)((lo >> 8) & 0xFFu), w2 = (float)((lo >> 16) & 0xFFu),
+                    w3 = (float)(lo >> 24), w4 = (float)(hi & 0xFFu), w5 = (float)((hi >> 8) & 0xFFu),
+                    w6 = (float)((hi >> 16) & 0xFFu), w7 = (float)(hi >> 24);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const e16_t *pa = sa + kk * 16 * 128 + offA[i];
+          const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pa);
+          const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pa + 4 * 128));
+          uint4 w = __builtin_bit_cast(uint4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          w.x = tn_affine_relu_pair_w(w.x, aga[i], agb[i], w0, w1);
+          w.y = tn_affine_relu_pair_w(w.y, aga[i], agb[i], w2, w3);
+          w.z = tn_affine_relu_pair_w(w.z, aga[i], agb[i], w4, w5);
+          w.w = tn_affine_relu_pair_w(w.w, aga[i], agb[i], w6, w7);
+          fa[i] = __builtin_bit_cast(e16x8, w);
+          if (do_colsum)
+            csum[i] += ((e16_lo(w.x) + e16_hi(w.x)) + (e16_lo(w.y) + e16_hi(w.y))) +
+                       ((e16_lo(w.z) + e16_hi(w.z)) + (e16_lo(w.w) + e16_hi(w.w)));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = mfma_e16_32x32x16(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float t = csum[i] + __shfl_xor(csum[i], 32, 64);
+      const int ch = m0 + wm * 64 + i * 32 + lane;
+      if (lane < 32 && ch < g.M) colsum[(size_t)slab * g.M + ch] = t;
+    }
+  }
+  float *C = part + (size_t)slab * g.M * g.N;
+  const int ccl = lane & 31, crow0 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gc = n0 + wn * 64 + j * 32 + ccl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+        if (gr < g.M && gc < g.N) C[(size_t)gr * g.N + gc] = acc[i][j][r];
+      }
+    }
+}
+
 // REG: the register-prefetch program (tools/bench_tn_grouped.py compares the two; omnipq_tn_debug(1) selects it)
 template <bool REG>
 __global__ __launch_bounds__(256, REG ? 4 : 3) void gemm_tn_kernel(TnArgs g, const e16_t *__restrict__ A,
@@ -774,6 +1038,65 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
                                                                                reinterpret_cast<f32x4 *>(C));
   }
   OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// ---- last layer of a planned stage: [hit | w X2]^T X2 (see gemm_tn_dz_kernel) -------------------------------------------
+// R (f32 [(C3 + N)][N]) = the reduced product, cs_part = float[slabs][C3 + N] partial column sums (entries C3 .. C3 + N are
+// valid), *slabs_out = the slabs in use.  workspace: omnipq_gemm_tn_dz_workspace_floats(C3, N, P) floats; R and cs_part point
+// into it (R = workspace, cs_part behind the slabs).  A plan is REQUIRED.
+static int tn_dz_slabs(int tiles, int P) { return omnipq_gemm_tn_slabs(tiles, P, omnipq::TBK); }
+
+extern "C" long long omnipq_gemm_tn_dz_workspace_floats(int C3, int N, int P) {
+  const long long M = (long long)C3 + N;
+  const int tiles = (int)(M / 128) * ((N + 127) / 128);
+  const long long slabs = tn_dz_slabs(tiles, P);
+  // [R: M N] [mid: kReduceGroups M N] [slabs: slabs M N] [cs: slabs M]
+  return M * N * (1 + omnipq::kReduceGroups + slabs) + slabs * M;
+}
+
+extern "C" int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, const float *ba, const float *bb,
+                                  const unsigned *hot, const int *unit_src, int nsample, float *workspace, int *slabs_out,
+                                  long long *cs_offset_out, const omnipq_row_plan *plan, void *stream) {
+  omnipq::PlanScope plan_scope_(plan);
+  using namespace omnipq;
+  if (C3 <= 0 || N <= 0 || P <= 0 || (C3 % 128) || (N % 128) || (ldb % 8) || ldb < N) return OMNIPQ_EINVAL;
+  if (!Y2 || !ba || !bb || !hot || !unit_src || !workspace || nsample < 8 || (nsample & (nsample - 1))) return OMNIPQ_EINVAL;
+  const RowPlan &rp = row_plan();
+  if (!rp.rows_dev || !rp.row_w || rp.rows != P) return OMNIPQ_EINVAL;
+  const int M = C3 + N;
+  TnArgs g{M, N, P, ldb, ldb, 0, M / 128, N / 128};
+  g.rows_dev = rp.rows_dev;
+  const int tiles = g.m_tiles * g.n_tiles;
+  const int slabs = tn_dz_slabs(tiles, P);
+  g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
+  const int used = (P + g.p_chunk - 1) / g.p_chunk;
+  g.colsum_rows = 1;
+  int sh = 0;
+  while ((1 << sh) < nsample) ++sh;
+  const size_t mn = (size_t)M * N;
+  float *R = workspace, *mid = workspace + mn, *part = workspace + mn * (1 + kReduceGroups);
+  float *cs = part + mn * (size_t)slabs;
+  TnDz dz{hot, unit_src, rp.row_w, C3, sh};
+  // (every slab in use writes its partial column-sum row, also one that holds no rows in use: zeros)
+  gemm_tn_dz_kernel<<<dim3(tiles * ((used + 7) / 8) * 8), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)Y2, part, cs, ba, bb,
+                                                                                       dz);
+  OMNIPQ_LAUNCH_CHECK();
+  const int n4 = (int)(mn / 4);
+  const f32x4 *part4 = reinterpret_cast<const f32x4 *>(part);
+  if (used > 2 * kReduceGroups) {
+    slab_reduce_kernel<<<dim3((n4 + 255) / 256, kReduceGroups), 256, 0, (hipStream_t)stream>>>(
+        n4, used, kReduceGroups, part4, reinterpret_cast<f32x4 *>(mid));
+    OMNIPQ_LAUNCH_CHECK();
+    slab_reduce_kernel<<<dim3((n4 + 255) / 256, 1), 256, 0, (hipStream_t)stream>>>(
+        n4, kReduceGroups, 1, reinterpret_cast<const f32x4 *>(mid), reinterpret_cast<f32x4 *>(R));
+  } else {
+    slab_reduce_kernel<<<dim3((n4 + 255) / 256, 1), 256, 0, (hipStream_t)stream>>>(n4, used, 1, part4,
+                                                                               reinterpret_cast<f32x4 *>(R));
+  }
+  OMNIPQ_LAUNCH_CHECK();
+  if (slabs_out) *slabs_out = used;
+  if (cs_offset_out) *cs_offset_out = (long long)(cs - workspace);
   return OMNIPQ_OK;
 }
 

@@ -417,9 +417,10 @@ def _plan_pool_gamma(gamma):
     _plan_state.struct.pool_gamma = _p(gamma).value
 
 
-def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None):
-    """bf16 C = relu(below.a * Y + below.b) Bw^T (+ bias); sums (f64 [2][N], zero on entry): also C's statistics."""
-    C = torch.empty((M, N), device=Y.device, dtype=E16.dtype) if out is None else out
+def gemm_nt_affine(Y, below, Bw, M, N, K, sums=None, bias=None, out=None, pool=None, store=True):
+    """bf16 C = relu(below.a * Y + below.b) Bw^T (+ bias); sums (f64 [2][N], zero on entry): also C's statistics.
+    store=False (with pool, on a plan): C is not written -- statistics and ball extrema only; returns None."""
+    C = (torch.empty((M, N), device=Y.device, dtype=E16.dtype) if out is None else out) if store else None
     ws = None
     if sums is not None:
         n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(M, N))
@@ -480,6 +481,38 @@ hoist_uses = 0
 def hoist_ok(training, features, cin, cin_raw, L, c1, xgen):
     return HOIST_L1 and training and features is not None and not xgen and cin == cin_raw and cin % 32 == 0 and cin > 0 and \
         L >= 2 and AFFINE_OPERANDS and c1 % 32 == 0 and 32 <= c1 <= 640
+
+
+# The LAST layer of a planned stage, backward without its output gradient (round 6; csrc/sa_last_bwd.hip):
+# dY3 = a hit - w (alpha + beta Y3) with Y3 = X2 W3^T substituted, so that dX2 and dW3 are contractions of X2 (rebuilt from Y2
+# as everywhere), the one-hot pool gradient `hit` (generated inside the two GEMMs from one word per ball and column) and
+# C2-sized matrices.  Neither dY3 nor Y3 exists: the forward's last GEMM stores statistics and ball extrema only.
+# LAST_NO_DY = False restores the stored Y3 / dY3 (tests compare the two).
+LAST_NO_DY = True
+last_no_dy_uses = 0
+_lib.omnipq_gemm_tn_dz_workspace_floats.restype = ctypes.c_longlong
+
+
+def last_no_dy_ok(plan, L, c2, c3, S, below_keeps_y_only):
+    """a plan with its unit map, the layer below consumed as (Y, a, b), whole 128-column tiles on both sides"""
+    return LAST_NO_DY and plan is not None and getattr(plan, "unit_src", None) is not None and L >= 2 and \
+        below_keeps_y_only and c2 % 128 == 0 and c3 % 128 == 0 and c2 + 32 <= 1024 and S >= 8 and (S & (S - 1)) == 0 and \
+        AFFINE_OPERANDS and POOL_EPILOGUE and _FOLD_SMALL
+
+
+def last_wgrad_dz(Y2, below, hot, plan, S, C3, C2, P, alpha, beta, Wp, out=None):
+    """dW3 (f32 [C3][C2]) of a stage's last layer from the layer below's pre-BN output and the pool's one-hot gradient
+    (omnipq_gemm_tn_dz + omnipq_sa_last_wgrad_combine); inside the caller's _row_plan block."""
+    dev = Y2.device
+    ws = torch.empty((int(_lib.omnipq_gemm_tn_dz_workspace_floats(C3, C2, P)),), device=dev, dtype=torch.float32)
+    slabs, cs_off = ctypes.c_int(0), ctypes.c_longlong(0)
+    _call(_lib.omnipq_gemm_tn_dz, Y2, C3, C2, P, _p(Y2), Y2.stride(0), _p(below.a), _p(below.b), _p(hot), _p(plan.unit_src), S,
+          _p(ws), ctypes.byref(slabs), ctypes.byref(cs_off))
+    if out is None:
+        out = torch.empty((C3, C2), device=dev, dtype=torch.float32)
+    _call(_lib.omnipq_sa_last_wgrad_combine, Y2, C3, C2, _p(ws), ctypes.c_void_p(ws.data_ptr() + 4 * cs_off.value),
+          slabs.value, C3 + C2, _p(alpha), _p(beta), _p(Wp), Wp.stride(0), _p(out), C2, 0)
+    return out
 
 
 def gemm_nt_f32(A, B, M, N, K, lda, ldb):
@@ -712,6 +745,7 @@ class deferred_wgrads:
         self.items = []             # (dY, X, M, N, P, weight target, (cout, cin[, rot]), bias target | None, affine | None, row plan | None)
         self.sa_items = []          # the same for the SA stages' layers: a grouped launch of their own (see add_sa)
         self.ln_items = []          # (partials [blocks][2C], blocks, C, gamma, beta): LayerNorm parameter gradients
+        self.dz_items = []          # (arguments of last_wgrad_dz, weight target, stage label): last layers without dY (LAST_NO_DY)
         self.producers = set()      # streams other than the flushing one on which collected operands were produced
         deferred_wgrads.active = self
         return self
@@ -743,6 +777,13 @@ class deferred_wgrads:
         # blk: the stage's row plan (_Plan: the positions in use live in device memory), or None
         self.sa_items.append((dY, X, M, N, P, wt, crop, None, None if below is None else (below.a, below.b), blk))
 
+    def add_dz(self, args, wt, stage):
+        """The last layer of a planned SA stage (LAST_NO_DY): its weight gradient is launched with the other SA stages' when
+        the block ends (last_wgrad_dz: its own launch, the operands are generated)."""
+        _refuse_ddp(wt)
+        self._note_producer(args[0])
+        self.dz_items.append((args, wt, stage))
+
     def __exit__(self, et, ev, tb):
         deferred_wgrads.active = None
         global COLLECTIVES_LAST_STEP, _COLLECTIVES_MARK
@@ -759,6 +800,7 @@ class deferred_wgrads:
                 self._accumulate(param, g)
         self.items = None
         self.sa_items = None
+        self.dz_items = None
         self.ln_items = None
         self._inflight = None
         self._assign = None
@@ -825,6 +867,15 @@ class deferred_wgrads:
             with _tagged("@sa"):
                 self._flush_items(items)
             self.__dict__.setdefault("_inflight", []).extend(items)
+        if self.dz_items and deferred_wgrads.active is None:
+            todo, self.dz_items = self.dz_items, []
+            assign = self.__dict__.setdefault("_assign", [])
+            for args, wt, stage in todo:
+                Y2, below, hot, plan, S, C3, C2, P, alpha, beta, Wp = args
+                with _tagged("@sa", stage), _row_plan(plan, P):
+                    buf = last_wgrad_dz(Y2, below, hot, plan, S, C3, C2, P, alpha, beta, Wp)
+                assign.append((wt[1], buf.view(wt[1].shape)))
+            self.__dict__.setdefault("_inflight", []).extend(todo)
 
     def _flush_items(self, items):
         dev = items[0][0].device
@@ -1253,6 +1304,7 @@ class FusedSAStage(torch.autograd.Function):
             if plan is None or plan.gs != PLAN_GROUP:
                 plan = make_row_plan(idx, P)
         ctx.plan = plan
+        ctx.no_dy = False
         hoist = hoist_ok(training, features, cin, cin_raw, L, params[0].shape[0], xgen) and \
             (plan is None or not xyz_grad)
         ctx.hoist = None
@@ -1333,7 +1385,14 @@ class FusedSAStage(torch.autograd.Function):
                     lay.Y = gemm_nt_xyz(X0, layers[0], lay.Wp, P, cout, K, sums)
                 elif l > 0 and X is None:
                     # the layer below never stored relu(bn(Y)): this GEMM rebuilds it while staging its operand
-                    lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums, pool=pool)
+                    nody = l == L - 1 and pool is not None and layers[l - 1].fin is not None and \
+                        last_no_dy_ok(getattr(ctx, "plan", None), L, K, cout, S, True)
+                    if nody:
+                        global last_no_dy_uses
+                        last_no_dy_uses += 1
+                        ctx.no_dy = True
+                    lay.Y = gemm_nt_affine(layers[l - 1].Y, layers[l - 1], lay.Wp, P, cout, K, sums=sums, pool=pool,
+                                           store=not nody)
                 else:
                     lay.Y = _gemm_nt_stats(X, lay.Wp, P, cout, K, sums, pool=pool)     # GEMM + batch statistics
                 _allreduce_(sums, world)
@@ -1455,8 +1514,43 @@ class FusedSAStage(torch.autograd.Function):
             _call(_lib.omnipq_sa_pool_bwd_stats, g_out, B, M, S, last.C, _p(last.Y), _p(last.mean), _p(last.invstd),
                   _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(sums))
         # dgamma = sum dz * yhat, dbeta = sum dz: LOCAL totals (DDP averages them), taken before the all-reduce
-        dY = torch.empty_like(last.Y)
-        if world > 1 or _FORCE_COLLECTIVES or not _FOLD_SMALL:
+        no_dy = getattr(ctx, "no_dy", False)
+        dY = None if no_dy else torch.empty_like(last.Y)
+        if no_dy:
+            below = layers[L - 2]
+            C3, C2 = last.C, last.K
+            plan = ctx.plan
+            gb3 = None
+            if world > 1 or _FORCE_COLLECTIVES:
+                grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, C3)
+                _allreduce_(sums[:2], world)
+            else:
+                gb3 = torch.empty((2, C3), device=dev, dtype=torch.float32)      # dbeta | dgamma, written by the prep
+                grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = gb3[1], gb3[0]
+            hot = torch.empty((B * M, C3), device=dev, dtype=torch.int32)
+            B1 = torch.empty((C2, C2 + 32), device=dev, dtype=E16.dtype)
+            ab = torch.empty((2, C3), device=dev, dtype=torch.float32)          # alpha | beta
+            _call(_lib.omnipq_sa_last_bwd_prep, g_out, ctypes.c_longlong(B * M), C3, C2, _p(sums), total, _p(last.a),
+                  _p(last.mean), _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(last.Wt), last.Wt.stride(0),
+                  _p(hot), _p(B1), C2 + 32, _p(ab[0]), _p(ab[1]), _p(gb3))
+            # the layer's weight gradient: from Y2 and `hot`, with the other SA stages' when the deferred block ends
+            dfr = deferred_wgrads.active
+            wt = ctx.wtargets[L - 1] if (dfr is not None and SA_WGRADS_GROUPED) else None
+            if ctx.needs_input_grad[9 + 3 * (L - 1)]:
+                if wt is not None and wt[0] == "param" and wt[2] == 0 and wt[1].numel() == C3 * C2:
+                    dfr.add_dz((below.Y, below, hot, plan, S, C3, C2, P, ab[0], ab[1], last.Wp), wt, ctx.stage_label)
+                else:
+                    grads[3 * (L - 1)] = last_wgrad_dz(below.Y, below, hot, plan, S, C3, C2, P, ab[0], ab[1],
+                                                       last.Wp).view(C3, C2, 1, 1)
+            # the data gradient + the BatchNorm-backward sums of the layer below
+            pend0 = zeros_f64(3, below.C, dev)
+            dX2 = torch.empty((P, C2), device=dev, dtype=E16.dtype)
+            n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(P, C2))
+            ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
+            _call(_lib.omnipq_gemm_nt_e16_dz_bnbwd, dX2, P, C2, C3, _p(below.Y), C2, _p(B1), C2 + 32, _p(last.Wt),
+                  last.Wt.stride(0), _p(hot), _p(plan.unit_src), S, _p(dX2), C2, _p(below.a), _p(below.b), _p(below.mean),
+                  _p(below.invstd), _p(pend0), _p(ws))
+        elif world > 1 or _FORCE_COLLECTIVES or not _FOLD_SMALL:
             grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
             _allreduce_(sums[:2], world)
             _call(_lib.omnipq_sa_pool_bwd_apply, g_out, B, M, S, last.C, total, _p(last.Y), _p(last.a), _p(last.mean),
@@ -1472,7 +1566,9 @@ class FusedSAStage(torch.autograd.Function):
         xgen = getattr(ctx, "xgen", False)
         dfr = deferred_wgrads.active
         pend = None                  # BatchNorm-backward totals of layer l when `dY` still holds dX (gradient w.r.t. its ReLU output)
-        for l in range(L - 1, -1, -1):
+        if no_dy:
+            dY, pend = dX2, pend0        # the last layer is done: the loop starts at the layer below
+        for l in range(L - 2 if no_dy else L - 1, -1, -1):
             lay = layers[l]
             if pend is not None:
                 grads[3 * l + 1], grads[3 * l + 2] = bn_backward_apply(dY, lay, P, lay.C, total, pend, world)
