@@ -518,18 +518,25 @@ __device__ __forceinline__ void tn_tile_dma(const TnArgs &g, const e16_t *__rest
 // output Y2 (e16 [P][ldb], N channels) as in tn_tile_dma<AFFB>:
 //   M-tiles below C3 / 128   A = the one-hot gradient of the max-pool (one nonzero per ball and column): GENERATED as MFMA
 //                            fragments from hot[ball][c] = e16(a dz) << 16 | row in the ball -- a lane holds ONE column at the 8
-//                            rows of one plan unit, i.e. one word decides its fragment; no A block is fetched
+//                            rows of one plan unit, i.e. one word decides its fragment.  No A block is fetched; the words of a
+//                            step's four units (4 x 128 columns) travel by LDS-DMA into the unused A half of the ring slot
 //   the N / 128 tiles above  A = w X2: the same Y2 block fetched at the tile's columns, affine + ReLU and the rows' weights
 //                            applied to the fragments (Gram = X2^T diag(w) X2); the tiles of the first column block also
 //                            leave the column sums of w X2 (cs)
-// Loads that feed registers (units, hot words, row weights) are issued BEFORE the LDS-DMA of the step after next, so that the
-// counted vmcnt wait that lets only that DMA stay in flight also covers them.
+// NOTHING is loaded from memory into registers inside the loop: the compiler's wait-count insertion treats a loop-carried
+// register load conservatively (vmcnt(0) per step: the ring's two steps in flight collapse to one trip to memory per step --
+// measured: 198 us instead of ~100 on sa1; and it does not scalarise loads behind an LDS-DMA either).  Everything comes
+// through LDS-DMA: the hot words into the ring, the wave-uniform operands (the four units' positions in the full layout of
+// step kt + 3, or the 32 row weights of step kt + 2) into a four-deep side ring `aux`, 16 / 32 bytes per step, written by
+// every wave alike and read back with ds_read.  Per step and wave: one aux instruction, then four of the step's blocks.
 struct TnDz {
   const unsigned *hot;
   const int *unit_src;
   const unsigned char *row_w;
   int C3, s_shift;
 };
+constexpr int TDZ_HPITCH = 160;      // dwords between the hot words of two units of a step (128 + 32: the lane halves of a
+                                     // fragment read units j, j + 1 -- 32 banks apart)
 
 __device__ __forceinline__ unsigned tn_affine_relu_pair_w(unsigned w, float a, float b, float w0, float w1) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
   if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
   const int mt = tile / g.n_tiles, nt = tile % g.n_tiles;
   const int m0 = mt * 128, n0 = nt * 128;
-  const bool hit_tile = m0 < dz.C3;                              // wave-uniform (workgroup-uniform)
+  const bool hit_tile = m0 < dz.C3;                              // workgroup-uniform
   const int Peff = g.rows_dev ? *g.rows_dev : g.P;
   int chunk = g.p_chunk;
   if (g.rows_dev) {
@@ -565,8 +572,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
   const int nk = pend > pbeg ? (pend - pbeg + TBK - 1) / TBK : 0;
 
   const int tid = (int)threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const int lhalf = lane >> 5;
 
   int fcolA[2], fcolB[2], frow[2];
 #pragma unroll
@@ -577,6 +586,28 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
     fcolB[j] = n0 + slot * 8 < g.N ? n0 + slot * 8 : 0;
   }
   const int plast = Peff > 0 ? Peff - 1 : 0;
+  const int units_in_use = Peff >> 3;
+  __shared__ __attribute__((aligned(16))) unsigned aux[4][8];
+  // aux DMA of step kt: hit tiles -- unit_src of its four units (lanes 0..3); Gram tiles -- its 32 row weights (lanes 0..7)
+  auto fetch_aux = [&](int kt) {
+    unsigned *dst = aux[kt & 3];
+    if (hit_tile) {
+      if (lane < 4) {
+        int u = ((pbeg + kt * TBK) >> 3) + lane;
+        u = u < units_in_use ? u : (units_in_use > 0 ? units_in_use - 1 : 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dz.unit_src + u),
+                                         (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+      }
+    } else {
+      if (lane < 8)         // (+ 32 <= P: the weights of rows past Peff are masked by `live`)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(dz.row_w + (size_t)(pbeg + kt * TBK) + 4 * lane),
+            (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+    }
+  };
+  // the DMA of one step: this wave's four rows of the B block (and of the A block: Gram tiles), or -- hit tiles -- the hot
+  // words of unit `wave` of the step for the tile's 128 columns, into the A half of the slot.  Hit tiles read the unit's
+  // position from aux (its DMA was issued a step earlier and has landed: see the loop's wait)
   auto fetch = [&](int kt, int buf) {
     e16_t *const sa = stage + buf * TD_STAGE_ELEMS;
 #pragma unroll
@@ -590,6 +621,16 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
                                        (__attribute__((address_space(3))) void *)(sa + TBK * 128 + (8 * wave + 4 * j) * 128), 16,
                                        0, 0);
     }
+    if (hit_tile) {
+      const int us = (int)aux[kt & 3][wave];
+      const size_t ball = (size_t)((us * 8) >> dz.s_shift);
+      const unsigned *src = dz.hot + ball * dz.C3 + m0 + lane;
+      unsigned *dst = reinterpret_cast<unsigned *>(sa) + wave * TDZ_HPITCH;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 64 * h),
+                                         (__attribute__((address_space(3))) void *)(dst + 64 * h), 4, 0, 0);
+    }
   };
 
   f32x16 acc[2][2];
@@ -599,47 +640,6 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // this lane's fragments cover the 8 positions  pbeg + 32 kt + 16 kk + 8 (lane >> 5) + [0, 8)  = one plan unit
-  const int lhalf = lane >> 5;
-  const int units_in_use = Peff >> 3;
-  auto unit_of = [&](int kt, int kk) { return (pbeg + kt * TBK + 16 * kk + 8 * lhalf) >> 3; };
-  int us[2] = {0, 0}, us_next[2] = {0, 0};        // unit_src of the units of step kt (+1): hit tiles
-  unsigned hw[2][2] = {{0u, 0u}, {0u, 0u}};        // [kk][i]: the hot word of (unit's ball, this lane's column)
-  uint2 wq[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};       // [kk]: the 8 row weights (Gram tiles)
-  const int ccol[2] = {m0 + wm * 64 + (lane & 31), m0 + wm * 64 + 32 + (lane & 31)};      // hit tiles: the lane's columns
-  auto load_units = [&](int kt, int (&dst)[2]) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      int u = unit_of(kt, kk);
-      u = u < units_in_use ? u : (units_in_use > 0 ? units_in_use - 1 : 0);
-      dst[kk] = dz.unit_src[u];
-    }
-  };
-  auto load_step_regs = [&](int kt, const int (&usrc)[2]) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      if (hit_tile) {
-        const size_t ball = (size_t)((usrc[kk] * 8) >> dz.s_shift);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) hw[kk][i] = dz.hot[ball * dz.C3 + ccol[i]];
-      } else {
-        int p = pbeg + kt * TBK + 16 * kk + 8 * lhalf;
-        p = p + 8 <= Peff ? p : (Peff >= 8 ? Peff - 8 : 0);
-        wq[kk] = *reinterpret_cast<const uint2 *>(dz.row_w + p);
-      }
-    }
-  };
-
-  if (nk > 0) {
-    if (hit_tile) {
-      load_units(0, us);
-      if (nk > 1) load_units(1, us_next);
-    }
-    load_step_regs(0, us);
-    fetch(0, 0);
-  }
-  if (nk > 1) fetch(1, 1);
 
   const int grp = lane >> 4, l16 = lane & 15;
   const int tr_row = 8 * (grp >> 1) + (l16 >> 2);
@@ -664,36 +664,35 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
   }
   const bool do_colsum = colsum != nullptr && !hit_tile && nt == 0 && wn == 0;
   float csum[2] = {0.f, 0.f};
+  // prologue: the aux words of the first steps, then the blocks of steps 0 and 1 (eight instructions in flight)
+  if (nk > 0) {
+    fetch_aux(0);
+    if (nk > 1) fetch_aux(1);
+    if (nk > 2) fetch_aux(2);
+    tn_wait_vm<0>();
+    fetch(0, 0);
+    if (nk > 1) fetch(1, 1);
+  }
+
   const unsigned smask = (1u << dz.s_shift) - 1u;
+  // the hot word of (unit j = 2 kk + lhalf, this lane's column of block i): dword j * TDZ_HPITCH + wm * 64 + i * 32 + lane % 32
+  const int hoff = lhalf * TDZ_HPITCH + wm * 64 + (lane & 31);
 
   for (int kt = 0; kt < nk; ++kt) {
-    // what this step consumes has landed once everything but this wave's DMA instructions for step kt + 1 is done
-    if (kt + 1 < nk) {
-      if (hit_tile) tn_wait_vm<2>(); else tn_wait_vm<4>();
-    } else {
-      tn_wait_vm<0>();
-    }
+    // step kt (and the aux words issued with step kt + 1's blocks, in front of them) has landed once this wave's four block
+    // instructions for step kt + 1 are all that is in flight
+    if (kt + 1 < nk) tn_wait_vm<4>(); else tn_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    // the registers of THIS step (hot words / weights were requested one step ago)
-    unsigned cur_hw[2][2];
-    uint2 cur_wq[2];
-    int cur_us[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      cur_us[kk] = us[kk];
-      cur_wq[kk] = wq[kk];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) cur_hw[kk][i] = hw[kk][i];
+    if (kt + 2 < nk) {
+      if (hit_tile) {
+        if (kt + 3 < nk) fetch_aux(kt + 3);
+      } else {
+        fetch_aux(kt + 2);
+      }
+      fetch(kt + 2, (kt + 2) % TD_NBUF);
     }
-    // requests for the following steps: registers of step kt + 1, units of step kt + 2, then the DMA of step kt + 2
-    if (kt + 1 < nk) {
-      us[0] = us_next[0];
-      us[1] = us_next[1];
-      load_step_regs(kt + 1, us);
-      if (hit_tile && kt + 2 < nk) load_units(kt + 2, us_next);
-    }
-    if (kt + 2 < nk) fetch(kt + 2, (kt + 2) % TD_NBUF);
     const e16_t *sa = stage + (kt % TD_NBUF) * TD_STAGE_ELEMS;
+    const unsigned *sh = reinterpret_cast<const unsigned *>(sa);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       e16x8 fa[2], fb[2];
@@ -713,10 +712,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
       }
       if (hit_tile) {
         // the unit's first row within its ball; the column's hit lies in this unit iff its row is in [t0, t0 + 8)
-        const unsigned t0 = ((unsigned)cur_us[kk] * 8u) & smask;
+        const unsigned t0 = (aux[kt & 3][2 * kk + lhalf] * 8u) & smask;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const unsigned word = cur_hw[kk][i];
+          const unsigned word = sh[hoff + 2 * kk * TDZ_HPITCH + 32 * i];
           const unsigned d = (word & 0xFFu) - t0;
           const bool in = live && d < 8u;
           const unsigned v = (word >> 16) << ((d & 1u) * 16u);
@@ -726,7 +725,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
           fa[i] = __builtin_bit_cast(e16x8, w);
         }
       } else {
-        const unsigned lo = live ? cur_wq[kk].x : 0u, hi = live ? cur_wq[kk].y : 0u;   // rows past the slab: weight 0
+        unsigned lo = aux[kt & 3][4 * kk + 2 * lhalf], hi = aux[kt & 3][4 * kk + 2 * lhalf + 1];
+        lo = live ? lo : 0u;                                      // rows past the slab: weight 0
+        hi = live ? hi : 0u;
         const float w0 = (float)(lo & 0xFFu), w1 = (float)((lo >> 8) & 0xFFu), w2 = (float)((lo >> 16) & 0xFFu),
                     w3 = (float)(lo >> 24), w4 = (float)(hi & 0xFFu), w5 = (float)((hi >> 8) & 0xFFu),
                     w6 = (float)((hi >> 16) & 0xFFu), w7 = (float)(hi >> 24);

@@ -132,7 +132,7 @@ def main():
             tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
         sa_ms = sum(v for k, v in tot.items() if k.endswith("@sa")) / args.steps
         print(f"{args.capi or args.flag}={mode}: sa stage {sa_ms:.3f} ms/step (event-timed C-ABI calls)")
-        for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]:
+        for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:int(os.environ.get('SA_AB_TOP', '14'))]:
             print(f"    {k:50s} {v / args.steps * 1e3:9.1f} us/step")
 
     if args.per_stage:
