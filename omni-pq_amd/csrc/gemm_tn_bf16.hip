@@ -587,10 +587,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
   }
   const int plast = Peff > 0 ? Peff - 1 : 0;
   const int units_in_use = Peff >> 3;
-  __shared__ __attribute__((aligned(16))) unsigned aux[4][8];
+  __shared__ __attribute__((aligned(16))) unsigned aux[8][8];
+  const int lead = hit_tile ? 4 : 2;          // steps an aux word travels ahead of its use
   // aux DMA of step kt: hit tiles -- unit_src of its four units (lanes 0..3); Gram tiles -- its 32 row weights (lanes 0..7)
-  auto fetch_aux = [&](int kt) {
-    unsigned *dst = aux[kt & 3];
+  auto fetch_aux = [&](int kt_) {
+    const int kt = kt_ < nk ? kt_ : nk - 1;       // (past the slab: a redundant fetch into a slot nobody reads -- the group of
+                                                   // instructions a step issues keeps its length, which the counted wait relies on)
+    unsigned *dst = aux[kt_ & 7];
     if (hit_tile) {
       if (lane < 4) {
         int u = ((pbeg + kt * TBK) >> 3) + lane;
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
                                        0, 0);
     }
     if (hit_tile) {
-      const int us = (int)aux[kt & 3][wave];
+      const int us = (int)aux[kt & 7][wave];
       const size_t ball = (size_t)((us * 8) >> dz.s_shift);
       const unsigned *src = dz.hot + ball * dz.C3 + m0 + lane;
       unsigned *dst = reinterpret_cast<unsigned *>(sa) + wave * TDZ_HPITCH;
@@ -666,12 +669,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
   float csum[2] = {0.f, 0.f};
   // prologue: the aux words of the first steps, then the blocks of steps 0 and 1 (eight instructions in flight)
   if (nk > 0) {
-    fetch_aux(0);
-    if (nk > 1) fetch_aux(1);
-    if (nk > 2) fetch_aux(2);
+    for (int i = 0; i < lead; ++i) fetch_aux(i);
     tn_wait_vm<0>();
     fetch(0, 0);
-    if (nk > 1) fetch(1, 1);
+    if (nk > 1) {
+      fetch_aux(lead - 1);                     // (again: every group is one aux instruction + four block instructions)
+      fetch(1, 1);
+    }
   }
 
   const unsigned smask = (1u << dz.s_shift) - 1u;
@@ -679,16 +683,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
   const int hoff = lhalf * TDZ_HPITCH + wm * 64 + (lane & 31);
 
   for (int kt = 0; kt < nk; ++kt) {
-    // step kt (and the aux words issued with step kt + 1's blocks, in front of them) has landed once this wave's four block
-    // instructions for step kt + 1 are all that is in flight
-    if (kt + 1 < nk) tn_wait_vm<4>(); else tn_wait_vm<0>();
+    // step kt has landed once the group issued with step kt + 1 -- one aux instruction, four block instructions -- is all
+    // that is in flight; the aux words a step needs (its own, and -- hit tiles -- those that address the hot words of step
+    // kt + 2) were issued two steps ago or earlier
+    if (kt + 1 < nk) tn_wait_vm<5>(); else tn_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) {
-      if (hit_tile) {
-        if (kt + 3 < nk) fetch_aux(kt + 3);
-      } else {
-        fetch_aux(kt + 2);
-      }
+      fetch_aux(kt + lead);
       fetch(kt + 2, (kt + 2) % TD_NBUF);
     }
     const e16_t *sa = stage + (kt % TD_NBUF) * TD_STAGE_ELEMS;
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
       }
       if (hit_tile) {
         // the unit's first row within its ball; the column's hit lies in this unit iff its row is in [t0, t0 + 8)
-        const unsigned t0 = (aux[kt & 3][2 * kk + lhalf] * 8u) & smask;
+        const unsigned t0 = (aux[kt & 7][2 * kk + lhalf] * 8u) & smask;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const unsigned word = sh[hoff + 2 * kk * TDZ_HPITCH + 32 * i];
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
           fa[i] = __builtin_bit_cast(e16x8, w);
         }
       } else {
-        unsigned lo = aux[kt & 3][4 * kk + 2 * lhalf], hi = aux[kt & 3][4 * kk + 2 * lhalf + 1];
+        unsigned lo = aux[kt & 7][4 * kk + 2 * lhalf], hi = aux[kt & 7][4 * kk + 2 * lhalf + 1];
         lo = live ? lo : 0u;                                      // rows past the slab: weight 0
         hi = live ? hi : 0u;
         const float w0 = (float)(lo & 0xFFu), w1 = (float)((lo >> 8) & 0xFFu), w2 = (float)((lo >> 16) & 0xFFu),
@@ -1046,7 +1047,13 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
 // R (f32 [(C3 + N)][N]) = the reduced product, cs_part = float[slabs][C3 + N] partial column sums (entries C3 .. C3 + N are
 // valid), *slabs_out = the slabs in use.  workspace: omnipq_gemm_tn_dz_workspace_floats(C3, N, P) floats; R and cs_part point
 // into it (R = workspace, cs_part behind the slabs).  A plan is REQUIRED.
-static int tn_dz_slabs(int tiles, int P) { return omnipq_gemm_tn_slabs(tiles, P, omnipq::TBK); }
+// (three workgroups per CU and nothing else on the chip: ~768 workgroups, at least 16 K-steps each)
+static int tn_dz_slabs(int tiles, int P) {
+  long long slabs = (768 + tiles - 1) / tiles;
+  const long long max_slabs = (P + 32LL * 16 - 1) / (32LL * 16);
+  if (slabs > max_slabs) slabs = max_slabs;
+  return slabs < 1 ? 1 : (int)slabs;
+}
 
 extern "C" long long omnipq_gemm_tn_dz_workspace_floats(int C3, int N, int P) {
   const long long M = (long long)C3 + N;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void sa_last_bwd_prep_kernel(
     float *__restrict__ alpha_out, float *__restrict__ beta_out, float *__restrict__ gb_out) {
   const int tid = (int)threadIdx.x;
   if ((int)blockIdx.x < g_blocks) {
-    __shared__ float sj[32][33], sk[32][33], sal[32], sbe[32];
+    __shared__ float sj[32][65], sk[32][65], sal[64], sbe[64];
     const int tiles = C2 / 32;
     const int j0 = ((int)blockIdx.x / tiles) * 32, k0 = ((int)blockIdx.x % tiles) * 32;
     const int tj = tid >> 4, tk = tid & 15;            // 16 x 16 threads, 2 x 2 outputs each
@@ -50,25 +50,44 @@ __global__ __launch_bounds__(256) void sa_last_bwd_prep_kernel(
         }
       }
     }
-    for (int c0 = 0; c0 < C3; c0 += 32) {
-      __syncthreads();
-      if (tid < 32) {
+    // chunks of 64 columns, the next chunk's loads in flight underneath the current chunk's arithmetic (the loop is a chain
+    // of trips to L2 otherwise: 16 of them at C3 = 512)
+    const int r = tid >> 3, q = (tid & 7) * 8;              // 32 rows x 64 columns of each side: 8 elements (16 bytes) per thread
+    auto load_chunk = [&](int c0, uint4 &wj, uint4 &wk, float &al, float &be) {
+      wj = *reinterpret_cast<const uint4 *>(Wt + (size_t)(j0 + r) * ldwt + c0 + q);
+      wk = *reinterpret_cast<const uint4 *>(Wt + (size_t)(k0 + r) * ldwt + c0 + q);
+      if (tid < 64) {
         const int c = c0 + tid;
         const float m1 = (float)(sums[c] * inv_total), m2 = (float)(sums[C3 + c] * inv_total);
-        sal[tid] = a[c] * (m1 - mean[c] * invstd[c] * m2);
-        sbe[tid] = a[c] * invstd[c] * m2;
+        al = a[c] * (m1 - mean[c] * invstd[c] * m2);
+        be = a[c] * invstd[c] * m2;
       }
-      // 32 rows x 32 columns of each side, four elements (8 bytes) per thread
-      const int r = tid >> 3, q = (tid & 7) * 4;
-      const uint2 wj = *reinterpret_cast<const uint2 *>(Wt + (size_t)(j0 + r) * ldwt + c0 + q);
-      const uint2 wk = *reinterpret_cast<const uint2 *>(Wt + (size_t)(k0 + r) * ldwt + c0 + q);
-      sj[r][q] = e16_lo(wj.x); sj[r][q + 1] = e16_hi(wj.x); sj[r][q + 2] = e16_lo(wj.y); sj[r][q + 3] = e16_hi(wj.y);
-      sk[r][q] = e16_lo(wk.x); sk[r][q + 1] = e16_hi(wk.x); sk[r][q + 2] = e16_lo(wk.y); sk[r][q + 3] = e16_hi(wk.y);
+    };
+    uint4 wj, wk;
+    float al = 0.f, be = 0.f;
+    load_chunk(0, wj, wk, al, be);
+    for (int c0 = 0; c0 < C3; c0 += 64) {
       __syncthreads();
+      {
+        const unsigned a4[4] = {wj.x, wj.y, wj.z, wj.w}, b4[4] = {wk.x, wk.y, wk.z, wk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sj[r][q + 2 * e] = e16_lo(a4[e]);
+          sj[r][q + 2 * e + 1] = e16_hi(a4[e]);
+          sk[r][q + 2 * e] = e16_lo(b4[e]);
+          sk[r][q + 2 * e + 1] = e16_hi(b4[e]);
+        }
+        if (tid < 64) {
+          sal[tid] = al;
+          sbe[tid] = be;
+        }
+      }
+      __syncthreads();
+      if (c0 + 64 < C3) load_chunk(c0 + 64, wj, wk, al, be);
 #pragma unroll 8
-      for (int cc = 0; cc < 32; ++cc) {
-        const float be = sbe[cc];
-        const float x0 = sj[2 * tj][cc] * be, x1 = sj[2 * tj + 1][cc] * be;
+      for (int cc = 0; cc < 64; ++cc) {
+        const float bev = sbe[cc];
+        const float x0 = sj[2 * tj][cc] * bev, x1 = sj[2 * tj + 1][cc] * bev;
         const float y0 = sk[2 * tk][cc], y1 = sk[2 * tk + 1][cc];
         acc[0][0] = __builtin_fmaf(x0, y0, acc[0][0]);
         acc[0][1] = __builtin_fmaf(x0, y1, acc[0][1]);
@@ -139,20 +158,33 @@ __global__ __launch_bounds__(256) void sa_last_wgrad_combine_kernel(int C3, int 
   const int tiles = C2 / 32;
   const int c0 = ((int)blockIdx.x / tiles) * 32, k0 = ((int)blockIdx.x % tiles) * 32;
   const int tc = tid >> 4, tk = tid & 15;
-  if (tid < 32) {
+  {
+    // cs[k] = the slabs' partial rows added in a FIXED order: eight interleaved chains per column, then the eight in order
+    const int col = tid & 31, chain = tid >> 5;
     float t = 0.f;
-    for (int z = 0; z < slabs; ++z) t += cs_part[(size_t)z * cs_ld + C3 + k0 + tid];
-    scs[tid] = t;
+    for (int z = chain; z < slabs; z += 8) t += cs_part[(size_t)z * cs_ld + C3 + k0 + col];
+    sw[chain][col] = t;
+    __syncthreads();
+    if (tid < 32) {
+      float v = 0.f;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) v += sw[h][tid];
+      scs[tid] = v;
+    }
   }
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  const int r = tid >> 3, q = (tid & 7) * 4;
+  uint2 wv = *reinterpret_cast<const uint2 *>(Wp + (size_t)(c0 + r) * ldw + q);
+  float4 gv = *reinterpret_cast<const float4 *>(R + (size_t)(C3 + r) * C2 + k0 + q);
   for (int j0 = 0; j0 < C2; j0 += 32) {
     __syncthreads();
-    const int r = tid >> 3, q = (tid & 7) * 4;
-    const uint2 wv = *reinterpret_cast<const uint2 *>(Wp + (size_t)(c0 + r) * ldw + j0 + q);
     sw[r][q] = e16_lo(wv.x); sw[r][q + 1] = e16_hi(wv.x); sw[r][q + 2] = e16_lo(wv.y); sw[r][q + 3] = e16_hi(wv.y);
-    const float4 gv = *reinterpret_cast<const float4 *>(R + (size_t)(C3 + j0 + r) * C2 + k0 + q);
     sg[r][q] = gv.x; sg[r][q + 1] = gv.y; sg[r][q + 2] = gv.z; sg[r][q + 3] = gv.w;
     __syncthreads();
+    if (j0 + 32 < C2) {
+      wv = *reinterpret_cast<const uint2 *>(Wp + (size_t)(c0 + r) * ldw + j0 + 32 + q);
+      gv = *reinterpret_cast<const float4 *>(R + (size_t)(C3 + j0 + 32 + r) * C2 + k0 + q);
+    }
 #pragma unroll 8
     for (int jj = 0; jj < 32; ++jj) {
       const float x0 = sw[2 * tc][jj], x1 = sw[2 * tc + 1][jj];
@@ -183,7 +215,7 @@ extern "C" int omnipq_sa_last_bwd_prep(long long balls, int C3, int C2, const do
                                         const void *out_pm, const unsigned char *arg, const void *Wt, int ldwt, unsigned *hot,
                                         void *B1, int ldb1, float *alpha, float *beta, float *gb, void *stream) {
   using namespace omnipq;
-  if (balls <= 0 || C3 <= 0 || C2 <= 0 || (C3 % 32) || (C2 % 32) || !(total_positions > 0)) return OMNIPQ_EINVAL;
+  if (balls <= 0 || C3 <= 0 || C2 <= 0 || (C3 % 64) || (C2 % 32) || !(total_positions > 0)) return OMNIPQ_EINVAL;
   if (!sums || !a || !mean || !invstd || !g_out || !out_pm || !arg || !Wt || !hot || !B1 || !alpha || !beta) return OMNIPQ_EINVAL;
   if (ldwt < C3 || (ldwt % 8) || ldb1 < C2 + 32 || (ldb1 % 8)) return OMNIPQ_EINVAL;
   const long long items = balls * (C3 / 8);
