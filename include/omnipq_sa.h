@@ -31,6 +31,13 @@ typedef struct omnipq_row_plan {
   long long rows;              /* the static row count the stage's launches are issued with */
   int gs;                      /* rows per group: 8 or 16 */
   const float *pool_gamma;     /* see below; may be NULL */
+  /* Scratch of the BatchNorm-statistics folds inside the GEMMs (round 6; csrc/gemm_bf16.hip: stats_ticket_fold), may be NULL:
+   * ticket_words 32-bit words, ZERO when the first call that is handed them starts; every call leaves them zero, so calls
+   * issued one after another on ONE stream may share them.  With them a statistics GEMM over more than 8192 rows folds its
+   * per-tile partial sums itself (no reduction launch); a call needs ceil(ceil(M / 128) / 16) * ceil(N / 128) words and
+   * ignores a scratch that is too small.  Independent of the row plan: rows_dev may be NULL (every row) with tickets set. */
+  void *tickets;
+  long long ticket_words;
 } omnipq_row_plan;
 
 #endif
@@ -173,6 +180,11 @@ int omnipq_sa_pool_select_finalize(long long BM, int C, const void *ymax, const 
 
 int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
                                  const float *g_out, const void *out_pm, double *sums, int zeroed, void *stream);
+/* ... and hot u32 [BM][C] = e16(a[c] dz) << 16 | arg[ball][c]: the one-hot operand of omnipq_gemm_nt_e16_dz_bnbwd /
+ * omnipq_gemm_tn_dz (below), from the values this pass reads anyway */
+int omnipq_sa_pool_bwd_stats_sel_hot(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
+                                     const float *g_out, const void *out_pm, double *sums, int zeroed, const float *a,
+                                     const unsigned char *arg, unsigned *hot, void *stream);
 int omnipq_gemm_tn_e16_affine(int M, int N, int P, const void *A, int lda, const void *B, int ldb, const float *ba,
                                const float *bb, float *C, float *workspace, float *colsum, const omnipq_row_plan *plan, void *stream);
 int omnipq_gemm_tn_grouped(int nprob, const void *probs, float *workspace, void *stream);
@@ -382,7 +394,8 @@ int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd
  *     dW3 = [a hit]^T X2 - alpha (x) cs - diag(beta) W3 Gram,   Gram = X2^T diag(w) X2,  cs = X2^T w
  *   omnipq_sa_last_bwd_prep       from the totals `sums` (double [2][C3] = sum dz | sum dz yhat of omnipq_sa_pool_bwd_stats_sel,
  *                                 all-reduced by the caller under SyncBatchNorm) and the pool's (g_out f32, out_pm e16, arg u8,
- *                                 all [balls][C3]): hot u32 [balls][C3] = e16(a dz) << 16 | arg;  B1 e16 [C2][ldb1 >= C2 + 32] =
+ *                                 all [balls][C3]): hot u32 [balls][C3] = e16(a dz) << 16 | arg (hot == NULL: not written -- it
+ *                                 came from omnipq_sa_pool_bwd_stats_sel_hot);  B1 e16 [C2][ldb1 >= C2 + 32] =
  *                                 [-G | -v_hi, -v_lo, 0..];  alpha, beta f32 [C3];  gb (may be NULL) f32 [2][C3] = dbeta | dgamma.
  *                                 Wt = the layer's prepared TRANSPOSED weight e16 [C2][ldwt] (K-contiguous over C3).
  *   omnipq_gemm_nt_e16_dz_bnbwd   dX2 (e16 [M][ldc], M = the plan's static row count, N = C2 columns) and the

@@ -75,6 +75,10 @@ PlanScope::PlanScope(const omnipq_row_plan *plan) : saved_(t_row_plan) {
     rp.gs = plan->gs == 8 ? 8 : 16;
     rp.pool_gamma = plan->pool_gamma;
   }
+  if (plan && plan->tickets && plan->ticket_words > 0) {
+    rp.tickets = (unsigned *)plan->tickets;
+    rp.ticket_words = plan->ticket_words;
+  }
   t_row_plan = rp;
 }
 PlanScope::~PlanScope() { t_row_plan = saved_; }

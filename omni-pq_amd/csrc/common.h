@@ -189,6 +189,9 @@ struct RowPlan {
   // minimum (a = gamma * invstd has gamma's sign) -- into ymax / amax, and pool_select_finalize reads only those
   const float *pool_gamma = nullptr;
   long long rows = 0;                            // the static row count the stage's launches are issued with
+  // scratch of the statistics folds inside the GEMMs (omnipq_row_plan.tickets): valid with or without a row plan
+  unsigned *tickets = nullptr;
+  long long ticket_words = 0;
 };
 // The plan of the CALL in progress on this thread.  A plan is an argument of the public entry points (include/omnipq_sa.h:
 // omnipq_row_plan); every such entry point opens a PlanScope for its duration, so the internals below it read row_plan()

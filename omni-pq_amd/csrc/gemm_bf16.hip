@@ -48,7 +48,13 @@ struct GemmArgs {
   // statistics variants with ball extrema: the tile itself is not stored (the last layer of a stage whose backward runs
   // without dY / Y of that layer: omnipq_gemm_nt_e16_dz_bnbwd) -- statistics and extrema are all that leaves the kernel
   int no_store = 0;
+  // partial-sum statistics (STATS = 2 / 4) WITHOUT the reduction launch: tickets != NULL (zero on entry, one 32-bit word per
+  // group of kTicketGroup row tiles and column tile) -- of every group the workgroup that arrives last adds the group's partial
+  // rows up in row order and issues the group's f64 atomics into fold_sums (see stats_ticket_fold)
+  unsigned *tickets = nullptr;
+  double *fold_sums = nullptr;
 };
+constexpr int kTicketGroup = 16;
 
 __device__ __forceinline__ uint4 ldg16(const e16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
@@ -180,6 +186,56 @@ __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
   return pack_e16x2(lo, hi);
 }
 
+// The statistics tail of the partial-sum variants without a second launch (round 6; the scheme of sa_stage.hip:
+// fold_groups_and_publish carried into the GEMM epilogues -- VERDICT r5 item 1c: partial_reduce_kernel was 20 launches and
+// 0.11 ms of a step for 46 MB).  Every row tile leaves its NS x 128 column sums as a plain f32 row (device-scope relaxed
+// stores: write-through, no fence), waits for the acknowledgement of its own stores, takes a ticket of its group of
+// kTicketGroup consecutive row tiles (same column tile); the last to arrive reads the group's rows (coherent loads), adds them
+// in row order in f64 and issues ONE atomic per column and sum.  Tiles that hold no rows in use (row plan) take their ticket
+// and write nothing; their rows are not read.  Called by all 256 threads; `part` rows are [m_tile][NS][N].
+template <int NS>
+__device__ __forceinline__ void stats_ticket_fold(const GemmArgs &g, const float *part, int mt, int nt, int n0, int Meff,
+                                                  int *lds_word) {
+  // (lds_word: one word of the workgroup's LDS that nothing else uses at this point -- a __shared__ variable of its own would
+  // be the byte that costs the 128 x 128 tiles, 4 x 40 KB per CU, their fourth workgroup)
+  int &s_last = *lds_word;
+  const int grp = mt / kTicketGroup, g0 = grp * kTicketGroup;
+  int gsize = g.m_tiles - g0;
+  gsize = gsize < kTicketGroup ? gsize : kTicketGroup;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(g.tickets + (size_t)grp * g.n_tiles + nt, 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == (unsigned)(gsize - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // (the word is zero again for the next launch that is handed the same tickets: launches on one stream run one after another)
+  if (threadIdx.x == 0)
+    __hip_atomic_store(g.tickets + (size_t)grp * g.n_tiles + nt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int rows = (Meff + GBM - 1) / GBM - g0;            // row tiles of the group that hold rows in use
+  rows = rows < gsize ? rows : gsize;
+  if (rows <= 0) return;
+  for (int c = (int)threadIdx.x; c < NS * GBN; c += 256) {
+    const int which = c / GBN, col = c - which * GBN;
+    if (n0 + col >= g.N) continue;
+    // four rows in flight at a time (sixteen cost the 128 x 128 tiles their fourth workgroup per CU)
+    double tot = 0.0;
+    const float *src = part + ((size_t)g0 * NS + which) * g.N + n0 + col;
+    for (int r = 0; r < rows; r += 4) {
+      float vals[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        vals[q] = r + q < rows ? __hip_atomic_load(src + (size_t)(r + q) * NS * g.N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tot += (double)vals[q];
+    }
+    atomicAdd(g.fold_sums + (size_t)which * g.N + n0 + col, tot);
+  }
+}
+
 // T: tile edge, 128 (four waves x 2 x 2 MFMA blocks) or 64 (four waves x one block).  The per-point layers outside
 // the SA stages have 96..200 tiles of 128 x 128 and 9 K-steps: one wave per SIMD on a third of the chip, each issuing
 // its 8 MFMAs per K-step back to back (0.21 of the 0.36 us a K-step takes) -- they are bound by the MFMA issue of ONE
@@ -259,7 +315,12 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   static_assert(!PLAN || (T == 128 && !OUT_F32 && !KRES), "row plans: 128 x 128 tiles with e16 output");
   constexpr bool planned = PLAN;                 // (the launchers pick the PLAN instantiation iff g.rows_dev is set)
   const int Meff = planned ? *g.rows_dev : g.M;
-  if (planned && m0 >= Meff) return;            // (partial_reduce_kernel reads the partial rows of the tiles in use only)
+  if (planned && m0 >= Meff) {                  // (the reduction reads the partial rows of the tiles in use only)
+    if ((STATS == 2 || STATS == 4) && T == 128 && g.tickets && blockIdx.z == 0)
+      stats_ticket_fold<(XG == 2 ? 5 : 2)>(g, reinterpret_cast<const float *>(stats_out), mt, nt, n0, Meff,
+                                           reinterpret_cast<int *>(smem) + 8192);
+    return;
+  }
 
   // staging assignment: chunk q = tid + i*256 -> row q>>2, 16-byte piece q&3
   // Rows past M (or N) are clamped to the last valid row instead of being zero-filled: whatever they
@@ -918,10 +979,16 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
         if (n0 + col < g.N) {
           if (STATS == 1 || STATS == 3)
             atomicAdd(reinterpret_cast<double *>(stats_out) + (size_t)which * g.N + n0 + col, (double)tot);
+          else if (T == 128 && g.tickets)
+            __hip_atomic_store(reinterpret_cast<float *>(stats_out) + ((size_t)mt * NS + which) * g.N + n0 + col, tot,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else
             reinterpret_cast<float *>(stats_out)[((size_t)mt * NS + which) * g.N + n0 + col] = tot;
         }
       }
+      if ((STATS == 2 || STATS == 4) && T == 128 && g.tickets)
+        stats_ticket_fold<NS>(g, reinterpret_cast<const float *>(stats_out), mt, nt, n0, Meff,
+                              reinterpret_cast<int *>(smem) + 8192);          // (behind the 16 KB of the column-sum fold)
     }
   }
   NT_STAMP(7);
@@ -1102,6 +1169,27 @@ static void plan_rows(omnipq::GemmArgs &g) {
   }
 }
 
+// Partial-sum statistics of 128 x 128-tile launches: with ticket words from the caller (omnipq_row_plan.tickets) the fold runs
+// inside the GEMM (stats_ticket_fold) and `sums` receives the totals directly; otherwise the reduction launch below.
+static void stats_tickets(omnipq::GemmArgs &g, double *sums) {
+  const omnipq::RowPlan &rp = omnipq::row_plan();
+  const long long need = (long long)((g.m_tiles + omnipq::kTicketGroup - 1) / omnipq::kTicketGroup) * g.n_tiles;
+  if (rp.tickets && need <= rp.ticket_words && g.m_tiles > 64) {
+    g.tickets = rp.tickets;
+    g.fold_sums = sums;
+  }
+}
+static int stats_reduce(const omnipq::GemmArgs &g, int ns, float *workspace, double *sums, void *stream) {
+  if (g.tickets) return OMNIPQ_OK;
+  int slabs = g.m_tiles / 64;
+  if (slabs > 128) slabs = 128;
+  if (slabs < 1) slabs = 1;
+  omnipq::partial_reduce_kernel<<<dim3((ns * g.N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(
+      g.m_tiles, ns * g.N, workspace, sums, g.rows_dev);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
 static omnipq::GemmArgs gemm_nt_args(int M, int N, int K, int lda, int ldb, int ldc, int T) {
   return omnipq::GemmArgs{M, N, K, lda, ldb, ldc, K, (M + T - 1) / T, (N + T - 1) / T};
 }
@@ -1249,6 +1337,7 @@ extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int 
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums);
   if (g.rows_dev)
     gemm_nt_kernel<false, 2, false, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
         g, (const e16_t *)A, (const e16_t *)B, C, bias, workspace);
@@ -1256,13 +1345,7 @@ extern "C" int omnipq_gemm_nt_e16_stats(int M, int N, int K, const void *A, int 
     gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                                 workspace);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  if (slabs < 1) slabs = 1;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 2, workspace, sums, stream);
 }
 
 static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, const omnipq::AffineIn &aff, const void *B,
@@ -1306,6 +1389,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums);
   if (g.rows_dev)
     gemm_nt_kernel<false, 2, true, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
         g, (const e16_t *)A, (const e16_t *)B, C, bias, workspace, BnBwdEpilogue(), aff, pool);
@@ -1313,13 +1397,7 @@ static int gemm_nt_affine_impl(int M, int N, int K, const void *A, int lda, cons
     gemm_nt_kernel<false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                                       workspace, BnBwdEpilogue(), aff, pool);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  if (slabs < 1) slabs = 1;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 2, workspace, sums, stream);
 }
 
 // C = relu(a_in .* A + b_in) B^T (+ bias), the A operand transformed on the fly (see AffineIn); with `sums`
@@ -1442,6 +1520,7 @@ extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A,
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums);
   if (g.rows_dev)
     gemm_nt_kernel<false, 2, false, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
         g, (const e16_t *)A, (const e16_t *)B, C, bias, workspace, BnBwdEpilogue(), AffineIn(), pool);
@@ -1449,13 +1528,7 @@ extern "C" int omnipq_gemm_nt_e16_stats_pool(int M, int N, int K, const void *A,
     gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, bias,
                                                                 workspace, BnBwdEpilogue(), AffineIn(), pool);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  if (slabs < 1) slabs = 1;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 2, workspace, sums, stream);
 }
 
 // Data-gradient GEMM of a conv+BN+ReLU stack with the BatchNorm-backward sums of the layer BELOW folded in:
@@ -1490,6 +1563,7 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
     return OMNIPQ_OK;
   }
   if (!workspace) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums);
   if (g.rows_dev)
     gemm_nt_kernel<false, 4, false, 128, 0, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
         g, (const e16_t *)A, (const e16_t *)B, C, nullptr, workspace, bn);
@@ -1497,13 +1571,7 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
     gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)A, (const e16_t *)B, C, nullptr,
                                                                 workspace, bn);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  if (slabs < 1) slabs = 1;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 2, workspace, sums, stream);
 }
 
 
@@ -1529,6 +1597,7 @@ extern "C" int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2,
   GemmArgs g{M, N, K, lda, ldb1, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   plan_rows(g);
   if (!g.rows_dev || !g.row_w || g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums);
   int sh = 0;
   while ((1 << sh) < nsample) ++sh;
   DzGen dz;
@@ -1545,13 +1614,7 @@ extern "C" int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2,
   gemm_nt_kernel<false, 4, true, 128, 0, false, true, true><<<gemm_nt_grid(g), 256, 0, (hipStream_t)stream>>>(
       g, (const e16_t *)Y2, (const e16_t *)B1, C, nullptr, workspace, bn, aff, PoolOut(), XyzGen(), dz);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  if (slabs < 1) slabs = 1;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 2, workspace, sums, stream);
 }
 
 
@@ -1582,6 +1645,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
   GemmArgs g{M, N, K, 0, ldb, ldc, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   plan_rows(g);
   if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums);
   AffineIn aff{};
   aff.sums = fin_sums;
   aff.gamma = gamma;
@@ -1605,12 +1669,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnaffine(int M, int N, int K, const void *
     gemm_nt_kernel<false, 2, true, 128, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
         g, (const e16_t *)B, (const e16_t *)B, C, nullptr, workspace, BnBwdEpilogue(), aff, PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  partial_reduce_kernel<<<dim3((2 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 2 * N, workspace,
-                                                                                    sums, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 2, workspace, sums, stream);
 }
 
 // The data-gradient GEMM into that first layer, reduced to what is needed of it: with dX = A B^T (A = dY of the layer
@@ -1631,6 +1690,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, 
   GemmArgs g{M, N, K, lda, ldb, N, K, (M + GBM - 1) / GBM, (N + GBN - 1) / GBN};
   plan_rows(g);
   if (g.m_tiles <= kStatsDirectTiles) return OMNIPQ_EINVAL;
+  stats_tickets(g, sums5);
   const XyzGen xg{(const e16_t *)X0, ldx, (const e16_t *)W0, ldw0};
   const BnBwdEpilogue bn{nullptr, a, b, mean, invstd};
   const int groups = (g.m_tiles + 7) / 8;
@@ -1642,12 +1702,7 @@ extern "C" int omnipq_gemm_nt_e16_xyz_bnbwd(int M, int N, int K, const void *A, 
     gemm_nt_kernel<false, 4, false, 128, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
         g, (const e16_t *)A, (const e16_t *)B, nullptr, nullptr, workspace, bn, AffineIn(), PoolOut(), xg);
   OMNIPQ_LAUNCH_CHECK();
-  int slabs = g.m_tiles / 64;
-  if (slabs > 128) slabs = 128;
-  partial_reduce_kernel<<<dim3((5 * N + 255) / 256, slabs), 256, 0, (hipStream_t)stream>>>(g.m_tiles, 5 * N, workspace,
-                                                                                    sums5, g.rows_dev);
-  OMNIPQ_LAUNCH_CHECK();
-  return OMNIPQ_OK;
+  return stats_reduce(g, 5, workspace, sums5, stream);
 }
 
 // Same with a per-column f32 bias added to the accumulators before rounding:  C = A B^T + bias[n].

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void sa_last_bwd_prep_kernel(
     float *__restrict__ alpha_out, float *__restrict__ beta_out, float *__restrict__ gb_out) {
   const int tid = (int)threadIdx.x;
   if ((int)blockIdx.x < g_blocks) {
-    __shared__ float sj[32][65], sk[32][65], sal[64], sbe[64];
+    __shared__ __attribute__((aligned(16))) float sj[32][68], sk[32][68], sal[64], sbe[64];
     const int tiles = C2 / 32;
     const int j0 = ((int)blockIdx.x / tiles) * 32, k0 = ((int)blockIdx.x % tiles) * 32;
     const int tj = tid >> 4, tk = tid & 15;            // 16 x 16 threads, 2 x 2 outputs each
@@ -84,18 +84,31 @@ __global__ __launch_bounds__(256) void sa_last_bwd_prep_kernel(
       }
       __syncthreads();
       if (c0 + 64 < C3) load_chunk(c0 + 64, wj, wk, al, be);
-#pragma unroll 8
-      for (int cc = 0; cc < 64; ++cc) {
-        const float bev = sbe[cc];
-        const float x0 = sj[2 * tj][cc] * bev, x1 = sj[2 * tj + 1][cc] * bev;
-        const float y0 = sk[2 * tk][cc], y1 = sk[2 * tk + 1][cc];
-        acc[0][0] = __builtin_fmaf(x0, y0, acc[0][0]);
-        acc[0][1] = __builtin_fmaf(x0, y1, acc[0][1]);
-        acc[1][0] = __builtin_fmaf(x1, y0, acc[1][0]);
-        acc[1][1] = __builtin_fmaf(x1, y1, acc[1][1]);
+#pragma unroll 4
+      for (int cc = 0; cc < 64; cc += 4) {
+        // four columns per LDS read (pitch 68 floats: the 16 rows a wave reads of sk start 4 banks apart)
+        const float4 bev = *reinterpret_cast<const float4 *>(&sbe[cc]);
+        const float4 xa = *reinterpret_cast<const float4 *>(&sj[2 * tj][cc]), xb = *reinterpret_cast<const float4 *>(&sj[2 * tj + 1][cc]);
+        const float4 ya = *reinterpret_cast<const float4 *>(&sk[2 * tk][cc]), yb = *reinterpret_cast<const float4 *>(&sk[2 * tk + 1][cc]);
+        const float be4[4] = {bev.x, bev.y, bev.z, bev.w};
+        const float x0[4] = {xa.x, xa.y, xa.z, xa.w}, x1[4] = {xb.x, xb.y, xb.z, xb.w};
+        const float y0[4] = {ya.x, ya.y, ya.z, ya.w}, y1[4] = {yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = x0[e] * be4[e], p1 = x1[e] * be4[e];
+          acc[0][0] = __builtin_fmaf(p0, y0[e], acc[0][0]);
+          acc[0][1] = __builtin_fmaf(p0, y1[e], acc[0][1]);
+          acc[1][0] = __builtin_fmaf(p1, y0[e], acc[1][0]);
+          acc[1][1] = __builtin_fmaf(p1, y1[e], acc[1][1]);
+        }
         if (j0 == 0 && tj == 0) {
-          vacc[0] = __builtin_fmaf(sal[cc], y0, vacc[0]);
-          vacc[1] = __builtin_fmaf(sal[cc], y1, vacc[1]);
+          const float4 al4 = *reinterpret_cast<const float4 *>(&sal[cc]);
+          const float a4[4] = {al4.x, al4.y, al4.z, al4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vacc[0] = __builtin_fmaf(a4[e], y0[e], vacc[0]);
+            vacc[1] = __builtin_fmaf(a4[e], y1[e], vacc[1]);
+          }
         }
       }
     }
@@ -216,9 +229,10 @@ extern "C" int omnipq_sa_last_bwd_prep(long long balls, int C3, int C2, const do
                                         void *B1, int ldb1, float *alpha, float *beta, float *gb, void *stream) {
   using namespace omnipq;
   if (balls <= 0 || C3 <= 0 || C2 <= 0 || (C3 % 64) || (C2 % 32) || !(total_positions > 0)) return OMNIPQ_EINVAL;
-  if (!sums || !a || !mean || !invstd || !g_out || !out_pm || !arg || !Wt || !hot || !B1 || !alpha || !beta) return OMNIPQ_EINVAL;
+  if (!sums || !a || !mean || !invstd || !Wt || !B1 || !alpha || !beta) return OMNIPQ_EINVAL;
+  if (hot && (!g_out || !out_pm || !arg)) return OMNIPQ_EINVAL;
   if (ldwt < C3 || (ldwt % 8) || ldb1 < C2 + 32 || (ldb1 % 8)) return OMNIPQ_EINVAL;
-  const long long items = balls * (C3 / 8);
+  const long long items = hot ? balls * (C3 / 8) : 0;      // hot == NULL: it came from omnipq_sa_pool_bwd_stats_sel_hot
   const long long hot_blocks = (items + 255) / 256;
   const int g_blocks = (C2 / 32) * (C2 / 32);
   if (hot_blocks + g_blocks > 0x7fffffffLL) return OMNIPQ_ETOOLARGE;

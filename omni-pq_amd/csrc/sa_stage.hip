@@ -532,14 +532,21 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, i
                                                                 const float *__restrict__ invstd,
                                                                 const float *__restrict__ g_out,
                                                                 const e16_t *__restrict__ out_pm,
-                                                                double *__restrict__ sums) {
+                                                                double *__restrict__ sums,
+                                                                const float *__restrict__ a_hot,
+                                                                const unsigned char *__restrict__ arg,
+                                                                unsigned *__restrict__ hot) {
+  // hot (may be NULL; with a_hot = the layer's a and arg = the pool's selected rows): also hot[ball][c] = e16(a dz) << 16 | arg
+  // -- the one-hot operand of the backward without the layer's output gradient (sa_last_bwd.hip), from the values this
+  // kernel holds anyway
   int cgs, rpb, cg, rsub;
   row_partition(C, cgs, rpb, cg, rsub);
   float u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rsub < rpb) {
-    float mu[8], is[8];
+    float mu[8], is[8], ah[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     load8f(mean + cg * 8, mu);
     load8f(invstd + cg * 8, is);
+    if (hot) load8f(a_hot + cg * 8, ah);
     // four balls per iteration, their sixteen loads requested before the first is used: with at most 128 workgroups (the
     // atomics of the fold) a thread walks 16-32 balls, and one ball per iteration was one memory round trip per ball
     const long long step = (long long)gridDim.x * rpb;
@@ -563,11 +570,24 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long BM, i
         unpack8(ro[q], o);
         unpack8(ry[q], y);
         const float gg[8] = {g0[q].x, g0[q].y, g0[q].z, g0[q].w, g1[q].x, g1[q].y, g1[q].z, g1[q].w};
+        float gm[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float g = o[e] > 0.f ? gg[e] : 0.f;
+          gm[e] = g;
           u[e] += g;
           v[e] = __builtin_fmaf(g, (y[e] - mu[e]) * is[e], v[e]);
+        }
+        if (hot) {
+          const size_t at = (size_t)(bm0 + q * step) * C + cg * 8;
+          const unsigned long long packed = *reinterpret_cast<const unsigned long long *>(arg + at);
+          unsigned w[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            w[e] = ((unsigned)f2bf(ah[e] * gm[e]) << 16) | (unsigned)((packed >> (8 * e)) & 0xFF);
+          uint4 *dst = reinterpret_cast<uint4 *>(hot + at);
+          dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+          dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
       }
     }
@@ -1616,7 +1636,24 @@ extern "C" int omnipq_sa_pool_bwd_stats_sel(long long BM, int C, const void *yse
   int blocks = stats_grid(BM, C);
   if (blocks > 128) blocks = 128;
   pool_bwd_stats_sel_kernel<<<blocks, 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
-      BM, C, (const e16_t *)ysel, mean, invstd, g_out, (const e16_t *)out_pm, sums);
+      BM, C, (const e16_t *)ysel, mean, invstd, g_out, (const e16_t *)out_pm, sums, nullptr, nullptr, nullptr);
+  OMNIPQ_LAUNCH_CHECK();
+  return OMNIPQ_OK;
+}
+
+// The same, and hot[ball][c] = e16(a[c] dz) << 16 | arg[ball][c] (u32 [BM][C]): the one-hot operand of the last layer's
+// backward without its output gradient (include/omnipq_sa.h: omnipq_sa_last_bwd_prep), from the values this pass reads anyway.
+extern "C" int omnipq_sa_pool_bwd_stats_sel_hot(long long BM, int C, const void *ysel, const float *mean, const float *invstd,
+                                                const float *g_out, const void *out_pm, double *sums, int zeroed,
+                                                const float *a, const unsigned char *arg, unsigned *hot, void *stream) {
+  if (BM < 0 || C < 16 || (C % 8) || C > kMaxC) return OMNIPQ_EINVAL;
+  if (!ysel || !mean || !invstd || !g_out || !out_pm || !sums || !a || !arg || !hot) return OMNIPQ_EINVAL;
+  if (!zeroed) OMNIPQ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
+  if (BM == 0) return OMNIPQ_OK;
+  int blocks = stats_grid(BM, C);
+  if (blocks > 128) blocks = 128;
+  pool_bwd_stats_sel_kernel<<<blocks, 256, fold_lds_bytes(C), (hipStream_t)stream>>>(
+      BM, C, (const e16_t *)ysel, mean, invstd, g_out, (const e16_t *)out_pm, sums, a, arg, hot);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }

@@ -52,7 +52,8 @@ def _call(fn, anchor, *args):
 class RowPlanArg(ctypes.Structure):
     """include/omnipq_sa.h: omnipq_row_plan"""
     _fields_ = [("rows_dev", ctypes.c_void_p), ("row_w", ctypes.c_void_p), ("goff", ctypes.c_void_p),
-                ("rows", ctypes.c_longlong), ("gs", ctypes.c_int), ("pool_gamma", ctypes.c_void_p)]
+                ("rows", ctypes.c_longlong), ("gs", ctypes.c_int), ("pool_gamma", ctypes.c_void_p),
+                ("tickets", ctypes.c_void_p), ("ticket_words", ctypes.c_longlong)]
 
 
 PLAN_AWARE = _ext.PLAN_AWARE      # asked of the loaded library (omnipq_plan_aware_entry_points), not parsed from a header
@@ -283,6 +284,7 @@ _FOLD_SMALL = True
 # computation up to the order of the f32 sums (tests/test_gpu_fused_sa.py::test_row_plan_equals_the_full_stage).
 # ROW_PLAN = False: every row is computed.
 ROW_PLAN = True
+STATS_TICKETS = True            # the partial-sum statistics of the big GEMMs folded inside the GEMM (no partial_reduce launch)
 PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
 ONE_SIDED_EXTREMA = True        # planned stages with 8-row groups: record max OR min per column, by the sign of gamma
 # (A BatchNorm weight of EXACTLY zero makes every row of a ball tie after BatchNorm + ReLU; the reference's max-pool then picks
@@ -387,6 +389,7 @@ def plan_from_state(flat, B, M, P):
 class _PlanState(threading.local):       # per Python thread (forward thread / autograd thread): which plan _call passes
     arg = None                           # ctypes pointer to a RowPlanArg, or None
     struct = None
+    keep = None                          # the ticket words the struct points at
 
 
 _plan_state = _PlanState()
@@ -399,17 +402,26 @@ class _row_plan:
         self.plan, self.rows = plan, rows
 
     def __enter__(self):
-        self.prev = (_plan_state.arg, _plan_state.struct)
+        self.prev = (_plan_state.arg, _plan_state.struct, _plan_state.keep)
+        # ticket words of the statistics folds inside the GEMMs (include/omnipq_sa.h: omnipq_row_plan.tickets): zero from the
+        # pool, shared by the block's launches (one stream, one after another; every launch leaves them zero)
+        tk, words = None, 0
+        if STATS_TICKETS and self.rows >= (1 << 13) and torch.cuda.is_available():
+            words = ((self.rows // 128 + 15) // 16 + 1) * 8
+            tk = zeros_f32(words, torch.device("cuda", torch.cuda.current_device()))
         if self.plan is not None:
             st = RowPlanArg(_p(self.plan.rows_dev).value, _p(self.plan.row_w).value, _p(self.plan.goff).value, self.rows,
-                            self.plan.gs, None)
-            _plan_state.struct = st
-            _plan_state.arg = ctypes.pointer(st)
+                            self.plan.gs, None, _p(tk).value, words)
+        elif tk is not None:
+            st = RowPlanArg(None, None, None, self.rows, 16, None, _p(tk).value, words)
         else:
-            _plan_state.arg = _plan_state.struct = None
+            st = None
+        _plan_state.struct = st
+        _plan_state.arg = ctypes.pointer(st) if st is not None else None
+        _plan_state.keep = tk
 
     def __exit__(self, *exc):
-        _plan_state.arg, _plan_state.struct = self.prev
+        _plan_state.arg, _plan_state.struct, _plan_state.keep = self.prev
 
 
 def _plan_pool_gamma(gamma):
@@ -1505,7 +1517,14 @@ class FusedSAStage(torch.autograd.Function):
         grads = [None] * (3 * L)
 
         last = layers[-1]
-        if ctx.ysel is not None:
+        hot = None
+        if ctx.ysel is not None and getattr(ctx, "no_dy", False):
+            # ... and the one-hot operand of the backward without dY (LAST_NO_DY), from the values this pass reads anyway
+            sums = zeros_f64(3, last.C, dev)
+            hot = torch.empty((B * M, last.C), device=dev, dtype=torch.int32)
+            _call(_lib.omnipq_sa_pool_bwd_stats_sel_hot, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
+                  _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), 1, _p(last.a), _p(ctx.arg), _p(hot))
+        elif ctx.ysel is not None:
             sums = zeros_f64(3, last.C, dev)                                     # [S | T | scratch], zero from the arena
             _call(_lib.omnipq_sa_pool_bwd_stats_sel, g_out, ctypes.c_longlong(B * M), last.C, _p(ctx.ysel), _p(last.mean),
                   _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(sums), 1)
@@ -1527,12 +1546,11 @@ class FusedSAStage(torch.autograd.Function):
             else:
                 gb3 = torch.empty((2, C3), device=dev, dtype=torch.float32)      # dbeta | dgamma, written by the prep
                 grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = gb3[1], gb3[0]
-            hot = torch.empty((B * M, C3), device=dev, dtype=torch.int32)
             B1 = torch.empty((C2, C2 + 32), device=dev, dtype=E16.dtype)
             ab = torch.empty((2, C3), device=dev, dtype=torch.float32)          # alpha | beta
             _call(_lib.omnipq_sa_last_bwd_prep, g_out, ctypes.c_longlong(B * M), C3, C2, _p(sums), total, _p(last.a),
-                  _p(last.mean), _p(last.invstd), _p(g_out), _p(ctx.out_pm), _p(ctx.arg), _p(last.Wt), last.Wt.stride(0),
-                  _p(hot), _p(B1), C2 + 32, _p(ab[0]), _p(ab[1]), _p(gb3))
+                  _p(last.mean), _p(last.invstd), _p(None), _p(None), _p(None), _p(last.Wt), last.Wt.stride(0),
+                  _p(None), _p(B1), C2 + 32, _p(ab[0]), _p(ab[1]), _p(gb3))
             # the layer's weight gradient: from Y2 and `hot`, with the other SA stages' when the deferred block ends
             dfr = deferred_wgrads.active
             wt = ctx.wtargets[L - 1] if (dfr is not None and SA_WGRADS_GROUPED) else None
