@@ -284,7 +284,9 @@ _FOLD_SMALL = True
 # computation up to the order of the f32 sums (tests/test_gpu_fused_sa.py::test_row_plan_equals_the_full_stage).
 # ROW_PLAN = False: every row is computed.
 ROW_PLAN = True
-STATS_TICKETS = True            # the partial-sum statistics of the big GEMMs folded inside the GEMM (no partial_reduce launch)
+STATS_TICKETS = False           # the partial-sum statistics of the big GEMMs folded inside the GEMM instead of a partial_reduce launch: built and
+                                # measured in round 6 -- SLOWER (sa1: xyz_bnbwd 74 -> 120 us, bnaffine_pool 124 -> 143): the contended f64
+                                # atomics of 272 groups and a ticket round trip per tile cost more than the 5 us launch
 PLAN_GROUP = 8                  # rows per group of a plan: 8 or 16
 ONE_SIDED_EXTREMA = True        # planned stages with 8-row groups: record max OR min per column, by the sign of gamma
 # (A BatchNorm weight of EXACTLY zero makes every row of a ball tie after BatchNorm + ReLU; the reference's max-pool then picks
