@@ -401,9 +401,11 @@ int omnipq_place_rows(long long rows, int C, const void *src, void *dst, int ldd
  *   omnipq_gemm_nt_e16_dz_bnbwd   dX2 (e16 [M][ldc], M = the plan's static row count, N = C2 columns) and the
  *                                 BatchNorm-backward sums of the layer below, as omnipq_gemm_nt_e16_bnbwd; the A operand is
  *                                 generated: Y2 (e16 [M][lda], lda == ldc), B1, B2 = Wt, hot, the plan's unit_src and nsample.
+ *                                 X2out (may be NULL): e16 [M][lda], receives X2 = relu(a y2 + b) for omnipq_gemm_tn_dz.
  *   omnipq_gemm_tn_dz             workspace[0 .. (C3 + N) N) = R = [[a hit]^T X2 ; Gram] (f32, reduced over *slabs_out slabs),
  *                                 workspace + *cs_offset_out = float[*slabs_out][C3 + N] partial rows of cs (entries C3 ..).
  *                                 workspace: omnipq_gemm_tn_dz_workspace_floats(C3, N, P) floats.  C3, N multiples of 128.
+ *                                 ba == bb == NULL: the operand IS X2 (omnipq_gemm_nt_e16_dz_bnbwd's X2out), no affine.
  *   omnipq_sa_last_wgrad_combine  out f32 [C3][out_ld] (+)= dW3 from R, the cs rows, alpha, beta and the prepared weight Wp
  *                                 (e16 [C3][ldw], K-contiguous over C2).
  * All four REQUIRE the stage's plan where they take one. */
@@ -414,7 +416,7 @@ int omnipq_sa_last_bwd_prep(long long balls, int C3, int C2, const double *sums,
 int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2, int lda, const void *B1, int ldb1, const void *B2,
                                  int ldb2, const unsigned *hot, const int *unit_src, int nsample, void *C, int ldc,
                                  const float *a, const float *b, const float *mean, const float *invstd, double *sums,
-                                 float *workspace, const omnipq_row_plan *plan, void *stream);
+                                 float *workspace, void *X2out, const omnipq_row_plan *plan, void *stream);
 long long omnipq_gemm_tn_dz_workspace_floats(int C3, int N, int P);
 int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, const float *ba, const float *bb, const unsigned *hot,
                       const int *unit_src, int nsample, float *workspace, int *slabs_out, long long *cs_offset_out,

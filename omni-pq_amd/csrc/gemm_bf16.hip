@@ -180,6 +180,10 @@ struct DzGen {
   const e16_t *B2 = nullptr;          // [N][ldb2]: prepared transposed weight of the last layer (K-contiguous over C3)
   const int *unit_src = nullptr;      // row plan: compact rows 8 u .. 8 u + 7 = positions 8 unit_src[u] .. of the full layout
   int C3 = 0, ldb2 = 0, s_shift = 0;  // nsample = 1 << s_shift
+  // may be NULL: [M][lda] e16, receives X2 = relu(a y2 + b) (without the row weight) as the first phase forms it -- the
+  // weight-gradient launch (gemm_tn_bf16.hip: gemm_tn_dz_kernel) then contracts plain operands instead of rebuilding X2 in
+  // every fragment of every tile (it is bound by exactly that arithmetic); column tile 0 writes
+  e16_t *X2out = nullptr;
 };
 
 __device__ __forceinline__ unsigned xg_pack2(float lo, float hi) {
@@ -470,6 +474,13 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
           RA[i_] = make_uint4(skc[i_] == 0 ? pack_e16x2(dzw[i_], dzw[i_]) : 0u, 0u, 0u, 0u);            \
       } else if (DZ) {                                                                                  \
       _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                               \
+        if (dz.X2out && nt == 0 && m0 + srow[i_] < Meff) {                                              \
+          const uint4 x_ = make_uint4(affine_relu_pair(RA[i_].x, fa4_[0][0], fb4_[0][0], fa4_[0][1], fb4_[0][1]),  \
+                                      affine_relu_pair(RA[i_].y, fa4_[0][2], fb4_[0][2], fa4_[0][3], fb4_[0][3]),  \
+                                      affine_relu_pair(RA[i_].z, fa4_[1][0], fb4_[1][0], fa4_[1][1], fb4_[1][1]),  \
+                                      affine_relu_pair(RA[i_].w, fa4_[1][2], fb4_[1][2], fa4_[1][3], fb4_[1][3])); \
+          *reinterpret_cast<uint4 *>(dz.X2out + (size_t)(m0 + srow[i_]) * g.lda + k0_) = x_;            \
+        }                                                                                               \
         RA[i_].x = affine_relu_pair_w(RA[i_].x, fa4_[0][0], fb4_[0][0], fa4_[0][1], fb4_[0][1], dzw[i_]); \
         RA[i_].y = affine_relu_pair_w(RA[i_].y, fa4_[0][2], fb4_[0][2], fa4_[0][3], fb4_[0][3], dzw[i_]); \
         RA[i_].z = affine_relu_pair_w(RA[i_].z, fa4_[1][0], fb4_[1][0], fa4_[1][1], fb4_[1][1], dzw[i_]); \
@@ -1584,7 +1595,7 @@ extern "C" int omnipq_gemm_nt_e16_bnbwd(int M, int N, int K, const void *A, int 
 extern "C" int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2, int lda, const void *B1, int ldb1,
                                             const void *B2, int ldb2, const unsigned *hot, const int *unit_src, int nsample,
                                             void *C, int ldc, const float *a, const float *b, const float *mean,
-                                            const float *invstd, double *sums, float *workspace,
+                                            const float *invstd, double *sums, float *workspace, void *X2out,
                                             const omnipq_row_plan *plan, void *stream) {
   omnipq::PlanScope plan_scope_(plan);
   using namespace omnipq;
@@ -1607,6 +1618,7 @@ extern "C" int omnipq_gemm_nt_e16_dz_bnbwd(int M, int N, int C3, const void *Y2,
   dz.C3 = C3;
   dz.ldb2 = ldb2;
   dz.s_shift = sh;
+  dz.X2out = (e16_t *)X2out;
   BnBwdEpilogue bn{(const e16_t *)Y2, a, b, mean, invstd};
   AffineIn aff{};
   aff.a = a;

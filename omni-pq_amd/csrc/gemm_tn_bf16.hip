@@ -653,9 +653,11 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
     offA[i] = tr_row * 128 + (((ca >> 3) ^ (4 * (tr_row & 3))) << 3) + (ca & 7);
     offB[i] = TBK * 128 + tr_row * 128 + (((cb >> 3) ^ (4 * (tr_row & 3))) << 3) + (cb & 7);
   }
-  float afa[2], afb[2], aga[2] = {0.f, 0.f}, agb[2] = {0.f, 0.f};
+  const bool plain = ba == nullptr;             // the operand is X2 itself (written by the data-gradient launch): no affine
+  float afa[2] = {1.f, 1.f}, afb[2] = {0.f, 0.f}, aga[2] = {1.f, 1.f}, agb[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    if (plain) continue;
     const int c = n0 + wn * 64 + i * 32 + (lane & 31);
     afa[i] = ba[c < g.N ? c : 0];
     afb[i] = bb[c < g.N ? c : 0];
@@ -705,10 +707,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
         const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pb);
         const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pb + 4 * 128));
         uint4 w = __builtin_bit_cast(uint4, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-        w.x = tn_affine_relu_pair(w.x, afa[i], afb[i], afa[i], afb[i]);
-        w.y = tn_affine_relu_pair(w.y, afa[i], afb[i], afa[i], afb[i]);
-        w.z = tn_affine_relu_pair(w.z, afa[i], afb[i], afa[i], afb[i]);
-        w.w = tn_affine_relu_pair(w.w, afa[i], afb[i], afa[i], afb[i]);
+        if (!plain) {
+          w.x = tn_affine_relu_pair(w.x, afa[i], afb[i], afa[i], afb[i]);
+          w.y = tn_affine_relu_pair(w.y, afa[i], afb[i], afa[i], afb[i]);
+          w.z = tn_affine_relu_pair(w.z, afa[i], afb[i], afa[i], afb[i]);
+          w.w = tn_affine_relu_pair(w.w, afa[i], afb[i], afa[i], afb[i]);
+        }
         fb[i] = __builtin_bit_cast(e16x8, w);
       }
       if (hit_tile) {
@@ -738,10 +742,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
           const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pa);
           const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pa + 4 * 128));
           uint4 w = __builtin_bit_cast(uint4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-          w.x = tn_affine_relu_pair_w(w.x, aga[i], agb[i], w0, w1);
-          w.y = tn_affine_relu_pair_w(w.y, aga[i], agb[i], w2, w3);
-          w.z = tn_affine_relu_pair_w(w.z, aga[i], agb[i], w4, w5);
-          w.w = tn_affine_relu_pair_w(w.w, aga[i], agb[i], w6, w7);
+          // (plain operands: a = 1, b = 0 -- the values are non-negative already; only rows that stand for copies change)
+          if (!plain || lo != 0x01010101u || hi != 0x01010101u) {
+            w.x = tn_affine_relu_pair_w(w.x, aga[i], agb[i], w0, w1);
+            w.y = tn_affine_relu_pair_w(w.y, aga[i], agb[i], w2, w3);
+            w.z = tn_affine_relu_pair_w(w.z, aga[i], agb[i], w4, w5);
+            w.w = tn_affine_relu_pair_w(w.w, aga[i], agb[i], w6, w7);
+          }
           fa[i] = __builtin_bit_cast(e16x8, w);
           if (do_colsum)
             csum[i] += ((e16_lo(w.x) + e16_hi(w.x)) + (e16_lo(w.y) + e16_hi(w.y))) +
@@ -1069,7 +1076,8 @@ extern "C" int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, 
   omnipq::PlanScope plan_scope_(plan);
   using namespace omnipq;
   if (C3 <= 0 || N <= 0 || P <= 0 || (C3 % 128) || (N % 128) || (ldb % 8) || ldb < N) return OMNIPQ_EINVAL;
-  if (!Y2 || !ba || !bb || !hot || !unit_src || !workspace || nsample < 8 || (nsample & (nsample - 1))) return OMNIPQ_EINVAL;
+  if (!Y2 || ((ba != nullptr) != (bb != nullptr)) || !hot || !unit_src || !workspace || nsample < 8 || (nsample & (nsample - 1)))
+    return OMNIPQ_EINVAL;
   const RowPlan &rp = row_plan();
   if (!rp.rows_dev || !rp.row_w || rp.rows != P) return OMNIPQ_EINVAL;
   const int M = C3 + N;

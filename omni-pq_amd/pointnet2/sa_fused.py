@@ -503,6 +503,7 @@ def hoist_ok(training, features, cin, cin_raw, L, c1, xgen):
 # C2-sized matrices.  Neither dY3 nor Y3 exists: the forward's last GEMM stores statistics and ball extrema only.
 # LAST_NO_DY = False restores the stored Y3 / dY3 (tests compare the two).
 LAST_NO_DY = True
+LAST_X2 = True                  # ... and its weight gradient contracts X2 as the data-gradient launch left it (no affine per fragment)
 last_no_dy_uses = 0
 _lib.omnipq_gemm_tn_dz_workspace_floats.restype = ctypes.c_longlong
 
@@ -515,13 +516,15 @@ def last_no_dy_ok(plan, L, c2, c3, S, below_keeps_y_only):
 
 
 def last_wgrad_dz(Y2, below, hot, plan, S, C3, C2, P, alpha, beta, Wp, out=None):
-    """dW3 (f32 [C3][C2]) of a stage's last layer from the layer below's pre-BN output and the pool's one-hot gradient
-    (omnipq_gemm_tn_dz + omnipq_sa_last_wgrad_combine); inside the caller's _row_plan block."""
+    """dW3 (f32 [C3][C2]) of a stage's last layer from the layer below's pre-BN output (below is None: from X2 = relu(bn(.))
+    itself, as the data-gradient launch left it) and the pool's one-hot gradient (omnipq_gemm_tn_dz +
+    omnipq_sa_last_wgrad_combine); inside the caller's _row_plan block."""
     dev = Y2.device
     ws = torch.empty((int(_lib.omnipq_gemm_tn_dz_workspace_floats(C3, C2, P)),), device=dev, dtype=torch.float32)
     slabs, cs_off = ctypes.c_int(0), ctypes.c_longlong(0)
-    _call(_lib.omnipq_gemm_tn_dz, Y2, C3, C2, P, _p(Y2), Y2.stride(0), _p(below.a), _p(below.b), _p(hot), _p(plan.unit_src), S,
-          _p(ws), ctypes.byref(slabs), ctypes.byref(cs_off))
+    _call(_lib.omnipq_gemm_tn_dz, Y2, C3, C2, P, _p(Y2), Y2.stride(0), _p(below.a if below is not None else None),
+          _p(below.b if below is not None else None), _p(hot), _p(plan.unit_src), S, _p(ws), ctypes.byref(slabs),
+          ctypes.byref(cs_off))
     if out is None:
         out = torch.empty((C3, C2), device=dev, dtype=torch.float32)
     _call(_lib.omnipq_sa_last_wgrad_combine, Y2, C3, C2, _p(ws), ctypes.c_void_p(ws.data_ptr() + 4 * cs_off.value),
@@ -1553,23 +1556,27 @@ class FusedSAStage(torch.autograd.Function):
             _call(_lib.omnipq_sa_last_bwd_prep, g_out, ctypes.c_longlong(B * M), C3, C2, _p(sums), total, _p(last.a),
                   _p(last.mean), _p(last.invstd), _p(None), _p(None), _p(None), _p(last.Wt), last.Wt.stride(0),
                   _p(None), _p(B1), C2 + 32, _p(ab[0]), _p(ab[1]), _p(gb3))
-            # the layer's weight gradient: from Y2 and `hot`, with the other SA stages' when the deferred block ends
-            dfr = deferred_wgrads.active
-            wt = ctx.wtargets[L - 1] if (dfr is not None and SA_WGRADS_GROUPED) else None
-            if ctx.needs_input_grad[9 + 3 * (L - 1)]:
-                if wt is not None and wt[0] == "param" and wt[2] == 0 and wt[1].numel() == C3 * C2:
-                    dfr.add_dz((below.Y, below, hot, plan, S, C3, C2, P, ab[0], ab[1], last.Wp), wt, ctx.stage_label)
-                else:
-                    grads[3 * (L - 1)] = last_wgrad_dz(below.Y, below, hot, plan, S, C3, C2, P, ab[0], ab[1],
-                                                       last.Wp).view(C3, C2, 1, 1)
-            # the data gradient + the BatchNorm-backward sums of the layer below
+            # the data gradient + the BatchNorm-backward sums of the layer below; X2 = relu(bn2(Y2)) as its first phase forms
+            # it is kept for the weight gradient (LAST_X2: the TN launch is bound by rebuilding X2 in every fragment)
+            want_w = ctx.needs_input_grad[9 + 3 * (L - 1)]
+            X2 = torch.empty((P, C2), device=dev, dtype=E16.dtype) if (want_w and LAST_X2) else None
             pend0 = zeros_f64(3, below.C, dev)
             dX2 = torch.empty((P, C2), device=dev, dtype=E16.dtype)
             n_ws = int(_lib.omnipq_gemm_nt_stats_workspace_floats(P, C2))
             ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
             _call(_lib.omnipq_gemm_nt_e16_dz_bnbwd, dX2, P, C2, C3, _p(below.Y), C2, _p(B1), C2 + 32, _p(last.Wt),
                   last.Wt.stride(0), _p(hot), _p(plan.unit_src), S, _p(dX2), C2, _p(below.a), _p(below.b), _p(below.mean),
-                  _p(below.invstd), _p(pend0), _p(ws))
+                  _p(below.invstd), _p(pend0), _p(ws), _p(X2))
+            # the layer's weight gradient: from X2 (or Y2) and `hot`, with the other SA stages' when the deferred block ends
+            dfr = deferred_wgrads.active
+            wt = ctx.wtargets[L - 1] if (dfr is not None and SA_WGRADS_GROUPED) else None
+            if want_w:
+                src, blw = (X2, None) if X2 is not None else (below.Y, below)
+                if wt is not None and wt[0] == "param" and wt[2] == 0 and wt[1].numel() == C3 * C2:
+                    dfr.add_dz((src, blw, hot, plan, S, C3, C2, P, ab[0], ab[1], last.Wp), wt, ctx.stage_label)
+                else:
+                    grads[3 * (L - 1)] = last_wgrad_dz(src, blw, hot, plan, S, C3, C2, P, ab[0], ab[1],
+                                                       last.Wp).view(C3, C2, 1, 1)
         elif world > 1 or _FORCE_COLLECTIVES or not _FOLD_SMALL:
             grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = affine_grads(sums, last.C)
             _allreduce_(sums[:2], world)
