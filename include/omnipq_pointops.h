@@ -37,8 +37,11 @@ extern "C" {
 
 /* 2: round 5's signatures (21 entry points take `const omnipq_row_plan *plan` in front of the stream; omnipq_fps_footprint,
  *    omnipq_sa_row_plan, omnipq_sa_plan_pool_gamma, omnipq_gemm_strip_* removed) + omnipq_plan_aware_entry_points().
+ * 3: round 6 -- omnipq_row_plan grew { tickets, ticket_words }; omnipq_gemm_nt_e16_bnaffine_pool accepts C == NULL (no store);
+ *    new: omnipq_sa_last_bwd_prep, omnipq_gemm_nt_e16_dz_bnbwd, omnipq_gemm_tn_dz, omnipq_sa_last_wgrad_combine,
+ *    omnipq_sa_pool_bwd_stats_sel_hot.
  * A binding must refuse a library whose version it was not written against: the argument lists differ. */
-#define OMNIPQ_ABI_VERSION 2
+#define OMNIPQ_ABI_VERSION 3
 
 #define OMNIPQ_OK 0
 #define OMNIPQ_EINVAL 10001     /* bad shape / null pointer */

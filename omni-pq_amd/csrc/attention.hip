@@ -597,6 +597,14 @@ static int fill_args(AttnArgs &g, int N, int H, int L, int S, int D, const long 
   if ((long long)N * H * L * S >= (1ll << 32)) return OMNIPQ_ETOOLARGE;
   for (int i = 0; i < 8; ++i)
     if (strides[i] % 4) return OMNIPQ_EINVAL;
+  // the kernels address a (batch, head) slice through a buffer descriptor: 32-bit byte offsets, num_records an int
+  {
+    const long long tok = L > S ? L : S;
+    for (int i = 0; i < 8; i += 2) {
+      const long long sl = strides[i] < 0 ? -strides[i] : strides[i];
+      if (((tok - 1) * sl + D) * 2 >= (1ll << 31) || 32 * sl * 2 >= (1ll << 31)) return OMNIPQ_ETOOLARGE;
+    }
+  }
   g.N = N, g.H = H, g.L = L, g.S = S, g.D = D;
   g.q_sl = strides[0], g.q_sn = strides[1], g.k_sl = strides[2], g.k_sn = strides[3];
   g.v_sl = strides[4], g.v_sn = strides[5], g.o_sl = strides[6], g.o_sn = strides[7];
@@ -638,6 +646,11 @@ extern "C" int omnipq_attn_bwd(int N, int H, int L, int S, int D, const void *q,
   if (rc) return rc;
   for (int i = 0; i < 6; ++i)
     if (grad_strides[i] % 4) return OMNIPQ_EINVAL;
+  for (int i = 0; i < 6; i += 2) {
+    const long long sl = grad_strides[i] < 0 ? -grad_strides[i] : grad_strides[i];
+    const long long tok = L > S ? L : S;
+    if (((tok - 1) * sl + D) * 2 >= (1ll << 31) || 32 * sl * 2 >= (1ll << 31)) return OMNIPQ_ETOOLARGE;
+  }
   attn_bwd_dq_kernel<<<dim3((L + 31) / 32, N * H), 256, 0, (hipStream_t)stream>>>(
       g, (const e16_t *)q, (const e16_t *)k, (const e16_t *)v, (const e16_t *)o, (const e16_t *)d_o, lse2, delta,
       (e16_t *)dq, grad_strides[0], grad_strides[1]);

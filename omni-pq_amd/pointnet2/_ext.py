@@ -27,7 +27,7 @@ if not os.path.exists(_LIB_PATH):
         f"pointnet2._ext: {_LIB_PATH} not found -- build it with `python omni-pq_amd/build.py` "
         "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for these operators.")
 
-ABI_VERSION = 2          # include/omnipq_pointops.h: OMNIPQ_ABI_VERSION
+ABI_VERSION = 3          # include/omnipq_pointops.h: OMNIPQ_ABI_VERSION
 
 
 def _load(path):

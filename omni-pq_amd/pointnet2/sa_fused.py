@@ -363,11 +363,14 @@ def build_csr_ahead(idx, N, plan, offsets, order):
         _call(_lib.omnipq_sa_build_csr, idx, B, N, M, S, _p(idx), _p(offsets), _p(order), _p(scratch))
 
 
-def _csr_of(idx, B, N, M, S, planned, anchor):
+def _csr_of(idx, B, N, M, S, plan, anchor):
     """(offsets, order) of the stage's backward: the ones made ahead of the stage (run(group=)) if they were made in the row
-    space this backward runs in, else built now (inside the caller's _row_plan block)."""
+    space this backward runs in -- the SAME plan state (its goff words and group size), or no plan on both sides (ADVICE r5:
+    a flag alone let a CSR of another row space through when a switch changed between prefetch and forward) -- else built
+    now (inside the caller's _row_plan block)."""
     pre = getattr(idx, "omnipq_csr", None)
-    if pre is not None and pre[2] == planned and tuple(pre[0].shape) == (B, N + 1) and tuple(pre[1].shape) == (B, M * S):
+    key = None if plan is None else (plan.goff.data_ptr(), plan.gs)
+    if pre is not None and pre[2] == key and tuple(pre[0].shape) == (B, N + 1) and tuple(pre[1].shape) == (B, M * S):
         return pre[0], pre[1]
     dev = idx.device
     offsets = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
@@ -1661,7 +1664,7 @@ class FusedSAStage(torch.autograd.Function):
                     d_cen = torch.empty((B, M, 3), device=dev)
                 # bucket the positions by source point, then every (point, 8-channel piece) sums its
                 # own bucket: no atomics, each dX row is read exactly once
-                offsets, order = _csr_of(ctx.idx, B, N, M, S, getattr(ctx, "plan", None) is not None, dX)
+                offsets, order = _csr_of(ctx.idx, B, N, M, S, getattr(ctx, "plan", None), dX)
                 _call(_lib.omnipq_sa_scatter_csr, dX, B, N, M, S, cin, kpad, ctypes.c_float(inv_r), _p(offsets),
                       _p(order), _p(dX), _p(dfeat_pm), _p(d_xyz), _p(d_cen))
                 if dfeat_pm is not None:
@@ -1685,7 +1688,7 @@ def _backward_hoisted(ctx, dY, lay, grads, dfr, dev):
     d_xyz = d_cen = d_feat = None
     if not (want_xyz or want_feat or want_w):
         return d_xyz, d_cen, d_feat
-    offsets, order = _csr_of(idx, B, N, M, S, plan is not None, dY)
+    offsets, order = _csr_of(idx, B, N, M, S, plan, dY)
     dXr = None
     if want_xyz:
         # gradient of the relative coordinates: dY W_x (the rows cin .. cin + 7 of the transposed prepared weight: W_x^T | 0)
@@ -1786,7 +1789,10 @@ def run(module, xyz, new_xyz, features, group=None):
             B_, M_, S_ = idx.shape
             idx.omnipq_plan = plan_from_state(group[1], B_, M_, B_ * M_ * S_)
         if len(group) > 3 and group[2] is not None:
-            idx.omnipq_csr = (group[2][0], group[2][1], bool(group[3]))
+            # the row space the CSR was built in: the plan state it travelled with (group[3]: built under that plan), or none
+            built_under = (group[1].data_ptr(), PLAN_GROUP) if (group[3] and group[1] is not None) else None
+            if bool(group[3]) == (built_under is not None):
+                idx.omnipq_csr = (group[2][0], group[2][1], built_under)
     if idx is None:
         with _tagged("@sa", _STAGE_LABEL):
             idx = pointnet2_utils.ball_query(module.radius, module.nsample, xyz, new_xyz)

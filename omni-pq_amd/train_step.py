@@ -73,7 +73,12 @@ class CapturedStep:
         self.amp_dtype, self.scale = amp_dtype, float(loss_scale)
         self.prefetch_at, self.footprint = prefetch, fps_footprint
         self.teacher = teacher
-        self.ema = ema[0] if isinstance(ema, (tuple, list)) else ema
+        if isinstance(ema, (tuple, list)):
+            # (decay, step) was the contract while the averaging ran inside step(); the step value would be dropped silently
+            # and -- if update_teacher() is never called -- the teacher would stay frozen
+            raise TypeError("CapturedStep(ema=...): pass the decay alone and call update_teacher(global_step) after "
+                            "optimizer.step(); the (decay, step) pair of earlier versions is no longer accepted")
+        self.ema = ema
         self.teacher_to_criterion = bool(teacher_to_criterion)
         self.teacher_end_points = None
         self._grads = None             # graph mode: (parameter, static gradient tensor) pairs, re-attached after every replay
@@ -207,6 +212,7 @@ class CapturedStep:
         kernel ARGUMENT and changes with every call, which a replayed launch could not follow."""
         if self.teacher is None or self.ema is None:
             return None
+        self._steps_unaveraged = 0
         import ema as _ema
         return _ema.update_ema_variables(self.net, self.teacher, self.ema, global_step)
 
@@ -264,6 +270,13 @@ class CapturedStep:
         coordinate-only sampling runs underneath this step.  inputs=None or the very object announced as `next_inputs` last
         time: the announced batch is taken as is; any other input is copied in and its sampling plan recomputed up front
         (correct, and ~5 ms slower for that call at 40 000 points).  next_inputs=None: nothing to announce (last batch)."""
+        if self.teacher is not None and self.ema is not None:
+            self._steps_unaveraged = getattr(self, "_steps_unaveraged", 0) + 1
+            if self._steps_unaveraged == 4:
+                import warnings
+                warnings.warn("CapturedStep: a teacher and an EMA decay are set but update_teacher(global_step) has not been "
+                              "called for three steps -- the teacher's weights are not being averaged (call it after "
+                              "optimizer.step(), where the reference calls update_ema_variables)")
         if self.graph is None:
             return self._eager_step(inputs, labels, next_inputs, teacher_inputs, next_teacher_inputs)
         net, teacher = self.net, self.teacher

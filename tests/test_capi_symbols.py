@@ -57,13 +57,13 @@ def test_library_names_its_plan_aware_entry_points(built_lib):
         assert all(hasattr(lib, n) for n in names)
     import pointnet2_utils
     assert pointnet2_utils._ext.PLAN_AWARE == capi.plan_aware()
-    assert pointnet2_utils._ext.ABI_VERSION == lib.omnipq_abi_version() == 2
+    assert pointnet2_utils._ext.ABI_VERSION == lib.omnipq_abi_version() == 3
 
 
 def test_host_helpers_without_gpu(built_lib):
     from oracle import oracle_ext
     lib = capi.lib()
-    assert lib.omnipq_abi_version() == 2
+    assert lib.omnipq_abi_version() == 3
     assert b"invalid" in lib.omnipq_error_string(10001)
     # the FPS tie geometry must agree between library, oracle and the reference's formula
     for n in list(range(1, 70)) + [100, 127, 128, 255, 256, 511, 512, 513, 1000, 1024, 2048, 4096, 8192,

@@ -550,3 +550,40 @@ def test_grouping_ahead_of_the_stages_is_taken_and_changes_nothing(monkeypatch):
     assert sorted(ggot) == sorted(gwant) and len(ggot) >= 30
     for n in gwant:
         assert torch.equal(ggot[n], gwant[n]), n
+
+
+@pytest.mark.gpu
+def test_a_csr_made_ahead_in_another_row_space_is_not_reused(monkeypatch):
+    """the backward CSR of a stage is made ahead of it in the row space of the plan the chain built.  If what
+    decides the row space changes between prefetch and forward (here: ROW_PLAN switched off after the chain ran), the stage
+    runs unplanned and must NOT take that CSR: outputs and gradients equal the run that never prefetched."""
+    import bench
+    import sa_fused
+    torch.manual_seed(2)
+    net = bench.build_model(0).to(dev()).train()
+    pc = synth.make_clouds(78, 8, 40000, kind="room").to(dev())
+
+    def run(prefetch_with_plan):
+        for p in net.parameters():
+            p.grad = None
+        net.backbone.forget_plan()
+        if prefetch_with_plan:
+            monkeypatch.setattr(sa_fused, "ROW_PLAN", True)
+            net.prefetch({"point_clouds": pc})            # the chain builds plans and CSRs in their compact row space
+            torch.cuda.synchronize()
+        monkeypatch.setattr(sa_fused, "ROW_PLAN", False)   # ... and the stages run without one
+        uses = sa_fused.row_plan_uses
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ep = net.backbone(pc, {})
+        (ep["fp2_features"].float().sum() + ep["sa4_features"].float().sum()).backward()
+        torch.cuda.synchronize()
+        assert sa_fused.row_plan_uses == uses
+        return ep["fp2_features"].detach().clone(), {n: p.grad.clone() for n, p in net.backbone.named_parameters()
+                                                     if p.grad is not None}
+
+    want, gwant = run(False)
+    got, ggot = run(True)
+    assert torch.equal(got, want)
+    assert sorted(ggot) == sorted(gwant) and len(ggot) >= 30
+    for n in gwant:
+        assert torch.equal(ggot[n], gwant[n]), n
