@@ -527,6 +527,8 @@ def workload_name(args):
             (16, 80000, 0): "BASELINE configs[4]"}.get(key, "custom configuration")
     if key == (16, 80000, 0) and args.dtype != "fp16":
         name += f" (in {args.dtype}; the configuration names fp16: --dtype fp16)"
+    if key == (16, 80000, 0) and getattr(args, "cloud", "room") != "uniform":
+        name += " (on room scenes; SURVEY 8d prescribes uniform clouds for this configuration: --cloud uniform)"
     return name
 
 
@@ -907,7 +909,8 @@ def main():
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
-            "metric": ((f"scenes/sec fwd+bwd, {args.points // 1000}k-pt ScanNet clouds, batch {args.batch}/GPU")
+            "metric": ((f"scenes/sec fwd+bwd, {args.points // 1000}k-pt "
+                        + ("ScanNet" if args.cloud == "room" else "uniform synthetic") + f" clouds, batch {args.batch}/GPU")
                        if not args.mean_teacher else
                        (f"student scenes/sec, mean-teacher step (student fwd+bwd + teacher fwd + EMA), "
                         f"{args.points // 1000}k-pt clouds, batch {args.batch}+{args.batch}/GPU")),

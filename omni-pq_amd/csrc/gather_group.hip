@@ -11,13 +11,12 @@
 //
 // The scatter-add gradients are BIT-REPRODUCIBLE: the reference (and rounds 1-3 here) add with f32 atomics, so the order of
 // the additions -- and with it the low bits of every gradient that more than two positions contribute to -- changes from run
-// to run.  Here the positions are sorted by (scene, source point) with a STABLE radix sort (hipCUB: the one library call of
-// this file), which leaves the positions of a source point in ascending order, and every source point's run is summed by ONE
+// to run.  Here the positions are sorted by (scene, source point) with a STABLE least-significant-digit radix sort (round 6:
+// the three kernels below -- 8-bit digits, 4096-position tiles, ballot-matched ranks; hipCUB's DeviceRadixSort until round 5,
+// 2.2 MB of the library), which leaves the positions of a source point in ascending order, and every source point's run is summed by ONE
 // owner in that fixed order: one thread per run and channel tile, or -- runs longer than kBigRun, e.g. the source point
 // that every empty ball's slots name -- one workgroup per run, strided partial sums folded in a fixed tree.
 #include <mutex>
-
-#include <hipcub/hipcub.hpp>
 
 #include "common.h"
 
@@ -190,7 +189,96 @@ __global__ __launch_bounds__(1024) void scatter_small_kernel(int c, int n, int P
   }
 }
 
-// grow-only scratch of the calling thread's sorts (keys / values in and out, hipCUB's temporary storage, the long-run list);
+// ---- stable LSD radix sort of (key, value) pairs, 8 bits per pass --------------------------------------------------------------
+// A tile = kRsTile consecutive pairs, one workgroup.  Pass = histogram (per tile and digit) -> exclusive scan over
+// [digit][tile] -> scatter: the tile's pairs are placed in 16 rounds of 256, within a round a pair's rank among the pairs of
+// the same digit is (pairs of lower waves, from a per-wave count table) + (lower lanes of its own wave that hold the digit: eight
+// ballots match the digit bit by bit), so equal keys keep their order -- the property the fixed summation order rests on.
+constexpr int kRsTile = 4096;
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(long long total, int shift, int ntiles,
+                                                        const unsigned *__restrict__ key, unsigned *__restrict__ hist) {
+  __shared__ unsigned s_h[256];
+  const int tid = (int)threadIdx.x;
+  s_h[tid] = 0;
+  __syncthreads();
+  const long long t0 = (long long)blockIdx.x * kRsTile;
+  for (int r = 0; r < kRsTile / 256; ++r) {
+    const long long i = t0 + r * 256 + tid;
+    if (i < total) atomicAdd(&s_h[(key[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)tid * ntiles + blockIdx.x] = s_h[tid];
+}
+
+// exclusive scan of `count` words in place, one workgroup of 1024 threads (count <= a few 10^5: [256 digits][tiles])
+__global__ __launch_bounds__(1024) void radix_scan_kernel(long long count, unsigned *__restrict__ data) {
+  __shared__ unsigned s_part[1024];
+  const int tid = (int)threadIdx.x;
+  const long long per = (count + 1023) / 1024;
+  const long long a = tid * per, b = a + per < count ? a + per : count;
+  unsigned sum = 0;
+  for (long long i = a; i < b; ++i) sum += data[i];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned v = tid >= d ? s_part[tid - d] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  unsigned run = s_part[tid] - sum;
+  for (long long i = a; i < b; ++i) {
+    const unsigned v = data[i];
+    data[i] = run;
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(long long total, int shift, int ntiles,
+                                                           const unsigned *__restrict__ key_in,
+                                                           const unsigned *__restrict__ val_in,
+                                                           unsigned *__restrict__ key_out, unsigned *__restrict__ val_out,
+                                                           const unsigned *__restrict__ offs) {
+  __shared__ unsigned s_base[256];
+  __shared__ unsigned s_wc[4][256];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  s_base[tid] = offs[(size_t)tid * ntiles + blockIdx.x];
+  const long long t0 = (long long)blockIdx.x * kRsTile;
+  for (int r = 0; r < kRsTile / 256; ++r) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_wc[w][tid] = 0;
+    __syncthreads();
+    const long long i = t0 + r * 256 + tid;
+    const bool valid = i < total;
+    unsigned k = 0, v = 0, d = 0;
+    if (valid) {
+      k = key_in[i];
+      v = val_in[i];
+      d = (k >> shift) & 255u;
+    }
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long m = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank == 0) s_wc[wave][d] = (unsigned)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      unsigned pos = s_base[d] + rank;
+      for (int w = 0; w < wave; ++w) pos += s_wc[w][d];
+      key_out[pos] = k;
+      val_out[pos] = v;
+    }
+    __syncthreads();
+    s_base[tid] += s_wc[0][tid] + s_wc[1][tid] + s_wc[2][tid] + s_wc[3][tid];
+    __syncthreads();
+  }
+}
+
+// grow-only scratch of the calling thread's sorts (keys / values in and out, the [digit][tile] histogram, the long-run list);
 // growth allocates -- a warm-up call at the largest size makes later calls capture-safe, as for the sampling workspace
 struct ScatterScratch {
   void *block = nullptr;
@@ -239,14 +327,11 @@ static int launch_scatter(int b, int c, int n, int P, const float *grad_out, con
   int bits = 1;
   while (bits < 32 && (1ull << bits) < (unsigned long long)b * (unsigned long long)n) ++bits;
   const int big_cap = (int)(total / kBigRun) + 1;            // no more runs than that can be longer than kBigRun
-  size_t tmp_bytes = 0;
-  if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                         (const unsigned *)nullptr, (unsigned *)nullptr, (int)total, 0, bits,
-                                         stream) != hipSuccess)
-    return (int)hipErrorUnknown;
+  const int ntiles = (int)((total + kRsTile - 1) / kRsTile);
+  const size_t hist_bytes = ((size_t)256 * ntiles * 4 + 255) / 256 * 256;
   const size_t arr = ((size_t)total * 4 + 255) / 256 * 256;
-  const size_t big_bytes = (size_t)(2 + 2 * big_cap) * 4;
-  const size_t need = 4 * arr + ((tmp_bytes + 255) / 256 * 256) + big_bytes;
+  const size_t big_bytes = ((size_t)(2 + 2 * big_cap) * 4 + 255) / 256 * 256;
+  const size_t need = 4 * arr + hist_bytes + big_bytes;
   ScatterScratch &sc = t_scatter;
   if (sc.bytes < need) {
     void *q = nullptr;                               // the old block is left to launches still in flight
@@ -255,16 +340,25 @@ static int launch_scatter(int b, int c, int n, int P, const float *grad_out, con
     sc.bytes = need;
   }
   unsigned char *base = (unsigned char *)sc.block;
-  unsigned *key_in = (unsigned *)base, *val_in = (unsigned *)(base + arr), *key_out = (unsigned *)(base + 2 * arr),
-           *val_out = (unsigned *)(base + 3 * arr);
+  unsigned *kbuf[2] = {(unsigned *)base, (unsigned *)(base + 2 * arr)}, *vbuf[2] = {(unsigned *)(base + arr),
+                                                                                 (unsigned *)(base + 3 * arr)};
   unsigned *big = (unsigned *)(base + 4 * arr);
-  void *tmp = base + 4 * arr + big_bytes;
+  unsigned *hist = (unsigned *)(base + 4 * arr + big_bytes);
   OMNIPQ_HIP(hipMemsetAsync(big, 0, 8, stream));
-  scatter_keys_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(total, n, P, idx, key_in, val_in);
+  scatter_keys_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(total, n, P, idx, kbuf[0], vbuf[0]);
   OMNIPQ_LAUNCH_CHECK();
-  if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)total, 0, bits, stream) !=
-      hipSuccess)
-    return (int)hipErrorUnknown;
+  int cur = 0;
+  for (int shift = 0; shift < bits; shift += 8) {
+    radix_hist_kernel<<<ntiles, 256, 0, stream>>>(total, shift, ntiles, kbuf[cur], hist);
+    OMNIPQ_LAUNCH_CHECK();
+    radix_scan_kernel<<<1, 1024, 0, stream>>>((long long)256 * ntiles, hist);
+    OMNIPQ_LAUNCH_CHECK();
+    radix_scatter_kernel<<<ntiles, 256, 0, stream>>>(total, shift, ntiles, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1],
+                                                     hist);
+    OMNIPQ_LAUNCH_CHECK();
+    cur ^= 1;
+  }
+  const unsigned *key_out = kbuf[cur], *val_out = vbuf[cur];
   dim3 grid((unsigned)((total + 255) / 256), (c + kCT - 1) / kCT);
   scatter_runs_kernel<<<grid, 256, 0, stream>>>(total, c, n, P, grad_out, key_out, val_out, grad_points, big, big_cap);
   OMNIPQ_LAUNCH_CHECK();

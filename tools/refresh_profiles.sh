@@ -64,7 +64,7 @@ if [ "${2:-}" != "--collect" ]; then
   python $R/tools/step_timeline.py $OUT/markers $OUT/step_timeline.md > /dev/null 2>&1
   rm -rf $OUT/markers
   : > $OUT/other_lines.jsonl
-  for F in "--mean-teacher" "--loss supervised" "--input-pipeline" "--dtype fp16 --batch 16 --points 80000" "--dtype bf16 --batch 16 --points 80000" "--batch 4 --points 50000 --extra-channels 6" "--dtype fp16" "--prefetch-at backward" "--fps-footprint fast" "--set sa_fused.ROW_PLAN=False" "--cloud uniform" "--dtype fp32"; do
+  for F in "--mean-teacher" "--loss supervised" "--input-pipeline" "--dtype fp16 --batch 16 --points 80000 --cloud uniform" "--dtype bf16 --batch 16 --points 80000 --cloud uniform" "--batch 4 --points 50000 --extra-channels 6" "--dtype fp16" "--prefetch-at backward" "--fps-footprint fast" "--set sa_fused.ROW_PLAN=False" "--cloud uniform" "--dtype fp32"; do
     # every line carries its own event-timed roofline (never --no-op-timing for a line that goes into profiles/)
     python $R/bench.py --no-cpu-baseline --steps 30 $F 2>/dev/null | grep "^{" | python -c "
 import sys, json
