@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
                     help="A/B runs on one box: set a module-level switch before the model is built, e.g. "
                          "--set sa_fused.SA_WGRADS_GROUPED=0 (int / float / True / False values)")
+    ap.add_argument("--capi", action="append", default=[], metavar="ENTRY=INT",
+                    help="A/B runs: call a timing-aid setter of the library before the model is built, e.g. "
+                         "--capi omnipq_gemm_nt_small_tile_limit=512")
     ap.add_argument("--loss-scale", type=float, default=0.0,
                     help="the loss is multiplied by this before backward (what torch.amp.GradScaler does for fp16: a mean "
                          "over 1e5 elements hands every element a gradient below fp16's normal range); 0 = 16384 for fp16, 1 otherwise")
@@ -759,6 +762,10 @@ def main():
         assert hasattr(m, attr), f"--set: {mod} has no attribute {attr}"
         setattr(m, attr, ast.literal_eval(value))
 
+    for item in args.capi:
+        name, value = item.split("=", 1)
+        for lib in ext._LIBS.values():
+            getattr(lib, name)(int(value))
     if args.sa_markers:
         import sa_fused
         sa_fused.SPAN_MARKERS = True

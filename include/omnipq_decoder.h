@@ -136,6 +136,19 @@ int omnipq_split_rows(int b, int p, int p0, int c, const void *x16, void *obj16,
 int omnipq_merge_rows(int b, int p, int p0, int c, const void *g_obj16, const void *g_quad16, const void *g_joint16,
                       void *out16, void *stream);
 
+/* The decoder layer's feed-forward block as one launch (+ a slab reduction), round 6 (csrc/ffn_fused.hip; reference
+ * models/transformer.py:188-228: linear2(dropout(relu(linear1(x))))):
+ *   H[R][ldh]  = dropout(relu(X W1^T + b1))   e16, stored for the backward pass -- the bits of
+ *                omnipq_gemm_nt_e16_relu_dropout(R, F, D, X, ..., H, ldh, b1, dropout_p, seed_ptr, salt)
+ *   Y[R][D]    = H W2^T + b2                   e16, one rounding of the f32 sum over the hs hidden slices
+ * X e16 [R][ldx], W1 e16 [F][ldw1] (K-contiguous over D), W2 e16 [D][ldw2] (K-contiguous over F), b1 f32 [F] / b2 f32 [D] (may be
+ * NULL).  D in {128, 256, 288}, F % (64 hs) == 0.  The grid is (R / 64 row blocks) x hs slices of the hidden axis: a workgroup
+ * streams 1 / hs of both weight matrices.  workspace: omnipq_ffn_fused_workspace_floats(R, D, hs) floats. */
+long long omnipq_ffn_fused_workspace_floats(int R, int D, int hs);
+int omnipq_ffn_fused_fwd(int R, int D, int F, const void *X, int ldx, const void *W1, int ldw1, const float *b1,
+                         const void *W2, int ldw2, const float *b2, void *H, int ldh, void *Y, float *workspace, int hs,
+                         float dropout_p, const unsigned long long *seed_ptr, unsigned salt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,6 +216,8 @@ int omnipq_sa_scatter_rows_csr(int b, int n, int m, int s, int C, float inv_radi
 /* Timing aid (tools/bench_tn_grouped.py): bit 0 selects the register-prefetch workgroup program of the TN kernels instead of
  * the LDS-DMA ring they run by default (csrc/gemm_tn_bf16.hip: tn_tile / tn_tile_dma); process-wide, not for production. */
 void omnipq_tn_debug(int flags);
+/* Timing aid: NT GEMMs of at most `tiles` 128 x 128 tiles run on 64 x 64 tiles (default 256); process-wide, not for production. */
+void omnipq_gemm_nt_small_tile_limit(int tiles);
 int omnipq_tn_occupancy(int which);   /* workgroups per CU of the grouped TN kernel: 0 plain, 1 affine, + 2 register program */
 
 /* Row plan of a stage whose balls hold duplicate rows (csrc/common.h: RowPlan).  ball_query pads a ball with copies of its

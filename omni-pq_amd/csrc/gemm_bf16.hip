@@ -1167,8 +1167,10 @@ static int gemm_nt_splitk_bf16(int M, int N, int K, const void *A, int lda, cons
 
 // Few 128 x 128 tiles (the per-point layers outside the SA stages): 64 x 64 tiles when at most 256 big tiles would be
 // launched, see the kernel's comment on T.
+static int g_small_tile_limit = 256;          // omnipq_gemm_nt_small_tile_limit: A/B of the 64 x 64-tile threshold (timing aid)
+extern "C" void omnipq_gemm_nt_small_tile_limit(int tiles) { g_small_tile_limit = tiles; }
 static bool gemm_nt_small_tiles(int M, int N) {
-  return (long long)((M + 127) / 128) * ((N + 127) / 128) <= 256;
+  return (long long)((M + 127) / 128) * ((N + 127) / 128) <= g_small_tile_limit;
 }
 
 // the calling thread's row plan (common.h: RowPlan), if it was made for this many rows
