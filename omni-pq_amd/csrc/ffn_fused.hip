@@ -33,7 +33,10 @@ struct FfnArgs {
 
 __device__ __forceinline__ uint4 ffn_ldg16(const e16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
-template <int NB>             // NB = D / 32 column blocks of the output
+// NB = D / 32 column blocks of the output; NCH = chunks per workgroup (F / hs / 64): the chunk loop is unrolled completely, so
+// that the wait counts of the register-staged weight stream are exact (a loop-carried register load makes the compiler wait for
+// everything in flight at the back edge)
+template <int NB, int NCH>
 __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const e16_t *__restrict__ X,
                                                               const e16_t *__restrict__ W1, const float *__restrict__ b1,
                                                               const e16_t *__restrict__ W2, e16_t *__restrict__ H,
@@ -58,11 +61,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const 
   const int row0 = rb * FFN_BM;
   const int fper = g.F / g.hs;
   const int f0 = slice * fper;
-  const int nchunks = fper / FFN_FC;
+  constexpr int nchunks = NCH;
   const unsigned rd_seed = g.drop_thresh ? dec_seed(g.drop_seed, g.drop_salt) : 0u;
 
   // ---- X block and the first W1 chunk -> LDS; the first W2 chunk -> registers -------------------------------------------------
-  uint4 stg[STG > STG2 ? STG : STG2];
+  // The weight stream travels TWO chunks ahead in registers (one workgroup per CU, one wave per SIMD: 512 VGPRs each -- the
+  // register file is the ring): W1 chunk k in r1[k & 1], W2 chunk k in r2[k & 1]; ~160 KB in flight per CU
+  uint4 r1[2][STG], r2[2][STG2];
 #pragma unroll
   for (int i = 0; i < STG; ++i) {
     const int q = tid + i * 256, r = q / PIECES, p = q % PIECES;
@@ -75,28 +80,28 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const 
     const int q = tid + i * 256, r = q / PIECES, p = q % PIECES;
     *reinterpret_cast<uint4 *>(W1s + r * XP + p * 8) = ffn_ldg16(W1 + (size_t)(f0 + r) * g.ldw1 + p * 8);
   }
-  auto load_w2 = [&](int c) {
+  auto load_w2 = [&](int c, uint4 (&stg)[STG2]) {
 #pragma unroll
     for (int i = 0; i < STG2; ++i) {
       const int q = tid + i * 256, r = q / (FFN_FC / 8), p = q % (FFN_FC / 8);
       stg[i] = ffn_ldg16(W2 + (size_t)r * g.ldw2 + f0 + c * FFN_FC + p * 8);
     }
   };
-  auto store_w2 = [&]() {
+  auto store_w2 = [&](const uint4 (&stg)[STG2]) {
 #pragma unroll
     for (int i = 0; i < STG2; ++i) {
       const int q = tid + i * 256, r = q / (FFN_FC / 8), p = q % (FFN_FC / 8);
       *reinterpret_cast<uint4 *>(W2s + r * HP + p * 8) = stg[i];
     }
   };
-  auto load_w1 = [&](int c) {
+  auto load_w1 = [&](int c, uint4 (&stg)[STG]) {
 #pragma unroll
     for (int i = 0; i < STG; ++i) {
       const int q = tid + i * 256, r = q / PIECES, p = q % PIECES;
       stg[i] = ffn_ldg16(W1 + (size_t)(f0 + c * FFN_FC + r) * g.ldw1 + p * 8);
     }
   };
-  auto store_w1 = [&]() {
+  auto store_w1 = [&](const uint4 (&stg)[STG]) {
 #pragma unroll
     for (int i = 0; i < STG; ++i) {
       const int q = tid + i * 256, r = q / PIECES, p = q % PIECES;
@@ -114,7 +119,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const 
   const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
   const int nb_begin = wn == 0 ? 0 : NB0, nb_count = wn == 0 ? NB0 : NB - NB0;
 
-  load_w2(0);
+  if (nchunks > 1) load_w1(1, r1[1]);
+  if (nchunks > 2) load_w1(2, r1[0]);
+  load_w2(0, r2[0]);
+  if (nchunks > 1) load_w2(1, r2[1]);
+#pragma unroll
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();                                     // Xs / W1s of this chunk are in place; phase B of the last chunk is over
     // ---- phase A: this wave's 32 x 32 block of Hc ---------------------------------------------------------------------------
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const 
       const e16x8 fb = *reinterpret_cast<const e16x8 *>(pb + k * 16);
       accH = mfma_e16_32x32x16(fa, fb, accH);
     }
-    store_w2();                                          // (the loads were issued a phase ago)
+    store_w2(r2[c & 1]);                                 // (requested two chunks ago)
+    if (c + 2 < nchunks) load_w2(c + 2, r2[c & 1]);
     // bias + ReLU + dropout, rounded once, into Hs
     {
       const int hcol = f0 + c * FFN_FC + wn * 32 + ccol;
@@ -145,7 +155,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const 
         Hs[row * HP + wn * 32 + ccol] = (e16_t)v;
       }
     }
-    if (c + 1 < nchunks) load_w1(c + 1);
     __syncthreads();                                     // Hs and W2s are in place; phase A is over everywhere (W1s is free)
     // Hc -> memory for the backward pass: 64 rows x 8 pieces
 #pragma unroll
@@ -168,8 +177,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs g, const 
         }
     }
     if (c + 1 < nchunks) {
-      store_w1();
-      load_w2(c + 1);
+      store_w1(r1[(c + 1) & 1]);
+      if (c + 3 < nchunks) load_w1(c + 3, r1[(c + 1) & 1]);
     }
   }
   // ---- the f32 partial of this hidden slice --------------------------------------------------------------------------------------
@@ -226,21 +235,26 @@ extern "C" int omnipq_ffn_fused_fwd(int R, int D, int F, const void *X, int ldx,
   }
   const int blocks = ((R + FFN_BM - 1) / FFN_BM) * hs;
   const int lds = (FFN_BM * (D + 8) + FFN_FC * (D + 8) + D * (FFN_FC + 8) + FFN_BM * (FFN_FC + 8)) * 2;
-#define OMNIPQ_FFN_CASE(NB_)                                                                                              \
-  case NB_: {                                                                                                             \
-    auto kern = ffn_fused_fwd_kernel<NB_>;                                                                                \
+#define OMNIPQ_FFN_CASE(NB_, NCH_)                                                                                        \
+  if (D / 32 == NB_ && nch == NCH_) {                                                                                     \
+    auto kern = ffn_fused_fwd_kernel<NB_, NCH_>;                                                                          \
     static const hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                          \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
     (void)prepared;                                                                                                       \
     kern<<<blocks, 256, lds, (hipStream_t)stream>>>(g, (const e16_t *)X, (const e16_t *)W1, b1, (const e16_t *)W2,        \
                                                     (e16_t *)H, workspace);                                               \
-  } break;
-  switch (D / 32) {
-    OMNIPQ_FFN_CASE(9)
-    OMNIPQ_FFN_CASE(8)
-    OMNIPQ_FFN_CASE(4)
-    default: return OMNIPQ_EINVAL;
+    launched = true;                                                                                                      \
   }
+  const int nch = F / hs / FFN_FC;
+  bool launched = false;
+  OMNIPQ_FFN_CASE(9, 32)
+  OMNIPQ_FFN_CASE(9, 16)
+  OMNIPQ_FFN_CASE(9, 8)
+  OMNIPQ_FFN_CASE(9, 4)
+  OMNIPQ_FFN_CASE(9, 2)
+  OMNIPQ_FFN_CASE(8, 8)
+  OMNIPQ_FFN_CASE(4, 8)
+  if (!launched) return OMNIPQ_EINVAL;
 #undef OMNIPQ_FFN_CASE
   OMNIPQ_LAUNCH_CHECK();
   const long long n4 = (long long)R * D / 4;

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--d", type=int, default=288)
     ap.add_argument("--f", type=int, default=2048)
     ap.add_argument("--p", type=float, default=0.1)
-    ap.add_argument("--hs", type=int, nargs="+", default=[1, 2, 4, 8])
+    ap.add_argument("--hs", type=int, nargs="+", default=[1, 2, 4, 8, 16])
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
     import sa_fused
