@@ -913,6 +913,20 @@ def main():
                      f"the {b.late_arrivals if b is not None else 0} bucket-0 gradients that arrive after that flush; "
                      + ("buckets on a communicator of their own" if getattr(args, "bucket_group", None) is not None else
                         "buckets on the default communicator") + ")")
+    # what the collectives actually spanned (VERDICT r5 item 6 iv: the first scaling run must describe itself): one record per
+    # rank as RCCL delivered it -- a communicator that silently lost a rank, or two ranks on one device, shows up here
+    dp_detail = None
+    if distributed and dist.is_initialized():
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": torch.cuda.current_device(),
+                "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None), "ms_per_step": round(1e3 * dt / args.steps, 3)}
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, mine)
+        b_ = getattr(args, "buckets", None)
+        dp_detail = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": seen,
+                     "syncbn_collectives_per_step": int(timed_collectives) if not ddp else None,
+                     "gradient_collectives_per_step": (int(b_.collectives) if b_ is not None else None),
+                     "inside_graph": bool(use_graph), "rccl_graph_probe": bool(probe_ok)}
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
@@ -940,6 +954,7 @@ def main():
                                if use_graph else
                                ("DistributedDataParallel, eager" if ddp else f"{dp_counts}, eager launches") +
                                (" (RCCL graph probe passed)" if probe_ok else " (RCCL graph probe failed or skipped)"))),
+            "data_parallel_detail": dp_detail,
             "config": {"workload": f"{workload_name(args)}: PQ_Transformer fwd+bwd, {args.points}-pt synthetic "
                                    f"{args.cloud} scenes, batch {args.batch}/GPU, {3 + args.extra_channels} input channels",
                        "global_batch": world * args.batch, "points": args.points,

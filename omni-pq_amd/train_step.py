@@ -240,7 +240,7 @@ class CapturedStep:
                 self._body(self.cur, self.nxt if self.prefetch_at else None, self.lab, self.cur_t, self.nxt_t, True)
             torch.cuda.synchronize()
             if self.distributed:
-                _quiesce_process_groups(self.cur.device)
+                _quiesce_process_groups(self.cur.device, (getattr(self.buckets, "group", None),))
             if before_capture is not None:
                 before_capture()
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -351,7 +351,7 @@ class CapturedStep:
         return self._body(pc, nxt, labels, t_cur, t_nxt, False)
 
 
-def _quiesce_process_groups(device):
+def _quiesce_process_groups(device, extra_groups=()):
     """Before a capture that will hold collectives.  What goes wrong otherwise (ROCm 7.0 / torch 2.10, seen in 1 of 7 runs
     on a 1-rank RCCL group, `Process group watchdog thread terminated with exception: HIP error: operation not permitted
     on an event last recorded in a capturing stream`): every process group's watchdog thread polls the end-events of the
@@ -365,4 +365,19 @@ def _quiesce_process_groups(device):
     import time
     dist.barrier()
     torch.cuda.synchronize(device)
-    time.sleep(0.35)
+    # Round 6: ProcessGroup._wait_for_pending_works() returns once the backend's list of issued-but-not-retired works -- the
+    # very list the watchdog polls -- is empty: the condition itself instead of a pause long enough for it (three watchdog
+    # cycles, 0.35 s, until round 5).  Every group that may hold such work: the default one and the ones created on top of it.
+    waited = False
+    try:
+        groups = [dist.distributed_c10d._get_default_group()] + [g for g in extra_groups if g is not None]
+        for g in groups:
+            if hasattr(g, "_wait_for_pending_works"):
+                g._wait_for_pending_works()
+                waited = True
+    except Exception:
+        waited = False
+    if not waited:
+        time.sleep(0.35)                      # (no such call in this torch: the three-cycle pause)
+    else:
+        time.sleep(0.02)                      # the watchdog drops a retired work right after its query; let that pass finish

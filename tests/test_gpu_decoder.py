@@ -760,3 +760,39 @@ def test_fan_out_adds_position_major_views_as_rows():
     h1, h2 = torch.randn_like(x2), torch.randn_like(x2)
     (gx2,) = torch.autograd.grad([a, b], [x2], [h1, h2])
     assert float((gx2.float() - (h1.float() + h2.float())).abs().max()) <= 2.0 ** -7 * 8
+
+
+@pytest.mark.gpu
+def test_fused_feed_forward_equals_the_two_gemm_route():
+    """csrc/ffn_fused.hip (round 6 experiment, reference models/transformer.py:188-228: linear2(dropout(relu(linear1(x))))):
+    the hidden activations it stores are the BITS of omnipq_gemm_nt_e16_relu_dropout (same counter-hash dropout decisions),
+    the output equals the split-K route within one rounding step of bf16, for every slicing of the hidden axis; ragged rows."""
+    import ctypes
+    import sa_fused
+    from sa_fused import _call, _lib, _p
+    dev = torch.device("cuda", 0)
+    _lib.omnipq_ffn_fused_workspace_floats.restype = ctypes.c_longlong
+    g = torch.Generator(device=dev).manual_seed(11)
+    for R, p in ((4096, 0.1), (1000, 0.0)):
+        D, F = 288, 2048
+        X = torch.randn(R, D, device=dev, generator=g).to(torch.bfloat16)
+        W1 = (torch.randn(F, D, device=dev, generator=g) / D ** 0.5).to(torch.bfloat16)
+        W2 = (torch.randn(D, F, device=dev, generator=g) / F ** 0.5).to(torch.bfloat16)
+        b1, b2 = torch.randn(F, device=dev, generator=g) * 0.1, torch.randn(D, device=dev, generator=g) * 0.1
+        seed = torch.tensor([777], device=dev, dtype=torch.int64)
+        H0 = torch.empty(R, F, device=dev, dtype=torch.bfloat16)
+        Y0 = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
+        _call(_lib.omnipq_gemm_nt_e16_relu_dropout, X, R, F, D, _p(X), D, _p(W1), D, _p(H0), F, _p(b1), ctypes.c_float(p),
+              _p(seed if p else None), 5)
+        sa_fused.gemm_nt_into(H0, W2, Y0, R, D, F, bias=b2)
+        want = (H0.float() @ W2.float().t() + b2)
+        for hs in (1, 4, 8):
+            H1 = torch.zeros(R, F, device=dev, dtype=torch.bfloat16)
+            Y1 = torch.zeros(R, D, device=dev, dtype=torch.bfloat16)
+            ws = torch.empty(int(_lib.omnipq_ffn_fused_workspace_floats(R, D, hs)), device=dev, dtype=torch.float32)
+            _call(_lib.omnipq_ffn_fused_fwd, X, R, D, F, _p(X), D, _p(W1), D, _p(b1), _p(W2), F, _p(b2), _p(H1), F, _p(Y1),
+                  _p(ws), hs, ctypes.c_float(p), _p(seed if p else None), 5)
+            torch.cuda.synchronize()
+            assert torch.equal(H1, H0), (R, hs)
+            err = float((Y1.float() - want).abs().max()), float((Y0.float() - want).abs().max())
+            assert err[0] <= max(2 * err[1], 2e-2), (R, hs, err)
