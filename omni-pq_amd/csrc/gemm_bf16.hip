@@ -55,6 +55,9 @@ struct GemmArgs {
   double *fold_sums = nullptr;
 };
 constexpr int kTicketGroup = 16;
+#ifndef OMNIPQ_DZ_WGS
+#define OMNIPQ_DZ_WGS 3          // workgroups per CU of the DZ variant (4 spills: see DESIGN.md section 4.7)
+#endif
 
 __device__ __forceinline__ uint4 ldg16(const e16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
@@ -343,22 +346,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
     ga[i] = A + (size_t)ar * g.lda + kbeg + skc[i] * 8;
     gb[i] = B + (size_t)br * g.ldb + kbeg + skc[i] * 8;
   }
-  // DZ: this thread's staged rows -- weight, ball (its row of `hot`) and row within the ball; the second B operand's rows
+  // DZ: this thread's staged rows -- weight and position in the full layout now (two registers per row through the first
+  // phase); the ball's row of `hot`, the row within the ball and the second B operand's rows are derived behind it
   float dzw[NI];
-  unsigned dzt[NI];
-  const unsigned *dzh[NI];
-  const e16_t *gb2[NI];
+  int dzpf[NI];
   if (DZ) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int ar = m0 + srow[i], br = n0 + srow[i];
+      int ar = m0 + srow[i];
       ar = ar < Meff ? ar : Meff - 1;
-      br = br < g.N ? br : g.N - 1;
       dzw[i] = (float)g.row_w[ar];
-      const int pf = dz.unit_src[ar >> 3] * 8 + (ar & 7);
-      dzt[i] = (unsigned)(pf & ((1 << dz.s_shift) - 1));
-      dzh[i] = dz.hot + (size_t)(pf >> dz.s_shift) * dz.C3 + skc[i] * 8;
-      gb2[i] = dz.B2 + (size_t)br * dz.ldb2 + skc[i] * 8;
+      dzpf[i] = dz.unit_src[ar >> 3] * 8 + (ar & 7);
     }
   }
 
@@ -577,6 +575,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
   if (DZ) {
     // second phase: K = C3, A = the rows' one-hot slices of a dz (generated), B = the last layer's transposed weight
     const int nk2 = dz.C3 / GBK;
+    unsigned dzt[NI];
+    const unsigned *dzh[NI];
+    const e16_t *gb2[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int br = n0 + srow[i];
+      br = br < g.N ? br : g.N - 1;
+      dzt[i] = (unsigned)(dzpf[i] & ((1 << dz.s_shift) - 1));
+      dzh[i] = dz.hot + (size_t)(dzpf[i] >> dz.s_shift) * dz.C3 + skc[i] * 8;
+      gb2[i] = dz.B2 + (size_t)br * dz.ldb2 + skc[i] * 8;
+    }
     uint4 h0[NI], h1[NI];
     auto dz_load = [&](int kt) {
 #pragma unroll
@@ -1006,7 +1015,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
 }
 
 template <bool OUT_F32, int STATS = 0, bool AFF = false, int T = 128, int XG = 0, bool KRES = false, bool PLAN = false, bool DZ = false>
-__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? (((PLAN && XG == 1) || DZ) ? 3 : 4) : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
+__global__ __launch_bounds__(256, (T == 128 && !OUT_F32 && XG != 2) ? ((PLAN && XG == 1) ? 3 : (DZ ? OMNIPQ_DZ_WGS : 4)) : 2) void gemm_nt_kernel(GemmArgs g, const e16_t *__restrict__ A,
                                                         const e16_t *__restrict__ B,
                                                         void *__restrict__ Cout,
                                                         const float *__restrict__ bias,
