@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
                                        (__attribute__((address_space(3))) void *)(sa + TBK * 128 + (8 * wave + 4 * j) * 128), 16,
                                        0, 0);
     }
-    if (hit_tile) {
+    if (hit_tile && !(g.debug & 16)) {
       const int us = (int)aux[kt & 7][wave];
       const size_t ball = (size_t)((us * 8) >> dz.s_shift);
       const unsigned *src = dz.hot + ball * dz.C3 + m0 + lane;
@@ -688,12 +688,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
     // step kt has landed once the group issued with step kt + 1 -- one aux instruction, four block instructions -- is all
     // that is in flight; the aux words a step needs (its own, and -- hit tiles -- those that address the hot words of step
     // kt + 2) were issued two steps ago or earlier
-    if (kt + 1 < nk) tn_wait_vm<5>(); else tn_wait_vm<0>();
+    if (g.debug & (2 | 16)) tn_wait_vm<0>(); else if (kt + 1 < nk) tn_wait_vm<5>(); else tn_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) {
+    if (kt + 2 < nk && !(g.debug & 2)) {
       fetch_aux(kt + lead);
       fetch(kt + 2, (kt + 2) % TD_NBUF);
     }
+    if (g.debug & 4) continue;
     const e16_t *sa = stage + (kt % TD_NBUF) * TD_STAGE_ELEMS;
     const unsigned *sh = reinterpret_cast<const unsigned *>(sa);
 #pragma unroll
@@ -1088,6 +1089,8 @@ extern "C" int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, 
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
   const int used = (P + g.p_chunk - 1) / g.p_chunk;
   g.colsum_rows = 1;
+  g.debug = g_tn_debug;                           // (ablation bits for tools/sa_ab.py --capi omnipq_tn_debug: 2 no fetches after
+                                                  // the prologue, 4 no fragment reads / MFMAs, 16 no hot-word DMA)
   int sh = 0;
   while ((1 << sh) < nsample) ++sh;
   const size_t mn = (size_t)M * N;
