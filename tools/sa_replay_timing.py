@@ -3,7 +3,7 @@
 
 A hipGraph replay cannot host timing events (torch refuses external events on ROCm), so bench.py's `roofline.avg_ms` is
 taken from eager steps.  With --sa-markers every SA span of the step -- ball query, fused forward, fused backward of each
-of the five stages and the grouped weight-gradient launch: 16 per step -- is bracketed by the one-wave kernels
+of the five stages and the grouped weight-gradient launch(es): 16 per step until round 5, 18 since -- is bracketed by the one-wave kernels
 omnipq::sa_span_begin_kernel / sa_span_end_kernel ON THE SPAN'S STREAM; captured with the step they are graph nodes in stream
 order.  This script takes the trace, pairs the markers per queue, and sums the kernels that start after a span's begin
 marker and end before its end marker on the same queue (kernels of other queues -- the sampling chain, the early
@@ -41,10 +41,21 @@ def main():
             open_at[key] = e
         elif "sa_span_end_kernel" in name and key in open_at:
             spans.append((open_at.pop(key), s, key))
-    # steps: consecutive groups of 16 spans; the replays are the LAST steps of the run (bench.py: eager warm-up, capture,
-    # replays), and bench.py's own eager op-timing steps are switched off in the traced command
-    n_steps = len(spans) // SPANS_PER_STEP
-    steps = [spans[i * SPANS_PER_STEP:(i + 1) * SPANS_PER_STEP] for i in range(n_steps)]
+    # steps: the spans between two launches of the 40 000-point sampling kernel (exactly one per step; it is launched inside
+    # the forward pass, so an interval is a step shifted in time -- the same set of spans).  Until round 5 the spans were cut
+    # into groups of a fixed 16, which round 6's two extra spans per step (the planned stages' last-layer weight gradients,
+    # launched when the deferred block ends) turned into an undercount of 16 / 18.  The replays are the LAST steps of the run.
+    marks = [s for s, e, name, q, st in rows if "fps_kernel<1024" in name]
+    steps = []
+    for a, b in zip(marks[:-1], marks[1:]):
+        inside = [sp for sp in spans if a <= sp[0] < b]
+        if inside:
+            steps.append(inside)
+    n_steps = len(steps)
+    per_count = collections.Counter(len(st_) for st_ in steps[-8:])
+    spans_per_step = per_count.most_common(1)[0][0] if per_count else SPANS_PER_STEP
+    steps = [st_ for st_ in steps if len(st_) == spans_per_step]
+    n_steps = len(steps)
     use = steps[-min(8, max(1, n_steps - 4)):]              # the last replays (the first steps of a run are eager)
     per_step, per_span_ms, by_kernel = [], [], collections.defaultdict(float)
     idx = 0
@@ -73,6 +84,7 @@ def main():
                    "last traced replays",
            "command": "rocprofv3 --kernel-trace -- python bench.py --sa-markers --steps 12 --warmup 3 --no-cpu-baseline --no-op-timing",
            "batch": batch, "points": points, "dtype": dtype, "steps": len(use), "spans_found": len(spans),
+           "spans_per_step": spans_per_step,
            "sa_kernel_ms_per_step": per_step[len(per_step) // 2],
            "sa_kernel_ms_min_max": [per_step[0], per_step[-1]],
            "sa_span_ms_per_step": per_span_ms[len(per_span_ms) // 2],
