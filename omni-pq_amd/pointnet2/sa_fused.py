@@ -137,6 +137,7 @@ COLLECTIVES = 0                  # SyncBatchNorm statistics all-reduces issued s
 COLLECTIVES_LAST_STEP = 0        # ... during the last PQ_Transformer forward + backward (set by deferred_wgrads.__exit__)
 _COLLECTIVES_MARK = 0
 _FORCE_COLLECTIVES = False       # test hook: issue the SyncBatchNorm all-reduces even over a 1-rank group
+IPC_STATS = None                 # an ipc_stats.IpcStats: the statistics exchange as peer-to-peer launches instead of RCCL (opt-in)
 
 
 def _allreduce_(sums, world=None):
@@ -147,7 +148,10 @@ def _allreduce_(sums, world=None):
     if world > 1 or (_FORCE_COLLECTIVES and dist.is_initialized()):
         global COLLECTIVES
         COLLECTIVES += 1
-        dist.all_reduce(sums)
+        if IPC_STATS is not None and sums.is_cuda and sums.dtype == torch.float64 and sums.is_contiguous():
+            IPC_STATS.allreduce_(sums)            # one launch, no RCCL (omni-pq_amd/ipc_stats.py; opt-in)
+        else:
+            dist.all_reduce(sums)
     return sums
 
 
