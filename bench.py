@@ -753,6 +753,13 @@ def main():
         sa_fused._FORCE_COLLECTIVES = True
     ext = pointnet2_utils._ext
     assert ext.__name__ == "pointnet2._ext", "the product binding must be the one that runs"
+    args.ipc_stats = None
+    if (world > 1 or force_dist) and os.environ.get("OMNIPQ_IPC_STATS") == "1":
+        # opt-in (round 6): SyncBatchNorm's statistics through peer-to-peer mailboxes instead of RCCL (omni-pq_amd/ipc_stats.py)
+        import ipc_stats
+        import sa_fused
+        args.ipc_stats = ipc_stats.IpcStats(dev)
+        sa_fused.IPC_STATS = args.ipc_stats
     for item in args.set:                       # --set module.ATTR=value (A/B runs)
         import ast
         import importlib
@@ -926,7 +933,11 @@ def main():
         dp_detail = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": seen,
                      "syncbn_collectives_per_step": int(timed_collectives) if not ddp else None,
                      "gradient_collectives_per_step": (int(b_.collectives) if b_ is not None else None),
-                     "inside_graph": bool(use_graph), "rccl_graph_probe": bool(probe_ok)}
+                     "inside_graph": bool(use_graph), "rccl_graph_probe": bool(probe_ok),
+                     "statistics_exchange": ("peer-to-peer mailboxes (ipc_stats.IpcStats, OMNIPQ_IPC_STATS=1)"
+                                             if getattr(args, "ipc_stats", None) is not None else "RCCL all-reduce")}
+        if getattr(args, "ipc_stats", None) is not None:
+            args.ipc_stats.check()
     if rank == 0:
         scenes = world * args.batch * args.steps
         rec = {
