@@ -432,15 +432,20 @@ int omnipq_sa_last_wgrad_combine(int C3, int C2, const float *R, const float *cs
  * (omnipq_ipc_mailbox_create: device memory + a 64-byte hipIpc handle for the peers; omnipq_ipc_mailbox_open maps a peer's),
  * an exchange is ONE launch that stores the rank's vector as tagged 8-byte granules into every mailbox and polls its own
  * until every rank's granules of this exchange have arrived, then adds them in rank order (same bits on every rank).
- * state: device memory, two zeroed 32-bit words {exchange counter, give-up flag}; every rank must issue the same sequence of
- * exchanges.  n <= 4096, world <= 16.  omnipq_ipc_check (synchronises the stream) -> OMNIPQ_ETIMEOUT if an exchange gave up
+ * Every rank must issue the same sequence of exchanges.  n <= 4096, world <= 16.  omnipq_ipc_check (synchronises the stream) -> OMNIPQ_ETIMEOUT if an exchange gave up
  * (~2 s without a peer).  Opt-in (sa_fused.IPC_STATS); see the file's header for what has and has not been exercised. */
-long long omnipq_ipc_mailbox_bytes(int world);
-int omnipq_ipc_mailbox_create(int world, void **ptr_out, unsigned char *handle_out);
+long long omnipq_ipc_site_granules(int world, int n);
+long long omnipq_ipc_mailbox_bytes(int world, long long extra_doubles);
+int omnipq_ipc_mailbox_create(int world, long long extra_doubles, void **ptr_out, unsigned char *handle_out);
 int omnipq_ipc_mailbox_open(const unsigned char *handle, void **ptr_out);
 int omnipq_ipc_mailbox_close(void *ptr, int own);
-int omnipq_ipc_allreduce_f64(double *vec, int n, void *const *boxes, int rank, int world, unsigned *state, void *stream);
-int omnipq_ipc_check(const unsigned *state, void *stream);
+/* counter: one zeroed device word per SITE; gave_up: one zeroed device word per mailbox.  base_granule = slot_doubles = 0: the
+ * eager site (its exchanges on one stream, same order on every rank); else a site of its own -- what a captured exchange
+ * needs, since a graph's streams may run in an order the ranks do not share: base_granule past the eager site
+ * (omnipq_ipc_site_granules(world, 4096)) + the sites before it, room for slot_doubles >= n per sender. */
+int omnipq_ipc_allreduce_f64(double *vec, int n, void *const *boxes, int rank, int world, unsigned *counter,
+                             unsigned *gave_up, long long base_granule, int slot_doubles, void *stream);
+int omnipq_ipc_check(const unsigned *gave_up, void *stream);
 
 /* out[0] += sum_i mean(tensor_i), i < nseg <= 72: the benchmark's stand-in loss in one launch over strided
  * views (<= 4 dims, f32 or e16; no casts, no concatenation).  HOST arrays: ptrs[nseg] device pointers,

@@ -30,13 +30,17 @@ struct IpcPeers {
   unsigned long long *box[kIpcMaxWorld];             // box[p] = rank p's mailbox as mapped in THIS process
 };
 
-__device__ __forceinline__ size_t ipc_slot(int parity, int sender, int world) {
-  return ((size_t)parity * world + sender) * kIpcMaxGranules;
+// A SITE = a region of every mailbox: [2 parities][world senders][slot_granules], starting at granule `base`.  Exchanges of
+// one site are matched by the site's own device counter, so different sites may execute in any relative order (a captured
+// graph runs its streams' nodes in an order the ranks need not share: every captured exchange gets a site of its own; eager
+// exchanges share site 0 and are serialised on one stream by the caller).
+__device__ __forceinline__ size_t ipc_slot(long long base, int slot_granules, int parity, int sender, int world) {
+  return (size_t)base + ((size_t)parity * world + sender) * (size_t)slot_granules;
 }
 
 __global__ __launch_bounds__(256) void ipc_allreduce_kernel(double *__restrict__ vec, int n, IpcPeers peers, int rank, int world,
                                                            unsigned *__restrict__ seq_dev, unsigned *__restrict__ gave_up,
-                                                           long long timeout_ticks) {
+                                                           long long base, int slot_granules, long long timeout_ticks) {
   const int tid = (int)threadIdx.x;
   const unsigned seq = *seq_dev + 1u;                 // tags start at 1: a zero-initialised mailbox carries no valid granule
   const int parity = (int)(seq & 1u);
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void ipc_allreduce_kernel(double *__restrict__
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, vec[i]);
     const unsigned long long g0 = ((bits & 0xFFFFFFFFull) << 32) | seq, g1 = ((bits >> 32) << 32) | seq;
     for (int p = 0; p < world; ++p) {
-      unsigned long long *dst = peers.box[p] + ipc_slot(parity, rank, world) + 2 * i;
+      unsigned long long *dst = peers.box[p] + ipc_slot(base, slot_granules, parity, rank, world) + 2 * i;
       __hip_atomic_store(dst, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(dst + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void ipc_allreduce_kernel(double *__restrict__
   for (int i = tid; i < n; i += 256) {
     double total = 0.0;
     for (int s = 0; s < world && ok; ++s) {
-      const unsigned long long *src = peers.box[rank] + ipc_slot(parity, s, world) + 2 * i;
+      const unsigned long long *src = peers.box[rank] + ipc_slot(base, slot_granules, parity, s, world) + 2 * i;
       unsigned long long g0, g1;
       for (;;) {
         g0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -80,15 +84,21 @@ __global__ __launch_bounds__(256) void ipc_allreduce_kernel(double *__restrict__
 }  // namespace omnipq
 
 // ---- host side: mailboxes ------------------------------------------------------------------------------------------------------
-extern "C" long long omnipq_ipc_mailbox_bytes(int world) {
-  if (world < 1 || world > omnipq::kIpcMaxWorld) return -1;
-  return (long long)2 * world * omnipq::kIpcMaxGranules * 8;
+// bytes of a mailbox that holds site 0 (the eager site: kIpcMaxDoubles per exchange) and `extra_doubles` doubles' worth of
+// further sites (omnipq_ipc_site_granules(n) granules each)
+extern "C" long long omnipq_ipc_site_granules(int world, int n) {
+  if (world < 1 || world > omnipq::kIpcMaxWorld || n < 0) return -1;
+  return (long long)2 * world * 2 * n;
+}
+extern "C" long long omnipq_ipc_mailbox_bytes(int world, long long extra_doubles) {
+  if (world < 1 || world > omnipq::kIpcMaxWorld || extra_doubles < 0) return -1;
+  return ((long long)2 * world * omnipq::kIpcMaxGranules + (long long)2 * world * 2 * extra_doubles) * 8;
 }
 
 // Allocates this rank's mailbox (zeroed; fine-grained if the runtime grants it) and exports it: handle_out = 64 bytes to hand
 // to the peers (torch.distributed.all_gather_object).
-extern "C" int omnipq_ipc_mailbox_create(int world, void **ptr_out, unsigned char *handle_out) {
-  const long long bytes = omnipq_ipc_mailbox_bytes(world);
+extern "C" int omnipq_ipc_mailbox_create(int world, long long extra_doubles, void **ptr_out, unsigned char *handle_out) {
+  const long long bytes = omnipq_ipc_mailbox_bytes(world, extra_doubles);
   if (bytes < 0 || !ptr_out || !handle_out) return OMNIPQ_EINVAL;
   void *p = nullptr;
   if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -133,26 +143,32 @@ extern "C" int omnipq_ipc_mailbox_close(void *ptr, int own) {
 // rank p's mailbox as mapped here, box[rank] = this rank's own); state: device memory, two 32-bit words {exchange counter,
 // give-up flag}, zero at start (the SAME counter value on every rank at every call: ranks issue the same sequence of
 // exchanges).  n <= 4096.  Capturable: nothing but the launch.
-extern "C" int omnipq_ipc_allreduce_f64(double *vec, int n, void *const *boxes, int rank, int world, unsigned *state,
-                                         void *stream) {
+// Site: base_granule = 0 and slot_doubles = 0 -> the eager site (every exchange of it must run on one stream, in the same
+// order on every rank); else a site of its own at granule base_granule (>= omnipq_ipc_site_granules(world, 4096), multiple of
+// 2) with room for slot_doubles >= n doubles per sender, and counter = ITS OWN zeroed device word.
+extern "C" int omnipq_ipc_allreduce_f64(double *vec, int n, void *const *boxes, int rank, int world, unsigned *counter,
+                                         unsigned *gave_up, long long base_granule, int slot_doubles, void *stream) {
   using namespace omnipq;
-  if (!vec || !boxes || !state || n < 0 || n > kIpcMaxDoubles || world < 1 || world > kIpcMaxWorld || rank < 0 || rank >= world)
+  unsigned *state = counter;
+  if (!vec || !boxes || !counter || !gave_up || n < 0 || n > kIpcMaxDoubles || world < 1 || world > kIpcMaxWorld || rank < 0 ||
+      rank >= world || base_granule < 0 || slot_doubles < 0 || (slot_doubles > 0 && slot_doubles < n))
     return OMNIPQ_EINVAL;
   if (n == 0) return OMNIPQ_OK;
   IpcPeers peers;
   for (int p = 0; p < kIpcMaxWorld; ++p) peers.box[p] = p < world ? (unsigned long long *)boxes[p] : nullptr;
   for (int p = 0; p < world; ++p)
     if (!peers.box[p]) return OMNIPQ_EINVAL;
-  ipc_allreduce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(vec, n, peers, rank, world, state, state + 1,
+  ipc_allreduce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(vec, n, peers, rank, world, state, gave_up, base_granule,
+                                                           slot_doubles > 0 ? 2 * slot_doubles : kIpcMaxGranules,
                                                            200000000ll /* 2 s of the 100 MHz counter */);
   OMNIPQ_LAUNCH_CHECK();
   return OMNIPQ_OK;
 }
 
 // After a synchronisation: did an exchange give up?
-extern "C" int omnipq_ipc_check(const unsigned *state, void *stream) {
+extern "C" int omnipq_ipc_check(const unsigned *gave_up, void *stream) {
   unsigned flag = 0;
-  OMNIPQ_HIP(hipMemcpyAsync(&flag, state + 1, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  OMNIPQ_HIP(hipMemcpyAsync(&flag, gave_up, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   OMNIPQ_HIP(hipStreamSynchronize((hipStream_t)stream));
   return flag ? OMNIPQ_ETIMEOUT : OMNIPQ_OK;
 }

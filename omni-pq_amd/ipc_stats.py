@@ -22,12 +22,15 @@ import pointnet2_utils
 _ext = pointnet2_utils._ext
 _lib0 = _ext._lib0
 _lib0.omnipq_ipc_mailbox_bytes.restype = ctypes.c_longlong
+_lib0.omnipq_ipc_site_granules.restype = ctypes.c_longlong
 
 
 class IpcStats:
     MAX_DOUBLES = 4096
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, capture_doubles=1 << 19):
+        """capture_doubles: room (doubles per sender and parity, summed over the exchanges) for exchanges issued INSIDE graph
+        captures -- each of them gets a region and a counter of its own (see allreduce_)."""
         if not dist.is_initialized():
             raise RuntimeError("IpcStats needs an initialised process group (the handles travel over it)")
         self.device = torch.device(device)
@@ -38,7 +41,7 @@ class IpcStats:
         own = ctypes.c_void_p()
         handle = (ctypes.c_ubyte * 64)()
         with torch.cuda.device(self.device):
-            rc = _lib0.omnipq_ipc_mailbox_create(self.world, ctypes.byref(own), handle)
+            rc = _lib0.omnipq_ipc_mailbox_create(self.world, ctypes.c_longlong(capture_doubles), ctypes.byref(own), handle)
         if rc:
             raise RuntimeError(f"omnipq_ipc_mailbox_create: {_lib0.omnipq_error_string(rc).decode()}")
         self._own = own
@@ -58,7 +61,11 @@ class IpcStats:
                 raise RuntimeError(f"omnipq_ipc_mailbox_open (rank {p}): {_lib0.omnipq_error_string(rc).decode()}")
             self._boxes[p] = ptr.value
             self._opened.append(ptr)
-        self.state = torch.zeros(2, device=self.device, dtype=torch.int32)
+        self.state = torch.zeros(2, device=self.device, dtype=torch.int32)          # {the eager site's counter, give-up flag}
+        self._site_counters = torch.zeros(4096, device=self.device, dtype=torch.int32)
+        self._sites = 0
+        self._site_base = int(_lib0.omnipq_ipc_site_granules(self.world, self.MAX_DOUBLES))
+        self._site_end = self._site_base + 2 * self.world * 2 * int(capture_doubles)
         # Exchanges are matched by a counter that lives on the device, so every rank must EXECUTE them in the same order.  The
         # model issues statistics exchanges from several streams (main, key sides, heads); like a process group's internal
         # stream, one exchange stream serialises them in host issue order -- which is the same on every rank.
@@ -72,26 +79,46 @@ class IpcStats:
             raise ValueError("IpcStats.allreduce_: a contiguous float64 tensor on the mailbox's device")
         flat = vec.view(-1)
         cur = torch.cuda.current_stream(self.device)
+        gave_up = ctypes.c_void_p(self.state.data_ptr() + 4)
+        if torch.cuda.is_current_stream_capturing():
+            # Inside a capture: a graph runs the nodes of its streams in an order the ranks need not share, so every captured
+            # exchange gets a SITE of its own (a region of the mailboxes + a device counter, fixed in the node's arguments: the
+            # replays reuse them) and is launched on the capturing stream itself -- no fork, no join (hipStreamEndCapture dies
+            # beyond ~60 forks).  The capture order is the host's issue order: the same on every rank.
+            stream = ctypes.c_void_p(cur.cuda_stream)
+            for off in range(0, flat.numel(), self.MAX_DOUBLES):
+                n = min(self.MAX_DOUBLES, flat.numel() - off)
+                need = 2 * self.world * 2 * n
+                if self._sites >= self._site_counters.numel() or self._site_base + need > self._site_end:
+                    raise RuntimeError("IpcStats: out of room for captured exchanges (capture_doubles)")
+                rc = _lib0.omnipq_ipc_allreduce_f64(ctypes.c_void_p(flat.data_ptr() + 8 * off), n, self._boxes, self.rank,
+                                                    self.world, ctypes.c_void_p(self._site_counters.data_ptr() + 4 * self._sites),
+                                                    gave_up, ctypes.c_longlong(self._site_base), n, stream)
+                if rc:
+                    raise RuntimeError(f"omnipq_ipc_allreduce_f64: {_lib0.omnipq_error_string(rc).decode()}")
+                self._sites += 1
+                self._site_base += need
+                self.exchanges += 1
+            return vec
         xs = self._xstream
         xs.wait_stream(cur)
         stream = ctypes.c_void_p(xs.cuda_stream)
         for off in range(0, flat.numel(), self.MAX_DOUBLES):
             n = min(self.MAX_DOUBLES, flat.numel() - off)
             rc = _lib0.omnipq_ipc_allreduce_f64(ctypes.c_void_p(flat.data_ptr() + 8 * off), n, self._boxes, self.rank, self.world,
-                                                ctypes.c_void_p(self.state.data_ptr()), stream)
+                                                ctypes.c_void_p(self.state.data_ptr()), gave_up, ctypes.c_longlong(0), 0, stream)
             if rc:
                 raise RuntimeError(f"omnipq_ipc_allreduce_f64: {_lib0.omnipq_error_string(rc).decode()}")
             self.exchanges += 1
         cur.wait_stream(xs)
-        if not torch.cuda.is_current_stream_capturing():
-            vec.record_stream(xs)
+        vec.record_stream(xs)
         return vec
 
     def check(self):
         """Synchronises the current stream; raises if an exchange gave up waiting for a peer."""
         torch.cuda.current_stream(self.device).wait_stream(self._xstream)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = _lib0.omnipq_ipc_check(ctypes.c_void_p(self.state.data_ptr()), stream)
+        rc = _lib0.omnipq_ipc_check(ctypes.c_void_p(self.state.data_ptr() + 4), stream)
         if rc:
             raise RuntimeError(f"IpcStats: {_lib0.omnipq_error_string(rc).decode()} (an exchange waited ~2 s for a peer)")
 
