@@ -510,6 +510,9 @@ def hoist_ok(training, features, cin, cin_raw, L, c1, xgen):
 # C2-sized matrices.  Neither dY3 nor Y3 exists: the forward's last GEMM stores statistics and ball extrema only.
 # LAST_NO_DY = False restores the stored Y3 / dY3 (tests compare the two).
 LAST_NO_DY = True
+LAST_NO_DY_MAX_C3 = 256         # ... for last layers up to this width: sa1 (128 -> 256) gains ~20 us per step, sa2 (256 -> 512: 12 + 16
+                                # K-steps in the data-gradient GEMM, six 128 x 128 tiles per slab in the weight gradient) LOSES
+                                # 30-90 us (per-stage split of the bench line: sa2 0.69 -> 0.78 ms with it); 1 << 30 = every planned stage
 LAST_X2 = True                  # ... and its weight gradient contracts X2 as the data-gradient launch left it (no affine per fragment)
 last_no_dy_uses = 0
 _lib.omnipq_gemm_tn_dz_workspace_floats.restype = ctypes.c_longlong
@@ -517,7 +520,7 @@ _lib.omnipq_gemm_tn_dz_workspace_floats.restype = ctypes.c_longlong
 
 def last_no_dy_ok(plan, L, c2, c3, S, below_keeps_y_only):
     """a plan with its unit map, the layer below consumed as (Y, a, b), whole 128-column tiles on both sides"""
-    return LAST_NO_DY and plan is not None and getattr(plan, "unit_src", None) is not None and L >= 2 and \
+    return LAST_NO_DY and c3 <= LAST_NO_DY_MAX_C3 and plan is not None and getattr(plan, "unit_src", None) is not None and L >= 2 and \
         below_keeps_y_only and c2 % 128 == 0 and c3 % 128 == 0 and c2 + 32 <= 1024 and S >= 8 and (S & (S - 1)) == 0 and \
         AFFINE_OPERANDS and POOL_EPILOGUE and _FOLD_SMALL
 
