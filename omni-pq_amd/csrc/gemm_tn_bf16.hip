@@ -787,229 +787,6 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_dz_kernel(TnArgs g, const e16_
     }
 }
 
-// ---- the same product for N = 128 columns, ALL M-tiles of a slab in one workgroup ("tall") -------------------------------------
-// gemm_tn_dz_kernel runs a slab's M-tiles (sa1: two hit tiles + the Gram tile) as separate workgroups: each stages the X2 block
-// again, reads its B fragments again, and runs at ~1.4 us per 32-row step whatever it fetches.  Here ONE workgroup of four
-// waves owns the slab: 128 x 128 column block of X2 staged once per step (it is the B operand of every tile AND the A
-// operand of the Gram tile), the hot words of HT hit tiles next to it, (HT + 1) x 2 x 2 accumulator blocks per wave (192 VGPRs
-// at HT = 2: two workgroups per CU), a FOUR-deep ring (13.5 KB per step: three steps in flight), operands plain (X2 as the
-// data-gradient launch left it).  Per step and wave: one aux instruction (the four units' positions + the 32 row weights), two
-// of the X2 block, 2 HT of hot words = 7 at HT = 2 -- the counted wait leaves the two youngest groups in flight.
-constexpr int TT_NBUF = 4;
-constexpr int TT_LEAD = 2 * (TT_NBUF - 1);        // steps an aux word travels ahead: it must have LANDED when the fetch it addresses
-                                                   // is issued, i.e. be older than every group the counted wait leaves in flight
-template <int HT>
-__global__ __launch_bounds__(256, 2) void gemm_tn_dz_tall_kernel(TnArgs g, const e16_t *__restrict__ B, float *__restrict__ part,
-                                                                float *__restrict__ colsum, TnDz dz) {
-  constexpr int SLOT_E16 = TBK * 128 + HT * 4 * TDZ_HPITCH * 2;            // X2 block + hot words (in e16 units)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[TT_NBUF * SLOT_E16 * 2];
-  __shared__ __attribute__((aligned(16))) unsigned aux[8][12];             // [step & 7]: 4 unit_src words | 8 words of row weights
-  e16_t *const stage = reinterpret_cast<e16_t *>(smem);
-  constexpr int GRP = 3 + 2 * HT;                  // DMA instructions per wave and step
-  const int slab = (int)blockIdx.x;
-  if ((long long)slab * g.p_chunk >= g.P && slab > 0) return;
-  const int Peff = g.rows_dev ? *g.rows_dev : g.P;
-  int chunk = g.p_chunk;
-  if (g.rows_dev) {
-    const int nslab = (g.P + g.p_chunk - 1) / g.p_chunk;
-    chunk = ((Peff + nslab - 1) / nslab + TBK - 1) / TBK * TBK;
-    if (chunk < TBK) chunk = TBK;
-  }
-  const int pbeg = slab * chunk;
-  int pend = pbeg + chunk;
-  if (pend > Peff) pend = Peff;
-  const int nk = pend > pbeg ? (pend - pbeg + TBK - 1) / TBK : 0;
-  const int tid = (int)threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, lhalf = lane >> 5;
-  const int plast = Peff > 0 ? Peff - 1 : 0, units_in_use = Peff >> 3;
-
-  int fcol[2], frow[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    frow[j] = 8 * wave + 4 * j + (lane >> 4);
-    fcol[j] = ((lane & 15) ^ (4 * (frow[j] & 3))) * 8;
-  }
-  auto fetch_aux = [&](int kt_) {
-    const int kt = kt_ < nk ? kt_ : (nk > 0 ? nk - 1 : 0);
-    unsigned *dst = aux[kt_ & 7];
-    if (lane < 12) {
-      const void *src;
-      if (lane < 4) {
-        int u = ((pbeg + kt * TBK) >> 3) + lane;
-        u = u < units_in_use ? u : (units_in_use > 0 ? units_in_use - 1 : 0);
-        src = dz.unit_src + u;
-      } else {
-        src = dz.row_w + (size_t)(pbeg + kt * TBK) + 4 * (lane - 4);       // (+ 32 <= P; rows past Peff are masked by `live`)
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-    }
-  };
-  auto fetch = [&](int kt, int buf) {
-    e16_t *const sb = stage + buf * SLOT_E16;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int p = pbeg + kt * TBK + frow[j];
-      p = p < pend ? p : plast;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (size_t)p * g.ldb + fcol[j]),
-                                       (__attribute__((address_space(3))) void *)(sb + (8 * wave + 4 * j) * 128), 16, 0, 0);
-    }
-    const int us = (int)aux[kt & 7][wave];
-    const size_t ball = (size_t)((us * 8) >> dz.s_shift);
-    const unsigned *src = dz.hot + ball * dz.C3 + lane;
-    unsigned *dst = reinterpret_cast<unsigned *>(sb + TBK * 128) + wave * TDZ_HPITCH;
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + t * 128 + 64 * h),
-                                         (__attribute__((address_space(3))) void *)(dst + t * 4 * TDZ_HPITCH + 64 * h), 4, 0, 0);
-  };
-
-  f32x16 acc[HT + 1][2][2];
-#pragma unroll
-  for (int t = 0; t <= HT; ++t)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
-
-  const int grp = lane >> 4, l16 = lane & 15;
-  const int tr_row = 8 * (grp >> 1) + (l16 >> 2);
-  int offA[2], offB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ca = wm * 64 + i * 32 + 16 * (grp & 1) + (l16 & 3) * 4, cb = wn * 64 + i * 32 + 16 * (grp & 1) + (l16 & 3) * 4;
-    offA[i] = tr_row * 128 + (((ca >> 3) ^ (4 * (tr_row & 3))) << 3) + (ca & 7);
-    offB[i] = tr_row * 128 + (((cb >> 3) ^ (4 * (tr_row & 3))) << 3) + (cb & 7);
-  }
-  const bool do_colsum = colsum != nullptr && wn == 0;
-  float csum[2] = {0.f, 0.f};
-  const unsigned smask = (1u << dz.s_shift) - 1u;
-  const int hoff = lhalf * TDZ_HPITCH + wm * 64 + (lane & 31);
-
-  // prologue: the aux words the first fetches are addressed by, then NBUF - 1 groups of {aux, blocks}
-  if (nk > 0) {
-    for (int i = 0; i < TT_LEAD - (TT_NBUF - 1); ++i) fetch_aux(i);
-    tn_wait_vm<0>();
-    for (int s_ = 0; s_ < TT_NBUF - 1; ++s_) {
-      fetch_aux(TT_LEAD - (TT_NBUF - 1) + s_);
-      if (s_ < nk) fetch(s_, s_);
-      else {                                     // (keep the groups' length: the counted wait relies on it)
-#pragma unroll
-        for (int z = 0; z < GRP - 1; ++z) fetch_aux(TT_LEAD);
-      }
-    }
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    // what this step consumes has landed once the groups of steps kt + 1 and kt + 2 are all that is in flight
-    tn_wait_vm<2 * GRP>();
-    __builtin_amdgcn_s_barrier();
-    fetch_aux(kt + TT_LEAD);
-    if (kt + TT_NBUF - 1 < nk) fetch(kt + TT_NBUF - 1, (kt + TT_NBUF - 1) % TT_NBUF);
-    else {
-#pragma unroll
-      for (int z = 0; z < GRP - 1; ++z) fetch_aux(kt + TT_LEAD);
-    }
-    const e16_t *sb = stage + (kt % TT_NBUF) * SLOT_E16;
-    const unsigned *sh = reinterpret_cast<const unsigned *>(sb + TBK * 128);
-    const unsigned *ax = aux[kt & 7];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int first = pbeg + kt * TBK + 16 * kk + 8 * lhalf;
-      const bool live = first < pend;
-      e16x8 fb[2], fg[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const e16_t *pb = sb + kk * 16 * 128 + offB[i];
-        const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pb);
-        const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pb + 4 * 128));
-        fb[i] = __builtin_bit_cast(e16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-      // the Gram tile's A fragments: the same block at this wave's ROW half of the columns, times the rows' weights
-      {
-        unsigned lo = ax[4 + 4 * kk + 2 * lhalf], hi = ax[4 + 4 * kk + 2 * lhalf + 1];
-        lo = live ? lo : 0u;
-        hi = live ? hi : 0u;
-        const bool ones = lo == 0x01010101u && hi == 0x01010101u;
-        const float w0 = (float)(lo & 0xFFu), w1 = (float)((lo >> 8) & 0xFFu), w2 = (float)((lo >> 16) & 0xFFu),
-                    w3 = (float)(lo >> 24), w4 = (float)(hi & 0xFFu), w5 = (float)((hi >> 8) & 0xFFu),
-                    w6 = (float)((hi >> 16) & 0xFFu), w7 = (float)(hi >> 24);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const e16_t *pa = sb + kk * 16 * 128 + offA[i];
-          const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)pa);
-          const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(pa + 4 * 128));
-          uint4 w = __builtin_bit_cast(uint4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-          if (!ones) {
-            w.x = tn_affine_relu_pair_w(w.x, 1.f, 0.f, w0, w1);
-            w.y = tn_affine_relu_pair_w(w.y, 1.f, 0.f, w2, w3);
-            w.z = tn_affine_relu_pair_w(w.z, 1.f, 0.f, w4, w5);
-            w.w = tn_affine_relu_pair_w(w.w, 1.f, 0.f, w6, w7);
-          }
-          fg[i] = __builtin_bit_cast(e16x8, w);
-          if (do_colsum)
-            csum[i] += ((e16_lo(w.x) + e16_hi(w.x)) + (e16_lo(w.y) + e16_hi(w.y))) +
-                       ((e16_lo(w.z) + e16_hi(w.z)) + (e16_lo(w.w) + e16_hi(w.w)));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[HT][i][j] = mfma_e16_32x32x16(fg[i], fb[j], acc[HT][i][j]);
-      // the hit tiles: one hot word per (unit, column) decides the fragment
-      const unsigned t0 = (ax[2 * kk + lhalf] * 8u) & smask;
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        e16x8 fa[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const unsigned word = sh[t * 4 * TDZ_HPITCH + hoff + 2 * kk * TDZ_HPITCH + 32 * i];
-          const unsigned d = (word & 0xFFu) - t0;
-          const bool in = live && d < 8u;
-          const unsigned v = (word >> 16) << ((d & 1u) * 16u);
-          const unsigned q = d >> 1;
-          const uint4 w = make_uint4((in && q == 0u) ? v : 0u, (in && q == 1u) ? v : 0u, (in && q == 2u) ? v : 0u,
-                                     (in && q == 3u) ? v : 0u);
-          fa[i] = __builtin_bit_cast(e16x8, w);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[t][i][j] = mfma_e16_32x32x16(fa[i], fb[j], acc[t][i][j]);
-      }
-    }
-  }
-  tn_wait_vm<0>();                                  // (the tail's filler instructions)
-  const int M = g.M;
-  if (do_colsum) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float t = csum[i] + __shfl_xor(csum[i], 32, 64);
-      const int ch = HT * 128 + wm * 64 + i * 32 + lane;
-      if (lane < 32) colsum[(size_t)slab * M + ch] = t;
-    }
-  }
-  float *C = part + (size_t)slab * M * g.N;
-  const int ccl = lane & 31, crow0 = 4 * (lane >> 5);
-#pragma unroll
-  for (int t = 0; t <= HT; ++t)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int gc = wn * 64 + j * 32 + ccl;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gr = t * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
-          C[(size_t)gr * g.N + gc] = acc[t][i][j][r];
-        }
-      }
-}
-
 // REG: the register-prefetch program (tools/bench_tn_grouped.py compares the two; omnipq_tn_debug(1) selects it)
 template <bool REG>
 __global__ __launch_bounds__(256, REG ? 4 : 3) void gemm_tn_kernel(TnArgs g, const e16_t *__restrict__ A,
@@ -1279,8 +1056,6 @@ static int gemm_tn_impl(int M, int N, int P, const void *A, int lda, const void 
 // valid), *slabs_out = the slabs in use.  workspace: omnipq_gemm_tn_dz_workspace_floats(C3, N, P) floats; R and cs_part point
 // into it (R = workspace, cs_part behind the slabs).  A plan is REQUIRED.
 // (three workgroups per CU and nothing else on the chip: ~768 workgroups, at least 16 K-steps each)
-static int g_tn_tall_div = 3;                       // 768 / this = slabs of the tall program (3: one workgroup per CU; 2: 384, 1: 768)
-static int tn_dz_tall_div() { return ((g_tn_debug >> 16) & 0xF) ? ((g_tn_debug >> 16) & 0xF) : g_tn_tall_div; }
 static int tn_dz_slabs(int tiles, int P) {
   long long slabs = (768 + tiles - 1) / tiles;
   const long long max_slabs = (P + 32LL * 16 - 1) / (32LL * 16);
@@ -1291,11 +1066,7 @@ static int tn_dz_slabs(int tiles, int P) {
 extern "C" long long omnipq_gemm_tn_dz_workspace_floats(int C3, int N, int P) {
   const long long M = (long long)C3 + N;
   const int tiles = (int)(M / 128) * ((N + 127) / 128);
-  long long slabs = tn_dz_slabs(tiles, P);
-  if (N == 128 && C3 <= 256) {                       // (the tall program's slab count, if it is larger)
-    const long long st = tn_dz_slabs(tn_dz_tall_div(), P);
-    slabs = st > slabs ? st : slabs;
-  }
+  const long long slabs = tn_dz_slabs(tiles, P);
   // [R: M N] [mid: kReduceGroups M N] [slabs: slabs M N] [cs: slabs M]
   return M * N * (1 + omnipq::kReduceGroups + slabs) + slabs * M;
 }
@@ -1313,9 +1084,7 @@ extern "C" int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, 
   const int M = C3 + N;
   TnArgs g{M, N, P, ldb, ldb, 0, M / 128, N / 128};
   g.rows_dev = rp.rows_dev;
-  // plain operands, one column tile, at most two hit tiles: the tall program (all M-tiles of a slab in one workgroup)
-  const bool tall = !ba && N == 128 && C3 <= 256 && !(g_tn_debug & 32);
-  const int tiles = tall ? tn_dz_tall_div() : g.m_tiles * g.n_tiles;
+  const int tiles = g.m_tiles * g.n_tiles;
   const int slabs = tn_dz_slabs(tiles, P);
   g.p_chunk = (((P + slabs - 1) / slabs) + TBK - 1) / TBK * TBK;
   const int used = (P + g.p_chunk - 1) / g.p_chunk;
@@ -1329,15 +1098,8 @@ extern "C" int omnipq_gemm_tn_dz(int C3, int N, int P, const void *Y2, int ldb, 
   float *cs = part + mn * (size_t)slabs;
   TnDz dz{hot, unit_src, rp.row_w, C3, sh};
   // (every slab in use writes its partial column-sum row, also one that holds no rows in use: zeros)
-  if (tall) {
-    if (C3 == 256)
-      gemm_tn_dz_tall_kernel<2><<<dim3(used), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)Y2, part, cs, dz);
-    else
-      gemm_tn_dz_tall_kernel<1><<<dim3(used), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)Y2, part, cs, dz);
-  } else {
-    gemm_tn_dz_kernel<<<dim3(tiles * ((used + 7) / 8) * 8), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)Y2, part, cs, ba,
-                                                                                         bb, dz);
-  }
+  gemm_tn_dz_kernel<<<dim3(tiles * ((used + 7) / 8) * 8), 256, 0, (hipStream_t)stream>>>(g, (const e16_t *)Y2, part, cs, ba, bb,
+                                                                                       dz);
   OMNIPQ_LAUNCH_CHECK();
   const int n4 = (int)(mn / 4);
   const f32x4 *part4 = reinterpret_cast<const f32x4 *>(part);
