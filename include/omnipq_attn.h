@@ -37,6 +37,10 @@ int omnipq_attn_bwd(int N, int H, int L, int S, int D, const void *q, const void
 int omnipq_attn_dropout_mask(int N, int H, int L, int S, float dropout_p, const unsigned long long *seed_ptr,
                              unsigned salt, unsigned char *mask, void *stream);
 
+/* timing aid: 0 = workgroups read (blockIdx.x, blockIdx.y) plainly, 1 (default) = the workgroups of one (batch, head) are
+   placed on one XCD (csrc/attention.hip att_block).  Results do not depend on it. */
+void omnipq_attn_block_map(int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ struct AttnArgs {
   float keep_inv;                   // 1 / (1 - p)
   unsigned drop_thresh;             // keep iff hash >= thresh; 0 = no dropout
   unsigned salt;
+  int xcd_map;                      // att_block: 1 = the workgroups of a (batch, head) on one XCD, 0 = plain grid reading
   const unsigned long long *seed_ptr;
 };
 
@@ -193,6 +194,22 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// ---- workgroup -> (block along the tiled axis, batch*head) ---------------------------------------------------------------
+// Workgroups are handed to the eight XCDs round-robin in launch order (x fastest), and every XCD has an L2 of its own: with
+// the plain (blockIdx.x, blockIdx.y) reading, the gx workgroups that stream the SAME (batch, head) slice of K / V (of Q / dO in
+// dK/dV) sit on gx different XCDs and each L2 fetches the slice for itself.  This mapping keeps the workgroups of one
+// (batch, head) on one XCD (g_y % 8 == 0; otherwise the plain reading): id = x + gx * y, xcd = id % 8, slot = id / 8 ->
+// nh = xcd + 8 * (slot / gx), block = slot % gx.  A bijection of the same grid.
+__device__ __forceinline__ void att_block(const AttnArgs &g, int &blk, int &nh) {
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+  blk = (int)blockIdx.x, nh = (int)blockIdx.y;
+  if (g.xcd_map && (gy & 7) == 0) {
+    const int id = blk + gx * nh, slot = id >> 3;
+    nh = (id & 7) + 8 * (slot / gx);
+    blk = slot % gx;
+  }
+}
+
 #define MFMA(a, b, c) mfma_e16_32x32x16(a, b, c)
 
 // ---- forward ------------------------------------------------------------------------------------------
@@ -202,8 +219,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs g, const e16_t *
                                                       e16_t *__restrict__ O, float *__restrict__ lse2) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4 + 4 * 32 * 4 * 2];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
-  const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
-  const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
+  int blk, nh;
+  att_block(g, blk, nh);
+  const int n = nh / g.H, hd = nh - n * g.H;
+  const int q0 = blk * 32, q = q0 + ql;
   const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
   e16_t *ks = reinterpret_cast<e16_t *>(smem) + wave * 2 * ATT_AREA, *vs = ks + ATT_AREA;     // this wave's staged K / V block
   stage_clear(ks, 2, lane);
@@ -347,8 +366,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs g, const e16_
                                                          e16_t *__restrict__ dQ, long long dq_sl, long long dq_sn) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 33 * 4];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, ql = lane & 31;
-  const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
-  const int q0 = (int)blockIdx.x * 32, q = q0 + ql;
+  int blk, nh;
+  att_block(g, blk, nh);
+  const int n = nh / g.H, hd = nh - n * g.H;
+  const int q0 = blk * 32, q = q0 + ql;
   const bool qv = q < g.L;
   const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
   const e16_t *Ob = O + n * g.o_sn + hd * g.D, *dOb = dO + n * g.o_sn + hd * g.D;
@@ -457,8 +478,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs g, const e1
   __shared__ __attribute__((aligned(16))) e16_t qs[2 * ATT_AREA];       // the staged Q block, then the dO block
   __shared__ float rowv[64];                                               // [0,32) lse2, [32,64) delta
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, kl = lane & 31;
-  const int nh = (int)blockIdx.y, n = nh / g.H, hd = nh - n * g.H;
-  const int kb0 = (int)blockIdx.x * 128, k0 = kb0 + wave * 32, key = k0 + kl;
+  int blk, nh;
+  att_block(g, blk, nh);
+  const int n = nh / g.H, hd = nh - n * g.H;
+  const int kb0 = blk * 128, k0 = kb0 + wave * 32, key = k0 + kl;
   const bool kv = key < g.S;
   const e16_t *Qb = Q + n * g.q_sn + hd * g.D, *Kb = K + n * g.k_sn + hd * g.D, *Vb = V + n * g.v_sn + hd * g.D;
   const e16_t *dOb = dO + n * g.o_sn + hd * g.D;
@@ -590,6 +613,8 @@ __global__ void attn_mask_kernel(AttnArgs g, unsigned char *__restrict__ mask) {
     mask[i] = !g.drop_thresh || drop_hash((unsigned)i, seed) >= g.drop_thresh;
 }
 
+static int g_attn_xcd_map = 1;     // omnipq_attn_block_map
+
 static int fill_args(AttnArgs &g, int N, int H, int L, int S, int D, const long long *strides, float dropout_p,
                      const unsigned long long *seed_ptr, unsigned salt) {
   if (N <= 0 || H <= 0 || L <= 0 || S <= 0 || D <= 0 || (D % 4) || D > ATT_DMAX) return OMNIPQ_EINVAL;
@@ -614,11 +639,15 @@ static int fill_args(AttnArgs &g, int N, int H, int L, int S, int D, const long 
   double th = (double)dropout_p * 4294967296.0;
   g.drop_thresh = dropout_p > 0.f ? (unsigned)(th < 1.0 ? 1.0 : (th > 4294967295.0 ? 4294967295.0 : th)) : 0u;
   g.salt = salt;
+  g.xcd_map = g_attn_xcd_map;
   g.seed_ptr = seed_ptr;
   return OMNIPQ_OK;
 }
 
 }  // namespace omnipq
+
+// Timing aid: 0 = read (blockIdx.x, blockIdx.y) plainly, 1 (default) = att_block's XCD-aware mapping.  Same results either way.
+extern "C" void omnipq_attn_block_map(int mode) { omnipq::g_attn_xcd_map = mode ? 1 : 0; }
 
 extern "C" int omnipq_attn_fwd(int N, int H, int L, int S, int D, const void *q, const void *k, const void *v,
                                void *o, const long long *strides, float *lse2, float dropout_p,

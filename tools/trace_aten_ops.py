@@ -3,7 +3,8 @@
 logs every op with the innermost repo frame; used to hunt stray casts / copies / zero-fills.  Run on a GPU box."""
 import sys, os, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv=["bench.py","--graph","off","--no-op-timing","--no-cpu-baseline"]
+CAPTURE=bool(os.environ.get("TRACE_CAPTURE"))     # log the ops recorded INTO the captured step instead of an eager step's
+sys.argv=["bench.py","--graph","on" if CAPTURE else "off","--no-op-timing","--no-cpu-baseline"]
 import bench, torch
 from torch.utils._python_dispatch import TorchDispatchMode
 args=bench.parse()
@@ -11,9 +12,6 @@ dev=torch.device("cuda",0)
 import pointnet2_utils, synth
 net=bench.build_model(0).to(dev); net.train()
 pool=[synth.make_clouds(100+i,args.batch,args.points,kind="room").to(dev) for i in range(3)]
-step,_=bench.make_step(net,net,pool,args,torch.bfloat16,1)
-for i in range(3): step(i)
-torch.cuda.synchronize()
 agg=collections.defaultdict(lambda:[0,0])
 shapes=collections.Counter()
 seq=[]
@@ -21,6 +19,7 @@ WATCH=("copy_","_to_copy","clone","cat","fill_","zeros","add","div","mul","zero_
 class M(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out=func(*args, **(kwargs or {}))
+        if CAPTURE and not torch.cuda.is_current_stream_capturing(): return out
         name=func.__name__ if hasattr(func,"__name__") else str(func)
         base=str(func).split(".")[1] if "." in str(func) else str(func)
         if torch.is_tensor(out) and out.is_cuda and base not in ("view","_unsafe_view","transpose","t","slice","select","unsqueeze","squeeze","expand","as_strided","detach","alias","permute","reshape","empty","empty_like","empty_strided","split","split_with_sizes","unbind","narrow","_reshape_alias","view_as","lift_fresh","chunk","record_stream","is_same_size","contiguous"):
@@ -43,8 +42,15 @@ class M(TorchDispatchMode):
                 # gradient accumulation runs between nodes: the node named is the one whose backward produced the addend
                 shapes[(base,tuple(out.shape),str(out.dtype).replace("torch.","")+" after "+(node.name() if node is not None else "-"))]+=1
         return out
-with M():
-    step(0)
+if CAPTURE:
+    with M():
+        step,_=bench.make_step(net,net,pool,args,torch.bfloat16,1)
+else:
+    step,_=bench.make_step(net,net,pool,args,torch.bfloat16,1)
+    for i in range(3): step(i)
+    torch.cuda.synchronize()
+    with M():
+        step(0)
 torch.cuda.synchronize()
 print("ops watched:", sum(v[0] for v in agg.values()))
 byfile=collections.defaultdict(int)
