@@ -80,6 +80,27 @@ def test_attention_forward_backward_matches_f32(L, S, N, H, D):
         assert rel_l2(a, b) < 2e-2, rel_l2(a, b)
 
 
+@pytest.mark.parametrize("L,S,N,H,D", [(256, 1024, 8, 8, 36), (256, 256, 8, 8, 36), (70, 45, 2, 4, 36)])
+def test_xcd_aware_workgroup_placement_is_a_relabelling_of_the_grid(L, S, N, H, D):
+    """csrc/attention.hip att_block: the workgroups of one (batch, head) are placed on one XCD (a bijection of the grid when
+    batch * heads is a multiple of 8, the plain reading otherwise).  Which workgroup computes a tile must not show in a
+    single bit of the output or of the three gradients."""
+    from utils import fused_attention
+    from sa_fused import _lib
+    _, q, k, v = make_qkv(L, S, N, H, D, 3)
+    g = torch.randn((L, N, H * D), generator=torch.Generator().manual_seed(9)).to(torch.bfloat16).to(dev())
+    got = {}
+    try:
+        for mode in (0, 1):
+            _lib.omnipq_attn_block_map(mode)
+            out = fused_attention.attention(q, k, v, H, 0.0)
+            got[mode] = (out.detach().clone(),) + tuple(t.clone() for t in torch.autograd.grad(out, [q, k, v], g))
+    finally:
+        _lib.omnipq_attn_block_map(1)
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+
+
 def test_attention_dropout_mask_is_consistent_forward_and_backward():
     """With dropout the kernels must use ONE mask in forward and backward: recover it through the test
     entry point and compare against the f32 restatement that applies the same mask."""

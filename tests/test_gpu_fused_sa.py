@@ -376,6 +376,41 @@ def test_sa_weight_gradients_deferred_into_one_grouped_launch_equal_the_immediat
         assert rel_l2(grads["deferred"][k], g) < 2e-5, (k, rel_l2(grads["deferred"][k], g))
 
 
+def test_sa_weight_gradients_started_per_stage_on_a_side_stream_equal_the_grouped_ones(monkeypatch):
+    """sa_fused.SA_WGRAD_SIDE (off by default: measured slower): every stage's collected weight gradients
+    are launched when ITS backward pass ends, on a stream of their own, instead of with all stages' when the block ends.
+    Same problems, launched earlier and elsewhere: the same gradients (another cut of the position axis into slabs ->
+    f32 summation order), nothing left for the end of the block, the stream joined before `.grad` is touched."""
+    import pointnet2_modules
+    import sa_fused
+    monkeypatch.setenv("OMNIPQ_SA", "fused")
+    grads = {}
+    for side in (False, True):
+        monkeypatch.setattr(sa_fused, "SA_WGRAD_SIDE", side)
+        mods, outs = [], []
+        xyz = synth.make_clouds(51, 2, 4096, kind="room").to(dev())
+        feats = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            for i, (spec, n, cin) in enumerate(SA_SPECS[:2]):
+                mod = load_procedural(pointnet2_modules.PointnetSAModuleVotes(
+                    mlp=list(spec["mlp"]), **{k: v for k, v in spec.items() if k != "mlp"}), 21 + i).to(dev()).train()
+                xyz, out, _ = mod(xyz, feats)          # (stage 2 takes the first stage's 512 centres and 128 channels)
+                feats = out
+                mods.append(mod)
+                outs.append(out)
+        loss = sum((o.float() * procedural_tensor(f"side.g{i}", tuple(o.shape), torch.float32).to(dev())).sum()
+                   for i, o in enumerate(outs))
+        with sa_fused.deferred_wgrads() as dfr:
+            loss.backward()
+            if side:
+                assert not dfr.sa_items and not dfr.dz_items, "a stage's gradients were left for the end of the block"
+                assert sa_fused._sa_wgrad_stream(dev()) in dfr._side_streams
+        grads[side] = {f"{i}.{k}": p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) >= 18
+    for k, g in grads[False].items():
+        assert rel_l2(grads[True][k], g) < 2e-5, (k, rel_l2(grads[True][k], g))
+
+
 def test_fused_sa_eval_mode_uses_running_statistics(monkeypatch):
     spec, n, cin = SA_SPECS[1]
     xyz = synth.make_clouds(43, 2, n, kind="room").to(dev())
