@@ -839,49 +839,65 @@ __device__ __forceinline__ void gemm_nt_body(const GemmArgs &g, const e16_t *__r
         const int gc = n0 + wn * (T / 2) + j * 32 + ccol;
         flip[j] = (pool.gamma && gc < g.N && pool.gamma[gc] < 0.f) ? 0xFFFFFFFFu : 0u;
       }
+      // two copies of the loop (wave-uniform choice, made once): with one-sided extrema the minimum's keys are never formed --
+      // they were a third of this block's instructions, and the block is two thirds of what a wave of the kernel issues
+      auto fold8 = [&](auto one_sided) {
+        constexpr bool ONE = decltype(one_sided)::value;
+        // (the two-sided copy's keys hang on a value the compiler cannot see through: it would otherwise compute them ABOVE
+        // the branch, for both copies -- it did)
+        unsigned opaque0 = 0u;
+        if (!ONE) asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int q8 = 0; q8 < 4; ++q8) {
-            unsigned mx = 0u, mn = 0xffffffffu;
+            for (int q8 = 0; q8 < 4; ++q8) {
+              unsigned mx = 0u, mn = 0xffffffffu;
 #pragma unroll
-            for (int r = 4 * q8; r < 4 * q8 + 4; r += 2) {
-              const unsigned pw = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
-              const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, pw) >> 15);
-              const unsigned o = (pw ^ (sg | 0x80008000u)) ^ flip[j];
-              const unsigned row = (unsigned)(r & 3);
-              const unsigned olo = o << 16, ohi = o & 0xffff0000u;
-              mx = max(max(mx, olo | (7u - row)), ohi | (6u - row));
-              mn = min(min(mn, olo | row), ohi | (row + 1u));
-            }
-            unsigned a = mx ^ hbit, b = mn | hbit;                 // 7 - (row + 4 h) | row + 4 h
-            a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
-            const int r0 = wm * (T / 2) + i * 32 + q8 * 8, gc = n0 + wn * (T / 2) + j * 32 + ccol;
-            const bool inside = m0 + r0 < g.M && gc < g.N;
-            const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
-            if (pool.gamma) {
-              // the selectable extremum only: the lower lane half stores its value, the upper half its row
-              const unsigned o = ((a >> 16) ^ flip[j]) & 0xFFFFu;
-              const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
-              if (inside) {
-                if (!upper) pool.ymax[oidx] = __builtin_bit_cast(e16_t, bits);
-                else pool.amax[oidx] = (unsigned char)(7u - (a & 7u));
+              for (int r = 4 * q8; r < 4 * q8 + 4; r += 2) {
+                const unsigned pw = pack_e16x2(acc[i][j][r], acc[i][j][r + 1]);
+                const unsigned sg = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, pw) >> 15);
+                const unsigned o = (pw ^ (sg | 0x80008000u)) ^ flip[j];
+                const unsigned row = (unsigned)(r & 3);
+                mx = max(max(mx, (o << 16) | (7u - row)), (o & 0xffff0000u) | (6u - row));
+                if (!ONE) {
+                  const unsigned o2 = o ^ opaque0;
+                  mn = min(min(mn, (o2 << 16) | row), (o2 & 0xffff0000u) | (row + 1u));
+                }
               }
-              continue;
+              unsigned a = mx ^ hbit;                                // 7 - (row + 4 h)
+              a = max(a, (unsigned)__shfl_xor((int)a, 32, 64));
+              const int r0 = wm * (T / 2) + i * 32 + q8 * 8, gc = n0 + wn * (T / 2) + j * 32 + ccol;
+              const bool inside = m0 + r0 < g.M && gc < g.N;
+              const size_t oidx = (size_t)((m0 + r0) >> 3) * g.N + gc;
+              if (ONE) {
+                // the selectable extremum only: the lower lane half stores its value, the upper half its row
+                const unsigned o = ((a >> 16) ^ flip[j]) & 0xFFFFu;
+                const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
+                if (inside) {
+                  if (!upper) pool.ymax[oidx] = __builtin_bit_cast(e16_t, bits);
+                  else pool.amax[oidx] = (unsigned char)(7u - (a & 7u));
+                }
+              } else {
+                unsigned b = mn | hbit;                              // row + 4 h
+                b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
+                const unsigned key = upper ? b : a;
+                const unsigned o = key >> 16;
+                const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
+                const unsigned low = key & 7u;
+                const unsigned char row = (unsigned char)(upper ? low : 7u - low);
+                if (inside) {
+                  (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
+                  (upper ? pool.amin : pool.amax)[oidx] = row;
+                }
+              }
             }
-            b = min(b, (unsigned)__shfl_xor((int)b, 32, 64));
-            const unsigned key = upper ? b : a;
-            const unsigned o = key >> 16;
-            const unsigned short bits = (unsigned short)((o & 0x8000u) ? (o ^ 0x8000u) : ~o);
-            const unsigned low = key & 7u;
-            const unsigned char row = (unsigned char)(upper ? low : 7u - low);
-            if (inside) {
-              (upper ? pool.ymin : pool.ymax)[oidx] = __builtin_bit_cast(e16_t, bits);
-              (upper ? pool.amin : pool.amax)[oidx] = row;
-            }
-          }
+      };
+      if (pool.gamma)
+        fold8(std::true_type{});
+      else
+        fold8(std::false_type{});
     } else if ((STATS == 1 || STATS == 2) && T == 128 && !bias && (pool.s == 16 || pool.s == 32 || pool.s == 64)) {
       // Ball extrema from the accumulators (no LDS read, no serial walk over the ball).  A lane holds 32 rows of each of
       // its two columns.  Two rows of one column are rounded together (the pair word equals what the C tile holds), the
