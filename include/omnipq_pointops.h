@@ -39,7 +39,8 @@ extern "C" {
  *    omnipq_sa_row_plan, omnipq_sa_plan_pool_gamma, omnipq_gemm_strip_* removed) + omnipq_plan_aware_entry_points().
  * 3: round 6 -- omnipq_row_plan grew { tickets, ticket_words }; omnipq_gemm_nt_e16_bnaffine_pool accepts C == NULL (no store);
  *    new: omnipq_sa_last_bwd_prep, omnipq_gemm_nt_e16_dz_bnbwd, omnipq_gemm_tn_dz, omnipq_sa_last_wgrad_combine,
- *    omnipq_sa_pool_bwd_stats_sel_hot.
+ *    omnipq_sa_pool_bwd_stats_sel_hot, omnipq_ipc_* (omnipq_sa.h), omnipq_ffn_fused_* (omnipq_decoder.h); timing aids
+ *    omnipq_gemm_nt_small_tile_limit, omnipq_attn_block_map (results do not depend on them).
  * A binding must refuse a library whose version it was not written against: the argument lists differ. */
 #define OMNIPQ_ABI_VERSION 3
 
